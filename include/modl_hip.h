@@ -1,0 +1,271 @@
+/*
+ * modl_hip.h — C-ABI of libmodl_hip.so, the MI355X (gfx950) implementation of
+ * MODL's per-minibatch SOMF hot path.
+ *
+ * This library takes the place of the reference's Cython extensions
+ *   modl/decomposition/dict_fact_fast.pyx, modl/utils/math/enet.pyx,
+ *   modl/utils/randomkit/{random_fast,sampler}.pyx (+ randomkit.c, distributions.c),
+ *   modl/decomposition/recsys_fast.pyx
+ * and of the numpy/BLAS calls of modl/decomposition/dict_fact.py:495-715.
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * the reference repository).
+ *
+ * Conventions
+ *  - every function returns int: 0 = ok, < 0 = MODL_E* (bad argument / state),
+ *    > 0 = hipError_t of a failed HIP call.  No exceptions cross the ABI.
+ *  - `_f32` / `_f64` suffixes mirror Cython's fused `floating` type.
+ *  - pointers named d_* are DEVICE pointers (hipMalloc'd or torch CUDA tensors),
+ *    h_* are HOST pointers.  `stream` is a hipStream_t passed as void*
+ *    (NULL = default stream).  Calls are asynchronous w.r.t. the host unless
+ *    stated otherwise; the caller owns all buffers.
+ *  - matrices are row-major (C order), leading dimension = number of columns
+ *    unless an explicit ld is given.
+ *  - the dictionary and the surrogate statistic B are held FEATURE-MAJOR on the
+ *    device: d_Dt[p][k] = components_.T, d_Bt[p][k] = B_.T, so that a sampled
+ *    feature is one contiguous k-vector (coalesced gather of subsampled columns).
+ */
+#ifndef MODL_HIP_H
+#define MODL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MODL_ABI_VERSION 1
+
+#define MODL_OK 0
+#define MODL_EINVAL (-1)   /* bad argument */
+#define MODL_ENOMEM (-2)   /* workspace too small / allocation failed */
+#define MODL_ESTATE (-3)   /* object used in the wrong state */
+#define MODL_ENOGPU (-4)   /* no HIP device available */
+
+#define MODL_F32 0
+#define MODL_F64 1
+
+#define MODL_AGG_MASKED 0
+#define MODL_AGG_FULL 1
+#define MODL_AGG_AVERAGE 2
+
+#define MODL_OPT_VARIATIONAL 0
+#define MODL_OPT_SGD 1
+
+int modl_abi_version(void);
+/* number of visible HIP devices (0 without a GPU); never fails */
+int modl_device_count(void);
+const char *modl_error_string(int code);
+
+/* ------------------------------------------------------------------------- *
+ * Host-side RNG — replaces modl/utils/randomkit/random_fast.pyx (RandomState,
+ * :49-150) over randomkit.c / distributions.c.  Streams are bit-identical to
+ * the reference for the same seed.  Pure host code: usable without a GPU.
+ * ------------------------------------------------------------------------- */
+typedef struct modl_rk modl_rk;
+int modl_rk_create(uint64_t seed, modl_rk **out);            /* RandomState(seed), rk_seed randomkit.c:138 */
+void modl_rk_destroy(modl_rk *rk);
+int modl_rk_seed(modl_rk *rk, uint64_t seed);                 /* random_fast.pyx:64 */
+int modl_rk_random(modl_rk *rk, uint32_t *out);               /* rk_random, randomkit.c:212 */
+int modl_rk_randint(modl_rk *rk, uint64_t high, int64_t *out);/* random_fast.pyx:76 -> rk_interval :260 */
+int modl_rk_double(modl_rk *rk, double *out);                 /* rk_double, randomkit.c:292 */
+int modl_rk_binomial(modl_rk *rk, int64_t n, double p, int64_t *out); /* random_fast.pyx:146 -> distributions.c:442 */
+int modl_rk_permutation(modl_rk *rk, int64_t n, int64_t *h_out);      /* random_fast.pyx:79 */
+int modl_rk_shuffle_i64(modl_rk *rk, int64_t *h_x, int64_t n);        /* random_fast.pyx:87 (1-D) */
+/* random_fast.pyx:127: draws one swap sequence; h_trace[n] receives the
+ * permutation, h_swaps[n] the swap targets to replay on other arrays. */
+int modl_rk_shuffle_trace(modl_rk *rk, int64_t n, int64_t *h_trace, int64_t *h_swaps);
+/* replays a swap sequence on the rows of a host array (random_fast.pyx:105-119) */
+int modl_apply_swaps_rows(void *h_base, int64_t n, size_t row_bytes, const int64_t *h_swaps);
+/* same on a DEVICE array (epoch shuffle of code_ / averages, dict_fact.py:359-379) */
+int modl_apply_swaps_rows_device(void *d_base, int64_t n, size_t row_bytes, const int64_t *h_swaps,
+                                 void *stream);
+
+/* Feature sampler — replaces modl/utils/randomkit/sampler.pyx:9-70 */
+typedef struct modl_sampler modl_sampler;
+int modl_sampler_create(int64_t range, int rand_size, int replacement, uint64_t seed, modl_sampler **out);
+void modl_sampler_destroy(modl_sampler *s);
+/* yield_subset(reduction), sampler.pyx:41.  h_out must hold `range` entries;
+ * *n_out receives the subset length.  Indices are unsorted, as in the reference. */
+int modl_sampler_yield_subset(modl_sampler *s, double reduction, int64_t *h_out, int64_t *n_out);
+/* public attributes of the reference class (sampler.pxd:4-14) */
+int modl_sampler_get(modl_sampler *s, int64_t *range, int64_t *lim_inf, int64_t *lim_sup, int64_t *h_box);
+/* full state save / restore (box, limits, MT key + position, binomial cache) */
+size_t modl_sampler_state_bytes(const modl_sampler *s);
+int modl_sampler_get_state(const modl_sampler *s, void *h_buf, size_t bytes);
+int modl_sampler_set_state(modl_sampler *s, const void *h_buf, size_t bytes);
+
+/* _batch_weight, dict_fact_fast.pyx:115-122 */
+int modl_batch_weight(int64_t count, int64_t batch_size, double learning_rate, double offset, double *out);
+
+/* ------------------------------------------------------------------------- *
+ * Fine-grained device entry points, 1:1 with the Cython functions
+ * (used by the parity tests and by transform()).
+ * ------------------------------------------------------------------------- */
+
+/* _enet_regression_single_gram, dict_fact_fast.pyx:125-215.
+ * d_G[k][k], d_Dx[b][k] (overwritten by the solution when l1_ratio == 0, as in
+ * the reference), d_X[b][ldx] (only the squared row norms are used, :334),
+ * d_code[n][k] (rows d_indices[ii] are warm starts and results), d_indices[b]
+ * int64 (NULL = 0..b-1).  d_sweeps (optional, int32[b]) receives the number of
+ * coordinate-descent sweeps per sample.  d_ws / ws_bytes: scratch, see
+ * modl_enet_regression_workspace(). */
+size_t modl_enet_regression_workspace(int dtype, int64_t b, int64_t k, int multi_gram);
+int modl_enet_regression_single_gram_f32(const float *d_G, float *d_Dx, const float *d_X, int64_t ldx,
+                                         int64_t p, float *d_code, const int64_t *d_indices, int64_t b,
+                                         int64_t k, float l1_ratio, float alpha, int positive, float tol,
+                                         int max_iter, int32_t *d_sweeps, void *d_ws, size_t ws_bytes,
+                                         void *stream);
+int modl_enet_regression_single_gram_f64(const double *d_G, double *d_Dx, const double *d_X, int64_t ldx,
+                                         int64_t p, double *d_code, const int64_t *d_indices, int64_t b,
+                                         int64_t k, double l1_ratio, double alpha, int positive, double tol,
+                                         int max_iter, int32_t *d_sweeps, void *d_ws, size_t ws_bytes,
+                                         void *stream);
+/* _enet_regression_multi_gram, dict_fact_fast.pyx:33-113: d_G[b][k][k] */
+int modl_enet_regression_multi_gram_f32(const float *d_G, float *d_Dx, const float *d_X, int64_t ldx,
+                                        int64_t p, float *d_code, const int64_t *d_indices, int64_t b,
+                                        int64_t k, float l1_ratio, float alpha, int positive, float tol,
+                                        int max_iter, int32_t *d_sweeps, void *d_ws, size_t ws_bytes,
+                                        void *stream);
+int modl_enet_regression_multi_gram_f64(const double *d_G, double *d_Dx, const double *d_X, int64_t ldx,
+                                        int64_t p, double *d_code, const int64_t *d_indices, int64_t b,
+                                        int64_t k, double l1_ratio, double alpha, int positive, double tol,
+                                        int max_iter, int32_t *d_sweeps, void *d_ws, size_t ws_bytes,
+                                        void *stream);
+/* _update_G_average, dict_fact_fast.pyx:217-228: d_G_average[b][k][k] in place */
+int modl_update_G_average_f32(float *d_G_average, const float *d_G, const float *d_w_sample, int64_t b,
+                              int64_t k, void *stream);
+int modl_update_G_average_f64(double *d_G_average, const double *d_G, const double *d_w_sample, int64_t b,
+                              int64_t k, void *stream);
+
+/* enet_norm / enet_projection / enet_scale, modl/utils/math/enet.pyx:125,38,150,
+ * batched over `rows` vectors of length n laid out with element stride `inc`
+ * and vector stride `ld` (so atoms can be rows of D or columns of Dt).
+ * d_radius[rows] (projection, scale), d_out_norm[rows] (norm). */
+int modl_enet_norm_f32(const float *d_v, int64_t rows, int64_t n, int64_t ld, int64_t inc, float l1_ratio,
+                       float *d_out_norm, void *stream);
+int modl_enet_norm_f64(const double *d_v, int64_t rows, int64_t n, int64_t ld, int64_t inc, double l1_ratio,
+                       double *d_out_norm, void *stream);
+int modl_enet_projection_f32(const float *d_v, float *d_out, int64_t rows, int64_t n, int64_t ld, int64_t inc,
+                             const float *d_radius, float l1_ratio, void *stream);
+int modl_enet_projection_f64(const double *d_v, double *d_out, int64_t rows, int64_t n, int64_t ld,
+                             int64_t inc, const double *d_radius, double l1_ratio, void *stream);
+int modl_enet_scale_f32(float *d_v, int64_t rows, int64_t n, int64_t ld, int64_t inc, float l1_ratio,
+                        float radius, void *stream);
+int modl_enet_scale_f64(double *d_v, int64_t rows, int64_t n, int64_t ld, int64_t inc, double l1_ratio,
+                        double radius, void *stream);
+
+/* _predict, recsys_fast.pyx:10-38: d_data[nnz] = (P Q) at the CSR pattern;
+ * P[n_rows][k], Q[k][n_cols] (f64, int32 CSR as in the reference). */
+int modl_predict_csr(double *d_data, const int32_t *d_indices, const int32_t *d_indptr, const double *d_P,
+                     int64_t n_rows, int64_t k, const double *d_Q, int64_t n_cols, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Fused, device-resident minibatch step = DictFact._single_batch_fit,
+ * dict_fact.py:495-533 (+ _compute_code :577-648, _update_C/_update_B :559-575,
+ * _update_dict :650-715).  The host keeps drawing `subset` (modl_sampler),
+ * `order` (numpy legacy RandomState.permutation, dict_fact.py:672) and `w`
+ * (modl_batch_weight) exactly as the reference does and passes them in.
+ * ------------------------------------------------------------------------- */
+typedef struct modl_somf_desc {
+    int32_t dtype;          /* MODL_F32 / MODL_F64 */
+    int32_t k;              /* n_components */
+    int64_t p;              /* n_features */
+    int64_t n_samples;      /* rows of code_ (and of the averages) */
+    int32_t G_agg;          /* MODL_AGG_* (dict_fact.py:132-133) */
+    int32_t Dx_agg;
+    int32_t optimizer;      /* MODL_OPT_* */
+    int32_t code_pos;
+    int32_t comp_pos;
+    int32_t max_iter;
+    double code_alpha;
+    double code_l1_ratio;
+    double comp_l1_ratio;
+    double tol;
+    double step_size;
+    int32_t max_batch;      /* largest minibatch this plan will see */
+    int32_t reserved;
+} modl_somf_desc;
+
+/* device state of one estimator (allocated by the caller; all T = dtype) */
+typedef struct modl_somf_state {
+    void *d_Dt;          /* [p][k]  components_.T */
+    void *d_Bt;          /* [p][k]  B_.T */
+    void *d_C;           /* [k][k]  C_ */
+    void *d_code;        /* [n_samples][k] code_ */
+    void *d_comp_norm;   /* [k] comp_norm_ */
+    void *d_G;           /* [k][k] G_ (G_agg == full), else NULL */
+    void *d_Dx_average;  /* [n_samples][k] (Dx_agg == average), else NULL */
+    void *d_G_average;   /* [n_samples][k][k] (G_agg == average), else NULL */
+} modl_somf_state;
+
+/* one minibatch; h_* arrays are copied to the device by the call */
+typedef struct modl_somf_batch {
+    const void *d_X;            /* [b][ldx] minibatch rows, device */
+    int64_t ldx;
+    int32_t b;                  /* rows in this rank's minibatch */
+    int32_t s;                  /* subset length; s == p with h_subset == NULL means all features */
+    const int64_t *h_sample_idx;/* [b] rows of code_ (NULL = 0..b-1) */
+    const int64_t *h_subset;    /* [s] feature subset (unsorted ok) */
+    const int64_t *h_order;     /* [k] atom order of the dictionary update */
+    const void *h_w_sample;     /* [b] T, w_sample (only for *_agg == average; may be NULL otherwise) */
+    double w;                   /* minibatch weight (_batch_weight) */
+    double reduction;           /* self.reduction (scales Dx and G, dict_fact.py:595,604) */
+    int64_t b_global;           /* sum of b over all ranks (== b on one GPU) */
+} modl_somf_batch;
+
+typedef struct modl_somf_plan modl_somf_plan;
+/* allocates the per-estimator scratch (device workspace, pinned staging) on the
+ * current device. */
+int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out);
+void modl_somf_plan_destroy(modl_somf_plan *plan);
+/* update solver / aggregation parameters between minibatches (set_params,
+ * dict_fact.py:339-357).  k, p, dtype, n_samples, max_batch must not change. */
+int modl_somf_plan_update(modl_somf_plan *plan, const modl_somf_desc *desc);
+
+/* number of T elements of the statistics increment buffer: k*k + p*k */
+int64_t modl_somf_delta_elems(const modl_somf_desc *desc);
+
+/* Phase 1 (per rank): code solve for the minibatch rows (writes d_code rows),
+ * then d_delta = [ code^T code (k*k) | X^T code (p*k, feature-major) ], NOT yet
+ * divided by the batch size.  With several GPUs the caller all-reduces d_delta
+ * (sum) between phase 1 and phase 2. */
+int modl_somf_code_and_partials(modl_somf_plan *plan, const modl_somf_state *st, const modl_somf_batch *bt,
+                                void *d_delta, void *stream);
+/* Phase 2 (identical on every rank): C_/B_ update from d_delta with weight w /
+ * b_global, then the block-coordinate dictionary update on the subset. */
+int modl_somf_apply_and_update_dict(modl_somf_plan *plan, const modl_somf_state *st,
+                                    const modl_somf_batch *bt, const void *d_delta, void *stream);
+/* both phases back to back (one GPU) */
+int modl_somf_step(modl_somf_plan *plan, const modl_somf_state *st, const modl_somf_batch *bt, void *d_delta,
+                   void *stream);
+
+/* G_ = D D^T (prepare / set_params(G_agg='full'), dict_fact.py:355,477) */
+int modl_somf_full_gram(modl_somf_plan *plan, const void *d_Dt, void *d_G, void *stream);
+
+/* CodingMixin.transform, dict_fact.py:47-92: d_code_out[n][k] from ones.
+ * d_G may be NULL (computed from d_Dt). */
+int modl_somf_transform(modl_somf_plan *plan, const void *d_Dt, const void *d_G, const void *d_X, int64_t ldx,
+                        int64_t n, void *d_code_out, void *stream);
+
+/* layout helpers: out[c][r] = in[r][c]  (components_ <-> Dt) */
+int modl_transpose_f32(const float *d_in, float *d_out, int64_t rows, int64_t cols, void *stream);
+int modl_transpose_f64(const double *d_in, double *d_out, int64_t rows, int64_t cols, void *stream);
+
+/* per-kernel-class timing of the fused step (HIP events on `stream`).
+ * enable: 0/1.  get: copies up to `cap` entries; names are static strings. */
+#define MODL_PROF_MAX 16
+typedef struct modl_prof_entry {
+    const char *name;
+    double ms_total;     /* accumulated device time */
+    int64_t launches;    /* kernel launches accumulated */
+    int64_t calls;       /* timed regions accumulated */
+} modl_prof_entry;
+int modl_somf_prof_enable(modl_somf_plan *plan, int enable);
+int modl_somf_prof_get(modl_somf_plan *plan, modl_prof_entry *out, int cap, int *n_out);
+int modl_somf_prof_reset(modl_somf_plan *plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MODL_HIP_H */

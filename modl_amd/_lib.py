@@ -1,0 +1,131 @@
+"""ctypes binding of libmodl_hip.so (the C-ABI of include/modl_hip.h).
+
+This module takes the place of the reference's compiled extension imports
+(`from .dict_fact_fast import ...`, modl/decomposition/dict_fact.py:14-18).
+There is no CPU fallback: if the shared library is missing the import fails
+loudly with the build command.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmodl_hip.so')
+
+MODL_F32, MODL_F64 = 0, 1
+AGG = {'masked': 0, 'full': 1, 'average': 2}
+OPT = {'variational': 0, 'sgd': 1}
+
+
+class ModlError(RuntimeError):
+    pass
+
+
+class SomfDesc(C.Structure):
+    _fields_ = [('dtype', C.c_int32), ('k', C.c_int32), ('p', C.c_int64), ('n_samples', C.c_int64),
+                ('G_agg', C.c_int32), ('Dx_agg', C.c_int32), ('optimizer', C.c_int32), ('code_pos', C.c_int32),
+                ('comp_pos', C.c_int32), ('max_iter', C.c_int32), ('code_alpha', C.c_double),
+                ('code_l1_ratio', C.c_double), ('comp_l1_ratio', C.c_double), ('tol', C.c_double),
+                ('step_size', C.c_double), ('max_batch', C.c_int32), ('reserved', C.c_int32)]
+
+
+class SomfState(C.Structure):
+    _fields_ = [('d_Dt', C.c_void_p), ('d_Bt', C.c_void_p), ('d_C', C.c_void_p), ('d_code', C.c_void_p),
+                ('d_comp_norm', C.c_void_p), ('d_G', C.c_void_p), ('d_Dx_average', C.c_void_p),
+                ('d_G_average', C.c_void_p)]
+
+
+class SomfBatch(C.Structure):
+    _fields_ = [('d_X', C.c_void_p), ('ldx', C.c_int64), ('b', C.c_int32), ('s', C.c_int32),
+                ('h_sample_idx', C.c_void_p), ('h_subset', C.c_void_p), ('h_order', C.c_void_p),
+                ('h_w_sample', C.c_void_p), ('w', C.c_double), ('reduction', C.c_double),
+                ('b_global', C.c_int64)]
+
+
+class ProfEntry(C.Structure):
+    _fields_ = [('name', C.c_char_p), ('ms_total', C.c_double), ('launches', C.c_int64), ('calls', C.c_int64)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'modl_amd: %s is missing. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            'or `make -C modl_amd/csrc` (needs hipcc, --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+    try:
+        return C.CDLL(LIB_PATH)
+    except OSError as e:                                   # pragma: no cover
+        raise ImportError('modl_amd: cannot load %s: %s' % (LIB_PATH, e))
+
+
+lib = _load()
+
+_vp, _i32, _i64, _u64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double, C.c_size_t
+_P = C.POINTER
+
+
+def _sig(name, restype, *argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+
+_sig('modl_abi_version', C.c_int)
+_sig('modl_device_count', C.c_int)
+_sig('modl_error_string', C.c_char_p, C.c_int)
+_sig('modl_rk_create', C.c_int, _u64, _P(_vp))
+_sig('modl_rk_destroy', None, _vp)
+_sig('modl_rk_seed', C.c_int, _vp, _u64)
+_sig('modl_rk_random', C.c_int, _vp, _P(C.c_uint32))
+_sig('modl_rk_randint', C.c_int, _vp, _u64, _P(_i64))
+_sig('modl_rk_double', C.c_int, _vp, _P(_f64))
+_sig('modl_rk_binomial', C.c_int, _vp, _i64, _f64, _P(_i64))
+_sig('modl_rk_permutation', C.c_int, _vp, _i64, _vp)
+_sig('modl_rk_shuffle_i64', C.c_int, _vp, _vp, _i64)
+_sig('modl_rk_shuffle_trace', C.c_int, _vp, _i64, _vp, _vp)
+_sig('modl_apply_swaps_rows', C.c_int, _vp, _i64, _sz, _vp)
+_sig('modl_apply_swaps_rows_device', C.c_int, _vp, _i64, _sz, _vp, _vp)
+_sig('modl_sampler_create', C.c_int, _i64, C.c_int, C.c_int, _u64, _P(_vp))
+_sig('modl_sampler_destroy', None, _vp)
+_sig('modl_sampler_yield_subset', C.c_int, _vp, _f64, _vp, _P(_i64))
+_sig('modl_sampler_get', C.c_int, _vp, _P(_i64), _P(_i64), _P(_i64), _vp)
+_sig('modl_sampler_state_bytes', _sz, _vp)
+_sig('modl_sampler_get_state', C.c_int, _vp, _vp, _sz)
+_sig('modl_sampler_set_state', C.c_int, _vp, _vp, _sz)
+_sig('modl_batch_weight', C.c_int, _i64, _i64, _f64, _f64, _P(_f64))
+_sig('modl_enet_regression_workspace', _sz, C.c_int, _i64, _i64, C.c_int)
+for _sfx, _ct in (('f32', C.c_float), ('f64', C.c_double)):
+    for _kind in ('single', 'multi'):
+        _sig('modl_enet_regression_%s_gram_%s' % (_kind, _sfx), C.c_int, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64,
+             _i64, _ct, _ct, C.c_int, _ct, C.c_int, _vp, _vp, _sz, _vp)
+    _sig('modl_update_G_average_' + _sfx, C.c_int, _vp, _vp, _vp, _i64, _i64, _vp)
+    _sig('modl_enet_norm_' + _sfx, C.c_int, _vp, _i64, _i64, _i64, _i64, _ct, _vp, _vp)
+    _sig('modl_enet_projection_' + _sfx, C.c_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _ct, _vp)
+    _sig('modl_enet_scale_' + _sfx, C.c_int, _vp, _i64, _i64, _i64, _i64, _ct, _ct, _vp)
+    _sig('modl_transpose_' + _sfx, C.c_int, _vp, _vp, _i64, _i64, _vp)
+_sig('modl_predict_csr', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp)
+_sig('modl_somf_plan_create', C.c_int, _P(SomfDesc), _P(_vp))
+_sig('modl_somf_plan_destroy', None, _vp)
+_sig('modl_somf_plan_update', C.c_int, _vp, _P(SomfDesc))
+_sig('modl_somf_delta_elems', _i64, _P(SomfDesc))
+_sig('modl_somf_code_and_partials', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
+_sig('modl_somf_apply_and_update_dict', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
+_sig('modl_somf_step', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
+_sig('modl_somf_full_gram', C.c_int, _vp, _vp, _vp, _vp)
+_sig('modl_somf_transform', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp)
+_sig('modl_somf_prof_enable', C.c_int, _vp, C.c_int)
+_sig('modl_somf_prof_get', C.c_int, _vp, _P(ProfEntry), C.c_int, _P(C.c_int))
+_sig('modl_somf_prof_reset', C.c_int, _vp)
+
+# every symbol declared in include/modl_hip.h (checked by tests/test_abi.py)
+DECLARED = [n for n in dir(lib) if n.startswith('modl_')]
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib.modl_error_string(rc).decode()
+        raise ModlError('%s failed: %s (code %d)' % (what or 'libmodl_hip call', msg, rc))
+
+
+def require_gpu():
+    if lib.modl_device_count() <= 0:
+        raise ModlError('modl_amd needs an AMD GPU (gfx950); no HIP device is visible and there is no CPU fallback')

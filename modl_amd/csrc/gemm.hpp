@@ -1,0 +1,220 @@
+// Tiled matrix-core contraction used by every dense product of the SOMF step
+// (Dx, Gram, C_/B_ increments, the blocked dictionary update).
+//
+//   out(m, n) = epilogue( sum_kk  A(m, kk) * B(n, kk) )
+//
+// Both operands are described the same way: element (i, kk) lives at
+// ptr[gi(i) * si + gk(kk) * sk] where gi / gk are optional gather indices
+// (feature subset, sample indices, atom order).  That covers X[:, subset],
+// D[:, subset] held feature-major, code_[idx] ... without materialising any
+// gathered copy: the subsampled feature rows are read straight from Dt / Bt.
+//
+// gfx950 mapping: 256-thread workgroups = 4 wavefronts in a 2x2 grid, each wave
+// owning RM x RN matrix-core tiles (f32: v_mfma_f32_32x32x2_f32, exact fp32 FMA
+// chains; f64: v_mfma_f64_16x16x4_f64).  Operand tiles are staged k-major in LDS
+// (+1 padding) so fragment reads are conflict-free 32-lane rows.  K can be split
+// over gridDim.z; partial tiles are then summed in a fixed order by
+// gemm_reduce_kernel, so results are run-to-run deterministic.
+#pragma once
+#include "common.hpp"
+
+namespace modl {
+
+struct Operand {
+    const void *ptr = nullptr;
+    int64_t si = 0, sk = 0;   // element strides of the free index and of the contraction index
+    Gather gi, gk;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+    typedef float acc_t __attribute__((ext_vector_type(16)));
+    static constexpr int TM = 32, TN = 32, TK = 2, NACC = 16;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int frag_i(int lane) { return lane & 31; }
+    static __device__ __forceinline__ int frag_k(int lane) { return lane >> 5; }
+    static __device__ __forceinline__ int acc_row(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+    static __device__ __forceinline__ int acc_col(int lane, int) { return lane & 31; }
+};
+template <> struct Mma<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static constexpr int TM = 16, TN = 16, TK = 4, NACC = 4;
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int frag_i(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int frag_k(int lane) { return lane >> 4; }
+    static __device__ __forceinline__ int acc_row(int lane, int r) { return (lane >> 4) + 4 * r; }
+    static __device__ __forceinline__ int acc_col(int lane, int) { return lane & 15; }
+};
+
+template <typename T, int BI, int BK>
+__device__ __forceinline__ void stage_tile(T (*S)[BI + 1], const Operand &op, int64_t i0, int64_t I, int64_t k0,
+                                           int64_t k_end) {
+    const T *base = static_cast<const T *>(op.ptr);
+    constexpr int kElems = BI * BK;
+    if (op.si == 1) {   // free index contiguous: lanes walk i
+#pragma unroll 4
+        for (int e = threadIdx.x; e < kElems; e += 256) {
+            const int il = e % BI, kl = e / BI;
+            const int64_t i = i0 + il, kk = k0 + kl;
+            T v = 0;
+            if (i < I && kk < k_end) v = base[op.gi(i) * op.si + op.gk(kk) * op.sk];
+            S[kl][il] = v;
+        }
+    } else {            // contraction index contiguous (or neither): lanes walk kk
+#pragma unroll 4
+        for (int e = threadIdx.x; e < kElems; e += 256) {
+            const int kl = e % BK, il = e / BK;
+            const int64_t i = i0 + il, kk = k0 + kl;
+            T v = 0;
+            if (i < I && kk < k_end) v = base[op.gi(i) * op.si + op.gk(kk) * op.sk];
+            S[kl][il] = v;
+        }
+    }
+}
+
+template <typename T, int RM, int RN, int WGM, int WGN, int BK, class Epi>
+__global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, int64_t M, int64_t N, int64_t K,
+                                                   int64_t k_per_split, T *partial, Epi epi) {
+    using MT = Mma<T>;
+    static_assert(WGM * WGN == 4, "4 wavefronts per workgroup");
+    constexpr int WTM = MT::TM * RM, WTN = MT::TN * RN, BM = WGM * WTM, BN = WGN * WTN;
+    __shared__ T As[BK][BM + 1];
+    __shared__ T Bs[BK][BN + 1];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    const int64_t k_begin = (int64_t)blockIdx.z * k_per_split;
+    const int64_t k_end = (k_begin + k_per_split < K) ? k_begin + k_per_split : K;
+
+    typename MT::acc_t acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < MT::NACC; ++r) acc[i][j][r] = 0;
+
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+        stage_tile<T, BM, BK>(As, A, m0, M, k0, k_end);
+        stage_tile<T, BN, BK>(Bs, B, n0, N, k0, k_end);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += MT::TK) {
+            T af[RM], bf[RN];
+            const int kr = kk + MT::frag_k(lane);
+#pragma unroll
+            for (int i = 0; i < RM; ++i) af[i] = As[kr][wm * WTM + i * MT::TM + MT::frag_i(lane)];
+#pragma unroll
+            for (int j = 0; j < RN; ++j) bf[j] = Bs[kr][wn * WTN + j * MT::TN + MT::frag_i(lane)];
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) acc[i][j] = MT::mma(af[i], bf[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    const bool direct = (gridDim.z == 1);
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < MT::NACC; ++r) {
+                const int64_t m = m0 + wm * WTM + i * MT::TM + MT::acc_row(lane, r);
+                const int64_t n = n0 + wn * WTN + j * MT::TN + MT::acc_col(lane, r);
+                if (m < M && n < N) {
+                    if (direct) epi(m, n, acc[i][j][r]);
+                    else partial[((int64_t)blockIdx.z * M + m) * N + n] = acc[i][j][r];
+                }
+            }
+}
+
+template <typename T, class Epi>
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const T *partial, int splits, int64_t M, int64_t N,
+                                                          Epi epi) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * N) return;
+    T v = 0;
+    for (int z = 0; z < splits; ++z) v += partial[(int64_t)z * M * N + e];
+    epi(e / N, e % N, v);
+}
+
+// ---- epilogues --------------------------------------------------------------
+template <typename T> struct EpiStore {          // out[m][n] = alpha * v
+    T *out; int64_t ld; T alpha;
+    __device__ __forceinline__ void operator()(int64_t m, int64_t n, T v) const { out[m * ld + n] = alpha * v; }
+};
+template <typename T> struct EpiAxpby {          // out[m][n] = beta * out[m][n] + alpha * v
+    T *out; int64_t ld; T alpha, beta;
+    __device__ __forceinline__ void operator()(int64_t m, int64_t n, T v) const {
+        T *o = out + m * ld + n;
+        *o = beta * (*o) + alpha * v;
+    }
+};
+
+// ---- launcher ---------------------------------------------------------------
+struct SplitWs {      // scratch for split-K partial tiles
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+// Tile configurations (block tile BM x BN): "big" 128x128 (2x2 waves, most operand reuse), "small"
+// 64x64 (2x2 waves, more workgroups for mid-size outputs), "tall" 128x32 (4x1 waves, for the narrow
+// N = 32 products of the blocked dictionary update).
+template <typename T> struct TileCfg;
+template <> struct TileCfg<float> { static constexpr int BK = 16, RB = 2, RS = 1, RT = 1; };
+template <> struct TileCfg<double> { static constexpr int BK = 16, RB = 4, RS = 2, RT = 2; };
+
+// target_wgs: how many workgroups we would like in flight (256 CUs, a few per CU)
+template <typename T, class Epi>
+int launch_gemm(hipStream_t stream, const Operand &A, const Operand &B, int64_t M, int64_t N, int64_t K,
+                const Epi &epi, const SplitWs &ws, int *launches = nullptr, int target_wgs = 512,
+                int max_splits = 64) {
+    if (M <= 0 || N <= 0) return MODL_OK;
+    using C = TileCfg<T>;
+    int cfg, bm, bn;                              // 0 big, 1 small, 2 tall
+    if (N <= 32) { cfg = 2; bm = 128; bn = 32; }
+    else if (cdiv(M, 128) * cdiv(N, 128) >= 512) { cfg = 0; bm = 128; bn = 128; }
+    else { cfg = 1; bm = 64; bn = 64; }
+    const int64_t tm = cdiv(M, bm), tn = cdiv(N, bn);
+    int64_t splits = 1;
+    if (K > 0 && tm * tn < target_wgs && max_splits > 1 && ws.ptr) {
+        splits = target_wgs / (tm * tn);
+        const int64_t max_by_k = K / (8 * C::BK) > 0 ? K / (8 * C::BK) : 1;   // >= 8 k-tiles per split
+        if (splits > max_by_k) splits = max_by_k;
+        if (splits > max_splits) splits = max_splits;
+        const int64_t max_by_ws = (int64_t)(ws.bytes / sizeof(T)) / (M * N);
+        if (splits > max_by_ws) splits = max_by_ws;
+        if (splits < 1) splits = 1;
+    }
+    const int64_t Kp = K > 0 ? K : 1;
+    const int64_t kps = cdiv(cdiv(Kp, splits), C::BK) * C::BK;
+    splits = cdiv(Kp, kps);
+    dim3 grid((unsigned)tn, (unsigned)tm, (unsigned)splits);
+    T *partial = static_cast<T *>(ws.ptr);
+    if (cfg == 0)
+        hipLaunchKernelGGL((gemm_kernel<T, C::RB, C::RB, 2, 2, C::BK, Epi>), grid, dim3(256), 0, stream, A, B, M, N, K,
+                           kps, partial, epi);
+    else if (cfg == 1)
+        hipLaunchKernelGGL((gemm_kernel<T, C::RS, C::RS, 2, 2, C::BK, Epi>), grid, dim3(256), 0, stream, A, B, M, N, K,
+                           kps, partial, epi);
+    else
+        hipLaunchKernelGGL((gemm_kernel<T, C::RT, C::RT, 4, 1, C::BK, Epi>), grid, dim3(256), 0, stream, A, B, M, N, K,
+                           kps, partial, epi);
+    MODL_LAUNCH_CHECK();
+    if (launches) ++*launches;
+    if (splits > 1) {
+        hipLaunchKernelGGL((gemm_reduce_kernel<T, Epi>), dim3((unsigned)cdiv(M * N, 256)), dim3(256), 0, stream,
+                           partial, (int)splits, M, N, epi);
+        MODL_LAUNCH_CHECK();
+        if (launches) ++*launches;
+    }
+    return MODL_OK;
+}
+
+}  // namespace modl

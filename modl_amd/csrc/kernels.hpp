@@ -1,0 +1,74 @@
+// Declarations shared between the translation units of libmodl_hip.
+#pragma once
+#include "common.hpp"
+
+namespace modl {
+
+// ---- cd_solver.hip ----------------------------------------------------------
+template <typename T>
+struct CdArgs {
+    const T *G;            // [k][k] shared, or [b][k][k] when g_stride != 0
+    int64_t g_stride;
+    const int64_t *g_idx;  // per-sample Gram index (rows of G_average_), or null: sample ii uses G[ii]
+    const T *Dx;           // [b][k]
+    const T *xnorm2;       // [b] squared norm of the full sample row
+    const T *H0;           // [b][k] initial Q w (from a matrix-core product), or null: computed in-kernel
+    T *code;               // [n][k]
+    const int64_t *idx;    // [b] or null (identity)
+    int32_t *sweeps;       // [b] or null
+    int b, k;
+    T alpha, beta, tol;
+    int max_iter, positive;
+};
+template <typename T> int launch_cd(hipStream_t stream, const CdArgs<T> &a);
+template <typename T> int launch_row_norm2(hipStream_t stream, const T *X, int64_t ldx, int64_t p, int64_t b, T *out);
+
+// ---- chol.hip ---------------------------------------------------------------
+// factor nmat matrices (G[m] + alpha I) into F[m] (symmetric storage of the
+// Cholesky factor: F[i][j] = L[max(i,j)][min(i,j)])
+template <typename T>
+int launch_cholesky(hipStream_t stream, const T *G, int64_t g_stride, const int64_t *g_idx, T *F, int k, T alpha,
+                    int nmat);
+// solve F[m] F[m]^T x = rhs for b right-hand sides (rows of rhs, in place);
+// f_stride == 0: one shared factor.  Results also scattered to code rows.
+template <typename T>
+int launch_chol_solve(hipStream_t stream, const T *F, int64_t f_stride, T *rhs, int b, int k, T *code,
+                      const int64_t *idx);
+
+// ---- enet.hip ---------------------------------------------------------------
+template <typename T>
+int launch_enet_norm(hipStream_t stream, const T *v, int64_t rows, int64_t n, int64_t ld, int64_t inc, T l1_ratio,
+                     T *out);
+template <typename T>
+int launch_enet_projection(hipStream_t stream, const T *v, T *out, int64_t rows, int64_t n, int64_t ld,
+                           int64_t inc, const T *radius, T l1_ratio);
+template <typename T>
+int launch_enet_scale(hipStream_t stream, T *v, int64_t rows, int64_t n, int64_t ld, int64_t inc, T l1_ratio,
+                      T radius);
+template <typename T>
+int launch_update_G_average(hipStream_t stream, T *G_average, const int64_t *idx, const T *G, const T *w_sample,
+                            int64_t b, int64_t k);
+template <typename T>
+int launch_transpose(hipStream_t stream, const T *in, T *out, int64_t rows, int64_t cols);
+
+// ---- bcd.hip ----------------------------------------------------------------
+template <typename T>
+struct DictUpdateArgs {
+    T *Dt;                    // [p][k] dictionary, feature-major, updated in place on the subset rows
+    const T *Bt;              // [p][k]
+    const T *C;               // [k][k] (bitwise symmetric)
+    T *comp_norm;             // [k]
+    const int32_t *subset;    // [s] device, or null = rows 0..s-1
+    const int32_t *order;     // [k] device
+    const int64_t *h_order;   // [k] host copy (the generic path issues one launch pair per atom)
+    int64_t s;
+    int k;
+    int optimizer, comp_pos;
+    double comp_l1_ratio, w, step_size;
+    void *ws;                 // scratch, dict_update_workspace() bytes
+    size_t ws_bytes;
+};
+size_t dict_update_workspace(int dtype, int64_t s_max, int k);
+template <typename T> int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches);
+
+}  // namespace modl

@@ -1,0 +1,648 @@
+// The fused, device-resident SOMF minibatch step and the fine-grained solver
+// entry points of the C-ABI (include/modl_hip.h).
+//
+// Replaces DictFact._single_batch_fit and what it calls
+//   (reference: modl/decomposition/dict_fact.py:495-533 _single_batch_fit,
+//    :577-648 _compute_code, :559-575 _update_C/_update_B, :650-715 _update_dict,
+//    :47-92 transform).
+//
+// Data layout in HBM (T = f32 or f64):
+//   Dt [p][k]  dictionary, feature-major (components_.T): a sampled feature is one
+//              contiguous k-vector, so the subset is read by row index, never copied;
+//   Bt [p][k]  surrogate statistic B_.T, same layout;
+//   C  [k][k]  surrogate statistic C_ (bitwise symmetric by construction);
+//   code [n][k], G_ [k][k], Dx_average_ [n][k], G_average_ [n][k][k] as in the reference.
+// A step is two phases so that several GPUs can all-reduce the statistics
+// increment [code^T code | X^T code] between them (RCCL, done by the caller).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gemm.hpp"
+#include "kernels.hpp"
+
+namespace modl {
+
+enum Section { SEC_CODE_GEMM = 0, SEC_CODE_SOLVE, SEC_STATS_GEMM, SEC_STATS_APPLY, SEC_DICT, SEC_COUNT };
+static const char *kSectionNames[SEC_COUNT] = {"code_gemm", "code_solve", "stats_gemm", "stats_apply", "dict_update"};
+
+constexpr int kStageSlots = 8;
+constexpr int kProfPool = 2048;      // event pairs kept before a flush
+
+template <typename T> struct EpiDxAverage {   // dict_fact.py:596-601
+    T *Dx; T *avg; const int64_t *idx; const T *w_sample; int64_t k; T alpha;
+    __device__ __forceinline__ void operator()(int64_t i, int64_t j, T v) const {
+        T *a = avg + (idx ? idx[i] : i) * k + j;
+        const T ws = w_sample[i];
+        T cur = *a * ((T)1 - ws);
+        cur = cur + (alpha * v) * ws;
+        *a = cur;
+        Dx[i * k + j] = cur;
+    }
+};
+
+// C = beta C + (wt d) / b ;  the same for Bt (dict_fact.py:559-575)
+template <typename T>
+__global__ __launch_bounds__(256) void stats_apply_kernel(T *dst, const T *delta, int64_t n, T beta, T wt, T bdiv,
+                                                          int replace) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {
+        const T d = delta[e];
+        if (replace) dst[e] = d / bdiv;
+        else dst[e] = dst[e] * beta + (wt * d) / bdiv;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fill_kernel(T *dst, int64_t n, T v) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) dst[e] = v;
+}
+
+}  // namespace modl
+
+using namespace modl;
+
+struct modl_somf_plan {
+    modl_somf_desc d;
+    size_t tsz;
+    // device arena
+    char *dws = nullptr;
+    size_t dws_bytes = 0;
+    size_t off_params, off_xnorm, off_Dx, off_H0, off_G, off_F, off_split, off_du;
+    size_t split_bytes, du_bytes, params_bytes;
+    // per-batch parameter block (device copy of the host arrays), layout within params:
+    size_t po_idx, po_subset, po_order, po_wsample;
+    // pinned staging ring
+    char *hstage[kStageSlots] = {nullptr};
+    hipEvent_t hev[kStageSlots] = {nullptr};
+    bool hev_used[kStageSlots] = {false};
+    int slot = 0;
+    // currently staged batch
+    bool staged = false;
+    bool has_idx = false, has_subset = false;
+    std::vector<int64_t> h_order_copy;
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> pev;       // 2 * kProfPool events
+    std::vector<int> psec, plaunch;
+    int pcount = 0;
+    double ms[SEC_COUNT] = {0};
+    int64_t launches[SEC_COUNT] = {0}, calls[SEC_COUNT] = {0};
+};
+
+namespace {
+
+size_t params_layout(modl_somf_plan *pl) {
+    const modl_somf_desc &d = pl->d;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 64); return r; };
+    pl->po_idx = take(sizeof(int64_t) * (size_t)d.max_batch);
+    pl->po_subset = take(sizeof(int32_t) * (size_t)d.p);
+    pl->po_order = take(sizeof(int32_t) * (size_t)d.k);
+    pl->po_wsample = take(pl->tsz * (size_t)d.max_batch);
+    return o;
+}
+
+int validate_desc(const modl_somf_desc *d) {
+    if (!d) return MODL_EINVAL;
+    if (d->dtype != MODL_F32 && d->dtype != MODL_F64) return MODL_EINVAL;
+    if (d->k <= 0 || d->k > 1024 || d->p <= 0 || d->p > 0x7fffffff || d->n_samples < 0 || d->max_batch <= 0)
+        return MODL_EINVAL;
+    if (d->G_agg < 0 || d->G_agg > 2 || d->Dx_agg < 0 || d->Dx_agg > 2) return MODL_EINVAL;
+    if (d->optimizer != MODL_OPT_VARIATIONAL && d->optimizer != MODL_OPT_SGD) return MODL_EINVAL;
+    if (!(d->code_l1_ratio >= 0.0 && d->code_l1_ratio <= 1.0)) return MODL_EINVAL;
+    if (!(d->comp_l1_ratio >= 0.0 && d->comp_l1_ratio <= 1.0)) return MODL_EINVAL;
+    if (d->code_l1_ratio == 0.0 && d->k > 512) return MODL_EINVAL;
+    return MODL_OK;
+}
+
+struct ProfScope {
+    modl_somf_plan *pl;
+    hipStream_t st;
+    int sec, idx = -1;
+    int launches = 0;
+    ProfScope(modl_somf_plan *p, hipStream_t s, int section) : pl(p), st(s), sec(section) {
+        if (!pl->prof) return;
+        if (pl->pcount >= kProfPool) return;           // pool full until the next prof_get/reset
+        idx = pl->pcount++;
+        (void)hipEventRecord(pl->pev[2 * idx], st);
+    }
+    ~ProfScope() {
+        if (idx < 0) return;
+        (void)hipEventRecord(pl->pev[2 * idx + 1], st);
+        pl->psec[idx] = sec;
+        pl->plaunch[idx] = launches;
+    }
+};
+
+int prof_flush(modl_somf_plan *pl) {
+    for (int i = 0; i < pl->pcount; ++i) {
+        MODL_HIP(hipEventSynchronize(pl->pev[2 * i + 1]));
+        float ms = 0;
+        MODL_HIP(hipEventElapsedTime(&ms, pl->pev[2 * i], pl->pev[2 * i + 1]));
+        pl->ms[pl->psec[i]] += ms;
+        pl->launches[pl->psec[i]] += pl->plaunch[i];
+        pl->calls[pl->psec[i]] += 1;
+    }
+    pl->pcount = 0;
+    return MODL_OK;
+}
+
+// copy the per-batch host arrays into the device parameter block through a pinned slot
+template <typename T>
+int stage_batch(modl_somf_plan *pl, const modl_somf_batch *bt, hipStream_t st) {
+    const modl_somf_desc &d = pl->d;
+    if (bt->b <= 0 || bt->b > d.max_batch || !bt->d_X || bt->ldx < d.p) return MODL_EINVAL;
+    if (bt->s < 0 || bt->s > d.p || !bt->h_order) return MODL_EINVAL;
+    if (!bt->h_subset && bt->s != d.p) return MODL_EINVAL;
+    if ((d.G_agg == MODL_AGG_AVERAGE || d.Dx_agg == MODL_AGG_AVERAGE) && !bt->h_w_sample) return MODL_EINVAL;
+    const int slot = pl->slot;
+    pl->slot = (slot + 1) % kStageSlots;
+    if (pl->hev_used[slot]) MODL_HIP(hipEventSynchronize(pl->hev[slot]));
+    char *h = pl->hstage[slot];
+    pl->has_idx = bt->h_sample_idx != nullptr;
+    if (pl->has_idx) {
+        for (int i = 0; i < bt->b; ++i)
+            if (bt->h_sample_idx[i] < 0 || bt->h_sample_idx[i] >= d.n_samples) return MODL_EINVAL;
+        std::memcpy(h + pl->po_idx, bt->h_sample_idx, sizeof(int64_t) * (size_t)bt->b);
+    } else if (bt->b > d.n_samples) {
+        return MODL_EINVAL;
+    }
+    pl->has_subset = bt->h_subset != nullptr;
+    if (pl->has_subset) {
+        int32_t *dst = reinterpret_cast<int32_t *>(h + pl->po_subset);
+        for (int i = 0; i < bt->s; ++i) {
+            const int64_t f = bt->h_subset[i];
+            if (f < 0 || f >= d.p) return MODL_EINVAL;
+            dst[i] = (int32_t)f;
+        }
+    }
+    {
+        int32_t *dst = reinterpret_cast<int32_t *>(h + pl->po_order);
+        pl->h_order_copy.assign(bt->h_order, bt->h_order + d.k);
+        for (int i = 0; i < d.k; ++i) {
+            if (bt->h_order[i] < 0 || bt->h_order[i] >= d.k) return MODL_EINVAL;
+            dst[i] = (int32_t)bt->h_order[i];
+        }
+    }
+    if (bt->h_w_sample) std::memcpy(h + pl->po_wsample, bt->h_w_sample, pl->tsz * (size_t)bt->b);
+    MODL_HIP(hipMemcpyAsync(pl->dws + pl->off_params, h, pl->params_bytes, hipMemcpyHostToDevice, st));
+    MODL_HIP(hipEventRecord(pl->hev[slot], st));
+    pl->hev_used[slot] = true;
+    pl->staged = true;
+    return MODL_OK;
+}
+
+template <typename T>
+Operand dict_rows(const T *Dt, int k, const int32_t *subset) {   // element (i = atom, kk = feature) of Dt
+    Operand o;
+    o.ptr = Dt; o.si = 1; o.sk = k; o.gk = gather32(subset);
+    return o;
+}
+
+// G = scale * Dt[subset]^T Dt[subset]   (k x k, bitwise symmetric)
+template <typename T, class Epi>
+int gram_of_rows(modl_somf_plan *pl, hipStream_t st, const T *Dt, const int32_t *subset, int64_t s, const Epi &epi,
+                 int *nl) {
+    const Operand A = dict_rows<T>(Dt, pl->d.k, subset);
+    SplitWs ws{pl->dws + pl->off_split, pl->split_bytes};
+    return launch_gemm<T, Epi>(st, A, A, pl->d.k, pl->d.k, s, epi, ws, nl);
+}
+
+template <typename T>
+int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride, const int64_t *g_idx, T *Dx,
+                const T *xnorm2, T *code, const int64_t *d_idx, int b, int32_t *d_sweeps, int *nl, T *H0buf, T *Fbuf) {
+    const modl_somf_desc &d = pl->d;
+    const int k = d.k;
+    if (d.code_l1_ratio == 0.0) {                                     // ridge: dict_fact_fast.pyx:82-94, 174-197
+        const int nmat = g_stride ? b : 1;
+        MODL_TRY(launch_cholesky<T>(st, G, g_stride, g_idx, Fbuf, k, (T)d.code_alpha, nmat));
+        MODL_TRY(launch_chol_solve<T>(st, Fbuf, g_stride ? (int64_t)k * k : 0, Dx, b, k, code, d_idx));
+        *nl += 2;
+        return MODL_OK;
+    }
+    const T *H0 = nullptr;
+    if (g_stride == 0) {                                             // H0 = code[idx] G on the matrix cores
+        Operand A, B;
+        A.ptr = code; A.si = k; A.sk = 1; A.gi = gather64(d_idx);
+        B.ptr = G; B.si = k; B.sk = 1;                               // B(n = j, kk = m) = G[j][m]
+        EpiStore<T> epi{H0buf, k, (T)1};
+        SplitWs none;
+        MODL_TRY((launch_gemm<T, EpiStore<T>>(st, A, B, b, k, k, epi, none, nl, 512, 1)));
+        H0 = H0buf;
+    }
+    CdArgs<T> a;
+    a.G = G; a.g_stride = g_stride; a.g_idx = g_idx; a.Dx = Dx; a.xnorm2 = xnorm2; a.H0 = H0; a.code = code;
+    a.idx = d_idx;
+    a.sweeps = d_sweeps; a.b = b; a.k = k;
+    a.alpha = (T)((T)d.code_alpha * (T)d.code_l1_ratio);
+    a.beta = (T)((double)(T)d.code_alpha * (1.0 - (double)(T)d.code_l1_ratio));
+    a.tol = (T)d.tol; a.max_iter = d.max_iter; a.positive = d.code_pos;
+    MODL_TRY(launch_cd<T>(st, a));
+    ++*nl;
+    return MODL_OK;
+}
+
+template <typename T>
+int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch *bt, T *delta, hipStream_t st) {
+    const modl_somf_desc &d = pl->d;
+    const int k = d.k, b = bt->b;
+    const int64_t p = d.p, s = bt->s;
+    if (!stt || !stt->d_Dt || !stt->d_code || !delta) return MODL_EINVAL;
+    if (d.G_agg == MODL_AGG_FULL && !stt->d_G) return MODL_EINVAL;
+    if (d.G_agg == MODL_AGG_AVERAGE && !stt->d_G_average) return MODL_EINVAL;
+    if (d.Dx_agg == MODL_AGG_AVERAGE && !stt->d_Dx_average) return MODL_EINVAL;
+    MODL_TRY(stage_batch<T>(pl, bt, st));
+    char *P = pl->dws + pl->off_params;
+    const int64_t *d_idx = pl->has_idx ? reinterpret_cast<const int64_t *>(P + pl->po_idx) : nullptr;
+    const int32_t *d_subset = pl->has_subset ? reinterpret_cast<const int32_t *>(P + pl->po_subset) : nullptr;
+    const T *d_wsample = reinterpret_cast<const T *>(P + pl->po_wsample);
+    const T *X = static_cast<const T *>(bt->d_X);
+    const T *Dt = static_cast<const T *>(stt->d_Dt);
+    T *code = static_cast<T *>(stt->d_code);
+    T *xnorm = reinterpret_cast<T *>(pl->dws + pl->off_xnorm);
+    T *Dx = reinterpret_cast<T *>(pl->dws + pl->off_Dx);
+    T *H0 = reinterpret_cast<T *>(pl->dws + pl->off_H0);
+    T *Gbuf = reinterpret_cast<T *>(pl->dws + pl->off_G);
+    T *Fbuf = reinterpret_cast<T *>(pl->dws + pl->off_F);
+    SplitWs sws{pl->dws + pl->off_split, pl->split_bytes};
+    const T red = (T)bt->reduction;
+
+    {   // ---- Dx, G  (dict_fact.py:588-620)
+        ProfScope ps(pl, st, SEC_CODE_GEMM);
+        if (d.code_l1_ratio != 0.0) {
+            MODL_TRY(launch_row_norm2<T>(st, X, bt->ldx, p, b, xnorm));
+            ++ps.launches;
+        }
+        Operand A, B;
+        A.ptr = X; A.si = bt->ldx; A.sk = 1;
+        B.ptr = Dt; B.si = 1; B.sk = k;
+        int64_t Kdim = p;
+        T scale = 1;
+        if (d.Dx_agg != MODL_AGG_FULL) {                              // X[:, subset] . D[:, subset]^T * reduction
+            A.gk = gather32(d_subset);
+            B.gk = gather32(d_subset);
+            Kdim = s;
+            scale = red;
+        }
+        if (d.Dx_agg == MODL_AGG_AVERAGE) {
+            EpiDxAverage<T> epi{Dx, static_cast<T *>(stt->d_Dx_average), d_idx, d_wsample, k, scale};
+            MODL_TRY((launch_gemm<T, EpiDxAverage<T>>(st, A, B, b, k, Kdim, epi, sws, &ps.launches)));
+        } else {
+            EpiStore<T> epi{Dx, k, scale};
+            MODL_TRY((launch_gemm<T, EpiStore<T>>(st, A, B, b, k, Kdim, epi, sws, &ps.launches)));
+        }
+        if (d.G_agg != MODL_AGG_FULL) {
+            EpiStore<T> epi{Gbuf, k, red};
+            MODL_TRY((gram_of_rows<T, EpiStore<T>>(pl, st, Dt, d_subset, s, epi, &ps.launches)));
+            if (d.G_agg == MODL_AGG_AVERAGE) {
+                MODL_TRY(launch_update_G_average<T>(st, static_cast<T *>(stt->d_G_average), d_idx, Gbuf, d_wsample, b, k));
+                ++ps.launches;
+            }
+        }
+    }
+    {   // ---- code solve  (dict_fact.py:636-648)
+        ProfScope ps(pl, st, SEC_CODE_SOLVE);
+        if (d.G_agg == MODL_AGG_AVERAGE) {                            // per-sample Gram = rows idx of G_average_
+            const T *Gavg = static_cast<const T *>(stt->d_G_average);
+            MODL_TRY(solve_codes<T>(pl, st, Gavg, (int64_t)k * k, d_idx, Dx, xnorm, code, d_idx, b, nullptr,
+                                    &ps.launches, H0, Fbuf));
+        } else {
+            const T *G = (d.G_agg == MODL_AGG_FULL) ? static_cast<const T *>(stt->d_G) : Gbuf;
+            MODL_TRY(solve_codes<T>(pl, st, G, 0, nullptr, Dx, xnorm, code, d_idx, b, nullptr, &ps.launches, H0, Fbuf));
+        }
+    }
+    {   // ---- statistics increments: delta = [ code^T code | X^T code ]
+        ProfScope ps(pl, st, SEC_STATS_GEMM);
+        Operand Cd;
+        Cd.ptr = code; Cd.si = 1; Cd.sk = k; Cd.gk = gather64(d_idx);     // element (i = atom, kk = sample)
+        EpiStore<T> epiC{delta, k, (T)1};
+        MODL_TRY((launch_gemm<T, EpiStore<T>>(st, Cd, Cd, k, k, b, epiC, sws, &ps.launches)));
+        Operand Xo;
+        Xo.ptr = X; Xo.si = 1; Xo.sk = bt->ldx;                         // element (i = feature, kk = sample)
+        EpiStore<T> epiB{delta + (size_t)k * k, k, (T)1};
+        MODL_TRY((launch_gemm<T, EpiStore<T>>(st, Xo, Cd, p, k, b, epiB, sws, &ps.launches)));
+    }
+    return MODL_OK;
+}
+
+template <typename T>
+int phase2(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch *bt, const T *delta, hipStream_t st) {
+    const modl_somf_desc &d = pl->d;
+    const int k = d.k;
+    const int64_t p = d.p, s = bt->s;
+    if (!pl->staged) return MODL_ESTATE;
+    if (!stt || !stt->d_Dt || !stt->d_Bt || !stt->d_C || !stt->d_comp_norm || !delta) return MODL_EINVAL;
+    if (bt->b_global <= 0) return MODL_EINVAL;
+    char *P = pl->dws + pl->off_params;
+    const int32_t *d_subset = pl->has_subset ? reinterpret_cast<const int32_t *>(P + pl->po_subset) : nullptr;
+    const int32_t *d_order = reinterpret_cast<const int32_t *>(P + pl->po_order);
+    T *Dt = static_cast<T *>(stt->d_Dt);
+    T *Bt = static_cast<T *>(stt->d_Bt);
+    T *Cm = static_cast<T *>(stt->d_C);
+    {
+        ProfScope ps(pl, st, SEC_STATS_APPLY);
+        const int replace = d.optimizer == MODL_OPT_SGD;
+        const T beta = (T)(1.0 - bt->w), wt = (T)bt->w, bdiv = (T)bt->b_global;
+        hipLaunchKernelGGL((stats_apply_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv((int64_t)k * k, 256), 1024)),
+                           dim3(256), 0, st, Cm, delta, (int64_t)k * k, beta, wt, bdiv, replace);
+        MODL_LAUNCH_CHECK();
+        hipLaunchKernelGGL((stats_apply_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv(p * k, 256), 2048)), dim3(256),
+                           0, st, Bt, delta + (size_t)k * k, p * k, beta, wt, bdiv, replace);
+        MODL_LAUNCH_CHECK();
+        ps.launches += 2;
+    }
+    {
+        ProfScope ps(pl, st, SEC_DICT);
+        const bool track_G = d.G_agg == MODL_AGG_FULL;
+        const bool partial_G = track_G && (double)s < (double)p / 2.0;   // dict_fact.py:667, 711-715
+        if (partial_G) {
+            EpiAxpby<T> epi{static_cast<T *>(stt->d_G), k, (T)-1, (T)1};
+            MODL_TRY((gram_of_rows<T, EpiAxpby<T>>(pl, st, Dt, d_subset, s, epi, &ps.launches)));
+        }
+        DictUpdateArgs<T> a;
+        a.Dt = Dt; a.Bt = Bt; a.C = Cm; a.comp_norm = static_cast<T *>(stt->d_comp_norm);
+        a.subset = d_subset; a.order = d_order; a.h_order = pl->h_order_copy.data();
+        a.s = s; a.k = k; a.optimizer = d.optimizer; a.comp_pos = d.comp_pos;
+        a.comp_l1_ratio = d.comp_l1_ratio; a.w = bt->w; a.step_size = d.step_size;
+        a.ws = pl->dws + pl->off_du; a.ws_bytes = pl->du_bytes;
+        MODL_TRY(dict_update<T>(st, a, &ps.launches));
+        if (track_G) {
+            if (partial_G) {
+                EpiAxpby<T> epi{static_cast<T *>(stt->d_G), k, (T)1, (T)1};
+                MODL_TRY((gram_of_rows<T, EpiAxpby<T>>(pl, st, Dt, d_subset, s, epi, &ps.launches)));
+            } else {
+                EpiStore<T> epi{static_cast<T *>(stt->d_G), k, (T)1};
+                MODL_TRY((gram_of_rows<T, EpiStore<T>>(pl, st, Dt, nullptr, p, epi, &ps.launches)));
+            }
+        }
+    }
+    return MODL_OK;
+}
+
+template <typename T>
+int transform_impl(modl_somf_plan *pl, const T *Dt, const T *G, const T *X, int64_t ldx, int64_t n, T *code_out,
+                   hipStream_t st) {
+    const modl_somf_desc &d = pl->d;
+    const int k = d.k;
+    const int64_t p = d.p;
+    T *xnorm = reinterpret_cast<T *>(pl->dws + pl->off_xnorm);
+    T *Dx = reinterpret_cast<T *>(pl->dws + pl->off_Dx);
+    T *H0 = reinterpret_cast<T *>(pl->dws + pl->off_H0);
+    T *Gbuf = reinterpret_cast<T *>(pl->dws + pl->off_G);
+    T *Fbuf = reinterpret_cast<T *>(pl->dws + pl->off_F);
+    SplitWs sws{pl->dws + pl->off_split, pl->split_bytes};
+    int nl = 0;
+    if (!G) {                                                         // dict_fact.py:67-70
+        EpiStore<T> epi{Gbuf, k, (T)1};
+        MODL_TRY((gram_of_rows<T, EpiStore<T>>(pl, st, Dt, nullptr, p, epi, &nl)));
+        G = Gbuf;
+    }
+    hipLaunchKernelGGL((fill_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv(n * k, 256), 2048)), dim3(256), 0, st,
+                       code_out, n * k, (T)1);                        // code = ones (:72)
+    MODL_LAUNCH_CHECK();
+    for (int64_t r0 = 0; r0 < n; r0 += d.max_batch) {
+        const int b = (int)std::min<int64_t>(d.max_batch, n - r0);
+        const T *Xb = X + r0 * ldx;
+        if (d.code_l1_ratio != 0.0) MODL_TRY(launch_row_norm2<T>(st, Xb, ldx, p, b, xnorm));
+        Operand A, B;
+        A.ptr = Xb; A.si = ldx; A.sk = 1;
+        B.ptr = Dt; B.si = 1; B.sk = k;
+        EpiStore<T> epi{Dx, k, (T)1};
+        MODL_TRY((launch_gemm<T, EpiStore<T>>(st, A, B, b, k, p, epi, sws, &nl)));
+        MODL_TRY(solve_codes<T>(pl, st, G, 0, nullptr, Dx, xnorm, code_out + r0 * k, nullptr, b, nullptr, &nl, H0, Fbuf));
+    }
+    return MODL_OK;
+}
+
+template <typename T>
+int enet_regression_abi(const T *G, int64_t g_stride, T *Dx, const T *X, int64_t ldx, int64_t p, T *code,
+                        const int64_t *d_indices, int64_t b, int64_t k, T l1_ratio, T alpha, int positive, T tol,
+                        int max_iter, int32_t *d_sweeps, void *d_ws, size_t ws_bytes, void *stream) {
+    if (!G || !Dx || !X || !code || b < 0 || k <= 0 || k > 1024 || p < 0 || ldx < p) return MODL_EINVAL;
+    if (!(l1_ratio >= 0 && l1_ratio <= 1)) return MODL_EINVAL;
+    if (b == 0) return MODL_OK;
+    const size_t need = modl_enet_regression_workspace(DType<T>::id, b, k, g_stride != 0);
+    if (!d_ws || ws_bytes < need) return MODL_ENOMEM;
+    hipStream_t st = (hipStream_t)stream;
+    char *w = static_cast<char *>(d_ws);
+    T *xnorm = reinterpret_cast<T *>(w);
+    T *H0 = reinterpret_cast<T *>(w + align_up(sizeof(T) * (size_t)b, 256));
+    T *F = reinterpret_cast<T *>(w + align_up(sizeof(T) * (size_t)b, 256) + align_up(sizeof(T) * (size_t)b * k, 256));
+    if (l1_ratio == 0) {
+        if (k > 512) return MODL_EINVAL;
+        const int nmat = g_stride ? (int)b : 1;
+        MODL_TRY(launch_cholesky<T>(st, G, g_stride, nullptr, F, (int)k, alpha, nmat));
+        return launch_chol_solve<T>(st, F, g_stride ? k * k : 0, Dx, (int)b, (int)k, code, d_indices);
+    }
+    MODL_TRY(launch_row_norm2<T>(st, X, ldx, p, b, xnorm));
+    const T *H0p = nullptr;
+    if (g_stride == 0) {
+        Operand A, B;
+        A.ptr = code; A.si = k; A.sk = 1; A.gi = gather64(d_indices);
+        B.ptr = G; B.si = k; B.sk = 1;
+        EpiStore<T> epi{H0, k, (T)1};
+        SplitWs none;
+        MODL_TRY((launch_gemm<T, EpiStore<T>>(st, A, B, b, k, k, epi, none, nullptr, 512, 1)));
+        H0p = H0;
+    }
+    CdArgs<T> a;
+    a.G = G; a.g_stride = g_stride; a.g_idx = nullptr; a.Dx = Dx; a.xnorm2 = xnorm; a.H0 = H0p; a.code = code;
+    a.idx = d_indices;
+    a.sweeps = d_sweeps; a.b = (int)b; a.k = (int)k;
+    a.alpha = alpha * l1_ratio;
+    a.beta = (T)((double)alpha * (1.0 - (double)l1_ratio));
+    a.tol = tol; a.max_iter = max_iter; a.positive = positive;
+    return launch_cd<T>(st, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+int modl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+size_t modl_enet_regression_workspace(int dtype, int64_t b, int64_t k, int multi_gram) {
+    const size_t t = dtype == MODL_F32 ? 4 : 8;
+    if (b < 0 || k < 0) return 0;
+    return align_up(t * (size_t)b, 256) + align_up(t * (size_t)b * k, 256) +
+           align_up(t * (size_t)k * k * (multi_gram ? (size_t)b : 1), 256);
+}
+
+#define ABI_REG(SFX, T)                                                                                            \
+    int modl_enet_regression_single_gram_##SFX(const T *d_G, T *d_Dx, const T *d_X, int64_t ldx, int64_t p,        \
+                                               T *d_code, const int64_t *d_indices, int64_t b, int64_t k,          \
+                                               T l1_ratio, T alpha, int positive, T tol, int max_iter,             \
+                                               int32_t *d_sweeps, void *d_ws, size_t ws_bytes, void *stream) {     \
+        return enet_regression_abi<T>(d_G, 0, d_Dx, d_X, ldx, p, d_code, d_indices, b, k, l1_ratio, alpha,          \
+                                      positive, tol, max_iter, d_sweeps, d_ws, ws_bytes, stream);                  \
+    }                                                                                                              \
+    int modl_enet_regression_multi_gram_##SFX(const T *d_G, T *d_Dx, const T *d_X, int64_t ldx, int64_t p,         \
+                                              T *d_code, const int64_t *d_indices, int64_t b, int64_t k,           \
+                                              T l1_ratio, T alpha, int positive, T tol, int max_iter,              \
+                                              int32_t *d_sweeps, void *d_ws, size_t ws_bytes, void *stream) {      \
+        return enet_regression_abi<T>(d_G, k * k, d_Dx, d_X, ldx, p, d_code, d_indices, b, k, l1_ratio, alpha,      \
+                                      positive, tol, max_iter, d_sweeps, d_ws, ws_bytes, stream);                  \
+    }
+ABI_REG(f32, float)
+ABI_REG(f64, double)
+#undef ABI_REG
+
+int64_t modl_somf_delta_elems(const modl_somf_desc *desc) {
+    if (!desc) return 0;
+    return (int64_t)desc->k * desc->k + desc->p * (int64_t)desc->k;
+}
+
+int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
+    if (!out) return MODL_EINVAL;
+    *out = nullptr;
+    MODL_TRY(validate_desc(desc));
+    if (modl_device_count() <= 0) return MODL_ENOGPU;
+    modl_somf_plan *pl = new (std::nothrow) modl_somf_plan();
+    if (!pl) return MODL_ENOMEM;
+    pl->d = *desc;
+    pl->tsz = desc->dtype == MODL_F32 ? 4 : 8;
+    const size_t t = pl->tsz;
+    const size_t k = (size_t)desc->k, b = (size_t)desc->max_batch, p = (size_t)desc->p;
+    pl->params_bytes = params_layout(pl);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    pl->off_params = take(pl->params_bytes);
+    pl->off_xnorm = take(t * b);
+    pl->off_Dx = take(t * b * k);
+    pl->off_H0 = take(t * b * k);
+    pl->off_G = take(t * k * k);
+    const bool per_sample = desc->G_agg == MODL_AGG_AVERAGE;
+    pl->off_F = take(t * k * k * (per_sample ? b : 1));                // Cholesky factors (one per sample for G_average_)
+    // split-K partial tiles: the largest split product is max(b, k) x k (Dx, Gram, C increment) with
+    // up to 64 splits; the p x k product (B increment) has >= 512 tiles at p >= 8k and is not split
+    pl->split_bytes = t * std::max(b, k) * k * 64;
+    if (p * k < std::max(b, k) * k * 64) pl->split_bytes = std::max(pl->split_bytes, t * p * k * 8);
+    pl->off_split = take(pl->split_bytes);
+    pl->du_bytes = dict_update_workspace(desc->dtype, (int64_t)p, desc->k);
+    pl->off_du = take(pl->du_bytes);
+    pl->dws_bytes = o;
+    hipError_t e = hipMalloc((void **)&pl->dws, pl->dws_bytes);
+    if (e != hipSuccess) { delete pl; return (int)e; }
+    for (int i = 0; i < kStageSlots; ++i) {
+        e = hipHostMalloc((void **)&pl->hstage[i], pl->params_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->hev[i], hipEventDisableTiming);
+        if (e != hipSuccess) { modl_somf_plan_destroy(pl); return (int)e; }
+    }
+    *out = pl;
+    return MODL_OK;
+}
+
+void modl_somf_plan_destroy(modl_somf_plan *pl) {
+    if (!pl) return;
+    if (pl->dws) (void)hipFree(pl->dws);
+    for (int i = 0; i < kStageSlots; ++i) {
+        if (pl->hstage[i]) (void)hipHostFree(pl->hstage[i]);
+        if (pl->hev[i]) (void)hipEventDestroy(pl->hev[i]);
+    }
+    for (hipEvent_t ev : pl->pev) (void)hipEventDestroy(ev);
+    delete pl;
+}
+
+int modl_somf_plan_update(modl_somf_plan *pl, const modl_somf_desc *desc) {
+    if (!pl) return MODL_EINVAL;
+    MODL_TRY(validate_desc(desc));
+    const modl_somf_desc &o = pl->d;
+    if (desc->dtype != o.dtype || desc->k != o.k || desc->p != o.p || desc->n_samples != o.n_samples ||
+        desc->max_batch != o.max_batch)
+        return MODL_EINVAL;
+    if (desc->G_agg == MODL_AGG_AVERAGE && o.G_agg != MODL_AGG_AVERAGE) return MODL_EINVAL;   // scratch was not sized for it
+    pl->d = *desc;
+    return MODL_OK;
+}
+
+#define DISPATCH(pl, CALLF, CALLD) ((pl)->d.dtype == MODL_F32 ? (CALLF) : (CALLD))
+
+int modl_somf_code_and_partials(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt, void *d_delta,
+                                void *stream) {
+    if (!pl || !bt) return MODL_EINVAL;
+    return DISPATCH(pl, phase1<float>(pl, st, bt, static_cast<float *>(d_delta), (hipStream_t)stream),
+                    phase1<double>(pl, st, bt, static_cast<double *>(d_delta), (hipStream_t)stream));
+}
+
+int modl_somf_apply_and_update_dict(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt,
+                                    const void *d_delta, void *stream) {
+    if (!pl || !bt) return MODL_EINVAL;
+    return DISPATCH(pl, phase2<float>(pl, st, bt, static_cast<const float *>(d_delta), (hipStream_t)stream),
+                    phase2<double>(pl, st, bt, static_cast<const double *>(d_delta), (hipStream_t)stream));
+}
+
+int modl_somf_step(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt, void *d_delta,
+                   void *stream) {
+    MODL_TRY(modl_somf_code_and_partials(pl, st, bt, d_delta, stream));
+    return modl_somf_apply_and_update_dict(pl, st, bt, d_delta, stream);
+}
+
+int modl_somf_full_gram(modl_somf_plan *pl, const void *d_Dt, void *d_G, void *stream) {
+    if (!pl || !d_Dt || !d_G) return MODL_EINVAL;
+    int nl = 0;
+    if (pl->d.dtype == MODL_F32) {
+        EpiStore<float> epi{static_cast<float *>(d_G), pl->d.k, 1.0f};
+        return gram_of_rows<float, EpiStore<float>>(pl, (hipStream_t)stream, static_cast<const float *>(d_Dt), nullptr,
+                                                    pl->d.p, epi, &nl);
+    }
+    EpiStore<double> epi{static_cast<double *>(d_G), pl->d.k, 1.0};
+    return gram_of_rows<double, EpiStore<double>>(pl, (hipStream_t)stream, static_cast<const double *>(d_Dt), nullptr,
+                                                  pl->d.p, epi, &nl);
+}
+
+int modl_somf_transform(modl_somf_plan *pl, const void *d_Dt, const void *d_G, const void *d_X, int64_t ldx, int64_t n,
+                        void *d_code_out, void *stream) {
+    if (!pl || !d_Dt || !d_X || !d_code_out || n < 0 || ldx < pl->d.p) return MODL_EINVAL;
+    if (n == 0) return MODL_OK;
+    return DISPATCH(pl,
+                    transform_impl<float>(pl, static_cast<const float *>(d_Dt), static_cast<const float *>(d_G),
+                                          static_cast<const float *>(d_X), ldx, n, static_cast<float *>(d_code_out),
+                                          (hipStream_t)stream),
+                    transform_impl<double>(pl, static_cast<const double *>(d_Dt), static_cast<const double *>(d_G),
+                                           static_cast<const double *>(d_X), ldx, n, static_cast<double *>(d_code_out),
+                                           (hipStream_t)stream));
+}
+
+int modl_somf_prof_enable(modl_somf_plan *pl, int enable) {
+    if (!pl) return MODL_EINVAL;
+    if (enable && pl->pev.empty()) {
+        pl->pev.resize(2 * kProfPool, nullptr);
+        pl->psec.resize(kProfPool);
+        pl->plaunch.resize(kProfPool);
+        for (auto &ev : pl->pev) MODL_HIP(hipEventCreate(&ev));
+    }
+    if (!enable && pl->prof) MODL_TRY(prof_flush(pl));
+    pl->prof = enable != 0;
+    return MODL_OK;
+}
+
+int modl_somf_prof_get(modl_somf_plan *pl, modl_prof_entry *out, int cap, int *n_out) {
+    if (!pl || !out || !n_out) return MODL_EINVAL;
+    MODL_TRY(prof_flush(pl));
+    int n = 0;
+    for (int s = 0; s < SEC_COUNT && n < cap; ++s, ++n) {
+        out[n].name = kSectionNames[s];
+        out[n].ms_total = pl->ms[s];
+        out[n].launches = pl->launches[s];
+        out[n].calls = pl->calls[s];
+    }
+    *n_out = n;
+    return MODL_OK;
+}
+
+int modl_somf_prof_reset(modl_somf_plan *pl) {
+    if (!pl) return MODL_EINVAL;
+    MODL_TRY(prof_flush(pl));
+    for (int s = 0; s < SEC_COUNT; ++s) { pl->ms[s] = 0; pl->launches[s] = 0; pl->calls[s] = 0; }
+    return MODL_OK;
+}
+
+}  // extern "C"

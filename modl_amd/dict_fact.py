@@ -1,0 +1,580 @@
+"""DictFact / Coder: the scikit-learn style surface of the reference
+(modl/decomposition/dict_fact.py:23-745) over the MI355X kernels of
+libmodl_hip.so.
+
+The Python estimator stays host code: it draws the feature subset
+(``Sampler``), the atom order (numpy legacy ``RandomState.permutation``,
+dict_fact.py:672) and the minibatch weight exactly as the reference does, and
+hands them to the device step (``modl_somf_code_and_partials`` +
+``modl_somf_apply_and_update_dict``).  All state lives in HBM between
+minibatches; attributes such as ``components_`` are copied back on access.
+
+With ``torch.distributed`` initialised, every rank processes its own rows of a
+global minibatch and the statistics increment ``[code^T code | X^T code]`` is
+all-reduced (RCCL over xGMI when the backend is ``nccl``) between the two
+phases; all ranks then perform the identical dictionary update.
+"""
+import ctypes as C
+import time
+from math import ceil
+
+import numpy as np
+import torch
+from sklearn.base import BaseEstimator, TransformerMixin
+from sklearn.utils import check_array, check_random_state, gen_batches
+from sklearn.utils.validation import check_is_fitted
+
+from . import _lib
+from ._lib import lib, check, SomfDesc, SomfState, SomfBatch, ProfEntry, AGG, OPT
+from .device import (default_device, dtype_id, sfx, torch_dtype, ptr, stream_ptr, to_device, transpose_to)
+from .randomkit import RandomState, Sampler, batch_weight
+from .utils import get_sub_slice
+
+MAX_INT = np.iinfo(np.int64).max
+
+
+def _as_float_array(X):
+    """check_array(order='C', dtype=[f32, f64]) for numpy input (dict_fact.py:299,328);
+    device tensors pass through."""
+    if isinstance(X, torch.Tensor):
+        if X.dtype not in (torch.float32, torch.float64):
+            X = X.to(torch.float64)
+        return X
+    return check_array(X, order='C', dtype=[np.float32, np.float64])
+
+
+class HipBackend:
+    """Device state + calls into libmodl_hip.so for one estimator."""
+
+    name = 'hip'
+
+    def __init__(self, device=None):
+        self.device = torch.device(device) if device is not None else default_device()
+        self.plan = None
+        self.delta = None
+
+    # -- allocation ---------------------------------------------------------
+    def allocate(self, desc_kwargs, n_samples, p, k, dtype):
+        self.dtype = np.dtype(dtype)
+        self.k, self.p, self.n = k, p, n_samples
+        td, dev = torch_dtype(dtype), self.device
+        z = lambda *s: torch.zeros(s, dtype=td, device=dev)
+        self.Dt, self.Bt, self.C = z(p, k), z(p, k), z(k, k)
+        self.code = torch.ones((n_samples, k), dtype=td, device=dev)        # dict_fact.py:470
+        self.comp_norm = z(k)
+        self.G = z(k, k) if desc_kwargs['G_agg'] == 'full' else None
+        self.Dx_average = z(n_samples, k) if desc_kwargs['Dx_agg'] == 'average' else None
+        self.G_average = z(n_samples, k, k) if desc_kwargs['G_agg'] == 'average' else None
+        self._make_plan(desc_kwargs)
+        self.delta = torch.zeros(k * k + p * k, dtype=td, device=dev)
+
+    def _desc(self, kw):
+        d = SomfDesc()
+        d.dtype = dtype_id(self.dtype)
+        d.k, d.p, d.n_samples = self.k, self.p, self.n
+        d.G_agg, d.Dx_agg, d.optimizer = AGG[kw['G_agg']], AGG[kw['Dx_agg']], OPT[kw['optimizer']]
+        d.code_pos, d.comp_pos, d.max_iter = int(bool(kw['code_pos'])), int(bool(kw['comp_pos'])), int(kw['max_iter'])
+        d.code_alpha, d.code_l1_ratio = float(kw['code_alpha']), float(kw['code_l1_ratio'])
+        d.comp_l1_ratio, d.tol, d.step_size = float(kw['comp_l1_ratio']), float(kw['tol']), float(kw['step_size'])
+        d.max_batch = int(kw['max_batch'])
+        return d
+
+    def _make_plan(self, kw):
+        self.release_plan()
+        self._desc_kw = dict(kw)
+        d = self._desc(kw)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.modl_somf_plan_create(C.byref(d), C.byref(h)), 'modl_somf_plan_create')
+        self.plan = h
+
+    def update_plan(self, kw):
+        """set_params between minibatches (dict_fact.py:339-357)."""
+        if kw['max_batch'] != self._desc_kw['max_batch'] or \
+                (kw['G_agg'] == 'average' and self._desc_kw['G_agg'] != 'average'):
+            self._make_plan(kw)
+            return
+        td, dev = torch_dtype(self.dtype), self.device
+        if kw['Dx_agg'] == 'average' and self.Dx_average is None:
+            self.Dx_average = torch.zeros((self.n, self.k), dtype=td, device=dev)
+        if kw['G_agg'] == 'full' and self.G is None:
+            self.G = torch.zeros((self.k, self.k), dtype=td, device=dev)
+        self._desc_kw = dict(kw)
+        d = self._desc(kw)
+        check(lib.modl_somf_plan_update(self.plan, C.byref(d)), 'modl_somf_plan_update')
+
+    def release_plan(self):
+        if getattr(self, 'plan', None):
+            lib.modl_somf_plan_destroy(self.plan)
+            self.plan = None
+
+    def release_all(self):
+        self.release_plan()
+        if getattr(self, 'tplan', None):
+            lib.modl_somf_plan_destroy(self.tplan)
+            self.tplan = None
+
+    def __del__(self):
+        try:
+            self.release_all()
+        except Exception:
+            pass
+
+    # -- state access ---------------------------------------------------------
+    def _state(self):
+        s = SomfState()
+        s.d_Dt, s.d_Bt, s.d_C, s.d_code = ptr(self.Dt), ptr(self.Bt), ptr(self.C), ptr(self.code)
+        s.d_comp_norm, s.d_G = ptr(self.comp_norm), ptr(self.G)
+        s.d_Dx_average, s.d_G_average = ptr(self.Dx_average), ptr(self.G_average)
+        return s
+
+    def set_dictionary(self, D):                      # D: (k, p) numpy or tensor
+        Dd = to_device(D, self.device, dtype=self.dtype)
+        self.Dt = transpose_to(Dd, self.k, self.p)
+
+    def get_dictionary(self):
+        return transpose_to(self.Dt, self.p, self.k).cpu().numpy()
+
+    def set_B(self, B):
+        self.Bt = transpose_to(to_device(B, self.device, dtype=self.dtype), self.k, self.p)
+
+    def get_B(self):
+        return transpose_to(self.Bt, self.p, self.k).cpu().numpy()
+
+    def get(self, name):
+        t = getattr(self, name)
+        return None if t is None else t.cpu().numpy()
+
+    def set(self, name, value):
+        cur = getattr(self, name)
+        new = to_device(value, self.device, dtype=self.dtype)
+        if cur is not None and tuple(cur.shape) == tuple(new.shape):
+            cur.copy_(new)
+        else:
+            setattr(self, name, new.clone())
+
+    def scale_atoms(self, l1_ratio, radius=1.0):      # enet_scale on every atom (dict_fact.py:465-468)
+        f = getattr(lib, 'modl_enet_scale_' + sfx(self.dtype))
+        check(f(ptr(self.Dt), self.k, self.p, 1, self.k, l1_ratio, radius, stream_ptr(self.device)), 'modl_enet_scale')
+
+    def full_gram(self):
+        if self.G is None:
+            self.G = torch.zeros((self.k, self.k), dtype=torch_dtype(self.dtype), device=self.device)
+        check(lib.modl_somf_full_gram(self.plan, ptr(self.Dt), ptr(self.G), stream_ptr(self.device)), 'modl_somf_full_gram')
+
+    def shuffle_rows(self, name, swaps):
+        t = getattr(self, name)
+        row_bytes = t[0].numel() * t.element_size()
+        check(lib.modl_apply_swaps_rows_device(ptr(t), t.shape[0], row_bytes, swaps.ctypes.data_as(C.c_void_p),
+                                               stream_ptr(self.device)), 'modl_apply_swaps_rows_device')
+
+    # -- data ---------------------------------------------------------------
+    def stage_X(self, X):
+        return to_device(X, self.device, dtype=self.dtype)
+
+    def take_rows(self, Xh, perm):
+        return Xh.index_select(0, torch.from_numpy(np.asarray(perm, dtype=np.int64)).to(Xh.device))
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+    # -- the step -------------------------------------------------------------
+    def _batch(self, Xh, batch, idx, subset, order, w_sample, w, reduction, b_global):
+        bt = SomfBatch()
+        rows = Xh[batch]
+        bt.d_X, bt.ldx, bt.b = ptr(rows), Xh.stride(0), rows.shape[0]
+        keep = [rows]
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        order = np.ascontiguousarray(order, dtype=np.int64)
+        keep += [idx, order]
+        bt.h_sample_idx, bt.h_order = idx.ctypes.data, order.ctypes.data
+        if subset is None or len(subset) == self.p:
+            bt.s, bt.h_subset = self.p, None                  # every feature: no gather (any order is the same set)
+        else:
+            subset = np.ascontiguousarray(subset, dtype=np.int64)
+            keep.append(subset)
+            bt.s, bt.h_subset = len(subset), subset.ctypes.data
+        if w_sample is not None:
+            w_sample = np.ascontiguousarray(w_sample, dtype=self.dtype)
+            keep.append(w_sample)
+            bt.h_w_sample = w_sample.ctypes.data
+        bt.w, bt.reduction, bt.b_global = float(w), float(reduction), int(b_global)
+        return bt, keep
+
+    def phase1(self, Xh, batch, idx, subset, order, w_sample, w, reduction, b_global):
+        bt, keep = self._batch(Xh, batch, idx, subset, order, w_sample, w, reduction, b_global)
+        st = self._state()
+        check(lib.modl_somf_code_and_partials(self.plan, C.byref(st), C.byref(bt), ptr(self.delta),
+                                              stream_ptr(self.device)), 'modl_somf_code_and_partials')
+        self._pending = (bt, keep)
+        return self.delta
+
+    def phase2(self, delta):
+        bt, keep = self._pending
+        st = self._state()
+        check(lib.modl_somf_apply_and_update_dict(self.plan, C.byref(st), C.byref(bt), ptr(delta),
+                                                  stream_ptr(self.device)), 'modl_somf_apply_and_update_dict')
+        self._pending = None
+
+    def transform(self, Xh, kw, G=None):
+        """Codes from a warm start of ones, in chunks of a dedicated plan (large max_batch)."""
+        kw = dict(kw, max_batch=4096, G_agg='masked', Dx_agg='masked', optimizer='variational')
+        if getattr(self, 'tplan', None) is None or kw != self._tplan_kw:
+            if getattr(self, 'tplan', None):
+                lib.modl_somf_plan_destroy(self.tplan)
+                self.tplan = None
+            d = self._desc(kw)
+            h = C.c_void_p()
+            with torch.cuda.device(self.device):
+                check(lib.modl_somf_plan_create(C.byref(d), C.byref(h)), 'modl_somf_plan_create')
+            self.tplan, self._tplan_kw = h, kw
+        n = Xh.shape[0]
+        out = torch.empty((n, self.k), dtype=torch_dtype(self.dtype), device=self.device)
+        check(lib.modl_somf_transform(self.tplan, ptr(self.Dt), ptr(G), ptr(Xh), Xh.stride(0), n, ptr(out),
+                                      stream_ptr(self.device)), 'modl_somf_transform')
+        return out.cpu().numpy()
+
+    # -- profiling ------------------------------------------------------------
+    def prof_enable(self, on=True):
+        check(lib.modl_somf_prof_enable(self.plan, int(on)))
+
+    def prof_reset(self):
+        check(lib.modl_somf_prof_reset(self.plan))
+
+    def prof_get(self):
+        arr = (ProfEntry * 16)()
+        n = C.c_int()
+        check(lib.modl_somf_prof_get(self.plan, arr, 16, C.byref(n)))
+        return {arr[i].name.decode(): dict(ms=arr[i].ms_total, launches=arr[i].launches, calls=arr[i].calls)
+                for i in range(n.value)}
+
+
+class _DeviceRows:
+    """Adapter so RandomState.shuffle_with_trace can permute device-resident rows."""
+
+    def __init__(self, backend, name):
+        self.backend, self.name = backend, name
+
+    def __len__(self):
+        return getattr(self.backend, self.name).shape[0]
+
+    def _modl_device_rows(self, swaps):
+        self.backend.shuffle_rows(self.name, swaps)
+
+
+class CodingMixin(TransformerMixin):
+    def _set_coding_params(self, n_components, code_alpha=1, code_l1_ratio=1, tol=1e-2, max_iter=100,
+                           code_pos=False, random_state=None, n_threads=1):
+        self.n_components = n_components
+        self.code_l1_ratio = code_l1_ratio
+        self.code_alpha = code_alpha
+        self.code_pos = code_pos
+        self.random_state = random_state
+        self.tol = tol
+        self.max_iter = max_iter
+        self.n_threads = n_threads            # kept for API compatibility; the GPU step has no thread pool
+
+    def _make_backend(self):
+        return HipBackend(getattr(self, 'device', None))
+
+    def _plan_kwargs(self, max_batch):
+        g = lambda n, d: getattr(self, n, d)
+        return dict(G_agg=g('G_agg', 'masked'), Dx_agg=g('Dx_agg', 'masked'), optimizer=g('optimizer', 'variational'),
+                    code_pos=self.code_pos, comp_pos=g('comp_pos', False), max_iter=self.max_iter,
+                    code_alpha=self.code_alpha, code_l1_ratio=self.code_l1_ratio,
+                    comp_l1_ratio=g('comp_l1_ratio', 0), tol=self.tol, step_size=g('step_size', 1),
+                    max_batch=max_batch)
+
+    def transform(self, X):
+        """Codes of the rows of X on the dictionary (dict_fact.py:47-92)."""
+        check_is_fitted(self, 'components_')
+        be = self._backend
+        if not isinstance(X, torch.Tensor):
+            X = check_array(X, order='C', dtype=be.dtype.type)
+        Xh = be.stage_X(X)
+        if Xh.shape[1] != be.p:
+            raise ValueError('X has %d features, the dictionary has %d' % (Xh.shape[1], be.p))
+        use_G = getattr(self, 'G_agg', None) == 'full' and be.G is not None
+        return be.transform(Xh, self._plan_kwargs(4096), be.G if use_G else None)
+
+    def score(self, X):
+        """Objective value on test data X (dict_fact.py:94-114)."""
+        check_is_fitted(self, 'components_')
+        code = self.transform(X)
+        Xn = X.cpu().numpy() if isinstance(X, torch.Tensor) else np.asarray(X)
+        D = self.components_
+        loss = np.sum((Xn - code.dot(D)) ** 2) / 2
+        regul = self.code_alpha * (np.sum(np.abs(code)) * self.code_l1_ratio
+                                   + (1 - self.code_l1_ratio) * np.sum(code ** 2) / 2)
+        return (loss + regul) / Xn.shape[0]
+
+
+def _state_property(name, getter=None, setter=None):
+    def fget(self):
+        be = self.__dict__.get('_backend')
+        if be is None or getattr(be, 'Dt', None) is None:
+            raise AttributeError(name)
+        val = getter(be) if getter else be.get(name)
+        if val is None:
+            raise AttributeError(name)
+        return val
+
+    def fset(self, value):
+        be = self.__dict__.get('_backend')
+        if be is None:
+            raise AttributeError('%s can only be set after prepare()' % name)
+        (setter(be, value) if setter else be.set(name, value))
+    return property(fget, fset)
+
+
+class DictFact(CodingMixin, BaseEstimator):
+    """Stochastic-subsampled online matrix factorization (SOMF) on one or several
+    MI355X.  Constructor, attributes and methods follow the reference estimator
+    (modl/decomposition/dict_fact.py:127-284); ``device`` is the only addition."""
+
+    def __init__(self, reduction=1, learning_rate=1, sample_learning_rate=0.76, Dx_agg='masked', G_agg='masked',
+                 optimizer='variational', dict_init=None, code_alpha=1, code_l1_ratio=1, comp_l1_ratio=0,
+                 step_size=1, tol=1e-2, max_iter=100, code_pos=False, comp_pos=False, random_state=None,
+                 n_epochs=1, n_components=10, batch_size=10, verbose=0, callback=None, n_threads=1,
+                 rand_size=True, replacement=True, device=None):
+        self.batch_size = batch_size
+        self.learning_rate = learning_rate
+        self.sample_learning_rate = sample_learning_rate
+        self.Dx_agg = Dx_agg
+        self.G_agg = G_agg
+        self.reduction = reduction
+        self.dict_init = dict_init
+        self._set_coding_params(n_components, code_l1_ratio=code_l1_ratio, code_alpha=code_alpha,
+                                code_pos=code_pos, random_state=random_state, tol=tol, max_iter=max_iter,
+                                n_threads=n_threads)
+        self.comp_l1_ratio = comp_l1_ratio
+        self.comp_pos = comp_pos
+        self.optimizer = optimizer
+        self.step_size = step_size
+        self.n_epochs = n_epochs
+        self.verbose = verbose
+        self.callback = callback
+        self.rand_size = rand_size
+        self.replacement = replacement
+        self.device = device
+
+    # device-resident attributes of the reference (dict_fact.py:225-249)
+    components_ = _state_property('components_', lambda be: be.get_dictionary(), lambda be, v: be.set_dictionary(v))
+    B_ = _state_property('B_', lambda be: be.get_B(), lambda be, v: be.set_B(v))
+    C_ = _state_property('C')
+    code_ = _state_property('code')
+    comp_norm_ = _state_property('comp_norm')
+    G_ = _state_property('G')
+    Dx_average_ = _state_property('Dx_average')
+    G_average_ = _state_property('G_average')
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, X):
+        """dict_fact.py:286-311"""
+        X = _as_float_array(X)
+        if self.dict_init is None:
+            dict_init = X
+        else:
+            dict_init = check_array(self.dict_init, dtype=(np.float32 if X.dtype in (np.float32, torch.float32)
+                                                           else np.float64))
+        self.prepare(n_samples=X.shape[0], X=dict_init)
+        Xh = self._backend.stage_X(X)
+        for _ in range(self.n_epochs):
+            self.partial_fit(Xh)
+            permutation = self.shuffle()
+            Xh = self._backend.take_rows(Xh, permutation)
+        return self
+
+    def partial_fit(self, X, sample_indices=None):
+        """dict_fact.py:313-337.  X: numpy array or device tensor (n, n_features)."""
+        X = _as_float_array(X)
+        be = self._backend
+        Xh = be.stage_X(X)
+        if Xh.shape[1] != be.p:
+            raise ValueError('X has %d features, expected %d' % (Xh.shape[1], be.p))
+        if self.batch_size > be._desc_kw['max_batch']:
+            be.update_plan(self._plan_kwargs(self.batch_size))
+        t0 = time.perf_counter()
+        self._cb_time = 0.0
+        for batch in gen_batches(Xh.shape[0], self.batch_size):
+            self._single_batch_fit(Xh, batch, get_sub_slice(sample_indices, batch))
+        be.synchronize()
+        self.time_ += time.perf_counter() - t0 - self._cb_time
+        return self
+
+    def set_params(self, **params):
+        """dict_fact.py:339-357: only a switch of G_agg to 'full' is honoured for
+        G_agg (G_ is then computed from the current dictionary)."""
+        G_agg = params.pop('G_agg', None)
+        be = self.__dict__.get('_backend')
+        if G_agg == 'full' and self.G_agg != 'full':
+            self.G_agg = 'full'
+            if be is not None and getattr(be, 'Dt', None) is not None:
+                be.update_plan(self._plan_kwargs(be._desc_kw['max_batch']))
+                be.full_gram()
+        BaseEstimator.set_params(self, **params)
+        if be is not None and getattr(be, 'Dt', None) is not None:
+            be.update_plan(self._plan_kwargs(be._desc_kw['max_batch']))
+        return self
+
+    def shuffle(self):
+        """Shuffle code_, G_average_, Dx_average_ rows; returns the permutation (dict_fact.py:359-379)."""
+        random_seed = self.random_state.randint(MAX_INT)
+        random_state = RandomState(random_seed)
+        be = self._backend
+        arrays = [_DeviceRows(be, 'code')]
+        if self.G_agg == 'average':
+            arrays.append(_DeviceRows(be, 'G_average'))
+        if self.Dx_agg == 'average' and be.Dx_average is not None:
+            arrays.append(_DeviceRows(be, 'Dx_average'))
+        perm = random_state.shuffle_with_trace(arrays)
+        self.labels_ = self.labels_[perm]
+        return perm
+
+    def prepare(self, n_samples=None, n_features=None, dtype=None, X=None):
+        """Allocate and initialise the estimator state (dict_fact.py:381-489)."""
+        if X is not None:
+            if isinstance(X, torch.Tensor):
+                X = X[:self.n_components].cpu().numpy()
+            X = check_array(X, order='C', dtype=[np.float32, np.float64])
+            if dtype is None:
+                dtype = X.dtype
+            if n_samples is None:
+                n_samples = X.shape[0]
+            if n_features is None:
+                n_features = X.shape[1]
+            elif n_features != X.shape[1]:
+                raise ValueError('n_features and X does not match')
+        else:
+            if n_features is None or n_samples is None:
+                raise ValueError('Either provide shape or data to function prepare.')
+            if dtype is None:
+                dtype = np.float64
+        dtype = np.dtype(dtype)
+        if dtype not in (np.float32, np.float64):
+            raise ValueError('dtype should be float32 or float64')       # the reference returns it (:422)
+        if self.optimizer not in ['variational', 'sgd']:
+            raise ValueError("optimizer should be 'variational' or 'sgd'")
+        if self.optimizer == 'sgd':
+            self.reduction = 1
+            self.G_agg = 'full'
+            self.Dx_agg = 'full'
+        k = self.n_components
+        self._backend = be = self._make_backend()
+        be.allocate(self._plan_kwargs(self.batch_size), n_samples, n_features, k, dtype)
+
+        self.random_state = check_random_state(self.random_state)
+        if X is None:
+            D = np.empty((k, n_features), dtype=dtype)
+            D[:, :] = self.random_state.randn(k, n_features)
+        else:
+            D = check_array(X[:k], dtype=dtype.type, copy=True)          # first k rows (:459-461)
+            if D.shape[0] < k:
+                raise ValueError('X should have at least n_components rows')
+        if self.comp_pos:
+            D[D <= 0] = -D[D <= 0]
+        be.set_dictionary(D)
+        be.scale_atoms(self.comp_l1_ratio, 1.0)
+        self.labels_ = np.arange(n_samples)
+        if self.G_agg == 'full':
+            be.full_gram()
+        self.n_iter_ = 0
+        self.sample_n_iter_ = np.zeros(n_samples, dtype='int')
+        self.random_state = check_random_state(self.random_state)
+        random_seed = self.random_state.randint(MAX_INT)
+        self.feature_sampler_ = Sampler(n_features, self.rand_size, self.replacement, random_seed)
+        if self.verbose:
+            self.verbose_iter_ = np.linspace(0, n_samples * self.n_epochs, self.verbose).tolist()
+        self.time_ = 0
+        self._cb_time = 0.0
+        return self
+
+    # ------------------------------------------------------------- internals
+    def _callback(self):
+        if self.callback is not None:
+            self.callback(self)
+
+    def _world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size()
+        return 1
+
+    def _all_reduce(self, delta):
+        import torch.distributed as dist
+        dist.all_reduce(delta, op=dist.ReduceOp.SUM)
+
+    def _single_batch_fit(self, Xh, batch, sample_indices):
+        """One SOMF iteration (dict_fact.py:495-526)."""
+        if self.verbose and self.verbose_iter_ and self.n_iter_ >= self.verbose_iter_[0]:
+            tc = time.perf_counter()
+            print('Iteration %i' % self.n_iter_)
+            self.verbose_iter_ = self.verbose_iter_[1:]
+            self._callback()
+            self._cb_time += time.perf_counter() - tc
+        be = self._backend
+        world = self._world()
+        subset = self.feature_sampler_.yield_subset(self.reduction)
+        batch_size = batch.stop - batch.start
+        b_global = batch_size * world
+        self.n_iter_ += b_global
+        self.sample_n_iter_[sample_indices] += 1
+        w_sample = None
+        if self.G_agg == 'average' or self.Dx_agg == 'average':
+            w_sample = np.power(self.sample_n_iter_[sample_indices].astype(np.float64),
+                                -self.sample_learning_rate).astype(be.dtype)
+        w = batch_weight(self.n_iter_, b_global, self.learning_rate, 0)
+        order = self.random_state.permutation(self.n_components)       # dict_fact.py:672
+        delta = be.phase1(Xh, batch, sample_indices, subset, order, w_sample, w, self.reduction, b_global)
+        if world > 1:
+            self._all_reduce(delta)
+        be.phase2(delta)
+
+    # ---------------------------------------------------------------- pickle
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        be = state.pop('_backend', None)
+        if be is not None and getattr(be, 'Dt', None) is not None:
+            be.synchronize()
+            state['_saved'] = dict(
+                dtype=str(be.dtype), n=be.n, p=be.p, k=be.k, components_=be.get_dictionary(), B_=be.get_B(),
+                C=be.get('C'), code=be.get('code'), comp_norm=be.get('comp_norm'), G=be.get('G'),
+                Dx_average=be.get('Dx_average'), G_average=be.get('G_average'))
+        return state
+
+    def __setstate__(self, state):
+        saved = state.pop('_saved', None)
+        self.__dict__.update(state)
+        if saved is not None:
+            self._backend = be = self._make_backend()
+            be.allocate(self._plan_kwargs(self.batch_size), saved['n'], saved['p'], saved['k'], np.dtype(saved['dtype']))
+            be.set_dictionary(saved['components_'])
+            be.set_B(saved['B_'])
+            for name in ('C', 'code', 'comp_norm', 'G', 'Dx_average', 'G_average'):
+                if saved[name] is not None:
+                    be.set(name, saved[name])
+
+
+class Coder(CodingMixin, BaseEstimator):
+    """Transform-only estimator over a fixed dictionary (dict_fact.py:724-745)."""
+
+    def __init__(self, dictionary, code_alpha=1, code_l1_ratio=1, tol=1e-2, max_iter=100, code_pos=False,
+                 random_state=None, n_threads=1, device=None):
+        self._set_coding_params(dictionary.shape[0], code_l1_ratio=code_l1_ratio, code_alpha=code_alpha,
+                                code_pos=code_pos, random_state=random_state, tol=tol, max_iter=max_iter,
+                                n_threads=n_threads)
+        self.dictionary = dictionary
+        self.device = device
+        D = np.ascontiguousarray(dictionary)
+        if D.dtype not in (np.float32, np.float64):
+            D = D.astype(np.float64)
+        self._backend = be = self._make_backend()
+        be.allocate(self._plan_kwargs(min(4096, 1 << 20)), 1, D.shape[1], D.shape[0], D.dtype)
+        be.set_dictionary(D)
+
+    @property
+    def components_(self):
+        return self._backend.get_dictionary()
+
+    def fit(self, X=None):
+        return self

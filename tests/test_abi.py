@@ -1,0 +1,152 @@
+"""CPU-only checks of the C-ABI boundary: the library loads without a GPU,
+exports every symbol include/modl_hip.h declares, and its host-side entry
+points (RNG, sampler, batch weight) reproduce the reference's draws bit for bit."""
+import ctypes as C
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+from numpy.testing import assert_array_equal
+
+from .conftest import load_golden, ROOT
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from modl_amd import _lib
+    return _lib.lib
+
+
+def test_library_exports_header(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'modl_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    names = set(re.findall(r'\b(modl_[a-z0-9_]+)\s*\(', hdr))
+    assert len(names) > 40
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.modl_abi_version() == 1
+    assert lib.modl_device_count() >= 0
+    assert lib.modl_error_string(-1) == b'invalid argument'
+
+
+def test_no_gpu_is_reported_not_faked(lib):
+    from modl_amd import _lib
+    if lib.modl_device_count() > 0:
+        pytest.skip('GPU present')
+    with pytest.raises(_lib.ModlError):
+        _lib.require_gpu()
+    d = _lib.SomfDesc()
+    d.dtype, d.k, d.p, d.n_samples, d.max_batch, d.max_iter = 0, 4, 8, 10, 2, 10
+    d.code_l1_ratio, d.code_alpha = 1.0, 1.0
+    h = C.c_void_p()
+    assert lib.modl_somf_plan_create(C.byref(d), C.byref(h)) == -4      # MODL_ENOGPU
+
+
+def test_argument_validation(lib):
+    assert lib.modl_rk_create(0, None) == -1
+    assert lib.modl_sampler_create(-1, 1, 1, 0, C.byref(C.c_void_p())) == -1
+    out = C.c_double()
+    assert lib.modl_batch_weight(10, 10, 0.9, 0.0, C.byref(out)) == 0 and out.value == 1.0
+
+
+def test_rng_known_answers_through_abi():
+    # modl/utils/randomkit/tests/test_random.py:10-47
+    from modl_amd.randomkit import RandomState
+    rs = RandomState(seed=0)
+    assert abs(np.mean([rs.randint(10) for _ in range(10000)]) - 5.018) < 1e-12
+    assert abs(np.mean([rs.binomial(1000, 0.8) for _ in range(10000)]) - 799.8564) < 1e-9
+    ind = np.arange(10)
+    rs = RandomState(seed=0)
+    rs.shuffle(ind)
+    assert_array_equal(ind, [2, 8, 4, 9, 1, 6, 7, 3, 0, 5])
+    ind, ind2 = np.arange(10), np.arange(9, -1, -1)
+    rs = RandomState(seed=0)
+    perm = rs.shuffle_with_trace([ind, ind2])
+    assert_array_equal(ind, [2, 8, 4, 9, 1, 6, 7, 3, 0, 5])
+    assert_array_equal(ind2, [7, 1, 5, 0, 8, 3, 2, 6, 9, 4])
+    assert_array_equal(ind, perm)
+    rs = RandomState(seed=0)
+    assert_array_equal(rs.permutation(10), [2, 8, 4, 9, 1, 6, 7, 3, 0, 5])
+    rs = RandomState(seed=0)
+    a = rs.randint(5)
+    assert pickle.loads(pickle.dumps(rs)).randint(5) == a
+
+
+def test_rng_golden_through_abi():
+    from modl_amd.randomkit import RandomState
+    g = load_golden('rng')
+    for a, s in enumerate(g['seeds']):
+        rs = RandomState(int(s))
+        for b, h in enumerate(g['highs']):
+            assert_array_equal([rs.randint(int(h)) for _ in range(8)], g['randint'][a, b])
+    rs = RandomState(7)
+    for rep in range(3):
+        for i, (n, p) in enumerate(zip(g['binom_n'], g['binom_p'])):
+            assert_array_equal([rs.binomial(int(n), float(p)) for _ in range(40)], g['binom_draws'][rep, i])
+    for n in (1, 2, 10, 257, 1000):
+        rs = RandomState(0)
+        x = np.arange(n)
+        rs.shuffle(x)
+        assert_array_equal(x, g['shuffle_%d' % n])
+        assert_array_equal(rs.permutation(n), g['perm_%d' % n])
+    rs = RandomState(3)
+    a, b2 = np.arange(12), np.arange(24, dtype=np.float64).reshape(12, 2)
+    tr = rs.shuffle_with_trace([a, b2])
+    assert_array_equal(tr, g['trace_perm'])
+    assert_array_equal(a, g['trace_a'])
+    assert_array_equal(b2, g['trace_b'])
+
+
+def test_sampler_through_abi():
+    from modl_amd.randomkit import Sampler
+    # modl/utils/randomkit/tests/test_sampler.py:6-45
+    s = Sampler(100, rand_size=True, replacement=True, random_seed=0)
+    assert_array_equal(s.yield_subset(10), [14, 58, 11, 49, 36, 62, 87, 45, 72, 47, 48, 13, 98, 97, 25, 93])
+    assert np.mean([s.yield_subset(10).shape[0] for _ in range(100)]) == 10.19
+    s = Sampler(100, rand_size=False, replacement=False, random_seed=0)
+    assert_array_equal(np.sort(np.concatenate([s.yield_subset(10) for _ in range(10)])), np.arange(100))
+    s = Sampler(100, rand_size=False, replacement=True, random_seed=0)
+    assert_array_equal(s.yield_subset(10), [6, 55, 1, 25, 87, 49, 69, 63, 13, 8])
+    s = Sampler(100, rand_size=True, replacement=False, random_seed=0)
+    A = np.concatenate([s.yield_subset(10) for _ in range(20)])
+    assert_array_equal(np.sort(A[:100]), np.arange(100))
+    g = load_golden('sampler')
+    for i, (rng_, rand_size, repl, red, seed) in enumerate(g['cfg']):
+        s = Sampler(int(rng_), bool(rand_size), bool(repl), int(seed))
+        lens = g['lens_%d' % i]
+        draws = [s.yield_subset(red) for _ in range(len(lens))]
+        assert_array_equal([len(d) for d in draws], lens)
+        assert_array_equal(np.concatenate(draws), g['draws_%d' % i])
+    s = Sampler(300, True, False, 99)
+    dr = [s.yield_subset(r) for r in g['var_red']]
+    assert_array_equal(np.concatenate(dr), g['var_draws'])
+
+
+def test_sampler_state_roundtrip():
+    from modl_amd.randomkit import Sampler
+    s = Sampler(500, True, False, 5)
+    for _ in range(3):
+        s.yield_subset(7)
+    s2 = pickle.loads(pickle.dumps(s))
+    for _ in range(10):
+        assert_array_equal(s.yield_subset(7), s2.yield_subset(7))
+    assert s.lim_sup == s2.lim_sup and np.array_equal(s.box, s2.box)
+
+
+def test_batch_weight_golden():
+    from modl_amd.randomkit import batch_weight
+    g = load_golden('batch_weight')
+    for count, b, lr, off, w in g['cases']:
+        got = batch_weight(int(count), int(b), lr, off)
+        assert got == w or (np.isnan(got) and np.isnan(w))
+
+
+def test_get_sub_slice():
+    # modl/utils/tests/test_utils.py:8-14
+    from modl_amd.utils import get_sub_slice
+    a, b = slice(10, 100), slice(20, 30)
+    assert_array_equal(get_sub_slice(a, b), np.arange(30, 40))
+    assert_array_equal(get_sub_slice(None, b), np.arange(20, 30))
+    assert_array_equal(get_sub_slice(np.arange(10, 100), b), np.arange(30, 40))

@@ -1,0 +1,171 @@
+"""GPU parity of the fine-grained C-ABI entry points (the ones that are 1:1 with
+the reference's Cython functions) against the golden vectors recorded from the
+reference and against the CPU oracle."""
+import numpy as np
+import pytest
+
+from .conftest import load_golden, rel_fro
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.dtype(np.float32): 1e-5, np.dtype(np.float64): 1e-10}
+
+
+@pytest.fixture(scope='module')
+def fast():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    from modl_amd import dict_fact_fast
+    return dict_fact_fast
+
+
+def test_cd_and_ridge_golden(fast):
+    g = load_golden('cd')
+    bad = []
+    for i, row in enumerate(g['meta']):
+        dti, k, p, b, n, l1, alpha, pos, tol, mi = row[:10]
+        dt = np.dtype(np.float32 if dti == 0 else np.float64)
+        tag = '%s_%d' % ('f32' if dti == 0 else 'f64', int(k))
+        G, Gm, Dx0, X = g['G_' + tag], g['Gm_' + tag], g['Dx_' + tag], g['X_' + tag]
+        idx = g['idx_%d' % i]
+        code = g['code_in_%d' % i].copy()
+        fast._enet_regression_single_gram(G, Dx0.copy(), X, code, idx, l1, alpha, bool(pos), tol, int(mi))
+        e1 = rel_fro(code, g['single_code_%d' % i])
+        code = g['code_in_%d' % i].copy()
+        fast._enet_regression_multi_gram(Gm.copy(), Dx0.copy(), X, code, idx, l1, alpha, bool(pos), tol, int(mi))
+        e2 = rel_fro(code, g['multi_code_%d' % i])
+        if not (e1 < TOL[dt] and e2 < TOL[dt]):
+            bad.append((i, tuple(row[:10]), e1, e2))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+@pytest.mark.parametrize('k,b,p', [(256, 64, 300), (70, 20, 150), (300, 9, 64), (5, 3, 7), (1024, 6, 40)])
+def test_cd_vs_oracle_sweeps_and_codes(fast, oracle, dt, k, b, p):
+    """Same number of sweeps per sample as the CPU restatement, codes within tolerance."""
+    rs = np.random.RandomState(k + b)
+    D = rs.randn(k, p).astype(dt)
+    D /= np.sqrt((D ** 2).sum(1))[:, None]
+    X = np.ascontiguousarray(((rs.randn(b, k) * (rs.rand(b, k) < 0.1)).dot(D) + 0.1 * rs.randn(b, p)).astype(dt))
+    G = np.ascontiguousarray(D.dot(D.T).astype(dt))
+    G = (G + G.T) / 2
+    Dx = np.ascontiguousarray(X.dot(D.T).astype(dt))
+    n = b + 3
+    idx = rs.permutation(n)[:b].astype(np.int64)
+    for l1, alpha, pos in ((1.0, 0.3, False), (0.7, 0.1, True)):
+        c_gpu = np.ones((n, k), dtype=dt)
+        c_cpu = np.ones((n, k), dtype=dt)
+        sw_gpu = np.zeros(b, dtype=np.int32)
+        sw_cpu = np.zeros(b, dtype=np.int32)
+        fast._enet_regression_single_gram(G, Dx.copy(), X, c_gpu, idx, l1, alpha, pos, 1e-2, 100, sweeps=sw_gpu)
+        oracle.enet_regression_single_gram(G, Dx.copy(), X, c_cpu, idx, l1, alpha, pos, 1e-2, 100, sweeps=sw_cpu)
+        assert rel_fro(c_gpu, c_cpu) < TOL[np.dtype(dt)], (l1, alpha, pos, sw_gpu, sw_cpu)
+        if dt == np.float64:
+            np.testing.assert_array_equal(sw_gpu, sw_cpu)
+        untouched = np.setdiff1d(np.arange(n), idx)
+        assert np.all(c_gpu[untouched] == 1)
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+@pytest.mark.parametrize('k', [50, 70, 200, 256])
+def test_ridge_vs_oracle(fast, oracle, dt, k):
+    rs = np.random.RandomState(k)
+    b, p = 20, 400
+    D = rs.randn(k, p).astype(dt)
+    X = np.ascontiguousarray(rs.randn(b, p).astype(dt))
+    G = np.ascontiguousarray((D.dot(D.T) / p).astype(dt))
+    G = (G + G.T) / 2
+    Dx = np.ascontiguousarray((X.dot(D.T) / p).astype(dt))
+    Gm = np.ascontiguousarray(np.stack([G * (1 + 0.05 * j) for j in range(b)]).astype(dt))
+    idx = np.arange(b, dtype=np.int64)[::-1].copy()
+    for alpha in (0.1, 1e-3):
+        c1, c2 = np.ones((b, k), dtype=dt), np.ones((b, k), dtype=dt)
+        fast._enet_regression_single_gram(G, Dx.copy(), X, c1, idx, 0.0, alpha, False, 1e-2, 100)
+        oracle.enet_regression_single_gram(G, Dx.copy(), X, c2, idx, 0.0, alpha, False, 1e-2, 100)
+        assert rel_fro(c1, c2) < (2e-4 if dt == np.float32 else 1e-9), (k, alpha)   # f32: cond(G + aI) * eps
+        c1, c2 = np.ones((b, k), dtype=dt), np.ones((b, k), dtype=dt)
+        fast._enet_regression_multi_gram(Gm.copy(), Dx.copy(), X, c1, idx, 0.0, alpha, False, 1e-2, 100)
+        oracle.enet_regression_multi_gram(Gm.copy(), Dx.copy(), X, c2, idx, 0.0, alpha, False, 1e-2, 100)
+        assert rel_fro(c1, c2) < (2e-4 if dt == np.float32 else 1e-9), (k, alpha)
+
+
+def test_update_G_average_golden(fast):
+    g = load_golden('cd')
+    for tag in ('f32_16', 'f32_64', 'f64_16', 'f64_64'):
+        Ga = g['Gm_' + tag].copy()
+        fast._update_G_average(Ga, g['G_' + tag], g['Gavg_w_' + tag])
+        np.testing.assert_allclose(Ga, g['Gavg_out_' + tag], rtol=2e-6 if 'f32' in tag else 1e-14)
+
+
+def test_enet_golden():
+    from modl_amd.enet import enet_norm, enet_projection, enet_scale
+    g = load_golden('enet')
+    bad = []
+    for i, (dti, n, l1, radius, nrm, sc_radius) in enumerate(g['meta']):
+        v = g['v_%d' % i]
+        f32 = dti == 0
+        got = enet_norm(v, l1)
+        if abs(got - nrm) > (1e-5 if f32 else 1e-12) * max(1.0, abs(nrm)):
+            bad.append(('norm', i, got, nrm))
+        out = np.zeros_like(v)
+        enet_projection(v, out, radius, l1)
+        ref = g['proj_%d' % i]
+        if not np.allclose(out, ref, rtol=2e-5 if f32 else 1e-10, atol=2e-6 if f32 else 1e-12):
+            bad.append(('proj', i, n, l1, radius, float(np.abs(out - ref).max())))
+        vs = v.copy()
+        enet_scale(vs, l1, sc_radius)
+        if not np.allclose(vs, g['scaled_%d' % i], rtol=1e-5 if f32 else 1e-11):
+            bad.append(('scale', i))
+    assert not bad, bad[:10]
+
+
+def test_enet_reference_properties():
+    """modl/utils/math/tests/test_enet.py:99-156 (norm of a projection = radius, l2/l1 balls, scale)."""
+    from modl_amd.enet import enet_norm, enet_projection, enet_scale
+    rs = np.random.RandomState(0)
+    norms = np.zeros(10)
+    for i in range(10):
+        a = rs.randn(20000)
+        a /= np.sqrt(np.sum(a ** 2))
+        c = np.zeros(20000)
+        enet_projection(a, c, 1, 0.15)
+        norms[i] = enet_norm(c, l1_ratio=0.15)
+    np.testing.assert_array_almost_equal(norms, np.ones(10))
+    for i in range(10):
+        a = rs.randn(100)
+        c = np.zeros(100)
+        enet_projection(a, c, 2, 0.0)
+        assert abs(np.sqrt(np.sum(c ** 2)) - np.sqrt(2)) < 1e-6
+        b = np.zeros(100)
+        enet_projection(a, b, 1, 1.0)
+        assert abs(np.sum(np.abs(b)) - 1) < 1e-6
+    a = rs.randn(100)
+    for r in (1., 2.):
+        for l1_ratio in (0., 0.5, 1.):
+            enet_scale(a, l1_ratio, r)
+            assert abs(enet_norm(a, l1_ratio) - r) < 1e-6
+    # batched rows
+    A = rs.randn(7, 333)
+    out = np.zeros_like(A)
+    enet_projection(A, out, 0.7, 0.3)
+    np.testing.assert_allclose(enet_norm(out, 0.3), 0.7, rtol=1e-9)
+
+
+def test_predict_csr_matches_dense(oracle):
+    import ctypes as C
+    import scipy.sparse as sp
+    import torch
+    from modl_amd._lib import lib, check
+    rs = np.random.RandomState(0)
+    P, Q = rs.randn(30, 6), rs.randn(6, 17)
+    mask = rs.rand(30, 17) < 0.3
+    X = sp.csr_matrix(mask.astype(np.float64))
+    dev = torch.device('cuda')
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    data, ind, ptr_, dP, dQ = t(np.zeros(X.nnz)), t(X.indices.astype(np.int32)), t(X.indptr.astype(np.int32)), t(P), t(Q)
+    check(lib.modl_predict_csr(C.c_void_p(data.data_ptr()), C.c_void_p(ind.data_ptr()), C.c_void_p(ptr_.data_ptr()),
+                               C.c_void_p(dP.data_ptr()), 30, 6, C.c_void_p(dQ.data_ptr()), 17, None))
+    exp = np.zeros(X.nnz)
+    oracle.predict_csr(exp, X.indices, X.indptr, P, Q)
+    np.testing.assert_allclose(data.cpu().numpy(), exp, rtol=1e-13)
+    np.testing.assert_allclose(exp, P.dot(Q)[mask], rtol=1e-13)

@@ -1,0 +1,253 @@
+"""GPU parity of the fused minibatch step / the estimator against the golden
+trajectories of the reference, the CPU oracle, and the reference's own
+functional tests (modl/decomposition/tests/test_dict_fact.py)."""
+import numpy as np
+import pytest
+from numpy.testing import assert_array_equal
+
+from .conftest import load_golden, rel_fro
+from .test_oracle_golden import small_case_params, synth, _cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def DictFact():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    from modl_amd import DictFact
+    return DictFact
+
+
+class Recorder:
+    """records per-minibatch subsets / codes of a modl_amd.DictFact run"""
+
+    def __init__(self, est):
+        self.est, self.subsets, self.codes = est, [], []
+        smp = est.feature_sampler_
+        rec = self
+
+        class Proxy:
+            def yield_subset(_, r):
+                s = smp.yield_subset(r)
+                rec.subsets.append(s.copy())
+                return s
+        est.feature_sampler_ = Proxy()
+
+
+@pytest.mark.parametrize('name', _cases())
+def test_trajectory_small_golden(DictFact, name):
+    """All aggregation modes / optimizers / atom constraints: the whole fit, against what the
+    reference produced (tests/golden/traj_small.npz)."""
+    g = load_golden('traj_small')
+    kw, X, dt = small_case_params(name)
+    est = DictFact(**kw)
+    est.prepare(n_samples=X.shape[0], X=X)
+    rec = Recorder(est)
+    Xh = X
+    first_codes = None
+    for ep in range(kw['n_epochs']):
+        if ep == 0:
+            # first minibatch alone, to compare its codes
+            est.partial_fit(Xh[:kw['batch_size']], np.arange(kw['batch_size']))
+            first_codes = est.code_[:kw['batch_size']].copy()
+            est.partial_fit(Xh[kw['batch_size']:], np.arange(kw['batch_size'], X.shape[0]))
+        else:
+            est.partial_fit(Xh)
+        perm = est.shuffle()
+        Xh = Xh[perm]
+    assert_array_equal(np.concatenate(rec.subsets), g[name + '/subset'])          # bit-exact draws
+    nb0 = int(g[name + '/code_len'][0])
+    tol = 2e-5 if dt == np.float32 else 1e-9
+    assert rel_fro(first_codes, g[name + '/code'][:nb0]) < tol
+    if dt == np.float64:
+        assert rel_fro(est.components_, g[name + '/D_final']) < tol
+        assert rel_fro(est.C_, g[name + '/C_final']) < tol
+        assert rel_fro(est.B_, g[name + '/B_final']) < tol
+        assert rel_fro(est.code_, g[name + '/code_final']) < tol
+        if (name + '/G_final') in g:
+            assert rel_fro(est.G_, g[name + '/G_final']) < tol
+    else:
+        assert rel_fro(est.components_, g[name + '/D_final']) < 1e-3
+    assert est.n_iter_ == int(g[name + '/n_iter'])
+
+
+def test_config1_golden(DictFact):
+    """BASELINE config 1 on the GPU path (2000 x 500, k = 16, r = 1, f64)."""
+    g = load_golden('traj_c1')
+    X = synth(2000, 500, 16, 0, np.float64)
+    est = DictFact(n_components=16, reduction=1, random_state=0, n_epochs=1, code_alpha=1e-4)
+    est.fit(X)
+    assert rel_fro(est.components_, g['c1/D_final']) < 1e-9
+    assert rel_fro(est.C_, g['c1/C_final']) < 1e-9
+    assert rel_fro(est.code_[:64], g['c1/code_final_head']) < 1e-9
+    assert rel_fro(est.B_[:, :32], g['c1/B_final_head']) < 1e-9
+
+
+def _one_step_pair(DictFact, oracle, dt, n, p, k, b, r, steps=1, seed=0, **extra):
+    rs = np.random.RandomState(seed)
+    k0 = min(k, 32)
+    X = ((rs.randn(n, k0) * (rs.rand(n, k0) < 0.3)).dot(rs.randn(k0, p)) / np.sqrt(0.3 * k0)
+         + 0.1 * rs.randn(n, p)).astype(dt)
+    kw = dict(n_components=k, batch_size=b, reduction=r, code_alpha=1.0, learning_rate=0.92, random_state=0)
+    kw.update(extra)
+    est = DictFact(**kw)
+    est.prepare(n_samples=n, X=X)
+    pr = oracle.SomfParams(**kw)
+    st = oracle.prepare(pr, n_samples=n, X=X)
+    rows = slice(0, steps * b)
+    est.partial_fit(X[rows])
+    oracle.partial_fit(st, pr, X[rows])
+    return est, st
+
+
+@pytest.mark.parametrize('r', [1, 10])
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+def test_headline_shape_step_vs_oracle(DictFact, oracle, dt, r):
+    """The metric's shape (k = 256, b = 256, l1 codes, l2 atoms) at p = 2000 so the CPU oracle
+    finishes in seconds: dictionary and codes after two minibatches within 1e-5 (f32)."""
+    est, st = _one_step_pair(DictFact, oracle, dt, n=600, p=2000, k=256, b=256, r=r, steps=2)
+    tol = 1e-5 if dt == np.float32 else 1e-10
+    eD, eC = rel_fro(est.components_, st.D), rel_fro(est.code_[:512], st.code[:512])
+    eB, eCm = rel_fro(est.B_, st.B), rel_fro(est.C_, st.C)
+    assert eD < tol and eC < tol and eB < tol and eCm < tol, (eD, eC, eB, eCm)
+
+
+@pytest.mark.parametrize('variant', ['fmri', 'nmf', 'enet', 'sgd', 'full', 'average'])
+def test_midsize_variants_vs_oracle(DictFact, oracle, variant):
+    extra = {
+        'fmri': dict(code_l1_ratio=0, comp_l1_ratio=1, code_alpha=1e-2),           # fmri.py:481-495
+        'nmf': dict(comp_pos=True, code_pos=True, code_alpha=0.1),
+        'enet': dict(comp_l1_ratio=0.4, code_l1_ratio=0.6, code_alpha=0.2),
+        'sgd': dict(optimizer='sgd', step_size=0.05, code_alpha=0.2),
+        'full': dict(G_agg='full', Dx_agg='full', code_alpha=0.3),
+        'average': dict(G_agg='average', Dx_agg='average', code_alpha=0.3),
+    }[variant]
+    est, st = _one_step_pair(DictFact, oracle, np.float64, n=200, p=700, k=70, b=20, r=4, steps=5, **extra)
+    eD, eC = rel_fro(est.components_, st.D), rel_fro(est.code_[:100], st.code[:100])
+    assert eD < 1e-9 and eC < 1e-9, (variant, eD, eC)
+    if variant == 'full':
+        assert rel_fro(est.G_, st.G) < 1e-9
+
+
+def test_full_size_step_properties(DictFact):
+    """Size-independent properties at the metric's full shape (k = 256, p = 10000, b = 256, f32)."""
+    import torch
+    k, p, b, n = 256, 10000, 256, 1024
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    Z = torch.randn(n, 64, device='cuda', generator=gen) * (torch.rand(n, 64, device='cuda', generator=gen) < 0.1)
+    X = (Z @ torch.randn(64, p, device='cuda', generator=gen)) / (0.1 * 64) ** 0.5 \
+        + 0.1 * torch.randn(n, p, device='cuda', generator=gen)
+    X = X.float().contiguous()
+    runs = []
+    for rep in range(2):
+        est = DictFact(n_components=k, batch_size=b, reduction=10, code_alpha=1.0, learning_rate=0.92, random_state=0)
+        est.prepare(n_samples=n, X=X[:k])
+        D0 = est.components_
+        rec = Recorder(est)
+        est.partial_fit(X[:2 * b])
+        runs.append((est.components_, est.code_[:2 * b].copy(), est.C_, rec.subsets))
+        D1 = runs[-1][0]
+        touched = np.unique(np.concatenate(rec.subsets))
+        untouched = np.setdiff1d(np.arange(p), touched)
+        assert_array_equal(D1[:, untouched], D0[:, untouched])            # only sampled columns move
+        assert np.any(D1[:, touched] != D0[:, touched])
+        assert np.all(np.sum(D1.astype(np.float64) ** 2, axis=1) <= 1 + 1e-4)    # atoms stay in the l2 ball
+        Cm = runs[-1][2]
+        assert_array_equal(Cm, Cm.T)                                      # bitwise symmetric statistics
+        assert np.all(np.isfinite(D1)) and np.all(np.isfinite(runs[-1][1]))
+    assert_array_equal(runs[0][0], runs[1][0])                            # run-to-run deterministic
+    assert_array_equal(runs[0][1], runs[1][1])
+
+
+# ---- the reference's own functional tests (modl/decomposition/tests/test_dict_fact.py) ----------
+solver_dict = {'masked': {'Dx_agg': 'masked', 'G_agg': 'masked'}, 'gram': {'Dx_agg': 'masked', 'G_agg': 'full'},
+               'average': {'Dx_agg': 'masked', 'G_agg': 'masked'}, 'full': {'Dx_agg': 'full', 'G_agg': 'full'}}
+
+
+def generate_synthetic(n_samples=200, n_components=4, n_features=16, dictionary_rank=None):
+    rng = np.random.RandomState(0)
+    if dictionary_rank is None:
+        Q = rng.randn(n_components, n_features)
+    else:
+        Q = rng.randn(n_components, dictionary_rank).dot(rng.randn(dictionary_rank, n_features)) \
+            if False else None
+        V = np.random.RandomState(0).randn(dictionary_rank, n_features)
+    if dictionary_rank is not None:
+        rng = np.random.RandomState(0)
+        V = rng.randn(dictionary_rank, n_features)
+        U = rng.randn(n_components, dictionary_rank)
+        Q = U.dot(V)
+    code = rng.randn(n_samples, n_components)
+    return code.dot(Q), Q
+
+
+@pytest.mark.parametrize('solver', list(solver_dict))
+def test_ref_reconstruction(DictFact, solver):                              # test_dict_fact.py:55-69
+    X, Q = generate_synthetic()
+    est = DictFact(n_components=4, code_alpha=1e-4, n_epochs=5, comp_l1_ratio=0, random_state=0, reduction=1,
+                   **solver_dict[solver])
+    est.fit(X)
+    Y = est.transform(X).dot(est.components_)
+    assert np.sum((X - Y) ** 2) / np.sum(X ** 2) < 0.02
+
+
+@pytest.mark.parametrize('solver', list(solver_dict))
+def test_ref_reconstruction_reduction_and_reproducible(DictFact, solver):   # test_dict_fact.py:71-112
+    X, Q = generate_synthetic(n_features=20, n_samples=400, dictionary_rank=4)
+    est = DictFact(n_components=4, code_alpha=1e-4, n_epochs=2, comp_l1_ratio=0, random_state=0, reduction=2,
+                   **solver_dict[solver])
+    est.fit(X)
+    D1, P1 = est.components_.copy(), est.transform(X)
+    assert np.sum((X - P1.dot(D1)) ** 2) / np.sum(X ** 2) < 0.02
+    est.random_state = 0
+    est.fit(X)
+    assert_array_equal(D1, est.components_)
+    assert_array_equal(P1, est.transform(X))
+
+
+@pytest.mark.parametrize('solver', list(solver_dict))
+def test_ref_sparse_dict_recovery(DictFact, solver):                        # test_dict_fact.py:135-154
+    rng = np.random.RandomState(0)
+    Q = np.zeros((4, 16))
+    for i in range(2):
+        for j in range(2):
+            atom = np.zeros((4, 4))
+            atom[2 * i:2 * (i + 1), 2 * j:2 * (j + 1)] = 1
+            Q[2 * i + j] = atom.ravel()
+    X = rng.randn(500, 4).dot(Q)
+    rng = np.random.RandomState(0)
+    dict_init = Q + rng.randn(*Q.shape) * 0.2
+    est = DictFact(n_components=4, code_alpha=1e-2, n_epochs=2, code_l1_ratio=0, comp_l1_ratio=1,
+                   dict_init=dict_init, random_state=0, **solver_dict[solver])
+    est.fit(X)
+    Qr = est.components_
+    Qr /= np.sqrt(np.sum(Qr ** 2, axis=1))[:, None]
+    Qn = Q / np.sqrt(np.sum(Q ** 2, axis=1))[:, None]
+    Gm = np.abs(Qr.dot(Qn.T))
+    assert min(np.sum(np.any(Gm > 0.95, axis=1)), np.sum(np.any(Gm > 0.95, axis=0))) >= 4
+
+
+def test_transform_and_score_golden():
+    from modl_amd import Coder
+    g = load_golden('transform')
+    for dn, tol in (('f64', 1e-10), ('f32', 1e-5)):
+        X, D = g['X_' + dn], g['D_' + dn]
+        for l1, alpha, pos in ((1.0, 0.1, False), (0.0, 0.1, False), (0.5, 0.05, True)):
+            cd = Coder(D, code_alpha=alpha, code_l1_ratio=l1, code_pos=pos)
+            key = '%s_%g_%g_%d' % (dn, l1, alpha, pos)
+            assert rel_fro(cd.transform(X), g['code_' + key]) < tol, key
+            assert abs(cd.score(X) - g['score_' + key]) < 1e-5 * abs(g['score_' + key])
+
+
+def test_pickle_roundtrip(DictFact):
+    import pickle
+    X, _ = generate_synthetic(n_features=20, n_samples=100, dictionary_rank=4)
+    est = DictFact(n_components=4, code_alpha=1e-3, random_state=0, reduction=2)
+    est.fit(X)
+    est2 = pickle.loads(pickle.dumps(est))
+    assert_array_equal(est.components_, est2.components_)
+    assert_array_equal(est.code_, est2.code_)
+    est.partial_fit(X[:20])
+    est2.partial_fit(X[:20])
+    assert_array_equal(est.components_, est2.components_)
