@@ -248,6 +248,10 @@ int modl_somf_full_gram(modl_somf_plan *plan, const void *d_Dt, void *d_G, void 
 int modl_somf_transform(modl_somf_plan *plan, const void *d_Dt, const void *d_G, const void *d_X, int64_t ldx,
                         int64_t n, void *d_code_out, void *stream);
 
+/* diagnostics: coordinate-descent sweeps per sample of the last phase-1 call of this plan
+ * (0 for the ridge branch).  Synchronises `stream`. */
+int modl_somf_last_sweeps(modl_somf_plan *plan, int32_t *h_out, int cap, int *n_out, void *stream);
+
 /* layout helpers: out[c][r] = in[r][c]  (components_ <-> Dt) */
 int modl_transpose_f32(const float *d_in, float *d_out, int64_t rows, int64_t cols, void *stream);
 int modl_transpose_f64(const double *d_in, double *d_out, int64_t rows, int64_t cols, void *stream);

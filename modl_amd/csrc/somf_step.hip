@@ -71,7 +71,8 @@ struct modl_somf_plan {
     // device arena
     char *dws = nullptr;
     size_t dws_bytes = 0;
-    size_t off_params, off_xnorm, off_Dx, off_H0, off_G, off_F, off_split, off_du;
+    size_t off_params, off_xnorm, off_Dx, off_H0, off_G, off_F, off_split, off_du, off_sweeps;
+    int last_b = 0;
     size_t split_bytes, du_bytes, params_bytes;
     // per-batch parameter block (device copy of the host arrays), layout within params:
     size_t po_idx, po_subset, po_order, po_wsample;
@@ -269,6 +270,8 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
     T *Gbuf = reinterpret_cast<T *>(pl->dws + pl->off_G);
     T *Fbuf = reinterpret_cast<T *>(pl->dws + pl->off_F);
     SplitWs sws{pl->dws + pl->off_split, pl->split_bytes};
+    int32_t *d_sweeps = reinterpret_cast<int32_t *>(pl->dws + pl->off_sweeps);
+    pl->last_b = b;
     const T red = (T)bt->reduction;
 
     {   // ---- Dx, G  (dict_fact.py:588-620)
@@ -308,11 +311,11 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         ProfScope ps(pl, st, SEC_CODE_SOLVE);
         if (d.G_agg == MODL_AGG_AVERAGE) {                            // per-sample Gram = rows idx of G_average_
             const T *Gavg = static_cast<const T *>(stt->d_G_average);
-            MODL_TRY(solve_codes<T>(pl, st, Gavg, (int64_t)k * k, d_idx, Dx, xnorm, code, d_idx, b, nullptr,
+            MODL_TRY(solve_codes<T>(pl, st, Gavg, (int64_t)k * k, d_idx, Dx, xnorm, code, d_idx, b, d_sweeps,
                                     &ps.launches, H0, Fbuf));
         } else {
             const T *G = (d.G_agg == MODL_AGG_FULL) ? static_cast<const T *>(stt->d_G) : Gbuf;
-            MODL_TRY(solve_codes<T>(pl, st, G, 0, nullptr, Dx, xnorm, code, d_idx, b, nullptr, &ps.launches, H0, Fbuf));
+            MODL_TRY(solve_codes<T>(pl, st, G, 0, nullptr, Dx, xnorm, code, d_idx, b, d_sweeps, &ps.launches, H0, Fbuf));
         }
     }
     {   // ---- statistics increments: delta = [ code^T code | X^T code ]
@@ -516,6 +519,7 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     pl->off_params = take(pl->params_bytes);
     pl->off_xnorm = take(t * b);
+    pl->off_sweeps = take(sizeof(int32_t) * b);
     pl->off_Dx = take(t * b * k);
     pl->off_H0 = take(t * b * k);
     pl->off_G = take(t * k * k);
@@ -609,6 +613,17 @@ int modl_somf_transform(modl_somf_plan *pl, const void *d_Dt, const void *d_G, c
                     transform_impl<double>(pl, static_cast<const double *>(d_Dt), static_cast<const double *>(d_G),
                                            static_cast<const double *>(d_X), ldx, n, static_cast<double *>(d_code_out),
                                            (hipStream_t)stream));
+}
+
+int modl_somf_last_sweeps(modl_somf_plan *pl, int32_t *h_out, int cap, int *n_out, void *stream) {
+    if (!pl || !h_out || !n_out) return MODL_EINVAL;
+    const int n = pl->last_b < cap ? pl->last_b : cap;
+    *n_out = n;
+    if (n <= 0) return MODL_OK;
+    MODL_HIP(hipMemcpyAsync(h_out, pl->dws + pl->off_sweeps, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost,
+                            (hipStream_t)stream));
+    MODL_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return MODL_OK;
 }
 
 int modl_somf_prof_enable(modl_somf_plan *pl, int enable) {

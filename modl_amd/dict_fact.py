@@ -234,6 +234,13 @@ class HipBackend:
                                       stream_ptr(self.device)), 'modl_somf_transform')
         return out.cpu().numpy()
 
+    def last_sweeps(self):
+        out = np.zeros(self._desc_kw['max_batch'], dtype=np.int32)
+        n = C.c_int()
+        check(lib.modl_somf_last_sweeps(self.plan, out.ctypes.data_as(C.c_void_p), out.shape[0], C.byref(n),
+                                        stream_ptr(self.device)))
+        return out[:n.value]
+
     # -- profiling ------------------------------------------------------------
     def prof_enable(self, on=True):
         check(lib.modl_somf_prof_enable(self.plan, int(on)))

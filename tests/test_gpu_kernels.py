@@ -40,7 +40,7 @@ def test_cd_and_ridge_golden(fast):
 
 
 @pytest.mark.parametrize('dt', [np.float32, np.float64])
-@pytest.mark.parametrize('k,b,p', [(256, 64, 300), (70, 20, 150), (300, 9, 64), (5, 3, 7), (1024, 6, 40)])
+@pytest.mark.parametrize('k,b,p', [(256, 64, 300), (70, 20, 150), (300, 9, 400), (5, 3, 7), (1024, 6, 1100)])
 def test_cd_vs_oracle_sweeps_and_codes(fast, oracle, dt, k, b, p):
     """Same number of sweeps per sample as the CPU restatement, codes within tolerance."""
     rs = np.random.RandomState(k + b)
