@@ -34,6 +34,7 @@
 #include "enet_block.hpp"
 #include "gemm.hpp"
 #include "kernels.hpp"
+#include <type_traits>
 
 namespace modl {
 
@@ -49,14 +50,14 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     DuLayout L;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
-    L.nslab_max = cdiv(s_max > 0 ? s_max : 1, kGramRows);
+    L.nslab_max = cdiv(s_max > 0 ? s_max : 1, 32);      // the fused block kernel uses slabs of 32 or 64 rows
     L.nwg_grad = 512;
     L.off_CP = take(tsz * (size_t)k * k);
     L.off_cdiag = take(tsz * (size_t)k);
     L.off_frozen = take(sizeof(int32_t) * (size_t)k);
     L.off_a = take(tsz * (size_t)s_max * kNB);
     L.off_partial = take(sizeof(double) * (size_t)L.nslab_max * (kNB * kNB + kNB));
-    L.off_Tp = take(sizeof(double) * kNB * kNB);
+    L.off_Tp = take(sizeof(double) * (kNB * kNB + kNB));
     L.off_u = take(tsz * (size_t)s_max);
     L.off_pold = take(sizeof(double) * (size_t)L.nwg_grad);
     L.off_Dnew = take(tsz * (size_t)s_max * k);                       // sgd only, but sized once
@@ -144,23 +145,201 @@ __global__ __launch_bounds__(256) void bcd_gram_kernel(const T *a, const T *Dt, 
     }
 }
 
+// ---- fused block kernel (f32): a = (B - D_cur CP) / diag on the matrix cores + partial Gram -------
+// One workgroup owns RB = 32 * RT sampled features and all NB atoms of the block.  Its four
+// wavefronts split the contraction over the k atoms; the dictionary rows are read straight from
+// HBM/L2 into MFMA A-operands (one 16-byte load per lane: 32 rows x 8 consecutive atoms per wave
+// instruction, every 128-byte line of a feature row is consumed by 4 consecutive loads), the k x NB
+// coefficient block sits in LDS.  Partial accumulators are summed across the waves in a fixed order,
+// the epilogue forms a_j, and the NB x NB Gram contribution of these RB features is accumulated in
+// double precision from LDS.
+struct BcdBlockArgs {
+    const float *Dt, *Bt, *CP, *cdiag;
+    const int32_t *frozen, *subset, *order;
+    float *a;
+    double *partial;
+    int64_t s;
+    int k, j0, nb;
+};
+
+template <int RT, int GPW>   // 32 * RT features per workgroup; GPW contraction groups (8 atoms) per wave
+__global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
+    constexpr int RB = 32 * RT;
+    constexpr int KPAD = GPW * 32;                   // 4 waves x GPW groups x 8 atoms  (>= k)
+    constexpr int EPT = RB / 8;                      // epilogue elements per thread
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int k = p.k;
+    float *CPs = reinterpret_cast<float *>(smem_raw);                          // [KPAD][NB]
+    float *red = CPs + (size_t)KPAD * kNB;                                     // [4][RB][NB + 1]
+    float *As = red + 4 * RB * (kNB + 1);                                      // [RB][NB + 1]
+    double *d2red = reinterpret_cast<double *>(As + RB * (kNB + 1) + ((RB * (kNB + 1)) & 1));   // [8][NB]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t f0 = (int64_t)blockIdx.x * RB;
+
+    // epilogue operands of this thread (column = tid % 32, rows tid / 32 + 8 q): issued first so that
+    // they arrive while the coefficient block is staged and the matrix cores run
+    const int col = threadIdx.x % kNB, rg = threadIdx.x / kNB;
+    const bool col_ok = col < p.nb;
+    const int ocol = col_ok ? p.order[p.j0 + col] : 0;
+    const float cdg = col_ok ? p.cdiag[p.j0 + col] : 1.f;
+    const int fz = col_ok ? p.frozen[p.j0 + col] : 0;
+    float eB[EPT], eD[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int64_t f = f0 + rg + 8 * q;
+        const bool ok = col_ok && f < p.s;
+        const int64_t el = ok ? sub_row(p.subset, f) * k + ocol : 0;
+        const float bv = p.Bt[el], dv = p.Dt[el];
+        eB[q] = ok ? bv : 0.f;
+        eD[q] = ok ? dv : 0.f;
+    }
+    // stage the k x NB coefficient block (rows beyond k and columns beyond nb are zero)
+    if (p.nb == kNB) {
+        for (int e = threadIdx.x; e < KPAD * (kNB / 4); e += 256) {
+            const int m = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < k) v = *reinterpret_cast<const float4 *>(p.CP + (int64_t)m * k + p.j0 + c4);
+            *reinterpret_cast<float4 *>(CPs + m * kNB + c4) = v;
+        }
+    } else {
+        for (int e = threadIdx.x; e < KPAD * kNB; e += 256) {
+            const int m = e / kNB, jj = e % kNB;
+            CPs[e] = (m < k && jj < p.nb) ? p.CP[(int64_t)m * k + p.j0 + jj] : 0.f;
+        }
+    }
+    // dictionary rows -> MFMA A operands, all loads of the wave's contraction range in flight at once
+    const int h = lane >> 5;
+    float4 av[GPW][RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        int64_t f = f0 + t * 32 + (lane & 31);
+        if (f >= p.s) f = p.s - 1;                   // clamped: results of padded rows are discarded
+        const float *rowp = p.Dt + sub_row(p.subset, f) * k;
+#pragma unroll
+        for (int g = 0; g < GPW; ++g) {
+            const int kb = (wid * GPW + g) * 8 + 4 * h;
+            const float4 v = *reinterpret_cast<const float4 *>(rowp + (kb + 3 < k ? kb : 0));
+            av[g][t] = (kb + 3 < k) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    f16v acc[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+        const int kb = (wid * GPW + g) * 8 + 4 * h;  // this lane's 4 consecutive atoms
+        const float *bp = CPs + (size_t)kb * kNB + (lane & 31);
+        const float b0 = bp[0], b1 = bp[kNB], b2 = bp[2 * kNB], b3 = bp[3 * kNB];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].x, b0, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].y, b1, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].z, b2, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].w, b3, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, c = lane & 31;
+            red[(wid * RB + row) * (kNB + 1) + c] = acc[t][r];
+        }
+    __syncthreads();
+    double d2 = 0;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int row = rg + 8 * q;
+        const int64_t f = f0 + row;
+        float val = 0.f;
+        if (f < p.s && col_ok) {
+            const float v = ((red[(0 * RB + row) * (kNB + 1) + col] + red[(1 * RB + row) * (kNB + 1) + col]) +
+                             red[(2 * RB + row) * (kNB + 1) + col]) + red[(3 * RB + row) * (kNB + 1) + col];
+            val = fz ? eD[q] : (eB[q] - v) / cdg;
+            p.a[f * kNB + col] = val;
+            d2 += (double)eD[q] * (double)eD[q];
+        }
+        As[row * (kNB + 1) + col] = val;
+    }
+    d2red[rg * kNB + col] = d2;
+    __syncthreads();
+    {   // partial Gram of the a_j over this workgroup's features, and old squared norms
+        const int i = threadIdx.x / 8, jb = (threadIdx.x % 8) * 4;
+        double g4[4] = {0, 0, 0, 0};
+        for (int r = 0; r < RB; ++r) {
+            const double ai = (double)As[r * (kNB + 1) + i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g4[q] += ai * (double)As[r * (kNB + 1) + jb + q];
+        }
+        double *out = p.partial + (int64_t)blockIdx.x * (kNB * kNB + kNB);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[i * kNB + jb + q] = g4[q];
+        if (threadIdx.x < kNB) {
+            double t = 0;
+            for (int gq = 0; gq < 8; ++gq) t += d2red[gq * kNB + threadIdx.x];
+            out[kNB * kNB + threadIdx.x] = t;
+        }
+    }
+}
+
+static size_t bcd_block_lds(int gpw, int RT) {
+    const int kpad = gpw * 32, RB = 32 * RT;
+    size_t fl = (size_t)kpad * kNB + 4 * RB * (kNB + 1) + RB * (kNB + 1) + ((RB * (kNB + 1)) & 1);
+    return fl * 4 + 8 * kNB * sizeof(double) + 16;
+}
+
+// ---- sum of 32 doubles held by one half-wave (lanes 0-31 or 32-63), DPP row operations ----------
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// every lane of a 16-lane row ends with the row's sum
+__device__ __forceinline__ double row16_sum(double x) {
+    x += dpp_move<0xB1>(x);      // quad_perm [1,0,3,2]
+    x += dpp_move<0x4E>(x);      // quad_perm [2,3,0,1]
+    x += dpp_move<0x141>(x);     // row_half_mirror
+    x += dpp_move<0x140>(x);     // row_mirror
+    return x;
+}
+
+// The alpha recursion of one block in wavefront 0.  With u_j = a_j - sum_{i<j} ca_i u_i,
+// ca_i = (C[o_i,o_j] / C[o_j,o_j]) alpha_i, it carries U[j][m] = <u_j, a_m> and V[j][i] = <u_j, u_i>:
+//   U[j][m] = M[j][m] - sum_{i<j} ca_i U[i][m]            (lanes 0..31, lane = m)
+//   V[j][i] = U[i][j] - sum_{i'<j} ca_i' V[i'][i]          (lanes 32..63, lane - 32 = i < j)
+//   |u_j|^2 = U[j][j] - sum_{i<j} ca_i V[j][i]
+// so both half-waves run the same length-j loop on different matrices.  Output: CA[i][j] = ca_i for
+// the apply kernel and alpha[j].
 template <typename T>
-__global__ __launch_bounds__(256) void bcd_resolve_kernel(const double *partial, int nslab, const T *C,
-                                                          const int32_t *order, const int32_t *frozen, int k, int j0,
-                                                          int nb, T *comp_norm, double *Tp) {
+__global__ __launch_bounds__(1024) void bcd_resolve_kernel(const double *partial, int nslab, const T *C,
+                                                           const int32_t *order, const int32_t *frozen, int k, int j0,
+                                                           int nb, T *comp_norm, double *CAout) {
     __shared__ double M[kNB][kNB + 1];
     __shared__ double D2[kNB];
-    __shared__ double Tm[kNB][kNB + 1];
+    __shared__ double Us[kNB][kNB + 1];
+    __shared__ double Vs[kNB][kNB + 1];
     __shared__ double coef[kNB][kNB + 1];
-    __shared__ double alph[kNB];
+    __shared__ double cas[kNB];
     constexpr int kStride = kNB * kNB + kNB;
-    for (int e = threadIdx.x; e < kStride; e += 256) {
-        double sum = 0;
-        for (int z = 0; z < nslab; ++z) sum += partial[(int64_t)z * kStride + e];   // fixed order: deterministic
+    for (int e = threadIdx.x; e < kStride; e += 1024) {
+        double sv[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // fixed association: deterministic
+        int z = 0;
+        for (; z + 8 <= nslab; z += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sv[u] += partial[(int64_t)(z + u) * kStride + e];
+        }
+        for (; z < nslab; ++z) sv[0] += partial[(int64_t)z * kStride + e];
+        const double sum = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
         if (e < kNB * kNB) M[e / kNB][e % kNB] = sum;
         else D2[e - kNB * kNB] = sum;
     }
-    for (int e = threadIdx.x; e < kNB * kNB; e += 256) {
+    for (int e = threadIdx.x; e < kNB * kNB; e += 1024) {
         const int i = e / kNB, j = e % kNB;
         double c = 0;
         if (i < j && j < nb && !frozen[j0 + j]) {
@@ -168,58 +347,79 @@ __global__ __launch_bounds__(256) void bcd_resolve_kernel(const double *partial,
             c = (double)C[(int64_t)oi * k + oj] / (double)C[(int64_t)oj * k + oj];
         }
         coef[i][j] = c;
-        Tm[i][j] = 0;
+        Us[i][j] = 0;
+        Vs[i][j] = 0;
     }
     __syncthreads();
     if (threadIdx.x >= 64) return;                    // the recursion runs in wavefront 0 (no block barrier below)
-    const int m = threadIdx.x;
+    const int x = threadIdx.x & 31, half = threadIdx.x >> 5;
+    const double (*Mat)[kNB + 1] = half ? Vs : Us;
+    double alpha_x = 0;                               // alpha of atom x once known
+    const int jj_x = (x < nb) ? order[j0 + x] : 0;    // the block's atoms and budgets, read once
+    const double cn_x = (x < nb) ? (double)comp_norm[jj_x] : 0.0;
     for (int j = 0; j < nb; ++j) {
-        double t = 0;
-        if (m < kNB) {
-            t = (m == j) ? 1.0 : 0.0;
-            for (int i = m; i < j; ++i) t -= coef[i][j] * alph[i] * Tm[i][m];
-            Tm[j][m] = t;
-        }
+        // ca_i for this j
+        if (half == 0) cas[x] = (x < j) ? coef[x][j] * alpha_x : 0.0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        double v = 0;
-        if (m <= j)
-            for (int m2 = 0; m2 <= j; ++m2) v += M[m2][m] * Tm[j][m2];
-        const double nrm = wave_sum(t * v);
-        const int jj = order[j0 + j];
-        const double radius = (double)comp_norm[jj] + D2[j];
+        double acc0 = half ? Us[x][j] : M[j][x], acc1 = 0, acc2 = 0, acc3 = 0;
+        int i = 0;
+        for (; i + 4 <= j; i += 4) {
+            acc0 -= cas[i] * Mat[i][x];
+            acc1 -= cas[i + 1] * Mat[i + 1][x];
+            acc2 -= cas[i + 2] * Mat[i + 2][x];
+            acc3 -= cas[i + 3] * Mat[i + 3][x];
+        }
+        for (; i < j; ++i) acc0 -= cas[i] * Mat[i][x];
+        const double val = (acc0 + acc1) + (acc2 + acc3);          // U[j][x] (half 0) or V[j][x] (half 1, x < j)
+        double prod = (half == 1 && x < j) ? cas[x] * val : 0.0;
+        prod = row16_sum(prod);
+        const double vsum = bcast_lane(prod, 32) + bcast_lane(prod, 48);
+        const double ujj = bcast_lane(val, j);                       // lane j of half 0 holds U[j][j]
+        const double nrm = ujj - vsum;
+        const double radius = bcast_lane(cn_x, j) + D2[j];
         double al;
         if (!(radius > 0.0)) al = 0.0;                // enet.pyx:57 (radius == 0 -> zero atom)
         else if (nrm <= radius) al = 1.0;             // enet.pyx:65
         else al = 1.0 / sqrt(nrm / radius);
-        if (m == 0) {
-            alph[j] = al;
-            comp_norm[jj] = (T)(radius - al * al * nrm);
+        if (half == 0) {
+            Us[j][x] = val;
+        } else {
+            if (x < j) { Vs[j][x] = val; Vs[x][j] = val; }
+            if (x == j) Vs[j][j] = nrm;
         }
+        if (x == j) alpha_x = al;
+        if (threadIdx.x == j) comp_norm[jj_x] = (T)(radius - al * al * nrm);
+        if (half == 0) CAout[j * kNB + x] = cas[x];    // row j: ca_i (i < j), zero beyond
+        if (threadIdx.x == j) CAout[kNB * kNB + j] = al;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    if (m < kNB)
-        for (int j = 0; j < kNB; ++j) Tp[j * kNB + m] = (j < nb) ? alph[j] * Tm[j][m] : 0.0;
+    if (half == 0 && x >= nb) CAout[kNB * kNB + x] = 0.0;
 }
 
+// D_new[f][o_j] = alpha_j u_j[f],  u_j = a_j - sum_{i<j} ca_ij u_i   (one thread per sampled feature)
 template <typename T>
-__global__ __launch_bounds__(256) void bcd_apply_kernel(const T *a, const double *Tp, T *Dt, const int32_t *subset,
-                                                        const int32_t *order, int64_t s, int k, int j0, int nb) {
-    __shared__ T As[64][kNB + 1];
-    __shared__ double Ts[kNB][kNB + 1];
-    const int64_t f0 = (int64_t)blockIdx.x * 64;
-    for (int e = threadIdx.x; e < 64 * kNB; e += 256) {
-        const int r = e / kNB, c = e % kNB;
-        As[r][c] = (f0 + r < s) ? a[(f0 + r) * kNB + c] : (T)0;
-    }
-    for (int e = threadIdx.x; e < kNB * kNB; e += 256) Ts[e / kNB][e % kNB] = Tp[e];
+__global__ __launch_bounds__(256) void bcd_apply_kernel(const T *a, const double *__restrict__ CA, T *Dt,
+                                                        const int32_t *subset, const int32_t *order, int64_t s, int k,
+                                                        int j0, int nb) {
+    __shared__ double CAs[kNB * kNB + kNB];
+    for (int e = threadIdx.x; e < kNB * kNB + kNB; e += 256) CAs[e] = CA[e];
     __syncthreads();
-    const int r = threadIdx.x / 4, jg = threadIdx.x % 4;
-    if (f0 + r >= s) return;
-    T *row = Dt + sub_row(subset, f0 + r) * k;
-    for (int j = jg; j < nb; j += 4) {
-        double acc = 0;
-        for (int m = 0; m <= j; ++m) acc += Ts[j][m] * (double)As[r][m];
-        row[order[j0 + j]] = (T)acc;
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= s) return;
+    double u[kNB];
+    const T *ar = a + f * kNB;
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) u[j] = (double)ar[j];
+    T *row = Dt + sub_row(subset, f) * k;
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) {
+        if (j < nb) {
+            double v = u[j];
+#pragma unroll
+            for (int i = 0; i < j; ++i) v -= CAs[j * kNB + i] * u[i];
+            u[j] = v;
+            row[order[j0 + j]] = (T)(CAs[kNB * kNB + j] * v);
+        }
     }
 }
 
@@ -361,25 +561,47 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                            a.order, k, CP, cdiag, frozen);
         MODL_LAUNCH_CHECK();
         ++nl;
-        const int nslab = (int)cdiv(s, kGramRows);
+        const bool fused = std::is_same<T, float>::value && (k % 4 == 0) && k <= 512;
+        const int RT = (s <= 2048) ? 1 : 2;
+        const int nslab = fused ? (int)cdiv(s, 32 * RT) : (int)cdiv(s, kGramRows);
+        const int GPW = (k <= 256) ? 8 : 16;
+        void (*blk)(BcdBlockArgs) = nullptr;
+        if (fused) {
+            blk = (RT == 1) ? (GPW == 8 ? bcd_block_kernel<1, 8> : bcd_block_kernel<1, 16>)
+                            : (GPW == 8 ? bcd_block_kernel<2, 8> : bcd_block_kernel<2, 16>);
+            MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(blk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024));
+        }
         for (int j0 = 0; j0 < k; j0 += kNB) {
             const int nb = (k - j0 < kNB) ? k - j0 : kNB;
-            Operand A, B;
-            A.ptr = a.Dt; A.si = k; A.sk = 1; A.gi = gather32(a.subset);
-            B.ptr = CP + j0; B.si = 1; B.sk = k;         // B(n = jj, kk = m) = CP[m][j0 + jj]
-            EpiBcdA<T> epi{abuf, a.Dt, a.Bt, cdiag, frozen, a.subset, a.order, k, j0};
-            SplitWs none;
-            MODL_TRY((launch_gemm<T, EpiBcdA<T>>(stream, A, B, s, nb, k, epi, none, &nl, 512, 1)));
-            hipLaunchKernelGGL((bcd_gram_kernel<T>), dim3(nslab), dim3(256), 0, stream, abuf, a.Dt, a.subset, a.order,
-                               s, k, j0, nb, partial);
-            MODL_LAUNCH_CHECK();
-            hipLaunchKernelGGL((bcd_resolve_kernel<T>), dim3(1), dim3(256), 0, stream, partial, nslab, a.C, a.order,
+            if (fused) {
+                BcdBlockArgs ba;
+                ba.Dt = reinterpret_cast<const float *>(a.Dt); ba.Bt = reinterpret_cast<const float *>(a.Bt);
+                ba.CP = reinterpret_cast<const float *>(CP); ba.cdiag = reinterpret_cast<const float *>(cdiag);
+                ba.frozen = frozen; ba.subset = a.subset; ba.order = a.order;
+                ba.a = reinterpret_cast<float *>(abuf); ba.partial = partial; ba.s = s; ba.k = k; ba.j0 = j0; ba.nb = nb;
+                hipLaunchKernelGGL(blk, dim3(nslab), dim3(256), bcd_block_lds(GPW, RT), stream, ba);
+                MODL_LAUNCH_CHECK();
+                ++nl;
+            } else {
+                Operand A, B;
+                A.ptr = a.Dt; A.si = k; A.sk = 1; A.gi = gather32(a.subset);
+                B.ptr = CP + j0; B.si = 1; B.sk = k;         // B(n = jj, kk = m) = CP[m][j0 + jj]
+                EpiBcdA<T> epi{abuf, a.Dt, a.Bt, cdiag, frozen, a.subset, a.order, k, j0};
+                SplitWs none;
+                MODL_TRY((launch_gemm<T, EpiBcdA<T>>(stream, A, B, s, nb, k, epi, none, &nl, 512, 1)));
+                hipLaunchKernelGGL((bcd_gram_kernel<T>), dim3(nslab), dim3(256), 0, stream, abuf, a.Dt, a.subset,
+                                   a.order, s, k, j0, nb, partial);
+                MODL_LAUNCH_CHECK();
+                ++nl;
+            }
+            hipLaunchKernelGGL((bcd_resolve_kernel<T>), dim3(1), dim3(1024), 0, stream, partial, nslab, a.C, a.order,
                                frozen, k, j0, nb, a.comp_norm, Tp);
             MODL_LAUNCH_CHECK();
-            hipLaunchKernelGGL((bcd_apply_kernel<T>), dim3((unsigned)cdiv(s, 64)), dim3(256), 0, stream, abuf, Tp, a.Dt,
+            hipLaunchKernelGGL((bcd_apply_kernel<T>), dim3((unsigned)cdiv(s, 256)), dim3(256), 0, stream, abuf, Tp, a.Dt,
                                a.subset, a.order, s, k, j0, nb);
             MODL_LAUNCH_CHECK();
-            nl += 3;
+            nl += 2;
         }
     } else {
         return dict_update_generic<T>(stream, a, launches);

@@ -20,60 +20,67 @@
 
 namespace modl {
 
-template <typename T, int KPL>
-__device__ __forceinline__ void load_row(const T *__restrict__ row, int k, int lane, T (&r)[KPL], bool vec_ok) {
-    const int e0 = lane * KPL;
-    if (vec_ok) {
-        if (e0 < k) {
-            constexpr int kAlign = (KPL * sizeof(T) >= 16) ? 16 : (int)(KPL * sizeof(T));
-            const T *p = static_cast<const T *>(__builtin_assume_aligned(row + e0, kAlign));
+// Row loader: KPL consecutive coefficients per lane.  VEC = rows are KPL-aligned (k % KPL == 0 and
+// an aligned base): one 16-byte load per lane at k = 256.  No branches: lanes past the end read a
+// clamped address and select zero, so the loads of a chunk stay in flight together.
+template <typename T, int KPL, bool VEC>
+__device__ __forceinline__ void load_row(const T *__restrict__ row, int k, int lane, int n_li, T (&r)[KPL]) {
+    if constexpr (VEC) {
+        const int lc = lane < n_li ? lane : n_li - 1;
+        constexpr int kAlign = (KPL * sizeof(T) >= 16) ? 16 : (int)(KPL * sizeof(T));
+        const T *p = static_cast<const T *>(__builtin_assume_aligned(row + lc * KPL, kAlign));
 #pragma unroll
-            for (int c = 0; c < KPL; ++c) r[c] = p[c];
-        } else {
+        for (int c = 0; c < KPL; ++c) r[c] = p[c];
+        if (lane >= n_li) {
 #pragma unroll
             for (int c = 0; c < KPL; ++c) r[c] = 0;
         }
     } else {
+        const int e0 = lane * KPL;
 #pragma unroll
-        for (int c = 0; c < KPL; ++c) r[c] = (e0 + c < k) ? row[e0 + c] : (T)0;
+        for (int c = 0; c < KPL; ++c) {
+            const int e = e0 + c;
+            const T v = row[e < k ? e : k - 1];
+            r[c] = e < k ? v : (T)0;
+        }
     }
 }
 
+// One coordinate (dict_fact_fast.pyx:354-386).  All scalars are wave-uniform (v_readlane);
+// the H update is unconditional: with a zero coefficient the fused multiply-add returns H.
 template <typename T, int KPL, int C>
 __device__ __forceinline__ void cd_coordinate(int li, int lane, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
-                                              const T (&dg)[KPL], const T (&row)[KPL], T alpha, T beta,
+                                              const T (&dg)[KPL], const T (&inv)[KPL], const T (&row)[KPL], T alpha,
                                               bool positive, T &w_max, T &d_w_max) {
     const T Qii = bcast_lane(dg[C], li);
-    if (Qii == (T)0) return;                                  // dict_fact_fast.pyx:357
+    const T rinv = bcast_lane(inv[C], li);
     const T w_ii = bcast_lane(w[C], li);
-    T Hii = bcast_lane(H[C], li);
     const T qii = bcast_lane(q[C], li);
+    T Hii = bcast_lane(H[C], li);
     Hii = fma(-w_ii, Qii, Hii);                               // H[ii] after "H -= w_ii * Q[ii]" (:361-365)
     const T tmp = qii - Hii;                                  // :367
-    T wn;
-    if (positive && tmp < (T)0) {
-        wn = 0;
-    } else {                                                  // :372 soft threshold
-        T mag = fabs(tmp) - alpha;
-        mag = mag > (T)0 ? mag : (T)0;
-        const T sg = (tmp > (T)0) ? (T)1 : ((tmp < (T)0) ? (T)-1 : (T)0);
-        wn = sg * mag / (Qii + beta);
-    }
-    if (w_ii != (T)0 || wn != (T)0) {                         // the two axpys of :361-365 and :375-378
+    T mag = fabs(tmp) - alpha;                                // :372 soft threshold
+    mag = mag > (T)0 ? mag : (T)0;
+    T wn = copysign(mag * rinv, tmp);
+    if (positive && tmp < (T)0) wn = 0;
+    if (Qii == (T)0) wn = w_ii;                               // :357 coordinate skipped (rinv = 0 there)
+    const T dwn = (Qii == (T)0) ? (T)0 : wn;                  // a skipped coordinate leaves H untouched
+    const T dwo = (Qii == (T)0) ? (T)0 : w_ii;
 #pragma unroll
-        for (int c = 0; c < KPL; ++c) H[c] = fma(wn, row[c], fma(-w_ii, row[c], H[c]));
-    }
+    for (int c = 0; c < KPL; ++c) H[c] = fma(dwn, row[c], fma(-dwo, row[c], H[c]));   // :361-365, :375-378
     if (lane == li) w[C] = wn;
-    const T d = fabs(wn - w_ii);
-    d_w_max = d > d_w_max ? d : d_w_max;
-    const T aw = fabs(wn);
-    w_max = aw > w_max ? aw : w_max;
+    if (Qii != (T)0) {
+        const T d = fabs(wn - w_ii);
+        d_w_max = d > d_w_max ? d : d_w_max;
+        const T aw = fabs(wn);
+        w_max = aw > w_max ? aw : w_max;
+    }
 }
 
-template <typename T, int KPL, int PG, int C0>
+template <typename T, int KPL, int PG, int C0, bool VEC>
 __device__ __forceinline__ void cd_chunk(int li, int n_li, int lane, int k, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
-                                         const T (&dg)[KPL], T (&cur)[PG][KPL], T (&nxt)[PG][KPL],
-                                         const T *__restrict__ Q, bool vec_ok, T alpha, T beta, bool positive,
+                                         const T (&dg)[KPL], const T (&inv)[KPL], T (&cur)[PG][KPL],
+                                         T (&nxt)[PG][KPL], const T *__restrict__ Q, T alpha, bool positive,
                                          T &w_max, T &d_w_max) {
     const int ii0 = li * KPL + C0;
     // prefetch the rows of the next chunk (wraps to row 0 for the next sweep)
@@ -82,15 +89,25 @@ __device__ __forceinline__ void cd_chunk(int li, int n_li, int lane, int k, T (&
 #pragma unroll
     for (int j = 0; j < PG; ++j) {
         const int rn = (nxt0 + j < k) ? nxt0 + j : 0;
-        load_row<T, KPL>(Q + (int64_t)rn * k, k, lane, nxt[j], vec_ok);
+        load_row<T, KPL, VEC>(Q + (int64_t)rn * k, k, lane, n_li, nxt[j]);
     }
-    if (ii0 + 0 < k) cd_coordinate<T, KPL, C0 + 0>(li, lane, w, H, q, dg, cur[0], alpha, beta, positive, w_max, d_w_max);
-    if constexpr (PG > 1) {
-        if (ii0 + 1 < k) cd_coordinate<T, KPL, C0 + 1>(li, lane, w, H, q, dg, cur[1], alpha, beta, positive, w_max, d_w_max);
-    }
-    if constexpr (PG > 2) {
-        if (ii0 + 2 < k) cd_coordinate<T, KPL, C0 + 2>(li, lane, w, H, q, dg, cur[2], alpha, beta, positive, w_max, d_w_max);
-        if (ii0 + 3 < k) cd_coordinate<T, KPL, C0 + 3>(li, lane, w, H, q, dg, cur[3], alpha, beta, positive, w_max, d_w_max);
+    if (ii0 + PG <= k) {
+        cd_coordinate<T, KPL, C0 + 0>(li, lane, w, H, q, dg, inv, cur[0], alpha, positive, w_max, d_w_max);
+        if constexpr (PG > 1)
+            cd_coordinate<T, KPL, C0 + 1>(li, lane, w, H, q, dg, inv, cur[1], alpha, positive, w_max, d_w_max);
+        if constexpr (PG > 2) {
+            cd_coordinate<T, KPL, C0 + 2>(li, lane, w, H, q, dg, inv, cur[2], alpha, positive, w_max, d_w_max);
+            cd_coordinate<T, KPL, C0 + 3>(li, lane, w, H, q, dg, inv, cur[3], alpha, positive, w_max, d_w_max);
+        }
+    } else {                                                   // ragged tail of the last lane
+        if (ii0 + 0 < k) cd_coordinate<T, KPL, C0 + 0>(li, lane, w, H, q, dg, inv, cur[0], alpha, positive, w_max, d_w_max);
+        if constexpr (PG > 1) {
+            if (ii0 + 1 < k) cd_coordinate<T, KPL, C0 + 1>(li, lane, w, H, q, dg, inv, cur[1], alpha, positive, w_max, d_w_max);
+        }
+        if constexpr (PG > 2) {
+            if (ii0 + 2 < k) cd_coordinate<T, KPL, C0 + 2>(li, lane, w, H, q, dg, inv, cur[2], alpha, positive, w_max, d_w_max);
+            if (ii0 + 3 < k) cd_coordinate<T, KPL, C0 + 3>(li, lane, w, H, q, dg, inv, cur[3], alpha, positive, w_max, d_w_max);
+        }
     }
 #pragma unroll
     for (int j = 0; j < PG; ++j)
@@ -98,7 +115,7 @@ __device__ __forceinline__ void cd_chunk(int li, int n_li, int lane, int k, T (&
         for (int c = 0; c < KPL; ++c) cur[j][c] = nxt[j][c];
 }
 
-template <typename T, int KPL>
+template <typename T, int KPL, bool VEC>
 __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
     constexpr int PG = (KPL >= 4) ? 4 : KPL;     // rows per prefetch chunk
     const int lane = threadIdx.x & 63;
@@ -109,30 +126,34 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
     const int64_t row_out = a.idx ? a.idx[smp] : (int64_t)smp;
     T *wptr = a.code + row_out * k;
     const T *qptr = a.Dx + (int64_t)smp * k;
-    constexpr int kRowAlign = (KPL * sizeof(T) >= 16) ? 16 : (int)(KPL * sizeof(T));
-    const bool vec_ok = (k % KPL == 0) && ((reinterpret_cast<uintptr_t>(Q) % kRowAlign) == 0);
     const int e0 = lane * KPL;
     const int n_li = (k + KPL - 1) / KPL;          // lanes that own coefficients
+    const T alpha = a.alpha, beta = a.beta;
+    const bool positive = a.positive != 0;
 
-    T w[KPL], H[KPL], q[KPL], dg[KPL];
+    T w[KPL], H[KPL], q[KPL], dg[KPL], inv[KPL];
 #pragma unroll
     for (int c = 0; c < KPL; ++c) {
         const bool in = e0 + c < k;
-        w[c] = in ? wptr[e0 + c] : (T)0;
-        q[c] = in ? qptr[e0 + c] : (T)0;
-        dg[c] = in ? Q[(int64_t)(e0 + c) * k + (e0 + c)] : (T)0;
+        const int e = in ? e0 + c : 0;
+        const T wv = wptr[e], qv = qptr[e], dv = Q[(int64_t)e * k + e];
+        w[c] = in ? wv : (T)0;
+        q[c] = in ? qv : (T)0;
+        dg[c] = in ? dv : (T)0;
+        inv[c] = (dg[c] != (T)0) ? (T)1 / (dg[c] + beta) : (T)0;   // reciprocal of the step denominator (:373)
         H[c] = 0;
     }
     const T y_norm2 = a.xnorm2[smp];
     const T tol_abs = a.tol * y_norm2;             // :336
     const T d_w_tol = a.tol;
-    const T alpha = a.alpha, beta = a.beta;
-    const bool positive = a.positive != 0;
 
     if (a.H0) {
         const T *hp = a.H0 + (int64_t)smp * k;
 #pragma unroll
-        for (int c = 0; c < KPL; ++c) H[c] = (e0 + c < k) ? hp[e0 + c] : (T)0;
+        for (int c = 0; c < KPL; ++c) {
+            const T hv = hp[e0 + c < k ? e0 + c : 0];
+            H[c] = (e0 + c < k) ? hv : (T)0;
+        }
     } else {
         // H = Q w as a combination of rows (Q is symmetric, as the solver itself assumes)
         for (int li = 0; li < n_li; ++li) {
@@ -140,30 +161,28 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
             for (int c = 0; c < KPL; ++c) {
                 const int j = li * KPL + c;
                 const T wj = (j < k) ? bcast_lane(w[c], li) : (T)0;
-                if (wj != (T)0) {
-                    T r[KPL];
-                    load_row<T, KPL>(Q + (int64_t)j * k, k, lane, r, vec_ok);
+                T r[KPL];
+                load_row<T, KPL, VEC>(Q + (int64_t)(j < k ? j : 0) * k, k, lane, n_li, r);
 #pragma unroll
-                    for (int c2 = 0; c2 < KPL; ++c2) H[c2] = fma(wj, r[c2], H[c2]);
-                }
+                for (int c2 = 0; c2 < KPL; ++c2) H[c2] = fma(wj, r[c2], H[c2]);
             }
         }
     }
 
     T cur[PG][KPL], nxt[PG][KPL];
 #pragma unroll
-    for (int j = 0; j < PG; ++j) load_row<T, KPL>(Q + (int64_t)(j < k ? j : 0) * k, k, lane, cur[j], vec_ok);
+    for (int j = 0; j < PG; ++j) load_row<T, KPL, VEC>(Q + (int64_t)(j < k ? j : 0) * k, k, lane, n_li, cur[j]);
 
     int n_iter = 0;
     for (; n_iter < a.max_iter; ++n_iter) {
         T w_max = 0, d_w_max = 0;
         for (int li = 0; li < n_li; ++li) {
-            cd_chunk<T, KPL, PG, 0>(li, n_li, lane, k, w, H, q, dg, cur, nxt, Q, vec_ok, alpha, beta, positive, w_max, d_w_max);
+            cd_chunk<T, KPL, PG, 0, VEC>(li, n_li, lane, k, w, H, q, dg, inv, cur, nxt, Q, alpha, positive, w_max, d_w_max);
             if constexpr (KPL > 4)
-                cd_chunk<T, KPL, PG, 4>(li, n_li, lane, k, w, H, q, dg, cur, nxt, Q, vec_ok, alpha, beta, positive, w_max, d_w_max);
+                cd_chunk<T, KPL, PG, 4, VEC>(li, n_li, lane, k, w, H, q, dg, inv, cur, nxt, Q, alpha, positive, w_max, d_w_max);
             if constexpr (KPL > 8) {
-                cd_chunk<T, KPL, PG, 8>(li, n_li, lane, k, w, H, q, dg, cur, nxt, Q, vec_ok, alpha, beta, positive, w_max, d_w_max);
-                cd_chunk<T, KPL, PG, 12>(li, n_li, lane, k, w, H, q, dg, cur, nxt, Q, vec_ok, alpha, beta, positive, w_max, d_w_max);
+                cd_chunk<T, KPL, PG, 8, VEC>(li, n_li, lane, k, w, H, q, dg, inv, cur, nxt, Q, alpha, positive, w_max, d_w_max);
+                cd_chunk<T, KPL, PG, 12, VEC>(li, n_li, lane, k, w, H, q, dg, inv, cur, nxt, Q, alpha, positive, w_max, d_w_max);
             }
         }
         if (w_max == (T)0 || d_w_max / w_max < d_w_tol || n_iter == a.max_iter - 1) {   // :388
@@ -207,16 +226,25 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
     if (a.sweeps && lane == 0) a.sweeps[smp] = n_iter;
 }
 
+template <typename T, int KPL>
+static void launch_cd_kpl(hipStream_t stream, const CdArgs<T> &a, dim3 grid, dim3 block) {
+    constexpr size_t kRowAlign = (KPL * sizeof(T) >= 16) ? 16 : KPL * sizeof(T);
+    const bool vec = (a.k % KPL == 0) && (reinterpret_cast<uintptr_t>(a.G) % kRowAlign == 0) &&
+                     ((a.g_stride * sizeof(T)) % kRowAlign == 0) && (((size_t)a.k * sizeof(T)) % kRowAlign == 0);
+    if (vec) hipLaunchKernelGGL((cd_kernel<T, KPL, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((cd_kernel<T, KPL, false>), grid, block, 0, stream, a);
+}
+
 template <typename T>
 int launch_cd(hipStream_t stream, const CdArgs<T> &a) {
     if (a.b <= 0 || a.k <= 0) return MODL_OK;
     if (a.k > 1024) return MODL_EINVAL;
     dim3 grid((unsigned)cdiv(a.b, 4)), block(256);
-    if (a.k <= 64) hipLaunchKernelGGL((cd_kernel<T, 1>), grid, block, 0, stream, a);
-    else if (a.k <= 128) hipLaunchKernelGGL((cd_kernel<T, 2>), grid, block, 0, stream, a);
-    else if (a.k <= 256) hipLaunchKernelGGL((cd_kernel<T, 4>), grid, block, 0, stream, a);
-    else if (a.k <= 512) hipLaunchKernelGGL((cd_kernel<T, 8>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((cd_kernel<T, 16>), grid, block, 0, stream, a);
+    if (a.k <= 64) launch_cd_kpl<T, 1>(stream, a, grid, block);
+    else if (a.k <= 128) launch_cd_kpl<T, 2>(stream, a, grid, block);
+    else if (a.k <= 256) launch_cd_kpl<T, 4>(stream, a, grid, block);
+    else if (a.k <= 512) launch_cd_kpl<T, 8>(stream, a, grid, block);
+    else launch_cd_kpl<T, 16>(stream, a, grid, block);
     MODL_LAUNCH_CHECK();
     return MODL_OK;
 }

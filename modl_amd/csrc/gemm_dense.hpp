@@ -1,0 +1,247 @@
+// Dense, software-pipelined matrix-core contraction (no gathers):
+//
+//   out(m, n) = epilogue( sum_kk A(m, kk) * B(n, kk) ),   X(i, kk) = ptr[i * si + kk * sk], si == 1 or sk == 1
+//
+// This is the fast path of the SOMF step: the step first compacts what it
+// gathers (sampled dictionary rows, sampled columns of the minibatch, the
+// minibatch's code rows), then every product is a plain strided GEMM.
+//
+// gfx950 mapping: 64x64 block tile, BK = 32, 4 wavefronts (2x2) each owning one
+// 32x32 v_mfma_f32_32x32x2_f32 tile (f64: 2x2 v_mfma_f64_16x16x4_f64 tiles).
+// Global -> register -> LDS staging with 16-byte loads along the contiguous
+// dimension; the loads of K-tile t+1 are issued before the MFMA loop of tile t
+// and written to the other LDS buffer afterwards (one barrier per K-tile).
+// Operands are k-major in LDS (row stride BI + 4: 16-byte aligned vector stores,
+// conflict-free fragment reads).  Split-K partial tiles are reduced in a fixed
+// order (gemm_reduce_kernel) -> deterministic results.
+#pragma once
+#include "gemm.hpp"
+
+namespace modl {
+
+struct DenseOperand {
+    const void *ptr = nullptr;
+    int64_t si = 0, sk = 0;
+};
+
+template <typename T> struct Vec4;   // 16-byte vector of T
+template <> struct Vec4<float> { typedef float4 type; static constexpr int N = 4; };
+template <> struct Vec4<double> { typedef double2 type; static constexpr int N = 2; };
+
+// Stage one BI x BK operand tile global -> registers (16-byte vectors along the contiguous dim).
+// NV vectors per thread.  FAST = tile fully inside the matrix; otherwise element-wise guarded.
+template <typename T, int BI, int BK, bool IFAST>
+struct TileLoader {
+    static constexpr int VN = Vec4<T>::N;
+    static constexpr int NV = BI * BK / VN / 256;
+    typedef typename Vec4<T>::type V;
+    V r[NV];
+
+    __device__ __forceinline__ void load(const DenseOperand &op, int64_t i0, int64_t I, int64_t k0, int64_t k_end) {
+        const T *base = static_cast<const T *>(op.ptr);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            int il, kl;
+            if (IFAST) { il = (e % (BI / VN)) * VN; kl = e / (BI / VN); }
+            else { kl = (e % (BK / VN)) * VN; il = e / (BK / VN); }
+            const int64_t i = i0 + il, kk = k0 + kl;
+            const T *p = base + i * op.si + kk * op.sk;
+            const bool full = IFAST ? (i + VN <= I && kk < k_end) : (i < I && kk + VN <= k_end);
+            if (full) {
+                r[q] = *reinterpret_cast<const V *>(p);
+            } else {
+                T t[VN];
+#pragma unroll
+                for (int c = 0; c < VN; ++c) {
+                    const bool in = IFAST ? (i + c < I && kk < k_end) : (i < I && kk + c < k_end);
+                    t[c] = in ? p[c] : (T)0;
+                }
+                V v;
+                T *vp = reinterpret_cast<T *>(&v);
+#pragma unroll
+                for (int c = 0; c < VN; ++c) vp[c] = t[c];
+                r[q] = v;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(T (*S)[BI + 4]) const {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            if (IFAST) {
+                const int il = (e % (BI / VN)) * VN, kl = e / (BI / VN);
+                *reinterpret_cast<V *>(&S[kl][il]) = r[q];
+            } else {
+                const int kl = (e % (BK / VN)) * VN, il = e / (BK / VN);
+                const T *t = reinterpret_cast<const T *>(&r[q]);
+#pragma unroll
+                for (int c = 0; c < VN; ++c) S[kl + c][il] = t[c];
+            }
+        }
+    }
+};
+
+template <typename T, bool AIFAST, bool BIFAST, class Epi>
+__global__ __launch_bounds__(256) void gemm_dense_kernel(DenseOperand A, DenseOperand B, int64_t M, int64_t N, int64_t K,
+                                                         int64_t k_per_split, T *partial, Epi epi) {
+    using MT = Mma<T>;
+    constexpr int BM = 64, BN = 64, BK = (sizeof(T) == 4) ? 32 : 16;
+    constexpr int RM = 32 / MT::TM, RN = 32 / MT::TN;     // wave tile 32 x 32
+    __shared__ __attribute__((aligned(16))) T As[2][BK][BM + 4];
+    __shared__ __attribute__((aligned(16))) T Bs[2][BK][BN + 4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    const int64_t k_begin = (int64_t)blockIdx.z * k_per_split;
+    const int64_t k_end = (k_begin + k_per_split < K) ? k_begin + k_per_split : K;
+
+    typename MT::acc_t acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < MT::NACC; ++r) acc[i][j][r] = 0;
+
+    TileLoader<T, BM, BK, AIFAST> la;
+    TileLoader<T, BN, BK, BIFAST> lb;
+    la.load(A, m0, M, k_begin, k_end);
+    lb.load(B, n0, N, k_begin, k_end);
+    la.store(As[0]);
+    lb.store(Bs[0]);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+        const bool more = k0 + BK < k_end;
+        if (more) {
+            la.load(A, m0, M, k0 + BK, k_end);
+            lb.load(B, n0, N, k0 + BK, k_end);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += MT::TK) {
+            T af[RM], bf[RN];
+            const int kr = kk + MT::frag_k(lane);
+#pragma unroll
+            for (int i = 0; i < RM; ++i) af[i] = As[cur][kr][wm * 32 + i * MT::TM + MT::frag_i(lane)];
+#pragma unroll
+            for (int j = 0; j < RN; ++j) bf[j] = Bs[cur][kr][wn * 32 + j * MT::TN + MT::frag_i(lane)];
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) acc[i][j] = MT::mma(af[i], bf[j], acc[i][j]);
+        }
+        if (more) {
+            la.store(As[cur ^ 1]);
+            lb.store(Bs[cur ^ 1]);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    const bool direct = (gridDim.z == 1);
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < MT::NACC; ++r) {
+                const int64_t m = m0 + wm * 32 + i * MT::TM + MT::acc_row(lane, r);
+                const int64_t n = n0 + wn * 32 + j * MT::TN + MT::acc_col(lane, r);
+                if (m < M && n < N) {
+                    if (direct) epi(m, n, acc[i][j][r]);
+                    else partial[((int64_t)blockIdx.z * M + m) * N + n] = acc[i][j][r];
+                }
+            }
+}
+
+// Dense launcher.  Requires 16-byte aligned bases and leading strides that keep every vector
+// aligned; otherwise falls back to the generic gather kernel (gemm.hpp).
+template <typename T, class Epi>
+int launch_gemm_dense(hipStream_t stream, const DenseOperand &A, const DenseOperand &B, int64_t M, int64_t N, int64_t K,
+                      const Epi &epi, const SplitWs &ws, int *launches = nullptr, int target_wgs = 512,
+                      int max_splits = 64) {
+    if (M <= 0 || N <= 0) return MODL_OK;
+    constexpr int VN = Vec4<T>::N;
+    auto aligned = [](const DenseOperand &o) {
+        if (o.si != 1 && o.sk != 1) return false;
+        const int64_t ld = (o.si == 1) ? o.sk : o.si;
+        return (reinterpret_cast<uintptr_t>(o.ptr) % 16 == 0) && (ld % VN == 0);
+    };
+    if (!aligned(A) || !aligned(B) || K <= 0) {
+        Operand a, b;
+        a.ptr = A.ptr; a.si = A.si; a.sk = A.sk;
+        b.ptr = B.ptr; b.si = B.si; b.sk = B.sk;
+        return launch_gemm<T, Epi>(stream, a, b, M, N, K, epi, ws, launches, target_wgs, max_splits);
+    }
+    constexpr int BK = (sizeof(T) == 4) ? 32 : 16;
+    const int64_t tm = cdiv(M, 64), tn = cdiv(N, 64);
+    int64_t splits = 1;
+    if (tm * tn < target_wgs && max_splits > 1 && ws.ptr) {
+        splits = target_wgs / (tm * tn);
+        const int64_t max_by_k = K / (4 * BK) > 0 ? K / (4 * BK) : 1;       // >= 4 k-tiles per split
+        if (splits > max_by_k) splits = max_by_k;
+        if (splits > max_splits) splits = max_splits;
+        const int64_t max_by_ws = (int64_t)(ws.bytes / sizeof(T)) / (M * N);
+        if (splits > max_by_ws) splits = max_by_ws;
+        if (splits < 1) splits = 1;
+    }
+    const int64_t kps = cdiv(cdiv(K, splits), BK) * BK;
+    splits = cdiv(K, kps);
+    dim3 grid((unsigned)tn, (unsigned)tm, (unsigned)splits);
+    T *partial = static_cast<T *>(ws.ptr);
+    const bool ai = A.si == 1, bi = B.si == 1;
+#define MODL_GD(AI, BI) \
+    hipLaunchKernelGGL((gemm_dense_kernel<T, AI, BI, Epi>), grid, dim3(256), 0, stream, A, B, M, N, K, kps, partial, epi)
+    if (ai && bi) MODL_GD(true, true);
+    else if (ai) MODL_GD(true, false);
+    else if (bi) MODL_GD(false, true);
+    else MODL_GD(false, false);
+#undef MODL_GD
+    MODL_LAUNCH_CHECK();
+    if (launches) ++*launches;
+    if (splits > 1) {
+        hipLaunchKernelGGL((gemm_reduce_kernel<T, Epi>), dim3((unsigned)cdiv(M * N, 256)), dim3(256), 0, stream,
+                           partial, (int)splits, M, N, epi);
+        MODL_LAUNCH_CHECK();
+        if (launches) ++*launches;
+    }
+    return MODL_OK;
+}
+
+// ---- compaction kernels -------------------------------------------------------
+// dst[r][0..cols) = src[idx[r]][0..cols)   (rows r >= n_rows of the padded destination are zero)
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void gather_rows_T_kernel(const T *src, int64_t src_ld, const I *idx, int64_t n_rows,
+                                                            int64_t n_rows_pad, int64_t cols, T *dst, int64_t dst_ld) {
+    const int64_t r = blockIdx.x;
+    if (r >= n_rows_pad) return;
+    T *d = dst + r * dst_ld;
+    if (r < n_rows) {
+        const T *s = src + (int64_t)idx[r] * src_ld;
+        for (int64_t c = threadIdx.x; c < cols; c += 256) d[c] = s[c];
+    } else {
+        for (int64_t c = threadIdx.x; c < cols; c += 256) d[c] = 0;
+    }
+}
+// src[idx[r]][0..cols) = dst-compact[r][0..cols)
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void scatter_rows_T_kernel(T *dst, int64_t dst_ld, const I *idx, int64_t n_rows,
+                                                             int64_t cols, const T *src, int64_t src_ld) {
+    const int64_t r = blockIdx.x;
+    if (r >= n_rows) return;
+    T *d = dst + (int64_t)idx[r] * dst_ld;
+    const T *s = src + r * src_ld;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) d[c] = s[c];
+}
+// dst[i][f] = src[i][cols_idx[f]] for f < s, zero for s <= f < s_pad
+template <typename T>
+__global__ __launch_bounds__(256) void gather_cols_T_kernel(const T *src, int64_t src_ld, const int32_t *cols_idx,
+                                                            int64_t s, int64_t s_pad, T *dst) {
+    const int64_t i = blockIdx.y;
+    const T *row = src + i * src_ld;
+    for (int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x; f < s_pad; f += (int64_t)gridDim.x * 256)
+        dst[i * s_pad + f] = (f < s) ? row[cols_idx[f]] : (T)0;
+}
+
+}  // namespace modl

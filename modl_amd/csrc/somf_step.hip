@@ -20,7 +20,7 @@
 #include <new>
 #include <vector>
 
-#include "gemm.hpp"
+#include "gemm_dense.hpp"
 #include "kernels.hpp"
 
 namespace modl {
@@ -71,7 +71,7 @@ struct modl_somf_plan {
     // device arena
     char *dws = nullptr;
     size_t dws_bytes = 0;
-    size_t off_params, off_xnorm, off_Dx, off_H0, off_G, off_F, off_split, off_du, off_sweeps;
+    size_t off_params, off_xnorm, off_Dx, off_H0, off_G, off_F, off_split, off_du, off_sweeps, off_Ds, off_Xs, off_codeb;
     int last_b = 0;
     size_t split_bytes, du_bytes, params_bytes;
     // per-batch parameter block (device copy of the host arrays), layout within params:
@@ -227,12 +227,19 @@ int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride
     }
     const T *H0 = nullptr;
     if (g_stride == 0) {                                             // H0 = code[idx] G on the matrix cores
-        Operand A, B;
-        A.ptr = code; A.si = k; A.sk = 1; A.gi = gather64(d_idx);
-        B.ptr = G; B.si = k; B.sk = 1;                               // B(n = j, kk = m) = G[j][m]
         EpiStore<T> epi{H0buf, k, (T)1};
         SplitWs none;
-        MODL_TRY((launch_gemm<T, EpiStore<T>>(st, A, B, b, k, k, epi, none, nl, 512, 1)));
+        if (!d_idx) {
+            DenseOperand A, B;
+            A.ptr = code; A.si = k; A.sk = 1;
+            B.ptr = G; B.si = 1; B.sk = k;                           // B(n = j, kk = m) = G[m][j] (G symmetric)
+            MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, A, B, b, k, k, epi, none, nl, 512, 1)));
+        } else {
+            Operand A, B;
+            A.ptr = code; A.si = k; A.sk = 1; A.gi = gather64(d_idx);
+            B.ptr = G; B.si = 1; B.sk = k;
+            MODL_TRY((launch_gemm<T, EpiStore<T>>(st, A, B, b, k, k, epi, none, nl, 512, 1)));
+        }
         H0 = H0buf;
     }
     CdArgs<T> a;
@@ -274,37 +281,75 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
     pl->last_b = b;
     const T red = (T)bt->reduction;
 
+    T *Dsb = reinterpret_cast<T *>(pl->dws + pl->off_Ds);
+    T *Xsb = reinterpret_cast<T *>(pl->dws + pl->off_Xs);
+    T *codeb = reinterpret_cast<T *>(pl->dws + pl->off_codeb);
+    const int64_t s_pad = (s + 3) / 4 * 4;
+    // the minibatch's code rows, compact (warm starts now, solutions after the solve)
+    const bool cd_on_compact = d.code_l1_ratio != 0.0 && d.G_agg != MODL_AGG_AVERAGE;
+    T *cb = codeb;
+    if (!d_idx) cb = code;                                             // rows 0..b-1 are already contiguous
+
     {   // ---- Dx, G  (dict_fact.py:588-620)
         ProfScope ps(pl, st, SEC_CODE_GEMM);
         if (d.code_l1_ratio != 0.0) {
             MODL_TRY(launch_row_norm2<T>(st, X, bt->ldx, p, b, xnorm));
             ++ps.launches;
         }
-        Operand A, B;
-        A.ptr = X; A.si = bt->ldx; A.sk = 1;
-        B.ptr = Dt; B.si = 1; B.sk = k;
-        int64_t Kdim = p;
-        T scale = 1;
-        if (d.Dx_agg != MODL_AGG_FULL) {                              // X[:, subset] . D[:, subset]^T * reduction
-            A.gk = gather32(d_subset);
-            B.gk = gather32(d_subset);
-            Kdim = s;
-            scale = red;
+        // compaction: gather once, contract dense.  Ds = Dt[subset] (whole 1 KiB feature rows),
+        // Xs = X[:, subset].  With every feature sampled nothing is copied.
+        const T *Dsrc = Dt, *Xsrc = X;
+        int64_t ldxs = bt->ldx;
+        const bool need_sub = d_subset && (d.Dx_agg != MODL_AGG_FULL || d.G_agg != MODL_AGG_FULL);
+        if (need_sub) {
+            hipLaunchKernelGGL((gather_rows_T_kernel<T, int32_t>), dim3((unsigned)s), dim3(256), 0, st, Dt, (int64_t)k,
+                               d_subset, s, s, (int64_t)k, Dsb, (int64_t)k);
+            MODL_LAUNCH_CHECK();
+            ++ps.launches;
+            Dsrc = Dsb;
+            if (d.Dx_agg != MODL_AGG_FULL) {
+                hipLaunchKernelGGL((gather_cols_T_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv(s_pad, 256), 64), b),
+                                   dim3(256), 0, st, X, bt->ldx, d_subset, s, s_pad, Xsb);
+                MODL_LAUNCH_CHECK();
+                ++ps.launches;
+                Xsrc = Xsb;
+                ldxs = s_pad;
+            }
+        }
+        DenseOperand A, B;
+        int64_t Kdim;
+        T scale;
+        if (d.Dx_agg == MODL_AGG_FULL) {                              // X . D^T
+            A.ptr = X; A.si = bt->ldx; A.sk = 1;
+            B.ptr = Dt; B.si = 1; B.sk = k;
+            Kdim = p; scale = 1;
+        } else {                                                       // X[:, subset] . D[:, subset]^T * reduction
+            A.ptr = Xsrc; A.si = ldxs; A.sk = 1;
+            B.ptr = Dsrc; B.si = 1; B.sk = k;
+            Kdim = s; scale = red;
         }
         if (d.Dx_agg == MODL_AGG_AVERAGE) {
             EpiDxAverage<T> epi{Dx, static_cast<T *>(stt->d_Dx_average), d_idx, d_wsample, k, scale};
-            MODL_TRY((launch_gemm<T, EpiDxAverage<T>>(st, A, B, b, k, Kdim, epi, sws, &ps.launches)));
+            MODL_TRY((launch_gemm_dense<T, EpiDxAverage<T>>(st, A, B, b, k, Kdim, epi, sws, &ps.launches)));
         } else {
             EpiStore<T> epi{Dx, k, scale};
-            MODL_TRY((launch_gemm<T, EpiStore<T>>(st, A, B, b, k, Kdim, epi, sws, &ps.launches)));
+            MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, A, B, b, k, Kdim, epi, sws, &ps.launches)));
         }
         if (d.G_agg != MODL_AGG_FULL) {
+            DenseOperand Dg;
+            Dg.ptr = Dsrc; Dg.si = 1; Dg.sk = k;
             EpiStore<T> epi{Gbuf, k, red};
-            MODL_TRY((gram_of_rows<T, EpiStore<T>>(pl, st, Dt, d_subset, s, epi, &ps.launches)));
+            MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Dg, Dg, k, k, s, epi, sws, &ps.launches)));
             if (d.G_agg == MODL_AGG_AVERAGE) {
                 MODL_TRY(launch_update_G_average<T>(st, static_cast<T *>(stt->d_G_average), d_idx, Gbuf, d_wsample, b, k));
                 ++ps.launches;
             }
+        }
+        if (cd_on_compact && d_idx) {
+            hipLaunchKernelGGL((gather_rows_T_kernel<T, int64_t>), dim3((unsigned)b), dim3(256), 0, st, code, (int64_t)k,
+                               d_idx, (int64_t)b, (int64_t)b, (int64_t)k, codeb, (int64_t)k);
+            MODL_LAUNCH_CHECK();
+            ++ps.launches;
         }
     }
     {   // ---- code solve  (dict_fact.py:636-648)
@@ -315,19 +360,35 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
                                     &ps.launches, H0, Fbuf));
         } else {
             const T *G = (d.G_agg == MODL_AGG_FULL) ? static_cast<const T *>(stt->d_G) : Gbuf;
-            MODL_TRY(solve_codes<T>(pl, st, G, 0, nullptr, Dx, xnorm, code, d_idx, b, d_sweeps, &ps.launches, H0, Fbuf));
+            if (cd_on_compact) {
+                MODL_TRY(solve_codes<T>(pl, st, G, 0, nullptr, Dx, xnorm, cb, nullptr, b, d_sweeps, &ps.launches, H0, Fbuf));
+                if (d_idx) {
+                    hipLaunchKernelGGL((scatter_rows_T_kernel<T, int64_t>), dim3((unsigned)b), dim3(256), 0, st, code,
+                                       (int64_t)k, d_idx, (int64_t)b, (int64_t)k, codeb, (int64_t)k);
+                    MODL_LAUNCH_CHECK();
+                    ++ps.launches;
+                }
+            } else {
+                MODL_TRY(solve_codes<T>(pl, st, G, 0, nullptr, Dx, xnorm, code, d_idx, b, d_sweeps, &ps.launches, H0, Fbuf));
+            }
         }
     }
     {   // ---- statistics increments: delta = [ code^T code | X^T code ]
         ProfScope ps(pl, st, SEC_STATS_GEMM);
-        Operand Cd;
-        Cd.ptr = code; Cd.si = 1; Cd.sk = k; Cd.gk = gather64(d_idx);     // element (i = atom, kk = sample)
+        if (!cd_on_compact && d_idx) {
+            hipLaunchKernelGGL((gather_rows_T_kernel<T, int64_t>), dim3((unsigned)b), dim3(256), 0, st, code, (int64_t)k,
+                               d_idx, (int64_t)b, (int64_t)b, (int64_t)k, codeb, (int64_t)k);
+            MODL_LAUNCH_CHECK();
+            ++ps.launches;
+        }
+        DenseOperand Cd;
+        Cd.ptr = cb; Cd.si = 1; Cd.sk = k;                              // element (i = atom, kk = sample)
         EpiStore<T> epiC{delta, k, (T)1};
-        MODL_TRY((launch_gemm<T, EpiStore<T>>(st, Cd, Cd, k, k, b, epiC, sws, &ps.launches)));
-        Operand Xo;
+        MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Cd, Cd, k, k, b, epiC, sws, &ps.launches)));
+        DenseOperand Xo;
         Xo.ptr = X; Xo.si = 1; Xo.sk = bt->ldx;                         // element (i = feature, kk = sample)
         EpiStore<T> epiB{delta + (size_t)k * k, k, (T)1};
-        MODL_TRY((launch_gemm<T, EpiStore<T>>(st, Xo, Cd, p, k, b, epiB, sws, &ps.launches)));
+        MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Xo, Cd, p, k, b, epiB, sws, &ps.launches)));
     }
     return MODL_OK;
 }
@@ -411,11 +472,11 @@ int transform_impl(modl_somf_plan *pl, const T *Dt, const T *G, const T *X, int6
         const int b = (int)std::min<int64_t>(d.max_batch, n - r0);
         const T *Xb = X + r0 * ldx;
         if (d.code_l1_ratio != 0.0) MODL_TRY(launch_row_norm2<T>(st, Xb, ldx, p, b, xnorm));
-        Operand A, B;
+        DenseOperand A, B;
         A.ptr = Xb; A.si = ldx; A.sk = 1;
         B.ptr = Dt; B.si = 1; B.sk = k;
         EpiStore<T> epi{Dx, k, (T)1};
-        MODL_TRY((launch_gemm<T, EpiStore<T>>(st, A, B, b, k, p, epi, sws, &nl)));
+        MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, A, B, b, k, p, epi, sws, &nl)));
         MODL_TRY(solve_codes<T>(pl, st, G, 0, nullptr, Dx, xnorm, code_out + r0 * k, nullptr, b, nullptr, &nl, H0, Fbuf));
     }
     return MODL_OK;
@@ -523,6 +584,10 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     pl->off_Dx = take(t * b * k);
     pl->off_H0 = take(t * b * k);
     pl->off_G = take(t * k * k);
+    const size_t p_pad = align_up(p, 4);
+    pl->off_Ds = take(t * p_pad * k);          // compacted sampled dictionary rows
+    pl->off_Xs = take(t * b * p_pad);          // compacted sampled minibatch columns
+    pl->off_codeb = take(t * b * k);           // the minibatch's code rows
     const bool per_sample = desc->G_agg == MODL_AGG_AVERAGE;
     pl->off_F = take(t * k * k * (per_sample ? b : 1));                // Cholesky factors (one per sample for G_average_)
     // split-K partial tiles: the largest split product is max(b, k) x k (Dx, Gram, C increment) with
