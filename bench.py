@@ -102,7 +102,9 @@ def run_gpu(args, reduction, steps, warmup, rank, world, device):
     dt = time.perf_counter() - t0
     prof = be.prof_get()
     be.prof_enable(False)
-    sweeps = float(be.last_sweeps().mean())
+    lsw = be.last_sweeps()
+    sweeps = float(lsw.mean())
+    run_gpu.sweeps_max = int(lsw.max())
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -197,7 +199,7 @@ def main():
                                         'masked/masked' % (CHUNK, P_FEAT, K_COMP, BATCH, args.reduction),
                                reduction=args.reduction, global_batch=BATCH * world,
                                parallelism='dp%d (row-sharded minibatch, all-reduce of [C|B] increments)' % world),
-                   roofline=roof, sections=sections, cd_sweeps_mean=sweeps,
+                   roofline=roof, sections=sections, cd_sweeps_mean=sweeps, cd_sweeps_max=getattr(run_gpu, 'sweeps_max', None),
                    step_tflops=total_fl / (dt / args.steps) / 1e12, finite=ok)
     if args.also_r1:
         dt1, prof1, sw1, ok1 = run_gpu(args, 1.0, max(args.steps // 2, 10), max(args.warmup // 2, 2), rank, world, device)

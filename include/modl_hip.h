@@ -252,6 +252,9 @@ int modl_somf_transform(modl_somf_plan *plan, const void *d_Dt, const void *d_G,
  * (0 for the ridge branch).  Synchronises `stream`. */
 int modl_somf_last_sweeps(modl_somf_plan *plan, int32_t *h_out, int cap, int *n_out, void *stream);
 
+/* diagnostics: 8 shader-clock stamps of the last fused dictionary-update launch (synchronises the device) */
+int modl_somf_debug_stamps(modl_somf_plan *plan, unsigned long long *h_out);
+
 /* layout helpers: out[c][r] = in[r][c]  (components_ <-> Dt) */
 int modl_transpose_f32(const float *d_in, float *d_out, int64_t rows, int64_t cols, void *stream);
 int modl_transpose_f64(const double *d_in, double *d_out, int64_t rows, int64_t cols, void *stream);

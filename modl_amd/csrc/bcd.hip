@@ -42,7 +42,7 @@ constexpr int kNB = 32;            // atoms per block of the blocked path
 constexpr int kGramRows = 128;     // feature rows per Gram slab
 
 struct DuLayout {
-    size_t off_CP, off_cdiag, off_frozen, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, total;
+    size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, total;
     int64_t nslab_max, nwg_grad;
 };
 
@@ -55,15 +55,20 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     L.off_CP = take(tsz * (size_t)k * k);
     L.off_cdiag = take(tsz * (size_t)k);
     L.off_frozen = take(sizeof(int32_t) * (size_t)k);
+    L.off_coef = take(sizeof(double) * (size_t)kNB * k);
     L.off_a = take(tsz * (size_t)s_max * kNB);
     L.off_partial = take(sizeof(double) * (size_t)L.nslab_max * (kNB * kNB + kNB));
-    L.off_Tp = take(sizeof(double) * (kNB * kNB + kNB));
+    L.off_Tp = take(sizeof(double) * 2 * (kNB * kNB + kNB) + 64 + 256);   // two CA records (ping-pong) + arrival counter + debug stamps
     L.off_u = take(tsz * (size_t)s_max);
     L.off_pold = take(sizeof(double) * (size_t)L.nwg_grad);
     L.off_Dnew = take(tsz * (size_t)s_max * k);                       // sgd only, but sized once
     L.off_colp = take(sizeof(double) * (size_t)L.nslab_max * k);
     L.total = o;
     return L;
+}
+
+size_t dict_update_stamps_offset(int dtype, int64_t s_max, int k) {
+    return du_layout(dtype == MODL_F32 ? 4 : 8, s_max, k).off_Tp + sizeof(double) * 2 * (kNB * kNB + kNB) + 64;
 }
 
 size_t dict_update_workspace(int dtype, int64_t s_max, int k) {
@@ -75,20 +80,37 @@ __device__ __forceinline__ int64_t sub_row(const int32_t *subset, int64_t f) { r
 // ---------------------------------------------------------------- blocked path
 template <typename T>
 __global__ __launch_bounds__(256) void bcd_prepare_kernel(const T *C, const int32_t *order, int k, T *CP, T *cdiag,
-                                                          int32_t *frozen) {
+                                                          int32_t *frozen, double *coef_all, unsigned int *counter) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;   // arrival ticket of the fused block kernel
     extern __shared__ int32_t inv[];                 // position of each atom in the sweep
     for (int j = threadIdx.x; j < k; j += 256) inv[order[j]] = j;
     __syncthreads();
     const int m = blockIdx.x;                        // source atom (row of C)
-    const int pm = inv[m];
-    for (int jj = threadIdx.x; jj < k; jj += 256) {
-        T v = C[(int64_t)m * k + order[jj]];
-        if (pm / kNB == jj / kNB && pm <= jj) v = 0;  // same block, not after jj: handled by the recursion
-        CP[(int64_t)m * k + jj] = v;
-        if (m == 0) {
-            const T d = C[(int64_t)order[jj] * k + order[jj]];
-            cdiag[jj] = d;
-            frozen[jj] = !(d > (T)1e-20);             // dict_fact.py:681 "else do not update"
+    if (m < k) {
+        const int pm = inv[m];
+        for (int jj = threadIdx.x; jj < k; jj += 256) {
+            T v = C[(int64_t)m * k + order[jj]];
+            if (pm / kNB == jj / kNB && pm <= jj) v = 0;  // same block, not after jj: handled by the recursion
+            CP[(int64_t)m * k + jj] = v;
+            if (m == 0) {
+                const T d = C[(int64_t)order[jj] * k + order[jj]];
+                cdiag[jj] = d;
+                frozen[jj] = !(d > (T)1e-20);         // dict_fact.py:681 "else do not update"
+            }
+        }
+    }
+    // coefficients of the in-block recursion: coef_all[i][jj] = C[o_i', o_jj] / C[o_jj, o_jj] where i' is the
+    // i-th atom of jj's block and i < position of jj in its block (zero otherwise / for frozen atoms)
+    if (m < kNB) {
+        for (int jj = threadIdx.x; jj < k; jj += 256) {
+            const int jl = jj % kNB, jb0 = jj - jl;
+            double c = 0;
+            if (m < jl && jb0 + m < k) {
+                const int oi = order[jb0 + m], oj = order[jj];
+                const T d = C[(int64_t)oj * k + oj];
+                if (d > (T)1e-20) c = (double)C[(int64_t)oi * k + oj] / (double)d;
+            }
+            coef_all[(int64_t)m * k + jj] = c;
         }
     }
 }
@@ -145,21 +167,190 @@ __global__ __launch_bounds__(256) void bcd_gram_kernel(const T *a, const T *Dt, 
     }
 }
 
-// ---- fused block kernel (f32): a = (B - D_cur CP) / diag on the matrix cores + partial Gram -------
-// One workgroup owns RB = 32 * RT sampled features and all NB atoms of the block.  Its four
-// wavefronts split the contraction over the k atoms; the dictionary rows are read straight from
-// HBM/L2 into MFMA A-operands (one 16-byte load per lane: 32 rows x 8 consecutive atoms per wave
-// instruction, every 128-byte line of a feature row is consumed by 4 consecutive loads), the k x NB
-// coefficient block sits in LDS.  Partial accumulators are summed across the waves in a fixed order,
-// the epilogue forms a_j, and the NB x NB Gram contribution of these RB features is accumulated in
-// double precision from LDS.
+// ---- sum of 32 doubles held by one half-wave (lanes 0-31 or 32-63), DPP row operations ----------
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// every lane of a 16-lane row ends with the row's sum
+__device__ __forceinline__ double row16_sum(double x) {
+    x += dpp_move<0xB1>(x);      // quad_perm [1,0,3,2]
+    x += dpp_move<0x4E>(x);      // quad_perm [2,3,0,1]
+    x += dpp_move<0x141>(x);     // row_half_mirror
+    x += dpp_move<0x140>(x);     // row_mirror
+    return x;
+}
+
+// 1 / sqrt(q) in double from a single-precision seed and two Newton steps (|rel err| < 1e-15); the
+// IEEE double sqrt + divide sequences cost several hundred cycles on the recursion's critical path.
+__device__ __forceinline__ double fast_rsqrt(double q) {
+    const float qf = (float)q;
+    if (!(qf > 1e-30f && qf < 1e30f)) return 1.0 / sqrt(q);
+    double y = (double)rsqrtf(qf);
+    y = y * (1.5 - 0.5 * q * y * y);
+    y = y * (1.5 - 0.5 * q * y * y);
+    return y;
+}
+__device__ __forceinline__ double fast_rcp(double v) {
+    const float vf = (float)v;
+    if (!(fabsf(vf) > 1e-30f && fabsf(vf) < 1e30f)) return 1.0 / v;
+    double r = (double)(1.0f / vf);
+    r = r * (2.0 - v * r);
+    r = r * (2.0 - v * r);
+    return r;
+}
+
+constexpr int kResStride = kNB * kNB + kNB;          // doubles per Gram partial / per CA record
+
+// Sum the per-workgroup Gram partials in a fixed order into LDS (all threads of the block).
+__device__ __forceinline__ void reduce_partials(const double *partial, int nslab, double (*M)[kNB + 1], double *D2) {
+    for (int e = threadIdx.x; e < kResStride; e += blockDim.x) {
+        double sv[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // fixed association: deterministic
+        int z = 0;
+        for (; z + 8 <= nslab; z += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sv[u] += partial[(int64_t)(z + u) * kResStride + e];
+        }
+        for (; z < nslab; ++z) sv[0] += partial[(int64_t)z * kResStride + e];
+        const double sum = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
+        if (e < kNB * kNB) M[e / kNB][e % kNB] = sum;
+        else D2[e - kNB * kNB] = sum;
+    }
+}
+
+// The alpha recursion of one block, run by ONE wavefront entirely in registers (lane x = lane & 31
+// owns column x).  With u_j = a_j - sum_{i<j} ca_i u_i, ca_i = (C[o_i,o_j] / C[o_j,o_j]) alpha_i, write
+// u_j = sum_m T[j][m] a_m:
+//     T[j][x]  = delta_jx - sum_{i<j} ca_i T[i][x]
+//     |u_j|^2  = sum_x T[j][x] (M T[j])[x],     M = Gram matrix of the a_m
+// The j loop is fully unrolled so every register index is static; wave-uniform scalars travel by
+// v_readlane, the only cross-lane reduction is a 4-step DPP row sum.  Output per block: CA[j][i] = ca_i
+// (consumed by the apply step, which replays the recursion feature by feature) and alpha[j].
+template <typename T>
+__device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const double *D2, const double *coef_all,
+                                             const int32_t *order, int k, int j0, int nb, T *comp_norm, double *CAout) {
+    const int lane = threadIdx.x & 63, x = lane & 31;
+    double Mrow[kNB], crow[kNB], Tcol[kNB];
+#pragma unroll
+    for (int m = 0; m < kNB; ++m) {
+        Mrow[m] = M[x][m];
+        crow[m] = (j0 + m < k) ? coef_all[(int64_t)x * k + j0 + m] : 0.0;   // C[o_x,o_m] / C[o_m,o_m] for x < m
+        Tcol[m] = 0.0;
+    }
+    const int jj_x = (x < nb) ? order[j0 + x] : 0;
+    const double cn_x = (x < nb) ? (double)comp_norm[jj_x] : 0.0;
+    const double d2_x = D2[x];
+    double alpha_x = 0.0;
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) {
+        if (j < nb) {
+            const double ca = crow[j] * alpha_x;                      // lane i: ca_i (zero for i >= j)
+            double t0 = (x == j) ? 1.0 : 0.0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+            for (int i = 0; i < j; ++i) {
+                const double c = bcast_lane(ca, i);
+                if ((i & 3) == 0) t0 -= c * Tcol[i];
+                else if ((i & 3) == 1) t1 -= c * Tcol[i];
+                else if ((i & 3) == 2) t2 -= c * Tcol[i];
+                else t3 -= c * Tcol[i];
+            }
+            const double t = (t0 + t1) + (t2 + t3);
+            Tcol[j] = t;
+            double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+#pragma unroll
+            for (int m = 0; m <= j; ++m) {
+                const double tm = bcast_lane(t, m);
+                if ((m & 3) == 0) v0 += Mrow[m] * tm;
+                else if ((m & 3) == 1) v1 += Mrow[m] * tm;
+                else if ((m & 3) == 2) v2 += Mrow[m] * tm;
+                else v3 += Mrow[m] * tm;
+            }
+            double prod = (lane < 32) ? t * ((v0 + v1) + (v2 + v3)) : 0.0;
+            prod = row16_sum(prod);
+            const double nrm = bcast_lane(prod, 0) + bcast_lane(prod, 16);
+            const double radius = bcast_lane(cn_x, j) + bcast_lane(d2_x, j);
+            double al;
+            if (!(radius > 0.0)) al = 0.0;                // enet.pyx:57 (radius == 0 -> zero atom)
+            else if (nrm <= radius) al = 1.0;             // enet.pyx:65
+            else al = fast_rsqrt(nrm * fast_rcp(radius));
+            if (x == j) alpha_x = al;
+            if (lane < 32) CAout[j * kNB + x] = al * t;   // row j of alpha_j T[j][.]: D_new[j] = sum_m Tp[j][m] a_m
+            if (lane == j) comp_norm[jj_x] = (T)(radius - al * al * nrm);
+        } else if (lane < 32) {
+            CAout[j * kNB + x] = 0.0;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bcd_resolve_kernel(const double *partial, int nslab, const double *coef_all,
+                                                          const int32_t *order, int k, int j0, int nb, T *comp_norm,
+                                                          double *CAout) {
+    __shared__ double M[kNB][kNB + 1];
+    __shared__ double D2[kNB];
+    reduce_partials(partial, nslab, M, D2);
+    __syncthreads();
+    if (threadIdx.x < 64) resolve_wave<T>(M, D2, coef_all, order, k, j0, nb, comp_norm, CAout);
+}
+
+// D_new[f][o_j] = sum_{m <= j} Tp[j][m] a_m[f]  for the atoms j = jg, jg + NSTR, ... of one sampled feature
+template <typename T, int NSTR>
+__device__ __forceinline__ void apply_row(const T *ar, const double *Tps, T *row, const int32_t *order, int j0, int nb,
+                                          int jg) {
+    double av[kNB];
+#pragma unroll
+    for (int m = 0; m < kNB; ++m) av[m] = (m < nb) ? (double)ar[m] : 0.0;   // columns >= nb were never written
+    for (int j = jg; j < nb; j += NSTR) {
+        double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+#pragma unroll
+        for (int m = 0; m < kNB; m += 4) {
+            acc0 += Tps[j * kNB + m] * av[m];
+            acc1 += Tps[j * kNB + m + 1] * av[m + 1];
+            acc2 += Tps[j * kNB + m + 2] * av[m + 2];
+            acc3 += Tps[j * kNB + m + 3] * av[m + 3];
+        }
+        row[order[j0 + j]] = (T)((acc0 + acc1) + (acc2 + acc3));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bcd_apply_kernel(const T *a, const double *__restrict__ CA, T *Dt,
+                                                        const int32_t *subset, const int32_t *order, int64_t s, int k,
+                                                        int j0, int nb) {
+    __shared__ double CAs[kResStride];
+    for (int e = threadIdx.x; e < kResStride; e += 256) CAs[e] = CA[e];
+    __syncthreads();
+    const int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x / 4;       // 4 threads per feature
+    if (f >= s) return;
+    apply_row<T, 4>(a + f * kNB, CAs, Dt + sub_row(subset, f) * k, order, j0, nb, threadIdx.x % 4);
+}
+
+// ---- fused block kernel (f32) -------------------------------------------------------------------
+// One launch per block of NB atoms:
+//   (0) apply the PREVIOUS block's result to this workgroup's features (they are workgroup-private);
+//   (1) a = (B - D_cur CP) / diag on the matrix cores: the four wavefronts split the contraction over
+//       the k atoms, dictionary rows go straight from HBM/L2 into MFMA A-operands (one 16-byte load per
+//       lane: 32 rows x 8 consecutive atoms per wave instruction), the k x NB coefficient block sits in
+//       LDS, partial accumulators are summed across the waves in a fixed order;
+//   (2) the NB x NB Gram contribution of these RB features, in double precision from LDS;
+//   (3) the LAST workgroup to finish (agent-scope release / relaxed ticket / acquire, no spinning) sums
+//       the partials in a fixed order and runs the alpha recursion for the block.
 struct BcdBlockArgs {
-    const float *Dt, *Bt, *CP, *cdiag;
+    float *Dt;
+    const float *Bt, *CP, *cdiag;
     const int32_t *frozen, *subset, *order;
     float *a;
     double *partial;
+    const double *coef_all;
+    double *CA_prev, *CA_out;       // CA record of the previous block (null for the first) / of this block
+    float *comp_norm;
+    unsigned int *counter;
+    unsigned long long *stamps;     // optional phase timestamps of the last-arriving workgroup (diagnostics)
     int64_t s;
-    int k, j0, nb;
+    int k, j0, nb, j0_prev, nb_prev;
 };
 
 template <int RT, int GPW>   // 32 * RT features per workgroup; GPW contraction groups (8 atoms) per wave
@@ -170,12 +361,19 @@ __global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
     typedef float f16v __attribute__((ext_vector_type(16)));
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int k = p.k;
-    float *CPs = reinterpret_cast<float *>(smem_raw);                          // [KPAD][NB]
+    // LDS carve (all from the dynamic region, 16-byte aligned pieces)
+    double *Ms = reinterpret_cast<double *>(smem_raw);                        // [NB][NB + 1]  (last workgroup)
+    double *D2s = Ms + kNB * (kNB + 1);                                        // [NB]
+    double *CAs = D2s + kNB;                                                   // [NB * NB + NB] previous block's CA
+    double *d2red = CAs + kResStride;                                          // [8][NB]
+    float *CPs = reinterpret_cast<float *>(d2red + 8 * kNB);                   // [KPAD][NB]
     float *red = CPs + (size_t)KPAD * kNB;                                     // [4][RB][NB + 1]
     float *As = red + 4 * RB * (kNB + 1);                                      // [RB][NB + 1]
-    double *d2red = reinterpret_cast<double *>(As + RB * (kNB + 1) + ((RB * (kNB + 1)) & 1));   // [8][NB]
+    int *flag = reinterpret_cast<int *>(As + RB * (kNB + 1));
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t f0 = (int64_t)blockIdx.x * RB;
+    unsigned long long ts[8];
+    ts[0] = clock64();
 
     // epilogue operands of this thread (column = tid % 32, rows tid / 32 + 8 q): issued first so that
     // they arrive while the coefficient block is staged and the matrix cores run
@@ -208,6 +406,22 @@ __global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
             CPs[e] = (m < k && jj < p.nb) ? p.CP[(int64_t)m * k + p.j0 + jj] : 0.f;
         }
     }
+    // (0) previous block: D[f][o_j] = alpha_j u_j[f] for this workgroup's features, then make the new
+    // values visible to the other waves of the workgroup before they are read back as MFMA operands
+    if (p.CA_prev) {
+        for (int e = threadIdx.x; e < kResStride; e += 256) CAs[e] = p.CA_prev[e];
+        __syncthreads();
+        {
+            constexpr int TPR = 256 / RB;                // threads per feature row
+            const int64_t f = f0 + threadIdx.x / TPR;
+            if (f < p.s)
+                apply_row<float, TPR>(p.a + f * kNB, CAs, p.Dt + sub_row(p.subset, f) * k, p.order, p.j0_prev, p.nb_prev,
+                                      threadIdx.x % TPR);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    ts[1] = clock64();
     // dictionary rows -> MFMA A operands, all loads of the wave's contraction range in flight at once
     const int h = lane >> 5;
     float4 av[GPW][RT];
@@ -250,6 +464,7 @@ __global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
             red[(wid * RB + row) * (kNB + 1) + c] = acc[t][r];
         }
     __syncthreads();
+    ts[2] = clock64();
     double d2 = 0;
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
@@ -267,7 +482,7 @@ __global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
     }
     d2red[rg * kNB + col] = d2;
     __syncthreads();
-    {   // partial Gram of the a_j over this workgroup's features, and old squared norms
+    {   // (2) partial Gram of the a_j over this workgroup's features, and old squared norms
         const int i = threadIdx.x / 8, jb = (threadIdx.x % 8) * 4;
         double g4[4] = {0, 0, 0, 0};
         for (int r = 0; r < RB; ++r) {
@@ -275,7 +490,7 @@ __global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) g4[q] += ai * (double)As[r * (kNB + 1) + jb + q];
         }
-        double *out = p.partial + (int64_t)blockIdx.x * (kNB * kNB + kNB);
+        double *out = p.partial + (int64_t)blockIdx.x * kResStride;
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[i * kNB + jb + q] = g4[q];
         if (threadIdx.x < kNB) {
@@ -284,143 +499,40 @@ __global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
             out[kNB * kNB + threadIdx.x] = t;
         }
     }
+    // (3) last workgroup to arrive resolves the block (cdna guide, split-K "last arriver" recipe)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ts[3] = clock64();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int ticket = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (ticket == gridDim.x - 1);
+        if (last) {
+            __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    ts[4] = clock64();
+    reduce_partials(p.partial, (int)gridDim.x, reinterpret_cast<double (*)[kNB + 1]>(Ms), D2s);
+    __syncthreads();
+    ts[5] = clock64();
+    if (threadIdx.x < 64)
+        resolve_wave<float>(reinterpret_cast<const double (*)[kNB + 1]>(Ms), D2s, p.coef_all, p.order, k, p.j0, p.nb,
+                            p.comp_norm, p.CA_out);
+    ts[6] = clock64();
+    if (p.stamps && threadIdx.x == 0)
+        for (int i = 0; i < 7; ++i) p.stamps[i] = ts[i];
 }
 
 static size_t bcd_block_lds(int gpw, int RT) {
     const int kpad = gpw * 32, RB = 32 * RT;
-    size_t fl = (size_t)kpad * kNB + 4 * RB * (kNB + 1) + RB * (kNB + 1) + ((RB * (kNB + 1)) & 1);
-    return fl * 4 + 8 * kNB * sizeof(double) + 16;
-}
-
-// ---- sum of 32 doubles held by one half-wave (lanes 0-31 or 32-63), DPP row operations ----------
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double x) {
-    const long long b = __double_as_longlong(x);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-// every lane of a 16-lane row ends with the row's sum
-__device__ __forceinline__ double row16_sum(double x) {
-    x += dpp_move<0xB1>(x);      // quad_perm [1,0,3,2]
-    x += dpp_move<0x4E>(x);      // quad_perm [2,3,0,1]
-    x += dpp_move<0x141>(x);     // row_half_mirror
-    x += dpp_move<0x140>(x);     // row_mirror
-    return x;
-}
-
-// The alpha recursion of one block in wavefront 0.  With u_j = a_j - sum_{i<j} ca_i u_i,
-// ca_i = (C[o_i,o_j] / C[o_j,o_j]) alpha_i, it carries U[j][m] = <u_j, a_m> and V[j][i] = <u_j, u_i>:
-//   U[j][m] = M[j][m] - sum_{i<j} ca_i U[i][m]            (lanes 0..31, lane = m)
-//   V[j][i] = U[i][j] - sum_{i'<j} ca_i' V[i'][i]          (lanes 32..63, lane - 32 = i < j)
-//   |u_j|^2 = U[j][j] - sum_{i<j} ca_i V[j][i]
-// so both half-waves run the same length-j loop on different matrices.  Output: CA[i][j] = ca_i for
-// the apply kernel and alpha[j].
-template <typename T>
-__global__ __launch_bounds__(1024) void bcd_resolve_kernel(const double *partial, int nslab, const T *C,
-                                                           const int32_t *order, const int32_t *frozen, int k, int j0,
-                                                           int nb, T *comp_norm, double *CAout) {
-    __shared__ double M[kNB][kNB + 1];
-    __shared__ double D2[kNB];
-    __shared__ double Us[kNB][kNB + 1];
-    __shared__ double Vs[kNB][kNB + 1];
-    __shared__ double coef[kNB][kNB + 1];
-    __shared__ double cas[kNB];
-    constexpr int kStride = kNB * kNB + kNB;
-    for (int e = threadIdx.x; e < kStride; e += 1024) {
-        double sv[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // fixed association: deterministic
-        int z = 0;
-        for (; z + 8 <= nslab; z += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) sv[u] += partial[(int64_t)(z + u) * kStride + e];
-        }
-        for (; z < nslab; ++z) sv[0] += partial[(int64_t)z * kStride + e];
-        const double sum = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
-        if (e < kNB * kNB) M[e / kNB][e % kNB] = sum;
-        else D2[e - kNB * kNB] = sum;
-    }
-    for (int e = threadIdx.x; e < kNB * kNB; e += 1024) {
-        const int i = e / kNB, j = e % kNB;
-        double c = 0;
-        if (i < j && j < nb && !frozen[j0 + j]) {
-            const int oi = order[j0 + i], oj = order[j0 + j];
-            c = (double)C[(int64_t)oi * k + oj] / (double)C[(int64_t)oj * k + oj];
-        }
-        coef[i][j] = c;
-        Us[i][j] = 0;
-        Vs[i][j] = 0;
-    }
-    __syncthreads();
-    if (threadIdx.x >= 64) return;                    // the recursion runs in wavefront 0 (no block barrier below)
-    const int x = threadIdx.x & 31, half = threadIdx.x >> 5;
-    const double (*Mat)[kNB + 1] = half ? Vs : Us;
-    double alpha_x = 0;                               // alpha of atom x once known
-    const int jj_x = (x < nb) ? order[j0 + x] : 0;    // the block's atoms and budgets, read once
-    const double cn_x = (x < nb) ? (double)comp_norm[jj_x] : 0.0;
-    for (int j = 0; j < nb; ++j) {
-        // ca_i for this j
-        if (half == 0) cas[x] = (x < j) ? coef[x][j] * alpha_x : 0.0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        double acc0 = half ? Us[x][j] : M[j][x], acc1 = 0, acc2 = 0, acc3 = 0;
-        int i = 0;
-        for (; i + 4 <= j; i += 4) {
-            acc0 -= cas[i] * Mat[i][x];
-            acc1 -= cas[i + 1] * Mat[i + 1][x];
-            acc2 -= cas[i + 2] * Mat[i + 2][x];
-            acc3 -= cas[i + 3] * Mat[i + 3][x];
-        }
-        for (; i < j; ++i) acc0 -= cas[i] * Mat[i][x];
-        const double val = (acc0 + acc1) + (acc2 + acc3);          // U[j][x] (half 0) or V[j][x] (half 1, x < j)
-        double prod = (half == 1 && x < j) ? cas[x] * val : 0.0;
-        prod = row16_sum(prod);
-        const double vsum = bcast_lane(prod, 32) + bcast_lane(prod, 48);
-        const double ujj = bcast_lane(val, j);                       // lane j of half 0 holds U[j][j]
-        const double nrm = ujj - vsum;
-        const double radius = bcast_lane(cn_x, j) + D2[j];
-        double al;
-        if (!(radius > 0.0)) al = 0.0;                // enet.pyx:57 (radius == 0 -> zero atom)
-        else if (nrm <= radius) al = 1.0;             // enet.pyx:65
-        else al = 1.0 / sqrt(nrm / radius);
-        if (half == 0) {
-            Us[j][x] = val;
-        } else {
-            if (x < j) { Vs[j][x] = val; Vs[x][j] = val; }
-            if (x == j) Vs[j][j] = nrm;
-        }
-        if (x == j) alpha_x = al;
-        if (threadIdx.x == j) comp_norm[jj_x] = (T)(radius - al * al * nrm);
-        if (half == 0) CAout[j * kNB + x] = cas[x];    // row j: ca_i (i < j), zero beyond
-        if (threadIdx.x == j) CAout[kNB * kNB + j] = al;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    if (half == 0 && x >= nb) CAout[kNB * kNB + x] = 0.0;
-}
-
-// D_new[f][o_j] = alpha_j u_j[f],  u_j = a_j - sum_{i<j} ca_ij u_i   (one thread per sampled feature)
-template <typename T>
-__global__ __launch_bounds__(256) void bcd_apply_kernel(const T *a, const double *__restrict__ CA, T *Dt,
-                                                        const int32_t *subset, const int32_t *order, int64_t s, int k,
-                                                        int j0, int nb) {
-    __shared__ double CAs[kNB * kNB + kNB];
-    for (int e = threadIdx.x; e < kNB * kNB + kNB; e += 256) CAs[e] = CA[e];
-    __syncthreads();
-    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (f >= s) return;
-    double u[kNB];
-    const T *ar = a + f * kNB;
-#pragma unroll
-    for (int j = 0; j < kNB; ++j) u[j] = (double)ar[j];
-    T *row = Dt + sub_row(subset, f) * k;
-#pragma unroll
-    for (int j = 0; j < kNB; ++j) {
-        if (j < nb) {
-            double v = u[j];
-#pragma unroll
-            for (int i = 0; i < j; ++i) v -= CAs[j * kNB + i] * u[i];
-            u[j] = v;
-            row[order[j0 + j]] = (T)(CAs[kNB * kNB + j] * v);
-        }
-    }
+    const size_t dbl = (size_t)kNB * (kNB + 1) + kNB + kResStride + 8 * kNB;
+    const size_t fl = (size_t)kpad * kNB + 4 * RB * (kNB + 1) + RB * (kNB + 1) + 4;
+    return dbl * 8 + fl * 4 + 16;
 }
 
 // ---------------------------------------------------------------- generic path
@@ -557,12 +669,15 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         T *abuf = reinterpret_cast<T *>(ws + L.off_a);
         double *partial = reinterpret_cast<double *>(ws + L.off_partial);
         double *Tp = reinterpret_cast<double *>(ws + L.off_Tp);
-        hipLaunchKernelGGL((bcd_prepare_kernel<T>), dim3(k), dim3(256), sizeof(int32_t) * (size_t)k, stream, a.C,
-                           a.order, k, CP, cdiag, frozen);
+        double *coef_all = reinterpret_cast<double *>(ws + L.off_coef);
+        double *CA[2] = {Tp, Tp + kResStride};
+        unsigned int *counter = reinterpret_cast<unsigned int *>(Tp + 2 * kResStride);
+        hipLaunchKernelGGL((bcd_prepare_kernel<T>), dim3(k > kNB ? k : kNB), dim3(256), sizeof(int32_t) * (size_t)k,
+                           stream, a.C, a.order, k, CP, cdiag, frozen, coef_all, counter);
         MODL_LAUNCH_CHECK();
         ++nl;
         const bool fused = std::is_same<T, float>::value && (k % 4 == 0) && k <= 512;
-        const int RT = (s <= 2048) ? 1 : 2;
+        const int RT = (s <= 256) ? 1 : 2;
         const int nslab = fused ? (int)cdiv(s, 32 * RT) : (int)cdiv(s, kGramRows);
         const int GPW = (k <= 256) ? 8 : 16;
         void (*blk)(BcdBlockArgs) = nullptr;
@@ -572,18 +687,28 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(blk), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024));
         }
-        for (int j0 = 0; j0 < k; j0 += kNB) {
+        int blk_i = 0, j0_prev = 0, nb_prev = 0;
+        for (int j0 = 0; j0 < k; j0 += kNB, ++blk_i) {
             const int nb = (k - j0 < kNB) ? k - j0 : kNB;
+            double *CAcur = CA[blk_i & 1], *CAprev = blk_i ? CA[(blk_i - 1) & 1] : nullptr;
             if (fused) {
                 BcdBlockArgs ba;
-                ba.Dt = reinterpret_cast<const float *>(a.Dt); ba.Bt = reinterpret_cast<const float *>(a.Bt);
+                ba.Dt = reinterpret_cast<float *>(a.Dt); ba.Bt = reinterpret_cast<const float *>(a.Bt);
                 ba.CP = reinterpret_cast<const float *>(CP); ba.cdiag = reinterpret_cast<const float *>(cdiag);
                 ba.frozen = frozen; ba.subset = a.subset; ba.order = a.order;
-                ba.a = reinterpret_cast<float *>(abuf); ba.partial = partial; ba.s = s; ba.k = k; ba.j0 = j0; ba.nb = nb;
+                ba.a = reinterpret_cast<float *>(abuf); ba.partial = partial; ba.coef_all = coef_all;
+                ba.CA_prev = CAprev; ba.CA_out = CAcur; ba.comp_norm = reinterpret_cast<float *>(a.comp_norm);
+                ba.counter = counter; ba.stamps = reinterpret_cast<unsigned long long *>(counter + 16); ba.s = s; ba.k = k; ba.j0 = j0; ba.nb = nb; ba.j0_prev = j0_prev; ba.nb_prev = nb_prev;
                 hipLaunchKernelGGL(blk, dim3(nslab), dim3(256), bcd_block_lds(GPW, RT), stream, ba);
                 MODL_LAUNCH_CHECK();
                 ++nl;
             } else {
+                if (CAprev) {
+                    hipLaunchKernelGGL((bcd_apply_kernel<T>), dim3((unsigned)cdiv(s, 64)), dim3(256), 0, stream, abuf,
+                                       CAprev, a.Dt, a.subset, a.order, s, k, j0_prev, nb_prev);
+                    MODL_LAUNCH_CHECK();
+                    ++nl;
+                }
                 Operand A, B;
                 A.ptr = a.Dt; A.si = k; A.sk = 1; A.gi = gather32(a.subset);
                 B.ptr = CP + j0; B.si = 1; B.sk = k;         // B(n = jj, kk = m) = CP[m][j0 + jj]
@@ -593,16 +718,18 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                 hipLaunchKernelGGL((bcd_gram_kernel<T>), dim3(nslab), dim3(256), 0, stream, abuf, a.Dt, a.subset,
                                    a.order, s, k, j0, nb, partial);
                 MODL_LAUNCH_CHECK();
-                ++nl;
+                hipLaunchKernelGGL((bcd_resolve_kernel<T>), dim3(1), dim3(256), 0, stream, partial, nslab, coef_all,
+                                   a.order, k, j0, nb, a.comp_norm, CAcur);
+                MODL_LAUNCH_CHECK();
+                nl += 2;
             }
-            hipLaunchKernelGGL((bcd_resolve_kernel<T>), dim3(1), dim3(1024), 0, stream, partial, nslab, a.C, a.order,
-                               frozen, k, j0, nb, a.comp_norm, Tp);
-            MODL_LAUNCH_CHECK();
-            hipLaunchKernelGGL((bcd_apply_kernel<T>), dim3((unsigned)cdiv(s, 256)), dim3(256), 0, stream, abuf, Tp, a.Dt,
-                               a.subset, a.order, s, k, j0, nb);
-            MODL_LAUNCH_CHECK();
-            nl += 2;
+            j0_prev = j0; nb_prev = nb;
         }
+        // the last block's atoms
+        hipLaunchKernelGGL((bcd_apply_kernel<T>), dim3((unsigned)cdiv(s, 64)), dim3(256), 0, stream, abuf,
+                           CA[(blk_i - 1) & 1], a.Dt, a.subset, a.order, s, k, j0_prev, nb_prev);
+        MODL_LAUNCH_CHECK();
+        ++nl;
     } else {
         return dict_update_generic<T>(stream, a, launches);
     }

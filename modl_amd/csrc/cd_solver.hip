@@ -46,42 +46,16 @@ __device__ __forceinline__ void load_row(const T *__restrict__ row, int k, int l
     }
 }
 
-// One coordinate (dict_fact_fast.pyx:354-386).  All scalars are wave-uniform (v_readlane);
-// the H update is unconditional: with a zero coefficient the fused multiply-add returns H.
-template <typename T, int KPL, int C>
-__device__ __forceinline__ void cd_coordinate(int li, int lane, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
-                                              const T (&dg)[KPL], const T (&inv)[KPL], const T (&row)[KPL], T alpha,
-                                              bool positive, T &w_max, T &d_w_max) {
-    const T Qii = bcast_lane(dg[C], li);
-    const T rinv = bcast_lane(inv[C], li);
-    const T w_ii = bcast_lane(w[C], li);
-    const T qii = bcast_lane(q[C], li);
-    T Hii = bcast_lane(H[C], li);
-    Hii = fma(-w_ii, Qii, Hii);                               // H[ii] after "H -= w_ii * Q[ii]" (:361-365)
-    const T tmp = qii - Hii;                                  // :367
-    T mag = fabs(tmp) - alpha;                                // :372 soft threshold
-    mag = mag > (T)0 ? mag : (T)0;
-    T wn = copysign(mag * rinv, tmp);
-    if (positive && tmp < (T)0) wn = 0;
-    if (Qii == (T)0) wn = w_ii;                               // :357 coordinate skipped (rinv = 0 there)
-    const T dwn = (Qii == (T)0) ? (T)0 : wn;                  // a skipped coordinate leaves H untouched
-    const T dwo = (Qii == (T)0) ? (T)0 : w_ii;
-#pragma unroll
-    for (int c = 0; c < KPL; ++c) H[c] = fma(dwn, row[c], fma(-dwo, row[c], H[c]));   // :361-365, :375-378
-    if (lane == li) w[C] = wn;
-    if (Qii != (T)0) {
-        const T d = fabs(wn - w_ii);
-        d_w_max = d > d_w_max ? d : d_w_max;
-        const T aw = fabs(wn);
-        w_max = aw > w_max ? aw : w_max;
-    }
-}
-
-template <typename T, int KPL, int PG, int C0, bool VEC>
+// A chunk of PG consecutive coordinates (dict_fact_fast.pyx:354-386).  They all live in lane `li`
+// (registers C0 .. C0+PG-1), so the chunk's Gauss-Seidel recurrence is run on wave-uniform scalars:
+// the PG entries of H it needs are read once (v_readlane), and after each coordinate the later ones
+// are advanced with the same two fused multiply-adds the vector update applies to lane li — the
+// values stay bit-identical to the vector H.  The k-wide H update (two FMAs per register and
+// coordinate) is off the dependency chain.  A zero diagonal skips the coordinate (:357).
+template <typename T, int KPL, int PG, int C0, bool VEC, bool POSITIVE>
 __device__ __forceinline__ void cd_chunk(int li, int n_li, int lane, int k, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
-                                         const T (&dg)[KPL], const T (&inv)[KPL], T (&cur)[PG][KPL],
-                                         T (&nxt)[PG][KPL], const T *__restrict__ Q, T alpha, bool positive,
-                                         T &w_max, T &d_w_max) {
+                                         const T (&inv)[KPL], T (&cur)[PG][KPL], T (&nxt)[PG][KPL],
+                                         const T *__restrict__ Q, T alpha, T &w_max, T &d_w_max) {
     const int ii0 = li * KPL + C0;
     // prefetch the rows of the next chunk (wraps to row 0 for the next sweep)
     int nxt0 = ii0 + PG;
@@ -91,23 +65,41 @@ __device__ __forceinline__ void cd_chunk(int li, int n_li, int lane, int k, T (&
         const int rn = (nxt0 + j < k) ? nxt0 + j : 0;
         load_row<T, KPL, VEC>(Q + (int64_t)rn * k, k, lane, n_li, nxt[j]);
     }
-    if (ii0 + PG <= k) {
-        cd_coordinate<T, KPL, C0 + 0>(li, lane, w, H, q, dg, inv, cur[0], alpha, positive, w_max, d_w_max);
-        if constexpr (PG > 1)
-            cd_coordinate<T, KPL, C0 + 1>(li, lane, w, H, q, dg, inv, cur[1], alpha, positive, w_max, d_w_max);
-        if constexpr (PG > 2) {
-            cd_coordinate<T, KPL, C0 + 2>(li, lane, w, H, q, dg, inv, cur[2], alpha, positive, w_max, d_w_max);
-            cd_coordinate<T, KPL, C0 + 3>(li, lane, w, H, q, dg, inv, cur[3], alpha, positive, w_max, d_w_max);
+    T h[PG], wo[PG], qq[PG], ri[PG], wn[PG], Qb[PG][PG];
+#pragma unroll
+    for (int c = 0; c < PG; ++c) {
+        h[c] = bcast_lane(H[C0 + c], li);
+        wo[c] = bcast_lane(w[C0 + c], li);
+        qq[c] = bcast_lane(q[C0 + c], li);
+        ri[c] = (ii0 + c < k) ? bcast_lane(inv[C0 + c], li) : (T)0;      // 0: skipped coordinate
+#pragma unroll
+        for (int c2 = c; c2 < PG; ++c2) Qb[c][c2] = bcast_lane(cur[c][C0 + c2], li);
+    }
+#pragma unroll
+    for (int c = 0; c < PG; ++c) {
+        const bool live = ri[c] != (T)0;
+        const T Hii = fma(-wo[c], Qb[c][c], h[c]);                // H[ii] after "H -= w_ii * Q[ii]" (:361-365)
+        const T tmp = qq[c] - Hii;                                // :367
+        T mag = fabs(tmp) - alpha;                                // :372 soft threshold
+        mag = mag > (T)0 ? mag : (T)0;
+        T x = copysign(mag * ri[c], tmp);
+        if (POSITIVE && tmp < (T)0) x = 0;
+        wn[c] = live ? x : wo[c];
+        const T dn = live ? x : (T)0, dold = live ? wo[c] : (T)0;
+#pragma unroll
+        for (int c2 = c + 1; c2 < PG; ++c2) h[c2] = fma(dn, Qb[c][c2], fma(-dold, Qb[c][c2], h[c2]));
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) H[r] = fma(dn, cur[c][r], fma(-dold, cur[c][r], H[r]));   // :361-365, :375-378
+        if (live) {
+            const T d = fabs(x - wo[c]);
+            d_w_max = d > d_w_max ? d : d_w_max;
+            const T aw = fabs(x);
+            w_max = aw > w_max ? aw : w_max;
         }
-    } else {                                                   // ragged tail of the last lane
-        if (ii0 + 0 < k) cd_coordinate<T, KPL, C0 + 0>(li, lane, w, H, q, dg, inv, cur[0], alpha, positive, w_max, d_w_max);
-        if constexpr (PG > 1) {
-            if (ii0 + 1 < k) cd_coordinate<T, KPL, C0 + 1>(li, lane, w, H, q, dg, inv, cur[1], alpha, positive, w_max, d_w_max);
-        }
-        if constexpr (PG > 2) {
-            if (ii0 + 2 < k) cd_coordinate<T, KPL, C0 + 2>(li, lane, w, H, q, dg, inv, cur[2], alpha, positive, w_max, d_w_max);
-            if (ii0 + 3 < k) cd_coordinate<T, KPL, C0 + 3>(li, lane, w, H, q, dg, inv, cur[3], alpha, positive, w_max, d_w_max);
-        }
+    }
+    if (lane == li) {
+#pragma unroll
+        for (int c = 0; c < PG; ++c) w[C0 + c] = wn[c];
     }
 #pragma unroll
     for (int j = 0; j < PG; ++j)
@@ -115,7 +107,7 @@ __device__ __forceinline__ void cd_chunk(int li, int n_li, int lane, int k, T (&
         for (int c = 0; c < KPL; ++c) cur[j][c] = nxt[j][c];
 }
 
-template <typename T, int KPL, bool VEC>
+template <typename T, int KPL, bool VEC, bool POSITIVE>
 __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
     constexpr int PG = (KPL >= 4) ? 4 : KPL;     // rows per prefetch chunk
     const int lane = threadIdx.x & 63;
@@ -129,7 +121,7 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
     const int e0 = lane * KPL;
     const int n_li = (k + KPL - 1) / KPL;          // lanes that own coefficients
     const T alpha = a.alpha, beta = a.beta;
-    const bool positive = a.positive != 0;
+    constexpr bool positive = POSITIVE;
 
     T w[KPL], H[KPL], q[KPL], dg[KPL], inv[KPL];
 #pragma unroll
@@ -177,12 +169,12 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
     for (; n_iter < a.max_iter; ++n_iter) {
         T w_max = 0, d_w_max = 0;
         for (int li = 0; li < n_li; ++li) {
-            cd_chunk<T, KPL, PG, 0, VEC>(li, n_li, lane, k, w, H, q, dg, inv, cur, nxt, Q, alpha, positive, w_max, d_w_max);
+            cd_chunk<T, KPL, PG, 0, VEC, POSITIVE>(li, n_li, lane, k, w, H, q, inv, cur, nxt, Q, alpha, w_max, d_w_max);
             if constexpr (KPL > 4)
-                cd_chunk<T, KPL, PG, 4, VEC>(li, n_li, lane, k, w, H, q, dg, inv, cur, nxt, Q, alpha, positive, w_max, d_w_max);
+                cd_chunk<T, KPL, PG, 4, VEC, POSITIVE>(li, n_li, lane, k, w, H, q, inv, cur, nxt, Q, alpha, w_max, d_w_max);
             if constexpr (KPL > 8) {
-                cd_chunk<T, KPL, PG, 8, VEC>(li, n_li, lane, k, w, H, q, dg, inv, cur, nxt, Q, alpha, positive, w_max, d_w_max);
-                cd_chunk<T, KPL, PG, 12, VEC>(li, n_li, lane, k, w, H, q, dg, inv, cur, nxt, Q, alpha, positive, w_max, d_w_max);
+                cd_chunk<T, KPL, PG, 8, VEC, POSITIVE>(li, n_li, lane, k, w, H, q, inv, cur, nxt, Q, alpha, w_max, d_w_max);
+                cd_chunk<T, KPL, PG, 12, VEC, POSITIVE>(li, n_li, lane, k, w, H, q, inv, cur, nxt, Q, alpha, w_max, d_w_max);
             }
         }
         if (w_max == (T)0 || d_w_max / w_max < d_w_tol || n_iter == a.max_iter - 1) {   // :388
@@ -231,8 +223,13 @@ static void launch_cd_kpl(hipStream_t stream, const CdArgs<T> &a, dim3 grid, dim
     constexpr size_t kRowAlign = (KPL * sizeof(T) >= 16) ? 16 : KPL * sizeof(T);
     const bool vec = (a.k % KPL == 0) && (reinterpret_cast<uintptr_t>(a.G) % kRowAlign == 0) &&
                      ((a.g_stride * sizeof(T)) % kRowAlign == 0) && (((size_t)a.k * sizeof(T)) % kRowAlign == 0);
-    if (vec) hipLaunchKernelGGL((cd_kernel<T, KPL, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((cd_kernel<T, KPL, false>), grid, block, 0, stream, a);
+    if (vec) {
+        if (a.positive) hipLaunchKernelGGL((cd_kernel<T, KPL, true, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((cd_kernel<T, KPL, true, false>), grid, block, 0, stream, a);
+    } else {
+        if (a.positive) hipLaunchKernelGGL((cd_kernel<T, KPL, false, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((cd_kernel<T, KPL, false, false>), grid, block, 0, stream, a);
+    }
 }
 
 template <typename T>

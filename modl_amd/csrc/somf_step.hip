@@ -680,6 +680,15 @@ int modl_somf_transform(modl_somf_plan *pl, const void *d_Dt, const void *d_G, c
                                            (hipStream_t)stream));
 }
 
+int modl_somf_debug_stamps(modl_somf_plan *pl, unsigned long long *h_out) {
+    // diagnostics only: phase timestamps (shader clock) left by the last fused dictionary-update launch
+    if (!pl || !h_out) return MODL_EINVAL;
+    MODL_HIP(hipDeviceSynchronize());
+    const size_t off = modl::dict_update_stamps_offset(pl->d.dtype, pl->d.p, pl->d.k);
+    MODL_HIP(hipMemcpy(h_out, pl->dws + pl->off_du + off, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return MODL_OK;
+}
+
 int modl_somf_last_sweeps(modl_somf_plan *pl, int32_t *h_out, int cap, int *n_out, void *stream) {
     if (!pl || !h_out || !n_out) return MODL_EINVAL;
     const int n = pl->last_b < cap ? pl->last_b : cap;
