@@ -162,6 +162,9 @@ class HipBackend:
             self.G = torch.zeros((self.k, self.k), dtype=torch_dtype(self.dtype), device=self.device)
         check(lib.modl_somf_full_gram(self.plan, ptr(self.Dt), ptr(self.G), stream_ptr(self.device)), 'modl_somf_full_gram')
 
+    def n_rows(self, name):
+        return getattr(self, name).shape[0]
+
     def shuffle_rows(self, name, swaps):
         t = getattr(self, name)
         row_bytes = t[0].numel() * t.element_size()
@@ -263,7 +266,7 @@ class _DeviceRows:
         self.backend, self.name = backend, name
 
     def __len__(self):
-        return getattr(self.backend, self.name).shape[0]
+        return self.backend.n_rows(self.name)
 
     def _modl_device_rows(self, swaps):
         self.backend.shuffle_rows(self.name, swaps)
