@@ -1,0 +1,139 @@
+"""fMRIDictFact on raw 2-D records: the streaming loop of the reference's
+fMRI estimator (modl/decomposition/fmri.py:423-546 `_compute_components`, :549-556
+`_flip`, :364-367 the ridge `Coder`) without the nilearn masking layer, which is
+IO and out of scope.  A record is what the
+reference's `MultiRawMasker` yields (modl/input_data/fmri/unmask.py:37-55): a
+2-D array (time points x voxels) or the path of a .npy file holding one."""
+import time
+from math import sqrt
+
+import numpy as np
+from sklearn.base import BaseEstimator
+from sklearn.utils import check_random_state
+
+from .dict_fact import DictFact, Coder
+
+METHODS = {'masked': {'G_agg': 'masked', 'Dx_agg': 'masked'},           # fmri.py:440-445
+           'dictionary only': {'G_agg': 'full', 'Dx_agg': 'full'},
+           'gram': {'G_agg': 'masked', 'Dx_agg': 'masked'},             # first epochs; switched at epoch 5
+           'average': {'G_agg': 'average', 'Dx_agg': 'average'},
+           'reducing ratio': {'G_agg': 'masked', 'Dx_agg': 'masked'}}
+
+
+def _load(record, mmap=False):
+    if isinstance(record, str):
+        return np.load(record, mmap_mode='r' if mmap else None)
+    return record
+
+
+def _flip(components):
+    """Flip a map when its negative part is larger (fmri.py:549-556)."""
+    components = components.copy()
+    for component in components:
+        if np.sum(component < 0) > np.sum(component > 0):
+            component *= -1
+    return components
+
+
+class fMRIDictFact(BaseEstimator):
+    """Constructor arguments follow fmri.py:273-291 (masking arguments dropped)."""
+
+    _dict_fact_class = DictFact
+    _coder_class = Coder
+
+    def __init__(self, method='masked', step_size=1, n_components=20, n_epochs=1, alpha=0.1, dict_init=None,
+                 random_state=None, batch_size=20, reduction=1, learning_rate=1, positive=False, verbose=0,
+                 callback=None, n_jobs=1):
+        self.method = method
+        self.step_size = step_size
+        self.n_components = n_components
+        self.n_epochs = n_epochs
+        self.alpha = alpha
+        self.dict_init = dict_init
+        self.random_state = random_state
+        self.batch_size = batch_size
+        self.reduction = reduction
+        self.learning_rate = learning_rate
+        self.positive = positive
+        self.verbose = verbose
+        self.callback = callback
+        self.n_jobs = n_jobs
+
+    def fit(self, records, y=None):
+        """records: list of 2-D arrays / .npy paths.  fmri.py:423-546."""
+        if records is None:
+            raise ValueError('records is None, use Coder instead')
+        n_components = self.n_components
+        dict_init = self.dict_init
+        if dict_init is not None:                                    # fmri.py:415-416, 468-469
+            dict_init = np.asarray(dict_init)[:n_components]
+            n_components = dict_init.shape[0]
+        random_state = check_random_state(self.random_state)
+        reduction = self.reduction
+        if self.method == 'sgd':
+            optimizer, G_agg, Dx_agg, reduction = 'sgd', 'full', 'full', 1
+        else:
+            G_agg, Dx_agg = METHODS[self.method]['G_agg'], METHODS[self.method]['Dx_agg']
+            optimizer = 'variational'
+        n_records = len(records)
+        lengths, dtype, n_voxels = [], None, None
+        for rec in records:                                          # _lazy_scan, fmri.py:559-575
+            arr = _load(rec, mmap=True)
+            lengths.append(arr.shape[0])
+            dtype, n_voxels = arr.dtype, arr.shape[1]
+        indices_list = np.zeros(n_records + 1, dtype='int')
+        indices_list[1:] = np.cumsum(lengths)
+        n_samples = int(indices_list[-1]) + 1                        # fmri.py:476 (the + 1 is the reference's)
+        if dtype not in (np.float32, np.float64):
+            dtype = np.dtype(np.float64)
+        dict_fact = self._dict_fact_class(
+            n_components=n_components, code_alpha=self.alpha, code_l1_ratio=0, comp_l1_ratio=1,
+            comp_pos=self.positive, reduction=reduction, Dx_agg=Dx_agg, optimizer=optimizer, step_size=self.step_size,
+            G_agg=G_agg, learning_rate=self.learning_rate, batch_size=self.batch_size, random_state=random_state,
+            n_threads=self.n_jobs, verbose=0)
+        dict_fact.prepare(n_samples=n_samples, n_features=n_voxels,
+                          X=None if dict_init is None else dict_init.astype(dtype), dtype=dtype)
+        self.cpu_time_, self.io_time_ = 0.0, 0.0
+        if n_records > 0:
+            verbose_iter_ = np.linspace(0, n_records * self.n_epochs, self.verbose).tolist() if self.verbose else []
+            current_n_records = 0
+            for i in range(self.n_epochs):
+                if self.method == 'gram' and i == 5:
+                    dict_fact.set_params(G_agg='full', Dx_agg='average')
+                if self.method == 'reducing ratio':
+                    reduction = 1 + (reduction - 1) / sqrt(i + 1)    # compounds across epochs (fmri.py:511-513)
+                    dict_fact.set_params(reduction=reduction)
+                record_list = random_state.permutation(n_records)
+                for record in record_list:
+                    if self.verbose and verbose_iter_ and current_n_records >= verbose_iter_[0]:
+                        print('Record %i' % current_n_records)
+                        if self.callback is not None:
+                            self.callback(self, dict_fact, self.cpu_time_, self.io_time_)
+                        verbose_iter_ = verbose_iter_[1:]
+                    t0 = time.perf_counter()
+                    data = np.asarray(_load(records[record])).astype(dtype)
+                    self.io_time_ += time.perf_counter() - t0
+                    t0 = time.perf_counter()
+                    permutation = random_state.permutation(data.shape[0])
+                    if self.method in ['average', 'gram']:
+                        sample_indices = np.arange(indices_list[record], indices_list[record + 1])[permutation]
+                    else:
+                        sample_indices = None
+                    dict_fact.partial_fit(data[permutation], sample_indices=sample_indices)
+                    current_n_records += 1
+                    self.cpu_time_ += time.perf_counter() - t0
+        self.dict_fact_ = dict_fact
+        self.components_ = _flip(dict_fact.components_)
+        self.coder_ = self._coder_class(dictionary=self.components_, code_alpha=self.alpha, code_l1_ratio=0).fit()
+        return self
+
+    def transform(self, records):
+        """Loadings of each record on the learned maps (fmri.py:131-164)."""
+        return [self.coder_.transform(np.asarray(_load(r))) for r in records]
+
+    def score(self, records):
+        """Length-weighted mean objective (fmri.py:95-129)."""
+        arrays = [np.asarray(_load(r)) for r in records]
+        scores = np.array([self.coder_.score(a) for a in arrays])
+        lens = np.array([a.shape[0] for a in arrays])
+        return np.sum(scores * lens) / np.sum(lens)

@@ -1,0 +1,239 @@
+"""ImageDictFact: dictionary learning on image patches (reference:
+modl/decomposition/image.py:13-224), driving modl_amd.DictFact's
+prepare / partial_fit / shuffle / set_params exactly as the reference does
+(image.py:96-152).  Patch extraction and normalisation are host code here
+(reference: modl/feature_extraction/image.py:8-83, modl/input_data/image.py:4-23,
+image_fast.pyx:12-74); the per-minibatch SOMF step runs on the GPU."""
+import time
+from math import sqrt
+
+import numpy as np
+from numpy.lib.stride_tricks import sliding_window_view
+from sklearn.base import BaseEstimator
+from sklearn.utils import check_random_state, gen_batches
+
+from .dict_fact import DictFact
+
+
+def scale_patches(X, with_mean=True, with_std=True, channel_wise=True, copy=True):
+    """Centre / normalise patches (n, ph, pw, c) — modl/input_data/image.py:4-23."""
+    if copy:
+        X = X.copy()
+    if with_mean:
+        if channel_wise:
+            X -= np.mean(X, axis=(1, 2))[:, np.newaxis, np.newaxis, :]
+        else:
+            X -= np.mean(X, axis=(1, 2, 3))[:, np.newaxis, np.newaxis, np.newaxis]
+    if with_std:
+        if channel_wise:
+            n_channel = X.shape[3]
+            std = np.sqrt(np.sum(X ** 2, axis=(1, 2)))
+            std[std == 0] = 1
+            X /= std[:, np.newaxis, np.newaxis, :] * sqrt(n_channel)
+        else:
+            std = np.sqrt(np.sum(X ** 2, axis=(1, 2, 3)))
+            std[std == 0] = 1
+            X /= std[:, np.newaxis, np.newaxis, np.newaxis]
+    return X
+
+
+def fill(p, q, r):
+    """All patch coordinates in C order (image_fast.pyx:59-74)."""
+    return np.stack(np.meshgrid(np.arange(p), np.arange(q), np.arange(r), indexing='ij'), axis=-1).reshape(-1, 3)
+
+
+def clean_mask(patches, image):
+    """Coordinates of the patches without any missing (-1) pixel (image_fast.pyx:12-57)."""
+    p, q, r = patches.shape[:3]
+    x, y, z = patches.shape[3:]
+    bad = (image == -1)
+    win = sliding_window_view(bad, (x, y, z))            # (p, q, r, x, y, z)
+    take = ~win.any(axis=(3, 4, 5))
+    return np.argwhere(take)
+
+
+class LazyCleanPatchExtractor(BaseEstimator):
+    """modl/feature_extraction/image.py:8-83"""
+
+    def __init__(self, patch_size=None, random_state=None, max_patches=None):
+        self.patch_size = patch_size
+        self.max_patches = max_patches
+        self.random_state = random_state
+
+    def fit(self, X, y=None):
+        self.random_state = check_random_state(self.random_state)
+        i_h, i_w, n_channels = X.shape
+        patch_size = (i_h // 10, i_w // 10) if self.patch_size is None else self.patch_size
+        patch_shape = (patch_size[0], patch_size[1], n_channels)
+        self.patches_ = sliding_window_view(X, patch_shape)       # == sklearn extract_patches, step 1
+        if not np.all(X != -1):
+            self.indices_3d = clean_mask(self.patches_, X)
+        else:
+            self.indices_3d = fill(*self.patches_.shape[:3])
+        n_samples = self.indices_3d.shape[0]
+        selection = self.random_state.permutation(n_samples)[:self.max_patches]
+        self.indices_3d = self.indices_3d[selection]
+        return self
+
+    def partial_transform(self, X=None, batch=None):
+        if X is not None:
+            self.fit(X)
+        if batch is None:
+            return self.transform()
+        if isinstance(batch, int):
+            batch = slice(0, batch)
+        return self.patches_[tuple(self.indices_3d[batch].T)]
+
+    def transform(self, X=None):
+        if X is not None:
+            self.fit(X)
+        return self.patches_[tuple(self.indices_3d.T)]
+
+    def shuffle(self, permutation=None):
+        if permutation is None:
+            permutation = self.random_state.permutation(self.indices_3d.shape[0])
+        self.indices_3d = self.indices_3d[permutation]
+
+    @property
+    def n_patches_(self):
+        return self.indices_3d.shape[0]
+
+    @property
+    def patch_shape_(self):
+        return self.patches_.shape[-3:]
+
+
+def _flatten_patches(patches, with_mean=True, with_std=True, copy=False):
+    n_patches = patches.shape[0]
+    patches = scale_patches(patches, with_mean=with_mean, with_std=with_std, copy=copy)
+    return patches.reshape((n_patches, -1))
+
+
+class ImageDictFact(BaseEstimator):
+    methods = {'masked': {'G_agg': 'masked', 'Dx_agg': 'masked'},
+               'dictionary only': {'G_agg': 'full', 'Dx_agg': 'full'},
+               'gram': {'G_agg': 'masked', 'Dx_agg': 'masked'},      # first epochs; switched at epoch 4
+               'average': {'G_agg': 'average', 'Dx_agg': 'average'},
+               'reducing ratio': {'G_agg': 'masked', 'Dx_agg': 'masked'}}
+
+    settings = {'dictionary learning': {'comp_l1_ratio': 0, 'code_l1_ratio': 1, 'comp_pos': False,
+                                        'code_pos': False, 'with_std': True, 'with_mean': True},
+                'NMF': {'comp_l1_ratio': 0, 'code_l1_ratio': 1, 'comp_pos': True, 'code_pos': True,
+                        'with_std': True, 'with_mean': False}}
+
+    def __init__(self, method='masked', setting='dictionary learning', patch_size=(8, 8), batch_size=100,
+                 buffer_size=None, step_size=1e-3, n_components=50, alpha=0.1, learning_rate=0.92, reduction=10,
+                 n_epochs=1, random_state=None, callback=None, max_patches=None, verbose=0, n_threads=1):
+        self.n_threads = n_threads
+        self.step_size = step_size
+        self.verbose = verbose
+        self.callback = callback
+        self.random_state = random_state
+        self.n_epochs = n_epochs
+        self.reduction = reduction
+        self.learning_rate = learning_rate
+        self.alpha = alpha
+        self.n_components = n_components
+        self.batch_size = batch_size
+        self.method = method
+        self.setting = setting
+        self.patch_size = patch_size
+        self.buffer_size = buffer_size
+        self.max_patches = max_patches
+
+    _dict_fact_class = DictFact
+
+    def fit(self, image, y=None):
+        """image.py:68-153"""
+        self.random_state = check_random_state(self.random_state)
+        if self.method != 'sgd':
+            method = ImageDictFact.methods[self.method]
+            G_agg, Dx_agg = method['G_agg'], method['Dx_agg']
+            reduction = self.reduction
+            optimizer = 'variational'
+        else:
+            optimizer, reduction, G_agg, Dx_agg = 'sgd', 1, 'full', 'full'
+        setting = ImageDictFact.settings[self.setting]
+        with_std, with_mean = setting['with_std'], setting['with_mean']
+        buffer_size = self.batch_size * 10 if self.buffer_size is None else self.buffer_size
+
+        self.dict_fact_ = self._dict_fact_class(
+            n_epochs=self.n_epochs, random_state=self.random_state, n_components=self.n_components,
+            comp_l1_ratio=setting['comp_l1_ratio'], learning_rate=self.learning_rate, comp_pos=setting['comp_pos'],
+            optimizer=optimizer, step_size=self.step_size, code_pos=setting['code_pos'], batch_size=self.batch_size,
+            G_agg=G_agg, Dx_agg=Dx_agg, reduction=reduction, code_alpha=self.alpha,
+            code_l1_ratio=setting['code_l1_ratio'], tol=1e-2, callback=self._callback, verbose=self.verbose,
+            n_threads=self.n_threads)
+
+        patch_extractor = LazyCleanPatchExtractor(patch_size=self.patch_size, max_patches=self.max_patches,
+                                                  random_state=self.random_state)
+        patch_extractor.fit(image)
+        n_patches = patch_extractor.n_patches_
+        self.patch_shape_ = patch_extractor.patch_shape_
+
+        init_patches = patch_extractor.partial_transform(batch=self.n_components)
+        init_patches = _flatten_patches(init_patches, with_std=with_std, with_mean=with_mean, copy=True)
+        self.dict_fact_.prepare(n_samples=n_patches, X=init_patches)
+        for i in range(self.n_epochs):
+            if i >= 1:
+                permutation = self.dict_fact_.shuffle()
+                patch_extractor.shuffle(permutation)
+            buffers = gen_batches(n_patches, buffer_size)
+            if self.method == 'gram' and i == 4:
+                self.dict_fact_.set_params(G_agg='full', Dx_agg='average')
+            if self.method == 'reducing ratio':
+                reduction = 1 + (self.reduction - 1) / sqrt(i + 1)
+                self.dict_fact_.set_params(reduction=reduction)
+            for buffer in buffers:
+                patches = patch_extractor.partial_transform(batch=buffer)
+                patches = _flatten_patches(patches, with_mean=with_mean, with_std=with_std, copy=True)
+                self.dict_fact_.partial_fit(patches, buffer)
+        return self
+
+    def _prep(self, patches):
+        s = ImageDictFact.settings[self.setting]
+        return _flatten_patches(np.asarray(patches), with_mean=s['with_mean'], with_std=s['with_std'], copy=True)
+
+    def transform(self, patches):
+        return self.dict_fact_.transform(self._prep(patches))
+
+    def score(self, patches):
+        return self.dict_fact_.score(self._prep(patches))
+
+    @property
+    def n_iter_(self):
+        return self.dict_fact_.n_iter_
+
+    @property
+    def time_(self):
+        return self.dict_fact_.time_
+
+    @property
+    def components_(self):
+        return self.dict_fact_.components_.reshape((self.n_components,) + tuple(self.patch_shape_))
+
+    def _callback(self, *args):
+        if self.callback is not None:
+            self.callback(self)
+
+
+class DictionaryScorer:
+    """image.py:202-225 (time.clock is gone from Python 3.8: perf_counter)."""
+
+    def __init__(self, test_data, info=None):
+        self.start_time = time.perf_counter()
+        self.test_data = test_data
+        self.test_time = 0
+        self.time, self.cpu_time, self.score, self.iter = [], [], [], []
+        self.info = info
+
+    def __call__(self, dict_fact):
+        t0 = time.perf_counter()
+        score = dict_fact.score(self.test_data)
+        self.test_time += time.perf_counter() - t0
+        self.time.append(time.perf_counter() - self.start_time - self.test_time)
+        self.score.append(score)
+        self.iter.append(dict_fact.n_iter_)
+        self.cpu_time.append(dict_fact.time_)
+        if self.info is not None:
+            self.info['time'], self.info['score'], self.info['iter'] = self.cpu_time, self.score, self.iter

@@ -33,7 +33,7 @@ def build_reference():
         return
     if os.path.isdir(SCRATCH):
         shutil.rmtree(SCRATCH)
-    for d in ('decomposition', 'utils/math', 'utils/randomkit', 'utils/recsys'):
+    for d in ('decomposition', 'utils/math', 'utils/randomkit', 'utils/recsys', 'feature_extraction', 'input_data'):
         os.makedirs(os.path.join(pkg, d))
     cp = lambda rel: shutil.copy(os.path.join(REF, rel), os.path.join(pkg, rel))
     for f in ('dict_fact.py', 'dict_fact_fast.pyx', 'recsys.py', 'recsys_fast.pyx'):
@@ -45,7 +45,14 @@ def build_reference():
               'randomkit.c', 'randomkit.h', 'distributions.c', 'distributions.h'):
         cp('utils/randomkit/' + f)
     cp('utils/recsys/cross_validation.py')
-    for d in ('', 'decomposition', 'utils/math', 'utils/recsys'):
+    for f in ('decomposition/image.py', 'feature_extraction/image.py', 'input_data/image.py', 'input_data/image_fast.pyx'):
+        cp(f)
+    # sklearn made extract_patches private; the scratch copy (never the repository) is pointed at it
+    fe = os.path.join(pkg, 'feature_extraction', 'image.py')
+    src = open(fe).read().replace('from sklearn.feature_extraction.image import extract_patches',
+                                  'from sklearn.feature_extraction.image import _extract_patches as extract_patches')
+    open(fe, 'w').write(src)
+    for d in ('', 'decomposition', 'utils/math', 'utils/recsys', 'feature_extraction', 'input_data'):
         open(os.path.join(pkg, d, '__init__.py'), 'a').close()
     with open(os.path.join(SCRATCH, 'setup_ref.py'), 'w') as f:
         f.write(textwrap.dedent('''
@@ -59,6 +66,7 @@ def build_reference():
                 E('modl.decomposition.dict_fact_fast', ['modl/decomposition/dict_fact_fast.pyx']),
                 E('modl.decomposition.recsys_fast', ['modl/decomposition/recsys_fast.pyx']),
                 E('modl.utils.math.enet', ['modl/utils/math/enet.pyx']),
+                E('modl.input_data.image_fast', ['modl/input_data/image_fast.pyx']),
                 E('modl.utils.randomkit.random_fast',
                   [rk + 'random_fast.pyx', rk + 'randomkit.c', rk + 'distributions.c'], language='c++'),
                 E('modl.utils.randomkit.sampler', [rk + 'sampler.pyx'], language='c++'),
@@ -403,6 +411,59 @@ def gen_recsys():
     save('recsys', **out)
 
 
+def synth_image(h, w, c, seed=0, holes=False):
+    """Sum of 2-D sinusoids + noise in [0, 1]; optional missing (-1) pixels."""
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, c))
+    for ch in range(c):
+        for _ in range(4):
+            fy, fx, ph = rs.uniform(0.05, 0.6), rs.uniform(0.05, 0.6), rs.uniform(0, 6.28)
+            img[:, :, ch] += np.sin(fy * yy + fx * xx + ph)
+    img += 0.05 * rs.randn(h, w, c)
+    img = (img - img.min()) / (img.max() - img.min())
+    if holes:
+        img[rs.rand(h, w) < 0.01] = -1
+    return img
+
+
+def gen_image():
+    import contextlib, io
+    from modl.decomposition.image import ImageDictFact
+    from modl.feature_extraction.image import LazyCleanPatchExtractor
+    from modl.input_data.image import scale_patches
+    out = {}
+    cases = []
+    for name, kw, (h, w, c), holes in (
+            ('masked', dict(method='masked', n_epochs=2, reduction=2), (28, 30, 1), False),
+            ('masked_rgb_holes', dict(method='masked', n_epochs=1, reduction=2), (24, 26, 3), True),
+            ('average', dict(method='average', n_epochs=2, reduction=2), (26, 26, 1), False),
+            ('dict_only', dict(method='dictionary only', n_epochs=1), (26, 26, 1), False),
+            ('reducing', dict(method='reducing ratio', n_epochs=3, reduction=3), (26, 26, 1), False),
+            ('sgd', dict(method='sgd', n_epochs=1, step_size=0.05), (26, 26, 1), False),
+            ('nmf', dict(method='masked', setting='NMF', n_epochs=1, reduction=2), (26, 26, 1), False)):
+        img = synth_image(h, w, c, seed=len(cases), holes=holes)
+        est = ImageDictFact(patch_size=(6, 6), n_components=7, batch_size=25, alpha=0.05, random_state=0,
+                            max_patches=300, **kw)
+        with contextlib.redirect_stdout(io.StringIO()):
+            est.fit(img)
+        out[name + '/D'] = est.components_
+        out[name + '/code'] = est.dict_fact_.code_
+        out[name + '/n_iter'] = np.array(est.n_iter_)
+        test = LazyCleanPatchExtractor(patch_size=(6, 6), max_patches=40, random_state=1).fit(img).transform()
+        out[name + '/test_patches'] = test
+        out[name + '/test_code'] = est.transform(test.copy())
+        out[name + '/test_score'] = np.array(est.score(test.copy()))
+        cases.append(name)
+    img = synth_image(12, 13, 2, seed=9, holes=True)
+    ex = LazyCleanPatchExtractor(patch_size=(3, 4), random_state=0).fit(img)
+    out['extract/indices'] = ex.indices_3d
+    out['extract/patches'] = ex.transform()
+    out['extract/scaled'] = scale_patches(ex.transform(), with_mean=True, with_std=True, copy=True)
+    out['cases'] = np.array(cases)
+    save('image', **out)
+
+
 if __name__ == '__main__':
     build_reference()
     sys.path.insert(0, SCRATCH)
@@ -414,3 +475,4 @@ if __name__ == '__main__':
     gen_transform()
     gen_traj()
     gen_recsys()
+    gen_image()

@@ -1,0 +1,176 @@
+"""ImageDictFact / fMRIDictFact wrapper loops.
+
+CPU (no GPU): the wrappers' host logic with the oracle standing in for the
+device kernels, against the reference's golden outputs (image) and against the
+oracle's own restatement of the fMRI record loop.  GPU (-m gpu): the same
+wrappers on the real device path."""
+import numpy as np
+import pytest
+from numpy.testing import assert_array_equal
+
+from .conftest import load_golden, rel_fro
+
+IMAGE_CASES = {
+    'masked': (dict(method='masked', n_epochs=2, reduction=2), (28, 30, 1), False),
+    'masked_rgb_holes': (dict(method='masked', n_epochs=1, reduction=2), (24, 26, 3), True),
+    'average': (dict(method='average', n_epochs=2, reduction=2), (26, 26, 1), False),
+    'dict_only': (dict(method='dictionary only', n_epochs=1), (26, 26, 1), False),
+    'reducing': (dict(method='reducing ratio', n_epochs=3, reduction=3), (26, 26, 1), False),
+    'sgd': (dict(method='sgd', n_epochs=1, step_size=0.05), (26, 26, 1), False),
+    'nmf': (dict(method='masked', setting='NMF', n_epochs=1, reduction=2), (26, 26, 1), False),
+}
+
+
+def synth_image(h, w, c, seed=0, holes=False):          # mirrors tests/golden/make_golden.py
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, c))
+    for ch in range(c):
+        for _ in range(4):
+            fy, fx, ph = rs.uniform(0.05, 0.6), rs.uniform(0.05, 0.6), rs.uniform(0, 6.28)
+            img[:, :, ch] += np.sin(fy * yy + fx * xx + ph)
+    img += 0.05 * rs.randn(h, w, c)
+    img = (img - img.min()) / (img.max() - img.min())
+    if holes:
+        img[rs.rand(h, w) < 0.01] = -1
+    return img
+
+
+def _host_classes():
+    from modl_amd.dict_fact import DictFact, Coder
+    from .oracle_backend import OracleBackend
+
+    class HostDictFact(DictFact):
+        def _make_backend(self):
+            return OracleBackend()
+
+    class HostCoder(Coder):
+        def _make_backend(self):
+            return OracleBackend()
+    return HostDictFact, HostCoder
+
+
+def _image_estimator(host):
+    from modl_amd.image import ImageDictFact
+    if not host:
+        return ImageDictFact
+    HostDictFact, _ = _host_classes()
+
+    class HostImageDictFact(ImageDictFact):
+        _dict_fact_class = HostDictFact
+    return HostImageDictFact
+
+
+def _fmri_estimator(host):
+    from modl_amd.fmri import fMRIDictFact
+    if not host:
+        return fMRIDictFact
+    HostDictFact, HostCoder = _host_classes()
+
+    class HostfMRIDictFact(fMRIDictFact):
+        _dict_fact_class = HostDictFact
+        _coder_class = HostCoder
+    return HostfMRIDictFact
+
+
+def test_patch_extraction_golden():
+    from modl_amd.image import LazyCleanPatchExtractor, scale_patches
+    g = load_golden('image')
+    img = synth_image(12, 13, 2, seed=9, holes=True)
+    ex = LazyCleanPatchExtractor(patch_size=(3, 4), random_state=0).fit(img)
+    assert_array_equal(ex.indices_3d, g['extract/indices'])
+    assert_array_equal(ex.transform(), g['extract/patches'])
+    np.testing.assert_allclose(scale_patches(ex.transform()), g['extract/scaled'], rtol=1e-13, atol=1e-15)
+
+
+def _check_image_case(name, host):
+    g = load_golden('image')
+    kw, (h, w, c), holes = IMAGE_CASES[name]
+    img = synth_image(h, w, c, seed=list(IMAGE_CASES).index(name), holes=holes)
+    est = _image_estimator(host)(patch_size=(6, 6), n_components=7, batch_size=25, alpha=0.05, random_state=0,
+                                 max_patches=300, **kw)
+    est.fit(img)
+    assert est.n_iter_ == int(g[name + '/n_iter'])
+    assert rel_fro(est.components_, g[name + '/D']) < 1e-9, name
+    assert rel_fro(est.dict_fact_.code_, g[name + '/code']) < 1e-9, name
+    test = g[name + '/test_patches']
+    assert rel_fro(est.transform(test), g[name + '/test_code']) < 1e-9
+    assert abs(est.score(test) - g[name + '/test_score']) < 1e-9 * abs(g[name + '/test_score'])
+
+
+@pytest.mark.parametrize('name', list(IMAGE_CASES))
+def test_image_dict_fact_host_logic(name):
+    _check_image_case(name, host=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', list(IMAGE_CASES))
+def test_image_dict_fact_gpu(name):
+    _check_image_case(name, host=False)
+
+
+def _fmri_records(dtype=np.float64, n_records=5, length=30, p=120, k=4, seed=0):
+    rs = np.random.RandomState(seed)
+    maps = np.zeros((k, p))
+    for j in range(k):
+        maps[j, j * (p // k):(j + 1) * (p // k)] = 1 + rs.rand(p // k)
+    recs = []
+    for _ in range(n_records):
+        x = rs.randn(length, k).dot(maps) + 0.01 * rs.randn(length, p)
+        x = (x - x.mean(0)) / x.std(0)
+        recs.append(np.ascontiguousarray(x.astype(dtype)))
+    dict_init = maps + rs.randn(k, p)                      # as modl/decomposition/tests/test_fmri.py:68
+    return recs, dict_init
+
+
+FMRI_CASES = [dict(method='masked', reduction=3, n_epochs=2), dict(method='average', reduction=2, n_epochs=2),
+              dict(method='dictionary only', n_epochs=1), dict(method='reducing ratio', reduction=4, n_epochs=3),
+              dict(method='masked', reduction=2, n_epochs=1, positive=True), dict(method='gram', reduction=2, n_epochs=7)]
+
+
+def _check_fmri_case(kw, host, with_init=True):
+    from oracle import wrappers_oracle
+    recs, dict_init = _fmri_records()
+    common = dict(n_components=4, alpha=1e-2, batch_size=10, learning_rate=0.92, random_state=0,
+                  dict_init=dict_init if with_init else None)
+    est = _fmri_estimator(host)(**common, **kw)
+    est.fit(recs)
+    D_ref, st = wrappers_oracle.fmri_fit(recs, **common, **kw)
+    assert rel_fro(est.components_, D_ref) < 1e-9, kw
+    assert rel_fro(est.dict_fact_.code_, st.code) < 1e-9
+    codes = est.transform(recs[:2])
+    assert codes[0].shape == (30, 4) and np.isfinite(est.score(recs))
+    # the sign convention of _flip (fmri.py:549-556)
+    for comp in est.components_:
+        assert np.sum(comp < 0) <= np.sum(comp > 0)
+
+
+@pytest.mark.parametrize('kw', FMRI_CASES, ids=lambda kw: kw['method'] + ('_pos' if kw.get('positive') else ''))
+def test_fmri_dict_fact_host_logic(kw):
+    _check_fmri_case(kw, host=True)
+
+
+def test_fmri_random_init_host_logic():
+    _check_fmri_case(dict(method='masked', reduction=2, n_epochs=1), host=True, with_init=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kw', FMRI_CASES, ids=lambda kw: kw['method'] + ('_pos' if kw.get('positive') else ''))
+def test_fmri_dict_fact_gpu(kw):
+    _check_fmri_case(kw, host=False)
+
+
+@pytest.mark.gpu
+def test_fmri_records_from_npy_files(tmp_path):
+    from modl_amd.fmri import fMRIDictFact
+    recs, dict_init = _fmri_records(np.float32)
+    paths = []
+    for i, r in enumerate(recs):
+        pth = str(tmp_path / ('rec%d.npy' % i))
+        np.save(pth, r)
+        paths.append(pth)
+    kw = dict(n_components=4, alpha=1e-2, batch_size=10, reduction=2, random_state=0, dict_init=dict_init)
+    a = fMRIDictFact(**kw).fit(paths)
+    b = fMRIDictFact(**kw).fit(recs)
+    assert_array_equal(a.components_, b.components_)
+    assert a.components_.dtype == np.float32
