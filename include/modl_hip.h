@@ -161,6 +161,51 @@ int modl_predict_csr(double *d_data, const int32_t *d_indices, const int32_t *d_
                      int64_t n_rows, int64_t k, const double *d_Q, int64_t n_cols, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * Masked (missing-data) path — RecsysDictFact, modl/decomposition/recsys.py.
+ * CSR pieces are int32 as in the reference (recsys_fast.pyx:11-13).
+ * ------------------------------------------------------------------------- */
+/* Ridge codes on the observed columns of b CSR rows (recsys.py:168-181 and _refit :254-265):
+ * code = (D_S D_S^T + alpha |S| / p I)^-1 D_S x_S.  d_row_ids[b] selects rows of the CSR matrix
+ * (NULL = rows 0..b-1), d_code_rows[b] the destination rows of d_code (NULL = the CSR row id).
+ * Rows without entries keep their code. */
+int modl_recsys_codes_f32(const float *d_Dt, int64_t p, int k, const int32_t *d_indptr, const int32_t *d_indices,
+                          const float *d_data, const int64_t *d_row_ids, const int64_t *d_code_rows, int64_t b,
+                          double alpha, float *d_code, void *stream);
+int modl_recsys_codes_f64(const double *d_Dt, int64_t p, int k, const int32_t *d_indptr, const int32_t *d_indices,
+                          const double *d_data, const int64_t *d_row_ids, const int64_t *d_code_rows, int64_t b,
+                          double alpha, double *d_code, void *stream);
+/* Per-feature weighted B_ update of one minibatch (recsys.py:175,182-185).  d_subset[u]: the features
+ * touched by the batch; d_fptr[u+1] / d_entry_sample / d_entry_val: for each of them its entries IN
+ * BATCH ORDER (position of the row in the batch, rating); d_code_b[b][k]: the batch's codes;
+ * w_times_n_iter = w * n_iter_.  Updates d_feature_n_iter (int64[p]) too. */
+int modl_recsys_update_B_f32(float *d_Bt, int k, int64_t *d_feature_n_iter, const int32_t *d_subset,
+                             const int32_t *d_fptr, const int32_t *d_entry_sample, const float *d_entry_val,
+                             const float *d_code_b, double w_times_n_iter, int64_t u, void *stream);
+int modl_recsys_update_B_f64(double *d_Bt, int k, int64_t *d_feature_n_iter, const int32_t *d_subset,
+                             const int32_t *d_fptr, const int32_t *d_entry_sample, const double *d_entry_val,
+                             const double *d_code_b, double w_times_n_iter, int64_t u, void *stream);
+/* _predict (recsys_fast.pyx:10-38) against the feature-major dictionary: d_out[nnz] (double) */
+int modl_recsys_predict_f32(double *d_out, const int32_t *d_indices, const int32_t *d_indptr, const float *d_code,
+                            int64_t n_rows, int k, const float *d_Dt, void *stream);
+int modl_recsys_predict_f64(double *d_out, const int32_t *d_indices, const int32_t *d_indptr, const double *d_code,
+                            int64_t n_rows, int k, const double *d_Dt, void *stream);
+/* C = beta C + alpha rows^T rows, rows[b][k]  (recsys.py:159-160: beta = 1 - w, alpha = w / b) */
+int modl_gram_axpby_f32(const float *d_rows, int64_t b, int k, float *d_C, float beta, float alpha, void *stream);
+int modl_gram_axpby_f64(const double *d_rows, int64_t b, int k, double *d_C, double beta, double alpha, void *stream);
+/* _update_dict on device-resident state (dict_fact.py:650-715, recsys.py:187-213): block-coordinate
+ * update of the rows d_subset[s] (int32, NULL = all rows 0..s-1) of d_Dt[p][k].  d_order / h_order: the
+ * atom order on the device (int32) and on the host (int64).  Scratch: modl_dict_update_workspace(). */
+size_t modl_dict_update_workspace(int dtype, int64_t s_max, int k);
+int modl_dict_update_f32(float *d_Dt, const float *d_Bt, const float *d_C, float *d_comp_norm,
+                         const int32_t *d_subset, int64_t s, const int32_t *d_order, const int64_t *h_order, int k,
+                         int optimizer, int comp_pos, double comp_l1_ratio, double w, double step_size, void *d_ws,
+                         size_t ws_bytes, void *stream);
+int modl_dict_update_f64(double *d_Dt, const double *d_Bt, const double *d_C, double *d_comp_norm,
+                         const int32_t *d_subset, int64_t s, const int32_t *d_order, const int64_t *h_order, int k,
+                         int optimizer, int comp_pos, double comp_l1_ratio, double w, double step_size, void *d_ws,
+                         size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * Fused, device-resident minibatch step = DictFact._single_batch_fit,
  * dict_fact.py:495-533 (+ _compute_code :577-648, _update_C/_update_B :559-575,
  * _update_dict :650-715).  The host keeps drawing `subset` (modl_sampler),
