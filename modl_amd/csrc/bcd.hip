@@ -42,7 +42,7 @@ constexpr int kNB = 32;            // atoms per block of the blocked path
 constexpr int kGramRows = 128;     // feature rows per Gram slab
 
 struct DuLayout {
-    size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, total;
+    size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, off_BsP, total;
     int64_t nslab_max, nwg_grad;
 };
 
@@ -58,11 +58,12 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     L.off_coef = take(sizeof(double) * (size_t)kNB * k);
     L.off_a = take(tsz * (size_t)s_max * kNB);
     L.off_partial = take(sizeof(double) * (size_t)L.nslab_max * (kNB * kNB + kNB));
-    L.off_Tp = take(sizeof(double) * 2 * (kNB * kNB + kNB) + 64 + 256);   // two CA records (ping-pong) + arrival counter + debug stamps
+    L.off_Tp = take(sizeof(double) * 2 * (kNB * kNB + kNB) + 64 + 512);   // two CA records (ping-pong) + arrival counter + debug stamps
     L.off_u = take(tsz * (size_t)s_max);
     L.off_pold = take(sizeof(double) * (size_t)L.nwg_grad);
     L.off_Dnew = take(tsz * (size_t)s_max * k);                       // sgd only, but sized once
     L.off_colp = take(sizeof(double) * (size_t)L.nslab_max * k);
+    L.off_BsP = take(tsz * (size_t)s_max * k);                        // packed B rows (packed D shares off_Dnew)
     L.total = o;
     return L;
 }
@@ -231,7 +232,8 @@ __device__ __forceinline__ void reduce_partials(const double *partial, int nslab
 // (consumed by the apply step, which replays the recursion feature by feature) and alpha[j].
 template <typename T>
 __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const double *D2, const double *coef_all,
-                                             const int32_t *order, int k, int j0, int nb, T *comp_norm, double *CAout) {
+                                             const int32_t *order, int k, int j0, int nb, T *comp_norm, double *CAout,
+                                             unsigned long long *stamps = nullptr) {
     const int lane = threadIdx.x & 63, x = lane & 31;
     double Mrow[kNB], crow[kNB], Tcol[kNB];
 #pragma unroll
@@ -241,11 +243,12 @@ __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const d
         Tcol[m] = 0.0;
     }
     const int jj_x = (x < nb) ? order[j0 + x] : 0;
-    const double cn_x = (x < nb) ? (double)comp_norm[jj_x] : 0.0;
-    const double d2_x = D2[x];
+    const double rad_x = ((x < nb) ? (double)comp_norm[jj_x] : 0.0) + D2[x];    // budget + old squared norm
     double alpha_x = 0.0;
+    if (stamps && threadIdx.x == 0) stamps[8] = clock64() + (unsigned long long)(rad_x * 0);
 #pragma unroll
     for (int j = 0; j < kNB; ++j) {
+        if (stamps && threadIdx.x == 0 && (j % 8) == 0 && j > 0) stamps[8 + j / 8] = clock64();
         if (j < nb) {
             const double ca = crow[j] * alpha_x;                      // lane i: ca_i (zero for i >= j)
             double t0 = (x == j) ? 1.0 : 0.0, t1 = 0, t2 = 0, t3 = 0;
@@ -271,14 +274,20 @@ __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const d
             double prod = (lane < 32) ? t * ((v0 + v1) + (v2 + v3)) : 0.0;
             prod = row16_sum(prod);
             const double nrm = bcast_lane(prod, 0) + bcast_lane(prod, 16);
-            const double radius = bcast_lane(cn_x, j) + bcast_lane(d2_x, j);
-            double al;
-            if (!(radius > 0.0)) al = 0.0;                // enet.pyx:57 (radius == 0 -> zero atom)
-            else if (nrm <= radius) al = 1.0;             // enet.pyx:65
-            else al = fast_rsqrt(nrm * fast_rcp(radius));
+            const double radius = bcast_lane(rad_x, j);
+            // alpha = 0 (radius == 0, enet.pyx:57), 1 (inside the ball, :65) or sqrt(radius / |u|^2):
+            // branch-free, single-precision seeds + one Newton step each (|rel err| ~ 1e-14)
+            const bool scaled = (nrm > radius) && (radius > 0.0);
+            const double nsafe = scaled ? nrm : 1.0, rsafe = scaled ? radius : 1.0;
+            double rn = (double)(1.0f / (float)nsafe);
+            rn = rn * (2.0 - nsafe * rn);                           // 1 / |u|^2
+            const double q = rsafe * rn;                            // radius / |u|^2  in (0, 1)
+            double y = (double)rsqrtf((float)q);
+            y = y * (1.5 - 0.5 * q * y * y);                        // 1 / sqrt(q)
+            const double root = q * y;                              // sqrt(q)
+            const double al = scaled ? root : ((radius > 0.0) ? 1.0 : 0.0);
             if (x == j) alpha_x = al;
-            if (lane < 32) CAout[j * kNB + x] = al * t;   // row j of alpha_j T[j][.]: D_new[j] = sum_m Tp[j][m] a_m
-            if (lane == j) comp_norm[jj_x] = (T)(radius - al * al * nrm);
+            if (lane < 32) CAout[j * kNB + x] = al * t;            if (lane == j) comp_norm[jj_x] = (T)(radius - al * al * nrm);
         } else if (lane < 32) {
             CAout[j * kNB + x] = 0.0;
         }
@@ -312,7 +321,7 @@ __device__ __forceinline__ void apply_row(const T *ar, const double *Tps, T *row
             acc2 += Tps[j * kNB + m + 2] * av[m + 2];
             acc3 += Tps[j * kNB + m + 3] * av[m + 3];
         }
-        row[order[j0 + j]] = (T)((acc0 + acc1) + (acc2 + acc3));
+        row[order ? order[j0 + j] : j0 + j] = (T)((acc0 + acc1) + (acc2 + acc3));
     }
 }
 
@@ -328,6 +337,41 @@ __global__ __launch_bounds__(256) void bcd_apply_kernel(const T *a, const double
     apply_row<T, 4>(a + f * kNB, CAs, Dt + sub_row(subset, f) * k, order, j0, nb, threadIdx.x % 4);
 }
 
+// ---- packing for the fused path: gather the sampled rows once, in sweep order --------------------
+// DsP[f][jj] = Dt[subset[f]][order[jj]], BsP likewise: every later access of the block kernels is a
+// plain contiguous row, no index loads on the critical path.
+template <typename T>
+__global__ __launch_bounds__(256) void bcd_pack_kernel(const T *Dt, const T *Bt, const int32_t *subset,
+                                                       const int32_t *order, int64_t s, int k, T *DsP, T *BsP) {
+    const int64_t f = blockIdx.x;
+    if (f >= s) return;
+    const int64_t src = sub_row(subset, f) * k;
+    for (int jj = threadIdx.x; jj < k; jj += 256) {
+        const int o = order[jj];
+        DsP[f * k + jj] = Dt[src + o];
+        BsP[f * k + jj] = Bt[src + o];
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bcd_unpack_kernel(T *Dt, const int32_t *subset, const int32_t *order, int64_t s,
+                                                         int k, const T *DsP) {
+    const int64_t f = blockIdx.x;
+    if (f >= s) return;
+    const int64_t dst = sub_row(subset, f) * k;
+    for (int jj = threadIdx.x; jj < k; jj += 256) Dt[dst + order[jj]] = DsP[f * k + jj];
+}
+// CPP[m'][jj] = C[o_m'][o_jj] in sweep coordinates, block-lower-triangular mask applied
+template <typename T>
+__global__ __launch_bounds__(256) void bcd_permute_C_kernel(const T *C, const int32_t *order, int k, T *CPP) {
+    const int mp = blockIdx.x;
+    const int om = order[mp];
+    for (int jj = threadIdx.x; jj < k; jj += 256) {
+        T v = C[(int64_t)om * k + order[jj]];
+        if (mp / kNB == jj / kNB && mp <= jj) v = 0;
+        CPP[(int64_t)mp * k + jj] = v;
+    }
+}
+
 // ---- fused block kernel (f32) -------------------------------------------------------------------
 // One launch per block of NB atoms:
 //   (0) apply the PREVIOUS block's result to this workgroup's features (they are workgroup-private);
@@ -339,9 +383,9 @@ __global__ __launch_bounds__(256) void bcd_apply_kernel(const T *a, const double
 //   (3) the LAST workgroup to finish (agent-scope release / relaxed ticket / acquire, no spinning) sums
 //       the partials in a fixed order and runs the alpha recursion for the block.
 struct BcdBlockArgs {
-    float *Dt;
-    const float *Bt, *CP, *cdiag;
-    const int32_t *frozen, *subset, *order;
+    float *Dt;                      // PACKED dictionary [s][k]: row = sampled feature, column = sweep position
+    const float *Bt, *CP, *cdiag;   // packed B [s][k]; CP [k][k] in sweep coordinates (rows and columns)
+    const int32_t *frozen, *order;
     float *a;
     double *partial;
     const double *coef_all;
@@ -369,7 +413,8 @@ __global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
     float *CPs = reinterpret_cast<float *>(d2red + 8 * kNB);                   // [KPAD][NB]
     float *red = CPs + (size_t)KPAD * kNB;                                     // [4][RB][NB + 1]
     float *As = red + 4 * RB * (kNB + 1);                                      // [RB][NB + 1]
-    int *flag = reinterpret_cast<int *>(As + RB * (kNB + 1));
+    float *Dl = As + RB * (kNB + 1) + ((4 - (RB * (kNB + 1)) % 4) % 4);        // [RB][NB + 4] Delta of the previous block
+    int *flag = reinterpret_cast<int *>(Dl + RB * (kNB + 4));
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t f0 = (int64_t)blockIdx.x * RB;
     unsigned long long ts[8];
@@ -379,7 +424,7 @@ __global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
     // they arrive while the coefficient block is staged and the matrix cores run
     const int col = threadIdx.x % kNB, rg = threadIdx.x / kNB;
     const bool col_ok = col < p.nb;
-    const int ocol = col_ok ? p.order[p.j0 + col] : 0;
+    const int ocol = p.j0 + col;                    // packed layout: column = sweep position
     const float cdg = col_ok ? p.cdiag[p.j0 + col] : 1.f;
     const int fz = col_ok ? p.frozen[p.j0 + col] : 0;
     float eB[EPT], eD[EPT];
@@ -387,18 +432,28 @@ __global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
     for (int q = 0; q < EPT; ++q) {
         const int64_t f = f0 + rg + 8 * q;
         const bool ok = col_ok && f < p.s;
-        const int64_t el = ok ? sub_row(p.subset, f) * k + ocol : 0;
+        const int64_t el = ok ? f * k + ocol : 0;
         const float bv = p.Bt[el], dv = p.Dt[el];
         eB[q] = ok ? bv : 0.f;
         eD[q] = ok ? dv : 0.f;
     }
-    // stage the k x NB coefficient block (rows beyond k and columns beyond nb are zero)
+    // stage the k x NB coefficient block (rows beyond k and columns beyond nb are zero): all loads are
+    // issued before the first LDS store, otherwise every iteration is a full memory round trip
     if (p.nb == kNB) {
-        for (int e = threadIdx.x; e < KPAD * (kNB / 4); e += 256) {
+        constexpr int NQ = KPAD * (kNB / 4) / 256;
+        float4 cv[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = threadIdx.x + 256 * q;
             const int m = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < k) v = *reinterpret_cast<const float4 *>(p.CP + (int64_t)m * k + p.j0 + c4);
-            *reinterpret_cast<float4 *>(CPs + m * kNB + c4) = v;
+            const float4 v = *reinterpret_cast<const float4 *>(p.CP + (int64_t)(m < k ? m : 0) * k + p.j0 + c4);
+            cv[q] = (m < k) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            const int m = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
+            *reinterpret_cast<float4 *>(CPs + m * kNB + c4) = cv[q];
         }
     } else {
         for (int e = threadIdx.x; e < KPAD * kNB; e += 256) {
@@ -406,30 +461,17 @@ __global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
             CPs[e] = (m < k && jj < p.nb) ? p.CP[(int64_t)m * k + p.j0 + jj] : 0.f;
         }
     }
-    // (0) previous block: D[f][o_j] = alpha_j u_j[f] for this workgroup's features, then make the new
-    // values visible to the other waves of the workgroup before they are read back as MFMA operands
-    if (p.CA_prev) {
-        for (int e = threadIdx.x; e < kResStride; e += 256) CAs[e] = p.CA_prev[e];
-        __syncthreads();
-        {
-            constexpr int TPR = 256 / RB;                // threads per feature row
-            const int64_t f = f0 + threadIdx.x / TPR;
-            if (f < p.s)
-                apply_row<float, TPR>(p.a + f * kNB, CAs, p.Dt + sub_row(p.subset, f) * k, p.order, p.j0_prev, p.nb_prev,
-                                      threadIdx.x % TPR);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    ts[1] = clock64();
-    // dictionary rows -> MFMA A operands, all loads of the wave's contraction range in flight at once
+    // dictionary rows -> MFMA A operands, all loads of the wave's contraction range in flight at once.
+    // They are issued BEFORE the previous block is applied: the product below uses the dictionary as it
+    // is in memory and the 32 columns the previous block changes enter through a rank-32 correction
+    // (D_cur = D_mem + Delta), so no store -> load round trip sits on the critical path.
     const int h = lane >> 5;
     float4 av[GPW][RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
         int64_t f = f0 + t * 32 + (lane & 31);
         if (f >= p.s) f = p.s - 1;                   // clamped: results of padded rows are discarded
-        const float *rowp = p.Dt + sub_row(p.subset, f) * k;
+        const float *rowp = p.Dt + f * k;
 #pragma unroll
         for (int g = 0; g < GPW; ++g) {
             const int kb = (wid * GPW + g) * 8 + 4 * h;
@@ -437,12 +479,81 @@ __global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
             av[g][t] = (kb + 3 < k) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    // (0) previous block: D[f][o_j] = sum_m Tp[j][m] a_m[f] for this workgroup's features; Delta -> LDS
+    constexpr int TPR = 256 / RB;                    // threads per feature row
+    constexpr int DLS = kNB + 4;                     // row stride of the Delta tile (16-byte aligned rows)
+    if (p.CA_prev) {
+        const int arow = threadIdx.x / TPR, jg = threadIdx.x % TPR;
+        const int64_t f = f0 + arow;
+        const bool rok = f < p.s;
+        float *drow = p.Dt + (rok ? f * k : 0);
+        float dold[kNB / TPR];
+        double aprev[kNB];
+#pragma unroll
+        for (int q = 0; q < kNB / TPR; ++q) {        // old values of the columns this thread rewrites
+            const int j = jg + TPR * q;
+            dold[q] = (rok && j < p.nb_prev) ? drow[p.j0_prev + j] : 0.f;
+        }
+        // the previous block's a-tile of this workgroup: coalesced 16-byte loads -> LDS (the `red` area is free here)
+        float *Ap = red;                                             // [RB][NB]
+        {
+            constexpr int NA = RB * (kNB / 4) / 256, NC = kNB * kNB / 256;
+            float4 va[NA];
+            double vc[NC];
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const int e = threadIdx.x + 256 * q;
+                const int r = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
+                const int64_t fr = (f0 + r < p.s) ? f0 + r : p.s - 1;
+                va[q] = *reinterpret_cast<const float4 *>(p.a + fr * kNB + c4);
+            }
+#pragma unroll
+            for (int q = 0; q < NC; ++q) vc[q] = p.CA_prev[threadIdx.x + 256 * q];
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const int e = threadIdx.x + 256 * q;
+                const int r = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
+                *reinterpret_cast<float4 *>(Ap + r * kNB + c4) = va[q];
+            }
+#pragma unroll
+            for (int q = 0; q < NC; ++q) CAs[threadIdx.x + 256 * q] = vc[q];
+        }
+        // every A-operand load of the workgroup must have landed before any new value is stored
+        const unsigned long long tq0 = clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tq1 = clock64();
+        __syncthreads();
+        const unsigned long long tq2 = clock64();
+        if (p.stamps && threadIdx.x == 0 && blockIdx.x == 0) { p.stamps[12] = tq0 - ts[0]; p.stamps[13] = tq1 - tq0; p.stamps[14] = tq2 - tq1; }
+#pragma unroll
+        for (int m = 0; m < kNB; ++m) aprev[m] = (m < p.nb_prev) ? (double)Ap[arow * kNB + m] : 0.0;
+#pragma unroll
+        for (int q = 0; q < kNB / TPR; ++q) {
+            const int j = jg + TPR * q;
+            double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+#pragma unroll
+            for (int m = 0; m < kNB; m += 4) {
+                acc0 += CAs[j * kNB + m] * aprev[m];
+                acc1 += CAs[j * kNB + m + 1] * aprev[m + 1];
+                acc2 += CAs[j * kNB + m + 2] * aprev[m + 2];
+                acc3 += CAs[j * kNB + m + 3] * aprev[m + 3];
+            }
+            const float dnew = (float)((acc0 + acc1) + (acc2 + acc3));
+            const bool live = rok && j < p.nb_prev;
+            if (live) drow[p.j0_prev + j] = dnew;
+            Dl[arow * DLS + j] = live ? dnew - dold[q] : 0.f;
+        }
+    }
     f16v acc[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    __syncthreads();
+    // LDS hand-off only (coefficient block, Delta tile): the D stores above stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ts[1] = clock64();
 #pragma unroll
     for (int g = 0; g < GPW; ++g) {
         const int kb = (wid * GPW + g) * 8 + 4 * h;  // this lane's 4 consecutive atoms
@@ -454,6 +565,23 @@ __global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].y, b1, acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].z, b2, acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].w, b3, acc[t], 0, 0, 0);
+        }
+    }
+    if (p.CA_prev) {   // rank-32 correction: wave w contracts the previous block's atoms 8w .. 8w+7
+        const int jb = wid * 8 + 4 * h;
+        float bq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = jb + u;
+            bq[u] = (j < p.nb_prev) ? CPs[(size_t)(p.j0_prev + j) * kNB + (lane & 31)] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const float4 dv = *reinterpret_cast<const float4 *>(Dl + (t * 32 + (lane & 31)) * DLS + jb);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv.x, bq[0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv.y, bq[1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv.z, bq[2], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv.w, bq[3], acc[t], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -522,7 +650,7 @@ __global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
     ts[5] = clock64();
     if (threadIdx.x < 64)
         resolve_wave<float>(reinterpret_cast<const double (*)[kNB + 1]>(Ms), D2s, p.coef_all, p.order, k, p.j0, p.nb,
-                            p.comp_norm, p.CA_out);
+                            p.comp_norm, p.CA_out, p.stamps);
     ts[6] = clock64();
     if (p.stamps && threadIdx.x == 0)
         for (int i = 0; i < 7; ++i) p.stamps[i] = ts[i];
@@ -531,7 +659,7 @@ __global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
 static size_t bcd_block_lds(int gpw, int RT) {
     const int kpad = gpw * 32, RB = 32 * RT;
     const size_t dbl = (size_t)kNB * (kNB + 1) + kNB + kResStride + 8 * kNB;
-    const size_t fl = (size_t)kpad * kNB + 4 * RB * (kNB + 1) + RB * (kNB + 1) + 4;
+    const size_t fl = (size_t)kpad * kNB + 4 * RB * (kNB + 1) + RB * (kNB + 1) + 4 + RB * (kNB + 4) + 4;
     return dbl * 8 + fl * 4 + 16;
 }
 
@@ -687,18 +815,28 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(blk), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024));
         }
+        T *DsP = reinterpret_cast<T *>(ws + L.off_Dnew), *BsP = reinterpret_cast<T *>(ws + L.off_BsP), *CPP = CP;
+        if (fused) {
+            hipLaunchKernelGGL((bcd_pack_kernel<T>), dim3((unsigned)s), dim3(256), 0, stream, a.Dt, a.Bt, a.subset, a.order,
+                               s, k, DsP, BsP);
+            MODL_LAUNCH_CHECK();
+            hipLaunchKernelGGL((bcd_permute_C_kernel<T>), dim3(k), dim3(256), 0, stream, a.C, a.order, k, CPP);
+            MODL_LAUNCH_CHECK();
+            nl += 2;
+        }
         int blk_i = 0, j0_prev = 0, nb_prev = 0;
         for (int j0 = 0; j0 < k; j0 += kNB, ++blk_i) {
             const int nb = (k - j0 < kNB) ? k - j0 : kNB;
             double *CAcur = CA[blk_i & 1], *CAprev = blk_i ? CA[(blk_i - 1) & 1] : nullptr;
             if (fused) {
                 BcdBlockArgs ba;
-                ba.Dt = reinterpret_cast<float *>(a.Dt); ba.Bt = reinterpret_cast<const float *>(a.Bt);
-                ba.CP = reinterpret_cast<const float *>(CP); ba.cdiag = reinterpret_cast<const float *>(cdiag);
-                ba.frozen = frozen; ba.subset = a.subset; ba.order = a.order;
+                ba.Dt = reinterpret_cast<float *>(DsP); ba.Bt = reinterpret_cast<const float *>(BsP);
+                ba.CP = reinterpret_cast<const float *>(CPP); ba.cdiag = reinterpret_cast<const float *>(cdiag);
+                ba.frozen = frozen; ba.order = a.order;
                 ba.a = reinterpret_cast<float *>(abuf); ba.partial = partial; ba.coef_all = coef_all;
                 ba.CA_prev = CAprev; ba.CA_out = CAcur; ba.comp_norm = reinterpret_cast<float *>(a.comp_norm);
-                ba.counter = counter; ba.stamps = reinterpret_cast<unsigned long long *>(counter + 16); ba.s = s; ba.k = k; ba.j0 = j0; ba.nb = nb; ba.j0_prev = j0_prev; ba.nb_prev = nb_prev;
+                ba.counter = counter; ba.stamps = reinterpret_cast<unsigned long long *>(counter + 16); ba.s = s; ba.k = k;
+                ba.j0 = j0; ba.nb = nb; ba.j0_prev = j0_prev; ba.nb_prev = nb_prev;
                 hipLaunchKernelGGL(blk, dim3(nslab), dim3(256), bcd_block_lds(GPW, RT), stream, ba);
                 MODL_LAUNCH_CHECK();
                 ++nl;
@@ -726,10 +864,20 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             j0_prev = j0; nb_prev = nb;
         }
         // the last block's atoms
-        hipLaunchKernelGGL((bcd_apply_kernel<T>), dim3((unsigned)cdiv(s, 64)), dim3(256), 0, stream, abuf,
-                           CA[(blk_i - 1) & 1], a.Dt, a.subset, a.order, s, k, j0_prev, nb_prev);
-        MODL_LAUNCH_CHECK();
-        ++nl;
+        if (fused) {
+            hipLaunchKernelGGL((bcd_apply_kernel<T>), dim3((unsigned)cdiv(s, 64)), dim3(256), 0, stream, abuf,
+                               CA[(blk_i - 1) & 1], DsP, nullptr, nullptr, s, k, j0_prev, nb_prev);
+            MODL_LAUNCH_CHECK();
+            hipLaunchKernelGGL((bcd_unpack_kernel<T>), dim3((unsigned)s), dim3(256), 0, stream, a.Dt, a.subset, a.order, s,
+                               k, DsP);
+            MODL_LAUNCH_CHECK();
+            nl += 2;
+        } else {
+            hipLaunchKernelGGL((bcd_apply_kernel<T>), dim3((unsigned)cdiv(s, 64)), dim3(256), 0, stream, abuf,
+                               CA[(blk_i - 1) & 1], a.Dt, a.subset, a.order, s, k, j0_prev, nb_prev);
+            MODL_LAUNCH_CHECK();
+            ++nl;
+        }
     } else {
         return dict_update_generic<T>(stream, a, launches);
     }

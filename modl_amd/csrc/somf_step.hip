@@ -73,6 +73,7 @@ struct modl_somf_plan {
     size_t dws_bytes = 0;
     size_t off_params, off_xnorm, off_Dx, off_H0, off_G, off_F, off_split, off_du, off_sweeps, off_Ds, off_Xs, off_codeb;
     int last_b = 0;
+    int64_t last_s = 0;
     size_t split_bytes, du_bytes, params_bytes;
     // per-batch parameter block (device copy of the host arrays), layout within params:
     size_t po_idx, po_subset, po_order, po_wsample;
@@ -427,6 +428,7 @@ int phase2(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
             EpiAxpby<T> epi{static_cast<T *>(stt->d_G), k, (T)-1, (T)1};
             MODL_TRY((gram_of_rows<T, EpiAxpby<T>>(pl, st, Dt, d_subset, s, epi, &ps.launches)));
         }
+        pl->last_s = s;
         DictUpdateArgs<T> a;
         a.Dt = Dt; a.Bt = Bt; a.C = Cm; a.comp_norm = static_cast<T *>(stt->d_comp_norm);
         a.subset = d_subset; a.order = d_order; a.h_order = pl->h_order_copy.data();
@@ -684,8 +686,8 @@ int modl_somf_debug_stamps(modl_somf_plan *pl, unsigned long long *h_out) {
     // diagnostics only: phase timestamps (shader clock) left by the last fused dictionary-update launch
     if (!pl || !h_out) return MODL_EINVAL;
     MODL_HIP(hipDeviceSynchronize());
-    const size_t off = modl::dict_update_stamps_offset(pl->d.dtype, pl->d.p, pl->d.k);
-    MODL_HIP(hipMemcpy(h_out, pl->dws + pl->off_du + off, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const size_t off = modl::dict_update_stamps_offset(pl->d.dtype, pl->last_s, pl->d.k);
+    MODL_HIP(hipMemcpy(h_out, pl->dws + pl->off_du + off, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return MODL_OK;
 }
 
