@@ -222,75 +222,110 @@ __device__ __forceinline__ void reduce_partials(const double *partial, int nslab
     }
 }
 
-// The alpha recursion of one block, run by ONE wavefront entirely in registers (lane x = lane & 31
-// owns column x).  With u_j = a_j - sum_{i<j} ca_i u_i, ca_i = (C[o_i,o_j] / C[o_j,o_j]) alpha_i, write
-// u_j = sum_m T[j][m] a_m:
-//     T[j][x]  = delta_jx - sum_{i<j} ca_i T[i][x]
-//     |u_j|^2  = sum_x T[j][x] (M T[j])[x],     M = Gram matrix of the a_m
-// The j loop is fully unrolled so every register index is static; wave-uniform scalars travel by
-// v_readlane, the only cross-lane reduction is a 4-step DPP row sum.  Output per block: CA[j][i] = ca_i
-// (consumed by the apply step, which replays the recursion feature by feature) and alpha[j].
+// Coefficients of the in-block recursion of one block -> LDS, Cs[j][i] = C[o_i,o_j] / C[o_j,o_j] for i < j
+// (zero otherwise); called by every thread of the workgroup.
+__device__ __forceinline__ void stage_coef(const double *coef_all, int k, int j0, double *Cs) {
+    for (int e = threadIdx.x; e < kNB * kNB; e += blockDim.x) {
+        const int i = e / kNB, j = e % kNB;
+        Cs[j * kNB + i] = (j0 + j < k) ? coef_all[(int64_t)i * k + j0 + j] : 0.0;
+    }
+}
+
+// both halves of the wave see (lower half's value, upper half's value)
+__device__ __forceinline__ void halves(double z, double &low, double &high) {
+    const long long b = __double_as_longlong(z);
+    const unsigned int w0 = (unsigned int)(b & 0xffffffffll), w1 = (unsigned int)(b >> 32);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(w0, w0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(w1, w1, false, false);
+    low = __longlong_as_double(((long long)r1[0] << 32) | r0[0]);
+    high = __longlong_as_double(((long long)r1[1] << 32) | r0[1]);
+}
+
+__device__ __forceinline__ double pick(bool c, double a, double b) { return c ? a : b; }   // both sides evaluated
+
+// rows 0/1 (and 2/3) of the wave exchange: every lane sees (even row's value, odd row's value)
+__device__ __forceinline__ void rows_pair(double z, double &even, double &odd) {
+    const long long b = __double_as_longlong(z);
+    const unsigned int w0 = (unsigned int)(b & 0xffffffffll), w1 = (unsigned int)(b >> 32);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(w0, w0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(w1, w1, false, false);
+    even = __longlong_as_double(((long long)r1[0] << 32) | r0[0]);
+    odd = __longlong_as_double(((long long)r1[1] << 32) | r0[1]);
+}
+
+// The alpha recursion of one block, run by ONE wavefront entirely in registers.  With
+// u_j = a_j - sum_{i<j} c_ji alpha_i u_i  (c_ji = C[o_i,o_j] / C[o_j,o_j]) write u_j = sum_m T[j][m] a_m and
+// S[j] = alpha_j T[j]; with the Gram matrix M of the a_m and Y[j] = M S[j]:
+//     T[j]     = e_j    - sum_{i<j} c_ji S[i]          (lanes  0-31, lane x owns component x)
+//     M T[j]   = M[:,j] - sum_{i<j} c_ji Y[i]          (lanes 32-63: the SAME instruction stream)
+//     |u_j|^2  = T[j] . (M T[j])                       (half swap + DPP row sum)
+// The c_ji are wave-uniform LDS broadcast reads with static addresses (prefetched by the scheduler), so
+// the only cross-lane traffic on the serial chain is the half swap, the row sum and two v_readlane.
+// The j loop is fully unrolled: every register index is static.  Output per block: CA[j][m] = S[j][m]
+// (the apply step forms D_j = sum_m S[j][m] a_m feature by feature) and the new norm budgets.
 template <typename T>
-__device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const double *D2, const double *coef_all,
-                                             const int32_t *order, int k, int j0, int nb, T *comp_norm, double *CAout,
+__device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const double *D2, const double *Cs,
+                                             const int32_t *order, int j0, int nb, T *comp_norm, double *CAout,
                                              unsigned long long *stamps = nullptr) {
     const int lane = threadIdx.x & 63, x = lane & 31;
-    double Mrow[kNB], crow[kNB], Tcol[kNB];
-#pragma unroll
-    for (int m = 0; m < kNB; ++m) {
-        Mrow[m] = M[x][m];
-        crow[m] = (j0 + m < k) ? coef_all[(int64_t)x * k + j0 + m] : 0.0;   // C[o_x,o_m] / C[o_m,o_m] for x < m
-        Tcol[m] = 0.0;
-    }
+    const bool lower = lane < 32;
+    double Z[kNB];
     const int jj_x = (x < nb) ? order[j0 + x] : 0;
     const double rad_x = ((x < nb) ? (double)comp_norm[jj_x] : 0.0) + D2[x];    // budget + old squared norm
-    double alpha_x = 0.0;
-    if (stamps && threadIdx.x == 0) stamps[8] = clock64() + (unsigned long long)(rad_x * 0);
+    const double srad_x = (rad_x > 0.0) ? sqrt(rad_x) : 0.0;
+    double newnorm_x = 0.0;
+    const double hmask = lower ? 0.0 : 1.0;
+    if (stamps && threadIdx.x == 0) stamps[8] = clock64() + (unsigned long long)(srad_x * 0);
+    // One straight-line basic block (no branch inside the unrolled loop: columns >= nb get alpha = 0),
+    // software-pipelined by hand: while the serial tail of step j runs (half swap, row sums, 1/sqrt,
+    // selects), the terms i < j of step j + 1 are accumulated; between alpha_j and the start of step
+    // j + 1's tail sits ONE fma:  z_{j+1} = partial_{j+1} - alpha_j (c_{j+1,j} z_j).
+    double part = __builtin_fma(hmask, M[x][0], (lower && x == 0) ? 1.0 : 0.0);   // e_0 | M[:,0]
+    double al_prev = 0.0, q_prev = 0.0, z_prev = 0.0;
 #pragma unroll
     for (int j = 0; j < kNB; ++j) {
         if (stamps && threadIdx.x == 0 && (j % 8) == 0 && j > 0) stamps[8 + j / 8] = clock64();
-        if (j < nb) {
-            const double ca = crow[j] * alpha_x;                      // lane i: ca_i (zero for i >= j)
-            double t0 = (x == j) ? 1.0 : 0.0, t1 = 0, t2 = 0, t3 = 0;
+        const double z = __builtin_fma(-al_prev, q_prev, part);
+        double t, w;
+        halves(z, t, w);
+        const double prow = row16_sum(t * w);              // both halves hold the same products
+        double r0, r1;
+        rows_pair(prow, r0, r1);
+        const double nrm = r0 + r1;                        // every lane: |u_j|^2
+        // independent of this step's tail: finish S[j-1], start step j + 1
+        if (j > 0) Z[j - 1] = al_prev * z_prev;
+        double q = 0.0;
+        if (j + 1 < kNB) {
+            double p0 = __builtin_fma(hmask, M[x][j + 1], (lower && x == j + 1) ? 1.0 : 0.0), p1 = 0, p2 = 0, p3 = 0;
 #pragma unroll
             for (int i = 0; i < j; ++i) {
-                const double c = bcast_lane(ca, i);
-                if ((i & 3) == 0) t0 -= c * Tcol[i];
-                else if ((i & 3) == 1) t1 -= c * Tcol[i];
-                else if ((i & 3) == 2) t2 -= c * Tcol[i];
-                else t3 -= c * Tcol[i];
+                const double c = Cs[(j + 1) * kNB + i];
+                if ((i & 3) == 0) p0 -= c * Z[i];
+                else if ((i & 3) == 1) p1 -= c * Z[i];
+                else if ((i & 3) == 2) p2 -= c * Z[i];
+                else p3 -= c * Z[i];
             }
-            const double t = (t0 + t1) + (t2 + t3);
-            Tcol[j] = t;
-            double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-#pragma unroll
-            for (int m = 0; m <= j; ++m) {
-                const double tm = bcast_lane(t, m);
-                if ((m & 3) == 0) v0 += Mrow[m] * tm;
-                else if ((m & 3) == 1) v1 += Mrow[m] * tm;
-                else if ((m & 3) == 2) v2 += Mrow[m] * tm;
-                else v3 += Mrow[m] * tm;
-            }
-            double prod = (lane < 32) ? t * ((v0 + v1) + (v2 + v3)) : 0.0;
-            prod = row16_sum(prod);
-            const double nrm = bcast_lane(prod, 0) + bcast_lane(prod, 16);
-            const double radius = bcast_lane(rad_x, j);
-            // alpha = 0 (radius == 0, enet.pyx:57), 1 (inside the ball, :65) or sqrt(radius / |u|^2):
-            // branch-free, single-precision seeds + one Newton step each (|rel err| ~ 1e-14)
-            const bool scaled = (nrm > radius) && (radius > 0.0);
-            const double nsafe = scaled ? nrm : 1.0, rsafe = scaled ? radius : 1.0;
-            double rn = (double)(1.0f / (float)nsafe);
-            rn = rn * (2.0 - nsafe * rn);                           // 1 / |u|^2
-            const double q = rsafe * rn;                            // radius / |u|^2  in (0, 1)
-            double y = (double)rsqrtf((float)q);
-            y = y * (1.5 - 0.5 * q * y * y);                        // 1 / sqrt(q)
-            const double root = q * y;                              // sqrt(q)
-            const double al = scaled ? root : ((radius > 0.0) ? 1.0 : 0.0);
-            if (x == j) alpha_x = al;
-            if (lane < 32) CAout[j * kNB + x] = al * t;            if (lane == j) comp_norm[jj_x] = (T)(radius - al * al * nrm);
-        } else if (lane < 32) {
-            CAout[j * kNB + x] = 0.0;
+            part = (p0 + p1) + (p2 + p3);
+            q = Cs[(j + 1) * kNB + j] * z;
         }
+        const double radius = bcast_lane(rad_x, j), sr = bcast_lane(srad_x, j);
+        // alpha = 0 (radius == 0, enet.pyx:57), 1 (inside the ball, :65) or sqrt(radius / |u|^2):
+        // selects only (no branch); 1/sqrt from a single-precision seed and one Newton step
+        // (|rel err| ~ 1e-14).  nrm == 0 gives a NaN that the select discards.
+        const bool scaled = (nrm > radius) && (radius > 0.0) && (j < nb);
+        double y = (double)__builtin_amdgcn_rsqf((float)nrm);
+        y = y * (1.5 - 0.5 * nrm * y * y);
+        const double al = pick(scaled, sr * y, (radius > 0.0 && j < nb) ? 1.0 : 0.0);
+        if (x == j) newnorm_x = radius - al * al * nrm;
+        al_prev = al;
+        q_prev = q;
+        z_prev = z;
+    }
+    Z[kNB - 1] = al_prev * z_prev;
+    if (lower) {
+#pragma unroll
+        for (int j = 0; j < kNB; ++j) CAout[j * kNB + x] = Z[j];
+        if (x < nb) comp_norm[jj_x] = (T)newnorm_x;
     }
 }
 
@@ -300,9 +335,11 @@ __global__ __launch_bounds__(256) void bcd_resolve_kernel(const double *partial,
                                                           double *CAout) {
     __shared__ double M[kNB][kNB + 1];
     __shared__ double D2[kNB];
+    __shared__ __attribute__((aligned(16))) double Cs[kNB * kNB];
+    stage_coef(coef_all, k, j0, Cs);
     reduce_partials(partial, nslab, M, D2);
     __syncthreads();
-    if (threadIdx.x < 64) resolve_wave<T>(M, D2, coef_all, order, k, j0, nb, comp_norm, CAout);
+    if (threadIdx.x < 64) resolve_wave<T>(M, D2, Cs, order, j0, nb, comp_norm, CAout);
 }
 
 // D_new[f][o_j] = sum_{m <= j} Tp[j][m] a_m[f]  for the atoms j = jg, jg + NSTR, ... of one sampled feature
@@ -645,11 +682,13 @@ __global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
     __syncthreads();
     if (!*flag) return;
     ts[4] = clock64();
+    double *Cs = reinterpret_cast<double *>(CPs);                // the coefficient block is dead by now
+    stage_coef(p.coef_all, k, p.j0, Cs);
     reduce_partials(p.partial, (int)gridDim.x, reinterpret_cast<double (*)[kNB + 1]>(Ms), D2s);
     __syncthreads();
     ts[5] = clock64();
     if (threadIdx.x < 64)
-        resolve_wave<float>(reinterpret_cast<const double (*)[kNB + 1]>(Ms), D2s, p.coef_all, p.order, k, p.j0, p.nb,
+        resolve_wave<float>(reinterpret_cast<const double (*)[kNB + 1]>(Ms), D2s, Cs, p.order, p.j0, p.nb,
                             p.comp_norm, p.CA_out, p.stamps);
     ts[6] = clock64();
     if (p.stamps && threadIdx.x == 0)
