@@ -40,9 +40,11 @@ namespace modl {
 
 constexpr int kNB = 32;            // atoms per block of the blocked path
 constexpr int kGramRows = 128;     // feature rows per Gram slab
+constexpr int kGroup = 16;         // minimum workgroups per group of the two-level partial reduction
+constexpr int kCounters = 64;      // arrival counters: [0] final, [1 + g] group g
 
 struct DuLayout {
-    size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, off_BsP, total;
+    size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, off_BsP, off_gpartial, total;
     int64_t nslab_max, nwg_grad;
 };
 
@@ -58,18 +60,19 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     L.off_coef = take(sizeof(double) * (size_t)kNB * k);
     L.off_a = take(tsz * (size_t)s_max * kNB);
     L.off_partial = take(sizeof(double) * (size_t)L.nslab_max * (kNB * kNB + kNB));
-    L.off_Tp = take(sizeof(double) * 2 * (kNB * kNB + kNB) + 64 + 512);   // two CA records (ping-pong) + arrival counter + debug stamps
+    L.off_Tp = take(sizeof(double) * 2 * (kNB * kNB + kNB) + 256 + 512);  // two CA records (ping-pong) + arrival counters + debug stamps
     L.off_u = take(tsz * (size_t)s_max);
     L.off_pold = take(sizeof(double) * (size_t)L.nwg_grad);
     L.off_Dnew = take(tsz * (size_t)s_max * k);                       // sgd only, but sized once
     L.off_colp = take(sizeof(double) * (size_t)L.nslab_max * k);
     L.off_BsP = take(tsz * (size_t)s_max * k);                        // packed B rows (packed D shares off_Dnew)
+    L.off_gpartial = take(sizeof(double) * (size_t)kCounters * (kNB * kNB + kNB));   // group sums (two-level reduction)
     L.total = o;
     return L;
 }
 
 size_t dict_update_stamps_offset(int dtype, int64_t s_max, int k) {
-    return du_layout(dtype == MODL_F32 ? 4 : 8, s_max, k).off_Tp + sizeof(double) * 2 * (kNB * kNB + kNB) + 64;
+    return du_layout(dtype == MODL_F32 ? 4 : 8, s_max, k).off_Tp + sizeof(double) * 2 * (kNB * kNB + kNB) + 256;
 }
 
 size_t dict_update_workspace(int dtype, int64_t s_max, int k) {
@@ -82,7 +85,7 @@ __device__ __forceinline__ int64_t sub_row(const int32_t *subset, int64_t f) { r
 template <typename T>
 __global__ __launch_bounds__(256) void bcd_prepare_kernel(const T *C, const int32_t *order, int k, T *CP, T *cdiag,
                                                           int32_t *frozen, double *coef_all, unsigned int *counter) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;   // arrival ticket of the fused block kernel
+    if (blockIdx.x == 0 && threadIdx.x < kCounters) counter[threadIdx.x] = 0;   // arrival tickets of the fused block kernel
     extern __shared__ int32_t inv[];                 // position of each atom in the sweep
     for (int j = threadIdx.x; j < k; j += 256) inv[order[j]] = j;
     __syncthreads();
@@ -206,20 +209,75 @@ __device__ __forceinline__ double fast_rcp(double v) {
 
 constexpr int kResStride = kNB * kNB + kNB;          // doubles per Gram partial / per CA record
 
-// Sum the per-workgroup Gram partials in a fixed order into LDS (all threads of the block).
-__device__ __forceinline__ void reduce_partials(const double *partial, int nslab, double (*M)[kNB + 1], double *D2) {
-    for (int e = threadIdx.x; e < kResStride; e += blockDim.x) {
-        double sv[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // fixed association: deterministic
-        int z = 0;
-        for (; z + 8 <= nslab; z += 8) {
+// Sum n Gram records (kResStride doubles each) in a fixed order, all 256 threads of the workgroup; element
+// e = tid + 256 q goes to sink(e, sum).  Every load of a chunk of 16 records is issued before the first
+// add (a dependent load -> add loop costs one memory round trip per record).
+template <typename Sink>
+__device__ __forceinline__ void reduce_records(const double *rec, int n, Sink sink) {
+    constexpr int NQ = (kResStride + 255) / 256;
+    double tot[NQ];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) sv[u] += partial[(int64_t)(z + u) * kResStride + e];
+    for (int q = 0; q < NQ; ++q) tot[q] = 0.0;
+    for (int z0 = 0; z0 < n; z0 += 16) {
+        double v[NQ][16];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            const int ec = (e < kResStride) ? e : 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int z = (z0 + u < n) ? z0 + u : n - 1;
+                v[q][u] = rec[(int64_t)z * kResStride + ec];
+            }
         }
-        for (; z < nslab; ++z) sv[0] += partial[(int64_t)z * kResStride + e];
-        const double sum = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
-        if (e < kNB * kNB) M[e / kNB][e % kNB] = sum;
-        else D2[e - kNB * kNB] = sum;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[q][u] = (z0 + u < n) ? v[q][u] : 0.0;
+            const double c = (((v[q][0] + v[q][1]) + (v[q][2] + v[q][3])) + ((v[q][4] + v[q][5]) + (v[q][6] + v[q][7]))) +
+                             (((v[q][8] + v[q][9]) + (v[q][10] + v[q][11])) + ((v[q][12] + v[q][13]) + (v[q][14] + v[q][15])));
+            tot[q] += c;
+        }
     }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = threadIdx.x + 256 * q;
+        if (e < kResStride) sink(e, tot[q]);
+    }
+}
+struct SinkLds {
+    double (*M)[kNB + 1]; double *D2;
+    __device__ __forceinline__ void operator()(int e, double v) const {
+        if (e < kNB * kNB) M[e / kNB][e % kNB] = v;
+        else D2[e - kNB * kNB] = v;
+    }
+};
+struct SinkGlobal {
+    double *dst;
+    __device__ __forceinline__ void operator()(int e, double v) const { dst[e] = v; }
+};
+__device__ __forceinline__ void reduce_partials(const double *partial, int nslab, double (*M)[kNB + 1], double *D2) {
+    reduce_records(partial, nslab, SinkLds{M, D2});
+}
+
+// "Last arriver" hand-off (cdna guide, split-K recipe): release our stores, take a ticket, and if we are
+// the last of `expected` arrivals acquire the others' stores.  Called by every thread; no spinning.
+__device__ __forceinline__ bool arrive_last(unsigned int *counter, unsigned int expected, int *flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (ticket == expected - 1);
+        if (last) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    return *flag != 0;
 }
 
 // Coefficients of the in-block recursion of one block -> LDS, Cs[j][i] = C[o_i,o_j] / C[o_j,o_j] for i < j
@@ -424,14 +482,14 @@ struct BcdBlockArgs {
     const float *Bt, *CP, *cdiag;   // packed B [s][k]; CP [k][k] in sweep coordinates (rows and columns)
     const int32_t *frozen, *order;
     float *a;
-    double *partial;
+    double *partial, *gpartial;
     const double *coef_all;
     double *CA_prev, *CA_out;       // CA record of the previous block (null for the first) / of this block
     float *comp_norm;
     unsigned int *counter;
     unsigned long long *stamps;     // optional phase timestamps of the last-arriving workgroup (diagnostics)
     int64_t s;
-    int k, j0, nb, j0_prev, nb_prev;
+    int k, j0, nb, j0_prev, nb_prev, group;
 };
 
 template <int RT, int GPW>   // 32 * RT features per workgroup; GPW contraction groups (8 atoms) per wave
@@ -664,27 +722,28 @@ __global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
             out[kNB * kNB + threadIdx.x] = t;
         }
     }
-    // (3) last workgroup to arrive resolves the block (cdna guide, split-K "last arriver" recipe)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // (3) the last workgroup to arrive resolves the block.  More than kGroup workgroups: two levels (the last
+    //     of each group of kGroup sums its group, the last group leader sums the group sums), so no single
+    //     workgroup streams hundreds of records; the association is fixed either way.
     ts[3] = clock64();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int ticket = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (ticket == gridDim.x - 1);
-        if (last) {
-            __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        *flag = last;
+    const int nwg = (int)gridDim.x;
+    const int gsz = p.group;                        // >= kGroup, chosen by the host so that ngroups < kCounters
+    const int ngroups = (nwg + gsz - 1) / gsz;
+    const double *recs = p.partial;
+    int nrec = nwg;
+    if (ngroups > 1) {
+        const int g = (int)blockIdx.x / gsz;
+        const int gsize = (nwg - g * gsz < gsz) ? nwg - g * gsz : gsz;
+        if (!arrive_last(p.counter + 1 + g, (unsigned int)gsize, flag)) return;
+        reduce_records(p.partial + (int64_t)g * gsz * kResStride, gsize, SinkGlobal{p.gpartial + (int64_t)g * kResStride});
+        recs = p.gpartial;
+        nrec = ngroups;
     }
-    __syncthreads();
-    if (!*flag) return;
+    if (!arrive_last(p.counter, (unsigned int)nrec, flag)) return;
     ts[4] = clock64();
     double *Cs = reinterpret_cast<double *>(CPs);                // the coefficient block is dead by now
     stage_coef(p.coef_all, k, p.j0, Cs);
-    reduce_partials(p.partial, (int)gridDim.x, reinterpret_cast<double (*)[kNB + 1]>(Ms), D2s);
+    reduce_partials(recs, nrec, reinterpret_cast<double (*)[kNB + 1]>(Ms), D2s);
     __syncthreads();
     ts[5] = clock64();
     if (threadIdx.x < 64)
@@ -874,8 +933,10 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                 ba.frozen = frozen; ba.order = a.order;
                 ba.a = reinterpret_cast<float *>(abuf); ba.partial = partial; ba.coef_all = coef_all;
                 ba.CA_prev = CAprev; ba.CA_out = CAcur; ba.comp_norm = reinterpret_cast<float *>(a.comp_norm);
-                ba.counter = counter; ba.stamps = reinterpret_cast<unsigned long long *>(counter + 16); ba.s = s; ba.k = k;
+                ba.gpartial = reinterpret_cast<double *>(ws + L.off_gpartial);
+                ba.counter = counter; ba.stamps = reinterpret_cast<unsigned long long *>(counter + kCounters); ba.s = s; ba.k = k;
                 ba.j0 = j0; ba.nb = nb; ba.j0_prev = j0_prev; ba.nb_prev = nb_prev;
+                ba.group = (nslab + 31) / 32 > kGroup ? (nslab + 31) / 32 : kGroup;
                 hipLaunchKernelGGL(blk, dim3(nslab), dim3(256), bcd_block_lds(GPW, RT), stream, ba);
                 MODL_LAUNCH_CHECK();
                 ++nl;

@@ -8,108 +8,187 @@
 // sample performs the same number of sweeps; only float summation order inside
 // the gap evaluation differs (the reference uses BLAS dot/asum there).
 //
-// gfx950 mapping: the k-vectors H = Q w, w, q and diag(Q) live in registers,
-// KPL consecutive coefficients per lane (k <= 64 * KPL).  A coordinate step reads
-// its four scalars with v_readlane, updates H with two fused multiply-adds per
-// register against row ii of the Gram matrix, which is streamed from L2 as one
-// coalesced row (16 B per lane at k = 256) and prefetched one chunk of rows ahead
-// so that the load latency sits under the previous chunk's arithmetic.  The five
-// reductions of the gap test are wave shuffles.  b independent problems -> b
-// wavefronts, 4 per workgroup.
+// gfx950 mapping: the k-vectors H = Q w, w, q and 1 / (diag(Q) + beta) live in
+// registers, coefficient e in register e / 64 of lane e % 64 (k <= 64 * KPL), so
+// every row of the Gram matrix is read from L2 as KPL coalesced 256-byte loads.
+// Two kinds of sweep, chosen per sweep from the number of active coordinates:
+//   * dense: chunks of 4 consecutive coordinates; their Gauss-Seidel recurrence is
+//     run on wave-uniform scalars (v_readlane) while the k-wide H update (two fused
+//     multiply-adds per register and coordinate) is off the dependency chain; the
+//     rows of the next chunk are prefetched into the other half of a ping-pong
+//     register buffer;
+//   * sparse (active set): a coordinate with w_ii == 0 whose update stays 0
+//     (|q_ii - H_ii| <= alpha) is a no-op of the reference's sweep (nothing is
+//     written, d_w_max / w_max are unaffected), and that test is evaluated for ALL
+//     coordinates at once (one compare + ballot per register), so the sweep jumps
+//     from one active coordinate to the next with s_ff1.  With l1-penalised codes
+//     most coordinates are inactive after the first sweep.  The row of the predicted
+//     next active coordinate is prefetched; a coordinate activated in between is
+//     picked up exactly (it only costs a synchronous load).
+// Both produce the reference's iterates bit for bit.  The five reductions of the
+// gap test are wave shuffles.  b independent problems -> b wavefronts, 4 per
+// workgroup.
 #include "kernels.hpp"
 
 namespace modl {
 
-// Row loader: KPL consecutive coefficients per lane.  VEC = rows are KPL-aligned (k % KPL == 0 and
-// an aligned base): one 16-byte load per lane at k = 256.  No branches: lanes past the end read a
-// clamped address and select zero, so the loads of a chunk stay in flight together.
-template <typename T, int KPL, bool VEC>
-__device__ __forceinline__ void load_row(const T *__restrict__ row, int k, int lane, int n_li, T (&r)[KPL]) {
-    if constexpr (VEC) {
-        const int lc = lane < n_li ? lane : n_li - 1;
-        constexpr int kAlign = (KPL * sizeof(T) >= 16) ? 16 : (int)(KPL * sizeof(T));
-        const T *p = static_cast<const T *>(__builtin_assume_aligned(row + lc * KPL, kAlign));
+// Row loader: coefficient c * 64 + lane in r[c].  No branches: lanes past the end read a clamped
+// address and select zero, so all loads of a chunk stay in flight together.  FULL: k == 64 * KPL.
+template <typename T, int KPL, bool FULL>
+__device__ __forceinline__ void load_row(const T *__restrict__ row, int k, int lane, T (&r)[KPL]) {
 #pragma unroll
-        for (int c = 0; c < KPL; ++c) r[c] = p[c];
-        if (lane >= n_li) {
-#pragma unroll
-            for (int c = 0; c < KPL; ++c) r[c] = 0;
-        }
-    } else {
-        const int e0 = lane * KPL;
-#pragma unroll
-        for (int c = 0; c < KPL; ++c) {
-            const int e = e0 + c;
+    for (int c = 0; c < KPL; ++c) {
+        const int e = c * 64 + lane;
+        if constexpr (FULL) {
+            r[c] = row[e];
+        } else {
             const T v = row[e < k ? e : k - 1];
             r[c] = e < k ? v : (T)0;
         }
     }
 }
 
-// A chunk of PG consecutive coordinates (dict_fact_fast.pyx:354-386).  They all live in lane `li`
-// (registers C0 .. C0+PG-1), so the chunk's Gauss-Seidel recurrence is run on wave-uniform scalars:
-// the PG entries of H it needs are read once (v_readlane), and after each coordinate the later ones
-// are advanced with the same two fused multiply-adds the vector update applies to lane li — the
-// values stay bit-identical to the vector H.  The k-wide H update (two FMAs per register and
-// coordinate) is off the dependency chain.  A zero diagonal skips the coordinate (:357).
-template <typename T, int KPL, int PG, int C0, bool VEC, bool POSITIVE>
-__device__ __forceinline__ void cd_chunk(int li, int n_li, int lane, int k, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
-                                         const T (&inv)[KPL], T (&cur)[PG][KPL], T (&nxt)[PG][KPL],
-                                         const T *__restrict__ Q, T alpha, T &w_max, T &d_w_max) {
-    const int ii0 = li * KPL + C0;
-    // prefetch the rows of the next chunk (wraps to row 0 for the next sweep)
-    int nxt0 = ii0 + PG;
-    if (nxt0 >= n_li * KPL) nxt0 = 0;
-#pragma unroll
-    for (int j = 0; j < PG; ++j) {
-        const int rn = (nxt0 + j < k) ? nxt0 + j : 0;
-        load_row<T, KPL, VEC>(Q + (int64_t)rn * k, k, lane, n_li, nxt[j]);
-    }
-    T h[PG], wo[PG], qq[PG], ri[PG], wn[PG], Qb[PG][PG];
-#pragma unroll
-    for (int c = 0; c < PG; ++c) {
-        h[c] = bcast_lane(H[C0 + c], li);
-        wo[c] = bcast_lane(w[C0 + c], li);
-        qq[c] = bcast_lane(q[C0 + c], li);
-        ri[c] = (ii0 + c < k) ? bcast_lane(inv[C0 + c], li) : (T)0;      // 0: skipped coordinate
-#pragma unroll
-        for (int c2 = c; c2 < PG; ++c2) Qb[c][c2] = bcast_lane(cur[c][C0 + c2], li);
-    }
-#pragma unroll
-    for (int c = 0; c < PG; ++c) {
-        const bool live = ri[c] != (T)0;
-        const T Hii = fma(-wo[c], Qb[c][c], h[c]);                // H[ii] after "H -= w_ii * Q[ii]" (:361-365)
-        const T tmp = qq[c] - Hii;                                // :367
-        T mag = fabs(tmp) - alpha;                                // :372 soft threshold
-        mag = mag > (T)0 ? mag : (T)0;
-        T x = copysign(mag * ri[c], tmp);
-        if (POSITIVE && tmp < (T)0) x = 0;
-        wn[c] = live ? x : wo[c];
-        const T dn = live ? x : (T)0, dold = live ? wo[c] : (T)0;
-#pragma unroll
-        for (int c2 = c + 1; c2 < PG; ++c2) h[c2] = fma(dn, Qb[c][c2], fma(-dold, Qb[c][c2], h[c2]));
-#pragma unroll
-        for (int r = 0; r < KPL; ++r) H[r] = fma(dn, cur[c][r], fma(-dold, cur[c][r], H[r]));   // :361-365, :375-378
-        if (live) {
-            const T d = fabs(x - wo[c]);
-            d_w_max = d > d_w_max ? d : d_w_max;
-            const T aw = fabs(x);
-            w_max = aw > w_max ? aw : w_max;
-        }
-    }
-    if (lane == li) {
-#pragma unroll
-        for (int c = 0; c < PG; ++c) w[C0 + c] = wn[c];
-    }
-#pragma unroll
-    for (int j = 0; j < PG; ++j)
-#pragma unroll
-        for (int c = 0; c < KPL; ++c) cur[j][c] = nxt[j][c];
+// One coordinate on wave-uniform scalars (dict_fact_fast.pyx:354-386); returns the new coefficient.
+template <typename T, bool POSITIVE>
+__device__ __forceinline__ T cd_coordinate(T h, T wo, T qq, T ri, T Qcc, T alpha) {
+    const T Hii = fma(-wo, Qcc, h);                            // H[ii] after "H -= w_ii * Q[ii]" (:361-365)
+    const T tmp = qq - Hii;                                    // :367
+    T mag = fabs(tmp) - alpha;                                 // :372 soft threshold
+    mag = mag > (T)0 ? mag : (T)0;
+    T x = copysign(mag * ri, tmp);
+    if (POSITIVE && tmp < (T)0) x = 0;
+    return x;
 }
 
-template <typename T, int KPL, bool VEC, bool POSITIVE>
+constexpr int kCdRing = 8;       // Gram rows in flight in the dense sweep (an L2 hit costs several coordinates)
+
+// One coordinate ii = R * 64 + L of a dense sweep.  The update formula is evaluated by EVERY lane on its
+// own coefficient (the values of the other lanes are discarded): no scalar has to be fetched before the
+// arithmetic, and the only cross-lane traffic is the pair (w_new, w_old) of lane L, read with v_readlane
+// after it — 2 wave-wide reads per coordinate.  A zero diagonal skips the coordinate (:357): both
+// multipliers are then zero and H is unchanged bit for bit.
+template <typename T, int KPL, int R, bool POSITIVE>
+__device__ __forceinline__ void cd_coord(int L, unsigned long long live, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
+                                         const T (&inv)[KPL], const T (&row)[KPL], T alpha) {
+    const T wv = w[R];
+    const T xv = cd_coordinate<T, POSITIVE>(H[R], wv, q[R], inv[R], row[R], alpha);
+    const bool lv = inv[R] != (T)0;
+    const T dn = bcast_lane(lv ? xv : (T)0, L), dold = bcast_lane(lv ? wv : (T)0, L);
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) H[r] = fma(dn, row[r], fma(-dold, row[r], H[r]));   // :361-365, :375-378
+    w[R] = __builtin_amdgcn_inverse_ballot_w64((1ull << L) & live) ? xv : wv;   // lane L only (scalar mask)
+}
+
+// coordinates R * 64 .. R * 64 + 63 with a ring of kCdRing row buffers: row ii + kCdRing is requested as
+// soon as row ii has been consumed
+template <typename T, int KPL, int R, bool FULL, bool POSITIVE>
+__device__ __forceinline__ void cd_dense_register(int lane, int k, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
+                                                  const T (&inv)[KPL], T (&ring)[kCdRing][KPL],
+                                                  const T *__restrict__ Q, T alpha) {
+    const unsigned long long live = __ballot(inv[R] != (T)0);
+    int cnt = k - R * 64;
+    cnt = cnt > 64 ? 64 : cnt;
+    if (cnt <= 0) return;
+    const int groups = cnt / kCdRing, tail = cnt % kCdRing;
+    // whole groups: straight-line code, every load unconditional (row index clamped) so that no buffer is
+    // merged across a branch
+    for (int g = 0; g < groups; ++g) {
+#pragma unroll
+        for (int j = 0; j < kCdRing; ++j) {
+            const int ii = R * 64 + g * kCdRing + j;
+            cd_coord<T, KPL, R, POSITIVE>(g * kCdRing + j, live, w, H, q, inv, ring[j], alpha);
+            const int nx = (ii + kCdRing < k) ? ii + kCdRing : k - 1;
+            load_row<T, KPL, FULL>(Q + (int64_t)nx * k, k, lane, ring[j]);
+            // keep the request where it is: the scheduler otherwise gathers the group's loads at the end of
+            // the loop body, and the wait for row ii then sits right behind its own request
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if constexpr (!FULL) {                         // ragged end of the last register: its rows are in the ring
+#pragma unroll
+        for (int j = 0; j < kCdRing - 1; ++j)
+            if (j < tail) cd_coord<T, KPL, R, POSITIVE>(groups * kCdRing + j, live, w, H, q, inv, ring[j], alpha);
+    }
+}
+
+// Active coordinates as one 64-bit mask per register: live and (w != 0 or the update leaves zero).
+template <typename T, int KPL, bool POSITIVE>
+__device__ __forceinline__ void cd_active(const T (&w)[KPL], const T (&H)[KPL], const T (&q)[KPL], const T (&inv)[KPL],
+                                          T alpha, unsigned long long (&m)[KPL]) {
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+        const T tmp = q[r] - H[r];                            // w == 0 there: H[ii] needs no correction
+        bool act = (fabs(tmp) - alpha) > (T)0;
+        if (POSITIVE) act = act && !(tmp < (T)0);
+        act = (act || w[r] != (T)0) && inv[r] != (T)0;
+        m[r] = __ballot(act);
+    }
+}
+// first active coordinate >= pos, or a value >= 64 * KPL
+template <int KPL>
+__device__ __forceinline__ int cd_next(const unsigned long long (&m)[KPL], int pos) {
+    int res = 64 * KPL;
+#pragma unroll
+    for (int r = KPL - 1; r >= 0; --r) {
+        const int lo = pos - 64 * r;
+        const unsigned long long mm = (lo <= 0) ? m[r] : (lo >= 64 ? 0ull : (m[r] & (~0ull << lo)));
+        if (mm) res = 64 * r + __builtin_ctzll(mm);
+    }
+    return res;
+}
+
+// one active coordinate ii = R * 64 + L with its Gram row in `row`
+template <typename T, int KPL, int R, bool POSITIVE>
+__device__ __forceinline__ void cd_step(int L, int lane, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
+                                        const T (&inv)[KPL], const T (&row)[KPL], T alpha) {
+    const T h = bcast_lane(H[R], L), wo = bcast_lane(w[R], L), qq = bcast_lane(q[R], L), ri = bcast_lane(inv[R], L);
+    const T Qcc = bcast_lane(row[R], L);
+    const T x = cd_coordinate<T, POSITIVE>(h, wo, qq, ri, Qcc, alpha);
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) H[r] = fma(x, row[r], fma(-wo, row[r], H[r]));
+    if (lane == L) w[R] = x;
+}
+
+template <typename T, int KPL, bool FULL, bool POSITIVE>
+__device__ __forceinline__ void cd_sparse_sweep(int lane, int k, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
+                                                const T (&inv)[KPL], unsigned long long (&m)[KPL],
+                                                const T *__restrict__ Q, T alpha) {
+    T rowA[KPL], rowB[KPL];
+    int next = cd_next<KPL>(m, 0);
+    if (next >= k) return;
+    load_row<T, KPL, FULL>(Q + (int64_t)next * k, k, lane, rowA);
+    while (true) {
+        const int ii = next;
+        const int pred = cd_next<KPL>(m, ii + 1);             // next active coordinate as of now
+        if (pred < k) load_row<T, KPL, FULL>(Q + (int64_t)pred * k, k, lane, rowB);
+        const int L = ii & 63;
+        switch (ii >> 6) {
+#define MODL_CD_CASE(R)                                                                              \
+    case R:                                                                                          \
+        if constexpr (R < KPL) cd_step<T, KPL, R, POSITIVE>(L, lane, w, H, q, inv, rowA, alpha); \
+        break;
+            MODL_CD_CASE(0) MODL_CD_CASE(1) MODL_CD_CASE(2) MODL_CD_CASE(3) MODL_CD_CASE(4) MODL_CD_CASE(5)
+            MODL_CD_CASE(6) MODL_CD_CASE(7) MODL_CD_CASE(8) MODL_CD_CASE(9) MODL_CD_CASE(10) MODL_CD_CASE(11)
+            MODL_CD_CASE(12) MODL_CD_CASE(13) MODL_CD_CASE(14) MODL_CD_CASE(15)
+#undef MODL_CD_CASE
+        }
+        cd_active<T, KPL, POSITIVE>(w, H, q, inv, alpha, m);
+        const int nn = cd_next<KPL>(m, ii + 1);
+        if (pred < k && nn >= pred) {
+            // the prediction holds, or the predicted coordinate went inactive (w == 0 there: a no-op step)
+            next = pred;
+#pragma unroll
+            for (int r = 0; r < KPL; ++r) rowA[r] = rowB[r];
+        } else {
+            if (nn >= k) return;
+            next = nn;                                        // activated by this step: synchronous load
+            load_row<T, KPL, FULL>(Q + (int64_t)next * k, k, lane, rowA);
+        }
+    }
+}
+
+template <typename T, int KPL, bool FULL, bool POSITIVE>
 __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
-    constexpr int PG = (KPL >= 4) ? 4 : KPL;     // rows per prefetch chunk
     const int lane = threadIdx.x & 63;
     const int smp = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (smp >= a.b) return;                        // whole wave exits together
@@ -118,21 +197,20 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
     const int64_t row_out = a.idx ? a.idx[smp] : (int64_t)smp;
     T *wptr = a.code + row_out * k;
     const T *qptr = a.Dx + (int64_t)smp * k;
-    const int e0 = lane * KPL;
-    const int n_li = (k + KPL - 1) / KPL;          // lanes that own coefficients
     const T alpha = a.alpha, beta = a.beta;
     constexpr bool positive = POSITIVE;
 
-    T w[KPL], H[KPL], q[KPL], dg[KPL], inv[KPL];
+    T w[KPL], H[KPL], q[KPL], inv[KPL];
 #pragma unroll
     for (int c = 0; c < KPL; ++c) {
-        const bool in = e0 + c < k;
-        const int e = in ? e0 + c : 0;
+        const int e0 = c * 64 + lane;
+        const bool in = e0 < k;
+        const int e = in ? e0 : 0;
         const T wv = wptr[e], qv = qptr[e], dv = Q[(int64_t)e * k + e];
         w[c] = in ? wv : (T)0;
         q[c] = in ? qv : (T)0;
-        dg[c] = in ? dv : (T)0;
-        inv[c] = (dg[c] != (T)0) ? (T)1 / (dg[c] + beta) : (T)0;   // reciprocal of the step denominator (:373)
+        const T dg = in ? dv : (T)0;
+        inv[c] = (dg != (T)0) ? (T)1 / (dg + beta) : (T)0;   // reciprocal of the step denominator (:373); 0 = skipped
         H[c] = 0;
     }
     const T y_norm2 = a.xnorm2[smp];
@@ -143,40 +221,57 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
         const T *hp = a.H0 + (int64_t)smp * k;
 #pragma unroll
         for (int c = 0; c < KPL; ++c) {
-            const T hv = hp[e0 + c < k ? e0 + c : 0];
-            H[c] = (e0 + c < k) ? hv : (T)0;
+            const int e0 = c * 64 + lane;
+            const T hv = hp[e0 < k ? e0 : 0];
+            H[c] = (e0 < k) ? hv : (T)0;
         }
     } else {
         // H = Q w as a combination of rows (Q is symmetric, as the solver itself assumes)
-        for (int li = 0; li < n_li; ++li) {
 #pragma unroll
-            for (int c = 0; c < KPL; ++c) {
-                const int j = li * KPL + c;
-                const T wj = (j < k) ? bcast_lane(w[c], li) : (T)0;
+        for (int c = 0; c < KPL; ++c) {
+            for (int L = 0; L < 64 && c * 64 + L < k; ++L) {
+                const T wj = bcast_lane(w[c], L);
                 T r[KPL];
-                load_row<T, KPL, VEC>(Q + (int64_t)(j < k ? j : 0) * k, k, lane, n_li, r);
+                load_row<T, KPL, FULL>(Q + (int64_t)(c * 64 + L) * k, k, lane, r);
 #pragma unroll
                 for (int c2 = 0; c2 < KPL; ++c2) H[c2] = fma(wj, r[c2], H[c2]);
             }
         }
     }
 
-    T cur[PG][KPL], nxt[PG][KPL];
-#pragma unroll
-    for (int j = 0; j < PG; ++j) load_row<T, KPL, VEC>(Q + (int64_t)(j < k ? j : 0) * k, k, lane, n_li, cur[j]);
-
     int n_iter = 0;
     for (; n_iter < a.max_iter; ++n_iter) {
-        T w_max = 0, d_w_max = 0;
-        for (int li = 0; li < n_li; ++li) {
-            cd_chunk<T, KPL, PG, 0, VEC, POSITIVE>(li, n_li, lane, k, w, H, q, inv, cur, nxt, Q, alpha, w_max, d_w_max);
-            if constexpr (KPL > 4)
-                cd_chunk<T, KPL, PG, 4, VEC, POSITIVE>(li, n_li, lane, k, w, H, q, inv, cur, nxt, Q, alpha, w_max, d_w_max);
-            if constexpr (KPL > 8) {
-                cd_chunk<T, KPL, PG, 8, VEC, POSITIVE>(li, n_li, lane, k, w, H, q, inv, cur, nxt, Q, alpha, w_max, d_w_max);
-                cd_chunk<T, KPL, PG, 12, VEC, POSITIVE>(li, n_li, lane, k, w, H, q, inv, cur, nxt, Q, alpha, w_max, d_w_max);
-            }
+        unsigned long long m[KPL];
+        cd_active<T, KPL, POSITIVE>(w, H, q, inv, alpha, m);
+        int n_act = 0;
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) n_act += __builtin_popcountll(m[r]);
+        T w0[KPL];                                 // a coefficient changes once per sweep: d_w_ii = |w - w0| (:380-384)
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) w0[r] = w[r];
+        if (6 * n_act > k) {                       // a sparse step costs several dense coordinates
+            T ring[kCdRing][KPL];
+#pragma unroll
+            for (int j = 0; j < kCdRing; ++j)
+                load_row<T, KPL, FULL>(Q + (int64_t)(j < k ? j : k - 1) * k, k, lane, ring[j]);
+#define MODL_CD_REG(R) \
+    if constexpr (R < KPL) cd_dense_register<T, KPL, R, FULL, POSITIVE>(lane, k, w, H, q, inv, ring, Q, alpha);
+            MODL_CD_REG(0) MODL_CD_REG(1) MODL_CD_REG(2) MODL_CD_REG(3) MODL_CD_REG(4) MODL_CD_REG(5) MODL_CD_REG(6)
+            MODL_CD_REG(7) MODL_CD_REG(8) MODL_CD_REG(9) MODL_CD_REG(10) MODL_CD_REG(11) MODL_CD_REG(12)
+            MODL_CD_REG(13) MODL_CD_REG(14) MODL_CD_REG(15)
+#undef MODL_CD_REG
+        } else {
+            cd_sparse_sweep<T, KPL, FULL, POSITIVE>(lane, k, w, H, q, inv, m, Q, alpha);
         }
+        T dmx = 0, wmx = 0;                        // skipped coordinates (zero diagonal) do not count (:357)
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) {
+            const bool lv = inv[r] != (T)0;
+            const T d = lv ? fabs(w[r] - w0[r]) : (T)0, aw = lv ? fabs(w[r]) : (T)0;
+            dmx = d > dmx ? d : dmx;
+            wmx = aw > wmx ? aw : wmx;
+        }
+        const T d_w_max = wave_max(dmx), w_max = wave_max(wmx);
         if (w_max == (T)0 || d_w_max / w_max < d_w_tol || n_iter == a.max_iter - 1) {   // :388
             T s_qw = 0, s_wH = 0, s_ww = 0, s_l1 = 0;
             T xmax = positive ? -INFINITY : (T)0;
@@ -186,10 +281,10 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
                 s_wH += w[c] * H[c];
                 s_ww += w[c] * w[c];
                 s_l1 += fabs(w[c]);
-                if (e0 + c < k) {
+                if (c * 64 + lane < k) {
                     const T x = (q[c] - H[c]) - beta * w[c];                          // :397
-                    const T m = positive ? x : fabs(x);
-                    xmax = m > xmax ? m : xmax;
+                    const T mx = positive ? x : fabs(x);
+                    xmax = mx > xmax ? mx : xmax;
                 }
             }
             const T q_dot_w = wave_sum(s_qw);
@@ -214,22 +309,22 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
     }
 #pragma unroll
     for (int c = 0; c < KPL; ++c)
-        if (e0 + c < k) wptr[e0 + c] = w[c];
+        if (c * 64 + lane < k) wptr[c * 64 + lane] = w[c];
     if (a.sweeps && lane == 0) a.sweeps[smp] = n_iter;
 }
 
 template <typename T, int KPL>
 static void launch_cd_kpl(hipStream_t stream, const CdArgs<T> &a, dim3 grid, dim3 block) {
-    constexpr size_t kRowAlign = (KPL * sizeof(T) >= 16) ? 16 : KPL * sizeof(T);
-    const bool vec = (a.k % KPL == 0) && (reinterpret_cast<uintptr_t>(a.G) % kRowAlign == 0) &&
-                     ((a.g_stride * sizeof(T)) % kRowAlign == 0) && (((size_t)a.k * sizeof(T)) % kRowAlign == 0);
-    if (vec) {
-        if (a.positive) hipLaunchKernelGGL((cd_kernel<T, KPL, true, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((cd_kernel<T, KPL, true, false>), grid, block, 0, stream, a);
+    const bool full = a.k == 64 * KPL;
+#define MODL_CD_LAUNCH(FULL, POS) hipLaunchKernelGGL((cd_kernel<T, KPL, FULL, POS>), grid, block, 0, stream, a)
+    if (full) {
+        if (a.positive) MODL_CD_LAUNCH(true, true);
+        else MODL_CD_LAUNCH(true, false);
     } else {
-        if (a.positive) hipLaunchKernelGGL((cd_kernel<T, KPL, false, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((cd_kernel<T, KPL, false, false>), grid, block, 0, stream, a);
+        if (a.positive) MODL_CD_LAUNCH(false, true);
+        else MODL_CD_LAUNCH(false, false);
     }
+#undef MODL_CD_LAUNCH
 }
 
 template <typename T>
