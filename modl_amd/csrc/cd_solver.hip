@@ -35,29 +35,34 @@ namespace modl {
 // Row loader: coefficient c * 64 + lane in r[c].  No branches: lanes past the end read a clamped
 // address and select zero, so all loads of a chunk stay in flight together.  FULL: k == 64 * KPL.
 template <typename T, int KPL, bool FULL>
-__device__ __forceinline__ void load_row(const T *__restrict__ row, int k, int lane, T (&r)[KPL]) {
+__device__ __forceinline__ void load_row(const T *__restrict__ Q, int ii, int k, int lane, T (&r)[KPL]) {
+    const unsigned int base = (unsigned int)ii * (unsigned int)k;      // k <= 1024: 32-bit element offsets
+    if constexpr (FULL) {
+        const T *rp = (Q + lane) + base;           // one 64-bit add per row, the registers differ by an immediate
 #pragma unroll
-    for (int c = 0; c < KPL; ++c) {
-        const int e = c * 64 + lane;
-        if constexpr (FULL) {
-            r[c] = row[e];
-        } else {
-            const T v = row[e < k ? e : k - 1];
+        for (int c = 0; c < KPL; ++c) r[c] = rp[c * 64];
+    } else {
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+            const int e = c * 64 + lane;
+            const T v = Q[base + (unsigned int)(e < k ? e : k - 1)];
             r[c] = e < k ? v : (T)0;
         }
     }
 }
+
+__device__ __forceinline__ float clamp3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ double clamp3(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 
 // One coordinate on wave-uniform scalars (dict_fact_fast.pyx:354-386); returns the new coefficient.
 template <typename T, bool POSITIVE>
 __device__ __forceinline__ T cd_coordinate(T h, T wo, T qq, T ri, T Qcc, T alpha) {
     const T Hii = fma(-wo, Qcc, h);                            // H[ii] after "H -= w_ii * Q[ii]" (:361-365)
     const T tmp = qq - Hii;                                    // :367
-    T mag = fabs(tmp) - alpha;                                 // :372 soft threshold
-    mag = mag > (T)0 ? mag : (T)0;
-    T x = copysign(mag * ri, tmp);
-    if (POSITIVE && tmp < (T)0) x = 0;
-    return x;
+    // :372 soft threshold sign(tmp) max(|tmp| - alpha, 0) as tmp - clamp(tmp, -alpha, alpha): the same
+    // rounded difference, two operations shorter (a zero result may carry the other sign)
+    const T cl = POSITIVE ? (tmp < alpha ? tmp : alpha) : clamp3(tmp, -alpha, alpha);
+    return (tmp - cl) * ri;
 }
 
 constexpr int kCdRing = 8;       // Gram rows in flight in the dense sweep (an L2 hit costs several coordinates)
@@ -65,18 +70,17 @@ constexpr int kCdRing = 8;       // Gram rows in flight in the dense sweep (an L
 // One coordinate ii = R * 64 + L of a dense sweep.  The update formula is evaluated by EVERY lane on its
 // own coefficient (the values of the other lanes are discarded): no scalar has to be fetched before the
 // arithmetic, and the only cross-lane traffic is the pair (w_new, w_old) of lane L, read with v_readlane
-// after it — 2 wave-wide reads per coordinate.  A zero diagonal skips the coordinate (:357): both
-// multipliers are then zero and H is unchanged bit for bit.
+// after it — 2 wave-wide reads per coordinate.  A zero diagonal skips the coordinate (:357): its working
+// coefficient is 0 and so is its step (inv = 0), both multipliers vanish and H is unchanged bit for bit.
 template <typename T, int KPL, int R, bool POSITIVE>
-__device__ __forceinline__ void cd_coord(int L, unsigned long long live, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
+__device__ __forceinline__ void cd_coord(int L, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
                                          const T (&inv)[KPL], const T (&row)[KPL], T alpha) {
     const T wv = w[R];
     const T xv = cd_coordinate<T, POSITIVE>(H[R], wv, q[R], inv[R], row[R], alpha);
-    const bool lv = inv[R] != (T)0;
-    const T dn = bcast_lane(lv ? xv : (T)0, L), dold = bcast_lane(lv ? wv : (T)0, L);
+    const T dn = bcast_lane(xv, L), dold = bcast_lane(wv, L);
 #pragma unroll
     for (int r = 0; r < KPL; ++r) H[r] = fma(dn, row[r], fma(-dold, row[r], H[r]));   // :361-365, :375-378
-    w[R] = __builtin_amdgcn_inverse_ballot_w64((1ull << L) & live) ? xv : wv;   // lane L only (scalar mask)
+    w[R] = __builtin_amdgcn_inverse_ballot_w64(1ull << L) ? xv : wv;   // lane L only (scalar mask)
 }
 
 // coordinates R * 64 .. R * 64 + 63 with a ring of kCdRing row buffers: row ii + kCdRing is requested as
@@ -85,7 +89,6 @@ template <typename T, int KPL, int R, bool FULL, bool POSITIVE>
 __device__ __forceinline__ void cd_dense_register(int lane, int k, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
                                                   const T (&inv)[KPL], T (&ring)[kCdRing][KPL],
                                                   const T *__restrict__ Q, T alpha) {
-    const unsigned long long live = __ballot(inv[R] != (T)0);
     int cnt = k - R * 64;
     cnt = cnt > 64 ? 64 : cnt;
     if (cnt <= 0) return;
@@ -96,9 +99,10 @@ __device__ __forceinline__ void cd_dense_register(int lane, int k, T (&w)[KPL], 
 #pragma unroll
         for (int j = 0; j < kCdRing; ++j) {
             const int ii = R * 64 + g * kCdRing + j;
-            cd_coord<T, KPL, R, POSITIVE>(g * kCdRing + j, live, w, H, q, inv, ring[j], alpha);
+            cd_coord<T, KPL, R, POSITIVE>(g * kCdRing + j, w, H, q, inv, ring[j], alpha);
+            __builtin_amdgcn_sched_barrier(0);
             const int nx = (ii + kCdRing < k) ? ii + kCdRing : k - 1;
-            load_row<T, KPL, FULL>(Q + (int64_t)nx * k, k, lane, ring[j]);
+            load_row<T, KPL, FULL>(Q, nx, k, lane, ring[j]);
             // keep the request where it is: the scheduler otherwise gathers the group's loads at the end of
             // the loop body, and the wait for row ii then sits right behind its own request
             __builtin_amdgcn_sched_barrier(0);
@@ -107,7 +111,7 @@ __device__ __forceinline__ void cd_dense_register(int lane, int k, T (&w)[KPL], 
     if constexpr (!FULL) {                         // ragged end of the last register: its rows are in the ring
 #pragma unroll
         for (int j = 0; j < kCdRing - 1; ++j)
-            if (j < tail) cd_coord<T, KPL, R, POSITIVE>(groups * kCdRing + j, live, w, H, q, inv, ring[j], alpha);
+            if (j < tail) cd_coord<T, KPL, R, POSITIVE>(groups * kCdRing + j, w, H, q, inv, ring[j], alpha);
     }
 }
 
@@ -156,11 +160,11 @@ __device__ __forceinline__ void cd_sparse_sweep(int lane, int k, T (&w)[KPL], T 
     T rowA[KPL], rowB[KPL];
     int next = cd_next<KPL>(m, 0);
     if (next >= k) return;
-    load_row<T, KPL, FULL>(Q + (int64_t)next * k, k, lane, rowA);
+    load_row<T, KPL, FULL>(Q, next, k, lane, rowA);
     while (true) {
         const int ii = next;
         const int pred = cd_next<KPL>(m, ii + 1);             // next active coordinate as of now
-        if (pred < k) load_row<T, KPL, FULL>(Q + (int64_t)pred * k, k, lane, rowB);
+        if (pred < k) load_row<T, KPL, FULL>(Q, pred, k, lane, rowB);
         const int L = ii & 63;
         switch (ii >> 6) {
 #define MODL_CD_CASE(R)                                                                              \
@@ -182,7 +186,7 @@ __device__ __forceinline__ void cd_sparse_sweep(int lane, int k, T (&w)[KPL], T 
         } else {
             if (nn >= k) return;
             next = nn;                                        // activated by this step: synchronous load
-            load_row<T, KPL, FULL>(Q + (int64_t)next * k, k, lane, rowA);
+            load_row<T, KPL, FULL>(Q, next, k, lane, rowA);
         }
     }
 }
@@ -232,11 +236,21 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
             for (int L = 0; L < 64 && c * 64 + L < k; ++L) {
                 const T wj = bcast_lane(w[c], L);
                 T r[KPL];
-                load_row<T, KPL, FULL>(Q + (int64_t)(c * 64 + L) * k, k, lane, r);
+                load_row<T, KPL, FULL>(Q, c * 64 + L, k, lane, r);
 #pragma unroll
                 for (int c2 = 0; c2 < KPL; ++c2) H[c2] = fma(wj, r[c2], H[c2]);
             }
         }
+    }
+
+    // Working coefficients: a skipped coordinate (zero diagonal, :357) keeps its value in wfix and carries 0
+    // in w, so that the sweeps need no per-coordinate liveness test (its step inv is 0 as well).
+    T wfix[KPL];
+#pragma unroll
+    for (int c = 0; c < KPL; ++c) {
+        const bool lv = inv[c] != (T)0;
+        wfix[c] = lv ? (T)0 : w[c];
+        w[c] = lv ? w[c] : (T)0;
     }
 
     int n_iter = 0;
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
             T ring[kCdRing][KPL];
 #pragma unroll
             for (int j = 0; j < kCdRing; ++j)
-                load_row<T, KPL, FULL>(Q + (int64_t)(j < k ? j : k - 1) * k, k, lane, ring[j]);
+                load_row<T, KPL, FULL>(Q, j < k ? j : k - 1, k, lane, ring[j]);
 #define MODL_CD_REG(R) \
     if constexpr (R < KPL) cd_dense_register<T, KPL, R, FULL, POSITIVE>(lane, k, w, H, q, inv, ring, Q, alpha);
             MODL_CD_REG(0) MODL_CD_REG(1) MODL_CD_REG(2) MODL_CD_REG(3) MODL_CD_REG(4) MODL_CD_REG(5) MODL_CD_REG(6)
@@ -263,11 +277,10 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
         } else {
             cd_sparse_sweep<T, KPL, FULL, POSITIVE>(lane, k, w, H, q, inv, m, Q, alpha);
         }
-        T dmx = 0, wmx = 0;                        // skipped coordinates (zero diagonal) do not count (:357)
+        T dmx = 0, wmx = 0;                        // skipped coordinates do not count (:357): their w is 0 here
 #pragma unroll
         for (int r = 0; r < KPL; ++r) {
-            const bool lv = inv[r] != (T)0;
-            const T d = lv ? fabs(w[r] - w0[r]) : (T)0, aw = lv ? fabs(w[r]) : (T)0;
+            const T d = fabs(w[r] - w0[r]), aw = fabs(w[r]);
             dmx = d > dmx ? d : dmx;
             wmx = aw > wmx ? aw : wmx;
         }
@@ -277,12 +290,13 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
             T xmax = positive ? -INFINITY : (T)0;
 #pragma unroll
             for (int c = 0; c < KPL; ++c) {
-                s_qw += w[c] * q[c];
-                s_wH += w[c] * H[c];
-                s_ww += w[c] * w[c];
-                s_l1 += fabs(w[c]);
+                const T wt = w[c] + wfix[c];                                          // one of the two is zero
+                s_qw += wt * q[c];
+                s_wH += wt * H[c];
+                s_ww += wt * wt;
+                s_l1 += fabs(wt);
                 if (c * 64 + lane < k) {
-                    const T x = (q[c] - H[c]) - beta * w[c];                          // :397
+                    const T x = (q[c] - H[c]) - beta * wt;                            // :397
                     const T mx = positive ? x : fabs(x);
                     xmax = mx > xmax ? mx : xmax;
                 }
@@ -309,7 +323,7 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
     }
 #pragma unroll
     for (int c = 0; c < KPL; ++c)
-        if (c * 64 + lane < k) wptr[c * 64 + lane] = w[c];
+        if (c * 64 + lane < k) wptr[c * 64 + lane] = w[c] + wfix[c];
     if (a.sweeps && lane == 0) a.sweeps[smp] = n_iter;
 }
 
