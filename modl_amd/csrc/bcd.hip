@@ -44,7 +44,7 @@ constexpr int kGroup = 16;         // minimum workgroups per group of the two-le
 constexpr int kCounters = 64;      // arrival counters: [0] final, [1 + g] group g
 
 struct DuLayout {
-    size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, off_BsP, off_gpartial, total;
+    size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, off_BsP, off_gpartial, off_norm_in, total;
     int64_t nslab_max, nwg_grad;
 };
 
@@ -59,14 +59,15 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     L.off_frozen = take(sizeof(int32_t) * (size_t)k);
     L.off_coef = take(sizeof(double) * (size_t)kNB * k);
     L.off_a = take(tsz * (size_t)s_max * kNB);
-    L.off_partial = take(sizeof(double) * (size_t)L.nslab_max * (kNB * kNB + kNB));
+    L.off_partial = take(sizeof(double) * 2 * (size_t)L.nslab_max * (kNB * kNB + kNB));   // two record buffers (ping-pong)
     L.off_Tp = take(sizeof(double) * 2 * (kNB * kNB + kNB) + 256 + 512);  // two CA records (ping-pong) + arrival counters + debug stamps
     L.off_u = take(tsz * (size_t)s_max);
     L.off_pold = take(sizeof(double) * (size_t)L.nwg_grad);
     L.off_Dnew = take(tsz * (size_t)s_max * k);                       // sgd only, but sized once
     L.off_colp = take(sizeof(double) * (size_t)L.nslab_max * k);
     L.off_BsP = take(tsz * (size_t)s_max * k);                        // packed B rows (packed D shares off_Dnew)
-    L.off_gpartial = take(sizeof(double) * (size_t)kCounters * (kNB * kNB + kNB));   // group sums (two-level reduction)
+    L.off_gpartial = take(sizeof(double) * 2 * (size_t)kCounters * (kNB * kNB + kNB));   // group sums (two-level reduction), ping-pong
+    L.off_norm_in = take(tsz * (size_t)k);
     L.total = o;
     return L;
 }
@@ -84,8 +85,11 @@ __device__ __forceinline__ int64_t sub_row(const int32_t *subset, int64_t f) { r
 // ---------------------------------------------------------------- blocked path
 template <typename T>
 __global__ __launch_bounds__(256) void bcd_prepare_kernel(const T *C, const int32_t *order, int k, T *CP, T *cdiag,
-                                                          int32_t *frozen, double *coef_all, unsigned int *counter) {
+                                                          int32_t *frozen, double *coef_all, unsigned int *counter,
+                                                          const T *comp_norm, T *norm_in) {
     if (blockIdx.x == 0 && threadIdx.x < kCounters) counter[threadIdx.x] = 0;   // arrival tickets of the fused block kernel
+    if (blockIdx.x == 0)                             // the budgets as they are before this update (fused path)
+        for (int j = threadIdx.x; j < k; j += 256) norm_in[j] = comp_norm[j];
     extern __shared__ int32_t inv[];                 // position of each atom in the sweep
     for (int j = threadIdx.x; j < k; j += 256) inv[order[j]] = j;
     __syncthreads();
@@ -208,13 +212,14 @@ __device__ __forceinline__ double fast_rcp(double v) {
 }
 
 constexpr int kResStride = kNB * kNB + kNB;          // doubles per Gram partial / per CA record
+constexpr int kPackStride = 3 * 256 + kNB;           // fused path: tiles (0,0) (0,1) (1,1) of 16 x 16 + old norms (the Gram is symmetric)
 
 // Sum n Gram records (kResStride doubles each) in a fixed order, all 256 threads of the workgroup; element
 // e = tid + 256 q goes to sink(e, sum).  Every load of a chunk of 16 records is issued before the first
 // add (a dependent load -> add loop costs one memory round trip per record).
-template <typename Sink>
+template <int STRIDE, typename Sink>
 __device__ __forceinline__ void reduce_records(const double *rec, int n, Sink sink) {
-    constexpr int NQ = (kResStride + 255) / 256;
+    constexpr int NQ = (STRIDE + 255) / 256;
     double tot[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) tot[q] = 0.0;
@@ -223,13 +228,14 @@ __device__ __forceinline__ void reduce_records(const double *rec, int n, Sink si
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int e = threadIdx.x + 256 * q;
-            const int ec = (e < kResStride) ? e : 0;
+            const int ec = (e < STRIDE) ? e : 0;
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int z = (z0 + u < n) ? z0 + u : n - 1;
-                v[q][u] = rec[(int64_t)z * kResStride + ec];
+                v[q][u] = rec[(int64_t)z * STRIDE + ec];
             }
         }
+        __builtin_amdgcn_sched_barrier(0);           // all requests first: one memory round trip, not NQ
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
 #pragma unroll
@@ -242,7 +248,7 @@ __device__ __forceinline__ void reduce_records(const double *rec, int n, Sink si
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int e = threadIdx.x + 256 * q;
-        if (e < kResStride) sink(e, tot[q]);
+        if (e < STRIDE) sink(e, tot[q]);
     }
 }
 struct SinkLds {
@@ -252,12 +258,22 @@ struct SinkLds {
         else D2[e - kNB * kNB] = v;
     }
 };
+struct SinkLdsPacked {   // packed record -> full symmetric matrix
+    double (*M)[kNB + 1]; double *D2;
+    __device__ __forceinline__ void operator()(int e, double v) const {
+        if (e >= 3 * 256) { D2[e - 3 * 256] = v; return; }
+        const int t = e >> 8, r = (e >> 4) & 15, c = e & 15;
+        const int i = (t == 2 ? 16 : 0) + r, j = (t == 0 ? 0 : 16) + c;
+        M[i][j] = v;
+        if (t == 1) M[j][i] = v;
+    }
+};
 struct SinkGlobal {
     double *dst;
     __device__ __forceinline__ void operator()(int e, double v) const { dst[e] = v; }
 };
 __device__ __forceinline__ void reduce_partials(const double *partial, int nslab, double (*M)[kNB + 1], double *D2) {
-    reduce_records(partial, nslab, SinkLds{M, D2});
+    reduce_records<kResStride>(partial, nslab, SinkLds{M, D2});
 }
 
 // "Last arriver" hand-off (cdna guide, split-K recipe): release our stores, take a ticket, and if we are
@@ -321,19 +337,19 @@ __device__ __forceinline__ void rows_pair(double z, double &even, double &odd) {
 // the only cross-lane traffic on the serial chain is the half swap, the row sum and two v_readlane.
 // The j loop is fully unrolled: every register index is static.  Output per block: CA[j][m] = S[j][m]
 // (the apply step forms D_j = sum_m S[j][m] a_m feature by feature) and the new norm budgets.
+// budget_x: the norm budget of atom x of the block before the update (0 beyond nb); jj_x: its atom index
 template <typename T>
 __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const double *D2, const double *Cs,
-                                             const int32_t *order, int j0, int nb, T *comp_norm, double *CAout,
-                                             unsigned long long *stamps = nullptr) {
+                                             int jj_x, double budget_x, int nb, T *norm_out,
+                                             double *CAout, int ca_stride, unsigned long long *stamps = nullptr) {
     const int lane = threadIdx.x & 63, x = lane & 31;
     const bool lower = lane < 32;
     double Z[kNB];
-    const int jj_x = (x < nb) ? order[j0 + x] : 0;
-    const double rad_x = ((x < nb) ? (double)comp_norm[jj_x] : 0.0) + D2[x];    // budget + old squared norm
+    const double rad_x = budget_x + D2[x];                                       // budget + old squared norm
     const double srad_x = (rad_x > 0.0) ? sqrt(rad_x) : 0.0;
     double newnorm_x = 0.0;
     const double hmask = lower ? 0.0 : 1.0;
-    if (stamps && threadIdx.x == 0) stamps[8] = clock64() + (unsigned long long)(srad_x * 0);
+    if (stamps && lane == 0) stamps[8] = clock64() + (unsigned long long)(srad_x * 0);
     // One straight-line basic block (no branch inside the unrolled loop: columns >= nb get alpha = 0),
     // software-pipelined by hand: while the serial tail of step j runs (half swap, row sums, 1/sqrt,
     // selects), the terms i < j of step j + 1 are accumulated; between alpha_j and the start of step
@@ -342,7 +358,7 @@ __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const d
     double al_prev = 0.0, q_prev = 0.0, z_prev = 0.0;
 #pragma unroll
     for (int j = 0; j < kNB; ++j) {
-        if (stamps && threadIdx.x == 0 && (j % 8) == 0 && j > 0) stamps[8 + j / 8] = clock64();
+        if (stamps && lane == 0 && (j % 8) == 0 && j > 0) stamps[8 + j / 8] = clock64();
         const double z = __builtin_fma(-al_prev, q_prev, part);
         double t, w;
         halves(z, t, w);
@@ -382,8 +398,8 @@ __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const d
     Z[kNB - 1] = al_prev * z_prev;
     if (lower) {
 #pragma unroll
-        for (int j = 0; j < kNB; ++j) CAout[j * kNB + x] = Z[j];
-        if (x < nb) comp_norm[jj_x] = (T)newnorm_x;
+        for (int j = 0; j < kNB; ++j) CAout[j * ca_stride + x] = Z[j];
+        if (norm_out && x < nb) norm_out[jj_x] = (T)newnorm_x;
     }
 }
 
@@ -397,7 +413,12 @@ __global__ __launch_bounds__(256) void bcd_resolve_kernel(const double *partial,
     stage_coef(coef_all, k, j0, Cs);
     reduce_partials(partial, nslab, M, D2);
     __syncthreads();
-    if (threadIdx.x < 64) resolve_wave<T>(M, D2, Cs, order, j0, nb, comp_norm, CAout);
+    if (threadIdx.x < 64) {
+        const int x = threadIdx.x & 31;
+        const int jj_x = (x < nb) ? order[j0 + x] : 0;
+        const double budget_x = (x < nb) ? (double)comp_norm[jj_x] : 0.0;
+        resolve_wave<T>(M, D2, Cs, jj_x, budget_x, nb, comp_norm, CAout, kNB);
+    }
 }
 
 // D_new[f][o_j] = sum_{m <= j} Tp[j][m] a_m[f]  for the atoms j = jg, jg + NSTR, ... of one sampled feature
@@ -468,295 +489,346 @@ __global__ __launch_bounds__(256) void bcd_permute_C_kernel(const T *C, const in
 }
 
 // ---- fused block kernel (f32) -------------------------------------------------------------------
-// One launch per block of NB atoms:
-//   (0) apply the PREVIOUS block's result to this workgroup's features (they are workgroup-private);
-//   (1) a = (B - D_cur CP) / diag on the matrix cores: the four wavefronts split the contraction over
-//       the k atoms, dictionary rows go straight from HBM/L2 into MFMA A-operands (one 16-byte load per
-//       lane: 32 rows x 8 consecutive atoms per wave instruction), the k x NB coefficient block sits in
-//       LDS, partial accumulators are summed across the waves in a fixed order;
-//   (2) the NB x NB Gram contribution of these RB features, in double precision from LDS;
-//   (3) the LAST workgroup to finish (agent-scope release / relaxed ticket / acquire, no spinning) sums
-//       the partials in a fixed order and runs the alpha recursion for the block.
+// One launch per block of NB atoms, 5 wavefronts per workgroup (4 workers + 1 resolver), RB features per
+// workgroup.  Launch b
+//   (A) requests everything it needs from HBM/L2 at once (one memory round trip);
+//   (B) sums the Gram records of block b - 1 (written by launch b - 1) in a fixed order — EVERY workgroup
+//       does this redundantly, so no cross-workgroup hand-off sits on the critical path;
+//   (C) resolver wave: the alpha recursion of block b - 1 (its result stays in LDS);  meanwhile the
+//       workers form a = D CP on the matrix cores with the dictionary AS IT IS IN MEMORY: dictionary rows go
+//       straight from HBM/L2 into MFMA A-operands, the k x NB coefficient block sits in LDS, the four
+//       waves split the contraction over the k atoms;
+//   (D) apply block b - 1 to this workgroup's features: D_j = sum_m S[j][m] a_m on the f64 matrix cores;
+//   (E) the 32 columns that (D) changed enter the product through a rank-32 correction (D_cur = D_mem + Delta);
+//   (F) a = (B - D CP) / diag, written out and kept in LDS;
+//   (G) the NB x NB Gram contribution of these RB features on the f64 matrix cores -> one record per
+//       workgroup (two buffers: the records a launch reads in (B) are not the ones it writes in (G)).
+//       With more than `group` workgroups the last workgroup of each group to finish pre-sums its group's
+//       records (release / relaxed ticket / acquire, no spinning), so that (B) of the next launch reads at
+//       most kCounters records.
+// The last launch (nb == 0) only runs (A)-(D) for the final block.
+constexpr int kCaStride = kNB + 2;      // LDS row stride (doubles) of the S matrix: 2-way instead of 16-way conflicts
+constexpr int kApStride = kNB + 4;      // LDS row stride (floats) of the staged a-tile
+
 struct BcdBlockArgs {
     float *Dt;                      // PACKED dictionary [s][k]: row = sampled feature, column = sweep position
     const float *Bt, *CP, *cdiag;   // packed B [s][k]; CP [k][k] in sweep coordinates (rows and columns)
     const int32_t *frozen, *order;
-    float *a;
-    double *partial, *gpartial;
+    float *a;                       // [s][NB] the a-tile: block b - 1's on entry, block b's on exit
+    double *rec_out, *grec_out;     // Gram records / group sums written by this launch
+    const double *rec_in, *grec_in; // ... written by the previous launch
     const double *coef_all;
-    double *CA_prev, *CA_out;       // CA record of the previous block (null for the first) / of this block
-    float *comp_norm;
+    const float *norm_in;           // norm budgets as they were before this dictionary update
+    float *norm_out;                // comp_norm (written by workgroup 0 only)
     unsigned int *counter;
-    unsigned long long *stamps;     // optional phase timestamps of the last-arriving workgroup (diagnostics)
+    unsigned long long *stamps;     // optional phase timestamps of workgroup 0 (diagnostics)
     int64_t s;
     int k, j0, nb, j0_prev, nb_prev, group;
 };
 
-template <int RT, int GPW>   // 32 * RT features per workgroup; GPW contraction groups (8 atoms) per wave
-__global__ __launch_bounds__(256) void bcd_block_kernel(BcdBlockArgs p) {
+template <int RT, int GPW>   // 32 * RT features per workgroup; GPW contraction groups (8 atoms) per worker wave
+__global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
     constexpr int RB = 32 * RT;
     constexpr int KPAD = GPW * 32;                   // 4 waves x GPW groups x 8 atoms  (>= k)
     constexpr int EPT = RB / 8;                      // epilogue elements per thread
+    constexpr int DLS = kNB + 4;                     // row stride of the Delta tile (16-byte aligned rows)
     typedef float f16v __attribute__((ext_vector_type(16)));
+    typedef double d4v __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int k = p.k;
     // LDS carve (all from the dynamic region, 16-byte aligned pieces)
-    double *Ms = reinterpret_cast<double *>(smem_raw);                        // [NB][NB + 1]  (last workgroup)
+    double *Ms = reinterpret_cast<double *>(smem_raw);                        // [NB][NB + 1]
     double *D2s = Ms + kNB * (kNB + 1);                                        // [NB]
-    double *CAs = D2s + kNB;                                                   // [NB * NB + NB] previous block's CA
-    double *d2red = CAs + kResStride;                                          // [8][NB]
+    double *Cs = D2s + kNB;                                                    // [NB][NB] recursion coefficients
+    double *CAs = Cs + kNB * kNB;                                              // [NB][kCaStride] S of the previous block
+    double *d2red = CAs + kNB * kCaStride;                                     // [8][NB]
     float *CPs = reinterpret_cast<float *>(d2red + 8 * kNB);                   // [KPAD][NB]
-    float *red = CPs + (size_t)KPAD * kNB;                                     // [4][RB][NB + 1]
+    float *red = CPs + (size_t)KPAD * kNB;                                     // [4][RB][NB + 1]; before (E): a-tile [RB][kApStride]
     float *As = red + 4 * RB * (kNB + 1);                                      // [RB][NB + 1]
-    float *Dl = As + RB * (kNB + 1) + ((4 - (RB * (kNB + 1)) % 4) % 4);        // [RB][NB + 4] Delta of the previous block
-    int *flag = reinterpret_cast<int *>(Dl + RB * (kNB + 4));
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float *Dl = As + RB * (kNB + 1) + ((4 - (RB * (kNB + 1)) % 4) % 4);        // [RB][DLS] Delta of the previous block
+    int *flag = reinterpret_cast<int *>(Dl + RB * DLS);
+    float *Ap = red;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const bool worker = wid < 4;
+    const bool has_prev = p.nb_prev > 0, fin = p.nb == 0;
     const int64_t f0 = (int64_t)blockIdx.x * RB;
-    unsigned long long ts[8];
-    ts[0] = clock64();
+    const int nwg = (int)gridDim.x, gsz = p.group, ngroups = (nwg + gsz - 1) / gsz;
+    unsigned long long *st = (p.stamps && blockIdx.x == 0 && !fin) ? p.stamps : nullptr;
+    if (st && tid == 0) st[0] = clock64();
 
-    // epilogue operands of this thread (column = tid % 32, rows tid / 32 + 8 q): issued first so that
-    // they arrive while the coefficient block is staged and the matrix cores run
-    const int col = threadIdx.x % kNB, rg = threadIdx.x / kNB;
+    // ---------------------------------------------------------------- (A) every global load, issued up front
+    const int col = tid % kNB, rg = (tid / kNB) % 8;             // epilogue: column, row group
     const bool col_ok = col < p.nb;
-    const int ocol = p.j0 + col;                    // packed layout: column = sweep position
-    const float cdg = col_ok ? p.cdiag[p.j0 + col] : 1.f;
-    const int fz = col_ok ? p.frozen[p.j0 + col] : 0;
-    float eB[EPT], eD[EPT];
-#pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int64_t f = f0 + rg + 8 * q;
-        const bool ok = col_ok && f < p.s;
-        const int64_t el = ok ? f * k + ocol : 0;
-        const float bv = p.Bt[el], dv = p.Dt[el];
-        eB[q] = ok ? bv : 0.f;
-        eD[q] = ok ? dv : 0.f;
-    }
-    // stage the k x NB coefficient block (rows beyond k and columns beyond nb are zero): all loads are
-    // issued before the first LDS store, otherwise every iteration is a full memory round trip
-    if (p.nb == kNB) {
-        constexpr int NQ = KPAD * (kNB / 4) / 256;
-        float4 cv[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int e = threadIdx.x + 256 * q;
-            const int m = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
-            const float4 v = *reinterpret_cast<const float4 *>(p.CP + (int64_t)(m < k ? m : 0) * k + p.j0 + c4);
-            cv[q] = (m < k) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int e = threadIdx.x + 256 * q;
-            const int m = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
-            *reinterpret_cast<float4 *>(CPs + m * kNB + c4) = cv[q];
-        }
-    } else {
-        for (int e = threadIdx.x; e < KPAD * kNB; e += 256) {
-            const int m = e / kNB, jj = e % kNB;
-            CPs[e] = (m < k && jj < p.nb) ? p.CP[(int64_t)m * k + p.j0 + jj] : 0.f;
-        }
-    }
-    // dictionary rows -> MFMA A operands, all loads of the wave's contraction range in flight at once.
-    // They are issued BEFORE the previous block is applied: the product below uses the dictionary as it
-    // is in memory and the 32 columns the previous block changes enter through a rank-32 correction
-    // (D_cur = D_mem + Delta), so no store -> load round trip sits on the critical path.
+    float cdg = 1.f, eB[EPT], eD[EPT];
+    int fz = 0;
+    constexpr int NQ = KPAD * (kNB / 4) / 256;
+    float4 cv[NQ];
     const int h = lane >> 5;
     float4 av[GPW][RT];
+    if (worker && !fin) {
+        cdg = col_ok ? p.cdiag[p.j0 + col] : 1.f;
+        fz = col_ok ? p.frozen[p.j0 + col] : 0;
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        int64_t f = f0 + t * 32 + (lane & 31);
-        if (f >= p.s) f = p.s - 1;                   // clamped: results of padded rows are discarded
-        const float *rowp = p.Dt + f * k;
+        for (int q = 0; q < EPT; ++q) {
+            const int64_t f = f0 + rg + 8 * q;
+            const bool ok = col_ok && f < p.s;
+            const int64_t el = ok ? f * k + p.j0 + col : 0;
+            const float bv = p.Bt[el], dv = p.Dt[el];
+            eB[q] = ok ? bv : 0.f;
+            eD[q] = ok ? dv : 0.f;
+        }
+        if (p.nb == kNB) {                           // coefficient block: rows beyond k are zero
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int e = tid + 256 * q;
+                const int m = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
+                const float4 v = *reinterpret_cast<const float4 *>(p.CP + (int64_t)(m < k ? m : 0) * k + p.j0 + c4);
+                cv[q] = (m < k) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        // dictionary rows -> MFMA A operands, the wave's whole contraction range in flight at once
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            int64_t f = f0 + t * 32 + (lane & 31);
+            if (f >= p.s) f = p.s - 1;               // clamped: results of padded rows are discarded
+            const float *rowp = p.Dt + f * k;
+#pragma unroll
+            for (int g = 0; g < GPW; ++g) {
+                const int kb = (wid * GPW + g) * 8 + 4 * h;
+                const float4 v = *reinterpret_cast<const float4 *>(rowp + (kb + 3 < k ? kb : 0));
+                av[g][t] = (kb + 3 < k) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    // operands of the apply step, in the output layout of its matrix-core tiles: worker wave w owns tiles
+    // w * RT .. w * RT + RT - 1 of the (RB / 16) x 2 grid (feature tile ft = t / 2, atom tile jt = t % 2)
+    constexpr int NA = RB * (kNB / 4) / 256;
+    float dold[RT][4];
+    float4 va[NA];
+    if (worker && has_prev) {
+#pragma unroll
+        for (int u = 0; u < RT; ++u) {
+            const int t = wid * RT + u, ft = t >> 1, jt = t & 1;
+            const int cj = jt * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t f = f0 + ft * 16 + (lane >> 4) + 4 * r;
+                const bool live = f < p.s && cj < p.nb_prev;
+                const float dv = p.Dt[live ? f * k + p.j0_prev + cj : 0];
+                dold[u][r] = live ? dv : 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int e = tid + 256 * q;
+            const int r = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
+            const int64_t fr = (f0 + r < p.s) ? f0 + r : p.s - 1;
+            va[q] = *reinterpret_cast<const float4 *>(p.a + fr * kNB + c4);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (st && tid == 0) st[13] = clock64();
+    // the resolver's own inputs: atom index and norm budget of column x of the previous block
+    int res_jj = 0;
+    double res_budget = 0.0;
+    if (!worker && has_prev) {
+        const int x = lane & 31;
+        res_jj = (x < p.nb_prev) ? p.order[p.j0_prev + x] : 0;
+        res_budget = (x < p.nb_prev) ? (double)p.norm_in[res_jj] : 0.0;
+    }
+    // ---------------------------------------------------------------- (B) Gram of the previous block
+    if (has_prev) {
+        if (worker) {
+            const double *recs = (ngroups > 1) ? p.grec_in : p.rec_in;
+            reduce_records<kPackStride>(recs, (ngroups > 1) ? ngroups : nwg,
+                                        SinkLdsPacked{reinterpret_cast<double (*)[kNB + 1]>(Ms), D2s});
+        } else {
+            double cf[kNB * kNB / 64];
+#pragma unroll
+            for (int q = 0; q < kNB * kNB / 64; ++q) {
+                const int e = lane + 64 * q, i = e / kNB, j = e % kNB;
+                cf[q] = (p.j0_prev + j < k) ? p.coef_all[(int64_t)i * k + p.j0_prev + j] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < kNB * kNB / 64; ++q) {
+                const int e = lane + 64 * q, i = e / kNB, j = e % kNB;
+                Cs[j * kNB + i] = cf[q];
+            }
+        }
+    }
+    if (st && tid == 0) st[14] = clock64();
+    if (worker && !fin) {
+        if (p.nb == kNB) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int e = tid + 256 * q;
+                const int m = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
+                *reinterpret_cast<float4 *>(CPs + m * kNB + c4) = cv[q];
+            }
+        } else {
+            for (int e = tid; e < KPAD * kNB; e += 256) {
+                const int m = e / kNB, jj = e % kNB;
+                CPs[e] = (m < k && jj < p.nb) ? p.CP[(int64_t)m * k + p.j0 + jj] : 0.f;
+            }
+        }
+    }
+    if (worker && has_prev) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int e = tid + 256 * q;
+            const int r = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
+            float4 v = va[q];                        // columns >= nb_prev were never written
+            v.x = (c4 + 0 < p.nb_prev) ? v.x : 0.f;
+            v.y = (c4 + 1 < p.nb_prev) ? v.y : 0.f;
+            v.z = (c4 + 2 < p.nb_prev) ? v.z : 0.f;
+            v.w = (c4 + 3 < p.nb_prev) ? v.w : 0.f;
+            *reinterpret_cast<float4 *>(Ap + r * kApStride + c4) = v;
+        }
+    }
+    __syncthreads();                                                                  // ---- barrier 1
+    if (st && tid == 0) st[1] = clock64();
+    // ---------------------------------------------------------------- (C) resolver | main product
+    f16v acc[RT];
+    if (!worker) {
+        if (has_prev)
+            resolve_wave<float>(reinterpret_cast<const double (*)[kNB + 1]>(Ms), D2s, Cs, res_jj, res_budget, p.nb_prev,
+                                blockIdx.x == 0 ? p.norm_out : nullptr, CAs, kCaStride, st);
+        if (st && lane == 0) st[2] = clock64();
+    } else if (!fin) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
         for (int g = 0; g < GPW; ++g) {
-            const int kb = (wid * GPW + g) * 8 + 4 * h;
-            const float4 v = *reinterpret_cast<const float4 *>(rowp + (kb + 3 < k ? kb : 0));
-            av[g][t] = (kb + 3 < k) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int kb = (wid * GPW + g) * 8 + 4 * h;  // this lane's 4 consecutive atoms
+            const float *bp = CPs + (size_t)kb * kNB + (lane & 31);
+            const float b0 = bp[0], b1 = bp[kNB], b2 = bp[2 * kNB], b3 = bp[3 * kNB];
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].x, b0, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].y, b1, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].z, b2, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].w, b3, acc[t], 0, 0, 0);
+            }
+        }
+        if (st && tid == 0) st[3] = clock64();
+    }
+    __syncthreads();                                                                  // ---- barrier 2
+    if (st && tid == 0) st[4] = clock64();
+    // ---------------------------------------------------------------- (D) apply the previous block
+    // Every A-operand load of the workgroup has been consumed by (C), so the stores below cannot overtake a
+    // load of the old values.
+    if (worker && has_prev) {
+#pragma unroll
+        for (int u = 0; u < RT; ++u) {
+            const int t = wid * RT + u, ft = t >> 1, jt = t & 1;
+            d4v dn = {0.0, 0.0, 0.0, 0.0};
+            const float *ap = Ap + (ft * 16 + (lane & 15)) * kApStride + (lane >> 4);
+            const double *sp = CAs + (jt * 16 + (lane & 15)) * kCaStride + (lane >> 4);
+#pragma unroll
+            for (int kk = 0; kk < kNB / 4; ++kk)
+                dn = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ap[4 * kk], sp[4 * kk], dn, 0, 0, 0);
+            const int cj = jt * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int frow = ft * 16 + (lane >> 4) + 4 * r;
+                const int64_t f = f0 + frow;
+                const bool live = f < p.s && cj < p.nb_prev;
+                const float dnew = (float)dn[r];
+                if (live) p.Dt[f * k + p.j0_prev + cj] = dnew;
+                Dl[frow * DLS + cj] = live ? dnew - dold[u][r] : 0.f;
+            }
         }
     }
-    // (0) previous block: D[f][o_j] = sum_m Tp[j][m] a_m[f] for this workgroup's features; Delta -> LDS
-    constexpr int TPR = 256 / RB;                    // threads per feature row
-    constexpr int DLS = kNB + 4;                     // row stride of the Delta tile (16-byte aligned rows)
-    if (p.CA_prev) {
-        const int arow = threadIdx.x / TPR, jg = threadIdx.x % TPR;
-        const int64_t f = f0 + arow;
-        const bool rok = f < p.s;
-        float *drow = p.Dt + (rok ? f * k : 0);
-        float dold[kNB / TPR];
-        double aprev[kNB];
+    if (fin) return;
+    __syncthreads();                                                                  // ---- barrier 3
+    if (st && tid == 0) st[5] = clock64();
+    // ---------------------------------------------------------------- (E) rank-32 correction, cross-wave sum
+    if (worker) {
+        if (has_prev) {   // wave w contracts the previous block's atoms 8w .. 8w+7
+            const int jb = wid * 8 + 4 * h;
+            float bq[4];
 #pragma unroll
-        for (int q = 0; q < kNB / TPR; ++q) {        // old values of the columns this thread rewrites
-            const int j = jg + TPR * q;
-            dold[q] = (rok && j < p.nb_prev) ? drow[p.j0_prev + j] : 0.f;
-        }
-        // the previous block's a-tile of this workgroup: coalesced 16-byte loads -> LDS (the `red` area is free here)
-        float *Ap = red;                                             // [RB][NB]
-        {
-            constexpr int NA = RB * (kNB / 4) / 256, NC = kNB * kNB / 256;
-            float4 va[NA];
-            double vc[NC];
-#pragma unroll
-            for (int q = 0; q < NA; ++q) {
-                const int e = threadIdx.x + 256 * q;
-                const int r = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
-                const int64_t fr = (f0 + r < p.s) ? f0 + r : p.s - 1;
-                va[q] = *reinterpret_cast<const float4 *>(p.a + fr * kNB + c4);
+            for (int u = 0; u < 4; ++u) {
+                const int j = jb + u;
+                bq[u] = (j < p.nb_prev) ? CPs[(size_t)(p.j0_prev + j) * kNB + (lane & 31)] : 0.f;
             }
 #pragma unroll
-            for (int q = 0; q < NC; ++q) vc[q] = p.CA_prev[threadIdx.x + 256 * q];
-#pragma unroll
-            for (int q = 0; q < NA; ++q) {
-                const int e = threadIdx.x + 256 * q;
-                const int r = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
-                *reinterpret_cast<float4 *>(Ap + r * kNB + c4) = va[q];
+            for (int t = 0; t < RT; ++t) {
+                const float4 dv = *reinterpret_cast<const float4 *>(Dl + (t * 32 + (lane & 31)) * DLS + jb);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv.x, bq[0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv.y, bq[1], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv.z, bq[2], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv.w, bq[3], acc[t], 0, 0, 0);
             }
-#pragma unroll
-            for (int q = 0; q < NC; ++q) CAs[threadIdx.x + 256 * q] = vc[q];
         }
-        // every A-operand load of the workgroup must have landed before any new value is stored
-        const unsigned long long tq0 = clock64();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long tq1 = clock64();
-        __syncthreads();
-        const unsigned long long tq2 = clock64();
-        if (p.stamps && threadIdx.x == 0 && blockIdx.x == 0) { p.stamps[12] = tq0 - ts[0]; p.stamps[13] = tq1 - tq0; p.stamps[14] = tq2 - tq1; }
 #pragma unroll
-        for (int m = 0; m < kNB; ++m) aprev[m] = (m < p.nb_prev) ? (double)Ap[arow * kNB + m] : 0.0;
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int q = 0; q < kNB / TPR; ++q) {
-            const int j = jg + TPR * q;
-            double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-#pragma unroll
-            for (int m = 0; m < kNB; m += 4) {
-                acc0 += CAs[j * kNB + m] * aprev[m];
-                acc1 += CAs[j * kNB + m + 1] * aprev[m + 1];
-                acc2 += CAs[j * kNB + m + 2] * aprev[m + 2];
-                acc3 += CAs[j * kNB + m + 3] * aprev[m + 3];
+            for (int r = 0; r < 16; ++r) {
+                const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, c = lane & 31;
+                red[(wid * RB + row) * (kNB + 1) + c] = acc[t][r];
             }
-            const float dnew = (float)((acc0 + acc1) + (acc2 + acc3));
-            const bool live = rok && j < p.nb_prev;
-            if (live) drow[p.j0_prev + j] = dnew;
-            Dl[arow * DLS + j] = live ? dnew - dold[q] : 0.f;
-        }
     }
-    f16v acc[RT];
+    __syncthreads();                                                                  // ---- barrier 4
+    if (st && tid == 0) st[6] = clock64();
+    // ---------------------------------------------------------------- (F) epilogue
+    if (worker) {
+        double d2 = 0;
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // LDS hand-off only (coefficient block, Delta tile): the D stores above stay in flight
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    ts[1] = clock64();
-#pragma unroll
-    for (int g = 0; g < GPW; ++g) {
-        const int kb = (wid * GPW + g) * 8 + 4 * h;  // this lane's 4 consecutive atoms
-        const float *bp = CPs + (size_t)kb * kNB + (lane & 31);
-        const float b0 = bp[0], b1 = bp[kNB], b2 = bp[2 * kNB], b3 = bp[3 * kNB];
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].x, b0, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].y, b1, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].z, b2, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].w, b3, acc[t], 0, 0, 0);
+        for (int q = 0; q < EPT; ++q) {
+            const int row = rg + 8 * q;
+            const int64_t f = f0 + row;
+            float val = 0.f;
+            if (f < p.s && col_ok) {
+                const float v = ((red[(0 * RB + row) * (kNB + 1) + col] + red[(1 * RB + row) * (kNB + 1) + col]) +
+                                 red[(2 * RB + row) * (kNB + 1) + col]) + red[(3 * RB + row) * (kNB + 1) + col];
+                val = fz ? eD[q] : (eB[q] - v) / cdg;
+                p.a[f * kNB + col] = val;
+                d2 += (double)eD[q] * (double)eD[q];
+            }
+            As[row * (kNB + 1) + col] = val;
         }
+        d2red[rg * kNB + col] = d2;
     }
-    if (p.CA_prev) {   // rank-32 correction: wave w contracts the previous block's atoms 8w .. 8w+7
-        const int jb = wid * 8 + 4 * h;
-        float bq[4];
+    __syncthreads();                                                                  // ---- barrier 5
+    if (st && tid == 0) st[7] = clock64();
+    // ---------------------------------------------------------------- (G) Gram record of this workgroup
+    if (worker) {
+        // tiles (0,0) (0,1) (1,1) of 16 x 16 on waves 0, 1, 3 (tile (1,0) is the transpose of (0,1))
+        const int it = wid >> 1, jt = wid & 1;
+        d4v g = {0.0, 0.0, 0.0, 0.0};
+        const float *ai = As + (lane >> 4) * (kNB + 1) + it * 16 + (lane & 15);
+        const float *aj = As + (lane >> 4) * (kNB + 1) + jt * 16 + (lane & 15);
+        double *out = p.rec_out + (int64_t)blockIdx.x * kPackStride;
+        if (wid != 2) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = jb + u;
-            bq[u] = (j < p.nb_prev) ? CPs[(size_t)(p.j0_prev + j) * kNB + (lane & 31)] : 0.f;
-        }
+            for (int kk = 0; kk < RB / 4; ++kk)
+                g = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ai[4 * kk * (kNB + 1)], (double)aj[4 * kk * (kNB + 1)], g, 0, 0, 0);
+            const int tile = it + jt;                // 0, 1, 2
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const float4 dv = *reinterpret_cast<const float4 *>(Dl + (t * 32 + (lane & 31)) * DLS + jb);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv.x, bq[0], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv.y, bq[1], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv.z, bq[2], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv.w, bq[3], acc[t], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, c = lane & 31;
-            red[(wid * RB + row) * (kNB + 1) + c] = acc[t][r];
-        }
-    __syncthreads();
-    ts[2] = clock64();
-    double d2 = 0;
-#pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int row = rg + 8 * q;
-        const int64_t f = f0 + row;
-        float val = 0.f;
-        if (f < p.s && col_ok) {
-            const float v = ((red[(0 * RB + row) * (kNB + 1) + col] + red[(1 * RB + row) * (kNB + 1) + col]) +
-                             red[(2 * RB + row) * (kNB + 1) + col]) + red[(3 * RB + row) * (kNB + 1) + col];
-            val = fz ? eD[q] : (eB[q] - v) / cdg;
-            p.a[f * kNB + col] = val;
-            d2 += (double)eD[q] * (double)eD[q];
-        }
-        As[row * (kNB + 1) + col] = val;
-    }
-    d2red[rg * kNB + col] = d2;
-    __syncthreads();
-    {   // (2) partial Gram of the a_j over this workgroup's features, and old squared norms
-        const int i = threadIdx.x / 8, jb = (threadIdx.x % 8) * 4;
-        double g4[4] = {0, 0, 0, 0};
-        for (int r = 0; r < RB; ++r) {
-            const double ai = (double)As[r * (kNB + 1) + i];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) g4[q] += ai * (double)As[r * (kNB + 1) + jb + q];
-        }
-        double *out = p.partial + (int64_t)blockIdx.x * kResStride;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) out[i * kNB + jb + q] = g4[q];
-        if (threadIdx.x < kNB) {
+            for (int r = 0; r < 4; ++r) out[tile * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = g[r];
+        } else if (lane < kNB) {
             double t = 0;
-            for (int gq = 0; gq < 8; ++gq) t += d2red[gq * kNB + threadIdx.x];
-            out[kNB * kNB + threadIdx.x] = t;
+            for (int gq = 0; gq < 8; ++gq) t += d2red[gq * kNB + lane];
+            out[3 * 256 + lane] = t;
         }
     }
-    // (3) the last workgroup to arrive resolves the block.  More than kGroup workgroups: two levels (the last
-    //     of each group of kGroup sums its group, the last group leader sums the group sums), so no single
-    //     workgroup streams hundreds of records; the association is fixed either way.
-    ts[3] = clock64();
-    const int nwg = (int)gridDim.x;
-    const int gsz = p.group;                        // >= kGroup, chosen by the host so that ngroups < kCounters
-    const int ngroups = (nwg + gsz - 1) / gsz;
-    const double *recs = p.partial;
-    int nrec = nwg;
-    if (ngroups > 1) {
+    if (st && tid == 0) st[12] = clock64();
+    if (ngroups > 1) {   // pre-sum this group's records: the last workgroup of the group to arrive does it
         const int g = (int)blockIdx.x / gsz;
         const int gsize = (nwg - g * gsz < gsz) ? nwg - g * gsz : gsz;
         if (!arrive_last(p.counter + 1 + g, (unsigned int)gsize, flag)) return;
-        reduce_records(p.partial + (int64_t)g * gsz * kResStride, gsize, SinkGlobal{p.gpartial + (int64_t)g * kResStride});
-        recs = p.gpartial;
-        nrec = ngroups;
+        if (worker)
+            reduce_records<kPackStride>(p.rec_out + (int64_t)g * gsz * kPackStride, gsize,
+                                        SinkGlobal{p.grec_out + (int64_t)g * kPackStride});
     }
-    if (!arrive_last(p.counter, (unsigned int)nrec, flag)) return;
-    ts[4] = clock64();
-    double *Cs = reinterpret_cast<double *>(CPs);                // the coefficient block is dead by now
-    stage_coef(p.coef_all, k, p.j0, Cs);
-    reduce_partials(recs, nrec, reinterpret_cast<double (*)[kNB + 1]>(Ms), D2s);
-    __syncthreads();
-    ts[5] = clock64();
-    if (threadIdx.x < 64)
-        resolve_wave<float>(reinterpret_cast<const double (*)[kNB + 1]>(Ms), D2s, Cs, p.order, p.j0, p.nb,
-                            p.comp_norm, p.CA_out, p.stamps);
-    ts[6] = clock64();
-    if (p.stamps && threadIdx.x == 0)
-        for (int i = 0; i < 7; ++i) p.stamps[i] = ts[i];
 }
 
 static size_t bcd_block_lds(int gpw, int RT) {
     const int kpad = gpw * 32, RB = 32 * RT;
-    const size_t dbl = (size_t)kNB * (kNB + 1) + kNB + kResStride + 8 * kNB;
+    const size_t dbl = (size_t)kNB * (kNB + 1) + kNB + kNB * kNB + (size_t)kNB * kCaStride + 8 * kNB;
     const size_t fl = (size_t)kpad * kNB + 4 * RB * (kNB + 1) + RB * (kNB + 1) + 4 + RB * (kNB + 4) + 4;
     return dbl * 8 + fl * 4 + 16;
 }
@@ -899,7 +971,8 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         double *CA[2] = {Tp, Tp + kResStride};
         unsigned int *counter = reinterpret_cast<unsigned int *>(Tp + 2 * kResStride);
         hipLaunchKernelGGL((bcd_prepare_kernel<T>), dim3(k > kNB ? k : kNB), dim3(256), sizeof(int32_t) * (size_t)k,
-                           stream, a.C, a.order, k, CP, cdiag, frozen, coef_all, counter);
+                           stream, a.C, a.order, k, CP, cdiag, frozen, coef_all, counter, a.comp_norm,
+                           reinterpret_cast<T *>(ws + L.off_norm_in));
         MODL_LAUNCH_CHECK();
         ++nl;
         const bool fused = std::is_same<T, float>::value && (k % 4 == 0) && k <= 512;
@@ -922,22 +995,28 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             MODL_LAUNCH_CHECK();
             nl += 2;
         }
+        const size_t rec_half = (size_t)L.nslab_max * kResStride, grec_half = (size_t)kCounters * kResStride;   // >= the packed sizes
+        double *gpart = reinterpret_cast<double *>(ws + L.off_gpartial);
+        BcdBlockArgs base;
+        if (fused) {
+            base.Dt = reinterpret_cast<float *>(DsP); base.Bt = reinterpret_cast<const float *>(BsP);
+            base.CP = reinterpret_cast<const float *>(CPP); base.cdiag = reinterpret_cast<const float *>(cdiag);
+            base.frozen = frozen; base.order = a.order; base.a = reinterpret_cast<float *>(abuf);
+            base.coef_all = coef_all; base.norm_in = reinterpret_cast<const float *>(ws + L.off_norm_in);
+            base.norm_out = reinterpret_cast<float *>(a.comp_norm); base.counter = counter;
+            base.stamps = reinterpret_cast<unsigned long long *>(counter + kCounters); base.s = s; base.k = k;
+            base.group = (nslab + 31) / 32 > kGroup ? (nslab + 31) / 32 : kGroup;
+        }
         int blk_i = 0, j0_prev = 0, nb_prev = 0;
         for (int j0 = 0; j0 < k; j0 += kNB, ++blk_i) {
             const int nb = (k - j0 < kNB) ? k - j0 : kNB;
             double *CAcur = CA[blk_i & 1], *CAprev = blk_i ? CA[(blk_i - 1) & 1] : nullptr;
             if (fused) {
-                BcdBlockArgs ba;
-                ba.Dt = reinterpret_cast<float *>(DsP); ba.Bt = reinterpret_cast<const float *>(BsP);
-                ba.CP = reinterpret_cast<const float *>(CPP); ba.cdiag = reinterpret_cast<const float *>(cdiag);
-                ba.frozen = frozen; ba.order = a.order;
-                ba.a = reinterpret_cast<float *>(abuf); ba.partial = partial; ba.coef_all = coef_all;
-                ba.CA_prev = CAprev; ba.CA_out = CAcur; ba.comp_norm = reinterpret_cast<float *>(a.comp_norm);
-                ba.gpartial = reinterpret_cast<double *>(ws + L.off_gpartial);
-                ba.counter = counter; ba.stamps = reinterpret_cast<unsigned long long *>(counter + kCounters); ba.s = s; ba.k = k;
-                ba.j0 = j0; ba.nb = nb; ba.j0_prev = j0_prev; ba.nb_prev = nb_prev;
-                ba.group = (nslab + 31) / 32 > kGroup ? (nslab + 31) / 32 : kGroup;
-                hipLaunchKernelGGL(blk, dim3(nslab), dim3(256), bcd_block_lds(GPW, RT), stream, ba);
+                BcdBlockArgs ba = base;
+                ba.rec_out = partial + (size_t)(blk_i & 1) * rec_half; ba.rec_in = partial + (size_t)((blk_i + 1) & 1) * rec_half;
+                ba.grec_out = gpart + (size_t)(blk_i & 1) * grec_half; ba.grec_in = gpart + (size_t)((blk_i + 1) & 1) * grec_half;
+                ba.j0 = j0; ba.nb = nb; ba.j0_prev = j0_prev; ba.nb_prev = blk_i ? nb_prev : 0;
+                hipLaunchKernelGGL(blk, dim3(nslab), dim3(320), bcd_block_lds(GPW, RT), stream, ba);
                 MODL_LAUNCH_CHECK();
                 ++nl;
             } else {
@@ -965,8 +1044,11 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         }
         // the last block's atoms
         if (fused) {
-            hipLaunchKernelGGL((bcd_apply_kernel<T>), dim3((unsigned)cdiv(s, 64)), dim3(256), 0, stream, abuf,
-                               CA[(blk_i - 1) & 1], DsP, nullptr, nullptr, s, k, j0_prev, nb_prev);
+            BcdBlockArgs ba = base;                  // nb == 0: resolve and apply only
+            ba.rec_out = nullptr; ba.grec_out = nullptr;
+            ba.rec_in = partial + (size_t)((blk_i + 1) & 1) * rec_half; ba.grec_in = gpart + (size_t)((blk_i + 1) & 1) * grec_half;
+            ba.j0 = 0; ba.nb = 0; ba.j0_prev = j0_prev; ba.nb_prev = nb_prev;
+            hipLaunchKernelGGL(blk, dim3(nslab), dim3(320), bcd_block_lds(GPW, RT), stream, ba);
             MODL_LAUNCH_CHECK();
             hipLaunchKernelGGL((bcd_unpack_kernel<T>), dim3((unsigned)s), dim3(256), 0, stream, a.Dt, a.subset, a.order, s,
                                k, DsP);

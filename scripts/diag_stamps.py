@@ -12,10 +12,13 @@ for r in (10, 1):
     est.partial_fit(X[:2048])
     out = (C.c_ulonglong * 16)()
     check(lib.modl_somf_debug_stamps(est._backend.plan, out))
-    t = np.array(list(out)[:7], dtype=np.float64)
-    d = np.diff(t)
-    names = ['prologue(loads,CP,apply)', 'A-loads+mfma+red', 'epilogue+gram+stores', 'ticket', 'reduce_partials', 'resolve_wave']
-    print('r=%g cycles:' % r, {n: int(v) for n, v in zip(names, d)})
-    print('   prologue (WG 0): issue', out[12], ' wait vmcnt(0)', out[13], ' barrier', out[14])
-    rs = np.array(list(out)[8:12], dtype=np.float64)
-    print('   resolve: start->loads done', int(rs[0] - t[5]), ' steps 0-7', int(rs[1]-rs[0]), ' 8-15', int(rs[2]-rs[1]), ' 16-23', int(rs[3]-rs[2]), ' 24-31', int(t[6]-rs[3]))
+    o = [float(v) for v in out]
+    names = ['A+B: loads, Gram records, LDS staging -> barrier 1', 'resolver wave (C)', 'workers: main MFMA product (C)',
+             'barrier 2 after the longer of the two', 'apply (D) -> barrier 3', 'correction + cross-wave (E) -> barrier 4',
+             'epilogue (F) -> barrier 5', 'Gram record (G)']
+    vals = [o[1] - o[0], o[2] - o[1], o[3] - o[1], o[4] - o[1], o[5] - o[4], o[6] - o[5], o[7] - o[6], o[12] - o[7]]
+    print('r=%g cycles (workgroup 0, last full block launch): total %d' % (r, o[12] - o[0]))
+    for n, v in zip(names, vals):
+        print('   %-56s %8d' % (n, v))
+    print('   A issue %d   B records %d   LDS staging + barrier %d' % (o[13] - o[0], o[14] - o[13], o[1] - o[14]))
+    print('   resolve: setup %d  steps 0-7 %d  8-15 %d  16-23 %d  24-31+stores %d' % (o[8] - o[1], o[9] - o[8], o[10] - o[9], o[11] - o[10], o[2] - o[11]))
