@@ -79,6 +79,7 @@ struct modl_somf_plan {
     size_t po_idx, po_subset, po_order, po_wsample;
     // pinned staging ring
     char *hstage[kStageSlots] = {nullptr};
+    char *hstage_dev[kStageSlots] = {nullptr};   // device-side addresses of the pinned slots
     hipEvent_t hev[kStageSlots] = {nullptr};
     bool hev_used[kStageSlots] = {false};
     int slot = 0;
@@ -153,6 +154,13 @@ int prof_flush(modl_somf_plan *pl) {
     return MODL_OK;
 }
 
+// Parameter block: pinned host slot -> HBM by a kernel that reads the (device-mapped) pinned memory over
+// the host link.  A hipMemcpyAsync here would hop to the copy engine and back between two kernels of the
+// same stream, which costs several times the kernel floor.
+__global__ __launch_bounds__(256) void stage_params_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 // copy the per-batch host arrays into the device parameter block through a pinned slot
 template <typename T>
 int stage_batch(modl_somf_plan *pl, const modl_somf_batch *bt, hipStream_t st) {
@@ -191,7 +199,14 @@ int stage_batch(modl_somf_plan *pl, const modl_somf_batch *bt, hipStream_t st) {
         }
     }
     if (bt->h_w_sample) std::memcpy(h + pl->po_wsample, bt->h_w_sample, pl->tsz * (size_t)bt->b);
-    MODL_HIP(hipMemcpyAsync(pl->dws + pl->off_params, h, pl->params_bytes, hipMemcpyHostToDevice, st));
+    {
+        const size_t n16 = (pl->params_bytes + 15) / 16;
+        unsigned grid = (unsigned)((n16 + 255) / 256);
+        if (grid > 64) grid = 64;
+        hipLaunchKernelGGL(stage_params_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint4 *>(pl->hstage_dev[slot]),
+                           reinterpret_cast<uint4 *>(pl->dws + pl->off_params), n16);
+        MODL_LAUNCH_CHECK();
+    }
     MODL_HIP(hipEventRecord(pl->hev[slot], st));
     pl->hev_used[slot] = true;
     pl->staged = true;
@@ -603,7 +618,8 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     hipError_t e = hipMalloc((void **)&pl->dws, pl->dws_bytes);
     if (e != hipSuccess) { delete pl; return (int)e; }
     for (int i = 0; i < kStageSlots; ++i) {
-        e = hipHostMalloc((void **)&pl->hstage[i], pl->params_bytes, hipHostMallocDefault);
+        e = hipHostMalloc((void **)&pl->hstage[i], align_up(pl->params_bytes, 16), hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&pl->hstage_dev[i], pl->hstage[i], 0);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->hev[i], hipEventDisableTiming);
         if (e != hipSuccess) { modl_somf_plan_destroy(pl); return (int)e; }
     }
@@ -708,7 +724,7 @@ int modl_somf_prof_enable(modl_somf_plan *pl, int enable) {
         pl->pev.resize(2 * kProfPool, nullptr);
         pl->psec.resize(kProfPool);
         pl->plaunch.resize(kProfPool);
-        for (auto &ev : pl->pev) MODL_HIP(hipEventCreate(&ev));
+        for (auto &ev : pl->pev) MODL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));   // device-side timing only
     }
     if (!enable && pl->prof) MODL_TRY(prof_flush(pl));
     pl->prof = enable != 0;
