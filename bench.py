@@ -69,11 +69,15 @@ def step_bytes(k, p, b, s, e=4):
                 dict_update=e * (k * k + 3 * s * k))
 
 
-def run_gpu(args, reduction, steps, warmup, rank, world, device):
+def run_gpu(args, reduction, steps, warmup, rank, world, device, breakdown=True):
+    """Warm-up (all sections timed -> picks the dominant one), the timed region (HIP events around the
+    dominant section only: every timed section costs two event records, i.e. a stream bubble of a few
+    microseconds each), then an untimed pass with all sections timed for the breakdown."""
     import torch
     import torch.distributed as dist
     from modl_amd import DictFact
-    n_rows = min(CHUNK, max(4096, (steps + warmup) * BATCH))
+    extra = min(steps, 50) if breakdown else 0
+    n_rows = min(CHUNK, max(4096, (steps + warmup + extra) * BATCH))
     X = make_stream(n_rows, P_FEAT, 1234 + rank, device)
     est = DictFact(n_components=K_COMP, batch_size=BATCH, reduction=reduction, code_alpha=1.0, code_l1_ratio=1,
                    comp_l1_ratio=0, learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0)
@@ -87,9 +91,15 @@ def run_gpu(args, reduction, steps, warmup, rank, world, device):
             est.partial_fit(X[r0:r0 + todo * BATCH], np.arange(r0, r0 + todo * BATCH))
             done += todo
 
-    run(warmup, 0)
     be = est._backend
     be.prof_enable(True)
+    be.prof_reset()
+    run(warmup, 0)
+    torch.cuda.synchronize()
+    pre = be.prof_get()
+    dom = max(pre, key=lambda n: pre[n]['ms']) if warmup > 0 and pre else 'dict_update'
+    be.prof_enable(False)
+    be.prof_enable(True, sections=[dom])
     be.prof_reset()
     if world > 1:
         dist.barrier()
@@ -100,18 +110,26 @@ def run_gpu(args, reduction, steps, warmup, rank, world, device):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    prof = be.prof_get()
+    prof_dom = be.prof_get()[dom]
     be.prof_enable(False)
     lsw = be.last_sweeps()
     sweeps = float(lsw.mean())
     run_gpu.sweeps_max = int(lsw.max())
+    prof = {}
+    if extra:
+        be.prof_enable(True)
+        be.prof_reset()
+        run(extra, warmup + steps)
+        torch.cuda.synchronize()
+        prof = be.prof_get()
+        be.prof_enable(False)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     D = est.components_
     ok = bool(np.all(np.isfinite(D)))
-    return dt, prof, sweeps, ok
+    return dt, prof, sweeps, ok, dom, prof_dom
 
 
 def cpu_baseline(reduction, budget_s=20.0):
@@ -163,7 +181,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
-    dt, prof, sweeps, ok = run_gpu(args, args.reduction, args.steps, args.warmup, rank, world, device)
+    dt, prof, sweeps, ok, dom, prof_dom = run_gpu(args, args.reduction, args.steps, args.warmup, rank, world, device)
     out = None
     if rank == 0:
         samples = args.steps * BATCH * world
@@ -177,18 +195,22 @@ def main():
             ms = e['ms'] / e['calls']
             sections[name] = dict(ms_per_step=ms, launches_per_step=e['launches'] / e['calls'],
                                   gflops=fl[name] / ms / 1e6, gbs=by[name] / ms / 1e6)
-        dom = max(sections, key=lambda n: sections[n]['ms_per_step']) if sections else None
+        # roofline of the dominant section, from the events recorded INSIDE the timed region
         roof = None
-        if dom:
-            sec = sections[dom]
+        if prof_dom['calls'] > 0:
+            ms = prof_dom['ms'] / prof_dom['calls']
+            nl = prof_dom['launches'] / prof_dom['calls']
+            gflops, gbs = fl[dom] / ms / 1e6, by[dom] / ms / 1e6
             ai = fl[dom] / by[dom]
             if ai * PEAK_HBM_GBS / 1e3 > PEAK_MFMA_F32_TFLOPS:       # ridge of the f32 roofline
-                roof = dict(bound='mfma', kernel=dom, achieved=sec['gflops'] / 1e3, peak=PEAK_MFMA_F32_TFLOPS,
-                            unit='TFLOP/s', frac=sec['gflops'] / 1e3 / PEAK_MFMA_F32_TFLOPS, traffic=None)
+                roof = dict(bound='mfma', kernel=dom, achieved=gflops / 1e3, peak=PEAK_MFMA_F32_TFLOPS,
+                            unit='TFLOP/s', frac=gflops / 1e3 / PEAK_MFMA_F32_TFLOPS, traffic=None)
             else:
-                roof = dict(bound='hbm', kernel=dom, achieved=sec['gbs'], peak=PEAK_HBM_GBS, unit='GB/s',
-                            frac=sec['gbs'] / PEAK_HBM_GBS, traffic=None)
-            roof['avg_launch_ms'] = sec['ms_per_step'] / max(sec['launches_per_step'], 1)
+                roof = dict(bound='hbm', kernel=dom, achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s',
+                            frac=gbs / PEAK_HBM_GBS, traffic=None)
+            roof['ms_per_step'] = ms
+            roof['launches_per_step'] = nl
+            roof['avg_launch_ms'] = ms / max(nl, 1)
         total_fl = sum(fl.values())
         out = dict(metric='samples/sec through DictFact.partial_fit at k=256, p=10k', value=samples / dt,
                    unit='samples/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -202,7 +224,8 @@ def main():
                    roofline=roof, sections=sections, cd_sweeps_mean=sweeps, cd_sweeps_max=getattr(run_gpu, 'sweeps_max', None),
                    step_tflops=total_fl / (dt / args.steps) / 1e12, finite=ok)
     if args.also_r1:
-        dt1, prof1, sw1, ok1 = run_gpu(args, 1.0, max(args.steps // 2, 10), max(args.warmup // 2, 2), rank, world, device)
+        dt1, prof1, sw1, ok1, _, _ = run_gpu(args, 1.0, max(args.steps // 2, 10), max(args.warmup // 2, 2), rank, world, device,
+                                             breakdown=False)
         if rank == 0:
             n1 = max(args.steps // 2, 10)
             out['also'] = dict(reduction_1=dict(value=n1 * BATCH * world / dt1, ms_per_step=dt1 / n1 * 1e3,

@@ -305,7 +305,9 @@ int modl_transpose_f32(const float *d_in, float *d_out, int64_t rows, int64_t co
 int modl_transpose_f64(const double *d_in, double *d_out, int64_t rows, int64_t cols, void *stream);
 
 /* per-kernel-class timing of the fused step (HIP events on `stream`).
- * enable: 0/1.  get: copies up to `cap` entries; names are static strings. */
+ * enable: 0 = off, 1 = every section, otherwise a mask: bit (i + 1) times section i of the order
+ * {code_gemm, code_solve, stats_gemm, stats_apply, dict_update} — each timed section costs two event
+ * records (a few microseconds of stream bubble each).  get: copies up to `cap` entries; names are static. */
 #define MODL_PROF_MAX 16
 typedef struct modl_prof_entry {
     const char *name;

@@ -365,8 +365,32 @@ __global__ __launch_bounds__(256) void row_norm2_kernel(const T *X, int64_t ldx,
     const int64_t i = blockIdx.x;
     if (i >= b) return;
     const T *x = X + i * ldx;
-    double s = 0;
-    for (int64_t f = threadIdx.x; f < p; f += 256) s += (double)x[f] * (double)x[f];
+    // 16-byte loads, four independent partial sums per thread (a dependent load -> add chain of p / 256
+    // single elements is latency bound)
+    constexpr int V = 16 / sizeof(T);
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    const bool vec = (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+    const int64_t nv = vec ? p / V : 0;
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    const vec_t *xv = reinterpret_cast<const vec_t *>(x);
+    int64_t f = threadIdx.x;
+    for (; f + 768 < nv; f += 1024) {
+        const vec_t a0 = xv[f], a1 = xv[f + 256], a2 = xv[f + 512], a3 = xv[f + 768];
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+            s0 += (double)a0[c] * (double)a0[c];
+            s1 += (double)a1[c] * (double)a1[c];
+            s2 += (double)a2[c] * (double)a2[c];
+            s3 += (double)a3[c] * (double)a3[c];
+        }
+    }
+    for (; f < nv; f += 256) {
+        const vec_t a0 = xv[f];
+#pragma unroll
+        for (int c = 0; c < V; ++c) s0 += (double)a0[c] * (double)a0[c];
+    }
+    for (int64_t e = nv * V + threadIdx.x; e < p; e += 256) s1 += (double)x[e] * (double)x[e];
+    double s = (s0 + s1) + (s2 + s3);
     s = block_sum(s, red);
     if (threadIdx.x == 0) out[i] = (T)s;
 }

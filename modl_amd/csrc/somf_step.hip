@@ -89,6 +89,7 @@ struct modl_somf_plan {
     std::vector<int64_t> h_order_copy;
     // profiling
     bool prof = false;
+    unsigned prof_mask = ~0u;          // sections that record events
     std::vector<hipEvent_t> pev;       // 2 * kProfPool events
     std::vector<int> psec, plaunch;
     int pcount = 0;
@@ -128,7 +129,7 @@ struct ProfScope {
     int sec, idx = -1;
     int launches = 0;
     ProfScope(modl_somf_plan *p, hipStream_t s, int section) : pl(p), st(s), sec(section) {
-        if (!pl->prof) return;
+        if (!pl->prof || !((pl->prof_mask >> section) & 1u)) return;
         if (pl->pcount >= kProfPool) return;           // pool full until the next prof_get/reset
         idx = pl->pcount++;
         (void)hipEventRecord(pl->pev[2 * idx], st);
@@ -728,6 +729,7 @@ int modl_somf_prof_enable(modl_somf_plan *pl, int enable) {
     }
     if (!enable && pl->prof) MODL_TRY(prof_flush(pl));
     pl->prof = enable != 0;
+    pl->prof_mask = (enable == 1 || enable == 0) ? ~0u : ((unsigned)enable >> 1);
     return MODL_OK;
 }
 

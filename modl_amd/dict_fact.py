@@ -245,8 +245,16 @@ class HipBackend:
         return out[:n.value]
 
     # -- profiling ------------------------------------------------------------
-    def prof_enable(self, on=True):
-        check(lib.modl_somf_prof_enable(self.plan, int(on)))
+    PROF_SECTIONS = ('code_gemm', 'code_solve', 'stats_gemm', 'stats_apply', 'dict_update')
+
+    def prof_enable(self, on=True, sections=None):
+        """Time the step's sections with HIP events; `sections` restricts the events to the named ones."""
+        flag = int(bool(on))
+        if on and sections is not None:
+            flag = 0
+            for name in sections:
+                flag |= 1 << (self.PROF_SECTIONS.index(name) + 1)
+        check(lib.modl_somf_prof_enable(self.plan, flag))
 
     def prof_reset(self):
         check(lib.modl_somf_prof_reset(self.plan))
