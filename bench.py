@@ -106,6 +106,7 @@ def run_gpu(args, reduction, steps, warmup, rank, world, device, breakdown=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(steps, warmup)
+    run_gpu.host_ms_per_step = (time.perf_counter() - t0) / steps * 1e3   # host time to ENQUEUE a step
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -222,7 +223,8 @@ def main():
                                reduction=args.reduction, global_batch=BATCH * world,
                                parallelism='dp%d (row-sharded minibatch, all-reduce of [C|B] increments)' % world),
                    roofline=roof, sections=sections, cd_sweeps_mean=sweeps, cd_sweeps_max=getattr(run_gpu, 'sweeps_max', None),
-                   step_tflops=total_fl / (dt / args.steps) / 1e12, finite=ok)
+                   step_tflops=total_fl / (dt / args.steps) / 1e12, finite=ok,
+                   host_enqueue_ms_per_step=getattr(run_gpu, 'host_ms_per_step', None))
     if args.also_r1:
         dt1, prof1, sw1, ok1, _, _ = run_gpu(args, 1.0, max(args.steps // 2, 10), max(args.warmup // 2, 2), rank, world, device,
                                              breakdown=False)

@@ -123,6 +123,61 @@ __global__ __launch_bounds__(256) void bcd_prepare_kernel(const T *C, const int3
     }
 }
 
+// Fused path: everything the block launches need, in ONE launch.  Blocks [0, NB): recursion coefficients
+// (block 0 also: arrival counters, snapshot of the norm budgets, diagonal and frozen flags); blocks
+// [NB, NB + k): C in sweep coordinates, CPP[m'][jj] = C[o_m'][o_jj] with the block-lower-triangular mask;
+// blocks [NB + k, NB + k + s): the sampled rows gathered in sweep order, DsP[f][jj] = Dt[subset[f]][order[jj]]
+// and BsP likewise — every later access of the block kernels is a plain contiguous row.
+template <typename T>
+__global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_t *order, int k, T *CPP, T *cdiag,
+                                                        int32_t *frozen, double *coef_all, unsigned int *counter,
+                                                        const T *comp_norm, T *norm_in, const T *Dt, const T *Bt,
+                                                        const int32_t *subset, int64_t s, T *DsP, T *BsP) {
+    int id = (int)blockIdx.x;
+    if (id < kNB) {
+        const int m = id;
+        if (m == 0) {
+            if (threadIdx.x < kCounters) counter[threadIdx.x] = 0;
+            for (int j = threadIdx.x; j < k; j += 256) {
+                norm_in[j] = comp_norm[j];
+                const T d = C[(int64_t)order[j] * k + order[j]];
+                cdiag[j] = d;
+                frozen[j] = !(d > (T)1e-20);          // dict_fact.py:681 "else do not update"
+            }
+        }
+        for (int jj = threadIdx.x; jj < k; jj += 256) {
+            const int jl = jj % kNB, jb0 = jj - jl;
+            double c = 0;
+            if (m < jl && jb0 + m < k) {
+                const int oi = order[jb0 + m], oj = order[jj];
+                const T d = C[(int64_t)oj * k + oj];
+                if (d > (T)1e-20) c = (double)C[(int64_t)oi * k + oj] / (double)d;
+            }
+            coef_all[(int64_t)m * k + jj] = c;
+        }
+        return;
+    }
+    id -= kNB;
+    if (id < k) {
+        const int mp = id, om = order[mp];
+        for (int jj = threadIdx.x; jj < k; jj += 256) {
+            T v = C[(int64_t)om * k + order[jj]];
+            if (mp / kNB == jj / kNB && mp <= jj) v = 0;
+            CPP[(int64_t)mp * k + jj] = v;
+        }
+        return;
+    }
+    id -= k;
+    if (id < s) {
+        const int64_t f = id, src = sub_row(subset, f) * k;
+        for (int jj = threadIdx.x; jj < k; jj += 256) {
+            const int o = order[jj];
+            DsP[f * k + jj] = Dt[src + o];
+            BsP[f * k + jj] = Bt[src + o];
+        }
+    }
+}
+
 template <typename T> struct EpiBcdA {
     T *a; const T *Dt; const T *Bt; const T *cdiag; const int32_t *frozen; const int32_t *subset; const int32_t *order;
     int k, j0;
@@ -970,30 +1025,28 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         double *coef_all = reinterpret_cast<double *>(ws + L.off_coef);
         double *CA[2] = {Tp, Tp + kResStride};
         unsigned int *counter = reinterpret_cast<unsigned int *>(Tp + 2 * kResStride);
-        hipLaunchKernelGGL((bcd_prepare_kernel<T>), dim3(k > kNB ? k : kNB), dim3(256), sizeof(int32_t) * (size_t)k,
-                           stream, a.C, a.order, k, CP, cdiag, frozen, coef_all, counter, a.comp_norm,
-                           reinterpret_cast<T *>(ws + L.off_norm_in));
-        MODL_LAUNCH_CHECK();
-        ++nl;
         const bool fused = std::is_same<T, float>::value && (k % 4 == 0) && k <= 512;
         const int RT = (s <= 256) ? 1 : 2;
         const int nslab = fused ? (int)cdiv(s, 32 * RT) : (int)cdiv(s, kGramRows);
         const int GPW = (k <= 256) ? 8 : 16;
         void (*blk)(BcdBlockArgs) = nullptr;
+        T *DsP = reinterpret_cast<T *>(ws + L.off_Dnew), *BsP = reinterpret_cast<T *>(ws + L.off_BsP), *CPP = CP;
         if (fused) {
             blk = (RT == 1) ? (GPW == 8 ? bcd_block_kernel<1, 8> : bcd_block_kernel<1, 16>)
                             : (GPW == 8 ? bcd_block_kernel<2, 8> : bcd_block_kernel<2, 16>);
             MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(blk), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024));
-        }
-        T *DsP = reinterpret_cast<T *>(ws + L.off_Dnew), *BsP = reinterpret_cast<T *>(ws + L.off_BsP), *CPP = CP;
-        if (fused) {
-            hipLaunchKernelGGL((bcd_pack_kernel<T>), dim3((unsigned)s), dim3(256), 0, stream, a.Dt, a.Bt, a.subset, a.order,
-                               s, k, DsP, BsP);
+            hipLaunchKernelGGL((bcd_setup_kernel<T>), dim3((unsigned)(kNB + k + s)), dim3(256), 0, stream, a.C, a.order, k, CPP,
+                               cdiag, frozen, coef_all, counter, a.comp_norm, reinterpret_cast<T *>(ws + L.off_norm_in), a.Dt,
+                               a.Bt, a.subset, s, DsP, BsP);
             MODL_LAUNCH_CHECK();
-            hipLaunchKernelGGL((bcd_permute_C_kernel<T>), dim3(k), dim3(256), 0, stream, a.C, a.order, k, CPP);
+            ++nl;
+        } else {
+            hipLaunchKernelGGL((bcd_prepare_kernel<T>), dim3(k > kNB ? k : kNB), dim3(256), sizeof(int32_t) * (size_t)k,
+                               stream, a.C, a.order, k, CP, cdiag, frozen, coef_all, counter, a.comp_norm,
+                               reinterpret_cast<T *>(ws + L.off_norm_in));
             MODL_LAUNCH_CHECK();
-            nl += 2;
+            ++nl;
         }
         const size_t rec_half = (size_t)L.nslab_max * kResStride, grec_half = (size_t)kCounters * kResStride;   // >= the packed sizes
         double *gpart = reinterpret_cast<double *>(ws + L.off_gpartial);

@@ -323,7 +323,10 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
     }
 #pragma unroll
     for (int c = 0; c < KPL; ++c)
-        if (c * 64 + lane < k) wptr[c * 64 + lane] = w[c] + wfix[c];
+        if (c * 64 + lane < k) {
+            wptr[c * 64 + lane] = w[c] + wfix[c];
+            if (a.code2) a.code2[(a.idx2 ? a.idx2[smp] : (int64_t)smp) * k + c * 64 + lane] = w[c] + wfix[c];
+        }
     if (a.sweeps && lane == 0) a.sweeps[smp] = n_iter;
 }
 

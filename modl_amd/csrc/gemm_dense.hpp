@@ -82,18 +82,17 @@ struct TileLoader {
     }
 };
 
-template <typename T, bool AIFAST, bool BIFAST, class Epi>
-__global__ __launch_bounds__(256) void gemm_dense_kernel(DenseOperand A, DenseOperand B, int64_t M, int64_t N, int64_t K,
-                                                         int64_t k_per_split, T *partial, Epi epi) {
+// One output tile of one (possibly K-split) product.  (bx, by, bz) = tile column, tile row, split index.
+template <typename T, bool AIFAST, bool BIFAST, class Epi, int BM, int BN, int BK>
+__device__ __forceinline__ void gemm_dense_tile(const DenseOperand &A, const DenseOperand &B, int64_t M, int64_t N,
+                                                int64_t K, int64_t k_per_split, T *partial, const Epi &epi, int bx, int by,
+                                                int bz, int nsplit, T (*As)[BK][BM + 4], T (*Bs)[BK][BN + 4]) {
     using MT = Mma<T>;
-    constexpr int BM = 64, BN = 64, BK = (sizeof(T) == 4) ? 32 : 16;
     constexpr int RM = 32 / MT::TM, RN = 32 / MT::TN;     // wave tile 32 x 32
-    __shared__ __attribute__((aligned(16))) T As[2][BK][BM + 4];
-    __shared__ __attribute__((aligned(16))) T Bs[2][BK][BN + 4];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
-    const int64_t k_begin = (int64_t)blockIdx.z * k_per_split;
+    const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
+    const int64_t k_begin = (int64_t)bz * k_per_split;
     const int64_t k_end = (k_begin + k_per_split < K) ? k_begin + k_per_split : K;
 
     typename MT::acc_t acc[RM][RN];
@@ -139,7 +138,7 @@ __global__ __launch_bounds__(256) void gemm_dense_kernel(DenseOperand A, DenseOp
         cur ^= 1;
     }
 
-    const bool direct = (gridDim.z == 1);
+    const bool direct = (nsplit == 1);
 #pragma unroll
     for (int i = 0; i < RM; ++i)
 #pragma unroll
@@ -150,9 +149,120 @@ __global__ __launch_bounds__(256) void gemm_dense_kernel(DenseOperand A, DenseOp
                 const int64_t n = n0 + wn * 32 + j * MT::TN + MT::acc_col(lane, r);
                 if (m < M && n < N) {
                     if (direct) epi(m, n, acc[i][j][r]);
-                    else partial[((int64_t)blockIdx.z * M + m) * N + n] = acc[i][j][r];
+                    else partial[((int64_t)bz * M + m) * N + n] = acc[i][j][r];
                 }
             }
+}
+
+template <typename T, bool AIFAST, bool BIFAST, class Epi>
+__global__ __launch_bounds__(256) void gemm_dense_kernel(DenseOperand A, DenseOperand B, int64_t M, int64_t N, int64_t K,
+                                                         int64_t k_per_split, T *partial, Epi epi) {
+    constexpr int BM = 64, BN = 64, BK = (sizeof(T) == 4) ? 32 : 16;
+    __shared__ __attribute__((aligned(16))) T As[2][BK][BM + 4];
+    __shared__ __attribute__((aligned(16))) T Bs[2][BK][BN + 4];
+    gemm_dense_tile<T, AIFAST, BIFAST, Epi, BM, BN, BK>(A, B, M, N, K, k_per_split, partial, epi, (int)blockIdx.x,
+                                                        (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.z, As, Bs);
+}
+
+// ---- two independent products in ONE launch (and their split-K reductions in one more) -------------
+// At the metric's shape the products of a minibatch are tiny (0.1 GFLOP): a launch costs more than the
+// arithmetic, so the independent ones travel together.
+template <typename T, class Epi> struct DenseProblem {
+    DenseOperand A, B;
+    int64_t M = 0, N = 0, K = 0, kps = 0;
+    T *partial = nullptr;
+    Epi epi;
+    int tn = 0, tm = 0, splits = 1;
+    bool ok = false;                                  // aligned: eligible for the dense kernels
+};
+
+template <typename T, class Epi>
+DenseProblem<T, Epi> plan_dense(const DenseOperand &A, const DenseOperand &B, int64_t M, int64_t N, int64_t K, const Epi &epi,
+                                T *ws, size_t ws_elems, int target_wgs = 512, int max_splits = 64) {
+    DenseProblem<T, Epi> P;
+    P.A = A; P.B = B; P.M = M; P.N = N; P.K = K; P.epi = epi;
+    constexpr int VN = Vec4<T>::N;
+    auto aligned = [](const DenseOperand &o) {
+        if (o.si != 1 && o.sk != 1) return false;
+        const int64_t ld = (o.si == 1) ? o.sk : o.si;
+        return (reinterpret_cast<uintptr_t>(o.ptr) % 16 == 0) && (ld % VN == 0);
+    };
+    P.ok = aligned(A) && aligned(B) && K > 0 && M > 0 && N > 0;
+    if (!P.ok) return P;
+    constexpr int BK = (sizeof(T) == 4) ? 32 : 16;
+    const int64_t tm = cdiv(M, 64), tn = cdiv(N, 64);
+    int64_t splits = 1;
+    if (tm * tn < target_wgs && max_splits > 1 && ws) {
+        splits = target_wgs / (tm * tn);
+        const int64_t max_by_k = K / (4 * BK) > 0 ? K / (4 * BK) : 1;       // >= 4 k-tiles per split
+        if (splits > max_by_k) splits = max_by_k;
+        if (splits > max_splits) splits = max_splits;
+        const int64_t max_by_ws = (int64_t)ws_elems / (M * N);
+        if (splits > max_by_ws) splits = max_by_ws;
+        if (splits < 1) splits = 1;
+    }
+    P.kps = cdiv(cdiv(K, splits), BK) * BK;
+    P.splits = (int)cdiv(K, P.kps);
+    P.tn = (int)tn; P.tm = (int)tm;
+    P.partial = ws;
+    return P;
+}
+
+template <typename T, bool AI0, bool BI0, class Epi0, bool AI1, bool BI1, class Epi1>
+__global__ __launch_bounds__(256) void gemm_dense_pair_kernel(DenseProblem<T, Epi0> P0, DenseProblem<T, Epi1> P1) {
+    constexpr int BM = 64, BN = 64, BK = (sizeof(T) == 4) ? 32 : 16;
+    __shared__ __attribute__((aligned(16))) T As[2][BK][BM + 4];
+    __shared__ __attribute__((aligned(16))) T Bs[2][BK][BN + 4];
+    int id = (int)blockIdx.x;
+    const int t0 = P0.tn * P0.tm * P0.splits;
+    if (id < t0) {
+        const int bx = id % P0.tn, by = (id / P0.tn) % P0.tm, bz = id / (P0.tn * P0.tm);
+        gemm_dense_tile<T, AI0, BI0, Epi0, BM, BN, BK>(P0.A, P0.B, P0.M, P0.N, P0.K, P0.kps, P0.partial, P0.epi, bx, by, bz,
+                                                       P0.splits, As, Bs);
+    } else {
+        id -= t0;
+        const int bx = id % P1.tn, by = (id / P1.tn) % P1.tm, bz = id / (P1.tn * P1.tm);
+        gemm_dense_tile<T, AI1, BI1, Epi1, BM, BN, BK>(P1.A, P1.B, P1.M, P1.N, P1.K, P1.kps, P1.partial, P1.epi, bx, by, bz,
+                                                       P1.splits, As, Bs);
+    }
+}
+
+template <typename T, class Epi0, class Epi1>
+__global__ __launch_bounds__(256) void gemm_reduce_pair_kernel(const T *partial0, int splits0, int64_t M0, int64_t N0, Epi0 epi0,
+                                                               int nblk0, const T *partial1, int splits1, int64_t M1,
+                                                               int64_t N1, Epi1 epi1) {
+    if ((int)blockIdx.x < nblk0) {
+        const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (e >= M0 * N0) return;
+        T v = 0;
+        for (int z = 0; z < splits0; ++z) v += partial0[(int64_t)z * M0 * N0 + e];
+        epi0(e / N0, e % N0, v);
+    } else {
+        const int64_t e = (int64_t)((int)blockIdx.x - nblk0) * 256 + threadIdx.x;
+        if (e >= M1 * N1) return;
+        T v = 0;
+        for (int z = 0; z < splits1; ++z) v += partial1[(int64_t)z * M1 * N1 + e];
+        epi1(e / N1, e % N1, v);
+    }
+}
+
+// Both problems must be `ok` (see plan_dense) and their operand orientations known statically.
+template <typename T, bool AI0, bool BI0, class Epi0, bool AI1, bool BI1, class Epi1>
+int launch_gemm_dense_pair(hipStream_t stream, const DenseProblem<T, Epi0> &P0, const DenseProblem<T, Epi1> &P1,
+                           int *launches = nullptr) {
+    const int total = P0.tn * P0.tm * P0.splits + P1.tn * P1.tm * P1.splits;
+    hipLaunchKernelGGL((gemm_dense_pair_kernel<T, AI0, BI0, Epi0, AI1, BI1, Epi1>), dim3((unsigned)total), dim3(256), 0, stream,
+                       P0, P1);
+    MODL_LAUNCH_CHECK();
+    if (launches) ++*launches;
+    const int nb0 = P0.splits > 1 ? (int)cdiv(P0.M * P0.N, 256) : 0, nb1 = P1.splits > 1 ? (int)cdiv(P1.M * P1.N, 256) : 0;
+    if (nb0 + nb1 > 0) {
+        hipLaunchKernelGGL((gemm_reduce_pair_kernel<T, Epi0, Epi1>), dim3((unsigned)(nb0 + nb1)), dim3(256), 0, stream,
+                           P0.partial, P0.splits, P0.M, P0.N, P0.epi, nb0, P1.partial, P1.splits, P1.M, P1.N, P1.epi);
+        MODL_LAUNCH_CHECK();
+        if (launches) ++*launches;
+    }
+    return MODL_OK;
 }
 
 // Dense launcher.  Requires 16-byte aligned bases and leading strides that keep every vector
@@ -162,37 +272,18 @@ int launch_gemm_dense(hipStream_t stream, const DenseOperand &A, const DenseOper
                       const Epi &epi, const SplitWs &ws, int *launches = nullptr, int target_wgs = 512,
                       int max_splits = 64) {
     if (M <= 0 || N <= 0) return MODL_OK;
-    constexpr int VN = Vec4<T>::N;
-    auto aligned = [](const DenseOperand &o) {
-        if (o.si != 1 && o.sk != 1) return false;
-        const int64_t ld = (o.si == 1) ? o.sk : o.si;
-        return (reinterpret_cast<uintptr_t>(o.ptr) % 16 == 0) && (ld % VN == 0);
-    };
-    if (!aligned(A) || !aligned(B) || K <= 0) {
+    const DenseProblem<T, Epi> P = plan_dense<T, Epi>(A, B, M, N, K, epi, static_cast<T *>(ws.ptr), ws.bytes / sizeof(T),
+                                                      target_wgs, max_splits);
+    if (!P.ok) {
         Operand a, b;
         a.ptr = A.ptr; a.si = A.si; a.sk = A.sk;
         b.ptr = B.ptr; b.si = B.si; b.sk = B.sk;
         return launch_gemm<T, Epi>(stream, a, b, M, N, K, epi, ws, launches, target_wgs, max_splits);
     }
-    constexpr int BK = (sizeof(T) == 4) ? 32 : 16;
-    const int64_t tm = cdiv(M, 64), tn = cdiv(N, 64);
-    int64_t splits = 1;
-    if (tm * tn < target_wgs && max_splits > 1 && ws.ptr) {
-        splits = target_wgs / (tm * tn);
-        const int64_t max_by_k = K / (4 * BK) > 0 ? K / (4 * BK) : 1;       // >= 4 k-tiles per split
-        if (splits > max_by_k) splits = max_by_k;
-        if (splits > max_splits) splits = max_splits;
-        const int64_t max_by_ws = (int64_t)(ws.bytes / sizeof(T)) / (M * N);
-        if (splits > max_by_ws) splits = max_by_ws;
-        if (splits < 1) splits = 1;
-    }
-    const int64_t kps = cdiv(cdiv(K, splits), BK) * BK;
-    splits = cdiv(K, kps);
-    dim3 grid((unsigned)tn, (unsigned)tm, (unsigned)splits);
-    T *partial = static_cast<T *>(ws.ptr);
+    dim3 grid((unsigned)P.tn, (unsigned)P.tm, (unsigned)P.splits);
     const bool ai = A.si == 1, bi = B.si == 1;
 #define MODL_GD(AI, BI) \
-    hipLaunchKernelGGL((gemm_dense_kernel<T, AI, BI, Epi>), grid, dim3(256), 0, stream, A, B, M, N, K, kps, partial, epi)
+    hipLaunchKernelGGL((gemm_dense_kernel<T, AI, BI, Epi>), grid, dim3(256), 0, stream, A, B, M, N, K, P.kps, P.partial, epi)
     if (ai && bi) MODL_GD(true, true);
     else if (ai) MODL_GD(true, false);
     else if (bi) MODL_GD(false, true);
@@ -200,9 +291,9 @@ int launch_gemm_dense(hipStream_t stream, const DenseOperand &A, const DenseOper
 #undef MODL_GD
     MODL_LAUNCH_CHECK();
     if (launches) ++*launches;
-    if (splits > 1) {
+    if (P.splits > 1) {
         hipLaunchKernelGGL((gemm_reduce_kernel<T, Epi>), dim3((unsigned)cdiv(M * N, 256)), dim3(256), 0, stream,
-                           partial, (int)splits, M, N, epi);
+                           P.partial, P.splits, M, N, epi);
         MODL_LAUNCH_CHECK();
         if (launches) ++*launches;
     }

@@ -15,6 +15,8 @@ struct CdArgs {
     const T *H0;           // [b][k] initial Q w (from a matrix-core product), or null: computed in-kernel
     T *code;               // [n][k]
     const int64_t *idx;    // [b] or null (identity)
+    T *code2 = nullptr;    // optional second destination: code2[idx2[i]] = solution i
+    const int64_t *idx2 = nullptr;
     int32_t *sweeps;       // [b] or null
     int b, k;
     T alpha, beta, tol;

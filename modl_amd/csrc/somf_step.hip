@@ -55,6 +55,102 @@ __global__ __launch_bounds__(256) void stats_apply_kernel(T *dst, const T *delta
     }
 }
 
+// both statistics in one launch: blocks [0, nblk0) -> C, the rest -> Bt
+template <typename T>
+__global__ __launch_bounds__(256) void stats_apply2_kernel(T *C, int64_t n0, int nblk0, T *Bt, int64_t n1, const T *delta,
+                                                           T beta, T wt, T bdiv, int replace) {
+    T *dst;
+    const T *src;
+    int64_t n, e, stride;
+    if ((int)blockIdx.x < nblk0) {
+        dst = C; src = delta; n = n0;
+        e = (int64_t)blockIdx.x * 256 + threadIdx.x; stride = (int64_t)nblk0 * 256;
+    } else {
+        dst = Bt; src = delta + n0; n = n1;
+        e = (int64_t)((int)blockIdx.x - nblk0) * 256 + threadIdx.x; stride = (int64_t)((int)gridDim.x - nblk0) * 256;
+    }
+    for (; e < n; e += stride) {
+        const T d = src[e];
+        if (replace) dst[e] = d / bdiv;
+        else dst[e] = dst[e] * beta + (wt * d) / bdiv;
+    }
+}
+
+// the same update as a GEMM epilogue (single-GPU step: the increments never travel through HBM)
+template <typename T> struct EpiStats {
+    T *out; int64_t ld; T beta, wt, bdiv; int replace;
+    __device__ __forceinline__ void operator()(int64_t m, int64_t n, T v) const {
+        T *o = out + m * ld + n;
+        if (replace) *o = v / bdiv;
+        else *o = (*o) * beta + (wt * v) / bdiv;
+    }
+};
+
+// Everything the code step gathers, in ONE launch: squared row norms of the minibatch, the sampled
+// dictionary rows Ds = Dt[subset], the sampled minibatch columns Xs = X[:, subset], the minibatch's code rows.
+template <typename T> struct PrepArgs {
+    const T *X; int64_t ldx, p; int b; T *xnorm; int n_norm;                 // n_norm = b or 0
+    const T *Dt; const int32_t *subset; int64_t s; int k; T *Ds; int n_rows;  // n_rows = s or 0
+    int64_t s_pad; T *Xs; int gx; int n_cols;                                 // n_cols = gx * b or 0
+    const T *code; const int64_t *idx; T *codeb; int n_code;                  // n_code = b or 0
+};
+template <typename T>
+__global__ __launch_bounds__(256) void prep_kernel(PrepArgs<T> a) {
+    __shared__ double red[4];
+    int id = (int)blockIdx.x;
+    if (id < a.n_norm) {                                 // dict_fact_fast.pyx:334 uses dot(y, y)
+        const T *x = a.X + (int64_t)id * a.ldx;
+        constexpr int V = 16 / sizeof(T);
+        typedef T vec_t __attribute__((ext_vector_type(V)));
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        const bool vec = (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+        const int64_t nv = vec ? a.p / V : 0;
+        const vec_t *xv = reinterpret_cast<const vec_t *>(x);
+        int64_t f = threadIdx.x;
+        for (; f + 768 < nv; f += 1024) {
+            const vec_t a0 = xv[f], a1 = xv[f + 256], a2 = xv[f + 512], a3 = xv[f + 768];
+#pragma unroll
+            for (int c = 0; c < V; ++c) {
+                s0 += (double)a0[c] * (double)a0[c];
+                s1 += (double)a1[c] * (double)a1[c];
+                s2 += (double)a2[c] * (double)a2[c];
+                s3 += (double)a3[c] * (double)a3[c];
+            }
+        }
+        for (; f < nv; f += 256) {
+            const vec_t a0 = xv[f];
+#pragma unroll
+            for (int c = 0; c < V; ++c) s0 += (double)a0[c] * (double)a0[c];
+        }
+        for (int64_t e = nv * V + threadIdx.x; e < a.p; e += 256) s1 += (double)x[e] * (double)x[e];
+        double sum = (s0 + s1) + (s2 + s3);
+        sum = block_sum(sum, red);
+        if (threadIdx.x == 0) a.xnorm[id] = (T)sum;
+        return;
+    }
+    id -= a.n_norm;
+    if (id < a.n_rows) {
+        const T *src = a.Dt + (int64_t)a.subset[id] * a.k;
+        T *dst = a.Ds + (int64_t)id * a.k;
+        for (int c = threadIdx.x; c < a.k; c += 256) dst[c] = src[c];
+        return;
+    }
+    id -= a.n_rows;
+    if (id < a.n_cols) {
+        const int i = id / a.gx, bx = id % a.gx;
+        const T *row = a.X + (int64_t)i * a.ldx;
+        for (int64_t f = (int64_t)bx * 256 + threadIdx.x; f < a.s_pad; f += (int64_t)a.gx * 256)
+            a.Xs[(int64_t)i * a.s_pad + f] = (f < a.s) ? row[a.subset[f]] : (T)0;
+        return;
+    }
+    id -= a.n_cols;
+    if (id < a.n_code) {
+        const T *src = a.code + a.idx[id] * a.k;
+        T *dst = a.codeb + (int64_t)id * a.k;
+        for (int c = threadIdx.x; c < a.k; c += 256) dst[c] = src[c];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void fill_kernel(T *dst, int64_t n, T v) {
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -89,6 +185,7 @@ struct modl_somf_plan {
     std::vector<int64_t> h_order_copy;
     // profiling
     bool prof = false;
+    bool stats_fused = false;          // the last phase 1 applied the statistics in its epilogues
     unsigned prof_mask = ~0u;          // sections that record events
     std::vector<hipEvent_t> pev;       // 2 * kProfPool events
     std::vector<int> psec, plaunch;
@@ -232,7 +329,8 @@ int gram_of_rows(modl_somf_plan *pl, hipStream_t st, const T *Dt, const int32_t 
 
 template <typename T>
 int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride, const int64_t *g_idx, T *Dx,
-                const T *xnorm2, T *code, const int64_t *d_idx, int b, int32_t *d_sweeps, int *nl, T *H0buf, T *Fbuf) {
+                const T *xnorm2, T *code, const int64_t *d_idx, int b, int32_t *d_sweeps, int *nl, T *H0buf, T *Fbuf,
+                T *scatter_dst = nullptr, const int64_t *scatter_idx = nullptr) {
     const modl_somf_desc &d = pl->d;
     const int k = d.k;
     if (d.code_l1_ratio == 0.0) {                                     // ridge: dict_fact_fast.pyx:82-94, 174-197
@@ -240,6 +338,12 @@ int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride
         MODL_TRY(launch_cholesky<T>(st, G, g_stride, g_idx, Fbuf, k, (T)d.code_alpha, nmat));
         MODL_TRY(launch_chol_solve<T>(st, Fbuf, g_stride ? (int64_t)k * k : 0, Dx, b, k, code, d_idx));
         *nl += 2;
+        if (scatter_dst) {
+            hipLaunchKernelGGL((scatter_rows_T_kernel<T, int64_t>), dim3((unsigned)b), dim3(256), 0, st, scatter_dst,
+                               (int64_t)k, scatter_idx, (int64_t)b, (int64_t)k, code, (int64_t)k);
+            MODL_LAUNCH_CHECK();
+            ++*nl;
+        }
         return MODL_OK;
     }
     const T *H0 = nullptr;
@@ -262,6 +366,7 @@ int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride
     CdArgs<T> a;
     a.G = G; a.g_stride = g_stride; a.g_idx = g_idx; a.Dx = Dx; a.xnorm2 = xnorm2; a.H0 = H0; a.code = code;
     a.idx = d_idx;
+    a.code2 = scatter_dst; a.idx2 = scatter_idx;
     a.sweeps = d_sweeps; a.b = b; a.k = k;
     a.alpha = (T)((T)d.code_alpha * (T)d.code_l1_ratio);
     a.beta = (T)((double)(T)d.code_alpha * (1.0 - (double)(T)d.code_l1_ratio));
@@ -271,8 +376,10 @@ int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride
     return MODL_OK;
 }
 
+// fuse_stats: apply the statistics update in the epilogue of the increment products (single-GPU step)
 template <typename T>
-int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch *bt, T *delta, hipStream_t st) {
+int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch *bt, T *delta, hipStream_t st,
+           bool fuse_stats = false) {
     const modl_somf_desc &d = pl->d;
     const int k = d.k, b = bt->b;
     const int64_t p = d.p, s = bt->s;
@@ -307,31 +414,31 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
     T *cb = codeb;
     if (!d_idx) cb = code;                                             // rows 0..b-1 are already contiguous
 
+    T *ws_split = reinterpret_cast<T *>(sws.ptr);
+    const size_t ws_elems = sws.bytes / sizeof(T);
     {   // ---- Dx, G  (dict_fact.py:588-620)
         ProfScope ps(pl, st, SEC_CODE_GEMM);
-        if (d.code_l1_ratio != 0.0) {
-            MODL_TRY(launch_row_norm2<T>(st, X, bt->ldx, p, b, xnorm));
-            ++ps.launches;
-        }
         // compaction: gather once, contract dense.  Ds = Dt[subset] (whole 1 KiB feature rows),
-        // Xs = X[:, subset].  With every feature sampled nothing is copied.
+        // Xs = X[:, subset].  With every feature sampled nothing is copied.  One launch for the row
+        // norms and every gather.
         const T *Dsrc = Dt, *Xsrc = X;
         int64_t ldxs = bt->ldx;
         const bool need_sub = d_subset && (d.Dx_agg != MODL_AGG_FULL || d.G_agg != MODL_AGG_FULL);
+        PrepArgs<T> pa;
+        pa.X = X; pa.ldx = bt->ldx; pa.p = p; pa.b = b; pa.xnorm = xnorm; pa.n_norm = (d.code_l1_ratio != 0.0) ? b : 0;
+        pa.Dt = Dt; pa.subset = d_subset; pa.s = s; pa.k = k; pa.Ds = Dsb; pa.n_rows = need_sub ? (int)s : 0;
+        pa.s_pad = s_pad; pa.Xs = Xsb; pa.gx = (int)std::min<int64_t>(cdiv(s_pad, 256), 64);
+        pa.n_cols = (need_sub && d.Dx_agg != MODL_AGG_FULL) ? pa.gx * b : 0;
+        pa.code = code; pa.idx = d_idx; pa.codeb = codeb; pa.n_code = (cd_on_compact && d_idx) ? b : 0;
         if (need_sub) {
-            hipLaunchKernelGGL((gather_rows_T_kernel<T, int32_t>), dim3((unsigned)s), dim3(256), 0, st, Dt, (int64_t)k,
-                               d_subset, s, s, (int64_t)k, Dsb, (int64_t)k);
+            Dsrc = Dsb;
+            if (d.Dx_agg != MODL_AGG_FULL) { Xsrc = Xsb; ldxs = s_pad; }
+        }
+        const int n_prep = pa.n_norm + pa.n_rows + pa.n_cols + pa.n_code;
+        if (n_prep > 0) {
+            hipLaunchKernelGGL((prep_kernel<T>), dim3((unsigned)n_prep), dim3(256), 0, st, pa);
             MODL_LAUNCH_CHECK();
             ++ps.launches;
-            Dsrc = Dsb;
-            if (d.Dx_agg != MODL_AGG_FULL) {
-                hipLaunchKernelGGL((gather_cols_T_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv(s_pad, 256), 64), b),
-                                   dim3(256), 0, st, X, bt->ldx, d_subset, s, s_pad, Xsb);
-                MODL_LAUNCH_CHECK();
-                ++ps.launches;
-                Xsrc = Xsb;
-                ldxs = s_pad;
-            }
         }
         DenseOperand A, B;
         int64_t Kdim;
@@ -345,27 +452,48 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
             B.ptr = Dsrc; B.si = 1; B.sk = k;
             Kdim = s; scale = red;
         }
-        if (d.Dx_agg == MODL_AGG_AVERAGE) {
-            EpiDxAverage<T> epi{Dx, static_cast<T *>(stt->d_Dx_average), d_idx, d_wsample, k, scale};
-            MODL_TRY((launch_gemm_dense<T, EpiDxAverage<T>>(st, A, B, b, k, Kdim, epi, sws, &ps.launches)));
-        } else {
-            EpiStore<T> epi{Dx, k, scale};
-            MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, A, B, b, k, Kdim, epi, sws, &ps.launches)));
-        }
-        if (d.G_agg != MODL_AGG_FULL) {
-            DenseOperand Dg;
-            Dg.ptr = Dsrc; Dg.si = 1; Dg.sk = k;
-            EpiStore<T> epi{Gbuf, k, red};
-            MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Dg, Dg, k, k, s, epi, sws, &ps.launches)));
-            if (d.G_agg == MODL_AGG_AVERAGE) {
-                MODL_TRY(launch_update_G_average<T>(st, static_cast<T *>(stt->d_G_average), d_idx, Gbuf, d_wsample, b, k));
-                ++ps.launches;
+        // the Dx product and the Gram product are independent: one launch (+ one for both split-K sums)
+        DenseOperand Dg;
+        Dg.ptr = Dsrc; Dg.si = 1; Dg.sk = k;
+        const bool want_G = d.G_agg != MODL_AGG_FULL;
+        bool paired = false;
+        if (want_G && A.si != 1) {
+            EpiStore<T> epiG{Gbuf, k, red};
+            const size_t half = ws_elems / 2;
+            auto PG = plan_dense<T, EpiStore<T>>(Dg, Dg, k, k, s, epiG, ws_split + half, ws_elems - half);
+            if (d.Dx_agg == MODL_AGG_AVERAGE) {
+                EpiDxAverage<T> epi{Dx, static_cast<T *>(stt->d_Dx_average), d_idx, d_wsample, k, scale};
+                auto PD = plan_dense<T, EpiDxAverage<T>>(A, B, b, k, Kdim, epi, ws_split, half);
+                if (PD.ok && PG.ok) {
+                    MODL_TRY((launch_gemm_dense_pair<T, false, true, EpiDxAverage<T>, true, true, EpiStore<T>>(st, PD, PG,
+                                                                                                                &ps.launches)));
+                    paired = true;
+                }
+            } else {
+                EpiStore<T> epi{Dx, k, scale};
+                auto PD = plan_dense<T, EpiStore<T>>(A, B, b, k, Kdim, epi, ws_split, half);
+                if (PD.ok && PG.ok) {
+                    MODL_TRY((launch_gemm_dense_pair<T, false, true, EpiStore<T>, true, true, EpiStore<T>>(st, PD, PG,
+                                                                                                            &ps.launches)));
+                    paired = true;
+                }
             }
         }
-        if (cd_on_compact && d_idx) {
-            hipLaunchKernelGGL((gather_rows_T_kernel<T, int64_t>), dim3((unsigned)b), dim3(256), 0, st, code, (int64_t)k,
-                               d_idx, (int64_t)b, (int64_t)b, (int64_t)k, codeb, (int64_t)k);
-            MODL_LAUNCH_CHECK();
+        if (!paired) {
+            if (d.Dx_agg == MODL_AGG_AVERAGE) {
+                EpiDxAverage<T> epi{Dx, static_cast<T *>(stt->d_Dx_average), d_idx, d_wsample, k, scale};
+                MODL_TRY((launch_gemm_dense<T, EpiDxAverage<T>>(st, A, B, b, k, Kdim, epi, sws, &ps.launches)));
+            } else {
+                EpiStore<T> epi{Dx, k, scale};
+                MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, A, B, b, k, Kdim, epi, sws, &ps.launches)));
+            }
+            if (want_G) {
+                EpiStore<T> epi{Gbuf, k, red};
+                MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Dg, Dg, k, k, s, epi, sws, &ps.launches)));
+            }
+        }
+        if (d.G_agg == MODL_AGG_AVERAGE) {
+            MODL_TRY(launch_update_G_average<T>(st, static_cast<T *>(stt->d_G_average), d_idx, Gbuf, d_wsample, b, k));
             ++ps.launches;
         }
     }
@@ -377,20 +505,15 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
                                     &ps.launches, H0, Fbuf));
         } else {
             const T *G = (d.G_agg == MODL_AGG_FULL) ? static_cast<const T *>(stt->d_G) : Gbuf;
-            if (cd_on_compact) {
-                MODL_TRY(solve_codes<T>(pl, st, G, 0, nullptr, Dx, xnorm, cb, nullptr, b, d_sweeps, &ps.launches, H0, Fbuf));
-                if (d_idx) {
-                    hipLaunchKernelGGL((scatter_rows_T_kernel<T, int64_t>), dim3((unsigned)b), dim3(256), 0, st, code,
-                                       (int64_t)k, d_idx, (int64_t)b, (int64_t)k, codeb, (int64_t)k);
-                    MODL_LAUNCH_CHECK();
-                    ++ps.launches;
-                }
+            if (cd_on_compact) {     // solve on the compact rows, the solver also writes code_[idx]
+                MODL_TRY(solve_codes<T>(pl, st, G, 0, nullptr, Dx, xnorm, cb, nullptr, b, d_sweeps, &ps.launches, H0, Fbuf,
+                                        d_idx ? code : nullptr, d_idx));
             } else {
                 MODL_TRY(solve_codes<T>(pl, st, G, 0, nullptr, Dx, xnorm, code, d_idx, b, d_sweeps, &ps.launches, H0, Fbuf));
             }
         }
     }
-    {   // ---- statistics increments: delta = [ code^T code | X^T code ]
+    {   // ---- statistics increments: delta = [ code^T code | X^T code ], one launch for both products
         ProfScope ps(pl, st, SEC_STATS_GEMM);
         if (!cd_on_compact && d_idx) {
             hipLaunchKernelGGL((gather_rows_T_kernel<T, int64_t>), dim3((unsigned)b), dim3(256), 0, st, code, (int64_t)k,
@@ -400,12 +523,34 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         }
         DenseOperand Cd;
         Cd.ptr = cb; Cd.si = 1; Cd.sk = k;                              // element (i = atom, kk = sample)
-        EpiStore<T> epiC{delta, k, (T)1};
-        MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Cd, Cd, k, k, b, epiC, sws, &ps.launches)));
         DenseOperand Xo;
         Xo.ptr = X; Xo.si = 1; Xo.sk = bt->ldx;                         // element (i = feature, kk = sample)
-        EpiStore<T> epiB{delta + (size_t)k * k, k, (T)1};
-        MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Xo, Cd, p, k, b, epiB, sws, &ps.launches)));
+        pl->stats_fused = false;
+        if (fuse_stats) {
+            if (!stt->d_Bt || !stt->d_C || bt->b_global <= 0) return MODL_EINVAL;
+            const int replace = d.optimizer == MODL_OPT_SGD;
+            const T beta = (T)(1.0 - bt->w), wt = (T)bt->w, bdiv = (T)bt->b_global;
+            EpiStats<T> eC{static_cast<T *>(stt->d_C), k, beta, wt, bdiv, replace};
+            EpiStats<T> eB{static_cast<T *>(stt->d_Bt), k, beta, wt, bdiv, replace};
+            auto PC = plan_dense<T, EpiStats<T>>(Cd, Cd, k, k, b, eC, nullptr, 0);
+            auto PB = plan_dense<T, EpiStats<T>>(Xo, Cd, p, k, b, eB, nullptr, 0);
+            if (PC.ok && PB.ok) {
+                MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStats<T>, true, true, EpiStats<T>>(st, PC, PB, &ps.launches)));
+                pl->stats_fused = true;
+            }
+        }
+        if (!pl->stats_fused) {
+            EpiStore<T> epiC{delta, k, (T)1};
+            EpiStore<T> epiB{delta + (size_t)k * k, k, (T)1};
+            auto PC = plan_dense<T, EpiStore<T>>(Cd, Cd, k, k, b, epiC, nullptr, 0);
+            auto PB = plan_dense<T, EpiStore<T>>(Xo, Cd, p, k, b, epiB, nullptr, 0);
+            if (PC.ok && PB.ok) {
+                MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStore<T>, true, true, EpiStore<T>>(st, PC, PB, &ps.launches)));
+            } else {
+                MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Cd, Cd, k, k, b, epiC, sws, &ps.launches)));
+                MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Xo, Cd, p, k, b, epiB, sws, &ps.launches)));
+            }
+        }
     }
     return MODL_OK;
 }
@@ -428,13 +573,15 @@ int phase2(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         ProfScope ps(pl, st, SEC_STATS_APPLY);
         const int replace = d.optimizer == MODL_OPT_SGD;
         const T beta = (T)(1.0 - bt->w), wt = (T)bt->w, bdiv = (T)bt->b_global;
-        hipLaunchKernelGGL((stats_apply_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv((int64_t)k * k, 256), 1024)),
-                           dim3(256), 0, st, Cm, delta, (int64_t)k * k, beta, wt, bdiv, replace);
-        MODL_LAUNCH_CHECK();
-        hipLaunchKernelGGL((stats_apply_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv(p * k, 256), 2048)), dim3(256),
-                           0, st, Bt, delta + (size_t)k * k, p * k, beta, wt, bdiv, replace);
-        MODL_LAUNCH_CHECK();
-        ps.launches += 2;
+        if (!pl->stats_fused) {
+            const int nb0 = (int)std::min<int64_t>(cdiv((int64_t)k * k, 256), 256);
+            const int nb1 = (int)std::min<int64_t>(cdiv(p * k, 256), 2048);
+            hipLaunchKernelGGL((stats_apply2_kernel<T>), dim3((unsigned)(nb0 + nb1)), dim3(256), 0, st, Cm, (int64_t)k * k, nb0,
+                               Bt, p * k, delta, beta, wt, bdiv, replace);
+            MODL_LAUNCH_CHECK();
+            ps.launches += 1;
+        }
+        pl->stats_fused = false;
     }
     {
         ProfScope ps(pl, st, SEC_DICT);
@@ -669,7 +816,10 @@ int modl_somf_apply_and_update_dict(modl_somf_plan *pl, const modl_somf_state *s
 
 int modl_somf_step(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt, void *d_delta,
                    void *stream) {
-    MODL_TRY(modl_somf_code_and_partials(pl, st, bt, d_delta, stream));
+    // single-GPU step: the statistics update rides in the epilogues of the increment products
+    if (!pl || !bt) return MODL_EINVAL;
+    MODL_TRY(DISPATCH(pl, phase1<float>(pl, st, bt, static_cast<float *>(d_delta), (hipStream_t)stream, true),
+                      phase1<double>(pl, st, bt, static_cast<double *>(d_delta), (hipStream_t)stream, true)));
     return modl_somf_apply_and_update_dict(pl, st, bt, d_delta, stream);
 }
 

@@ -212,6 +212,13 @@ class HipBackend:
         self._pending = (bt, keep)
         return self.delta
 
+    def step(self, Xh, batch, idx, subset, order, w_sample, w, reduction, b_global):
+        """Both phases in one call (single GPU): the statistics update rides in the GEMM epilogues."""
+        bt, keep = self._batch(Xh, batch, idx, subset, order, w_sample, w, reduction, b_global)
+        st = self._state()
+        check(lib.modl_somf_step(self.plan, C.byref(st), C.byref(bt), ptr(self.delta), stream_ptr(self.device)),
+              'modl_somf_step')
+
     def phase2(self, delta):
         bt, keep = self._pending
         st = self._state()
@@ -543,6 +550,9 @@ class DictFact(CodingMixin, BaseEstimator):
                                 -self.sample_learning_rate).astype(be.dtype)
         w = batch_weight(self.n_iter_, b_global, self.learning_rate, 0)
         order = self.random_state.permutation(self.n_components)       # dict_fact.py:672
+        if world == 1 and hasattr(be, 'step') and not getattr(self, '_two_phase', False):
+            be.step(Xh, batch, sample_indices, subset, order, w_sample, w, self.reduction, b_global)
+            return
         delta = be.phase1(Xh, batch, sample_indices, subset, order, w_sample, w, self.reduction, b_global)
         if world > 1:
             self._all_reduce(delta)

@@ -197,6 +197,24 @@ def test_full_size_step_properties(DictFact):
     assert_array_equal(runs[0][1], runs[1][1])
 
 
+@pytest.mark.parametrize('agg', [('masked', 'masked'), ('full', 'full'), ('average', 'average')])
+def test_two_phase_equals_fused_step(DictFact, agg):
+    """modl_somf_code_and_partials + modl_somf_apply_and_update_dict (the multi-GPU split, increments through
+    `delta`) and modl_somf_step (statistics applied in the GEMM epilogues) give the same bits."""
+    rng = np.random.RandomState(3)
+    X = rng.randn(300, 96).astype(np.float32)
+    out = []
+    for two_phase in (False, True):
+        est = DictFact(n_components=32, batch_size=40, reduction=3, code_alpha=0.5, learning_rate=0.9, random_state=0,
+                       G_agg=agg[0], Dx_agg=agg[1])
+        est._two_phase = two_phase
+        est.prepare(n_samples=300, X=X)
+        est.partial_fit(X[:200], np.arange(200))
+        out.append((est.components_, est.code_.copy(), est.C_, est.B_))
+    for a, b in zip(out[0], out[1]):
+        assert_array_equal(a, b)
+
+
 # ---- the reference's own functional tests (modl/decomposition/tests/test_dict_fact.py) ----------
 solver_dict = {'masked': {'Dx_agg': 'masked', 'G_agg': 'masked'}, 'gram': {'Dx_agg': 'masked', 'G_agg': 'full'},
                'average': {'Dx_agg': 'masked', 'G_agg': 'masked'}, 'full': {'Dx_agg': 'full', 'G_agg': 'full'}}
