@@ -9,14 +9,16 @@
 // the gap evaluation differs (the reference uses BLAS dot/asum there).
 //
 // gfx950 mapping: the k-vectors H = Q w, w, q and 1 / (diag(Q) + beta) live in
-// registers, coefficient e in register e / 64 of lane e % 64 (k <= 64 * KPL), so
-// every row of the Gram matrix is read from L2 as KPL coalesced 256-byte loads.
-// Two kinds of sweep, chosen per sweep from the number of active coordinates:
-//   * dense: chunks of 4 consecutive coordinates; their Gauss-Seidel recurrence is
-//     run on wave-uniform scalars (v_readlane) while the k-wide H update (two fused
-//     multiply-adds per register and coordinate) is off the dependency chain; the
-//     rows of the next chunk are prefetched into the other half of a ping-pong
-//     register buffer;
+// registers, KPL consecutive coefficients per lane (coefficient e in register
+// e % KPL of lane e / KPL, k <= 64 * KPL), so a row of the Gram matrix is ONE
+// 16-byte load per lane at k = 256 (f32).  Two kinds of sweep, chosen per sweep
+// from the number of active coordinates:
+//   * dense: the update formula of a coordinate is evaluated by EVERY lane on its
+//     own coefficient (the values of the other lanes are discarded), so no scalar
+//     has to be fetched before the arithmetic; the only cross-lane traffic is the
+//     pair (w_new, w_old) of the owning lane, read with v_readlane after it, then
+//     the k-wide update H <- fma(w_new, Q_ii, fma(-w_old, Q_ii, H)) (v_pk_fma_f32).
+//     Rows are prefetched through a ring of 8 row buffers;
 //   * sparse (active set): a coordinate with w_ii == 0 whose update stays 0
 //     (|q_ii - H_ii| <= alpha) is a no-op of the reference's sweep (nothing is
 //     written, d_w_max / w_max are unaffected), and that test is evaluated for ALL
@@ -29,22 +31,40 @@
 // gap test are wave shuffles.  b independent problems -> b wavefronts, 4 per
 // workgroup.
 #include "kernels.hpp"
+#include <utility>
 
 namespace modl {
 
-// Row loader: coefficient c * 64 + lane in r[c].  No branches: lanes past the end read a clamped
-// address and select zero, so all loads of a chunk stay in flight together.  FULL: k == 64 * KPL.
-template <typename T, int KPL, bool FULL>
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>)
+template <int... Js, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Js...>, F &&f) {
+    (f(std::integral_constant<int, Js>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
+}
+
+// Row loader: coefficients lane * KPL .. lane * KPL + KPL - 1 of row ii in r[].  VEC (k == 64 * KPL, 16-byte
+// aligned rows): 16-byte loads; otherwise element loads with a clamped address and a select — no branches
+// either way, so all requests of a group stay in flight together.
+template <typename T, int KPL, bool VEC>
 __device__ __forceinline__ void load_row(const T *__restrict__ Q, int ii, int k, int lane, T (&r)[KPL]) {
     const unsigned int base = (unsigned int)ii * (unsigned int)k;      // k <= 1024: 32-bit element offsets
-    if constexpr (FULL) {
-        const T *rp = (Q + lane) + base;           // one 64-bit add per row, the registers differ by an immediate
+    if constexpr (VEC) {
+        constexpr int V = (KPL * sizeof(T) >= 16) ? (int)(16 / sizeof(T)) : KPL;   // elements per load
+        typedef T vec_t __attribute__((ext_vector_type(V)));
+        const vec_t *rp = reinterpret_cast<const vec_t *>((Q + lane * KPL) + base);
 #pragma unroll
-        for (int c = 0; c < KPL; ++c) r[c] = rp[c * 64];
+        for (int v = 0; v < KPL / V; ++v) {
+            const vec_t x = rp[v];
+#pragma unroll
+            for (int c = 0; c < V; ++c) r[v * V + c] = x[c];
+        }
     } else {
 #pragma unroll
         for (int c = 0; c < KPL; ++c) {
-            const int e = c * 64 + lane;
+            const int e = lane * KPL + c;
             const T v = Q[base + (unsigned int)(e < k ? e : k - 1)];
             r[c] = e < k ? v : (T)0;
         }
@@ -54,7 +74,8 @@ __device__ __forceinline__ void load_row(const T *__restrict__ Q, int ii, int k,
 __device__ __forceinline__ float clamp3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 __device__ __forceinline__ double clamp3(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 
-// One coordinate on wave-uniform scalars (dict_fact_fast.pyx:354-386); returns the new coefficient.
+// One coordinate (dict_fact_fast.pyx:354-386), elementwise or on wave-uniform scalars; returns the new
+// coefficient.
 template <typename T, bool POSITIVE>
 __device__ __forceinline__ T cd_coordinate(T h, T wo, T qq, T ri, T Qcc, T alpha) {
     const T Hii = fma(-wo, Qcc, h);                            // H[ii] after "H -= w_ii * Q[ii]" (:361-365)
@@ -67,55 +88,57 @@ __device__ __forceinline__ T cd_coordinate(T h, T wo, T qq, T ri, T Qcc, T alpha
 
 constexpr int kCdRing = 8;       // Gram rows in flight in the dense sweep (an L2 hit costs several coordinates)
 
-// One coordinate ii = R * 64 + L of a dense sweep.  The update formula is evaluated by EVERY lane on its
-// own coefficient (the values of the other lanes are discarded): no scalar has to be fetched before the
-// arithmetic, and the only cross-lane traffic is the pair (w_new, w_old) of lane L, read with v_readlane
-// after it — 2 wave-wide reads per coordinate.  A zero diagonal skips the coordinate (:357): its working
-// coefficient is 0 and so is its step (inv = 0), both multipliers vanish and H is unchanged bit for bit.
-template <typename T, int KPL, int R, bool POSITIVE>
-__device__ __forceinline__ void cd_coord(int L, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
-                                         const T (&inv)[KPL], const T (&row)[KPL], T alpha) {
-    const T wv = w[R];
-    const T xv = cd_coordinate<T, POSITIVE>(H[R], wv, q[R], inv[R], row[R], alpha);
+// One coordinate ii = L * KPL + C of a dense sweep.  A zero diagonal skips the coordinate (:357): its
+// working coefficient is 0 and so is its step (inv = 0), both multipliers vanish and H is unchanged bit
+// for bit.
+template <typename T, int KPL, int C, bool POSITIVE>
+__device__ __forceinline__ void cd_coord(int L, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL], const T (&inv)[KPL],
+                                         const T (&row)[KPL], T alpha) {
+    const T wv = w[C];
+    const T xv = cd_coordinate<T, POSITIVE>(H[C], wv, q[C], inv[C], row[C], alpha);
     const T dn = bcast_lane(xv, L), dold = bcast_lane(wv, L);
 #pragma unroll
     for (int r = 0; r < KPL; ++r) H[r] = fma(dn, row[r], fma(-dold, row[r], H[r]));   // :361-365, :375-378
-    w[R] = __builtin_amdgcn_inverse_ballot_w64(1ull << L) ? xv : wv;   // lane L only (scalar mask)
+    w[C] = __builtin_amdgcn_inverse_ballot_w64(1ull << L) ? xv : wv;   // lane L only (scalar mask)
 }
 
-// coordinates R * 64 .. R * 64 + 63 with a ring of kCdRing row buffers: row ii + kCdRing is requested as
-// soon as row ii has been consumed
-template <typename T, int KPL, int R, bool FULL, bool POSITIVE>
-__device__ __forceinline__ void cd_dense_register(int lane, int k, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
-                                                  const T (&inv)[KPL], T (&ring)[kCdRing][KPL],
-                                                  const T *__restrict__ Q, T alpha) {
-    int cnt = k - R * 64;
-    cnt = cnt > 64 ? 64 : cnt;
-    if (cnt <= 0) return;
-    const int groups = cnt / kCdRing, tail = cnt % kCdRing;
-    // whole groups: straight-line code, every load unconditional (row index clamped) so that no buffer is
-    // merged across a branch
-    for (int g = 0; g < groups; ++g) {
+// A dense sweep: groups of U = max(8, KPL) coordinates, straight-line code with static register indices;
+// row ii + 8 is requested as soon as row ii has been consumed (ring of 8 buffers).  The scheduler barriers
+// keep every request where it is: otherwise the scheduler gathers the group's loads at the end of the loop
+// body and the wait for a row sits right behind its own request.
+template <typename T, int KPL, bool VEC, bool POSITIVE>
+__device__ __forceinline__ void cd_dense_sweep(int lane, int k, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
+                                               const T (&inv)[KPL], const T *__restrict__ Q, T alpha) {
+    constexpr int U = KPL > kCdRing ? KPL : kCdRing;
+    T ring[kCdRing][KPL];
 #pragma unroll
-        for (int j = 0; j < kCdRing; ++j) {
-            const int ii = R * 64 + g * kCdRing + j;
-            cd_coord<T, KPL, R, POSITIVE>(g * kCdRing + j, w, H, q, inv, ring[j], alpha);
+    for (int j = 0; j < kCdRing; ++j) load_row<T, KPL, VEC>(Q, j < k ? j : k - 1, k, lane, ring[j]);
+    const int groups = k / U;
+    for (int g = 0; g < groups; ++g) {
+        static_for<U>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const int ii = g * U + j;
+            cd_coord<T, KPL, j % KPL, POSITIVE>(g * (U / KPL) + j / KPL, w, H, q, inv, ring[j % kCdRing], alpha);
             __builtin_amdgcn_sched_barrier(0);
             const int nx = (ii + kCdRing < k) ? ii + kCdRing : k - 1;
-            load_row<T, KPL, FULL>(Q, nx, k, lane, ring[j]);
-            // keep the request where it is: the scheduler otherwise gathers the group's loads at the end of
-            // the loop body, and the wait for row ii then sits right behind its own request
+            load_row<T, KPL, VEC>(Q, nx, k, lane, ring[j % kCdRing]);
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
     }
-    if constexpr (!FULL) {                         // ragged end of the last register: its rows are in the ring
-#pragma unroll
-        for (int j = 0; j < kCdRing - 1; ++j)
-            if (j < tail) cd_coord<T, KPL, R, POSITIVE>(groups * kCdRing + j, w, H, q, inv, ring[j], alpha);
+    if constexpr (!VEC) {                          // ragged end: fewer than U coordinates, rows (clamped) are in the ring
+        const int done = groups * U, tail = k - done;
+        static_for<U - 1>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            if (j < tail) {
+                cd_coord<T, KPL, j % KPL, POSITIVE>((done + j) / KPL, w, H, q, inv, ring[j % kCdRing], alpha);
+                if (j + kCdRing < tail) load_row<T, KPL, VEC>(Q, done + j + kCdRing, k, lane, ring[j % kCdRing]);
+            }
+        });
     }
 }
 
-// Active coordinates as one 64-bit mask per register: live and (w != 0 or the update leaves zero).
+// Active coordinates as one 64-bit mask per register (bit L of m[c] = coordinate L * KPL + c): live and
+// (w != 0 or the update leaves zero).
 template <typename T, int KPL, bool POSITIVE>
 __device__ __forceinline__ void cd_active(const T (&w)[KPL], const T (&H)[KPL], const T (&q)[KPL], const T (&inv)[KPL],
                                           T alpha, unsigned long long (&m)[KPL]) {
@@ -133,43 +156,44 @@ template <int KPL>
 __device__ __forceinline__ int cd_next(const unsigned long long (&m)[KPL], int pos) {
     int res = 64 * KPL;
 #pragma unroll
-    for (int r = KPL - 1; r >= 0; --r) {
-        const int lo = pos - 64 * r;
-        const unsigned long long mm = (lo <= 0) ? m[r] : (lo >= 64 ? 0ull : (m[r] & (~0ull << lo)));
-        if (mm) res = 64 * r + __builtin_ctzll(mm);
+    for (int c = 0; c < KPL; ++c) {
+        const int lo = (pos - c + KPL - 1) / KPL;             // first lane whose coordinate lane * KPL + c is >= pos
+        const unsigned long long mm = (lo <= 0) ? m[c] : (lo >= 64 ? 0ull : (m[c] & (~0ull << lo)));
+        const int cand = mm ? __builtin_ctzll(mm) * KPL + c : 64 * KPL;
+        res = cand < res ? cand : res;
     }
     return res;
 }
 
-// one active coordinate ii = R * 64 + L with its Gram row in `row`
-template <typename T, int KPL, int R, bool POSITIVE>
+// one active coordinate ii = L * KPL + C with its Gram row in `row`
+template <typename T, int KPL, int C, bool POSITIVE>
 __device__ __forceinline__ void cd_step(int L, int lane, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
                                         const T (&inv)[KPL], const T (&row)[KPL], T alpha) {
-    const T h = bcast_lane(H[R], L), wo = bcast_lane(w[R], L), qq = bcast_lane(q[R], L), ri = bcast_lane(inv[R], L);
-    const T Qcc = bcast_lane(row[R], L);
+    const T h = bcast_lane(H[C], L), wo = bcast_lane(w[C], L), qq = bcast_lane(q[C], L), ri = bcast_lane(inv[C], L);
+    const T Qcc = bcast_lane(row[C], L);
     const T x = cd_coordinate<T, POSITIVE>(h, wo, qq, ri, Qcc, alpha);
 #pragma unroll
     for (int r = 0; r < KPL; ++r) H[r] = fma(x, row[r], fma(-wo, row[r], H[r]));
-    if (lane == L) w[R] = x;
+    if (lane == L) w[C] = x;
 }
 
-template <typename T, int KPL, bool FULL, bool POSITIVE>
+template <typename T, int KPL, bool VEC, bool POSITIVE>
 __device__ __forceinline__ void cd_sparse_sweep(int lane, int k, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
                                                 const T (&inv)[KPL], unsigned long long (&m)[KPL],
                                                 const T *__restrict__ Q, T alpha) {
     T rowA[KPL], rowB[KPL];
     int next = cd_next<KPL>(m, 0);
     if (next >= k) return;
-    load_row<T, KPL, FULL>(Q, next, k, lane, rowA);
+    load_row<T, KPL, VEC>(Q, next, k, lane, rowA);
     while (true) {
         const int ii = next;
         const int pred = cd_next<KPL>(m, ii + 1);             // next active coordinate as of now
-        if (pred < k) load_row<T, KPL, FULL>(Q, pred, k, lane, rowB);
-        const int L = ii & 63;
-        switch (ii >> 6) {
-#define MODL_CD_CASE(R)                                                                              \
-    case R:                                                                                          \
-        if constexpr (R < KPL) cd_step<T, KPL, R, POSITIVE>(L, lane, w, H, q, inv, rowA, alpha); \
+        if (pred < k) load_row<T, KPL, VEC>(Q, pred, k, lane, rowB);
+        const int L = ii / KPL;
+        switch (ii % KPL) {
+#define MODL_CD_CASE(C)                                                                          \
+    case C:                                                                                      \
+        if constexpr (C < KPL) cd_step<T, KPL, C, POSITIVE>(L, lane, w, H, q, inv, rowA, alpha); \
         break;
             MODL_CD_CASE(0) MODL_CD_CASE(1) MODL_CD_CASE(2) MODL_CD_CASE(3) MODL_CD_CASE(4) MODL_CD_CASE(5)
             MODL_CD_CASE(6) MODL_CD_CASE(7) MODL_CD_CASE(8) MODL_CD_CASE(9) MODL_CD_CASE(10) MODL_CD_CASE(11)
@@ -186,12 +210,12 @@ __device__ __forceinline__ void cd_sparse_sweep(int lane, int k, T (&w)[KPL], T 
         } else {
             if (nn >= k) return;
             next = nn;                                        // activated by this step: synchronous load
-            load_row<T, KPL, FULL>(Q, next, k, lane, rowA);
+            load_row<T, KPL, VEC>(Q, next, k, lane, rowA);
         }
     }
 }
 
-template <typename T, int KPL, bool FULL, bool POSITIVE>
+template <typename T, int KPL, bool VEC, bool POSITIVE>
 __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
     const int lane = threadIdx.x & 63;
     const int smp = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -203,13 +227,13 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
     const T *qptr = a.Dx + (int64_t)smp * k;
     const T alpha = a.alpha, beta = a.beta;
     constexpr bool positive = POSITIVE;
+    const int e0 = lane * KPL;
 
     T w[KPL], H[KPL], q[KPL], inv[KPL];
 #pragma unroll
     for (int c = 0; c < KPL; ++c) {
-        const int e0 = c * 64 + lane;
-        const bool in = e0 < k;
-        const int e = in ? e0 : 0;
+        const bool in = e0 + c < k;
+        const int e = in ? e0 + c : 0;
         const T wv = wptr[e], qv = qptr[e], dv = Q[(int64_t)e * k + e];
         w[c] = in ? wv : (T)0;
         q[c] = in ? qv : (T)0;
@@ -225,21 +249,29 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
         const T *hp = a.H0 + (int64_t)smp * k;
 #pragma unroll
         for (int c = 0; c < KPL; ++c) {
-            const int e0 = c * 64 + lane;
-            const T hv = hp[e0 < k ? e0 : 0];
-            H[c] = (e0 < k) ? hv : (T)0;
+            const T hv = hp[e0 + c < k ? e0 + c : 0];
+            H[c] = (e0 + c < k) ? hv : (T)0;
         }
     } else {
-        // H = Q w as a combination of rows (Q is symmetric, as the solver itself assumes)
+        // H = Q w as a combination of rows (Q is symmetric, as the solver itself assumes), rows prefetched
+        // through the same ring as the sweeps: cheaper than a separate product launch for one minibatch
+        constexpr int U = KPL > kCdRing ? KPL : kCdRing;
+        T ring[kCdRing][KPL];
 #pragma unroll
-        for (int c = 0; c < KPL; ++c) {
-            for (int L = 0; L < 64 && c * 64 + L < k; ++L) {
-                const T wj = bcast_lane(w[c], L);
-                T r[KPL];
-                load_row<T, KPL, FULL>(Q, c * 64 + L, k, lane, r);
+        for (int j = 0; j < kCdRing; ++j) load_row<T, KPL, VEC>(Q, j < k ? j : k - 1, k, lane, ring[j]);
+        for (int j0 = 0; j0 < k; j0 += U) {
+            static_for<U>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const int jj = j0 + j;
+                T wj = bcast_lane(w[j % KPL], (j0 / KPL + j / KPL) & 63);   // coefficient jj (zero beyond k)
+                if (!VEC && jj >= k) wj = 0;
 #pragma unroll
-                for (int c2 = 0; c2 < KPL; ++c2) H[c2] = fma(wj, r[c2], H[c2]);
-            }
+                for (int c2 = 0; c2 < KPL; ++c2) H[c2] = fma(wj, ring[j % kCdRing][c2], H[c2]);
+                __builtin_amdgcn_sched_barrier(0);
+                const int nx = (jj + kCdRing < k) ? jj + kCdRing : k - 1;
+                load_row<T, KPL, VEC>(Q, nx, k, lane, ring[j % kCdRing]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
     }
 
@@ -263,20 +295,8 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
         T w0[KPL];                                 // a coefficient changes once per sweep: d_w_ii = |w - w0| (:380-384)
 #pragma unroll
         for (int r = 0; r < KPL; ++r) w0[r] = w[r];
-        if (6 * n_act > k) {                       // a sparse step costs several dense coordinates
-            T ring[kCdRing][KPL];
-#pragma unroll
-            for (int j = 0; j < kCdRing; ++j)
-                load_row<T, KPL, FULL>(Q, j < k ? j : k - 1, k, lane, ring[j]);
-#define MODL_CD_REG(R) \
-    if constexpr (R < KPL) cd_dense_register<T, KPL, R, FULL, POSITIVE>(lane, k, w, H, q, inv, ring, Q, alpha);
-            MODL_CD_REG(0) MODL_CD_REG(1) MODL_CD_REG(2) MODL_CD_REG(3) MODL_CD_REG(4) MODL_CD_REG(5) MODL_CD_REG(6)
-            MODL_CD_REG(7) MODL_CD_REG(8) MODL_CD_REG(9) MODL_CD_REG(10) MODL_CD_REG(11) MODL_CD_REG(12)
-            MODL_CD_REG(13) MODL_CD_REG(14) MODL_CD_REG(15)
-#undef MODL_CD_REG
-        } else {
-            cd_sparse_sweep<T, KPL, FULL, POSITIVE>(lane, k, w, H, q, inv, m, Q, alpha);
-        }
+        if (6 * n_act > k) cd_dense_sweep<T, KPL, VEC, POSITIVE>(lane, k, w, H, q, inv, Q, alpha);   // a sparse step costs several dense coordinates
+        else cd_sparse_sweep<T, KPL, VEC, POSITIVE>(lane, k, w, H, q, inv, m, Q, alpha);
         T dmx = 0, wmx = 0;                        // skipped coordinates do not count (:357): their w is 0 here
 #pragma unroll
         for (int r = 0; r < KPL; ++r) {
@@ -295,7 +315,7 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
                 s_wH += wt * H[c];
                 s_ww += wt * wt;
                 s_l1 += fabs(wt);
-                if (c * 64 + lane < k) {
+                if (e0 + c < k) {
                     const T x = (q[c] - H[c]) - beta * wt;                            // :397
                     const T mx = positive ? x : fabs(x);
                     xmax = mx > xmax ? mx : xmax;
@@ -321,20 +341,23 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
             if (gap < tol_abs) { ++n_iter; break; }                                   // :425
         }
     }
+    T *w2 = a.code2 ? a.code2 + (a.idx2 ? a.idx2[smp] : (int64_t)smp) * k : nullptr;
 #pragma unroll
     for (int c = 0; c < KPL; ++c)
-        if (c * 64 + lane < k) {
-            wptr[c * 64 + lane] = w[c] + wfix[c];
-            if (a.code2) a.code2[(a.idx2 ? a.idx2[smp] : (int64_t)smp) * k + c * 64 + lane] = w[c] + wfix[c];
+        if (e0 + c < k) {
+            wptr[e0 + c] = w[c] + wfix[c];
+            if (w2) w2[e0 + c] = w[c] + wfix[c];
         }
     if (a.sweeps && lane == 0) a.sweeps[smp] = n_iter;
 }
 
 template <typename T, int KPL>
 static void launch_cd_kpl(hipStream_t stream, const CdArgs<T> &a, dim3 grid, dim3 block) {
-    const bool full = a.k == 64 * KPL;
-#define MODL_CD_LAUNCH(FULL, POS) hipLaunchKernelGGL((cd_kernel<T, KPL, FULL, POS>), grid, block, 0, stream, a)
-    if (full) {
+    constexpr size_t kRowAlign = (KPL * sizeof(T) >= 16) ? 16 : KPL * sizeof(T);
+    const bool vec = (a.k == 64 * KPL) && (reinterpret_cast<uintptr_t>(a.G) % kRowAlign == 0) &&
+                     ((a.g_stride * sizeof(T)) % kRowAlign == 0);
+#define MODL_CD_LAUNCH(VEC, POS) hipLaunchKernelGGL((cd_kernel<T, KPL, VEC, POS>), grid, block, 0, stream, a)
+    if (vec) {
         if (a.positive) MODL_CD_LAUNCH(true, true);
         else MODL_CD_LAUNCH(true, false);
     } else {

@@ -346,23 +346,10 @@ int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride
         }
         return MODL_OK;
     }
+    // H0 = Q w is formed inside the solver (rows stream through its prefetch ring: ~6 us at k = 256, less
+    // than the launch of a separate 256 x 256 x 256 product that only occupies 16 workgroups)
     const T *H0 = nullptr;
-    if (g_stride == 0) {                                             // H0 = code[idx] G on the matrix cores
-        EpiStore<T> epi{H0buf, k, (T)1};
-        SplitWs none;
-        if (!d_idx) {
-            DenseOperand A, B;
-            A.ptr = code; A.si = k; A.sk = 1;
-            B.ptr = G; B.si = 1; B.sk = k;                           // B(n = j, kk = m) = G[m][j] (G symmetric)
-            MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, A, B, b, k, k, epi, none, nl, 512, 1)));
-        } else {
-            Operand A, B;
-            A.ptr = code; A.si = k; A.sk = 1; A.gi = gather64(d_idx);
-            B.ptr = G; B.si = 1; B.sk = k;
-            MODL_TRY((launch_gemm<T, EpiStore<T>>(st, A, B, b, k, k, epi, none, nl, 512, 1)));
-        }
-        H0 = H0buf;
-    }
+    (void)H0buf;
     CdArgs<T> a;
     a.G = G; a.g_stride = g_stride; a.g_idx = g_idx; a.Dx = Dx; a.xnorm2 = xnorm2; a.H0 = H0; a.code = code;
     a.idx = d_idx;
