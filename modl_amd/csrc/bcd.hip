@@ -387,40 +387,55 @@ __device__ __forceinline__ void rows_pair(double z, double &even, double &odd) {
 // S[j] = alpha_j T[j]; with the Gram matrix M of the a_m and Y[j] = M S[j]:
 //     T[j]     = e_j    - sum_{i<j} c_ji S[i]          (lanes  0-31, lane x owns component x)
 //     M T[j]   = M[:,j] - sum_{i<j} c_ji Y[i]          (lanes 32-63: the SAME instruction stream)
-//     |u_j|^2  = T[j] . (M T[j])                       (half swap + DPP row sum)
-// The c_ji are wave-uniform LDS broadcast reads with static addresses (prefetched by the scheduler), so
-// the only cross-lane traffic on the serial chain is the half swap, the row sum and two v_readlane.
-// The j loop is fully unrolled: every register index is static.  Output per block: CA[j][m] = S[j][m]
-// (the apply step forms D_j = sum_m S[j][m] a_m feature by feature) and the new norm budgets.
-// budget_x: the norm budget of atom x of the block before the update (0 beyond nb); jj_x: its atom index
+//     |u_j|^2  = T[j] . (M T[j])
+// The wave issues one instruction every ~5 cycles and nothing else runs on its critical path, so the
+// recursion is bound by its INSTRUCTION COUNT (measured: a version with a shorter dependency chain but more
+// instructions was slower).  Hence:
+//   * the c_ji are wave-uniform LDS broadcast reads with static addresses (two per ds_read_b128);
+//   * the 32-lane sum of T[j] . (M T[j]) is two f64 matrix-core instructions instead of five DPP / swap
+//     stages: v_mfma_f64_16x16x4 with B = 1/2 sums lanes {i, i+16, i+32, i+48}, three adds fold the four
+//     accumulator registers, a second MFMA with B = 1 sums the four lane groups — every lane ends with the
+//     total (the products are replicated in both halves, which the 1/2 accounts for);
+//   * alpha = min(sqrt(radius) / sqrt(|u|^2), [radius > 0]) needs no compare or select: v_rsq_f64 + one
+//     Newton step (rel. error ~1e-14), v_min_f64 (a NaN from |u|^2 <= 0 yields the other operand);
+//     radius = 0 gives alpha = 0 (enet.pyx:57), inside the ball alpha = 1 (:65);
+//   * per-step uniforms (sqrt(radius_j), [radius_j > 0]) come from LDS as one broadcast read, the results
+//     (alpha_j, |u_j|^2) leave through LDS and the new budgets are formed after the loop, one lane per atom.
+// The j loop is fully unrolled (static register indices, no branch) and software-pipelined by hand: the
+// terms i < j of step j + 1 are accumulated under the serial tail of step j; between alpha_j and the next
+// tail sits ONE fma, z_{j+1} = partial_{j+1} - alpha_j (c_{j+1,j} z_j).  Output: CA[j][m] = S[j][m] (the apply
+// step forms D_j = sum_m S[j][m] a_m) and the new norm budgets.
+// budget_x: the norm budget of atom x of the block before the update (0 beyond nb); jj_x: its atom index;
+// scr: >= 4 * NB doubles of LDS scratch private to the wave.
 template <typename T>
 __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const double *D2, const double *Cs,
-                                             int jj_x, double budget_x, int nb, T *norm_out,
-                                             double *CAout, int ca_stride, unsigned long long *stamps = nullptr) {
+                                             int jj_x, double budget_x, int nb, T *norm_out, double *CAout,
+                                             int ca_stride, double *scr, unsigned long long *stamps = nullptr) {
+    typedef double d4v __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, x = lane & 31;
     const bool lower = lane < 32;
     double Z[kNB];
     const double rad_x = budget_x + D2[x];                                       // budget + old squared norm
-    const double srad_x = (rad_x > 0.0) ? sqrt(rad_x) : 0.0;
-    double newnorm_x = 0.0;
+    const bool live_x = (rad_x > 0.0) && (x < nb);
+    if (lower) {
+        scr[2 * x] = live_x ? sqrt(rad_x) : 0.0;                                 // sqrt(radius_j) ...
+        scr[2 * x + 1] = live_x ? 1.0 : 0.0;                                     // ... and the cap of alpha_j
+    }
     const double hmask = lower ? 0.0 : 1.0;
-    if (stamps && lane == 0) stamps[8] = clock64() + (unsigned long long)(srad_x * 0);
-    // One straight-line basic block (no branch inside the unrolled loop: columns >= nb get alpha = 0),
-    // software-pipelined by hand: while the serial tail of step j runs (half swap, row sums, 1/sqrt,
-    // selects), the terms i < j of step j + 1 are accumulated; between alpha_j and the start of step
-    // j + 1's tail sits ONE fma:  z_{j+1} = partial_{j+1} - alpha_j (c_{j+1,j} z_j).
+    if (stamps && lane == 0) stamps[8] = clock64() + (unsigned long long)(rad_x * 0);
     double part = __builtin_fma(hmask, M[x][0], (lower && x == 0) ? 1.0 : 0.0);   // e_0 | M[:,0]
     double al_prev = 0.0, q_prev = 0.0, z_prev = 0.0;
+    const d4v zero4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int j = 0; j < kNB; ++j) {
         if (stamps && lane == 0 && (j % 8) == 0 && j > 0) stamps[8 + j / 8] = clock64();
         const double z = __builtin_fma(-al_prev, q_prev, part);
         double t, w;
         halves(z, t, w);
-        const double prow = row16_sum(t * w);              // both halves hold the same products
-        double r0, r1;
-        rows_pair(prow, r0, r1);
-        const double nrm = r0 + r1;                        // every lane: |u_j|^2
+        const d4v d = __builtin_amdgcn_mfma_f64_16x16x4f64(t * w, 0.5, zero4, 0, 0, 0);
+        const double fold = (d[0] + d[1]) + (d[2] + d[3]);
+        const d4v e = __builtin_amdgcn_mfma_f64_16x16x4f64(fold, 1.0, zero4, 0, 0, 0);
+        const double nrm = e[0];                           // every lane: |u_j|^2
         // independent of this step's tail: finish S[j-1], start step j + 1
         if (j > 0) Z[j - 1] = al_prev * z_prev;
         double q = 0.0;
@@ -437,15 +452,12 @@ __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const d
             part = (p0 + p1) + (p2 + p3);
             q = Cs[(j + 1) * kNB + j] * z;
         }
-        const double radius = bcast_lane(rad_x, j), sr = bcast_lane(srad_x, j);
-        // alpha = 0 (radius == 0, enet.pyx:57), 1 (inside the ball, :65) or sqrt(radius / |u|^2):
-        // selects only (no branch); 1/sqrt from a single-precision seed and one Newton step
-        // (|rel err| ~ 1e-14).  nrm == 0 gives a NaN that the select discards.
-        const bool scaled = (nrm > radius) && (radius > 0.0) && (j < nb);
-        double y = (double)__builtin_amdgcn_rsqf((float)nrm);
-        y = y * (1.5 - 0.5 * nrm * y * y);
-        const double al = pick(scaled, sr * y, (radius > 0.0 && j < nb) ? 1.0 : 0.0);
-        if (x == j) newnorm_x = radius - al * al * nrm;
+        const double sr = scr[2 * j], cap = scr[2 * j + 1];
+        double y = __builtin_amdgcn_rsq(nrm);                      // v_rsq_f64
+        y = y * (1.5 - (0.5 * nrm) * y * y);
+        const double al = __builtin_fmin(sr * y, cap);
+        scr[2 * kNB + 2 * j] = al;
+        scr[2 * kNB + 2 * j + 1] = nrm;
         al_prev = al;
         q_prev = q;
         z_prev = z;
@@ -454,7 +466,10 @@ __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const d
     if (lower) {
 #pragma unroll
         for (int j = 0; j < kNB; ++j) CAout[j * ca_stride + x] = Z[j];
-        if (norm_out && x < nb) norm_out[jj_x] = (T)newnorm_x;
+        if (norm_out && x < nb) {
+            const double al = scr[2 * kNB + 2 * x], nrm = scr[2 * kNB + 2 * x + 1];
+            norm_out[jj_x] = (T)(rad_x - al * al * nrm);
+        }
     }
 }
 
@@ -465,6 +480,7 @@ __global__ __launch_bounds__(256) void bcd_resolve_kernel(const double *partial,
     __shared__ double M[kNB][kNB + 1];
     __shared__ double D2[kNB];
     __shared__ __attribute__((aligned(16))) double Cs[kNB * kNB];
+    __shared__ __attribute__((aligned(16))) double scr[4 * kNB];
     stage_coef(coef_all, k, j0, Cs);
     reduce_partials(partial, nslab, M, D2);
     __syncthreads();
@@ -472,7 +488,7 @@ __global__ __launch_bounds__(256) void bcd_resolve_kernel(const double *partial,
         const int x = threadIdx.x & 31;
         const int jj_x = (x < nb) ? order[j0 + x] : 0;
         const double budget_x = (x < nb) ? (double)comp_norm[jj_x] : 0.0;
-        resolve_wave<T>(M, D2, Cs, jj_x, budget_x, nb, comp_norm, CAout, kNB);
+        resolve_wave<T>(M, D2, Cs, jj_x, budget_x, nb, comp_norm, CAout, kNB, scr);
     }
 }
 
@@ -584,7 +600,6 @@ struct BcdBlockArgs {
 template <int RT, int GPW>   // 32 * RT features per workgroup; GPW contraction groups (8 atoms) per worker wave
 __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
     constexpr int RB = 32 * RT;
-    constexpr int KPAD = GPW * 32;                   // 4 waves x GPW groups x 8 atoms  (>= k)
     constexpr int EPT = RB / 8;                      // epilogue elements per thread
     constexpr int DLS = kNB + 4;                     // row stride of the Delta tile (16-byte aligned rows)
     typedef float f16v __attribute__((ext_vector_type(16)));
@@ -597,8 +612,7 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
     double *Cs = D2s + kNB;                                                    // [NB][NB] recursion coefficients
     double *CAs = Cs + kNB * kNB;                                              // [NB][kCaStride] S of the previous block
     double *d2red = CAs + kNB * kCaStride;                                     // [8][NB]
-    float *CPs = reinterpret_cast<float *>(d2red + 8 * kNB);                   // [KPAD][NB]
-    float *red = CPs + (size_t)KPAD * kNB;                                     // [4][RB][NB + 1]; before (E): a-tile [RB][kApStride]
+    float *red = reinterpret_cast<float *>(d2red + 8 * kNB);                   // [4][RB][NB + 1]; before (E): a-tile [RB][kApStride]
     float *As = red + 4 * RB * (kNB + 1);                                      // [RB][NB + 1]
     float *Dl = As + RB * (kNB + 1) + ((4 - (RB * (kNB + 1)) % 4) % 4);        // [RB][DLS] Delta of the previous block
     int *flag = reinterpret_cast<int *>(Dl + RB * DLS);
@@ -611,99 +625,26 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
     unsigned long long *st = (p.stamps && blockIdx.x == 0 && !fin) ? p.stamps : nullptr;
     if (st && tid == 0) st[0] = clock64();
 
-    // ---------------------------------------------------------------- (A) every global load, issued up front
-    const int col = tid % kNB, rg = (tid / kNB) % 8;             // epilogue: column, row group
-    const bool col_ok = col < p.nb;
-    float cdg = 1.f, eB[EPT], eD[EPT];
-    int fz = 0;
-    constexpr int NQ = KPAD * (kNB / 4) / 256;
-    float4 cv[NQ];
-    const int h = lane >> 5;
-    float4 av[GPW][RT];
-    if (worker && !fin) {
-        cdg = col_ok ? p.cdiag[p.j0 + col] : 1.f;
-        fz = col_ok ? p.frozen[p.j0 + col] : 0;
-#pragma unroll
-        for (int q = 0; q < EPT; ++q) {
-            const int64_t f = f0 + rg + 8 * q;
-            const bool ok = col_ok && f < p.s;
-            const int64_t el = ok ? f * k + p.j0 + col : 0;
-            const float bv = p.Bt[el], dv = p.Dt[el];
-            eB[q] = ok ? bv : 0.f;
-            eD[q] = ok ? dv : 0.f;
-        }
-        if (p.nb == kNB) {                           // coefficient block: rows beyond k are zero
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int e = tid + 256 * q;
-                const int m = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
-                const float4 v = *reinterpret_cast<const float4 *>(p.CP + (int64_t)(m < k ? m : 0) * k + p.j0 + c4);
-                cv[q] = (m < k) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-        // dictionary rows -> MFMA A operands, the wave's whole contraction range in flight at once
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            int64_t f = f0 + t * 32 + (lane & 31);
-            if (f >= p.s) f = p.s - 1;               // clamped: results of padded rows are discarded
-            const float *rowp = p.Dt + f * k;
-#pragma unroll
-            for (int g = 0; g < GPW; ++g) {
-                const int kb = (wid * GPW + g) * 8 + 4 * h;
-                const float4 v = *reinterpret_cast<const float4 *>(rowp + (kb + 3 < k ? kb : 0));
-                av[g][t] = (kb + 3 < k) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    }
-    // operands of the apply step, in the output layout of its matrix-core tiles: worker wave w owns tiles
-    // w * RT .. w * RT + RT - 1 of the (RB / 16) x 2 grid (feature tile ft = t / 2, atom tile jt = t % 2)
-    constexpr int NA = RB * (kNB / 4) / 256;
-    float dold[RT][4];
-    float4 va[NA];
-    if (worker && has_prev) {
-#pragma unroll
-        for (int u = 0; u < RT; ++u) {
-            const int t = wid * RT + u, ft = t >> 1, jt = t & 1;
-            const int cj = jt * 16 + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t f = f0 + ft * 16 + (lane >> 4) + 4 * r;
-                const bool live = f < p.s && cj < p.nb_prev;
-                const float dv = p.Dt[live ? f * k + p.j0_prev + cj : 0];
-                dold[u][r] = live ? dv : 0.f;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NA; ++q) {
-            const int e = tid + 256 * q;
-            const int r = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
-            const int64_t fr = (f0 + r < p.s) ? f0 + r : p.s - 1;
-            va[q] = *reinterpret_cast<const float4 *>(p.a + fr * kNB + c4);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (st && tid == 0) st[13] = clock64();
-    // the resolver's own inputs: atom index and norm budget of column x of the previous block
+    // ---------------------------------------------------------------- (B) Gram of the previous block
+    // First thing in the launch: the recursion is the critical path and only needs these records.
     int res_jj = 0;
     double res_budget = 0.0;
-    if (!worker && has_prev) {
-        const int x = lane & 31;
-        res_jj = (x < p.nb_prev) ? p.order[p.j0_prev + x] : 0;
-        res_budget = (x < p.nb_prev) ? (double)p.norm_in[res_jj] : 0.0;
-    }
-    // ---------------------------------------------------------------- (B) Gram of the previous block
     if (has_prev) {
         if (worker) {
             const double *recs = (ngroups > 1) ? p.grec_in : p.rec_in;
             reduce_records<kPackStride>(recs, (ngroups > 1) ? ngroups : nwg,
                                         SinkLdsPacked{reinterpret_cast<double (*)[kNB + 1]>(Ms), D2s});
         } else {
+            // the resolver's own inputs: recursion coefficients, atom index and norm budget of column x
+            const int x = lane & 31;
+            res_jj = (x < p.nb_prev) ? p.order[p.j0_prev + x] : 0;
             double cf[kNB * kNB / 64];
 #pragma unroll
             for (int q = 0; q < kNB * kNB / 64; ++q) {
                 const int e = lane + 64 * q, i = e / kNB, j = e % kNB;
                 cf[q] = (p.j0_prev + j < k) ? p.coef_all[(int64_t)i * k + p.j0_prev + j] : 0.0;
             }
+            res_budget = (x < p.nb_prev) ? (double)p.norm_in[res_jj] : 0.0;
 #pragma unroll
             for (int q = 0; q < kNB * kNB / 64; ++q) {
                 const int e = lane + 64 * q, i = e / kNB, j = e % kNB;
@@ -711,60 +652,137 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
             }
         }
     }
-    if (st && tid == 0) st[14] = clock64();
-    if (worker && !fin) {
-        if (p.nb == kNB) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int e = tid + 256 * q;
-                const int m = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
-                *reinterpret_cast<float4 *>(CPs + m * kNB + c4) = cv[q];
-            }
-        } else {
-            for (int e = tid; e < KPAD * kNB; e += 256) {
-                const int m = e / kNB, jj = e % kNB;
-                CPs[e] = (m < k && jj < p.nb) ? p.CP[(int64_t)m * k + p.j0 + jj] : 0.f;
-            }
-        }
-    }
-    if (worker && has_prev) {
-#pragma unroll
-        for (int q = 0; q < NA; ++q) {
-            const int e = tid + 256 * q;
-            const int r = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
-            float4 v = va[q];                        // columns >= nb_prev were never written
-            v.x = (c4 + 0 < p.nb_prev) ? v.x : 0.f;
-            v.y = (c4 + 1 < p.nb_prev) ? v.y : 0.f;
-            v.z = (c4 + 2 < p.nb_prev) ? v.z : 0.f;
-            v.w = (c4 + 3 < p.nb_prev) ? v.w : 0.f;
-            *reinterpret_cast<float4 *>(Ap + r * kApStride + c4) = v;
-        }
-    }
     __syncthreads();                                                                  // ---- barrier 1
     if (st && tid == 0) st[1] = clock64();
-    // ---------------------------------------------------------------- (C) resolver | main product
+    // ---------------------------------------------------------------- (C) resolver | loads + main product
+    const int col = tid % kNB, rg = (tid / kNB) % 8;             // epilogue: column, row group
+    const bool col_ok = col < p.nb;
+    float cdg = 1.f, eB[EPT], eD[EPT];
+    int fz = 0;
+    const int h = lane >> 5;
+    constexpr int NA = RB * (kNB / 4) / 256;
+    float dold[RT][4];
+    float bq[4] = {0.f, 0.f, 0.f, 0.f};
     f16v acc[RT];
     if (!worker) {
         if (has_prev)
             resolve_wave<float>(reinterpret_cast<const double (*)[kNB + 1]>(Ms), D2s, Cs, res_jj, res_budget, p.nb_prev,
-                                blockIdx.x == 0 ? p.norm_out : nullptr, CAs, kCaStride, st);
+                                blockIdx.x == 0 ? p.norm_out : nullptr, CAs, kCaStride, d2red, st);
         if (st && lane == 0) st[2] = clock64();
-    } else if (!fin) {
+    } else {
+        // every global load of the workers, requested at once: epilogue operands, the coefficient block as
+        // MFMA B fragments (straight from L2: two 128-byte rows per wave instruction, no LDS staging and
+        // therefore no barrier in the resolver's shadow), the dictionary rows as A fragments, the previous
+        // block's old values and a-tile
+        // The resolver wave shares SIMD 0 with worker wave 0; back-to-back MFMAs of that wave would slow the
+        // recursion down (measured: +5 k cycles), so for k <= 256 the product is split over waves 1-3 only.
+        constexpr int PW0 = (GPW == 8) ? 1 : 0;                      // first wave that takes part in the product
+        constexpr int GW = (GPW == 8) ? 11 : GPW;                    // contraction groups (8 atoms) per product wave
+        const bool pwave = wid >= PW0;
+        float bfr[GW][4];
+        float4 av[GW][RT];
+        float4 va[NA];
+        if (!fin) {
+            cdg = col_ok ? p.cdiag[p.j0 + col] : 1.f;
+            fz = col_ok ? p.frozen[p.j0 + col] : 0;
 #pragma unroll
-        for (int t = 0; t < RT; ++t)
+            for (int q = 0; q < EPT; ++q) {
+                const int64_t f = f0 + rg + 8 * q;
+                const bool ok = col_ok && f < p.s;
+                const int64_t el = ok ? f * k + p.j0 + col : 0;
+                const float bv = p.Bt[el], dv = p.Dt[el];
+                eB[q] = ok ? bv : 0.f;
+                eD[q] = ok ? dv : 0.f;
+            }
+            const bool cok = (lane & 31) < p.nb;
+            const float *cpc = p.CP + p.j0 + (cok ? (lane & 31) : 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            for (int g = 0; g < GW; ++g) {
+                const int kb = ((wid - PW0) * GW + g) * 8 + 4 * h;  // this lane's 4 consecutive atoms
 #pragma unroll
-        for (int g = 0; g < GPW; ++g) {
-            const int kb = (wid * GPW + g) * 8 + 4 * h;  // this lane's 4 consecutive atoms
-            const float *bp = CPs + (size_t)kb * kNB + (lane & 31);
-            const float b0 = bp[0], b1 = bp[kNB], b2 = bp[2 * kNB], b3 = bp[3 * kNB];
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = pwave && cok && kb + u < k;
+                    const float v = cpc[(int64_t)(ok ? kb + u : 0) * k];
+                    bfr[g][u] = ok ? v : 0.f;
+                }
+            }
+            if (has_prev) {   // rank-32 correction: wave w contracts the previous block's atoms 8w .. 8w+7
+                const int jb = wid * 8 + 4 * h;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = cok && jb + u < p.nb_prev;
+                    const float v = cpc[(int64_t)(ok ? p.j0_prev + jb + u : 0) * k];
+                    bq[u] = ok ? v : 0.f;
+                }
+            }
+            // dictionary rows -> MFMA A operands, the wave's whole contraction range in flight at once
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].x, b0, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].y, b1, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].z, b2, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].w, b3, acc[t], 0, 0, 0);
+                int64_t f = f0 + t * 32 + (lane & 31);
+                if (f >= p.s) f = p.s - 1;               // clamped: results of padded rows are discarded
+                const float *rowp = p.Dt + f * k;
+#pragma unroll
+                for (int g = 0; g < GW; ++g) {
+                    const int kb = ((wid - PW0) * GW + g) * 8 + 4 * h;
+                    const bool ok = pwave && kb + 3 < k;
+                    const float4 v = *reinterpret_cast<const float4 *>(rowp + (ok ? kb : 0));
+                    av[g][t] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+        // operands of the apply step, in the output layout of its matrix-core tiles: worker wave w owns tiles
+        // w * RT .. w * RT + RT - 1 of the (RB / 16) x 2 grid (feature tile ft = t / 2, atom tile jt = t % 2)
+        if (has_prev) {
+#pragma unroll
+            for (int u = 0; u < RT; ++u) {
+                const int t = wid * RT + u, ft = t >> 1, jt = t & 1;
+                const int cj = jt * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t f = f0 + ft * 16 + (lane >> 4) + 4 * r;
+                    const bool live = f < p.s && cj < p.nb_prev;
+                    const float dv = p.Dt[live ? f * k + p.j0_prev + cj : 0];
+                    dold[u][r] = live ? dv : 0.f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const int e = tid + 256 * q;
+                const int r = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
+                const int64_t fr = (f0 + r < p.s) ? f0 + r : p.s - 1;
+                va[q] = *reinterpret_cast<const float4 *>(p.a + fr * kNB + c4);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (st && tid == 0) st[13] = clock64();
+        if (!fin) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            if (pwave)
+#pragma unroll
+            for (int g = 0; g < GW; ++g) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].x, bfr[g][0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].y, bfr[g][1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].z, bfr[g][2], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].w, bfr[g][3], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        if (has_prev) {                              // a-tile of the previous block -> LDS for (D)
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const int e = tid + 256 * q;
+                const int r = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
+                float4 v = va[q];                        // columns >= nb_prev were never written
+                v.x = (c4 + 0 < p.nb_prev) ? v.x : 0.f;
+                v.y = (c4 + 1 < p.nb_prev) ? v.y : 0.f;
+                v.z = (c4 + 2 < p.nb_prev) ? v.z : 0.f;
+                v.w = (c4 + 3 < p.nb_prev) ? v.w : 0.f;
+                *reinterpret_cast<float4 *>(Ap + r * kApStride + c4) = v;
             }
         }
         if (st && tid == 0) st[3] = clock64();
@@ -801,14 +819,8 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
     if (st && tid == 0) st[5] = clock64();
     // ---------------------------------------------------------------- (E) rank-32 correction, cross-wave sum
     if (worker) {
-        if (has_prev) {   // wave w contracts the previous block's atoms 8w .. 8w+7
+        if (has_prev) {   // wave w contracts the previous block's atoms 8w .. 8w+7 (bq: loaded in (C))
             const int jb = wid * 8 + 4 * h;
-            float bq[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = jb + u;
-                bq[u] = (j < p.nb_prev) ? CPs[(size_t)(p.j0_prev + j) * kNB + (lane & 31)] : 0.f;
-            }
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 const float4 dv = *reinterpret_cast<const float4 *>(Dl + (t * 32 + (lane & 31)) * DLS + jb);
@@ -884,7 +896,8 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
 static size_t bcd_block_lds(int gpw, int RT) {
     const int kpad = gpw * 32, RB = 32 * RT;
     const size_t dbl = (size_t)kNB * (kNB + 1) + kNB + kNB * kNB + (size_t)kNB * kCaStride + 8 * kNB;
-    const size_t fl = (size_t)kpad * kNB + 4 * RB * (kNB + 1) + RB * (kNB + 1) + 4 + RB * (kNB + 4) + 4;
+    const size_t fl = 4 * (size_t)RB * (kNB + 1) + RB * (kNB + 1) + 4 + RB * (kNB + 4) + 4;
+    (void)kpad;
     return dbl * 8 + fl * 4 + 16;
 }
 

@@ -10,15 +10,19 @@ for r in (10, 1):
     est = DictFact(n_components=256, batch_size=256, reduction=r, code_alpha=1.0, learning_rate=0.92, random_state=0)
     est.prepare(n_samples=4096, X=X[:256])
     est.partial_fit(X[:2048])
-    out = (C.c_ulonglong * 16)()
+    out = (C.c_ulonglong * 32)()
     check(lib.modl_somf_debug_stamps(est._backend.plan, out))
     o = [float(v) for v in out]
-    names = ['A+B: loads, Gram records, LDS staging -> barrier 1', 'resolver wave (C)', 'workers: main MFMA product (C)',
-             'barrier 2 after the longer of the two', 'apply (D) -> barrier 3', 'correction + cross-wave (E) -> barrier 4',
-             'epilogue (F) -> barrier 5', 'Gram record (G)']
-    vals = [o[1] - o[0], o[2] - o[1], o[3] - o[1], o[4] - o[1], o[5] - o[4], o[6] - o[5], o[7] - o[6], o[12] - o[7]]
     print('r=%g cycles (workgroup 0, last full block launch): total %d' % (r, o[12] - o[0]))
-    for n, v in zip(names, vals):
+    rows = [('B: Gram records of the previous block -> barrier 1', o[1] - o[0]),
+            ('C resolver wave', o[2] - o[1]),
+            ('C workers: all loads requested', o[13] - o[1]),
+            ('C workers: main MFMA product + a-tile staging', o[3] - o[13]),
+            ('barrier 2 (after the longer of the two)', o[4] - o[1]),
+            ('D apply -> barrier 3', o[5] - o[4]),
+            ('E correction + cross-wave -> barrier 4', o[6] - o[5]),
+            ('F epilogue -> barrier 5', o[7] - o[6]),
+            ('G Gram record', o[12] - o[7])]
+    for n, v in rows:
         print('   %-56s %8d' % (n, v))
-    print('   A issue %d   B records %d   LDS staging + barrier %d' % (o[13] - o[0], o[14] - o[13], o[1] - o[14]))
     print('   resolve: setup %d  steps 0-7 %d  8-15 %d  16-23 %d  24-31+stores %d' % (o[8] - o[1], o[9] - o[8], o[10] - o[9], o[11] - o[10], o[2] - o[11]))
