@@ -88,7 +88,8 @@ __device__ __forceinline__ void gemm_dense_tile(const DenseOperand &A, const Den
                                                 int64_t K, int64_t k_per_split, T *partial, const Epi &epi, int bx, int by,
                                                 int bz, int nsplit, T (*As)[BK][BM + 4], T (*Bs)[BK][BN + 4]) {
     using MT = Mma<T>;
-    constexpr int RM = 32 / MT::TM, RN = 32 / MT::TN;     // wave tile 32 x 32
+    constexpr int WM = BM / 2, WN = BN / 2;               // 2 x 2 waves
+    constexpr int RM = WM / MT::TM, RN = WN / MT::TN;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
@@ -122,9 +123,9 @@ __device__ __forceinline__ void gemm_dense_tile(const DenseOperand &A, const Den
             T af[RM], bf[RN];
             const int kr = kk + MT::frag_k(lane);
 #pragma unroll
-            for (int i = 0; i < RM; ++i) af[i] = As[cur][kr][wm * 32 + i * MT::TM + MT::frag_i(lane)];
+            for (int i = 0; i < RM; ++i) af[i] = As[cur][kr][wm * WM + i * MT::TM + MT::frag_i(lane)];
 #pragma unroll
-            for (int j = 0; j < RN; ++j) bf[j] = Bs[cur][kr][wn * 32 + j * MT::TN + MT::frag_i(lane)];
+            for (int j = 0; j < RN; ++j) bf[j] = Bs[cur][kr][wn * WN + j * MT::TN + MT::frag_i(lane)];
 #pragma unroll
             for (int i = 0; i < RM; ++i)
 #pragma unroll
@@ -145,8 +146,8 @@ __device__ __forceinline__ void gemm_dense_tile(const DenseOperand &A, const Den
         for (int j = 0; j < RN; ++j)
 #pragma unroll
             for (int r = 0; r < MT::NACC; ++r) {
-                const int64_t m = m0 + wm * 32 + i * MT::TM + MT::acc_row(lane, r);
-                const int64_t n = n0 + wn * 32 + j * MT::TN + MT::acc_col(lane, r);
+                const int64_t m = m0 + wm * WM + i * MT::TM + MT::acc_row(lane, r);
+                const int64_t n = n0 + wn * WN + j * MT::TN + MT::acc_col(lane, r);
                 if (m < M && n < N) {
                     if (direct) epi(m, n, acc[i][j][r]);
                     else partial[((int64_t)bz * M + m) * N + n] = acc[i][j][r];
@@ -178,7 +179,7 @@ template <typename T, class Epi> struct DenseProblem {
 
 template <typename T, class Epi>
 DenseProblem<T, Epi> plan_dense(const DenseOperand &A, const DenseOperand &B, int64_t M, int64_t N, int64_t K, const Epi &epi,
-                                T *ws, size_t ws_elems, int target_wgs = 512, int max_splits = 64) {
+                                T *ws, size_t ws_elems, int target_wgs = 512, int max_splits = 64, int bm = 64, int bn = 64) {
     DenseProblem<T, Epi> P;
     P.A = A; P.B = B; P.M = M; P.N = N; P.K = K; P.epi = epi;
     constexpr int VN = Vec4<T>::N;
@@ -190,7 +191,7 @@ DenseProblem<T, Epi> plan_dense(const DenseOperand &A, const DenseOperand &B, in
     P.ok = aligned(A) && aligned(B) && K > 0 && M > 0 && N > 0;
     if (!P.ok) return P;
     constexpr int BK = (sizeof(T) == 4) ? 32 : 16;
-    const int64_t tm = cdiv(M, 64), tn = cdiv(N, 64);
+    const int64_t tm = cdiv(M, bm), tn = cdiv(N, bn);
     int64_t splits = 1;
     if (tm * tn < target_wgs && max_splits > 1 && ws) {
         splits = target_wgs / (tm * tn);
@@ -208,22 +209,26 @@ DenseProblem<T, Epi> plan_dense(const DenseOperand &A, const DenseOperand &B, in
     return P;
 }
 
-template <typename T, bool AI0, bool BI0, class Epi0, bool AI1, bool BI1, class Epi1>
+template <typename T, bool AI0, bool BI0, class Epi0, bool AI1, bool BI1, class Epi1, int BM1 = 64, int BN1 = 64, int BK1 = 0>
 __global__ __launch_bounds__(256) void gemm_dense_pair_kernel(DenseProblem<T, Epi0> P0, DenseProblem<T, Epi1> P1) {
     constexpr int BM = 64, BN = 64, BK = (sizeof(T) == 4) ? 32 : 16;
-    __shared__ __attribute__((aligned(16))) T As[2][BK][BM + 4];
-    __shared__ __attribute__((aligned(16))) T Bs[2][BK][BN + 4];
+    extern __shared__ __attribute__((aligned(16))) char gd_smem[];   // sized for the larger of the two tilings
     int id = (int)blockIdx.x;
     const int t0 = P0.tn * P0.tm * P0.splits;
     if (id < t0) {
+        T (*As)[BK][BM + 4] = reinterpret_cast<T (*)[BK][BM + 4]>(gd_smem);
+        T (*Bs)[BK][BN + 4] = reinterpret_cast<T (*)[BK][BN + 4]>(gd_smem + sizeof(T) * 2 * BK * (BM + 4));
         const int bx = id % P0.tn, by = (id / P0.tn) % P0.tm, bz = id / (P0.tn * P0.tm);
         gemm_dense_tile<T, AI0, BI0, Epi0, BM, BN, BK>(P0.A, P0.B, P0.M, P0.N, P0.K, P0.kps, P0.partial, P0.epi, bx, by, bz,
                                                        P0.splits, As, Bs);
     } else {
         id -= t0;
+        constexpr int BKB = BK1 > 0 ? BK1 : BK;
+        T (*As)[BKB][BM1 + 4] = reinterpret_cast<T (*)[BKB][BM1 + 4]>(gd_smem);
+        T (*Bs)[BKB][BN1 + 4] = reinterpret_cast<T (*)[BKB][BN1 + 4]>(gd_smem + sizeof(T) * 2 * BKB * (BM1 + 4));
         const int bx = id % P1.tn, by = (id / P1.tn) % P1.tm, bz = id / (P1.tn * P1.tm);
-        gemm_dense_tile<T, AI1, BI1, Epi1, BM, BN, BK>(P1.A, P1.B, P1.M, P1.N, P1.K, P1.kps, P1.partial, P1.epi, bx, by, bz,
-                                                       P1.splits, As, Bs);
+        gemm_dense_tile<T, AI1, BI1, Epi1, BM1, BN1, BKB>(P1.A, P1.B, P1.M, P1.N, P1.K, P1.kps, P1.partial, P1.epi, bx, by, bz,
+                                                         P1.splits, As, Bs);
     }
 }
 
@@ -246,13 +251,20 @@ __global__ __launch_bounds__(256) void gemm_reduce_pair_kernel(const T *partial0
     }
 }
 
-// Both problems must be `ok` (see plan_dense) and their operand orientations known statically.
-template <typename T, bool AI0, bool BI0, class Epi0, bool AI1, bool BI1, class Epi1>
+// Both problems must be `ok` (see plan_dense) and their operand orientations known statically; the second
+// problem may use a larger block tile (BM1 x BN1, planned with the same values).
+template <typename T, bool AI0, bool BI0, class Epi0, bool AI1, bool BI1, class Epi1, int BM1 = 64, int BN1 = 64, int BK1 = 0>
 int launch_gemm_dense_pair(hipStream_t stream, const DenseProblem<T, Epi0> &P0, const DenseProblem<T, Epi1> &P1,
                            int *launches = nullptr) {
+    constexpr int BK = (sizeof(T) == 4) ? 32 : 16;
+    constexpr int BKB = BK1 > 0 ? BK1 : BK;
+    constexpr size_t lds0 = sizeof(T) * 2 * BK * ((64 + 4) + (64 + 4)), lds1 = sizeof(T) * 2 * BKB * ((BM1 + 4) + (BN1 + 4));
+    constexpr size_t lds = lds0 > lds1 ? lds0 : lds1;
     const int total = P0.tn * P0.tm * P0.splits + P1.tn * P1.tm * P1.splits;
-    hipLaunchKernelGGL((gemm_dense_pair_kernel<T, AI0, BI0, Epi0, AI1, BI1, Epi1>), dim3((unsigned)total), dim3(256), 0, stream,
-                       P0, P1);
+    auto kern = gemm_dense_pair_kernel<T, AI0, BI0, Epi0, AI1, BI1, Epi1, BM1, BN1, BK1>;
+    if (lds > 64 * 1024)
+        MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, stream, P0, P1);
     MODL_LAUNCH_CHECK();
     if (launches) ++*launches;
     const int nb0 = P0.splits > 1 ? (int)cdiv(P0.M * P0.N, 256) : 0, nb1 = P1.splits > 1 ? (int)cdiv(P1.M * P1.N, 256) : 0;

@@ -30,6 +30,14 @@ static const char *kSectionNames[SEC_COUNT] = {"code_gemm", "code_solve", "stats
 
 constexpr int kStageSlots = 8;
 constexpr int kProfPool = 2048;      // event pairs kept before a flush
+#ifndef MODL_STAT_BM
+#define MODL_STAT_BM 64
+#define MODL_STAT_BN 64
+#endif
+#ifndef MODL_STAT_BK
+#define MODL_STAT_BK 0
+#endif
+constexpr int kStatBM = MODL_STAT_BM, kStatBN = MODL_STAT_BN, kStatBK = MODL_STAT_BK;   // block tile of the p x k increment product
 
 template <typename T> struct EpiDxAverage {   // dict_fact.py:596-601
     T *Dx; T *avg; const int64_t *idx; const T *w_sample; int64_t k; T alpha;
@@ -520,9 +528,10 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
             EpiStats<T> eC{static_cast<T *>(stt->d_C), k, beta, wt, bdiv, replace};
             EpiStats<T> eB{static_cast<T *>(stt->d_Bt), k, beta, wt, bdiv, replace};
             auto PC = plan_dense<T, EpiStats<T>>(Cd, Cd, k, k, b, eC, nullptr, 0);
-            auto PB = plan_dense<T, EpiStats<T>>(Xo, Cd, p, k, b, eB, nullptr, 0);
+            auto PB = plan_dense<T, EpiStats<T>>(Xo, Cd, p, k, b, eB, nullptr, 0, 512, 1, kStatBM, kStatBN);
             if (PC.ok && PB.ok) {
-                MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStats<T>, true, true, EpiStats<T>>(st, PC, PB, &ps.launches)));
+                MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStats<T>, true, true, EpiStats<T>, kStatBM, kStatBN, kStatBK>(
+                    st, PC, PB, &ps.launches)));
                 pl->stats_fused = true;
             }
         }
@@ -530,9 +539,10 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
             EpiStore<T> epiC{delta, k, (T)1};
             EpiStore<T> epiB{delta + (size_t)k * k, k, (T)1};
             auto PC = plan_dense<T, EpiStore<T>>(Cd, Cd, k, k, b, epiC, nullptr, 0);
-            auto PB = plan_dense<T, EpiStore<T>>(Xo, Cd, p, k, b, epiB, nullptr, 0);
+            auto PB = plan_dense<T, EpiStore<T>>(Xo, Cd, p, k, b, epiB, nullptr, 0, 512, 1, kStatBM, kStatBN);
             if (PC.ok && PB.ok) {
-                MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStore<T>, true, true, EpiStore<T>>(st, PC, PB, &ps.launches)));
+                MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStore<T>, true, true, EpiStore<T>, kStatBM, kStatBN, kStatBK>(
+                    st, PC, PB, &ps.launches)));
             } else {
                 MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Cd, Cd, k, k, b, epiC, sws, &ps.launches)));
                 MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Xo, Cd, p, k, b, epiB, sws, &ps.launches)));
