@@ -30,6 +30,9 @@ sys.path.insert(0, ROOT)
 K_COMP, P_FEAT, BATCH, CHUNK = 256, 10000, 256, 65536
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
+PMC_FILE = 'r01_h_pmc_hbm_traffic.json'
+DOM_KERNEL = {'dict_update': 'modl::bcd_block_kernel', 'code_solve': 'modl::cd_kernel', 'stats_gemm': 'modl::gemm_dense_pair_kernel<float, true',
+              'code_gemm': 'modl::gemm_dense_pair_kernel<float, false', 'stats_apply': 'modl::stats_apply2_kernel'}
 
 
 def make_stream(n_rows, p, seed, device, k0=256, density=0.1, noise=0.1):
@@ -92,12 +95,16 @@ def run_gpu(args, reduction, steps, warmup, rank, world, device, breakdown=True)
             done += todo
 
     be = est._backend
+    # the dominant section is picked on the LAST quarter of the warm-up (the first minibatches of a fresh
+    # dictionary need several times more solver sweeps than the steady state)
+    w_head = warmup - max(warmup // 4, 1) if warmup >= 4 else warmup
+    run(w_head, 0)
     be.prof_enable(True)
     be.prof_reset()
-    run(warmup, 0)
+    run(warmup - w_head, w_head)
     torch.cuda.synchronize()
     pre = be.prof_get()
-    dom = max(pre, key=lambda n: pre[n]['ms']) if warmup > 0 and pre else 'dict_update'
+    dom = max(pre, key=lambda n: pre[n]['ms']) if warmup - w_head > 0 and pre else 'dict_update'
     be.prof_enable(False)
     be.prof_enable(True, sections=[dom])
     be.prof_reset()
@@ -212,6 +219,19 @@ def main():
             roof['ms_per_step'] = ms
             roof['launches_per_step'] = nl
             roof['avg_launch_ms'] = ms / max(nl, 1)
+            roof['algorithmic_per_launch'] = dict(flops=fl[dom] / max(nl, 1), bytes=by[dom] / max(nl, 1))
+            # HBM traffic per launch of the section's main kernel: from the committed rocprofv3 --pmc passes
+            # (FETCH_SIZE and WRITE_SIZE need separate passes and cannot be collected from inside this process)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', PMC_FILE)))
+                kern = [k_ for k_ in pmc if k_.startswith(DOM_KERNEL.get(dom, '?'))]
+                if kern and abs(args.reduction - 10.0) < 1e-9:
+                    e = pmc[kern[0]]
+                    roof['traffic'] = e.get('fetch_bytes_corrected', 0.0) + e.get('write_bytes', 0.0)
+                    roof['traffic_source'] = 'profiles/%s: %s, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per launch' % (
+                        PMC_FILE, kern[0])
+            except (OSError, ValueError):
+                pass
         total_fl = sum(fl.values())
         out = dict(metric='samples/sec through DictFact.partial_fit at k=256, p=10k', value=samples / dt,
                    unit='samples/s', n_gpus=world, steps=args.steps, warmup=args.warmup,

@@ -223,6 +223,11 @@ __global__ __launch_bounds__(256) void gemm_dense_pair_kernel(DenseProblem<T, Ep
                                                        P0.splits, As, Bs);
     } else {
         id -= t0;
+        // XCD-aware order for the large problem: workgroups are dealt round-robin to the 8 XCDs (each with its
+        // own L2), so the tiles that share an A row-tile are renumbered to land on ONE XCD and fetch it once
+        const int t1 = P1.tn * P1.tm * P1.splits, chunk = (t1 + 7) / 8;
+        id = (id % 8) * chunk + id / 8;
+        if (id >= t1) return;
         constexpr int BKB = BK1 > 0 ? BK1 : BK;
         T (*As)[BKB][BM1 + 4] = reinterpret_cast<T (*)[BKB][BM1 + 4]>(gd_smem);
         T (*Bs)[BKB][BN1 + 4] = reinterpret_cast<T (*)[BKB][BN1 + 4]>(gd_smem + sizeof(T) * 2 * BKB * (BM1 + 4));
@@ -260,7 +265,7 @@ int launch_gemm_dense_pair(hipStream_t stream, const DenseProblem<T, Epi0> &P0, 
     constexpr int BKB = BK1 > 0 ? BK1 : BK;
     constexpr size_t lds0 = sizeof(T) * 2 * BK * ((64 + 4) + (64 + 4)), lds1 = sizeof(T) * 2 * BKB * ((BM1 + 4) + (BN1 + 4));
     constexpr size_t lds = lds0 > lds1 ? lds0 : lds1;
-    const int total = P0.tn * P0.tm * P0.splits + P1.tn * P1.tm * P1.splits;
+    const int total = P0.tn * P0.tm * P0.splits + 8 * ((P1.tn * P1.tm * P1.splits + 7) / 8);   // second problem padded to 8 XCD chunks
     auto kern = gemm_dense_pair_kernel<T, AI0, BI0, Epi0, AI1, BI1, Epi1, BM1, BN1, BK1>;
     if (lds > 64 * 1024)
         MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
