@@ -591,6 +591,8 @@ struct BcdBlockArgs {
     const double *coef_all;
     const float *norm_in;           // norm budgets as they were before this dictionary update
     float *norm_out;                // comp_norm (written by workgroup 0 only)
+    float *Dt_out;                  // the real dictionary [p][k]: every applied column also goes straight back ...
+    const int32_t *subset;          // ... to row subset[f] (null: identity), column order[jj]
     unsigned int *counter;
     unsigned long long *stamps;     // optional phase timestamps of workgroup 0 (diagnostics)
     int64_t s;
@@ -662,6 +664,7 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
     const int h = lane >> 5;
     constexpr int NA = RB * (kNB / 4) / 256;
     float dold[RT][4];
+    int64_t orow[RT][4];            // destination of the applied values in the real dictionary
     float bq[4] = {0.f, 0.f, 0.f, 0.f};
     f16v acc[RT];
     if (!worker) {
@@ -737,12 +740,14 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
             for (int u = 0; u < RT; ++u) {
                 const int t = wid * RT + u, ft = t >> 1, jt = t & 1;
                 const int cj = jt * 16 + (lane & 15);
+                const int oc = (cj < p.nb_prev) ? p.order[p.j0_prev + cj] : 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t f = f0 + ft * 16 + (lane >> 4) + 4 * r;
                     const bool live = f < p.s && cj < p.nb_prev;
                     const float dv = p.Dt[live ? f * k + p.j0_prev + cj : 0];
                     dold[u][r] = live ? dv : 0.f;
+                    orow[u][r] = (live ? sub_row(p.subset, f) : 0) * k + oc;
                 }
             }
 #pragma unroll
@@ -809,7 +814,10 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
                 const int64_t f = f0 + frow;
                 const bool live = f < p.s && cj < p.nb_prev;
                 const float dnew = (float)dn[r];
-                if (live) p.Dt[f * k + p.j0_prev + cj] = dnew;
+                if (live) {
+                    p.Dt[f * k + p.j0_prev + cj] = dnew;
+                    p.Dt_out[orow[u][r]] = dnew;             // final: no unpack pass
+                }
                 Dl[frow * DLS + cj] = live ? dnew - dold[u][r] : 0.f;
             }
         }
@@ -1072,6 +1080,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             base.norm_out = reinterpret_cast<float *>(a.comp_norm); base.counter = counter;
             base.stamps = reinterpret_cast<unsigned long long *>(counter + kCounters); base.s = s; base.k = k;
             base.group = (nslab + 31) / 32 > kGroup ? (nslab + 31) / 32 : kGroup;
+            base.Dt_out = reinterpret_cast<float *>(a.Dt); base.subset = a.subset;
         }
         int blk_i = 0, j0_prev = 0, nb_prev = 0;
         for (int j0 = 0; j0 < k; j0 += kNB, ++blk_i) {
@@ -1116,10 +1125,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             ba.j0 = 0; ba.nb = 0; ba.j0_prev = j0_prev; ba.nb_prev = nb_prev;
             hipLaunchKernelGGL(blk, dim3(nslab), dim3(320), bcd_block_lds(GPW, RT), stream, ba);
             MODL_LAUNCH_CHECK();
-            hipLaunchKernelGGL((bcd_unpack_kernel<T>), dim3((unsigned)s), dim3(256), 0, stream, a.Dt, a.subset, a.order, s,
-                               k, DsP);
-            MODL_LAUNCH_CHECK();
-            nl += 2;
+            nl += 1;
         } else {
             hipLaunchKernelGGL((bcd_apply_kernel<T>), dim3((unsigned)cdiv(s, 64)), dim3(256), 0, stream, abuf,
                                CA[(blk_i - 1) & 1], a.Dt, a.subset, a.order, s, k, j0_prev, nb_prev);
