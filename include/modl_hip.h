@@ -268,20 +268,32 @@ void modl_somf_plan_destroy(modl_somf_plan *plan);
  * dict_fact.py:339-357).  k, p, dtype, n_samples, max_batch must not change. */
 int modl_somf_plan_update(modl_somf_plan *plan, const modl_somf_desc *desc);
 
-/* number of T elements of the statistics increment buffer: k*k + p*k */
+/* number of T elements of the statistics increment buffer (k*k + 2*p*k):
+ *   [ code^T code (k*k) | rows of X^T code of the SAMPLED features, compact (p*k slots, s*k used) | X^T code (p*k) ] */
 int64_t modl_somf_delta_elems(const modl_somf_desc *desc);
 
 /* Phase 1 (per rank): code solve for the minibatch rows (writes d_code rows),
- * then d_delta = [ code^T code (k*k) | X^T code (p*k, feature-major) ], NOT yet
- * divided by the batch size.  With several GPUs the caller all-reduces d_delta
- * (sum) between phase 1 and phase 2. */
+ * then the increments (layout above, feature-major, NOT yet divided by the batch
+ * size).  With several GPUs the caller sums d_delta over the ranks as
+ * modl_somf_delta_split says: the head before phase 2, the tail (the bulk) at
+ * the latest before modl_somf_apply_rest — i.e. under the dictionary update. */
 int modl_somf_code_and_partials(modl_somf_plan *plan, const modl_somf_state *st, const modl_somf_batch *bt,
                                 void *d_delta, void *stream);
+/* How to reduce the increments of the LAST phase 1 over the ranks:
+ *   d_delta[0 .. *head_elems)                      needed by phase 2 (C increment + sampled rows of the B increment);
+ *   d_delta[*tail_offset .. + *tail_elems)         the full B increment.  *tail_before_phase2 == 0: only
+ *   modl_somf_apply_rest reads it (sum it asynchronously);  == 1: the minibatch had no proper feature subset,
+ *   phase 2 applies it itself and it must be summed before phase 2. */
+int modl_somf_delta_split(const modl_somf_plan *plan, int64_t *head_elems, int64_t *tail_offset, int64_t *tail_elems,
+                          int *tail_before_phase2);
 /* Phase 2 (identical on every rank): C_/B_ update from d_delta with weight w /
- * b_global, then the block-coordinate dictionary update on the subset. */
+ * b_global (B_: the sampled rows only when the increments were split), then the
+ * block-coordinate dictionary update on the subset. */
 int modl_somf_apply_and_update_dict(modl_somf_plan *plan, const modl_somf_state *st,
                                     const modl_somf_batch *bt, const void *d_delta, void *stream);
-/* both phases back to back (one GPU) */
+/* Phase 3 (identical on every rank): the rows of B_ that phase 2 left out (no-op when nothing is pending). */
+int modl_somf_apply_rest(modl_somf_plan *plan, const modl_somf_state *st, const void *d_delta, void *stream);
+/* all phases back to back (one GPU): the C_/B_ update rides in the epilogues of the increment products */
 int modl_somf_step(modl_somf_plan *plan, const modl_somf_state *st, const modl_somf_batch *bt, void *d_delta,
                    void *stream);
 

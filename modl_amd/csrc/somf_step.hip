@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void stats_apply_kernel(T *dst, const T *delta
 // both statistics in one launch: blocks [0, nblk0) -> C, the rest -> Bt
 template <typename T>
 __global__ __launch_bounds__(256) void stats_apply2_kernel(T *C, int64_t n0, int nblk0, T *Bt, int64_t n1, const T *delta,
-                                                           T beta, T wt, T bdiv, int replace) {
+                                                           int64_t gap, T beta, T wt, T bdiv, int replace) {
     T *dst;
     const T *src;
     int64_t n, e, stride;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void stats_apply2_kernel(T *C, int64_t n0, int
         dst = C; src = delta; n = n0;
         e = (int64_t)blockIdx.x * 256 + threadIdx.x; stride = (int64_t)nblk0 * 256;
     } else {
-        dst = Bt; src = delta + n0; n = n1;
+        dst = Bt; src = delta + n0 + gap; n = n1;        // gap: the compact sampled-row block of the split protocol
         e = (int64_t)((int)blockIdx.x - nblk0) * 256 + threadIdx.x; stride = (int64_t)((int)gridDim.x - nblk0) * 256;
     }
     for (; e < n; e += stride) {
@@ -94,6 +94,55 @@ template <typename T> struct EpiStats {
     }
 };
 
+// Two-phase (multi-GPU) protocol with a sampled subset: the B increment is also written, for the sampled
+// features only, into a compact block right behind the C increment, so that what the dictionary update needs
+// can be all-reduced first and the bulk of the B increment can be summed UNDER the dictionary update.
+// stamp[f] == step marks the features sampled in this minibatch, pos[f] their index in the subset.
+template <typename T> struct EpiStoreSplit {
+    T *out; int64_t ld; const int32_t *stamp; const int32_t *pos; int32_t step; T *compact;
+    __device__ __forceinline__ void operator()(int64_t m, int64_t n, T v) const {
+        out[m * ld + n] = v;
+        if (stamp[m] == step) compact[(int64_t)pos[m] * ld + n] = v;
+    }
+};
+// C and the SAMPLED rows of Bt from the head of the increment buffer: blocks [0, nblk0) -> C, block nblk0 + i
+// -> feature subset[i]
+template <typename T>
+__global__ __launch_bounds__(256) void stats_apply_head_kernel(T *C, int64_t n0, int nblk0, T *Bt, const int32_t *subset,
+                                                               int k, const T *delta, T beta, T wt, T bdiv, int replace) {
+    if ((int)blockIdx.x < nblk0) {
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n0; e += (int64_t)nblk0 * 256) {
+            const T d = delta[e];
+            if (replace) C[e] = d / bdiv;
+            else C[e] = C[e] * beta + (wt * d) / bdiv;
+        }
+    } else {
+        const int i = (int)blockIdx.x - nblk0;
+        T *dst = Bt + (int64_t)subset[i] * k;
+        const T *src = delta + n0 + (int64_t)i * k;
+        for (int c = threadIdx.x; c < k; c += 256) {
+            const T d = src[c];
+            if (replace) dst[c] = d / bdiv;
+            else dst[c] = dst[c] * beta + (wt * d) / bdiv;
+        }
+    }
+}
+// every row of Bt that was NOT sampled in minibatch `step`
+template <typename T>
+__global__ __launch_bounds__(256) void stats_apply_rest_kernel(T *Bt, const T *dB, const int32_t *stamp, int32_t step,
+                                                               int64_t p, int k, T beta, T wt, T bdiv, int replace) {
+    for (int64_t f = blockIdx.x; f < p; f += gridDim.x) {
+        if (stamp[f] == step) continue;
+        T *dst = Bt + f * k;
+        const T *src = dB + f * k;
+        for (int c = threadIdx.x; c < k; c += 256) {
+            const T d = src[c];
+            if (replace) dst[c] = d / bdiv;
+            else dst[c] = dst[c] * beta + (wt * d) / bdiv;
+        }
+    }
+}
+
 // Everything the code step gathers, in ONE launch: squared row norms of the minibatch, the sampled
 // dictionary rows Ds = Dt[subset], the sampled minibatch columns Xs = X[:, subset], the minibatch's code rows.
 template <typename T> struct PrepArgs {
@@ -101,6 +150,7 @@ template <typename T> struct PrepArgs {
     const T *Dt; const int32_t *subset; int64_t s; int k; T *Ds; int n_rows;  // n_rows = s or 0
     int64_t s_pad; T *Xs; int gx; int n_cols;                                 // n_cols = gx * b or 0
     const T *code; const int64_t *idx; T *codeb; int n_code;                  // n_code = b or 0
+    int32_t *stamp, *pos; int32_t step;                                       // stamp[subset[i]] = step, pos[subset[i]] = i
 };
 template <typename T>
 __global__ __launch_bounds__(256) void prep_kernel(PrepArgs<T> a) {
@@ -138,6 +188,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs<T> a) {
     }
     id -= a.n_norm;
     if (id < a.n_rows) {
+        if (a.stamp && threadIdx.x == 0) { a.stamp[a.subset[id]] = a.step; a.pos[a.subset[id]] = id; }
         const T *src = a.Dt + (int64_t)a.subset[id] * a.k;
         T *dst = a.Ds + (int64_t)id * a.k;
         for (int c = threadIdx.x; c < a.k; c += 256) dst[c] = src[c];
@@ -194,6 +245,13 @@ struct modl_somf_plan {
     // profiling
     bool prof = false;
     bool stats_fused = false;          // the last phase 1 applied the statistics in its epilogues
+    bool split_now = false;            // the last phase 1 wrote the compact sampled-row block (two-phase protocol)
+    bool rest_pending = false;         // phase 2 left the non-sampled rows of Bt to modl_somf_apply_rest
+    double rest_beta = 0, rest_wt = 0, rest_bdiv = 1;
+    int rest_replace = 0;
+    int32_t step_id = 0;
+    int64_t last_s_phase1 = 0;
+    size_t off_stamp = 0, off_pos = 0;
     unsigned prof_mask = ~0u;          // sections that record events
     std::vector<hipEvent_t> pev;       // 2 * kProfPool events
     std::vector<int> psec, plaunch;
@@ -425,6 +483,13 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         pa.s_pad = s_pad; pa.Xs = Xsb; pa.gx = (int)std::min<int64_t>(cdiv(s_pad, 256), 64);
         pa.n_cols = (need_sub && d.Dx_agg != MODL_AGG_FULL) ? pa.gx * b : 0;
         pa.code = code; pa.idx = d_idx; pa.codeb = codeb; pa.n_code = (cd_on_compact && d_idx) ? b : 0;
+        // two-phase protocol: mark the sampled features so that the B increment can be split (see EpiStoreSplit)
+        pl->split_now = !fuse_stats && need_sub && s > 0 && s < p;
+        if (pl->split_now) pl->step_id = (pl->step_id == 0x7fffffff) ? 1 : pl->step_id + 1;
+        pa.stamp = pl->split_now ? reinterpret_cast<int32_t *>(pl->dws + pl->off_stamp) : nullptr;
+        pa.pos = reinterpret_cast<int32_t *>(pl->dws + pl->off_pos);
+        pa.step = pl->step_id;
+        pl->last_s_phase1 = s;
         if (need_sub) {
             Dsrc = Dsb;
             if (d.Dx_agg != MODL_AGG_FULL) { Xsrc = Xsb; ldxs = s_pad; }
@@ -536,16 +601,31 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
             }
         }
         if (!pl->stats_fused) {
-            EpiStore<T> epiC{delta, k, (T)1};
-            EpiStore<T> epiB{delta + (size_t)k * k, k, (T)1};
+            // layout of the increment buffer: [ dC (k*k) | dB rows of the sampled features, compact (p*k slots) | dB (p*k) ]
+            T *dC = delta, *dBs = delta + (size_t)k * k, *dB = delta + (size_t)k * k + (size_t)p * k;
+            EpiStore<T> epiC{dC, k, (T)1};
             auto PC = plan_dense<T, EpiStore<T>>(Cd, Cd, k, k, b, epiC, nullptr, 0);
-            auto PB = plan_dense<T, EpiStore<T>>(Xo, Cd, p, k, b, epiB, nullptr, 0, 512, 1, kStatBM, kStatBN);
-            if (PC.ok && PB.ok) {
-                MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStore<T>, true, true, EpiStore<T>, kStatBM, kStatBN, kStatBK>(
-                    st, PC, PB, &ps.launches)));
-            } else {
-                MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Cd, Cd, k, k, b, epiC, sws, &ps.launches)));
-                MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Xo, Cd, p, k, b, epiB, sws, &ps.launches)));
+            if (pl->split_now) {
+                EpiStoreSplit<T> epiB{dB, k, reinterpret_cast<const int32_t *>(pl->dws + pl->off_stamp),
+                                      reinterpret_cast<const int32_t *>(pl->dws + pl->off_pos), pl->step_id, dBs};
+                auto PB = plan_dense<T, EpiStoreSplit<T>>(Xo, Cd, p, k, b, epiB, nullptr, 0);
+                if (PC.ok && PB.ok) {
+                    MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStore<T>, true, true, EpiStoreSplit<T>>(st, PC, PB,
+                                                                                                                 &ps.launches)));
+                } else {
+                    pl->split_now = false;
+                }
+            }
+            if (!pl->split_now) {
+                EpiStore<T> epiB{dB, k, (T)1};
+                auto PB = plan_dense<T, EpiStore<T>>(Xo, Cd, p, k, b, epiB, nullptr, 0, 512, 1, kStatBM, kStatBN);
+                if (PC.ok && PB.ok) {
+                    MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStore<T>, true, true, EpiStore<T>, kStatBM, kStatBN, kStatBK>(
+                        st, PC, PB, &ps.launches)));
+                } else {
+                    MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Cd, Cd, k, k, b, epiC, sws, &ps.launches)));
+                    MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Xo, Cd, p, k, b, epiB, sws, &ps.launches)));
+                }
             }
         }
     }
@@ -572,10 +652,18 @@ int phase2(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         const T beta = (T)(1.0 - bt->w), wt = (T)bt->w, bdiv = (T)bt->b_global;
         if (!pl->stats_fused) {
             const int nb0 = (int)std::min<int64_t>(cdiv((int64_t)k * k, 256), 256);
-            const int nb1 = (int)std::min<int64_t>(cdiv(p * k, 256), 2048);
-            hipLaunchKernelGGL((stats_apply2_kernel<T>), dim3((unsigned)(nb0 + nb1)), dim3(256), 0, st, Cm, (int64_t)k * k, nb0,
-                               Bt, p * k, delta, beta, wt, bdiv, replace);
-            MODL_LAUNCH_CHECK();
+            if (pl->split_now) {     // C and the sampled rows of Bt now; the rest in modl_somf_apply_rest
+                hipLaunchKernelGGL((stats_apply_head_kernel<T>), dim3((unsigned)(nb0 + s)), dim3(256), 0, st, Cm, (int64_t)k * k,
+                                   nb0, Bt, d_subset, k, delta, beta, wt, bdiv, replace);
+                MODL_LAUNCH_CHECK();
+                pl->rest_pending = true;
+                pl->rest_beta = (double)beta; pl->rest_wt = (double)wt; pl->rest_bdiv = (double)bdiv; pl->rest_replace = replace;
+            } else {
+                const int nb1 = (int)std::min<int64_t>(cdiv(p * k, 256), 2048);
+                hipLaunchKernelGGL((stats_apply2_kernel<T>), dim3((unsigned)(nb0 + nb1)), dim3(256), 0, st, Cm, (int64_t)k * k, nb0,
+                                   Bt, p * k, delta, (int64_t)p * k, beta, wt, bdiv, replace);
+                MODL_LAUNCH_CHECK();
+            }
             ps.launches += 1;
         }
         pl->stats_fused = false;
@@ -687,6 +775,21 @@ int enet_regression_abi(const T *G, int64_t g_stride, T *Dx, const T *X, int64_t
 
 }  // namespace
 
+template <typename T>
+static int apply_rest_impl(modl_somf_plan *pl, const modl_somf_state *stt, const T *delta, hipStream_t st) {
+    if (!pl->rest_pending) return MODL_OK;
+    if (!stt || !stt->d_Bt || !delta) return MODL_EINVAL;
+    const int k = pl->d.k;
+    const int64_t p = pl->d.p;
+    hipLaunchKernelGGL((stats_apply_rest_kernel<T>), dim3((unsigned)std::min<int64_t>(p, 4096)), dim3(256), 0, st,
+                       static_cast<T *>(stt->d_Bt), delta + (size_t)k * k + (size_t)p * k,
+                       reinterpret_cast<const int32_t *>(pl->dws + pl->off_stamp), pl->step_id, p, k, (T)pl->rest_beta,
+                       (T)pl->rest_wt, (T)pl->rest_bdiv, pl->rest_replace);
+    MODL_LAUNCH_CHECK();
+    pl->rest_pending = false;
+    return MODL_OK;
+}
+
 extern "C" {
 
 int modl_device_count(void) {
@@ -723,7 +826,7 @@ ABI_REG(f64, double)
 
 int64_t modl_somf_delta_elems(const modl_somf_desc *desc) {
     if (!desc) return 0;
-    return (int64_t)desc->k * desc->k + desc->p * (int64_t)desc->k;
+    return (int64_t)desc->k * desc->k + 2 * desc->p * (int64_t)desc->k;     // [dC | dB sampled rows, compact | dB]
 }
 
 int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
@@ -750,6 +853,8 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     pl->off_Ds = take(t * p_pad * k);          // compacted sampled dictionary rows
     pl->off_Xs = take(t * b * p_pad);          // compacted sampled minibatch columns
     pl->off_codeb = take(t * b * k);           // the minibatch's code rows
+    pl->off_stamp = take(sizeof(int32_t) * p); // stamp[f] = last minibatch that sampled feature f
+    pl->off_pos = take(sizeof(int32_t) * p);   // ... and its index in that minibatch's subset
     const bool per_sample = desc->G_agg == MODL_AGG_AVERAGE;
     pl->off_F = take(t * k * k * (per_sample ? b : 1));                // Cholesky factors (one per sample for G_average_)
     // split-K partial tiles: the largest split product is max(b, k) x k (Dx, Gram, C increment) with
@@ -762,6 +867,8 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     pl->dws_bytes = o;
     hipError_t e = hipMalloc((void **)&pl->dws, pl->dws_bytes);
     if (e != hipSuccess) { delete pl; return (int)e; }
+    e = hipMemset(pl->dws + pl->off_stamp, 0, sizeof(int32_t) * p);
+    if (e != hipSuccess) { modl_somf_plan_destroy(pl); return (int)e; }
     for (int i = 0; i < kStageSlots; ++i) {
         e = hipHostMalloc((void **)&pl->hstage[i], align_up(pl->params_bytes, 16), hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&pl->hstage_dev[i], pl->hstage[i], 0);
@@ -809,6 +916,23 @@ int modl_somf_apply_and_update_dict(modl_somf_plan *pl, const modl_somf_state *s
     if (!pl || !bt) return MODL_EINVAL;
     return DISPATCH(pl, phase2<float>(pl, st, bt, static_cast<const float *>(d_delta), (hipStream_t)stream),
                     phase2<double>(pl, st, bt, static_cast<const double *>(d_delta), (hipStream_t)stream));
+}
+
+int modl_somf_apply_rest(modl_somf_plan *pl, const modl_somf_state *st, const void *d_delta, void *stream) {
+    if (!pl) return MODL_EINVAL;
+    return DISPATCH(pl, apply_rest_impl<float>(pl, st, static_cast<const float *>(d_delta), (hipStream_t)stream),
+                    apply_rest_impl<double>(pl, st, static_cast<const double *>(d_delta), (hipStream_t)stream));
+}
+
+int modl_somf_delta_split(const modl_somf_plan *pl, int64_t *head_elems, int64_t *tail_offset, int64_t *tail_elems,
+                          int *tail_before_phase2) {
+    if (!pl || !head_elems || !tail_offset || !tail_elems || !tail_before_phase2) return MODL_EINVAL;
+    const int64_t k = pl->d.k, p = pl->d.p;
+    *head_elems = k * k + (pl->split_now ? pl->last_s_phase1 * k : 0);
+    *tail_offset = k * k + p * k;
+    *tail_elems = p * k;
+    *tail_before_phase2 = pl->split_now ? 0 : 1;
+    return MODL_OK;
 }
 
 int modl_somf_step(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt, void *d_delta,

@@ -66,7 +66,7 @@ class HipBackend:
         self.Dx_average = z(n_samples, k) if desc_kwargs['Dx_agg'] == 'average' else None
         self.G_average = z(n_samples, k, k) if desc_kwargs['G_agg'] == 'average' else None
         self._make_plan(desc_kwargs)
-        self.delta = torch.zeros(k * k + p * k, dtype=td, device=dev)
+        self.delta = torch.zeros(k * k + 2 * p * k, dtype=td, device=dev)   # [dC | dB sampled rows, compact | dB]
 
     def _desc(self, kw):
         d = SomfDesc()
@@ -218,6 +218,16 @@ class HipBackend:
         st = self._state()
         check(lib.modl_somf_step(self.plan, C.byref(st), C.byref(bt), ptr(self.delta), stream_ptr(self.device)),
               'modl_somf_step')
+
+    def delta_split(self):
+        """(head_elems, tail_offset, tail_elems, tail_before_phase2) of the increments of the last phase 1."""
+        h, o, n, f = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
+        check(lib.modl_somf_delta_split(self.plan, C.byref(h), C.byref(o), C.byref(n), C.byref(f)), 'modl_somf_delta_split')
+        return h.value, o.value, n.value, bool(f.value)
+
+    def apply_rest(self, delta):
+        st = self._state()
+        check(lib.modl_somf_apply_rest(self.plan, C.byref(st), ptr(delta), stream_ptr(self.device)), 'modl_somf_apply_rest')
 
     def phase2(self, delta):
         bt, keep = self._pending
@@ -525,9 +535,9 @@ class DictFact(CodingMixin, BaseEstimator):
             return dist.get_world_size()
         return 1
 
-    def _all_reduce(self, delta):
+    def _all_reduce(self, delta, async_op=False):
         import torch.distributed as dist
-        dist.all_reduce(delta, op=dist.ReduceOp.SUM)
+        return dist.all_reduce(delta, op=dist.ReduceOp.SUM, async_op=async_op)
 
     def _single_batch_fit(self, Xh, batch, sample_indices):
         """One SOMF iteration (dict_fact.py:495-526)."""
@@ -554,9 +564,25 @@ class DictFact(CodingMixin, BaseEstimator):
             be.step(Xh, batch, sample_indices, subset, order, w_sample, w, self.reduction, b_global)
             return
         delta = be.phase1(Xh, batch, sample_indices, subset, order, w_sample, w, self.reduction, b_global)
+        if not hasattr(be, 'delta_split'):
+            if world > 1:
+                self._all_reduce(delta)
+            be.phase2(delta)
+            return
+        # What the dictionary update needs (C increment + sampled rows of the B increment) is summed first; the
+        # bulk of the B increment is summed asynchronously, under the dictionary update, and applied afterwards.
+        head, toff, tn, tail_first = be.delta_split()
+        work = None
         if world > 1:
-            self._all_reduce(delta)
+            if tail_first:
+                self._all_reduce(delta[toff:toff + tn])
+            self._all_reduce(delta[:head])
+            if not tail_first:
+                work = self._all_reduce(delta[toff:toff + tn], async_op=True)
         be.phase2(delta)
+        if work is not None:
+            work.wait()
+        be.apply_rest(delta)
 
     # ---------------------------------------------------------------- pickle
     def __getstate__(self):

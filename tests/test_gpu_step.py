@@ -301,3 +301,52 @@ def test_pickle_roundtrip(DictFact):
     est.partial_fit(X[:20])
     est2.partial_fit(X[:20])
     assert_array_equal(est.components_, est2.components_)
+
+
+# ---- the data-parallel protocol on the real backend: 2 processes share the GPU, increments summed over gloo ------
+def _gpu_rank_main(rank, world, port, kw, X_parts, out):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from modl_amd import DictFact as DF
+        est = DF(**kw)
+        X = X_parts[rank]
+        est.prepare(n_samples=X.shape[0], X=X_parts[0])        # every rank initialises from the same rows
+        est.partial_fit(X)
+        out[rank] = dict(D=est.components_, C=est.C_, B=est.B_, code=est.code_, n_iter=est.n_iter_)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('variant', ['l1_masked_r3', 'l1_masked_r1'])
+def test_two_rank_gpu_equals_double_batch(oracle, variant):
+    """R ranks with local batch b == one rank with batch R b on the concatenated rows (f64, through the C-ABI
+    two-phase entry points and an all-reduce of the increments)."""
+    import socket
+    import torch.multiprocessing as mp
+    red = 3 if variant.endswith('r3') else 1
+    rs = np.random.RandomState(5)
+    b, steps, p, k = 16, 5, 64, 8
+    X0 = rs.randn(b * steps, 12).dot(rs.randn(12, p)) + 0.3 * rs.randn(b * steps, p)
+    X1 = rs.randn(b * steps, 12).dot(rs.randn(12, p)) + 0.3 * rs.randn(b * steps, p)
+    kw = dict(n_components=k, batch_size=b, reduction=red, random_state=0, learning_rate=0.9, code_alpha=0.1)
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gpu_rank_main, args=(2, port, kw, [X0, X1], out), nprocs=2, join=True)
+    Xc = np.concatenate([np.concatenate([X0[t * b:(t + 1) * b], X1[t * b:(t + 1) * b]]) for t in range(steps)])
+    pr = oracle.SomfParams(**dict(kw, batch_size=2 * b))
+    st = oracle.prepare(pr, n_samples=Xc.shape[0], X=X0)
+    oracle.partial_fit(st, pr, Xc)
+    for r in (0, 1):
+        assert rel_fro(out[r]['D'], st.D) < 1e-9, (variant, r)
+        assert rel_fro(out[r]['C'], st.C) < 1e-9
+        assert rel_fro(out[r]['B'], st.B) < 1e-9
+        assert out[r]['n_iter'] == st.n_iter
+    assert_array_equal(out[0]['D'], out[1]['D'])               # replicas stay bit-identical
