@@ -171,6 +171,8 @@ def main():
     ap.add_argument('--reduction', type=float, default=10.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--also-r1', action='store_true', help='also time reduction=1 (OMF) and report it under "also"')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to test the N > 1 path)')
+    ap.add_argument('--share-gpu', action='store_true', help='testing only: every rank uses cuda:0 (needs --backend gloo)')
     args = ap.parse_args()
 
     import torch
@@ -183,11 +185,13 @@ def main():
             raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     dt, prof, sweeps, ok, dom, prof_dom = run_gpu(args, args.reduction, args.steps, args.warmup, rank, world, device)
     out = None
@@ -241,7 +245,8 @@ def main():
                                         'reduction=%g, code_alpha=1 (l1 codes), l2 atoms, learning_rate=0.92, '
                                         'masked/masked' % (CHUNK, P_FEAT, K_COMP, BATCH, args.reduction),
                                reduction=args.reduction, global_batch=BATCH * world,
-                               parallelism='dp%d (row-sharded minibatch, all-reduce of [C|B] increments)' % world),
+                               parallelism='dp%d (row-sharded minibatch; all-reduce of the C increment and the sampled rows of the B increment, '
+                                           'the rest of the B increment all-reduced under the dictionary update)' % world),
                    roofline=roof, sections=sections, cd_sweeps_mean=sweeps, cd_sweeps_max=getattr(run_gpu, 'sweeps_max', None),
                    step_tflops=total_fl / (dt / args.steps) / 1e12, finite=ok,
                    host_enqueue_ms_per_step=getattr(run_gpu, 'host_ms_per_step', None))

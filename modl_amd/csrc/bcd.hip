@@ -230,42 +230,6 @@ __global__ __launch_bounds__(256) void bcd_gram_kernel(const T *a, const T *Dt, 
     }
 }
 
-// ---- sum of 32 doubles held by one half-wave (lanes 0-31 or 32-63), DPP row operations ----------
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double x) {
-    const long long b = __double_as_longlong(x);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-// every lane of a 16-lane row ends with the row's sum
-__device__ __forceinline__ double row16_sum(double x) {
-    x += dpp_move<0xB1>(x);      // quad_perm [1,0,3,2]
-    x += dpp_move<0x4E>(x);      // quad_perm [2,3,0,1]
-    x += dpp_move<0x141>(x);     // row_half_mirror
-    x += dpp_move<0x140>(x);     // row_mirror
-    return x;
-}
-
-// 1 / sqrt(q) in double from a single-precision seed and two Newton steps (|rel err| < 1e-15); the
-// IEEE double sqrt + divide sequences cost several hundred cycles on the recursion's critical path.
-__device__ __forceinline__ double fast_rsqrt(double q) {
-    const float qf = (float)q;
-    if (!(qf > 1e-30f && qf < 1e30f)) return 1.0 / sqrt(q);
-    double y = (double)rsqrtf(qf);
-    y = y * (1.5 - 0.5 * q * y * y);
-    y = y * (1.5 - 0.5 * q * y * y);
-    return y;
-}
-__device__ __forceinline__ double fast_rcp(double v) {
-    const float vf = (float)v;
-    if (!(fabsf(vf) > 1e-30f && fabsf(vf) < 1e30f)) return 1.0 / v;
-    double r = (double)(1.0f / vf);
-    r = r * (2.0 - v * r);
-    r = r * (2.0 - v * r);
-    return r;
-}
-
 constexpr int kResStride = kNB * kNB + kNB;          // doubles per Gram partial / per CA record
 constexpr int kPackStride = 3 * 256 + kNB;           // fused path: tiles (0,0) (0,1) (1,1) of 16 x 16 + old norms (the Gram is symmetric)
 
@@ -368,18 +332,6 @@ __device__ __forceinline__ void halves(double z, double &low, double &high) {
     const auto r1 = __builtin_amdgcn_permlane32_swap(w1, w1, false, false);
     low = __longlong_as_double(((long long)r1[0] << 32) | r0[0]);
     high = __longlong_as_double(((long long)r1[1] << 32) | r0[1]);
-}
-
-__device__ __forceinline__ double pick(bool c, double a, double b) { return c ? a : b; }   // both sides evaluated
-
-// rows 0/1 (and 2/3) of the wave exchange: every lane sees (even row's value, odd row's value)
-__device__ __forceinline__ void rows_pair(double z, double &even, double &odd) {
-    const long long b = __double_as_longlong(z);
-    const unsigned int w0 = (unsigned int)(b & 0xffffffffll), w1 = (unsigned int)(b >> 32);
-    const auto r0 = __builtin_amdgcn_permlane16_swap(w0, w0, false, false);
-    const auto r1 = __builtin_amdgcn_permlane16_swap(w1, w1, false, false);
-    even = __longlong_as_double(((long long)r1[0] << 32) | r0[0]);
-    odd = __longlong_as_double(((long long)r1[1] << 32) | r0[1]);
 }
 
 // The alpha recursion of one block, run by ONE wavefront entirely in registers.  With
@@ -522,41 +474,6 @@ __global__ __launch_bounds__(256) void bcd_apply_kernel(const T *a, const double
     const int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x / 4;       // 4 threads per feature
     if (f >= s) return;
     apply_row<T, 4>(a + f * kNB, CAs, Dt + sub_row(subset, f) * k, order, j0, nb, threadIdx.x % 4);
-}
-
-// ---- packing for the fused path: gather the sampled rows once, in sweep order --------------------
-// DsP[f][jj] = Dt[subset[f]][order[jj]], BsP likewise: every later access of the block kernels is a
-// plain contiguous row, no index loads on the critical path.
-template <typename T>
-__global__ __launch_bounds__(256) void bcd_pack_kernel(const T *Dt, const T *Bt, const int32_t *subset,
-                                                       const int32_t *order, int64_t s, int k, T *DsP, T *BsP) {
-    const int64_t f = blockIdx.x;
-    if (f >= s) return;
-    const int64_t src = sub_row(subset, f) * k;
-    for (int jj = threadIdx.x; jj < k; jj += 256) {
-        const int o = order[jj];
-        DsP[f * k + jj] = Dt[src + o];
-        BsP[f * k + jj] = Bt[src + o];
-    }
-}
-template <typename T>
-__global__ __launch_bounds__(256) void bcd_unpack_kernel(T *Dt, const int32_t *subset, const int32_t *order, int64_t s,
-                                                         int k, const T *DsP) {
-    const int64_t f = blockIdx.x;
-    if (f >= s) return;
-    const int64_t dst = sub_row(subset, f) * k;
-    for (int jj = threadIdx.x; jj < k; jj += 256) Dt[dst + order[jj]] = DsP[f * k + jj];
-}
-// CPP[m'][jj] = C[o_m'][o_jj] in sweep coordinates, block-lower-triangular mask applied
-template <typename T>
-__global__ __launch_bounds__(256) void bcd_permute_C_kernel(const T *C, const int32_t *order, int k, T *CPP) {
-    const int mp = blockIdx.x;
-    const int om = order[mp];
-    for (int jj = threadIdx.x; jj < k; jj += 256) {
-        T v = C[(int64_t)om * k + order[jj]];
-        if (mp / kNB == jj / kNB && mp <= jj) v = 0;
-        CPP[(int64_t)mp * k + jj] = v;
-    }
 }
 
 // ---- fused block kernel (f32) -------------------------------------------------------------------

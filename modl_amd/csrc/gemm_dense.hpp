@@ -342,14 +342,4 @@ __global__ __launch_bounds__(256) void scatter_rows_T_kernel(T *dst, int64_t dst
     const T *s = src + r * src_ld;
     for (int64_t c = threadIdx.x; c < cols; c += 256) d[c] = s[c];
 }
-// dst[i][f] = src[i][cols_idx[f]] for f < s, zero for s <= f < s_pad
-template <typename T>
-__global__ __launch_bounds__(256) void gather_cols_T_kernel(const T *src, int64_t src_ld, const int32_t *cols_idx,
-                                                            int64_t s, int64_t s_pad, T *dst) {
-    const int64_t i = blockIdx.y;
-    const T *row = src + i * src_ld;
-    for (int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x; f < s_pad; f += (int64_t)gridDim.x * 256)
-        dst[i * s_pad + f] = (f < s) ? row[cols_idx[f]] : (T)0;
-}
-
 }  // namespace modl

@@ -52,17 +52,6 @@ template <typename T> struct EpiDxAverage {   // dict_fact.py:596-601
 };
 
 // C = beta C + (wt d) / b ;  the same for Bt (dict_fact.py:559-575)
-template <typename T>
-__global__ __launch_bounds__(256) void stats_apply_kernel(T *dst, const T *delta, int64_t n, T beta, T wt, T bdiv,
-                                                          int replace) {
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {
-        const T d = delta[e];
-        if (replace) dst[e] = d / bdiv;
-        else dst[e] = dst[e] * beta + (wt * d) / bdiv;
-    }
-}
-
 // both statistics in one launch: blocks [0, nblk0) -> C, the rest -> Bt
 template <typename T>
 __global__ __launch_bounds__(256) void stats_apply2_kernel(T *C, int64_t n0, int nblk0, T *Bt, int64_t n1, const T *delta,
