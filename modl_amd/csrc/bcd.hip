@@ -38,9 +38,15 @@
 
 namespace modl {
 
+#ifndef MODL_RT1_MAX
+#define MODL_RT1_MAX 256
+#endif
 constexpr int kNB = 32;            // atoms per block of the blocked path
 constexpr int kGramRows = 128;     // feature rows per Gram slab
-constexpr int kGroup = 16;         // minimum workgroups per group of the two-level partial reduction
+#ifndef MODL_KGROUP
+#define MODL_KGROUP 16
+#endif
+constexpr int kGroup = MODL_KGROUP;         // minimum workgroups per group of the two-level partial reduction
 constexpr int kCounters = 64;      // arrival counters: [0] final, [1 + g] group g
 
 struct DuLayout {
@@ -964,14 +970,13 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         double *CA[2] = {Tp, Tp + kResStride};
         unsigned int *counter = reinterpret_cast<unsigned int *>(Tp + 2 * kResStride);
         const bool fused = std::is_same<T, float>::value && (k % 4 == 0) && k <= 512;
-        const int RT = (s <= 256) ? 1 : 2;
+        const int RT = (s <= MODL_RT1_MAX || k > 256) ? 1 : 2;   // k > 256: 64-row tiles would spill registers
         const int nslab = fused ? (int)cdiv(s, 32 * RT) : (int)cdiv(s, kGramRows);
         const int GPW = (k <= 256) ? 8 : 16;
         void (*blk)(BcdBlockArgs) = nullptr;
         T *DsP = reinterpret_cast<T *>(ws + L.off_Dnew), *BsP = reinterpret_cast<T *>(ws + L.off_BsP), *CPP = CP;
         if (fused) {
-            blk = (RT == 1) ? (GPW == 8 ? bcd_block_kernel<1, 8> : bcd_block_kernel<1, 16>)
-                            : (GPW == 8 ? bcd_block_kernel<2, 8> : bcd_block_kernel<2, 16>);
+            blk = (RT == 1) ? (GPW == 8 ? bcd_block_kernel<1, 8> : bcd_block_kernel<1, 16>) : bcd_block_kernel<2, 8>;
             MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(blk), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024));
             hipLaunchKernelGGL((bcd_setup_kernel<T>), dim3((unsigned)(kNB + k + s)), dim3(256), 0, stream, a.C, a.order, k, CPP,

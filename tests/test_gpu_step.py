@@ -197,6 +197,26 @@ def test_full_size_step_properties(DictFact):
     assert_array_equal(runs[0][1], runs[1][1])
 
 
+@pytest.mark.parametrize('k,p,b,red', [(320, 1200, 64, 2), (512, 700, 48, 1), (40, 333, 32, 3)])
+def test_wide_dictionaries_f32_vs_oracle(DictFact, oracle, k, p, b, red):
+    """k > 256 (two registers of coefficients per lane in the solver, 16 contraction groups per wave in the
+    fused dictionary update), k not a multiple of 32, p not a multiple of 4: first minibatch from identical
+    state, f32, against the f32 oracle."""
+    rs = np.random.RandomState(11)
+    n = max(2 * b, k)                                 # prepare() takes its initial atoms from the first k rows
+    X = (rs.randn(n, 96) @ rs.randn(96, p) / 10 + 0.5 * rs.randn(n, p)).astype(np.float32)
+    kw = dict(n_components=k, batch_size=b, reduction=red, code_alpha=0.3, learning_rate=0.9, random_state=0)
+    est = DictFact(**kw)
+    est.prepare(n_samples=n, X=X)
+    est.partial_fit(X[:b], np.arange(b))
+    pr = oracle.SomfParams(**kw)
+    st = oracle.prepare(pr, n_samples=n, X=X)
+    oracle.partial_fit(st, pr, X[:b], np.arange(b))
+    eD, ec = rel_fro(est.components_, st.D), rel_fro(est.code_[:b], st.code[:b])
+    assert eD < 1e-5 and ec < 1e-5, (k, p, eD, ec)
+    assert rel_fro(est.C_, st.C) < 1e-5 and rel_fro(est.B_, st.B) < 1e-5
+
+
 @pytest.mark.parametrize('agg', [('masked', 'masked'), ('full', 'full'), ('average', 'average')])
 def test_two_phase_equals_fused_step(DictFact, agg):
     """modl_somf_code_and_partials + modl_somf_apply_and_update_dict (the multi-GPU split, increments through
