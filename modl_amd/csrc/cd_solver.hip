@@ -106,7 +106,10 @@ __device__ __forceinline__ void cd_coord(int L, T (&w)[KPL], T (&H)[KPL], const 
 // row ii + 8 is requested as soon as row ii has been consumed (ring of 8 buffers).  The scheduler barriers
 // keep every request where it is: otherwise the scheduler gathers the group's loads at the end of the loop
 // body and the wait for a row sits right behind its own request.
-template <typename T, int KPL, bool VEC, bool POSITIVE>
+// PAD: at least kCdRing rows are readable behind the matrix, so the prefetch needs no clamp and the row
+// address is ONE 64-bit add per coordinate on a per-lane pointer (instead of min / mul / add on the scalar
+// unit plus the lane offset: the wave spends 2/3 of its cycles issuing instructions, every one counts).
+template <typename T, int KPL, bool VEC, bool POSITIVE, bool PAD>
 __device__ __forceinline__ void cd_dense_sweep(int lane, int k, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
                                                const T (&inv)[KPL], const T *__restrict__ Q, T alpha) {
     constexpr int U = KPL > kCdRing ? KPL : kCdRing;
@@ -114,6 +117,28 @@ __device__ __forceinline__ void cd_dense_sweep(int lane, int k, T (&w)[KPL], T (
 #pragma unroll
     for (int j = 0; j < kCdRing; ++j) load_row<T, KPL, VEC>(Q, j < k ? j : k - 1, k, lane, ring[j]);
     const int groups = k / U;
+    if constexpr (PAD && VEC) {
+        constexpr int V = (KPL * sizeof(T) >= 16) ? (int)(16 / sizeof(T)) : KPL;
+        typedef T vec_t __attribute__((ext_vector_type(V)));
+        const T *next = Q + (int64_t)kCdRing * k + lane * KPL;       // this lane's slice of row ii + kCdRing
+        for (int g = 0; g < groups; ++g) {
+            static_for<U>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                cd_coord<T, KPL, j % KPL, POSITIVE>(g * (U / KPL) + j / KPL, w, H, q, inv, ring[j % kCdRing], alpha);
+                __builtin_amdgcn_sched_barrier(0);
+                const vec_t *rp = reinterpret_cast<const vec_t *>(next);
+#pragma unroll
+                for (int v = 0; v < KPL / V; ++v) {
+                    const vec_t x = rp[v];
+#pragma unroll
+                    for (int c = 0; c < V; ++c) ring[j % kCdRing][v * V + c] = x[c];
+                }
+                next += k;
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        return;
+    }
     for (int g = 0; g < groups; ++g) {
         static_for<U>([&](auto J) {
             constexpr int j = decltype(J)::value;
@@ -215,7 +240,7 @@ __device__ __forceinline__ void cd_sparse_sweep(int lane, int k, T (&w)[KPL], T 
     }
 }
 
-template <typename T, int KPL, bool VEC, bool POSITIVE>
+template <typename T, int KPL, bool VEC, bool POSITIVE, bool PAD>
 __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
     const int lane = threadIdx.x & 63;
     const int smp = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -259,19 +284,43 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
         T ring[kCdRing][KPL];
 #pragma unroll
         for (int j = 0; j < kCdRing; ++j) load_row<T, KPL, VEC>(Q, j < k ? j : k - 1, k, lane, ring[j]);
-        for (int j0 = 0; j0 < k; j0 += U) {
-            static_for<U>([&](auto J) {
-                constexpr int j = decltype(J)::value;
-                const int jj = j0 + j;
-                T wj = bcast_lane(w[j % KPL], (j0 / KPL + j / KPL) & 63);   // coefficient jj (zero beyond k)
-                if (!VEC && jj >= k) wj = 0;
+        if constexpr (PAD && VEC) {
+            constexpr int V = (KPL * sizeof(T) >= 16) ? (int)(16 / sizeof(T)) : KPL;
+            typedef T vec_t __attribute__((ext_vector_type(V)));
+            const T *next = Q + (int64_t)kCdRing * k + lane * KPL;
+            for (int j0 = 0; j0 < k; j0 += U) {
+                static_for<U>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    const T wj = bcast_lane(w[j % KPL], (j0 / KPL + j / KPL) & 63);
 #pragma unroll
-                for (int c2 = 0; c2 < KPL; ++c2) H[c2] = fma(wj, ring[j % kCdRing][c2], H[c2]);
-                __builtin_amdgcn_sched_barrier(0);
-                const int nx = (jj + kCdRing < k) ? jj + kCdRing : k - 1;
-                load_row<T, KPL, VEC>(Q, nx, k, lane, ring[j % kCdRing]);
-                __builtin_amdgcn_sched_barrier(0);
-            });
+                    for (int c2 = 0; c2 < KPL; ++c2) H[c2] = fma(wj, ring[j % kCdRing][c2], H[c2]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const vec_t *rp = reinterpret_cast<const vec_t *>(next);
+#pragma unroll
+                    for (int v = 0; v < KPL / V; ++v) {
+                        const vec_t x = rp[v];
+#pragma unroll
+                        for (int c = 0; c < V; ++c) ring[j % kCdRing][v * V + c] = x[c];
+                    }
+                    next += k;
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+        } else {
+            for (int j0 = 0; j0 < k; j0 += U) {
+                static_for<U>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    const int jj = j0 + j;
+                    T wj = bcast_lane(w[j % KPL], (j0 / KPL + j / KPL) & 63);   // coefficient jj (zero beyond k)
+                    if (!VEC && jj >= k) wj = 0;
+#pragma unroll
+                    for (int c2 = 0; c2 < KPL; ++c2) H[c2] = fma(wj, ring[j % kCdRing][c2], H[c2]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int nx = (jj + kCdRing < k) ? jj + kCdRing : k - 1;
+                    load_row<T, KPL, VEC>(Q, nx, k, lane, ring[j % kCdRing]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
         }
     }
 
@@ -295,7 +344,7 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
         T w0[KPL];                                 // a coefficient changes once per sweep: d_w_ii = |w - w0| (:380-384)
 #pragma unroll
         for (int r = 0; r < KPL; ++r) w0[r] = w[r];
-        if (6 * n_act > k) cd_dense_sweep<T, KPL, VEC, POSITIVE>(lane, k, w, H, q, inv, Q, alpha);   // a sparse step costs several dense coordinates
+        if (6 * n_act > k) cd_dense_sweep<T, KPL, VEC, POSITIVE, PAD>(lane, k, w, H, q, inv, Q, alpha);   // a sparse step costs several dense coordinates
         else cd_sparse_sweep<T, KPL, VEC, POSITIVE>(lane, k, w, H, q, inv, m, Q, alpha);
         T dmx = 0, wmx = 0;                        // skipped coordinates do not count (:357): their w is 0 here
 #pragma unroll
@@ -356,13 +405,17 @@ static void launch_cd_kpl(hipStream_t stream, const CdArgs<T> &a, dim3 grid, dim
     constexpr size_t kRowAlign = (KPL * sizeof(T) >= 16) ? 16 : KPL * sizeof(T);
     const bool vec = (a.k == 64 * KPL) && (reinterpret_cast<uintptr_t>(a.G) % kRowAlign == 0) &&
                      ((a.g_stride * sizeof(T)) % kRowAlign == 0);
-#define MODL_CD_LAUNCH(VEC, POS) hipLaunchKernelGGL((cd_kernel<T, KPL, VEC, POS>), grid, block, 0, stream, a)
-    if (vec) {
-        if (a.positive) MODL_CD_LAUNCH(true, true);
-        else MODL_CD_LAUNCH(true, false);
+    const bool pad = vec && a.g_pad_rows >= kCdRing && a.g_stride == 0;
+#define MODL_CD_LAUNCH(VEC, POS, PAD) hipLaunchKernelGGL((cd_kernel<T, KPL, VEC, POS, PAD>), grid, block, 0, stream, a)
+    if (pad) {
+        if (a.positive) MODL_CD_LAUNCH(true, true, true);
+        else MODL_CD_LAUNCH(true, false, true);
+    } else if (vec) {
+        if (a.positive) MODL_CD_LAUNCH(true, true, false);
+        else MODL_CD_LAUNCH(true, false, false);
     } else {
-        if (a.positive) MODL_CD_LAUNCH(false, true);
-        else MODL_CD_LAUNCH(false, false);
+        if (a.positive) MODL_CD_LAUNCH(false, true, false);
+        else MODL_CD_LAUNCH(false, false, false);
     }
 #undef MODL_CD_LAUNCH
 }

@@ -409,6 +409,7 @@ int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride
     a.G = G; a.g_stride = g_stride; a.g_idx = g_idx; a.Dx = Dx; a.xnorm2 = xnorm2; a.H0 = H0; a.code = code;
     a.idx = d_idx;
     a.code2 = scatter_dst; a.idx2 = scatter_idx;
+    a.g_pad_rows = (G == reinterpret_cast<const T *>(pl->dws + pl->off_G)) ? 8 : 0;
     a.sweeps = d_sweeps; a.b = b; a.k = k;
     a.alpha = (T)((T)d.code_alpha * (T)d.code_l1_ratio);
     a.beta = (T)((double)(T)d.code_alpha * (1.0 - (double)(T)d.code_l1_ratio));
@@ -837,7 +838,7 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     pl->off_sweeps = take(sizeof(int32_t) * b);
     pl->off_Dx = take(t * b * k);
     pl->off_H0 = take(t * b * k);
-    pl->off_G = take(t * k * k);
+    pl->off_G = take(t * (k + 8) * k);         // 8 readable rows behind the Gram: the solver's row prefetch runs unclamped
     const size_t p_pad = align_up(p, 4);
     pl->off_Ds = take(t * p_pad * k);          // compacted sampled dictionary rows
     pl->off_Xs = take(t * b * p_pad);          // compacted sampled minibatch columns
