@@ -120,22 +120,23 @@ __device__ __forceinline__ void cd_dense_sweep(int lane, int k, T (&w)[KPL], T (
     if constexpr (PAD && VEC) {
         constexpr int V = (KPL * sizeof(T) >= 16) ? (int)(16 / sizeof(T)) : KPL;
         typedef T vec_t __attribute__((ext_vector_type(V)));
-        const T *next = Q + (int64_t)kCdRing * k + lane * KPL;       // this lane's slice of row ii + kCdRing
+        constexpr int K = 64 * KPL;                                   // VEC: k == 64 * KPL, the row stride is a constant
+        const T *next = Q + (int64_t)kCdRing * K + lane * KPL;       // this lane's slice of row ii + kCdRing
         for (int g = 0; g < groups; ++g) {
             static_for<U>([&](auto J) {
                 constexpr int j = decltype(J)::value;
                 cd_coord<T, KPL, j % KPL, POSITIVE>(g * (U / KPL) + j / KPL, w, H, q, inv, ring[j % kCdRing], alpha);
                 __builtin_amdgcn_sched_barrier(0);
-                const vec_t *rp = reinterpret_cast<const vec_t *>(next);
+                const vec_t *rp = reinterpret_cast<const vec_t *>(next + j * K);   // immediate offsets within the group
 #pragma unroll
                 for (int v = 0; v < KPL / V; ++v) {
                     const vec_t x = rp[v];
 #pragma unroll
                     for (int c = 0; c < V; ++c) ring[j % kCdRing][v * V + c] = x[c];
                 }
-                next += k;
                 __builtin_amdgcn_sched_barrier(0);
             });
+            next += U * K;
         }
         return;
     }
