@@ -867,19 +867,146 @@ __global__ __launch_bounds__(256) void atom_grad_kernel(const T *Dt, const T *Bt
     if (threadIdx.x == 0) partial_old[blockIdx.x] = old;
 }
 
+// The projection of one atom, by one workgroup: old-norm partials -> radius, Michelot, write-back.
+// Up to kProjEpt * 256 elements it is run by the FIRST FOUR wavefronts with the vector in registers (the caller
+// retires the other threads first: see block_enet_project_reg); beyond that every thread takes part and the
+// passes scan the vector (from its LDS copy `ul` when given, else from L2).  red: >= 32 doubles.
+constexpr int kProjEpt = 24;
+template <typename T>
+__device__ __forceinline__ void atom_project(T *u, T *ul, const double *partial_old, int nparts, T *Dt,
+                                             const int32_t *subset, int64_t s, int k, int j, double rho, T *comp_norm,
+                                             double *red, unsigned long long *dbg = nullptr) {
+    const bool in_regs = s <= (int64_t)kProjEpt * 256 && blockDim.x >= 256;
+    const int nthr = in_regs ? 256 : (int)blockDim.x;
+    if ((int)threadIdx.x >= nthr) return;
+    double old = 0, dummy = 0;
+    for (int i = threadIdx.x; i < nparts; i += nthr) old += partial_old[i];
+    T *w = u;
+    if (!in_regs && ul) {
+        for (int64_t f = threadIdx.x; f < s; f += nthr) ul[f] = u[f];
+        w = ul;
+    }
+    block_sum2(old, dummy, red, nthr);                               // (also orders the LDS copy)
+    const double radius = (double)(T)((double)comp_norm[j] + old);   // comp_norm_[k] += subset_norm (:676-678)
+    if (dbg && threadIdx.x == 0) dbg[7] = clock64();
+    double nrm;
+    if (in_regs) {                                                   // projected values go straight to the dictionary
+        nrm = block_enet_project_reg<T, kProjEpt>(u, Dt + j, subset, (int64_t)k, s, radius, rho, red, nthr, dbg);
+    } else {
+        nrm = block_enet_project<T>(w, 1, w, 1, s, radius, rho, red);
+        __syncthreads();
+        for (int64_t f = threadIdx.x; f < s; f += nthr) Dt[sub_row(subset, f) * k + j] = w[f];
+    }
+    if (threadIdx.x == 0) comp_norm[j] = (T)(radius - nrm);          // :690-692
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void atom_project_kernel(T *u, const double *partial_old, int nparts, T *Dt,
                                                             const int32_t *subset, int64_t s, int k, int j,
                                                             double rho, T *comp_norm) {
-    __shared__ double red[16];
+    __shared__ double red[32];
+    atom_project<T>(u, nullptr, partial_old, nparts, Dt, subset, s, k, j, rho, comp_norm, red);
+}
+
+// One atom in ONE launch: every workgroup evaluates its share of the gradient row (a wavefront per sampled
+// feature, coalesced), the LAST workgroup to finish (release / relaxed ticket / acquire, no spinning) projects.
+template <typename T, int KPL>
+__global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, const T *C, const int32_t *subset, int64_t s,
+                                                        int k, int j, int pos, double rho, T *u, double *partial_old,
+                                                        T *comp_norm, unsigned int *counter, int u_in_lds,
+                                                        unsigned long long *dbg) {
+    extern __shared__ __attribute__((aligned(16))) char step_smem[];   // the s-vector for the projection, if it fits
+    __shared__ double red[32];
+    __shared__ int flag;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned long long t0 = clock64();
+    const int e0 = lane * KPL;
+    T cc[KPL];
+#pragma unroll
+    for (int c = 0; c < KPL; ++c) cc[c] = (e0 + c < k) ? C[(int64_t)j * k + e0 + c] : (T)0;   // row j == column j
+    const T Cjj = C[(int64_t)j * k + j];
+    const bool frozen = !(Cjj > (T)1e-20);
     double old = 0;
-    for (int i = threadIdx.x; i < nparts; i += blockDim.x) old += partial_old[i];
+    const int nwv = (int)(blockDim.x >> 6);
+    for (int64_t f = (int64_t)blockIdx.x * nwv + wid; f < s; f += (int64_t)gridDim.x * nwv) {
+        const int64_t r = sub_row(subset, f) * k;
+        const T *row = Dt + r;
+        // every load of the row's step is requested before the reduction (one memory round trip per row)
+        const T dj = row[j], bj = Bt[r + j];
+        double dot = 0;
+#pragma unroll
+        for (int c = 0; c < KPL; ++c)
+            if (e0 + c < k) dot += (double)row[e0 + c] * (double)cc[c];
+        dot = wave_sum(dot);
+        if (lane == 0) {
+            T val = dj;
+            if (!frozen) val = (T)((((double)bj - dot) + (double)Cjj * (double)dj) / (double)Cjj);
+            if (pos && val < (T)0) val = 0;            // dict_fact.py:684-685
+            u[f] = val;
+            const double a = fabs((double)dj);
+            old += a * (rho + (1.0 - rho) * a);
+        }
+    }
     old = block_sum(old, red);
-    const double radius = (double)(T)((double)comp_norm[j] + old);   // comp_norm_[k] += subset_norm (:676-678)
-    const double nrm = block_enet_project<T>(u, 1, u, 1, s, radius, rho, red);
-    __syncthreads();
-    for (int64_t f = threadIdx.x; f < s; f += blockDim.x) Dt[sub_row(subset, f) * k + j] = u[f];
-    if (threadIdx.x == 0) comp_norm[j] = (T)(radius - nrm);          // :690-692
+    if (threadIdx.x == 0) partial_old[blockIdx.x] = old;
+    const unsigned long long t1 = clock64();
+    if (!arrive_last(counter, gridDim.x, &flag)) return;
+    const unsigned long long t2 = clock64();
+    atom_project<T>(u, u_in_lds ? reinterpret_cast<T *>(step_smem) : nullptr, partial_old, (int)gridDim.x, Dt, subset, s, k, j,
+                    rho, comp_norm, red, dbg);
+    if (dbg && threadIdx.x == 0) { dbg[0] = t0; dbg[1] = t1; dbg[2] = t2; dbg[3] = clock64(); }
+}
+
+// The whole sweep in ONE launch, by one workgroup, for TINY problems (u = the s-vector of the atom in flight
+// lives in LDS): the generic path is a chain of k strictly sequential atoms, each needing a few global
+// reductions over the sampled features (Michelot passes); for a handful of kilobytes one workgroup beats 2 k
+// launches.  Its thread-per-row reads are uncoalesced, so anything larger uses one multi-workgroup launch
+// per atom (atom_step_kernel).  Same arithmetic as atom_grad_kernel + atom_project_kernel (the dot product is accumulated
+// in double, sequentially over the atoms instead of lane-wise).
+template <typename T>
+__global__ __launch_bounds__(1024) void atom_sweep_kernel(T *Dt, const T *Bt, const T *C, const int32_t *subset,
+                                                          const int32_t *order, int64_t s, int k, int pos, double rho,
+                                                          T *comp_norm) {
+    extern __shared__ __attribute__((aligned(16))) char sweep_smem[];
+    double *red = reinterpret_cast<double *>(sweep_smem);             // [16]
+    double *ccol = red + 16;                                          // [k] column j of C (C is symmetric)
+    T *u = reinterpret_cast<T *>(ccol + k);                           // [s]
+    for (int t = 0; t < k; ++t) {
+        const int j = order[t];
+        for (int c = threadIdx.x; c < k; c += blockDim.x) ccol[c] = (double)C[(int64_t)j * k + c];
+        __syncthreads();
+        const T Cjj = C[(int64_t)j * k + j];
+        const bool frozen = !(Cjj > (T)1e-20);                        // dict_fact.py:681
+        double old = 0;
+        for (int64_t f = threadIdx.x; f < s; f += blockDim.x) {
+            const int64_t r = sub_row(subset, f) * k;
+            const T *row = Dt + r;
+            double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+            int c = 0;
+            for (; c + 3 < k; c += 4) {
+                d0 += (double)row[c] * ccol[c];
+                d1 += (double)row[c + 1] * ccol[c + 1];
+                d2 += (double)row[c + 2] * ccol[c + 2];
+                d3 += (double)row[c + 3] * ccol[c + 3];
+            }
+            for (; c < k; ++c) d0 += (double)row[c] * ccol[c];
+            const double dot = (d0 + d1) + (d2 + d3);
+            const T dj = row[j];
+            T val = dj;
+            if (!frozen) val = (T)((((double)Bt[r + j] - dot) + (double)Cjj * (double)dj) / (double)Cjj);
+            if (pos && val < (T)0) val = 0;                           // dict_fact.py:684-685
+            u[f] = val;
+            const double a = fabs((double)dj);
+            old += a * (rho + (1.0 - rho) * a);
+        }
+        old = block_sum(old, red);
+        const double radius = (double)(T)((double)comp_norm[j] + old);   // comp_norm_[k] += subset_norm (:676-678)
+        const double nrm = block_enet_project<T>(u, 1, u, 1, s, radius, rho, red);
+        __syncthreads();
+        for (int64_t f = threadIdx.x; f < s; f += blockDim.x) Dt[sub_row(subset, f) * k + j] = u[f];
+        if (threadIdx.x == 0) comp_norm[j] = (T)(radius - nrm);          // :690-692
+        __syncthreads();
+    }
 }
 
 // -------------------------------------------------------------------- sgd path
@@ -1075,27 +1202,40 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
     char *ws = static_cast<char *>(a.ws);
     T *u = reinterpret_cast<T *>(ws + L.off_u);
     double *pold = reinterpret_cast<double *>(ws + L.off_pold);
-    int nwg = (int)cdiv(s, 16);
+    // small problems: the whole sweep in one launch (u in LDS, see atom_sweep_kernel)
+    const size_t lds = sizeof(double) * (16 + (size_t)k) + sizeof(T) * (size_t)s + 16;
+    if (a.order && lds <= 64 * 1024 && (double)s * k <= 32e3) {     // thread-per-row reads: only worth it when tiny
+        for (int t = 0; t < k; ++t)
+            if (h_order[t] < 0 || h_order[t] >= k) return MODL_EINVAL;
+        auto kern = atom_sweep_kernel<T>;
+        hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, stream, a.Dt, a.Bt, a.C, a.subset, a.order, s, k, a.comp_pos,
+                           a.comp_l1_ratio, a.comp_norm);
+        MODL_LAUNCH_CHECK();
+        if (launches) *launches += 1;
+        return MODL_OK;
+    }
+    int nwg = (int)cdiv(s, 4);                       // 4 waves per workgroup (the projection wants registers: 256 threads), one feature per wave while the grid lasts
     if (nwg > L.nwg_grad) nwg = (int)L.nwg_grad;
     if (nwg < 1) nwg = 1;
+    unsigned int *counter = reinterpret_cast<unsigned int *>(reinterpret_cast<double *>(ws + L.off_Tp) + 2 * kResStride);
+    MODL_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned int), stream));   // the last arriver re-arms it after each atom
+    const size_t u_lds = (sizeof(T) * (size_t)s <= 60 * 1024) ? sizeof(T) * (size_t)s : 0;
     for (int t = 0; t < k; ++t) {
         const int j = (int)h_order[t];
         if (j < 0 || j >= k) return MODL_EINVAL;
-#define MODL_GRAD(KPL)                                                                                          \
-    hipLaunchKernelGGL((atom_grad_kernel<T, KPL>), dim3(nwg), dim3(256), 0, stream, a.Dt, a.Bt, a.C, a.subset, s, \
-                       k, j, a.comp_pos, a.comp_l1_ratio, u, pold)
-        if (k <= 64) MODL_GRAD(1);
-        else if (k <= 128) MODL_GRAD(2);
-        else if (k <= 256) MODL_GRAD(4);
-        else if (k <= 512) MODL_GRAD(8);
-        else MODL_GRAD(16);
-#undef MODL_GRAD
-        MODL_LAUNCH_CHECK();
-        hipLaunchKernelGGL((atom_project_kernel<T>), dim3(1), dim3(1024), 0, stream, u, pold, nwg, a.Dt, a.subset, s, k,
-                           j, a.comp_l1_ratio, a.comp_norm);
+#define MODL_STEP(KPL)                                                                                            \
+    hipLaunchKernelGGL((atom_step_kernel<T, KPL>), dim3(nwg), dim3(256), u_lds, stream, a.Dt, a.Bt, a.C, a.subset, s, k, j, \
+                       a.comp_pos, a.comp_l1_ratio, u, pold, a.comp_norm, counter, u_lds ? 1 : 0, \
+                       reinterpret_cast<unsigned long long *>(counter + kCounters))
+        if (k <= 64) MODL_STEP(1);
+        else if (k <= 128) MODL_STEP(2);
+        else if (k <= 256) MODL_STEP(4);
+        else if (k <= 512) MODL_STEP(8);
+        else MODL_STEP(16);
+#undef MODL_STEP
         MODL_LAUNCH_CHECK();
     }
-    if (launches) *launches += 2 * k;
+    if (launches) *launches += k;
     return MODL_OK;
 }
 

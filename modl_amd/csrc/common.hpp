@@ -36,20 +36,58 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane) {
 }
 __device__ __forceinline__ int bcast_lane(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 
+// Wave-wide reductions without the LDS crossbar: four DPP stages inside each row of 16 lanes
+// (quad_perm, quad_perm, row_half_mirror, row_mirror), then v_permlane16_swap (rows 0/1 and 2/3) and
+// v_permlane32_swap (the two halves).  Every lane ends with the result; ~20 cheap instructions instead of six
+// ds_bpermute round trips (~700 cycles).  Fixed association, so results are run-to-run deterministic.
+template <int CTRL> __device__ __forceinline__ float dpp_perm(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_perm(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// (a, b) = (value of the even / lower partner, value of the odd / upper partner), for rows (SWAP16) or halves
+template <bool SWAP16> __device__ __forceinline__ void lane_swap(float x, float &a, float &b) {
+    const unsigned int w = (unsigned int)__float_as_int(x);
+    const auto r = SWAP16 ? __builtin_amdgcn_permlane16_swap(w, w, false, false) : __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    a = __int_as_float((int)r[0]);
+    b = __int_as_float((int)r[1]);
+}
+template <bool SWAP16> __device__ __forceinline__ void lane_swap(double x, double &a, double &b) {
+    const long long v = __double_as_longlong(x);
+    const unsigned int w0 = (unsigned int)(v & 0xffffffffll), w1 = (unsigned int)(v >> 32);
+    const auto r0 = SWAP16 ? __builtin_amdgcn_permlane16_swap(w0, w0, false, false) : __builtin_amdgcn_permlane32_swap(w0, w0, false, false);
+    const auto r1 = SWAP16 ? __builtin_amdgcn_permlane16_swap(w1, w1, false, false) : __builtin_amdgcn_permlane32_swap(w1, w1, false, false);
+    a = __longlong_as_double(((long long)r1[0] << 32) | r0[0]);
+    b = __longlong_as_double(((long long)r1[1] << 32) | r0[1]);
+}
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_perm<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_perm<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_perm<0x141>(v);      // row_half_mirror
+    v += dpp_perm<0x140>(v);      // row_mirror
+    T a, b;
+    lane_swap<true>(v, a, b);
+    v = a + b;
+    lane_swap<false>(v, a, b);
+    return a + b;
 }
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const T u = __shfl_xor(v, o, 64);
-        v = (u > v) ? u : v;
-    }
-    return v;
+    T u;
+    u = dpp_perm<0xB1>(v); v = (u > v) ? u : v;
+    u = dpp_perm<0x4E>(v); v = (u > v) ? u : v;
+    u = dpp_perm<0x141>(v); v = (u > v) ? u : v;
+    u = dpp_perm<0x140>(v); v = (u > v) ? u : v;
+    T a, b;
+    lane_swap<true>(v, a, b);
+    v = (a > b) ? a : b;
+    lane_swap<false>(v, a, b);
+    return (a > b) ? a : b;
 }
 
 // block-wide sum of doubles; `red` = LDS scratch of >= blockDim/64 doubles.
@@ -60,9 +98,9 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
     __syncthreads();
     if (lane == 0) red[wid] = v;
     __syncthreads();
-    double t = 0;
-    for (int i = 0; i < nw; ++i) t += red[i];
-    return t;
+    // the <= 16 per-wave sums are combined by another wave-level reduction (a serial loop over LDS reads is a
+    // chain of ~150-cycle round trips)
+    return wave_sum(lane < nw ? red[lane] : 0.0);
 }
 __device__ __forceinline__ double block_max(double v, double *red) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -70,9 +108,7 @@ __device__ __forceinline__ double block_max(double v, double *red) {
     __syncthreads();
     if (lane == 0) red[wid] = v;
     __syncthreads();
-    double t = red[0];
-    for (int i = 1; i < nw; ++i) t = red[i] > t ? red[i] : t;
-    return t;
+    return wave_max(lane < nw ? red[lane] : red[0]);
 }
 
 // optional gather index: identity when both pointers are null

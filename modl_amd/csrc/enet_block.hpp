@@ -13,6 +13,9 @@
 #pragma once
 #include "common.hpp"
 
+#ifndef MODL_MAX_PASS
+#define MODL_MAX_PASS 256
+#endif
 namespace modl {
 
 template <typename T>
@@ -57,7 +60,7 @@ __device__ double block_enet_project(const T *v, int64_t inc_v, T *out, int64_t 
         return tot * l1_ratio;
     }
     double level = 0.0, prev_cnt = -1.0;
-    for (int pass = 0; pass < 256; ++pass) {
+    for (int pass = 0; pass < MODL_MAX_PASS; ++pass) {
         double S = 0, cnt = 0;
         for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
             const double a = fabs((double)v[i * inc_v]);
@@ -89,6 +92,128 @@ __device__ double block_enet_project(const T *v, int64_t inc_v, T *out, int64_t 
         nrm += a * (l1_ratio + (1.0 - l1_ratio) * a);
     }
     return block_sum(nrm, red);
+}
+
+// two block-wide sums with ONE exchange; red2 = LDS scratch of >= 2 * blockDim / 64 doubles
+__device__ __forceinline__ void block_sum2(double &a, double &b, double *red2, int nthreads) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (nthreads + 63) >> 6;
+    a = wave_sum(a);
+    b = wave_sum(b);
+    __syncthreads();
+    if (lane == 0) { red2[2 * wid] = a; red2[2 * wid + 1] = b; }
+    __syncthreads();
+    a = wave_sum(lane < nw ? red2[2 * lane] : 0.0);
+    b = wave_sum(lane < nw ? red2[2 * lane + 1] : 0.0);
+}
+
+// The same projection for vectors of at most EPT * nthreads elements (unit-stride input), run by the first
+// `nthreads` threads of the workgroup (the others must have left), with every thread's elements held in
+// REGISTERS across the Michelot passes: a pass is a handful of compares and one block exchange instead of a scan
+// of the vector.  Four wavefronts (one per SIMD) beat sixteen here: the passes are reductions, and wavefronts
+// sharing a SIMD serialise them.  red2: >= 2 * nthreads / 64 doubles.
+template <typename T, int EPT>
+__device__ double block_enet_project_reg(const T *v, T *out, const int32_t *rows, int64_t row_stride, int64_t n,
+                                         double radius, double l1_ratio, double *red2, int nthreads,
+                                         unsigned long long *dbg = nullptr) {
+    // element i is written to out[(rows ? rows[i] : i) * row_stride]: the scatter indices are fetched together
+    // with the vector, so that the write-back is not a chain of index load -> store round trips
+    int64_t dst[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int64_t i = threadIdx.x + (int64_t)e * nthreads;
+        dst[e] = (i < n) ? (rows ? (int64_t)rows[i] : i) * row_stride : 0;
+    }
+    if (!(radius > 0.0)) {                                   // enet.pyx:57-59 (radius == 0 -> zeros)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if (threadIdx.x + (int64_t)e * nthreads < n) out[dst[e]] = 0;
+        return 0.0;
+    }
+    double x[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int64_t i = threadIdx.x + (int64_t)e * nthreads;
+        x[e] = (i < n) ? (double)v[i] : 0.0;
+    }
+    if (l1_ratio == 0.0) {                                   // enet.pyx:62-70, radius in squared-norm units
+        double s = 0, dummy = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) s += x[e] * x[e];
+        block_sum2(s, dummy, red2, nthreads);
+        const T scale = (s <= radius) ? (T)1 : (T)sqrt(s / radius);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int64_t i = threadIdx.x + (int64_t)e * nthreads;
+            if (i < n) out[dst[e]] = (T)x[e] / scale;
+        }
+        return (s <= radius) ? s : radius;
+    }
+    const double gamma = 2.0 / l1_ratio - 2.0;
+    const double R = radius / l1_ratio;
+    double tot = 0, dummy = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const double a = fabs(x[e]);
+        tot += a * (1.0 + 0.5 * gamma * a);
+    }
+    block_sum2(tot, dummy, red2, nthreads);
+    if (tot <= R) {                                          // inside the ball: copy
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int64_t i = threadIdx.x + (int64_t)e * nthreads;
+            if (i < n) out[dst[e]] = (T)x[e];
+        }
+        return tot * l1_ratio;
+    }
+    double ax[EPT], term[EPT];                              // |x| and its contribution, computed once
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        ax[e] = fabs(x[e]);
+        term[e] = ax[e] * (1.0 + 0.5 * gamma * ax[e]);
+    }
+    double level = 0.0, prev_cnt = -1.0;
+    for (int pass = 0; pass < 256; ++pass) {
+        double S = 0, S1 = 0;
+        int c0 = 0, c1 = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; e += 2) {                  // selects, no branches; two chains
+            const bool i0 = ax[e] > level, i1 = ax[e + 1] > level;
+            S += i0 ? term[e] : 0.0;
+            S1 += i1 ? term[e + 1] : 0.0;
+            c0 += i0 ? 1 : 0;
+            c1 += i1 ? 1 : 0;
+        }
+        S += S1;
+        double cnt = (double)(c0 + c1);
+        block_sum2(S, cnt, red2, nthreads);
+        if (dbg && threadIdx.x == 0) { dbg[4] = pass + 1; dbg[5] = (unsigned long long)cnt; }
+        if (cnt == prev_cnt || cnt == 0.0) break;
+        prev_cnt = cnt;
+        if (gamma != 0.0) {                                  // enet.pyx:113-117
+            const double qa = gamma * gamma * R + gamma * cnt * 0.5;
+            const double qd = 2.0 * R * gamma + cnt;
+            const double qc = R - S;
+            level = (-qd + sqrt(qd * qd - 4.0 * qa * qc)) / (2.0 * qa);
+        } else {                                             // :119
+            level = (S - R) / cnt;
+        }
+    }
+    if (dbg && threadIdx.x == 0) dbg[6] = clock64();
+    const double lT = (double)(T)level;
+    const double den = 1.0 + lT * gamma;
+    double nrm = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int64_t i = threadIdx.x + (int64_t)e * nthreads;
+        double pos = fabs(x[e]) - lT;
+        pos = pos > 0 ? pos : 0;
+        const T o = (T)(((x[e] >= 0) ? pos : -pos) / den);   // enet.pyx:121, sign(0) = +1
+        if (i < n) out[dst[e]] = o;
+        const double a = (i < n) ? fabs((double)o) : 0.0;
+        nrm += a * (l1_ratio + (1.0 - l1_ratio) * a);
+    }
+    block_sum2(nrm, dummy, red2, nthreads);
+    return nrm;
 }
 
 }  // namespace modl
