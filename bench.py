@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 K_COMP, P_FEAT, BATCH, CHUNK = 256, 10000, 256, 65536
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = 'r01_i_pmc_hbm_traffic.json'
+PMC_FILE = 'r01_j_pmc_hbm_traffic.json'
 DOM_KERNEL = {'dict_update': 'modl::bcd_block_kernel', 'code_solve': 'modl::cd_kernel', 'stats_gemm': 'modl::gemm_dense_pair_kernel<float, true',
               'code_gemm': 'modl::gemm_dense_pair_kernel<float, false', 'stats_apply': 'modl::stats_apply2_kernel'}
 
@@ -145,7 +145,7 @@ def cpu_baseline(reduction, budget_s=20.0):
     import torch
     from oracle import somf_oracle as orc
     cores = os.cpu_count() or 1
-    n_rows = 8 * BATCH
+    n_rows = 40 * BATCH                 # bounded sample: the loop below stops after budget_s seconds
     X = make_stream(n_rows, P_FEAT, 1234, torch.device('cpu')).numpy()
     pr = orc.SomfParams(n_components=K_COMP, batch_size=BATCH, reduction=reduction, code_alpha=1.0, code_l1_ratio=1,
                         comp_l1_ratio=0, learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0)
