@@ -384,9 +384,18 @@ __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const d
     double part = __builtin_fma(hmask, M[x][0], (lower && x == 0) ? 1.0 : 0.0);   // e_0 | M[:,0]
     double al_prev = 0.0, q_prev = 0.0, z_prev = 0.0;
     const d4v zero4 = {0.0, 0.0, 0.0, 0.0};
+    // coefficient rows travel one step ahead of their use: row j + 2 is requested at the top of step j (its
+    // broadcast reads land under the step's serial tail), row j + 1 is consumed from registers
+    double crow[2][kNB];
+#pragma unroll
+    for (int i = 0; i < kNB; ++i) { crow[0][i] = 0.0; crow[1][i] = Cs[1 * kNB + i]; }
 #pragma unroll
     for (int j = 0; j < kNB; ++j) {
         if (stamps && lane == 0 && (j % 8) == 0 && j > 0) stamps[8 + j / 8] = clock64();
+        if (j + 2 < kNB) {
+#pragma unroll
+            for (int i = 0; i <= j + 1; ++i) crow[j & 1][i] = Cs[(j + 2) * kNB + i];
+        }
         const double z = __builtin_fma(-al_prev, q_prev, part);
         double t, w;
         halves(z, t, w);
@@ -401,14 +410,14 @@ __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const d
             double p0 = __builtin_fma(hmask, M[x][j + 1], (lower && x == j + 1) ? 1.0 : 0.0), p1 = 0, p2 = 0, p3 = 0;
 #pragma unroll
             for (int i = 0; i < j; ++i) {
-                const double c = Cs[(j + 1) * kNB + i];
+                const double c = crow[(j + 1) & 1][i];
                 if ((i & 3) == 0) p0 -= c * Z[i];
                 else if ((i & 3) == 1) p1 -= c * Z[i];
                 else if ((i & 3) == 2) p2 -= c * Z[i];
                 else p3 -= c * Z[i];
             }
             part = (p0 + p1) + (p2 + p3);
-            q = Cs[(j + 1) * kNB + j] * z;
+            q = crow[(j + 1) & 1][j] * z;
         }
         const double sr = scr[2 * j], cap = scr[2 * j + 1];
         double y = __builtin_amdgcn_rsq(nrm);                      // v_rsq_f64
