@@ -350,10 +350,10 @@ __device__ __forceinline__ void halves(double z, double &low, double &high) {
 // recursion is bound by its INSTRUCTION COUNT (measured: a version with a shorter dependency chain but more
 // instructions was slower).  Hence:
 //   * the c_ji are wave-uniform LDS broadcast reads with static addresses (two per ds_read_b128);
-//   * the 32-lane sum of T[j] . (M T[j]) is two f64 matrix-core instructions instead of five DPP / swap
-//     stages: v_mfma_f64_16x16x4 with B = 1/2 sums lanes {i, i+16, i+32, i+48}, three adds fold the four
-//     accumulator registers, a second MFMA with B = 1 sums the four lane groups — every lane ends with the
-//     total (the products are replicated in both halves, which the 1/2 accounts for);
+//   * the products T[j][x] (M T[j])[x] are formed in BOTH halves (one v_permlane32_swap pair), so their 32-lane
+//     sum is four DPP stages inside the rows of 16 lanes plus one v_permlane16_swap — no second half swap (a
+//     variant with two f64 MFMAs doing the sum had fewer instructions but was 20 % slower: MFMA issue + hazard
+//     wait states);
 //   * alpha = min(sqrt(radius) / sqrt(|u|^2), [radius > 0]) needs no compare or select: v_rsq_f64 + one
 //     Newton step (rel. error ~1e-14), v_min_f64 (a NaN from |u|^2 <= 0 yields the other operand);
 //     radius = 0 gives alpha = 0 (enet.pyx:57), inside the ball alpha = 1 (:65);
@@ -369,7 +369,6 @@ template <typename T>
 __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const double *D2, const double *Cs,
                                              int jj_x, double budget_x, int nb, T *norm_out, double *CAout,
                                              int ca_stride, double *scr, unsigned long long *stamps = nullptr) {
-    typedef double d4v __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, x = lane & 31;
     const bool lower = lane < 32;
     double Z[kNB];
@@ -383,7 +382,6 @@ __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const d
     if (stamps && lane == 0) stamps[8] = clock64() + (unsigned long long)(rad_x * 0);
     double part = __builtin_fma(hmask, M[x][0], (lower && x == 0) ? 1.0 : 0.0);   // e_0 | M[:,0]
     double al_prev = 0.0, q_prev = 0.0, z_prev = 0.0;
-    const d4v zero4 = {0.0, 0.0, 0.0, 0.0};
     // coefficient rows travel one step ahead of their use: row j + 2 is requested at the top of step j (its
     // broadcast reads land under the step's serial tail), row j + 1 is consumed from registers
     double crow[2][kNB];
@@ -399,10 +397,14 @@ __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const d
         const double z = __builtin_fma(-al_prev, q_prev, part);
         double t, w;
         halves(z, t, w);
-        const d4v d = __builtin_amdgcn_mfma_f64_16x16x4f64(t * w, 0.5, zero4, 0, 0, 0);
-        const double fold = (d[0] + d[1]) + (d[2] + d[3]);
-        const d4v e = __builtin_amdgcn_mfma_f64_16x16x4f64(fold, 1.0, zero4, 0, 0, 0);
-        const double nrm = e[0];                           // every lane: |u_j|^2
+        double pr = t * w;                                 // both halves hold the same products
+        pr += dpp_perm<0xB1>(pr);                          // four DPP stages inside each row of 16 lanes ...
+        pr += dpp_perm<0x4E>(pr);
+        pr += dpp_perm<0x141>(pr);
+        pr += dpp_perm<0x140>(pr);
+        double r0, r1;
+        lane_swap<true>(pr, r0, r1);                       // ... and the two rows of a half
+        const double nrm = r0 + r1;                        // every lane: |u_j|^2
         // independent of this step's tail: finish S[j-1], start step j + 1
         if (j > 0) Z[j - 1] = al_prev * z_prev;
         double q = 0.0;
@@ -420,9 +422,12 @@ __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const d
             q = crow[(j + 1) & 1][j] * z;
         }
         const double sr = scr[2 * j], cap = scr[2 * j + 1];
-        double y = __builtin_amdgcn_rsq(nrm);                      // v_rsq_f64
-        y = y * (1.5 - (0.5 * nrm) * y * y);
-        const double al = __builtin_fmin(sr * y, cap);
+        const double y = __builtin_amdgcn_rsq(nrm);                // v_rsq_f64
+        const double r = __builtin_fma(-(0.5 * y), nrm * y, 0.5);  // Newton: y <- y + y (1/2 - (y/2)(nrm y))
+        const double yn = __builtin_fma(y, r, y);
+        double al;
+        const double sy = sr * yn;
+        asm("v_min_f64 %0, %1, %2" : "=v"(al) : "v"(sy), "v"(cap));   // min(NaN, cap) = cap; no canonicalising v_max
         scr[2 * kNB + 2 * j] = al;
         scr[2 * kNB + 2 * j + 1] = nrm;
         al_prev = al;
