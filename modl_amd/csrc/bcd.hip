@@ -409,16 +409,14 @@ __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const d
         if (j > 0) Z[j - 1] = al_prev * z_prev;
         double q = 0.0;
         if (j + 1 < kNB) {
-            double p0 = __builtin_fma(hmask, M[x][j + 1], (lower && x == j + 1) ? 1.0 : 0.0), p1 = 0, p2 = 0, p3 = 0;
+            double p0 = __builtin_fma(hmask, M[x][j + 1], (lower && x == j + 1) ? 1.0 : 0.0), p1 = 0;
 #pragma unroll
-            for (int i = 0; i < j; ++i) {
+            for (int i = 0; i < j; ++i) {                  // two chains: the wave is issue-bound, not latency-bound here
                 const double c = crow[(j + 1) & 1][i];
-                if ((i & 3) == 0) p0 -= c * Z[i];
-                else if ((i & 3) == 1) p1 -= c * Z[i];
-                else if ((i & 3) == 2) p2 -= c * Z[i];
-                else p3 -= c * Z[i];
+                if ((i & 1) == 0) p0 -= c * Z[i];
+                else p1 -= c * Z[i];
             }
-            part = (p0 + p1) + (p2 + p3);
+            part = p0 + p1;
             q = crow[(j + 1) & 1][j] * z;
         }
         const double sr = scr[2 * j], cap = scr[2 * j + 1];
