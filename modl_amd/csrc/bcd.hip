@@ -513,6 +513,15 @@ __global__ __launch_bounds__(256) void bcd_apply_kernel(const T *a, const double
 //       records (release / relaxed ticket / acquire, no spinning), so that (B) of the next launch reads at
 //       most kCounters records.
 // The last launch (nb == 0) only runs (A)-(D) for the final block.
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global
+// store to be acknowledged (s_waitcnt vmcnt(0)); the phases of the block kernel only hand LDS tiles to each
+// other, their global stores may stay in flight.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 constexpr int kCaStride = kNB + 2;      // LDS row stride (doubles) of the S matrix: 2-way instead of 16-way conflicts
 constexpr int kApStride = kNB + 4;      // LDS row stride (floats) of the staged a-tile
 
@@ -727,7 +736,7 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
         }
         if (st && tid == 0) st[3] = clock64();
     }
-    __syncthreads();                                                                  // ---- barrier 2
+    lds_barrier();                                                                    // ---- barrier 2
     if (st && tid == 0) st[4] = clock64();
     // ---------------------------------------------------------------- (D) apply the previous block
     // Every A-operand load of the workgroup has been consumed by (C), so the stores below cannot overtake a
@@ -758,7 +767,7 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
         }
     }
     if (fin) return;
-    __syncthreads();                                                                  // ---- barrier 3
+    lds_barrier();                                                                    // ---- barrier 3
     if (st && tid == 0) st[5] = clock64();
     // ---------------------------------------------------------------- (E) rank-32 correction, cross-wave sum
     if (worker) {
@@ -781,7 +790,7 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
                 red[(wid * RB + row) * (kNB + 1) + c] = acc[t][r];
             }
     }
-    __syncthreads();                                                                  // ---- barrier 4
+    lds_barrier();                                                                    // ---- barrier 4
     if (st && tid == 0) st[6] = clock64();
     // ---------------------------------------------------------------- (F) epilogue
     if (worker) {
@@ -802,7 +811,7 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
         }
         d2red[rg * kNB + col] = d2;
     }
-    __syncthreads();                                                                  // ---- barrier 5
+    lds_barrier();                                                                    // ---- barrier 5
     if (st && tid == 0) st[7] = clock64();
     // ---------------------------------------------------------------- (G) Gram record of this workgroup
     if (worker) {
