@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void bcd_prepare_kernel(const T *C, const int3
             }
         }
     }
-    // coefficients of the in-block recursion: coef_all[i][jj] = C[o_i', o_jj] / C[o_jj, o_jj] where i' is the
+    // coefficients of the in-block recursion: coef_all[jj][i] = C[o_i', o_jj] / C[o_jj, o_jj] where i' is the
     // i-th atom of jj's block and i < position of jj in its block (zero otherwise / for frozen atoms)
     if (m < kNB) {
         for (int jj = threadIdx.x; jj < k; jj += 256) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void bcd_prepare_kernel(const T *C, const int3
                 const T d = C[(int64_t)oj * k + oj];
                 if (d > (T)1e-20) c = (double)C[(int64_t)oi * k + oj] / (double)d;
             }
-            coef_all[(int64_t)m * k + jj] = c;
+            coef_all[(int64_t)jj * kNB + m] = c;          // [sweep position][atom of its block]: one contiguous row per step
         }
     }
 }
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_
                 const T d = C[(int64_t)oj * k + oj];
                 if (d > (T)1e-20) c = (double)C[(int64_t)oi * k + oj] / (double)d;
             }
-            coef_all[(int64_t)m * k + jj] = c;
+            coef_all[(int64_t)jj * kNB + m] = c;          // [sweep position][atom of its block]: one contiguous row per step
         }
         return;
     }
@@ -326,7 +326,9 @@ __device__ __forceinline__ bool arrive_last(unsigned int *counter, unsigned int 
 __device__ __forceinline__ void stage_coef(const double *coef_all, int k, int j0, double *Cs) {
     for (int e = threadIdx.x; e < kNB * kNB; e += blockDim.x) {
         const int i = e / kNB, j = e % kNB;
-        Cs[j * kNB + i] = (j0 + j < k) ? coef_all[(int64_t)i * k + j0 + j] : 0.0;
+        const bool ok = j0 + j < k;
+        const double v = coef_all[ok ? (int64_t)(j0 + j) * kNB + i : 0];
+        Cs[j * kNB + i] = ok ? v : 0.0;
     }
 }
 
@@ -578,24 +580,25 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
     if (has_prev) {
         if (worker) {
             const double *recs = (ngroups > 1) ? p.grec_in : p.rec_in;
+            if (st && tid == 0) st[16] = clock64();
             reduce_records<kPackStride>(recs, (ngroups > 1) ? ngroups : nwg,
                                         SinkLdsPacked{reinterpret_cast<double (*)[kNB + 1]>(Ms), D2s});
+            if (st && tid == 0) st[17] = clock64();
         } else {
             // the resolver's own inputs: recursion coefficients, atom index and norm budget of column x
             const int x = lane & 31;
             res_jj = (x < p.nb_prev) ? p.order[p.j0_prev + x] : 0;
-            double cf[kNB * kNB / 64];
+            double cf[kNB * kNB / 64];                   // Cs[j][i] = coef_all[j0_prev + j][i]: a contiguous block
 #pragma unroll
             for (int q = 0; q < kNB * kNB / 64; ++q) {
-                const int e = lane + 64 * q, i = e / kNB, j = e % kNB;
-                cf[q] = (p.j0_prev + j < k) ? p.coef_all[(int64_t)i * k + p.j0_prev + j] : 0.0;
+                const int e = lane + 64 * q, j = e / kNB;
+                const bool ok = p.j0_prev + j < k;
+                const double v = p.coef_all[ok ? (int64_t)p.j0_prev * kNB + e : 0];
+                cf[q] = ok ? v : 0.0;
             }
             res_budget = (x < p.nb_prev) ? (double)p.norm_in[res_jj] : 0.0;
 #pragma unroll
-            for (int q = 0; q < kNB * kNB / 64; ++q) {
-                const int e = lane + 64 * q, i = e / kNB, j = e % kNB;
-                Cs[j * kNB + i] = cf[q];
-            }
+            for (int q = 0; q < kNB * kNB / 64; ++q) Cs[lane + 64 * q] = cf[q];      // conflict-free
         }
     }
     __syncthreads();                                                                  // ---- barrier 1

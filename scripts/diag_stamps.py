@@ -25,4 +25,5 @@ for r in (10, 1):
             ('G Gram record', o[12] - o[7])]
     for n, v in rows:
         print('   %-56s %8d' % (n, v))
+    print('   B detail: entry -> record loads start %d, records summed + in LDS %d, barrier 1 %d' % (o[16] - o[0], o[17] - o[16], o[1] - o[17]))
     print('   resolve: setup %d  steps 0-7 %d  8-15 %d  16-23 %d  24-31+stores %d' % (o[8] - o[1], o[9] - o[8], o[10] - o[9], o[11] - o[10], o[2] - o[11]))
