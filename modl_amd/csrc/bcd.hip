@@ -237,7 +237,9 @@ __global__ __launch_bounds__(256) void bcd_gram_kernel(const T *a, const T *Dt, 
 }
 
 constexpr int kResStride = kNB * kNB + kNB;          // doubles per Gram partial / per CA record
-constexpr int kPackStride = 3 * 256 + kNB;           // fused path: tiles (0,0) (0,1) (1,1) of 16 x 16 + old norms (the Gram is symmetric)
+constexpr int kTri = 136;                            // upper triangle (with diagonal) of a 16 x 16 tile
+constexpr int kPackStride = 2 * kTri + 256 + kNB;    // fused path: triangle of tile (0,0), tile (0,1), triangle of tile (1,1), old norms: 560 doubles (the Gram is symmetric)
+__device__ __forceinline__ int tri_index(int row, int col) { return row * 16 - row * (row - 1) / 2 + (col - row); }   // row <= col
 
 // Sum n Gram records (kResStride doubles each) in a fixed order, all 256 threads of the workgroup; element
 // e = tid + 256 q goes to sink(e, sum).  Every load of a chunk of 16 records is issued before the first
@@ -285,12 +287,28 @@ struct SinkLds {
 };
 struct SinkLdsPacked {   // packed record -> full symmetric matrix
     double (*M)[kNB + 1]; double *D2;
+    static __device__ __forceinline__ void untri(int e, int &row, int &col) {
+        row = 0;
+#pragma unroll
+        for (int r = 1; r < 16; ++r)
+            if (e >= r * 16 - r * (r - 1) / 2) row = r;
+        col = row + (e - (row * 16 - row * (row - 1) / 2));
+    }
     __device__ __forceinline__ void operator()(int e, double v) const {
-        if (e >= 3 * 256) { D2[e - 3 * 256] = v; return; }
-        const int t = e >> 8, r = (e >> 4) & 15, c = e & 15;
-        const int i = (t == 2 ? 16 : 0) + r, j = (t == 0 ? 0 : 16) + c;
+        int i, j;
+        if (e < kTri) {
+            untri(e, i, j);
+        } else if (e < kTri + 256) {
+            i = (e - kTri) >> 4; j = 16 + ((e - kTri) & 15);
+        } else if (e < 2 * kTri + 256) {
+            untri(e - kTri - 256, i, j);
+            i += 16; j += 16;
+        } else {
+            D2[e - 2 * kTri - 256] = v;
+            return;
+        }
         M[i][j] = v;
-        if (t == 1) M[j][i] = v;
+        M[j][i] = v;
     }
 };
 struct SinkGlobal {
@@ -828,13 +846,16 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
 #pragma unroll
             for (int kk = 0; kk < RB / 4; ++kk)
                 g = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ai[4 * kk * (kNB + 1)], (double)aj[4 * kk * (kNB + 1)], g, 0, 0, 0);
-            const int tile = it + jt;                // 0, 1, 2
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[tile * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = g[r];
+            for (int r = 0; r < 4; ++r) {
+                const int row = (lane >> 4) + 4 * r, col = lane & 15;
+                if (it != jt) out[kTri + row * 16 + col] = g[r];                                   // tile (0,1): full
+                else if (row <= col) out[(it ? kTri + 256 : 0) + tri_index(row, col)] = g[r];        // diagonal tiles: triangle
+            }
         } else if (lane < kNB) {
             double t = 0;
             for (int gq = 0; gq < 8; ++gq) t += d2red[gq * kNB + lane];
-            out[3 * 256 + lane] = t;
+            out[2 * kTri + 256 + lane] = t;
         }
     }
     if (st && tid == 0) st[12] = clock64();
