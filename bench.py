@@ -85,6 +85,9 @@ def run_gpu(args, reduction, steps, warmup, rank, world, device, breakdown=True)
     est = DictFact(n_components=K_COMP, batch_size=BATCH, reduction=reduction, code_alpha=1.0, code_l1_ratio=1,
                    comp_l1_ratio=0, learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0)
     est.prepare(n_samples=n_rows, X=X[:K_COMP])
+    if getattr(args, 'force_reduce', False):                 # testing only: the N > 1 step with one rank
+        est._two_phase = True
+        est._force_reduce = True
 
     def run(nsteps, start_step):
         done = 0
@@ -172,6 +175,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--also-r1', action='store_true', help='also time reduction=1 (OMF) and report it under "also"')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to test the N > 1 path)')
+    ap.add_argument('--force-reduce', action='store_true',
+                    help='testing only: run the multi-GPU step (two phases + RCCL all-reduces) even with one rank')
     ap.add_argument('--share-gpu', action='store_true', help='testing only: every rank uses cuda:0 (needs --backend gloo)')
     args = ap.parse_args()
 
@@ -189,8 +194,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 or args.force_reduce:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     dt, prof, sweeps, ok, dom, prof_dom = run_gpu(args, args.reduction, args.steps, args.warmup, rank, world, device)
@@ -262,9 +268,19 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args.reduction)
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_reduce:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to C stdio, which is flushed at exit when stdout is a pipe: push it out
+        # first, so that the JSON line is the LAST line of stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.write(json.dumps(out) + '\n')
+        sys.stdout.flush()
 
 
 if __name__ == '__main__':

@@ -573,7 +573,7 @@ class DictFact(CodingMixin, BaseEstimator):
         # bulk of the B increment is summed asynchronously, under the dictionary update, and applied afterwards.
         head, toff, tn, tail_first = be.delta_split()
         work = None
-        if world > 1:
+        if world > 1 or getattr(self, '_force_reduce', False):   # (the latter: single-rank RCCL test of this path)
             if tail_first:
                 self._all_reduce(delta[toff:toff + tn])
             self._all_reduce(delta[:head])

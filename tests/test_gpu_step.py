@@ -370,3 +370,52 @@ def test_two_rank_gpu_equals_double_batch(oracle, variant):
         assert rel_fro(out[r]['B'], st.B) < 1e-9
         assert out[r]['n_iter'] == st.n_iter
     assert_array_equal(out[0]['D'], out[1]['D'])               # replicas stay bit-identical
+
+
+# ---- the same protocol over RCCL itself: one rank (a 1-GPU box), every all-reduce of the step really issued ------
+def _rccl_rank_main(rank, port, kw, X, out):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        from modl_amd import DictFact as DF
+        res = {}
+        for name in ('fused', 'rccl'):
+            est = DF(**kw)
+            if name == 'rccl':
+                est._two_phase = True
+                est._force_reduce = True                         # head all-reduce + async tail all-reduce + wait
+            est.prepare(n_samples=X.shape[0], X=X)
+            est.partial_fit(X)
+            res[name] = dict(D=est.components_, C=est.C_, B=est.B_, code=est.code_)
+        out.update(res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('red', [4, 1])
+def test_rccl_single_rank_two_phase_equals_fused(red):
+    """The multi-GPU step (phase 1, RCCL all-reduce of the head, asynchronous all-reduce of the bulk under the
+    dictionary update, apply_rest) on the nccl backend with one rank: summing over one rank is the identity, so the
+    result must equal the fused single-GPU step bit for bit — this checks stream ordering between the HIP
+    kernels and RCCL's own stream on a 1-GPU box."""
+    import socket
+    import torch.multiprocessing as mp
+    rs = np.random.RandomState(11)
+    b, steps, p, k = 64, 12, 2048, 32
+    X = (rs.randn(b * steps, 40).dot(rs.randn(40, p)) + 0.3 * rs.randn(b * steps, p)).astype(np.float32)
+    kw = dict(n_components=k, batch_size=b, reduction=red, random_state=0, learning_rate=0.9, code_alpha=0.1)
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_rank_main, args=(port, kw, X, out), nprocs=1, join=True)
+    for name in ('D', 'C', 'B', 'code'):
+        assert_array_equal(out['fused'][name], out['rccl'][name], err_msg=name)
