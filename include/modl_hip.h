@@ -286,6 +286,12 @@ int modl_somf_code_and_partials(modl_somf_plan *plan, const modl_somf_state *st,
  *   phase 2 applies it itself and it must be summed before phase 2. */
 int modl_somf_delta_split(const modl_somf_plan *plan, int64_t *head_elems, int64_t *tail_offset, int64_t *tail_elems,
                           int *tail_before_phase2);
+/* Phase 1b (per rank): when the last phase 1 wrote only the HEAD of the increment (a minibatch with a proper
+ * feature subset: the head comes from its own small product over the gathered columns), this computes the bulk,
+ * the p x k product X^T code, into d_delta[*tail_offset ..).  Call it right after STARTING the all-reduce of the
+ * head, so that the product runs while the head travels; a no-op when nothing is pending.  `bt` is the batch of
+ * the last phase 1.  modl_somf_apply_rest returns MODL_ESTATE if the bulk is still pending. */
+int modl_somf_bulk_partials(modl_somf_plan *plan, const modl_somf_batch *bt, void *d_delta, void *stream);
 /* Phase 2 (identical on every rank): C_/B_ update from d_delta with weight w /
  * b_global (B_: the sampled rows only when the increments were split), then the
  * block-coordinate dictionary update on the subset. */

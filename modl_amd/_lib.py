@@ -119,6 +119,7 @@ _sig('modl_somf_code_and_partials', C.c_int, _vp, _P(SomfState), _P(SomfBatch), 
 _sig('modl_somf_apply_and_update_dict', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
 _sig('modl_somf_step', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
 _sig('modl_somf_apply_rest', C.c_int, _vp, _P(SomfState), _vp, _vp)
+_sig('modl_somf_bulk_partials', C.c_int, _vp, _P(SomfBatch), _vp, _vp)
 _sig('modl_somf_delta_split', C.c_int, _vp, _P(_i64), _P(_i64), _P(_i64), _P(C.c_int))
 _sig('modl_somf_full_gram', C.c_int, _vp, _vp, _vp, _vp)
 _sig('modl_somf_transform', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp)

@@ -236,6 +236,9 @@ struct modl_somf_plan {
     bool stats_fused = false;          // the last phase 1 applied the statistics in its epilogues
     bool split_now = false;            // the last phase 1 wrote the compact sampled-row block (two-phase protocol)
     bool rest_pending = false;         // phase 2 left the non-sampled rows of Bt to modl_somf_apply_rest
+    bool bulk_pending = false;         // phase 1 wrote only the head of the increment (C + sampled rows of B): the
+                                       // p x k product is left to modl_somf_bulk_partials (runs under the head's all-reduce)
+    const void *bulk_cb = nullptr;     // the minibatch's code rows (compact) for that product
     double rest_beta = 0, rest_wt = 0, rest_bdiv = 1;
     int rest_replace = 0;
     int32_t step_id = 0;
@@ -459,6 +462,8 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
 
     T *ws_split = reinterpret_cast<T *>(sws.ptr);
     const size_t ws_elems = sws.bytes / sizeof(T);
+    bool head_first = false;
+    pl->bulk_pending = false;
     {   // ---- Dx, G  (dict_fact.py:588-620)
         ProfScope ps(pl, st, SEC_CODE_GEMM);
         // compaction: gather once, contract dense.  Ds = Dt[subset] (whole 1 KiB feature rows),
@@ -484,6 +489,10 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
             Dsrc = Dsb;
             if (d.Dx_agg != MODL_AGG_FULL) { Xsrc = Xsb; ldxs = s_pad; }
         }
+        // with the sampled columns of X gathered anyway, the head of the increment comes from its own small
+        // product and the p x k product is deferred (see modl_somf_bulk_partials); the stamps still tell
+        // modl_somf_apply_rest which rows phase 2 has already updated
+        head_first = pl->split_now && Xsrc == Xsb;
         const int n_prep = pa.n_norm + pa.n_rows + pa.n_cols + pa.n_code;
         if (n_prep > 0) {
             hipLaunchKernelGGL((prep_kernel<T>), dim3((unsigned)n_prep), dim3(256), 0, st, pa);
@@ -595,7 +604,22 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
             T *dC = delta, *dBs = delta + (size_t)k * k, *dB = delta + (size_t)k * k + (size_t)p * k;
             EpiStore<T> epiC{dC, k, (T)1};
             auto PC = plan_dense<T, EpiStore<T>>(Cd, Cd, k, k, b, epiC, nullptr, 0);
-            if (pl->split_now) {
+            if (head_first) {
+                // head only: [ dC | dB rows of the sampled features ] = [ code^T code | Xs^T code ]
+                DenseOperand Xso;
+                Xso.ptr = Xsb; Xso.si = 1; Xso.sk = s_pad;              // element (i = sampled feature, kk = sample)
+                EpiStore<T> epiBs{dBs, k, (T)1};
+                auto PBs = plan_dense<T, EpiStore<T>>(Xso, Cd, s, k, b, epiBs, nullptr, 0);
+                if (PC.ok && PBs.ok) {
+                    MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStore<T>, true, true, EpiStore<T>>(st, PC, PBs,
+                                                                                                            &ps.launches)));
+                    pl->bulk_pending = true;
+                    pl->bulk_cb = cb;
+                } else {
+                    head_first = false;
+                    pl->split_now = false;
+                }
+            } else if (pl->split_now) {
                 EpiStoreSplit<T> epiB{dB, k, reinterpret_cast<const int32_t *>(pl->dws + pl->off_stamp),
                                       reinterpret_cast<const int32_t *>(pl->dws + pl->off_pos), pl->step_id, dBs};
                 auto PB = plan_dense<T, EpiStoreSplit<T>>(Xo, Cd, p, k, b, epiB, nullptr, 0);
@@ -619,6 +643,35 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
             }
         }
     }
+    return MODL_OK;
+}
+
+// The p x k product X^T code of the two-phase protocol, deferred so that it runs while the head of the increment
+// is being all-reduced.
+template <typename T>
+int bulk_partials_impl(modl_somf_plan *pl, const modl_somf_batch *bt, T *delta, hipStream_t st) {
+    if (!pl->bulk_pending) return MODL_OK;
+    if (!bt || !bt->d_X || !delta) return MODL_EINVAL;
+    const int k = pl->d.k, b = bt->b;
+    const int64_t p = pl->d.p;
+    ProfScope ps(pl, st, SEC_STATS_GEMM);
+    DenseOperand Cd;
+    Cd.ptr = static_cast<const T *>(pl->bulk_cb); Cd.si = 1; Cd.sk = k;
+    DenseOperand Xo;
+    Xo.ptr = static_cast<const T *>(bt->d_X); Xo.si = 1; Xo.sk = bt->ldx;
+    T *dB = delta + (size_t)k * k + (size_t)p * k;
+    EpiStore<T> epiB{dB, k, (T)1};
+    auto PB = plan_dense<T, EpiStore<T>>(Xo, Cd, p, k, b, epiB, nullptr, 0, 512, 1, kStatBM, kStatBN);
+    if (PB.ok) {
+        DenseProblem<T, EpiStore<T>> none;                              // no first problem: zero tiles
+        none.epi = epiB;
+        MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStore<T>, true, true, EpiStore<T>, kStatBM, kStatBN, kStatBK>(
+            st, none, PB, &ps.launches)));
+    } else {
+        SplitWs sws{pl->dws + pl->off_split, pl->split_bytes};
+        MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Xo, Cd, p, k, b, epiB, sws, &ps.launches)));
+    }
+    pl->bulk_pending = false;
     return MODL_OK;
 }
 
@@ -908,8 +961,15 @@ int modl_somf_apply_and_update_dict(modl_somf_plan *pl, const modl_somf_state *s
                     phase2<double>(pl, st, bt, static_cast<const double *>(d_delta), (hipStream_t)stream));
 }
 
+int modl_somf_bulk_partials(modl_somf_plan *pl, const modl_somf_batch *bt, void *d_delta, void *stream) {
+    if (!pl) return MODL_EINVAL;
+    return DISPATCH(pl, bulk_partials_impl<float>(pl, bt, static_cast<float *>(d_delta), (hipStream_t)stream),
+                    bulk_partials_impl<double>(pl, bt, static_cast<double *>(d_delta), (hipStream_t)stream));
+}
+
 int modl_somf_apply_rest(modl_somf_plan *pl, const modl_somf_state *st, const void *d_delta, void *stream) {
     if (!pl) return MODL_EINVAL;
+    if (pl->bulk_pending) return MODL_ESTATE;                           // the bulk of the increment was never computed
     return DISPATCH(pl, apply_rest_impl<float>(pl, st, static_cast<const float *>(d_delta), (hipStream_t)stream),
                     apply_rest_impl<double>(pl, st, static_cast<const double *>(d_delta), (hipStream_t)stream));
 }

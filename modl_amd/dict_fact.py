@@ -225,6 +225,12 @@ class HipBackend:
         check(lib.modl_somf_delta_split(self.plan, C.byref(h), C.byref(o), C.byref(n), C.byref(f)), 'modl_somf_delta_split')
         return h.value, o.value, n.value, bool(f.value)
 
+    def bulk_partials(self, delta):
+        """The p x k product the last phase 1 deferred (no-op otherwise); runs under the head's all-reduce."""
+        bt, keep = self._pending
+        check(lib.modl_somf_bulk_partials(self.plan, C.byref(bt), ptr(delta), stream_ptr(self.device)),
+              'modl_somf_bulk_partials')
+
     def apply_rest(self, delta):
         st = self._state()
         check(lib.modl_somf_apply_rest(self.plan, C.byref(st), ptr(delta), stream_ptr(self.device)), 'modl_somf_apply_rest')
@@ -569,16 +575,22 @@ class DictFact(CodingMixin, BaseEstimator):
                 self._all_reduce(delta)
             be.phase2(delta)
             return
-        # What the dictionary update needs (C increment + sampled rows of the B increment) is summed first; the
-        # bulk of the B increment is summed asynchronously, under the dictionary update, and applied afterwards.
+        # What the dictionary update needs (C increment + sampled rows of the B increment: the HEAD, written by
+        # its own small product) is summed first, and the p x k product X^T code is computed WHILE the head is
+        # travelling; the bulk is then summed asynchronously, under the dictionary update, and applied afterwards.
         head, toff, tn, tail_first = be.delta_split()
-        work = None
-        if world > 1 or getattr(self, '_force_reduce', False):   # (the latter: single-rank RCCL test of this path)
-            if tail_first:
+        reduce = world > 1 or getattr(self, '_force_reduce', False)   # (the latter: single-rank RCCL test of this path)
+        work_head = work = None
+        if reduce:
+            if tail_first:                                   # no proper subset: phase 2 needs everything
                 self._all_reduce(delta[toff:toff + tn])
-            self._all_reduce(delta[:head])
-            if not tail_first:
-                work = self._all_reduce(delta[toff:toff + tn], async_op=True)
+                self._all_reduce(delta[:head])
+            else:
+                work_head = self._all_reduce(delta[:head], async_op=True)
+        be.bulk_partials(delta)
+        if work_head is not None:
+            work_head.wait()
+            work = self._all_reduce(delta[toff:toff + tn], async_op=True)
         be.phase2(delta)
         if work is not None:
             work.wait()
