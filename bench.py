@@ -50,8 +50,10 @@ def make_stream(n_rows, p, seed, device, k0=256, density=0.1, noise=0.1):
     return X
 
 
-def step_flops(k, p, b, s, sweeps):
-    """Algorithmic flops of one minibatch (SURVEY.md §8d work model, blocked dictionary update)."""
+def step_flops(k, p, b, s, sweeps, ride=False):
+    """Algorithmic flops of one minibatch (SURVEY.md §8d work model, blocked dictionary update).
+    ride: the single-GPU step with a proper feature subset — the statistics section only carries the head
+    (C increment + sampled rows of the B increment); the p x k product rides along the dictionary update's launches."""
     dx = 2.0 * b * s * k
     gram = 2.0 * k * k * s
     h0 = 2.0 * b * k * k
@@ -59,12 +61,21 @@ def step_flops(k, p, b, s, sweeps):
     c_inc = 2.0 * k * k * b
     b_inc = 2.0 * b * k * p
     bcd = 2.0 * k * k * s
+    if ride:
+        return dict(code_gemm=dx + gram, code_solve=h0 + cd, stats_gemm=c_inc + 2.0 * b * k * s,
+                    stats_apply=3.0 * (k * k + p * k), dict_update=bcd + b_inc)
     return dict(code_gemm=dx + gram, code_solve=h0 + cd, stats_gemm=c_inc + b_inc, stats_apply=3.0 * (k * k + p * k),
                 dict_update=bcd)
 
 
-def step_bytes(k, p, b, s, e=4):
+def step_bytes(k, p, b, s, e=4, ride=False):
     """Algorithmic HBM bytes per minibatch per section (read each operand once, write each result once)."""
+    if ride:                                       # B_ is read and written once by the riding product
+        return dict(code_gemm=e * (b * s + s * k + b * k + k * k),
+                    code_solve=e * (k * k + 3 * b * k),
+                    stats_gemm=e * (b * s + b * k + 2 * k * k + 2 * s * k),
+                    stats_apply=e * 3 * (k * k + p * k),
+                    dict_update=e * (k * k + 3 * s * k) + e * (b * p + b * k + 2 * (p - s) * k))
     return dict(code_gemm=e * (b * s + s * k + b * k + k * k),
                 code_solve=e * (k * k + 3 * b * k),
                 stats_gemm=e * (b * p + b * k + k * k + p * k),
@@ -204,8 +215,9 @@ def main():
     if rank == 0:
         samples = args.steps * BATCH * world
         s_mean = P_FEAT / args.reduction
-        fl = step_flops(K_COMP, P_FEAT, BATCH, s_mean, sweeps)
-        by = step_bytes(K_COMP, P_FEAT, BATCH, s_mean)
+        ride = world == 1 and args.reduction > 1 and not args.force_reduce and not os.environ.get('MODL_NO_RIDER')
+        fl = step_flops(K_COMP, P_FEAT, BATCH, s_mean, sweeps, ride=ride)
+        by = step_bytes(K_COMP, P_FEAT, BATCH, s_mean, ride=ride)
         sections = {}
         for name, e in prof.items():
             if e['calls'] == 0:

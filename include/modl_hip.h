@@ -318,6 +318,11 @@ int modl_somf_last_sweeps(modl_somf_plan *plan, int32_t *h_out, int cap, int *n_
 /* diagnostics: 32 shader-clock stamps of the last fused dictionary-update block launch, h_out[32] (synchronises the device) */
 int modl_somf_debug_stamps(modl_somf_plan *plan, unsigned long long *h_out);
 
+/* diagnostics (env MODL_GEMM_STAMPS=1): h_out[8] = shader-clock stamps of one tile of the head statistics product:
+ * [0] entry, [1] loads issued, [2] first K-tile in LDS, [3] K loop done, [4] epilogue done; [6], [7] = 100 MHz wall
+ * clock at entry / exit (synchronises the device) */
+int modl_somf_debug_gemm_stamps(modl_somf_plan *plan, unsigned long long *h_out);
+
 /* layout helpers: out[c][r] = in[r][c]  (components_ <-> Dt) */
 int modl_transpose_f32(const float *d_in, float *d_out, int64_t rows, int64_t cols, void *stream);
 int modl_transpose_f64(const double *d_in, double *d_out, int64_t rows, int64_t cols, void *stream);

@@ -124,6 +124,7 @@ _sig('modl_somf_delta_split', C.c_int, _vp, _P(_i64), _P(_i64), _P(_i64), _P(C.c
 _sig('modl_somf_full_gram', C.c_int, _vp, _vp, _vp, _vp)
 _sig('modl_somf_transform', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp)
 _sig('modl_somf_debug_stamps', C.c_int, _vp, _vp)
+_sig('modl_somf_debug_gemm_stamps', C.c_int, _vp, _vp)
 _sig('modl_somf_last_sweeps', C.c_int, _vp, _vp, C.c_int, _P(C.c_int), _vp)
 _sig('modl_somf_prof_enable', C.c_int, _vp, C.c_int)
 _sig('modl_somf_prof_get', C.c_int, _vp, _P(ProfEntry), C.c_int, _P(C.c_int))

@@ -33,6 +33,7 @@
 //  * sgd path (dict_fact.py:695-708).
 #include "enet_block.hpp"
 #include "gemm.hpp"
+#include "gemm_dense.hpp"
 #include "kernels.hpp"
 #include <type_traits>
 
@@ -563,8 +564,30 @@ struct BcdBlockArgs {
     int k, j0, nb, j0_prev, nb_prev, group;
 };
 
+// Riding along (see StatsRider in kernels.hpp): the workgroups behind the first `nslab` ones each take one 64 x 64
+// tile of the deferred statistics product.  The block kernel needs one compute unit per workgroup (registers),
+// and at the metric's shape 157 of the 256 are busy with it, mostly waiting for the resolver wave: the 79 tiles a
+// launch carries run on the other ones and are done long before the block step is.
+struct BcdRiderArgs {
+    DenseProblem<float, EpiStatsSkip<float>> P;
+    int t0 = 0, t1 = 0;             // tiles [t0, t1) of P ride with this launch
+    int nslab = 0;                  // workgroups of the block step proper
+};
+
+__device__ __forceinline__ void bcd_rider_tile(const BcdRiderArgs &r, char *smem) {
+    constexpr int BM = 64, BN = 64, BK = 32;
+    if (threadIdx.x >= 256) return;                  // the product uses four waves
+    const int id = (int)blockIdx.x - r.nslab + r.t0;
+    if (id >= r.t1) return;
+    float (*As)[BK][BM + 4] = reinterpret_cast<float (*)[BK][BM + 4]>(smem);
+    float (*Bs)[BK][BN + 4] = reinterpret_cast<float (*)[BK][BN + 4]>(smem + sizeof(float) * 2 * BK * (BM + 4));
+    const int bx = id % r.P.tn, by = id / r.P.tn;
+    gemm_dense_tile_auto<float, true, true, EpiStatsSkip<float>, BM, BN, BK>(r.P.A, r.P.B, r.P.M, r.P.N, r.P.K, r.P.kps,
+                                                                              nullptr, r.P.epi, bx, by, 0, 1, As, Bs);
+}
+
 template <int RT, int GPW>   // 32 * RT features per workgroup; GPW contraction groups (8 atoms) per worker wave
-__global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
+__global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
     constexpr int RB = 32 * RT;
     constexpr int EPT = RB / 8;                      // epilogue elements per thread
     constexpr int DLS = kNB + 4;                     // row stride of the Delta tile (16-byte aligned rows)
@@ -584,10 +607,14 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p) {
     int *flag = reinterpret_cast<int *>(Dl + RB * DLS);
     float *Ap = red;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if ((int)blockIdx.x >= rider.nslab) {
+        bcd_rider_tile(rider, smem_raw);
+        return;
+    }
     const bool worker = wid < 4;
     const bool has_prev = p.nb_prev > 0, fin = p.nb == 0;
     const int64_t f0 = (int64_t)blockIdx.x * RB;
-    const int nwg = (int)gridDim.x, gsz = p.group, ngroups = (nwg + gsz - 1) / gsz;
+    const int nwg = rider.nslab, gsz = p.group, ngroups = (nwg + gsz - 1) / gsz;
     unsigned long long *st = (p.stamps && blockIdx.x == 0 && !fin) ? p.stamps : nullptr;
     if (st && tid == 0) st[0] = clock64();
 
@@ -1145,7 +1172,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         const int RT = (s <= MODL_RT1_MAX || k > 256) ? 1 : 2;   // k > 256: 64-row tiles would spill registers
         const int nslab = fused ? (int)cdiv(s, 32 * RT) : (int)cdiv(s, kGramRows);
         const int GPW = (k <= 256) ? 8 : 16;
-        void (*blk)(BcdBlockArgs) = nullptr;
+        void (*blk)(BcdBlockArgs, BcdRiderArgs) = nullptr;
         T *DsP = reinterpret_cast<T *>(ws + L.off_Dnew), *BsP = reinterpret_cast<T *>(ws + L.off_BsP), *CPP = CP;
         if (fused) {
             blk = (RT == 1) ? (GPW == 8 ? bcd_block_kernel<1, 8> : bcd_block_kernel<1, 16>) : bcd_block_kernel<2, 8>;
@@ -1176,6 +1203,31 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             base.group = (nslab + 31) / 32 > kGroup ? (nslab + 31) / 32 : kGroup;
             base.Dt_out = reinterpret_cast<float *>(a.Dt); base.subset = a.subset;
         }
+        // deferred statistics product riding along (launches 1 .. nblk carry cdiv(tiles, nblk) tiles each)
+        BcdRiderArgs rid;
+        rid.nslab = nslab;
+        int ride_tiles = 0, ride_per = 0, ride_next = 0;
+        if (fused && a.rider) {
+            const StatsRider &R = *a.rider;
+            DenseOperand Xo, Cd;
+            Xo.ptr = R.X; Xo.si = 1; Xo.sk = R.ldx;                    // element (i = feature, kk = sample)
+            Cd.ptr = R.code; Cd.si = 1; Cd.sk = k;                     // element (i = atom, kk = sample)
+            EpiStatsSkip<float> epi{static_cast<float *>(R.Bt), k, R.stamp, R.step, (float)R.beta, (float)R.wt,
+                                    (float)R.bdiv, R.replace};
+            rid.P = plan_dense<float, EpiStatsSkip<float>>(Xo, Cd, R.p, k, R.b, epi, nullptr, 0, 512, 1, 64, 64);
+            if (rid.P.ok) {
+                ride_tiles = rid.P.tn * rid.P.tm;
+                ride_per = (int)cdiv(ride_tiles, cdiv(k, kNB));
+                a.rider->consumed = 1;
+            }
+        }
+        auto ride = [&](BcdRiderArgs &r) {                             // the next share of tiles; returns their number
+            r = rid;
+            r.t0 = ride_next;
+            r.t1 = (ride_next + ride_per < ride_tiles) ? ride_next + ride_per : ride_tiles;
+            ride_next = r.t1;
+            return r.t1 - r.t0;
+        };
         int blk_i = 0, j0_prev = 0, nb_prev = 0;
         for (int j0 = 0; j0 < k; j0 += kNB, ++blk_i) {
             const int nb = (k - j0 < kNB) ? k - j0 : kNB;
@@ -1185,7 +1237,9 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                 ba.rec_out = partial + (size_t)(blk_i & 1) * rec_half; ba.rec_in = partial + (size_t)((blk_i + 1) & 1) * rec_half;
                 ba.grec_out = gpart + (size_t)(blk_i & 1) * grec_half; ba.grec_in = gpart + (size_t)((blk_i + 1) & 1) * grec_half;
                 ba.j0 = j0; ba.nb = nb; ba.j0_prev = j0_prev; ba.nb_prev = blk_i ? nb_prev : 0;
-                hipLaunchKernelGGL(blk, dim3(nslab), dim3(320), bcd_block_lds(GPW, RT), stream, ba);
+                BcdRiderArgs r = rid;
+                const int extra = blk_i ? ride(r) : 0;                 // (launch 0 is short: no resolver)
+                hipLaunchKernelGGL(blk, dim3(nslab + extra), dim3(320), bcd_block_lds(GPW, RT), stream, ba, r);
                 MODL_LAUNCH_CHECK();
                 ++nl;
             } else {
@@ -1217,7 +1271,10 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             ba.rec_out = nullptr; ba.grec_out = nullptr;
             ba.rec_in = partial + (size_t)((blk_i + 1) & 1) * rec_half; ba.grec_in = gpart + (size_t)((blk_i + 1) & 1) * grec_half;
             ba.j0 = 0; ba.nb = 0; ba.j0_prev = j0_prev; ba.nb_prev = nb_prev;
-            hipLaunchKernelGGL(blk, dim3(nslab), dim3(320), bcd_block_lds(GPW, RT), stream, ba);
+            BcdRiderArgs r = rid;
+            ride_per = ride_tiles - ride_next;                         // whatever is left
+            const int extra = ride(r);
+            hipLaunchKernelGGL(blk, dim3(nslab + extra), dim3(320), bcd_block_lds(GPW, RT), stream, ba, r);
             MODL_LAUNCH_CHECK();
             nl += 1;
         } else {

@@ -149,6 +149,19 @@ template <typename T> struct EpiStore {          // out[m][n] = alpha * v
     T *out; int64_t ld; T alpha;
     __device__ __forceinline__ void operator()(int64_t m, int64_t n, T v) const { out[m * ld + n] = alpha * v; }
 };
+// the statistics update  out <- (1 - w) out + w v / b  as an epilogue, leaving the rows stamped `step` alone
+// (they were updated earlier from the head of the increment)
+template <typename T> struct EpiStatsSkip {
+    static constexpr bool rmw = true;
+    T *out; int64_t ld; const int32_t *stamp; int32_t step; T beta, wt, bdiv; int replace;
+    // load() is unconditional (no branch around a load: see gemm_tile_epilogue); store() skips the stamped rows
+    __device__ __forceinline__ T load(int64_t m, int64_t n) const { return out[m * ld + n]; }
+    __device__ __forceinline__ void store(int64_t m, int64_t n, T v, T old) const {
+        if (stamp[m] == step) return;
+        out[m * ld + n] = replace ? v / bdiv : old * beta + (wt * v) / bdiv;
+    }
+    __device__ __forceinline__ void operator()(int64_t m, int64_t n, T v) const { store(m, n, v, load(m, n)); }
+};
 template <typename T> struct EpiAxpby {          // out[m][n] = beta * out[m][n] + alpha * v
     T *out; int64_t ld; T alpha, beta;
     __device__ __forceinline__ void operator()(int64_t m, int64_t n, T v) const {

@@ -16,6 +16,7 @@
 // order (gemm_reduce_kernel) -> deterministic results.
 #pragma once
 #include "gemm.hpp"
+#include <type_traits>
 
 namespace modl {
 
@@ -23,6 +24,11 @@ struct DenseOperand {
     const void *ptr = nullptr;
     int64_t si = 0, sk = 0;
 };
+
+// Epilogues that read what they overwrite declare `static constexpr bool rmw = true` and split into
+// load(m, n) -> old value and store(m, n, v, old); operator() stays (split-K reduction, generic kernel).
+template <class E, class = void> struct EpiIsRmw : std::false_type {};
+template <class E> struct EpiIsRmw<E, std::void_t<decltype(E::rmw)>> : std::true_type {};
 
 template <typename T> struct Vec4;   // 16-byte vector of T
 template <> struct Vec4<float> { typedef float4 type; static constexpr int N = 4; };
@@ -36,32 +42,42 @@ struct TileLoader {
     static constexpr int NV = BI * BK / VN / 256;
     typedef typename Vec4<T>::type V;
     V r[NV];
+    unsigned msk = 0;                                 // elements outside the operand (edge tiles): stored as zeros
 
+    // Requests the tile; nothing waits here.  A tile that lies fully inside the operand (a workgroup-uniform test)
+    // is fetched with plain 16-byte loads; an edge tile element by element from clamped addresses, selecting zeros
+    // afterwards — no per-thread branches either way: a branch around a load makes the compiler wait for that
+    // load right behind it, which serialises every memory round trip of the tile.
     __device__ __forceinline__ void load(const DenseOperand &op, int64_t i0, int64_t I, int64_t k0, int64_t k_end) {
         const T *base = static_cast<const T *>(op.ptr);
+        const bool interior = (i0 + BI <= I) && (k0 + BK <= k_end);
+        if (interior) {
+            msk = 0;
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            const int e = threadIdx.x + 256 * q;
-            int il, kl;
-            if (IFAST) { il = (e % (BI / VN)) * VN; kl = e / (BI / VN); }
-            else { kl = (e % (BK / VN)) * VN; il = e / (BK / VN); }
-            const int64_t i = i0 + il, kk = k0 + kl;
-            const T *p = base + i * op.si + kk * op.sk;
-            const bool full = IFAST ? (i + VN <= I && kk < k_end) : (i < I && kk + VN <= k_end);
-            if (full) {
-                r[q] = *reinterpret_cast<const V *>(p);
-            } else {
-                T t[VN];
+            for (int q = 0; q < NV; ++q) {
+                const int e = threadIdx.x + 256 * q;
+                int il, kl;
+                if (IFAST) { il = (e % (BI / VN)) * VN; kl = e / (BI / VN); }
+                else { kl = (e % (BK / VN)) * VN; il = e / (BK / VN); }
+                r[q] = *reinterpret_cast<const V *>(base + (i0 + il) * op.si + (k0 + kl) * op.sk);
+            }
+        } else {
+            msk = 0;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int e = threadIdx.x + 256 * q;
+                int il, kl;
+                if (IFAST) { il = (e % (BI / VN)) * VN; kl = e / (BI / VN); }
+                else { kl = (e % (BK / VN)) * VN; il = e / (BK / VN); }
+                const int64_t i = i0 + il, kk = k0 + kl;
+                const T *p = base + i * op.si + kk * op.sk;
+                T *vp = reinterpret_cast<T *>(&r[q]);
 #pragma unroll
                 for (int c = 0; c < VN; ++c) {
                     const bool in = IFAST ? (i + c < I && kk < k_end) : (i < I && kk + c < k_end);
-                    t[c] = in ? p[c] : (T)0;
+                    vp[c] = *(in ? p + c : base);             // the zeros are selected in store(): nothing waits here
+                    msk |= (in ? 0u : 1u) << (q * VN + c);
                 }
-                V v;
-                T *vp = reinterpret_cast<T *>(&v);
-#pragma unroll
-                for (int c = 0; c < VN; ++c) vp[c] = t[c];
-                r[q] = v;
             }
         }
     }
@@ -69,18 +85,75 @@ struct TileLoader {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int e = threadIdx.x + 256 * q;
+            V v = r[q];
+            T *t = reinterpret_cast<T *>(&v);
+#pragma unroll
+            for (int c = 0; c < VN; ++c) t[c] = ((msk >> (q * VN + c)) & 1u) ? (T)0 : t[c];
             if (IFAST) {
                 const int il = (e % (BI / VN)) * VN, kl = e / (BI / VN);
-                *reinterpret_cast<V *>(&S[kl][il]) = r[q];
+                *reinterpret_cast<V *>(&S[kl][il]) = v;
             } else {
                 const int kl = (e % (BK / VN)) * VN, il = e / (BK / VN);
-                const T *t = reinterpret_cast<const T *>(&r[q]);
 #pragma unroll
                 for (int c = 0; c < VN; ++c) S[kl + c][il] = t[c];
             }
         }
     }
 };
+
+// Epilogue of one tile: the accumulators of this thread go through `epi` (or to the split-K partial buffer).
+template <typename T, class Epi, int BM, int BN, int RM, int RN>
+__device__ __forceinline__ void gemm_tile_epilogue(typename Mma<T>::acc_t (&acc)[RM][RN], int64_t M, int64_t N, T *partial,
+                                                   const Epi &epi, int64_t m0, int64_t n0, int bz, int nsplit) {
+    using MT = Mma<T>;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const bool direct = (nsplit == 1);
+    if constexpr (EpiIsRmw<Epi>::value) {
+        // read-modify-write epilogues: ALL the old values are requested first, then everything is stored (element by
+        // element the compiler has to keep each load behind the previous store, which might alias it)
+        if (direct) {
+            T old[RM][RN][MT::NACC];
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+#pragma unroll
+                    for (int r = 0; r < MT::NACC; ++r) {
+                        const int64_t m = m0 + wm * WM + i * MT::TM + MT::acc_row(lane, r);
+                        const int64_t n = n0 + wn * WN + j * MT::TN + MT::acc_col(lane, r);
+                        // never a branch around a load (the compiler would wait for it right there): edge elements
+                        // read a clamped, valid address and are simply not stored
+                        old[i][j][r] = epi.load(m < M ? m : M - 1, n < N ? n : N - 1);
+                    }
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+#pragma unroll
+                    for (int r = 0; r < MT::NACC; ++r) {
+                        const int64_t m = m0 + wm * WM + i * MT::TM + MT::acc_row(lane, r);
+                        const int64_t n = n0 + wn * WN + j * MT::TN + MT::acc_col(lane, r);
+                        if (m < M && n < N) epi.store(m, n, acc[i][j][r], old[i][j][r]);
+                    }
+            return;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < MT::NACC; ++r) {
+                const int64_t m = m0 + wm * WM + i * MT::TM + MT::acc_row(lane, r);
+                const int64_t n = n0 + wn * WN + j * MT::TN + MT::acc_col(lane, r);
+                if (m < M && n < N) {
+                    if (direct) epi(m, n, acc[i][j][r]);
+                    else partial[((int64_t)bz * M + m) * N + n] = acc[i][j][r];
+                }
+            }
+}
 
 // One output tile of one (possibly K-split) product.  (bx, by, bz) = tile column, tile row, split index.
 template <typename T, bool AIFAST, bool BIFAST, class Epi, int BM, int BN, int BK>
@@ -139,20 +212,172 @@ __device__ __forceinline__ void gemm_dense_tile(const DenseOperand &A, const Den
         cur ^= 1;
     }
 
-    const bool direct = (nsplit == 1);
+    gemm_tile_epilogue<T, Epi, BM, BN, RM, RN>(acc, M, N, partial, epi, m0, n0, bz, nsplit);
+}
+
+// Workgroup barrier that orders LDS traffic only (__syncthreads() also waits for every outstanding global load).
+__device__ __forceinline__ void gemm_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// The same tile for a SHORT contraction (K <= NKT * BK, no split): every K-tile of both operands is requested from
+// memory at once and waits in registers (NKT * 16 VGPRs for f32 64 x 64 x 32 tiles), so the tile costs ONE memory
+// round trip instead of one per K-tile.  With K = 256 (the minibatch) the pipelined tile above spends ~3 us per
+// K-tile waiting for its single prefetch: 26 us for a tile whose matrix-core work is 3.4 us.
+template <typename T, bool AIFAST, bool BIFAST, class Epi, int BM, int BN, int BK, int NKT>
+__device__ __forceinline__ void gemm_dense_tile_rk(const DenseOperand &A, const DenseOperand &B, int64_t M, int64_t N,
+                                                   int64_t K, const Epi &epi, int bx, int by, T (*As)[BK][BM + 4],
+                                                   T (*Bs)[BK][BN + 4], unsigned long long *dbg = nullptr) {
+    using MT = Mma<T>;
+    if (dbg && threadIdx.x == 0) { dbg[0] = clock64(); dbg[6] = wall_clock64(); }
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int RM = WM / MT::TM, RN = WN / MT::TN;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
+    typename MT::acc_t acc[RM][RN];
 #pragma unroll
     for (int i = 0; i < RM; ++i)
 #pragma unroll
         for (int j = 0; j < RN; ++j)
 #pragma unroll
-            for (int r = 0; r < MT::NACC; ++r) {
-                const int64_t m = m0 + wm * WM + i * MT::TM + MT::acc_row(lane, r);
-                const int64_t n = n0 + wn * WN + j * MT::TN + MT::acc_col(lane, r);
-                if (m < M && n < N) {
-                    if (direct) epi(m, n, acc[i][j][r]);
-                    else partial[((int64_t)bz * M + m) * N + n] = acc[i][j][r];
-                }
+            for (int r = 0; r < MT::NACC; ++r) acc[i][j][r] = 0;
+    typename MT::acc_t acc2[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < MT::NACC; ++r) acc2[i][j][r] = 0;
+    TileLoader<T, BM, BK, AIFAST> la[NKT];
+    TileLoader<T, BN, BK, BIFAST> lb[NKT];
+    // the common case — a full tile of a full-length contraction, both operands contiguous along their rows — as
+    // straight-line code: one pointer per thread and operand, every load at a constant multiple of the row stride
+    const bool plain = AIFAST && BIFAST && m0 + BM <= M && n0 + BN <= N && K == (int64_t)NKT * BK;
+    if (plain) {
+        constexpr int VN = Vec4<T>::N;
+        typedef typename Vec4<T>::type V;
+        constexpr int NVA = TileLoader<T, BM, BK, AIFAST>::NV, NVB = TileLoader<T, BN, BK, BIFAST>::NV;
+        constexpr int KA = 256 / (BM / VN), KB = 256 / (BN / VN);      // K rows covered by one pass of the 256 threads
+        const T *pa = static_cast<const T *>(A.ptr) + (m0 + (threadIdx.x % (BM / VN)) * VN) +
+                      (int64_t)(threadIdx.x / (BM / VN)) * A.sk;
+        const T *pb = static_cast<const T *>(B.ptr) + (n0 + (threadIdx.x % (BN / VN)) * VN) +
+                      (int64_t)(threadIdx.x / (BN / VN)) * B.sk;
+        const int64_t sa = (int64_t)KA * A.sk, sb = (int64_t)KB * B.sk;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+            for (int q = 0; q < NVA; ++q) la[t].r[q] = *reinterpret_cast<const V *>(pa + (int64_t)(t * NVA + q) * sa);
+#pragma unroll
+            for (int q = 0; q < NVB; ++q) lb[t].r[q] = *reinterpret_cast<const V *>(pb + (int64_t)(t * NVB + q) * sb);
+            la[t].msk = 0;
+            lb[t].msk = 0;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+            if ((int64_t)t * BK < K) {
+                la[t].load(A, m0, M, (int64_t)t * BK, K);
+                lb[t].load(B, n0, N, (int64_t)t * BK, K);
             }
+    }
+    // a read-modify-write epilogue's old values do not depend on the product: requested now, with the operands
+    constexpr bool kRmw = EpiIsRmw<Epi>::value;
+    T old[RM][RN][MT::NACC];
+    if constexpr (kRmw) {
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+#pragma unroll
+                for (int r = 0; r < MT::NACC; ++r) {
+                    const int64_t m = m0 + wm * WM + i * MT::TM + MT::acc_row(lane, r);
+                    const int64_t n = n0 + wn * WN + j * MT::TN + MT::acc_col(lane, r);
+                    old[i][j][r] = epi.load(m < M ? m : M - 1, n < N ? n : N - 1);
+                }
+    }
+    if (dbg && threadIdx.x == 0) dbg[1] = clock64();
+    const int nkt = (int)((K + BK - 1) / BK);
+    la[0].store(As[0]);
+    lb[0].store(Bs[0]);
+    gemm_lds_barrier();
+    if (dbg && threadIdx.x == 0) dbg[2] = clock64();
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+        if (t < nkt) {
+            // the next K-tile goes to the other buffer (last read in step t - 1, before that step's barrier) while the
+            // matrix cores work on this one; all fragments of a K-tile are read before its first MFMA
+            if (t + 1 < NKT && t + 1 < nkt) {
+                la[(t + 1) % NKT].store(As[(t + 1) & 1]);
+                lb[(t + 1) % NKT].store(Bs[(t + 1) & 1]);
+            }
+            constexpr int NS = BK / MT::TK;
+            T af[NS][RM], bf[NS][RN];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const int kr = u * MT::TK + MT::frag_k(lane);
+#pragma unroll
+                for (int i = 0; i < RM; ++i) af[u][i] = As[t & 1][kr][wm * WM + i * MT::TM + MT::frag_i(lane)];
+#pragma unroll
+                for (int j = 0; j < RN; ++j) bf[u][j] = Bs[t & 1][kr][wn * WN + j * MT::TN + MT::frag_i(lane)];
+            }
+            // two accumulators (even / odd k-steps): a matrix-core instruction that accumulates onto the result of
+            // the previous one waits for it (~2x its issue time, measured), two independent chains do not
+#pragma unroll
+            for (int u = 0; u < NS; ++u)
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int j = 0; j < RN; ++j) {
+                        if (u & 1) acc2[i][j] = MT::mma(af[u][i], bf[u][j], acc2[i][j]);
+                        else acc[i][j] = MT::mma(af[u][i], bf[u][j], acc[i][j]);
+                    }
+            gemm_lds_barrier();
+        }
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < MT::NACC; ++r) acc[i][j][r] += acc2[i][j][r];
+    if (dbg && threadIdx.x == 0) dbg[3] = clock64();
+    if constexpr (kRmw) {
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+#pragma unroll
+                for (int r = 0; r < MT::NACC; ++r) {
+                    const int64_t m = m0 + wm * WM + i * MT::TM + MT::acc_row(lane, r);
+                    const int64_t n = n0 + wn * WN + j * MT::TN + MT::acc_col(lane, r);
+                    if (m < M && n < N) epi.store(m, n, acc[i][j][r], old[i][j][r]);
+                }
+    } else {
+        gemm_tile_epilogue<T, Epi, BM, BN, RM, RN>(acc, M, N, static_cast<T *>(nullptr), epi, m0, n0, 0, 1);
+    }
+    if (dbg && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dbg[4] = clock64();
+        dbg[7] = wall_clock64();
+    }
+}
+
+// tile of a planned problem: the resident-K variant when the contraction is short (f32)
+template <typename T, bool AI, bool BI, class Epi, int BM, int BN, int BK>
+__device__ __forceinline__ void gemm_dense_tile_auto(const DenseOperand &A, const DenseOperand &B, int64_t M, int64_t N,
+                                                     int64_t K, int64_t kps, T *partial, const Epi &epi, int bx, int by, int bz,
+                                                     int nsplit, T (*As)[BK][BM + 4], T (*Bs)[BK][BN + 4],
+                                                     unsigned long long *dbg = nullptr) {
+    constexpr int NKT = 8;
+    if constexpr (sizeof(T) == 4) {
+        if (nsplit == 1 && K <= (int64_t)NKT * BK) {
+            gemm_dense_tile_rk<T, AI, BI, Epi, BM, BN, BK, NKT>(A, B, M, N, K, epi, bx, by, As, Bs, dbg);
+            return;
+        }
+    }
+    gemm_dense_tile<T, AI, BI, Epi, BM, BN, BK>(A, B, M, N, K, kps, partial, epi, bx, by, bz, nsplit, As, Bs);
 }
 
 template <typename T, bool AIFAST, bool BIFAST, class Epi>
@@ -175,6 +400,7 @@ template <typename T, class Epi> struct DenseProblem {
     Epi epi;
     int tn = 0, tm = 0, splits = 1;
     bool ok = false;                                  // aligned: eligible for the dense kernels
+    unsigned long long *dbg = nullptr;                // diagnostics: shader-clock stamps of the FIRST tile (resident-K variant)
 };
 
 template <typename T, class Epi>
@@ -219,8 +445,8 @@ __global__ __launch_bounds__(256) void gemm_dense_pair_kernel(DenseProblem<T, Ep
         T (*As)[BK][BM + 4] = reinterpret_cast<T (*)[BK][BM + 4]>(gd_smem);
         T (*Bs)[BK][BN + 4] = reinterpret_cast<T (*)[BK][BN + 4]>(gd_smem + sizeof(T) * 2 * BK * (BM + 4));
         const int bx = id % P0.tn, by = (id / P0.tn) % P0.tm, bz = id / (P0.tn * P0.tm);
-        gemm_dense_tile<T, AI0, BI0, Epi0, BM, BN, BK>(P0.A, P0.B, P0.M, P0.N, P0.K, P0.kps, P0.partial, P0.epi, bx, by, bz,
-                                                       P0.splits, As, Bs);
+        gemm_dense_tile_auto<T, AI0, BI0, Epi0, BM, BN, BK>(P0.A, P0.B, P0.M, P0.N, P0.K, P0.kps, P0.partial, P0.epi, bx, by,
+                                                            bz, P0.splits, As, Bs);
     } else {
         id -= t0;
         // XCD-aware order for the large problem: workgroups are dealt round-robin to the 8 XCDs (each with its
@@ -232,8 +458,8 @@ __global__ __launch_bounds__(256) void gemm_dense_pair_kernel(DenseProblem<T, Ep
         T (*As)[BKB][BM1 + 4] = reinterpret_cast<T (*)[BKB][BM1 + 4]>(gd_smem);
         T (*Bs)[BKB][BN1 + 4] = reinterpret_cast<T (*)[BKB][BN1 + 4]>(gd_smem + sizeof(T) * 2 * BKB * (BM1 + 4));
         const int bx = id % P1.tn, by = (id / P1.tn) % P1.tm, bz = id / (P1.tn * P1.tm);
-        gemm_dense_tile<T, AI1, BI1, Epi1, BM1, BN1, BKB>(P1.A, P1.B, P1.M, P1.N, P1.K, P1.kps, P1.partial, P1.epi, bx, by, bz,
-                                                         P1.splits, As, Bs);
+        gemm_dense_tile_auto<T, AI1, BI1, Epi1, BM1, BN1, BKB>(P1.A, P1.B, P1.M, P1.N, P1.K, P1.kps, P1.partial, P1.epi, bx,
+                                                               by, bz, P1.splits, As, Bs, id == 0 ? P1.dbg : nullptr);
     }
 }
 

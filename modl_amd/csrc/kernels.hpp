@@ -55,6 +55,21 @@ template <typename T>
 int launch_transpose(hipStream_t stream, const T *in, T *out, int64_t rows, int64_t cols);
 
 // ---- bcd.hip ----------------------------------------------------------------
+// Work that rides along the block launches of the fused dictionary update, on the compute units that update
+// leaves idle: the statistics update of the rows of Bt that were NOT sampled,
+//   Bt[f] <- beta Bt[f] + wt (X^T code)[f] / bdiv   for stamp[f] != step,
+// a p x k x b product whose result the dictionary update does not need.  dict_update sets `consumed` when it
+// took the work; otherwise the caller runs it on its own.
+struct StatsRider {
+    const void *X; int64_t ldx;           // minibatch rows [b][ldx]
+    const void *code;                     // [b][k] the minibatch's code rows (compact)
+    int b; int64_t p;
+    void *Bt;                             // [p][k]
+    const int32_t *stamp; int32_t step;
+    double beta, wt, bdiv; int replace;
+    int consumed;
+};
+
 template <typename T>
 struct DictUpdateArgs {
     T *Dt;                    // [p][k] dictionary, feature-major, updated in place on the subset rows
@@ -70,6 +85,7 @@ struct DictUpdateArgs {
     double comp_l1_ratio, w, step_size;
     void *ws;                 // scratch, dict_update_workspace() bytes
     size_t ws_bytes;
+    StatsRider *rider = nullptr;   // optional (f32 fused path only)
 };
 size_t dict_update_workspace(int dtype, int64_t s_max, int k);
 size_t dict_update_stamps_offset(int dtype, int64_t s_max, int k);

@@ -75,12 +75,24 @@ __global__ __launch_bounds__(256) void stats_apply2_kernel(T *C, int64_t n0, int
 
 // the same update as a GEMM epilogue (single-GPU step: the increments never travel through HBM)
 template <typename T> struct EpiStats {
+    static constexpr bool rmw = true;
     T *out; int64_t ld; T beta, wt, bdiv; int replace;
-    __device__ __forceinline__ void operator()(int64_t m, int64_t n, T v) const {
-        T *o = out + m * ld + n;
-        if (replace) *o = v / bdiv;
-        else *o = (*o) * beta + (wt * v) / bdiv;
+    __device__ __forceinline__ T load(int64_t m, int64_t n) const { return out[m * ld + n]; }   // unconditional
+    __device__ __forceinline__ void store(int64_t m, int64_t n, T v, T old) const {
+        out[m * ld + n] = replace ? v / bdiv : old * beta + (wt * v) / bdiv;
     }
+    __device__ __forceinline__ void operator()(int64_t m, int64_t n, T v) const { store(m, n, v, load(m, n)); }
+};
+
+// ... for the sampled rows only: product row m is feature rows[m]
+template <typename T> struct EpiStatsRows {
+    static constexpr bool rmw = true;
+    T *out; int64_t ld; const int32_t *rows; T beta, wt, bdiv; int replace;
+    __device__ __forceinline__ T load(int64_t m, int64_t n) const { return out[(int64_t)rows[m] * ld + n]; }
+    __device__ __forceinline__ void store(int64_t m, int64_t n, T v, T old) const {
+        out[(int64_t)rows[m] * ld + n] = replace ? v / bdiv : old * beta + (wt * v) / bdiv;
+    }
+    __device__ __forceinline__ void operator()(int64_t m, int64_t n, T v) const { store(m, n, v, load(m, n)); }
 };
 
 // Two-phase (multi-GPU) protocol with a sampled subset: the B increment is also written, for the sampled
@@ -239,11 +251,13 @@ struct modl_somf_plan {
     bool bulk_pending = false;         // phase 1 wrote only the head of the increment (C + sampled rows of B): the
                                        // p x k product is left to modl_somf_bulk_partials (runs under the head's all-reduce)
     const void *bulk_cb = nullptr;     // the minibatch's code rows (compact) for that product
+    bool ride_pending = false;         // single-GPU step: the B_ update of the rows that were not sampled rides along
+    StatsRider rider{};                // the dictionary update (see StatsRider)
     double rest_beta = 0, rest_wt = 0, rest_bdiv = 1;
     int rest_replace = 0;
     int32_t step_id = 0;
     int64_t last_s_phase1 = 0;
-    size_t off_stamp = 0, off_pos = 0;
+    size_t off_stamp = 0, off_pos = 0, off_gstamps = 0;
     unsigned prof_mask = ~0u;          // sections that record events
     std::vector<hipEvent_t> pev;       // 2 * kProfPool events
     std::vector<int> psec, plaunch;
@@ -462,8 +476,9 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
 
     T *ws_split = reinterpret_cast<T *>(sws.ptr);
     const size_t ws_elems = sws.bytes / sizeof(T);
-    bool head_first = false;
+    bool head_first = false, ride = false;
     pl->bulk_pending = false;
+    pl->ride_pending = false;
     {   // ---- Dx, G  (dict_fact.py:588-620)
         ProfScope ps(pl, st, SEC_CODE_GEMM);
         // compaction: gather once, contract dense.  Ds = Dt[subset] (whole 1 KiB feature rows),
@@ -479,9 +494,14 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         pa.n_cols = (need_sub && d.Dx_agg != MODL_AGG_FULL) ? pa.gx * b : 0;
         pa.code = code; pa.idx = d_idx; pa.codeb = codeb; pa.n_code = (cd_on_compact && d_idx) ? b : 0;
         // two-phase protocol: mark the sampled features so that the B increment can be split (see EpiStoreSplit)
-        pl->split_now = !fuse_stats && need_sub && s > 0 && s < p;
-        if (pl->split_now) pl->step_id = (pl->step_id == 0x7fffffff) ? 1 : pl->step_id + 1;
-        pa.stamp = pl->split_now ? reinterpret_cast<int32_t *>(pl->dws + pl->off_stamp) : nullptr;
+        const bool proper = need_sub && s > 0 && s < p;               // a proper subset, gathered
+        pl->split_now = !fuse_stats && proper;
+        // single-GPU step: only the sampled rows of B_ are needed by the dictionary update -> the rest of the B_
+        // update is deferred and rides along its launches
+        static const bool no_rider = getenv("MODL_NO_RIDER") != nullptr;   // (diagnostics)
+        ride = fuse_stats && proper && d.Dx_agg != MODL_AGG_FULL && !no_rider;
+        if (pl->split_now || ride) pl->step_id = (pl->step_id == 0x7fffffff) ? 1 : pl->step_id + 1;
+        pa.stamp = (pl->split_now || ride) ? reinterpret_cast<int32_t *>(pl->dws + pl->off_stamp) : nullptr;
         pa.pos = reinterpret_cast<int32_t *>(pl->dws + pl->off_pos);
         pa.step = pl->step_id;
         pl->last_s_phase1 = s;
@@ -592,11 +612,33 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
             EpiStats<T> eC{static_cast<T *>(stt->d_C), k, beta, wt, bdiv, replace};
             EpiStats<T> eB{static_cast<T *>(stt->d_Bt), k, beta, wt, bdiv, replace};
             auto PC = plan_dense<T, EpiStats<T>>(Cd, Cd, k, k, b, eC, nullptr, 0);
-            auto PB = plan_dense<T, EpiStats<T>>(Xo, Cd, p, k, b, eB, nullptr, 0, 512, 1, kStatBM, kStatBN);
-            if (PC.ok && PB.ok) {
-                MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStats<T>, true, true, EpiStats<T>, kStatBM, kStatBN, kStatBK>(
-                    st, PC, PB, &ps.launches)));
-                pl->stats_fused = true;
+            if (ride) {
+                // C_ and the SAMPLED rows of B_ now (one small paired launch over the gathered columns of X) ...
+                DenseOperand Xso;
+                Xso.ptr = Xsb; Xso.si = 1; Xso.sk = s_pad;              // element (i = sampled feature, kk = sample)
+                EpiStatsRows<T> eBs{static_cast<T *>(stt->d_Bt), k, d_subset, beta, wt, bdiv, replace};
+                auto PBs = plan_dense<T, EpiStatsRows<T>>(Xso, Cd, s, k, b, eBs, nullptr, 0);
+                static const bool gstamps = getenv("MODL_GEMM_STAMPS") != nullptr;   // (diagnostics)
+                if (gstamps) PBs.dbg = reinterpret_cast<unsigned long long *>(pl->dws + pl->off_gstamps);
+                if (PC.ok && PBs.ok) {
+                    MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStats<T>, true, true, EpiStatsRows<T>>(st, PC, PBs,
+                                                                                                                &ps.launches)));
+                    // ... the other rows while the dictionary update runs
+                    StatsRider &R = pl->rider;
+                    R.X = X; R.ldx = bt->ldx; R.code = cb; R.b = b; R.p = p; R.Bt = stt->d_Bt;
+                    R.stamp = reinterpret_cast<const int32_t *>(pl->dws + pl->off_stamp); R.step = pl->step_id;
+                    R.beta = (double)beta; R.wt = (double)wt; R.bdiv = (double)bdiv; R.replace = replace; R.consumed = 0;
+                    pl->ride_pending = true;
+                    pl->stats_fused = true;
+                }
+            }
+            if (!pl->stats_fused) {
+                auto PB = plan_dense<T, EpiStats<T>>(Xo, Cd, p, k, b, eB, nullptr, 0, 512, 1, kStatBM, kStatBN);
+                if (PC.ok && PB.ok) {
+                    MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStats<T>, true, true, EpiStats<T>, kStatBM, kStatBN,
+                                                     kStatBK>(st, PC, PB, &ps.launches)));
+                    pl->stats_fused = true;
+                }
             }
         }
         if (!pl->stats_fused) {
@@ -726,7 +768,26 @@ int phase2(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         a.s = s; a.k = k; a.optimizer = d.optimizer; a.comp_pos = d.comp_pos;
         a.comp_l1_ratio = d.comp_l1_ratio; a.w = bt->w; a.step_size = d.step_size;
         a.ws = pl->dws + pl->off_du; a.ws_bytes = pl->du_bytes;
+        a.rider = pl->ride_pending ? &pl->rider : nullptr;
         MODL_TRY(dict_update<T>(st, a, &ps.launches));
+        if (pl->ride_pending && !pl->rider.consumed) {                 // this dictionary update has no fused path
+            const StatsRider &R = pl->rider;
+            DenseOperand Xo, Cd;
+            Xo.ptr = R.X; Xo.si = 1; Xo.sk = R.ldx;
+            Cd.ptr = R.code; Cd.si = 1; Cd.sk = k;
+            EpiStatsSkip<T> epi{Bt, k, R.stamp, R.step, (T)R.beta, (T)R.wt, (T)R.bdiv, R.replace};
+            auto PB = plan_dense<T, EpiStatsSkip<T>>(Xo, Cd, p, k, R.b, epi, nullptr, 0, 512, 1, kStatBM, kStatBN);
+            if (PB.ok) {
+                DenseProblem<T, EpiStatsSkip<T>> none;
+                none.epi = epi;
+                MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStatsSkip<T>, true, true, EpiStatsSkip<T>, kStatBM, kStatBN,
+                                                 kStatBK>(st, none, PB, &ps.launches)));
+            } else {
+                SplitWs sws{pl->dws + pl->off_split, pl->split_bytes};
+                MODL_TRY((launch_gemm_dense<T, EpiStatsSkip<T>>(st, Xo, Cd, p, k, R.b, epi, sws, &ps.launches)));
+            }
+        }
+        pl->ride_pending = false;
         if (track_G) {
             if (partial_G) {
                 EpiAxpby<T> epi{static_cast<T *>(stt->d_G), k, (T)1, (T)1};
@@ -898,6 +959,7 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     pl->off_codeb = take(t * b * k);           // the minibatch's code rows
     pl->off_stamp = take(sizeof(int32_t) * p); // stamp[f] = last minibatch that sampled feature f
     pl->off_pos = take(sizeof(int32_t) * p);   // ... and its index in that minibatch's subset
+    pl->off_gstamps = take(sizeof(unsigned long long) * 8);   // diagnostics (modl_somf_debug_gemm_stamps)
     const bool per_sample = desc->G_agg == MODL_AGG_AVERAGE;
     pl->off_F = take(t * k * k * (per_sample ? b : 1));                // Cholesky factors (one per sample for G_average_)
     // split-K partial tiles: the largest split product is max(b, k) x k (Dx, Gram, C increment) with
@@ -1026,6 +1088,14 @@ int modl_somf_debug_stamps(modl_somf_plan *pl, unsigned long long *h_out) {
     MODL_HIP(hipDeviceSynchronize());
     const size_t off = modl::dict_update_stamps_offset(pl->d.dtype, pl->last_s, pl->d.k);
     MODL_HIP(hipMemcpy(h_out, pl->dws + pl->off_du + off, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return MODL_OK;
+}
+
+int modl_somf_debug_gemm_stamps(modl_somf_plan *pl, unsigned long long *h_out) {
+    // diagnostics only (MODL_GEMM_STAMPS=1): stamps of the last tile of the head product of the single-GPU step
+    if (!pl || !h_out) return MODL_EINVAL;
+    MODL_HIP(hipDeviceSynchronize());
+    MODL_HIP(hipMemcpy(h_out, pl->dws + pl->off_gstamps, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return MODL_OK;
 }
 
