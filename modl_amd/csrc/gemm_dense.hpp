@@ -228,9 +228,11 @@ __device__ __forceinline__ void gemm_lds_barrier() {
 // K-tile waiting for its single prefetch: 26 us for a tile whose matrix-core work is 3.4 us.
 template <typename T, bool AIFAST, bool BIFAST, class Epi, int BM, int BN, int BK, int NKT>
 __device__ __forceinline__ void gemm_dense_tile_rk(const DenseOperand &A, const DenseOperand &B, int64_t M, int64_t N,
-                                                   int64_t K, const Epi &epi, int bx, int by, T (*As)[BK][BM + 4],
-                                                   T (*Bs)[BK][BN + 4], unsigned long long *dbg = nullptr) {
+                                                   int64_t k_begin, int64_t k_end, T *partial, const Epi &epi, int bx, int by,
+                                                   int bz, int nsplit, T (*As)[BK][BM + 4], T (*Bs)[BK][BN + 4],
+                                                   unsigned long long *dbg = nullptr) {
     using MT = Mma<T>;
+    const int64_t K = k_end - k_begin;               // at most NKT * BK
     if (dbg && threadIdx.x == 0) { dbg[0] = clock64(); dbg[6] = wall_clock64(); }
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int RM = WM / MT::TM, RN = WN / MT::TN;
@@ -253,53 +255,61 @@ __device__ __forceinline__ void gemm_dense_tile_rk(const DenseOperand &A, const 
             for (int r = 0; r < MT::NACC; ++r) acc2[i][j][r] = 0;
     TileLoader<T, BM, BK, AIFAST> la[NKT];
     TileLoader<T, BN, BK, BIFAST> lb[NKT];
-    // the common case — a full tile of a full-length contraction, both operands contiguous along their rows — as
-    // straight-line code: one pointer per thread and operand, every load at a constant multiple of the row stride
-    const bool plain = AIFAST && BIFAST && m0 + BM <= M && n0 + BN <= N && K == (int64_t)NKT * BK;
+    // the common case — a tile inside both operands, whole K-tiles — as straight-line code: one pointer per thread and
+    // operand, every load at a constant multiple of a stride
+    const int nkt = (int)((K + BK - 1) / BK);
+    const bool plain = m0 + BM <= M && n0 + BN <= N && K % BK == 0;
     if (plain) {
         constexpr int VN = Vec4<T>::N;
         typedef typename Vec4<T>::type V;
         constexpr int NVA = TileLoader<T, BM, BK, AIFAST>::NV, NVB = TileLoader<T, BN, BK, BIFAST>::NV;
-        constexpr int KA = 256 / (BM / VN), KB = 256 / (BN / VN);      // K rows covered by one pass of the 256 threads
-        const T *pa = static_cast<const T *>(A.ptr) + (m0 + (threadIdx.x % (BM / VN)) * VN) +
-                      (int64_t)(threadIdx.x / (BM / VN)) * A.sk;
-        const T *pb = static_cast<const T *>(B.ptr) + (n0 + (threadIdx.x % (BN / VN)) * VN) +
-                      (int64_t)(threadIdx.x / (BN / VN)) * B.sk;
-        const int64_t sa = (int64_t)KA * A.sk, sb = (int64_t)KB * B.sk;
+        // thread -> (row il, k kl) of its first vector; one pass of the 256 threads covers PA k-rows (row-contiguous
+        // operand) or PA rows (k-contiguous operand)
+        constexpr int PA = AIFAST ? 256 / (BM / VN) : 256 / (BK / VN), PB = BIFAST ? 256 / (BN / VN) : 256 / (BK / VN);
+        const int ila = AIFAST ? (threadIdx.x % (BM / VN)) * VN : threadIdx.x / (BK / VN);
+        const int kla = AIFAST ? threadIdx.x / (BM / VN) : (threadIdx.x % (BK / VN)) * VN;
+        const int ilb = BIFAST ? (threadIdx.x % (BN / VN)) * VN : threadIdx.x / (BK / VN);
+        const int klb = BIFAST ? threadIdx.x / (BN / VN) : (threadIdx.x % (BK / VN)) * VN;
+        const T *pa = static_cast<const T *>(A.ptr) + (m0 + ila) * A.si + (k_begin + kla) * A.sk;
+        const T *pb = static_cast<const T *>(B.ptr) + (n0 + ilb) * B.si + (k_begin + klb) * B.sk;
+        const int64_t qa = AIFAST ? (int64_t)PA * A.sk : (int64_t)PA * A.si, ta = (int64_t)BK * A.sk;
+        const int64_t qb = BIFAST ? (int64_t)PB * B.sk : (int64_t)PB * B.si, tb = (int64_t)BK * B.sk;
 #pragma unroll
-        for (int t = 0; t < NKT; ++t) {
+        for (int t = 0; t < NKT; ++t)
+            if (t < nkt) {
 #pragma unroll
-            for (int q = 0; q < NVA; ++q) la[t].r[q] = *reinterpret_cast<const V *>(pa + (int64_t)(t * NVA + q) * sa);
+                for (int q = 0; q < NVA; ++q) la[t].r[q] = *reinterpret_cast<const V *>(pa + t * ta + q * qa);
 #pragma unroll
-            for (int q = 0; q < NVB; ++q) lb[t].r[q] = *reinterpret_cast<const V *>(pb + (int64_t)(t * NVB + q) * sb);
-            la[t].msk = 0;
-            lb[t].msk = 0;
-        }
+                for (int q = 0; q < NVB; ++q) lb[t].r[q] = *reinterpret_cast<const V *>(pb + t * tb + q * qb);
+                la[t].msk = 0;
+                lb[t].msk = 0;
+            }
     } else {
 #pragma unroll
         for (int t = 0; t < NKT; ++t)
-            if ((int64_t)t * BK < K) {
-                la[t].load(A, m0, M, (int64_t)t * BK, K);
-                lb[t].load(B, n0, N, (int64_t)t * BK, K);
+            if (t < nkt) {
+                la[t].load(A, m0, M, k_begin + (int64_t)t * BK, k_end);
+                lb[t].load(B, n0, N, k_begin + (int64_t)t * BK, k_end);
             }
     }
     // a read-modify-write epilogue's old values do not depend on the product: requested now, with the operands
     constexpr bool kRmw = EpiIsRmw<Epi>::value;
     T old[RM][RN][MT::NACC];
     if constexpr (kRmw) {
+        if (nsplit == 1) {
 #pragma unroll
-        for (int i = 0; i < RM; ++i)
+            for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int j = 0; j < RN; ++j)
+                for (int j = 0; j < RN; ++j)
 #pragma unroll
-                for (int r = 0; r < MT::NACC; ++r) {
-                    const int64_t m = m0 + wm * WM + i * MT::TM + MT::acc_row(lane, r);
-                    const int64_t n = n0 + wn * WN + j * MT::TN + MT::acc_col(lane, r);
-                    old[i][j][r] = epi.load(m < M ? m : M - 1, n < N ? n : N - 1);
-                }
+                    for (int r = 0; r < MT::NACC; ++r) {
+                        const int64_t m = m0 + wm * WM + i * MT::TM + MT::acc_row(lane, r);
+                        const int64_t n = n0 + wn * WN + j * MT::TN + MT::acc_col(lane, r);
+                        old[i][j][r] = epi.load(m < M ? m : M - 1, n < N ? n : N - 1);
+                    }
+        }
     }
     if (dbg && threadIdx.x == 0) dbg[1] = clock64();
-    const int nkt = (int)((K + BK - 1) / BK);
     la[0].store(As[0]);
     lb[0].store(Bs[0]);
     gemm_lds_barrier();
@@ -343,20 +353,23 @@ __device__ __forceinline__ void gemm_dense_tile_rk(const DenseOperand &A, const 
 #pragma unroll
             for (int r = 0; r < MT::NACC; ++r) acc[i][j][r] += acc2[i][j][r];
     if (dbg && threadIdx.x == 0) dbg[3] = clock64();
+    bool stored = false;
     if constexpr (kRmw) {
+        if (nsplit == 1) {
 #pragma unroll
-        for (int i = 0; i < RM; ++i)
+            for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int j = 0; j < RN; ++j)
+                for (int j = 0; j < RN; ++j)
 #pragma unroll
-                for (int r = 0; r < MT::NACC; ++r) {
-                    const int64_t m = m0 + wm * WM + i * MT::TM + MT::acc_row(lane, r);
-                    const int64_t n = n0 + wn * WN + j * MT::TN + MT::acc_col(lane, r);
-                    if (m < M && n < N) epi.store(m, n, acc[i][j][r], old[i][j][r]);
-                }
-    } else {
-        gemm_tile_epilogue<T, Epi, BM, BN, RM, RN>(acc, M, N, static_cast<T *>(nullptr), epi, m0, n0, 0, 1);
+                    for (int r = 0; r < MT::NACC; ++r) {
+                        const int64_t m = m0 + wm * WM + i * MT::TM + MT::acc_row(lane, r);
+                        const int64_t n = n0 + wn * WN + j * MT::TN + MT::acc_col(lane, r);
+                        if (m < M && n < N) epi.store(m, n, acc[i][j][r], old[i][j][r]);
+                    }
+            stored = true;
+        }
     }
+    if (!stored) gemm_tile_epilogue<T, Epi, BM, BN, RM, RN>(acc, M, N, partial, epi, m0, n0, bz, nsplit);
     if (dbg && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         dbg[4] = clock64();
@@ -372,8 +385,10 @@ __device__ __forceinline__ void gemm_dense_tile_auto(const DenseOperand &A, cons
                                                      unsigned long long *dbg = nullptr) {
     constexpr int NKT = 8;
     if constexpr (sizeof(T) == 4) {
-        if (nsplit == 1 && K <= (int64_t)NKT * BK) {
-            gemm_dense_tile_rk<T, AI, BI, Epi, BM, BN, BK, NKT>(A, B, M, N, K, epi, bx, by, As, Bs, dbg);
+        const int64_t k_begin = (int64_t)bz * kps, k_end = (k_begin + kps < K) ? k_begin + kps : K;
+        if (k_end - k_begin <= (int64_t)NKT * BK) {
+            gemm_dense_tile_rk<T, AI, BI, Epi, BM, BN, BK, NKT>(A, B, M, N, k_begin, k_end, partial, epi, bx, by, bz, nsplit,
+                                                                As, Bs, dbg);
             return;
         }
     }
