@@ -40,7 +40,7 @@
 namespace modl {
 
 #ifndef MODL_RT1_MAX
-#define MODL_RT1_MAX 256
+#define MODL_RT1_MAX 2048
 #endif
 constexpr int kNB = 32;            // atoms per block of the blocked path
 constexpr int kGramRows = 128;     // feature rows per Gram slab
@@ -1169,7 +1169,8 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         double *CA[2] = {Tp, Tp + kResStride};
         unsigned int *counter = reinterpret_cast<unsigned int *>(Tp + 2 * kResStride);
         const bool fused = std::is_same<T, float>::value && (k % 4 == 0) && k <= 512;
-        const int RT = (s <= MODL_RT1_MAX || k > 256) ? 1 : 2;   // k > 256: 64-row tiles would spill registers
+        static const int64_t rt1_max = getenv("MODL_RT1_MAX") ? atoll(getenv("MODL_RT1_MAX")) : MODL_RT1_MAX;   // (tuning)
+        const int RT = (s <= rt1_max || k > 256) ? 1 : 2;        // k > 256: 64-row tiles would spill registers
         const int nslab = fused ? (int)cdiv(s, 32 * RT) : (int)cdiv(s, kGramRows);
         const int GPW = (k <= 256) ? 8 : 16;
         void (*blk)(BcdBlockArgs, BcdRiderArgs) = nullptr;
@@ -1217,7 +1218,22 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             rid.P = plan_dense<float, EpiStatsSkip<float>>(Xo, Cd, R.p, k, R.b, epi, nullptr, 0, 512, 1, 64, 64);
             if (rid.P.ok) {
                 ride_tiles = rid.P.tn * rid.P.tm;
-                ride_per = (int)cdiv(ride_tiles, cdiv(k, kNB));
+                // as few carrier launches as the idle compute units allow (a tile needs a compute unit to itself for
+                // most of a block step; more tiles than free units would queue and stretch the launch)
+                static const int ride_launches = getenv("MODL_RIDER_LAUNCHES") ? atoi(getenv("MODL_RIDER_LAUNCHES")) : 0;   // (tuning)
+                static const int ncu = [] {                             // one process per GPU: queried once
+                    int dev = 0;
+                    hipDeviceProp_t prop;
+                    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                        return prop.multiProcessorCount;
+                    return 256;
+                }();
+                const int free_cu = (ncu - nslab > 64) ? ncu - nslab : 64;
+                const int nblk_all = (int)cdiv(k, kNB);
+                int carriers = ride_launches > 0 ? ride_launches : (int)cdiv(ride_tiles, free_cu);
+                if (carriers > nblk_all) carriers = nblk_all;
+                if (carriers < 1) carriers = 1;
+                ride_per = (int)cdiv(ride_tiles, carriers);
                 a.rider->consumed = 1;
             }
         }
