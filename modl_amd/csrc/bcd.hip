@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_
         if (m == 0) {
             if (threadIdx.x < kCounters) counter[threadIdx.x] = 0;
             for (int j = threadIdx.x; j < k; j += 256) {
-                norm_in[j] = comp_norm[j];
+                norm_in[j] = comp_norm[order[j]];     // in SWEEP order: the resolver reads its budgets without a dependent load
                 const T d = C[(int64_t)order[j] * k + order[j]];
                 cdiag[j] = d;
                 frozen[j] = !(d > (T)1e-20);          // dict_fact.py:681 "else do not update"
@@ -277,6 +277,39 @@ __device__ __forceinline__ void reduce_records(const double *rec, int n, Sink si
     for (int q = 0; q < NQ; ++q) {
         const int e = threadIdx.x + 256 * q;
         if (e < STRIDE) sink(e, tot[q]);
+    }
+}
+// The same sum with 16-byte loads: this thread owns elements 2 e2, 2 e2 + 1 of every record.  A wavefront's memory
+// instruction costs the address unit ~16 cycles whatever its width (measured: 4 lanes per cycle), so the 8-byte
+// version above, 12 wavefront-loads per record, kept the texture unit busy for ~6 k cycles at 32 records; this one
+// needs 5 (four worker wavefronts + the first lanes of the resolver wavefront for the tail of the record).
+// Same summation order, same bits.
+template <int STRIDE, typename Sink>
+__device__ __forceinline__ void reduce_records_v2(const double *rec, int n, int e2, bool valid, Sink sink) {
+    static_assert(STRIDE % 2 == 0, "records are read as double2");
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const d2v *base = reinterpret_cast<const d2v *>(rec) + (valid ? e2 : 0);
+    d2v tot = {0.0, 0.0};
+    for (int z0 = 0; z0 < n; z0 += 16) {
+        d2v v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int z = (z0 + u < n) ? z0 + u : n - 1;
+            v[u] = base[(int64_t)z * (STRIDE / 2)];
+        }
+        __builtin_amdgcn_sched_barrier(0);           // all requests first: one memory round trip
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            v[u].x = (z0 + u < n) ? v[u].x : 0.0;
+            v[u].y = (z0 + u < n) ? v[u].y : 0.0;
+        }
+        const d2v c = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+                      (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+        tot += c;
+    }
+    if (valid) {
+        sink(2 * e2, tot.x);
+        sink(2 * e2 + 1, tot.y);
     }
 }
 struct SinkLds {
@@ -554,7 +587,7 @@ struct BcdBlockArgs {
     double *rec_out, *grec_out;     // Gram records / group sums written by this launch
     const double *rec_in, *grec_in; // ... written by the previous launch
     const double *coef_all;
-    const float *norm_in;           // norm budgets as they were before this dictionary update
+    const float *norm_in;           // norm budgets as they were before this dictionary update, in sweep order
     float *norm_out;                // comp_norm (written by workgroup 0 only)
     float *Dt_out;                  // the real dictionary [p][k]: every applied column also goes straight back ...
     const int32_t *subset;          // ... to row subset[f] (null: identity), column order[jj]
@@ -623,27 +656,38 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRider
     int res_jj = 0;
     double res_budget = 0.0;
     if (has_prev) {
+        const double *recs = (ngroups > 1) ? p.grec_in : p.rec_in;
+        const int nrec = (ngroups > 1) ? ngroups : nwg;
+        const SinkLdsPacked rsink{reinterpret_cast<double (*)[kNB + 1]>(Ms), D2s};
         if (worker) {
-            const double *recs = (ngroups > 1) ? p.grec_in : p.rec_in;
             if (st && tid == 0) st[16] = clock64();
-            reduce_records<kPackStride>(recs, (ngroups > 1) ? ngroups : nwg,
-                                        SinkLdsPacked{reinterpret_cast<double (*)[kNB + 1]>(Ms), D2s});
+            // the recursion coefficients of the block, Cs[j][i] = coef_all[j0_prev + j][i] (a contiguous block of 1024
+            // doubles: two 16-byte loads per worker thread, requested together with the first records)
+            typedef double d2v __attribute__((ext_vector_type(2)));
+            d2v cf[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = 2 * (tid + 256 * q);
+                const bool ok = p.j0_prev + e / kNB < k;
+                cf[q] = *reinterpret_cast<const d2v *>(p.coef_all + (ok ? (int64_t)p.j0_prev * kNB + e : 0));   // (zeroed below)
+            }
+            reduce_records_v2<kPackStride>(recs, nrec, tid, true, rsink);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = 2 * (tid + 256 * q);
+                const bool ok = p.j0_prev + e / kNB < k;
+                Cs[e] = ok ? cf[q].x : 0.0;
+                Cs[e + 1] = ok ? cf[q].y : 0.0;
+            }
             if (st && tid == 0) st[17] = clock64();
         } else {
-            // the resolver's own inputs: recursion coefficients, atom index and norm budget of column x
+            // the resolver's own inputs (atom index and norm budget of column x) and the tail of the records
+            // (elements 512 ..) that the 256 worker threads do not cover
             const int x = lane & 31;
             res_jj = (x < p.nb_prev) ? p.order[p.j0_prev + x] : 0;
-            double cf[kNB * kNB / 64];                   // Cs[j][i] = coef_all[j0_prev + j][i]: a contiguous block
-#pragma unroll
-            for (int q = 0; q < kNB * kNB / 64; ++q) {
-                const int e = lane + 64 * q, j = e / kNB;
-                const bool ok = p.j0_prev + j < k;
-                const double v = p.coef_all[ok ? (int64_t)p.j0_prev * kNB + e : 0];
-                cf[q] = ok ? v : 0.0;
-            }
-            res_budget = (x < p.nb_prev) ? (double)p.norm_in[res_jj] : 0.0;
-#pragma unroll
-            for (int q = 0; q < kNB * kNB / 64; ++q) Cs[lane + 64 * q] = cf[q];      // conflict-free
+            const float budget_raw = p.norm_in[(x < p.nb_prev) ? p.j0_prev + x : 0];
+            reduce_records_v2<kPackStride>(recs, nrec, 256 + lane, 256 + lane < kPackStride / 2, rsink);
+            res_budget = (x < p.nb_prev) ? (double)budget_raw : 0.0;
         }
     }
     __syncthreads();                                                                  // ---- barrier 1
@@ -890,9 +934,10 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRider
         const int g = (int)blockIdx.x / gsz;
         const int gsize = (nwg - g * gsz < gsz) ? nwg - g * gsz : gsz;
         if (!arrive_last(p.counter + 1 + g, (unsigned int)gsize, flag)) return;
-        if (worker)
-            reduce_records<kPackStride>(p.rec_out + (int64_t)g * gsz * kPackStride, gsize,
-                                        SinkGlobal{p.grec_out + (int64_t)g * kPackStride});
+        const double *grecs = p.rec_out + (int64_t)g * gsz * kPackStride;
+        const SinkGlobal gsink{p.grec_out + (int64_t)g * kPackStride};
+        if (worker) reduce_records_v2<kPackStride>(grecs, gsize, tid, true, gsink);
+        else reduce_records_v2<kPackStride>(grecs, gsize, 256 + lane, 256 + lane < kPackStride / 2, gsink);
     }
 }
 
