@@ -597,10 +597,10 @@ struct BcdBlockArgs {
     int k, j0, nb, j0_prev, nb_prev, group;
 };
 
-// Riding along (see StatsRider in kernels.hpp): the workgroups behind the first `nslab` ones each take one 64 x 64
+// Riding along (see StatsRider in kernels.hpp): the workgroups behind the first `nslab` ones each take one 32 x 32
 // tile of the deferred statistics product.  The block kernel needs one compute unit per workgroup (registers),
-// and at the metric's shape 157 of the 256 are busy with it, mostly waiting for the resolver wave: the 79 tiles a
-// launch carries run on the other ones and are done long before the block step is.
+// and at the metric's shape (s = 1000) 32 of the 256 are busy with it, mostly waiting for the resolver wave: the
+// tiles a launch carries run on the other ones, a few microseconds each, and are done before the block step is.
 struct BcdRiderArgs {
     DenseProblem<float, EpiStatsSkip<float>> P;
     int t0 = 0, t1 = 0;             // tiles [t0, t1) of P ride with this launch
@@ -608,15 +608,10 @@ struct BcdRiderArgs {
 };
 
 __device__ __forceinline__ void bcd_rider_tile(const BcdRiderArgs &r, char *smem) {
-    constexpr int BM = 64, BN = 64, BK = 32;
     if (threadIdx.x >= 256) return;                  // the product uses four waves
     const int id = (int)blockIdx.x - r.nslab + r.t0;
     if (id >= r.t1) return;
-    float (*As)[BK][BM + 4] = reinterpret_cast<float (*)[BK][BM + 4]>(smem);
-    float (*Bs)[BK][BN + 4] = reinterpret_cast<float (*)[BK][BN + 4]>(smem + sizeof(float) * 2 * BK * (BM + 4));
-    const int bx = id % r.P.tn, by = id / r.P.tn;
-    gemm_dense_tile_auto<float, true, true, EpiStatsSkip<float>, BM, BN, BK>(r.P.A, r.P.B, r.P.M, r.P.N, r.P.K, r.P.kps,
-                                                                              nullptr, r.P.epi, bx, by, 0, 1, As, Bs);
+    gemm_stats_tile<EpiStatsSkip<float>>(r.P, id, smem);     // the very tile of gemm_stats_pair_kernel: same bits
 }
 
 template <int RT, int GPW>   // 32 * RT features per workgroup; GPW contraction groups (8 atoms) per worker wave
@@ -1260,8 +1255,8 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             Cd.ptr = R.code; Cd.si = 1; Cd.sk = k;                     // element (i = atom, kk = sample)
             EpiStatsSkip<float> epi{static_cast<float *>(R.Bt), k, R.stamp, R.step, (float)R.beta, (float)R.wt,
                                     (float)R.bdiv, R.replace};
-            rid.P = plan_dense<float, EpiStatsSkip<float>>(Xo, Cd, R.p, k, R.b, epi, nullptr, 0, 512, 1, 64, 64);
-            if (rid.P.ok) {
+            rid.P = plan_stats<EpiStatsSkip<float>>(Xo, Cd, R.p, k, R.b, epi);
+            if (rid.P.ok && R.p > 0) {
                 ride_tiles = rid.P.tn * rid.P.tm;
                 // as few carrier launches as the idle compute units allow (a tile needs a compute unit to itself for
                 // most of a block step; more tiles than free units would queue and stretch the launch)

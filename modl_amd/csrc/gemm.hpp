@@ -38,6 +38,19 @@ template <> struct Mma<float> {
     static __device__ __forceinline__ int acc_row(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
     static __device__ __forceinline__ int acc_col(int lane, int) { return lane & 31; }
 };
+// 16 x 16 x 4 f32 tiles: a quarter of the work of the 32 x 32 x 2 tile per instruction stream, for products whose
+// 64 x 64 workgroup tiles would leave most of the chip idle (the statistics products: K = minibatch)
+struct Mma16f {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static constexpr int TM = 16, TN = 16, TK = 4, NACC = 4;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int frag_i(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int frag_k(int lane) { return lane >> 4; }
+    static __device__ __forceinline__ int acc_row(int lane, int r) { return 4 * (lane >> 4) + r; }
+    static __device__ __forceinline__ int acc_col(int lane, int) { return lane & 15; }
+};
 template <> struct Mma<double> {
     typedef double acc_t __attribute__((ext_vector_type(4)));
     static constexpr int TM = 16, TN = 16, TK = 4, NACC = 4;

@@ -102,10 +102,9 @@ struct TileLoader {
 };
 
 // Epilogue of one tile: the accumulators of this thread go through `epi` (or to the split-K partial buffer).
-template <typename T, class Epi, int BM, int BN, int RM, int RN>
-__device__ __forceinline__ void gemm_tile_epilogue(typename Mma<T>::acc_t (&acc)[RM][RN], int64_t M, int64_t N, T *partial,
+template <typename T, class Epi, int BM, int BN, int RM, int RN, class MT = Mma<T>>
+__device__ __forceinline__ void gemm_tile_epilogue(typename MT::acc_t (&acc)[RM][RN], int64_t M, int64_t N, T *partial,
                                                    const Epi &epi, int64_t m0, int64_t n0, int bz, int nsplit) {
-    using MT = Mma<T>;
     constexpr int WM = BM / 2, WN = BN / 2;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -226,12 +225,11 @@ __device__ __forceinline__ void gemm_lds_barrier() {
 // memory at once and waits in registers (NKT * 16 VGPRs for f32 64 x 64 x 32 tiles), so the tile costs ONE memory
 // round trip instead of one per K-tile.  With K = 256 (the minibatch) the pipelined tile above spends ~3 us per
 // K-tile waiting for its single prefetch: 26 us for a tile whose matrix-core work is 3.4 us.
-template <typename T, bool AIFAST, bool BIFAST, class Epi, int BM, int BN, int BK, int NKT>
+template <typename T, bool AIFAST, bool BIFAST, class Epi, int BM, int BN, int BK, int NKT, class MT = Mma<T>>
 __device__ __forceinline__ void gemm_dense_tile_rk(const DenseOperand &A, const DenseOperand &B, int64_t M, int64_t N,
                                                    int64_t k_begin, int64_t k_end, T *partial, const Epi &epi, int bx, int by,
                                                    int bz, int nsplit, T (*As)[BK][BM + 4], T (*Bs)[BK][BN + 4],
                                                    unsigned long long *dbg = nullptr) {
-    using MT = Mma<T>;
     const int64_t K = k_end - k_begin;               // at most NKT * BK
     if (dbg && threadIdx.x == 0) { dbg[0] = clock64(); dbg[6] = wall_clock64(); }
     constexpr int WM = BM / 2, WN = BN / 2;
@@ -369,7 +367,7 @@ __device__ __forceinline__ void gemm_dense_tile_rk(const DenseOperand &A, const 
             stored = true;
         }
     }
-    if (!stored) gemm_tile_epilogue<T, Epi, BM, BN, RM, RN>(acc, M, N, partial, epi, m0, n0, bz, nsplit);
+    if (!stored) gemm_tile_epilogue<T, Epi, BM, BN, RM, RN, MT>(acc, M, N, partial, epi, m0, n0, bz, nsplit);
     if (dbg && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         dbg[4] = clock64();
@@ -520,6 +518,63 @@ int launch_gemm_dense_pair(hipStream_t stream, const DenseProblem<T, Epi0> &P0, 
         MODL_LAUNCH_CHECK();
         if (launches) ++*launches;
     }
+    return MODL_OK;
+}
+
+// ---- the statistics products (f32, K = minibatch <= 256, both operands contiguous along their rows) ------------
+// 32 x 32 workgroup tiles of v_mfma_f32_16x16x4 (one 16 x 16 tile per wavefront) through the resident-K tile: four
+// times the workgroups of the 64 x 64 tiling and a quarter of the matrix-core work per wavefront.  These products
+// are latency-bound per tile, not throughput-bound (the head of the increment is 80 tiles of 64 x 64 on a
+// 256-CU chip), so the tile's critical path is what counts.  Same pairing / XCD renumbering as above.
+constexpr int kStatsTile = 32, kStatsBK = 32, kStatsNKT = 8;
+
+template <class Epi>
+__device__ __forceinline__ void gemm_stats_tile(const DenseProblem<float, Epi> &P, int id, char *smem,
+                                                unsigned long long *dbg = nullptr) {
+    constexpr int B = kStatsTile, BK = kStatsBK;
+    float (*As)[BK][B + 4] = reinterpret_cast<float (*)[BK][B + 4]>(smem);
+    float (*Bs)[BK][B + 4] = reinterpret_cast<float (*)[BK][B + 4]>(smem + sizeof(float) * 2 * BK * (B + 4));
+    const int bx = id % P.tn, by = id / P.tn;
+    gemm_dense_tile_rk<float, true, true, Epi, B, B, BK, kStatsNKT, Mma16f>(P.A, P.B, P.M, P.N, 0, P.K, nullptr, P.epi, bx, by,
+                                                                            0, 1, As, Bs, dbg);
+}
+constexpr size_t kStatsLds = sizeof(float) * 2 * kStatsBK * (kStatsTile + 4) * 2;
+
+template <class Epi0, class Epi1>
+__global__ __launch_bounds__(256) void gemm_stats_pair_kernel(DenseProblem<float, Epi0> P0, DenseProblem<float, Epi1> P1) {
+    __shared__ __attribute__((aligned(16))) char smem[kStatsLds];
+    int id = (int)blockIdx.x;
+    const int t0 = P0.tn * P0.tm;
+    if (id < t0) {
+        gemm_stats_tile<Epi0>(P0, id, smem);
+    } else {
+        id -= t0;
+        const int t1 = P1.tn * P1.tm, chunk = (t1 + 7) / 8;               // XCD-aware order, as in gemm_dense_pair_kernel
+        id = (id % 8) * chunk + id / 8;
+        if (id >= t1) return;
+        gemm_stats_tile<Epi1>(P1, id, smem, id == 0 ? P1.dbg : nullptr);
+    }
+}
+
+// eligible: f32 (the only instantiation), K <= 256, both operands row-contiguous and aligned (plan with 32 x 32 tiles)
+template <class Epi>
+DenseProblem<float, Epi> plan_stats(const DenseOperand &A, const DenseOperand &B, int64_t M, int64_t N, int64_t K,
+                                    const Epi &epi) {
+    DenseProblem<float, Epi> P;
+    if (M > 0 && N > 0) P = plan_dense<float, Epi>(A, B, M, N, K, epi, nullptr, 0, 512, 1, kStatsTile, kStatsTile);
+    P.epi = epi;
+    P.ok = (M <= 0 || N <= 0) || (P.ok && A.si == 1 && B.si == 1 && K <= (int64_t)kStatsNKT * kStatsBK);
+    return P;
+}
+
+template <class Epi0, class Epi1>
+int launch_gemm_stats_pair(hipStream_t stream, const DenseProblem<float, Epi0> &P0, const DenseProblem<float, Epi1> &P1,
+                           int *launches = nullptr) {
+    const int total = P0.tn * P0.tm + 8 * ((P1.tn * P1.tm + 7) / 8);
+    if (total <= 0) return MODL_OK;
+    hipLaunchKernelGGL((gemm_stats_pair_kernel<Epi0, Epi1>), dim3((unsigned)total), dim3(256), 0, stream, P0, P1);
+    MODL_LAUNCH_CHECK();
+    if (launches) ++*launches;
     return MODL_OK;
 }
 

@@ -436,6 +436,37 @@ int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride
     return MODL_OK;
 }
 
+// Two statistics products (contraction over the b samples of the minibatch, both operands contiguous along their
+// rows) in ONE launch; M0 == 0: only the second.  f32 with b <= 256 goes through the 32 x 32 / 16x16x4 tiling
+// (gemm_stats_pair_kernel), anything else through the generic pair kernel or, unaligned, the gather kernel.  Every
+// statistics product of the step comes through here, so that the fused, the two-phase and the riding variants of the
+// same product sum in the same order (bit-identical results).
+template <typename T, class Epi0, class Epi1>
+int stats_pair(hipStream_t st, const DenseOperand &A0, const DenseOperand &B0, int64_t M0, int64_t N0, const Epi0 &e0,
+               const DenseOperand &A1, const DenseOperand &B1, int64_t M1, int64_t N1, const Epi1 &e1, int64_t K,
+               const SplitWs &sws, int *launches, unsigned long long *dbg = nullptr) {
+    if constexpr (std::is_same<T, float>::value) {
+        auto P0 = plan_stats<Epi0>(A0, B0, M0, N0, K, e0);
+        auto P1 = plan_stats<Epi1>(A1, B1, M1, N1, K, e1);
+        if (P0.ok && P1.ok) {
+            P1.dbg = dbg;
+            return launch_gemm_stats_pair<Epi0, Epi1>(st, P0, P1, launches);
+        }
+    }
+    DenseProblem<T, Epi0> P0;
+    P0.epi = e0;
+    bool ok0 = true;
+    if (M0 > 0) {
+        P0 = plan_dense<T, Epi0>(A0, B0, M0, N0, K, e0, nullptr, 0);
+        ok0 = P0.ok;
+    }
+    auto P1 = plan_dense<T, Epi1>(A1, B1, M1, N1, K, e1, nullptr, 0, 512, 1, kStatBM, kStatBN);
+    if (ok0 && P1.ok)
+        return launch_gemm_dense_pair<T, true, true, Epi0, true, true, Epi1, kStatBM, kStatBN, kStatBK>(st, P0, P1, launches);
+    if (M0 > 0) MODL_TRY((launch_gemm_dense<T, Epi0>(st, A0, B0, M0, N0, K, e0, sws, launches)));
+    return launch_gemm_dense<T, Epi1>(st, A1, B1, M1, N1, K, e1, sws, launches);
+}
+
 // fuse_stats: apply the statistics update in the epilogue of the increment products (single-GPU step)
 template <typename T>
 int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch *bt, T *delta, hipStream_t st,
@@ -605,83 +636,47 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         DenseOperand Xo;
         Xo.ptr = X; Xo.si = 1; Xo.sk = bt->ldx;                         // element (i = feature, kk = sample)
         pl->stats_fused = false;
+        DenseOperand Xso;
+        Xso.ptr = Xsb; Xso.si = 1; Xso.sk = s_pad;                      // element (i = sampled feature, kk = sample)
         if (fuse_stats) {
             if (!stt->d_Bt || !stt->d_C || bt->b_global <= 0) return MODL_EINVAL;
             const int replace = d.optimizer == MODL_OPT_SGD;
             const T beta = (T)(1.0 - bt->w), wt = (T)bt->w, bdiv = (T)bt->b_global;
             EpiStats<T> eC{static_cast<T *>(stt->d_C), k, beta, wt, bdiv, replace};
-            EpiStats<T> eB{static_cast<T *>(stt->d_Bt), k, beta, wt, bdiv, replace};
-            auto PC = plan_dense<T, EpiStats<T>>(Cd, Cd, k, k, b, eC, nullptr, 0);
             if (ride) {
                 // C_ and the SAMPLED rows of B_ now (one small paired launch over the gathered columns of X) ...
-                DenseOperand Xso;
-                Xso.ptr = Xsb; Xso.si = 1; Xso.sk = s_pad;              // element (i = sampled feature, kk = sample)
                 EpiStatsRows<T> eBs{static_cast<T *>(stt->d_Bt), k, d_subset, beta, wt, bdiv, replace};
-                auto PBs = plan_dense<T, EpiStatsRows<T>>(Xso, Cd, s, k, b, eBs, nullptr, 0);
                 static const bool gstamps = getenv("MODL_GEMM_STAMPS") != nullptr;   // (diagnostics)
-                if (gstamps) PBs.dbg = reinterpret_cast<unsigned long long *>(pl->dws + pl->off_gstamps);
-                if (PC.ok && PBs.ok) {
-                    MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStats<T>, true, true, EpiStatsRows<T>>(st, PC, PBs,
-                                                                                                                &ps.launches)));
-                    // ... the other rows while the dictionary update runs
-                    StatsRider &R = pl->rider;
-                    R.X = X; R.ldx = bt->ldx; R.code = cb; R.b = b; R.p = p; R.Bt = stt->d_Bt;
-                    R.stamp = reinterpret_cast<const int32_t *>(pl->dws + pl->off_stamp); R.step = pl->step_id;
-                    R.beta = (double)beta; R.wt = (double)wt; R.bdiv = (double)bdiv; R.replace = replace; R.consumed = 0;
-                    pl->ride_pending = true;
-                    pl->stats_fused = true;
-                }
+                MODL_TRY((stats_pair<T>(st, Cd, Cd, k, k, eC, Xso, Cd, s, k, eBs, b, sws, &ps.launches,
+                                        gstamps ? reinterpret_cast<unsigned long long *>(pl->dws + pl->off_gstamps) : nullptr)));
+                // ... the other rows while the dictionary update runs
+                StatsRider &R = pl->rider;
+                R.X = X; R.ldx = bt->ldx; R.code = cb; R.b = b; R.p = p; R.Bt = stt->d_Bt;
+                R.stamp = reinterpret_cast<const int32_t *>(pl->dws + pl->off_stamp); R.step = pl->step_id;
+                R.beta = (double)beta; R.wt = (double)wt; R.bdiv = (double)bdiv; R.replace = replace; R.consumed = 0;
+                pl->ride_pending = true;
+            } else {
+                EpiStats<T> eB{static_cast<T *>(stt->d_Bt), k, beta, wt, bdiv, replace};
+                MODL_TRY((stats_pair<T>(st, Cd, Cd, k, k, eC, Xo, Cd, p, k, eB, b, sws, &ps.launches)));
             }
-            if (!pl->stats_fused) {
-                auto PB = plan_dense<T, EpiStats<T>>(Xo, Cd, p, k, b, eB, nullptr, 0, 512, 1, kStatBM, kStatBN);
-                if (PC.ok && PB.ok) {
-                    MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStats<T>, true, true, EpiStats<T>, kStatBM, kStatBN,
-                                                     kStatBK>(st, PC, PB, &ps.launches)));
-                    pl->stats_fused = true;
-                }
-            }
-        }
-        if (!pl->stats_fused) {
+            pl->stats_fused = true;
+        } else {
             // layout of the increment buffer: [ dC (k*k) | dB rows of the sampled features, compact (p*k slots) | dB (p*k) ]
             T *dC = delta, *dBs = delta + (size_t)k * k, *dB = delta + (size_t)k * k + (size_t)p * k;
             EpiStore<T> epiC{dC, k, (T)1};
-            auto PC = plan_dense<T, EpiStore<T>>(Cd, Cd, k, k, b, epiC, nullptr, 0);
             if (head_first) {
                 // head only: [ dC | dB rows of the sampled features ] = [ code^T code | Xs^T code ]
-                DenseOperand Xso;
-                Xso.ptr = Xsb; Xso.si = 1; Xso.sk = s_pad;              // element (i = sampled feature, kk = sample)
                 EpiStore<T> epiBs{dBs, k, (T)1};
-                auto PBs = plan_dense<T, EpiStore<T>>(Xso, Cd, s, k, b, epiBs, nullptr, 0);
-                if (PC.ok && PBs.ok) {
-                    MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStore<T>, true, true, EpiStore<T>>(st, PC, PBs,
-                                                                                                            &ps.launches)));
-                    pl->bulk_pending = true;
-                    pl->bulk_cb = cb;
-                } else {
-                    head_first = false;
-                    pl->split_now = false;
-                }
+                MODL_TRY((stats_pair<T>(st, Cd, Cd, k, k, epiC, Xso, Cd, s, k, epiBs, b, sws, &ps.launches)));
+                pl->bulk_pending = true;
+                pl->bulk_cb = cb;
             } else if (pl->split_now) {
                 EpiStoreSplit<T> epiB{dB, k, reinterpret_cast<const int32_t *>(pl->dws + pl->off_stamp),
                                       reinterpret_cast<const int32_t *>(pl->dws + pl->off_pos), pl->step_id, dBs};
-                auto PB = plan_dense<T, EpiStoreSplit<T>>(Xo, Cd, p, k, b, epiB, nullptr, 0);
-                if (PC.ok && PB.ok) {
-                    MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStore<T>, true, true, EpiStoreSplit<T>>(st, PC, PB,
-                                                                                                                 &ps.launches)));
-                } else {
-                    pl->split_now = false;
-                }
-            }
-            if (!pl->split_now) {
+                MODL_TRY((stats_pair<T>(st, Cd, Cd, k, k, epiC, Xo, Cd, p, k, epiB, b, sws, &ps.launches)));
+            } else {
                 EpiStore<T> epiB{dB, k, (T)1};
-                auto PB = plan_dense<T, EpiStore<T>>(Xo, Cd, p, k, b, epiB, nullptr, 0, 512, 1, kStatBM, kStatBN);
-                if (PC.ok && PB.ok) {
-                    MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStore<T>, true, true, EpiStore<T>, kStatBM, kStatBN, kStatBK>(
-                        st, PC, PB, &ps.launches)));
-                } else {
-                    MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Cd, Cd, k, k, b, epiC, sws, &ps.launches)));
-                    MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Xo, Cd, p, k, b, epiB, sws, &ps.launches)));
-                }
+                MODL_TRY((stats_pair<T>(st, Cd, Cd, k, k, epiC, Xo, Cd, p, k, epiB, b, sws, &ps.launches)));
             }
         }
     }
@@ -703,16 +698,8 @@ int bulk_partials_impl(modl_somf_plan *pl, const modl_somf_batch *bt, T *delta, 
     Xo.ptr = static_cast<const T *>(bt->d_X); Xo.si = 1; Xo.sk = bt->ldx;
     T *dB = delta + (size_t)k * k + (size_t)p * k;
     EpiStore<T> epiB{dB, k, (T)1};
-    auto PB = plan_dense<T, EpiStore<T>>(Xo, Cd, p, k, b, epiB, nullptr, 0, 512, 1, kStatBM, kStatBN);
-    if (PB.ok) {
-        DenseProblem<T, EpiStore<T>> none;                              // no first problem: zero tiles
-        none.epi = epiB;
-        MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStore<T>, true, true, EpiStore<T>, kStatBM, kStatBN, kStatBK>(
-            st, none, PB, &ps.launches)));
-    } else {
-        SplitWs sws{pl->dws + pl->off_split, pl->split_bytes};
-        MODL_TRY((launch_gemm_dense<T, EpiStore<T>>(st, Xo, Cd, p, k, b, epiB, sws, &ps.launches)));
-    }
+    SplitWs sws{pl->dws + pl->off_split, pl->split_bytes};
+    MODL_TRY((stats_pair<T>(st, Cd, Cd, 0, 0, epiB, Xo, Cd, p, k, epiB, b, sws, &ps.launches)));
     pl->bulk_pending = false;
     return MODL_OK;
 }
@@ -776,16 +763,8 @@ int phase2(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
             Xo.ptr = R.X; Xo.si = 1; Xo.sk = R.ldx;
             Cd.ptr = R.code; Cd.si = 1; Cd.sk = k;
             EpiStatsSkip<T> epi{Bt, k, R.stamp, R.step, (T)R.beta, (T)R.wt, (T)R.bdiv, R.replace};
-            auto PB = plan_dense<T, EpiStatsSkip<T>>(Xo, Cd, p, k, R.b, epi, nullptr, 0, 512, 1, kStatBM, kStatBN);
-            if (PB.ok) {
-                DenseProblem<T, EpiStatsSkip<T>> none;
-                none.epi = epi;
-                MODL_TRY((launch_gemm_dense_pair<T, true, true, EpiStatsSkip<T>, true, true, EpiStatsSkip<T>, kStatBM, kStatBN,
-                                                 kStatBK>(st, none, PB, &ps.launches)));
-            } else {
-                SplitWs sws{pl->dws + pl->off_split, pl->split_bytes};
-                MODL_TRY((launch_gemm_dense<T, EpiStatsSkip<T>>(st, Xo, Cd, p, k, R.b, epi, sws, &ps.launches)));
-            }
+            SplitWs sws{pl->dws + pl->off_split, pl->split_bytes};
+            MODL_TRY((stats_pair<T>(st, Cd, Cd, 0, 0, epi, Xo, Cd, p, k, epi, R.b, sws, &ps.launches)));
         }
         pl->ride_pending = false;
         if (track_G) {
