@@ -526,7 +526,7 @@ int launch_gemm_dense_pair(hipStream_t stream, const DenseProblem<T, Epi0> &P0, 
 // times the workgroups of the 64 x 64 tiling and a quarter of the matrix-core work per wavefront.  These products
 // are latency-bound per tile, not throughput-bound (the head of the increment is 80 tiles of 64 x 64 on a
 // 256-CU chip), so the tile's critical path is what counts.  Same pairing / XCD renumbering as above.
-constexpr int kStatsTile = 32, kStatsBK = 32, kStatsNKT = 8;
+constexpr int kStatsTile = 32, kStatsBK = 64, kStatsNKT = 4;
 
 template <class Epi>
 __device__ __forceinline__ void gemm_stats_tile(const DenseProblem<float, Epi> &P, int id, char *smem,
