@@ -16,11 +16,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   DBS="$DBS $(find /tmp/w/pmc_$c -name '*.db' | head -1)"
 done
 python3 $R/scripts/pmc_summary.py $DBS --json $OUT/${TAG}_pmc_hbm_traffic.json > $OUT/${TAG}_pmc_hbm_traffic.txt 2>&1
-DBS=""
-for c in "SQ_WAVES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_INSTS_LDS"; do
-  n=$(echo $c | tr ' ' '_'); rm -rf /tmp/w/sq_$n
-  timeout 600 rocprofv3 --kernel-trace --pmc $c -d /tmp/w/sq_$n -o t -- python3 $R/bench.py --steps 100 --warmup 40 --no-cpu-baseline > /tmp/w/sq_$n.log 2>&1
-  DBS="$DBS $(find /tmp/w/sq_$n -name '*.db' | head -1)"
-done
-python3 $R/scripts/pmc_summary.py $DBS > $OUT/${TAG}_pmc_sq_counters.txt 2>&1
+SQC="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS"
+rm -rf /tmp/w/sq; timeout 600 rocprofv3 --kernel-trace --pmc $SQC -d /tmp/w/sq -o t -- python3 $R/bench.py --steps 100 --warmup 40 --no-cpu-baseline > /tmp/w/sq.log 2>&1
+{ echo "rocprofv3 --kernel-trace --pmc $SQC"; echo "(averages over the counter-instance rows of all dispatches; SQ_* cycle counters are in quad-cycles; use the RATIOS)"; echo; python3 $R/scripts/pmc_summary.py $(find /tmp/w/sq -name '*.db' | head -1); } > $OUT/${TAG}_pmc_sq_counters.txt 2>&1
 ls -la $OUT | grep $TAG
