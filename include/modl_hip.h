@@ -323,6 +323,36 @@ int modl_somf_debug_stamps(modl_somf_plan *plan, unsigned long long *h_out);
  * clock at entry / exit (synchronises the device) */
 int modl_somf_debug_gemm_stamps(modl_somf_plan *plan, unsigned long long *h_out);
 
+/* ------------------------------------------------------------------------- *
+ * Either side of the step: the image patch pipeline and the
+ * objective value of CodingMixin.score.
+ * ------------------------------------------------------------------------- */
+/* fill, modl/input_data/image_fast.pyx:59-74: every (pp, qq, rr) of a p x q x r grid in C order, h_out[p*q*r][3]. Host. */
+int modl_image_fill(int64_t p, int64_t q, int64_t r, int64_t *h_out);
+/* clean_mask, image_fast.pyx:12-57: origins of the x*y*z windows of h_image[H][W][C] that hold no missing (-1)
+ * value, in C order; h_out[(H-x+1)(W-y+1)(C-z+1)][3] (may be NULL: count only), *n_out = number of rows.  Host. */
+int modl_image_clean_mask_f32(const float *h_image, int64_t H, int64_t W, int64_t C, int64_t x, int64_t y, int64_t z,
+                              int64_t *h_out, int64_t *n_out);
+int modl_image_clean_mask_f64(const double *h_image, int64_t H, int64_t W, int64_t C, int64_t x, int64_t y, int64_t z,
+                              int64_t *h_out, int64_t *n_out);
+/* LazyCleanPatchExtractor.partial_transform (modl/feature_extraction/image.py:54-63) + scale_patches
+ * (modl/input_data/image.py:4-23, channel-wise) + flattening (modl/decomposition/image.py:190-199) in one launch:
+ * d_out[r][:] = window of d_image[H][W][C] at origin d_idx3[r] = (i, j, c0), shape (x, y, z), C order, each channel
+ * centred (with_mean) and divided by (its l2 norm or 1 if 0) * sqrt(z) (with_std).  z <= 1024. */
+int modl_image_patches_f32(const float *d_image, int64_t H, int64_t W, int64_t C, const int64_t *d_idx3, int64_t n, int x,
+                           int y, int z, int with_mean, int with_std, float *d_out, int64_t ldo, void *stream);
+int modl_image_patches_f64(const double *d_image, int64_t H, int64_t W, int64_t C, const int64_t *d_idx3, int64_t n, int x,
+                           int y, int z, int with_mean, int with_std, double *d_out, int64_t ldo, void *stream);
+/* The three sums of CodingMixin.score (dict_fact.py:108-114) on device-resident operands:
+ * d_out3 = [ sum (X - code D)^2, sum |code|, sum code^2 ] (f64 accumulation, fixed order: run-to-run reproducible).
+ * d_X[n][ldx], d_Dt[p][k], d_code[n][k]; scratch of modl_objective_workspace() bytes (any smaller size that holds at
+ * least one row of X works too, in more passes). */
+size_t modl_objective_workspace(int dtype, int64_t n, int64_t p);
+int modl_objective_f32(const float *d_X, int64_t ldx, int64_t n, int64_t p, const float *d_Dt, int k, const float *d_code,
+                       void *d_ws, size_t ws_bytes, double *d_out3, void *stream);
+int modl_objective_f64(const double *d_X, int64_t ldx, int64_t n, int64_t p, const double *d_Dt, int k, const double *d_code,
+                       void *d_ws, size_t ws_bytes, double *d_out3, void *stream);
+
 /* layout helpers: out[c][r] = in[r][c]  (components_ <-> Dt) */
 int modl_transpose_f32(const float *d_in, float *d_out, int64_t rows, int64_t cols, void *stream);
 int modl_transpose_f64(const double *d_in, double *d_out, int64_t rows, int64_t cols, void *stream);

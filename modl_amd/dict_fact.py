@@ -175,6 +175,22 @@ class HipBackend:
     def stage_X(self, X):
         return to_device(X, self.device, dtype=self.dtype)
 
+    def stage_image(self, image):
+        """(H, W, C) float32 / float64 image -> HBM, once per fit (modl_amd/image.py)."""
+        return torch.from_numpy(np.ascontiguousarray(image)).to(self.device)
+
+    def image_patches(self, d_image, indices_3d, patch_shape, with_mean, with_std):
+        """Flattened, channel-wise centred / normalised patches at the origins indices_3d (n, 3) -> (n, x*y*z) tensor."""
+        H, W, Cc = d_image.shape
+        x, y, z = (int(v) for v in patch_shape)
+        idx = torch.from_numpy(np.ascontiguousarray(indices_3d, dtype=np.int64)).to(self.device)
+        n = idx.shape[0]
+        out = torch.empty((n, x * y * z), dtype=d_image.dtype, device=self.device)
+        f = getattr(lib, 'modl_image_patches_' + ('f32' if d_image.dtype == torch.float32 else 'f64'))
+        check(f(ptr(d_image), H, W, Cc, ptr(idx), n, x, y, z, int(bool(with_mean)), int(bool(with_std)), ptr(out),
+                x * y * z, stream_ptr(self.device)), 'modl_image_patches')
+        return out
+
     def take_rows(self, Xh, perm):
         return Xh.index_select(0, torch.from_numpy(np.asarray(perm, dtype=np.int64)).to(Xh.device))
 
@@ -242,7 +258,7 @@ class HipBackend:
                                                   stream_ptr(self.device)), 'modl_somf_apply_and_update_dict')
         self._pending = None
 
-    def transform(self, Xh, kw, G=None):
+    def transform(self, Xh, kw, G=None, to_host=True):
         """Codes from a warm start of ones, in chunks of a dedicated plan (large max_batch)."""
         kw = dict(kw, max_batch=4096, G_agg='masked', Dx_agg='masked', optimizer='variational')
         if getattr(self, 'tplan', None) is None or kw != self._tplan_kw:
@@ -258,6 +274,17 @@ class HipBackend:
         out = torch.empty((n, self.k), dtype=torch_dtype(self.dtype), device=self.device)
         check(lib.modl_somf_transform(self.tplan, ptr(self.Dt), ptr(G), ptr(Xh), Xh.stride(0), n, ptr(out),
                                       stream_ptr(self.device)), 'modl_somf_transform')
+        return out.cpu().numpy() if to_host else out
+
+    def objective(self, Xh, code):
+        """[sum (X - code D)^2, sum |code|, sum code^2] of device-resident X and codes (dict_fact.py:108-112)."""
+        n, p = Xh.shape
+        nbytes = lib.modl_objective_workspace(dtype_id(self.dtype), n, p)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        out = torch.empty(3, dtype=torch.float64, device=self.device)
+        f = getattr(lib, 'modl_objective_' + sfx(self.dtype))
+        check(f(ptr(Xh), Xh.stride(0), n, p, ptr(self.Dt), self.k, ptr(code), ptr(ws), nbytes, ptr(out),
+                stream_ptr(self.device)), 'modl_objective')
         return out.cpu().numpy()
 
     def last_sweeps(self):
@@ -326,8 +353,7 @@ class CodingMixin(TransformerMixin):
                     comp_l1_ratio=g('comp_l1_ratio', 0), tol=self.tol, step_size=g('step_size', 1),
                     max_batch=max_batch)
 
-    def transform(self, X):
-        """Codes of the rows of X on the dictionary (dict_fact.py:47-92)."""
+    def _transform(self, X, to_host):
         check_is_fitted(self, 'components_')
         be = self._backend
         if not isinstance(X, torch.Tensor):
@@ -336,18 +362,19 @@ class CodingMixin(TransformerMixin):
         if Xh.shape[1] != be.p:
             raise ValueError('X has %d features, the dictionary has %d' % (Xh.shape[1], be.p))
         use_G = getattr(self, 'G_agg', None) == 'full' and be.G is not None
-        return be.transform(Xh, self._plan_kwargs(4096), be.G if use_G else None)
+        return Xh, be.transform(Xh, self._plan_kwargs(4096), be.G if use_G else None, to_host=to_host)
+
+    def transform(self, X):
+        """Codes of the rows of X on the dictionary (dict_fact.py:47-92)."""
+        return self._transform(X, True)[1]
 
     def score(self, X):
-        """Objective value on test data X (dict_fact.py:94-114)."""
-        check_is_fitted(self, 'components_')
-        code = self.transform(X)
-        Xn = X.cpu().numpy() if isinstance(X, torch.Tensor) else np.asarray(X)
-        D = self.components_
-        loss = np.sum((Xn - code.dot(D)) ** 2) / 2
-        regul = self.code_alpha * (np.sum(np.abs(code)) * self.code_l1_ratio
-                                   + (1 - self.code_l1_ratio) * np.sum(code ** 2) / 2)
-        return (loss + regul) / Xn.shape[0]
+        """Objective value on test data X (dict_fact.py:94-114).  Test data, codes and dictionary stay on the device:
+        only the three sums of the objective come back (X may be a device tensor, e.g. a scorer's resident test set)."""
+        Xh, code = self._transform(X, False)
+        sq_res, norm1_code, norm2_code = self._backend.objective(Xh, code)
+        regul = self.code_alpha * (norm1_code * self.code_l1_ratio + (1 - self.code_l1_ratio) * norm2_code / 2)
+        return float((sq_res / 2 + regul) / Xh.shape[0])
 
 
 def _state_property(name, getter=None, setter=None):

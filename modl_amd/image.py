@@ -1,9 +1,14 @@
 """ImageDictFact: dictionary learning on image patches (reference:
 modl/decomposition/image.py:13-224), driving modl_amd.DictFact's
 prepare / partial_fit / shuffle / set_params exactly as the reference does
-(image.py:96-152).  Patch extraction and normalisation are host code here
-(reference: modl/feature_extraction/image.py:8-83, modl/input_data/image.py:4-23,
-image_fast.pyx:12-74); the per-minibatch SOMF step runs on the GPU."""
+(image.py:96-152).  The image is uploaded once and stays resident in HBM; every
+buffer of patches is gathered, centred, normalised and flattened by one HIP launch
+(modl_image_patches_*, csrc/image.hip: modl/feature_extraction/image.py:54-63 +
+modl/input_data/image.py:4-23 fused) and handed to the SOMF step as a device tensor.
+The patch-origin lists (fill / clean_mask, image_fast.pyx:12-74) are integer host
+work behind the same C-ABI.  The numpy `scale_patches` below serves the public
+transform / score on patches the caller holds in host memory."""
+import ctypes as C
 import time
 from math import sqrt
 
@@ -12,6 +17,7 @@ from numpy.lib.stride_tricks import sliding_window_view
 from sklearn.base import BaseEstimator
 from sklearn.utils import check_random_state, gen_batches
 
+from ._lib import lib, check
 from .dict_fact import DictFact
 
 
@@ -39,17 +45,24 @@ def scale_patches(X, with_mean=True, with_std=True, channel_wise=True, copy=True
 
 def fill(p, q, r):
     """All patch coordinates in C order (image_fast.pyx:59-74)."""
-    return np.stack(np.meshgrid(np.arange(p), np.arange(q), np.arange(r), indexing='ij'), axis=-1).reshape(-1, 3)
+    out = np.empty((p * q * r, 3), dtype=np.int64)
+    check(lib.modl_image_fill(p, q, r, out.ctypes.data_as(C.c_void_p)), 'modl_image_fill')
+    return out
 
 
 def clean_mask(patches, image):
     """Coordinates of the patches without any missing (-1) pixel (image_fast.pyx:12-57)."""
-    p, q, r = patches.shape[:3]
     x, y, z = patches.shape[3:]
-    bad = (image == -1)
-    win = sliding_window_view(bad, (x, y, z))            # (p, q, r, x, y, z)
-    take = ~win.any(axis=(3, 4, 5))
-    return np.argwhere(take)
+    if image.dtype not in (np.float32, np.float64):
+        raise TypeError('clean_mask: float32 or float64 image expected (fused `floating`, image_fast.pyx:12)')
+    image = np.ascontiguousarray(image)
+    H, W, Cc = image.shape
+    f = getattr(lib, 'modl_image_clean_mask_' + ('f32' if image.dtype == np.float32 else 'f64'))
+    out = np.empty(((H - x + 1) * (W - y + 1) * (Cc - z + 1), 3), dtype=np.int64)
+    n = C.c_int64()
+    check(f(image.ctypes.data_as(C.c_void_p), H, W, Cc, x, y, z, out.ctypes.data_as(C.c_void_p), C.byref(n)),
+          'modl_image_clean_mask')
+    return out[:n.value].copy()
 
 
 class LazyCleanPatchExtractor(BaseEstimator):
@@ -65,6 +78,8 @@ class LazyCleanPatchExtractor(BaseEstimator):
         i_h, i_w, n_channels = X.shape
         patch_size = (i_h // 10, i_w // 10) if self.patch_size is None else self.patch_size
         patch_shape = (patch_size[0], patch_size[1], n_channels)
+        self.image_ = X
+        self._device_image = None
         self.patches_ = sliding_window_view(X, patch_shape)       # == sklearn extract_patches, step 1
         if not np.all(X != -1):
             self.indices_3d = clean_mask(self.patches_, X)
@@ -88,6 +103,15 @@ class LazyCleanPatchExtractor(BaseEstimator):
         if X is not None:
             self.fit(X)
         return self.patches_[tuple(self.indices_3d.T)]
+
+    def partial_transform_scaled(self, backend, batch, with_mean=True, with_std=True):
+        """Device path of partial_transform + scale_patches + flattening: the patches `batch` of the HBM-resident
+        image as a (n, patch_size) device tensor (image.py:139-144 in one launch)."""
+        if isinstance(batch, int):
+            batch = slice(0, batch)
+        if self._device_image is None or self._device_image[0] is not backend:
+            self._device_image = (backend, backend.stage_image(self.image_))
+        return backend.image_patches(self._device_image[1], self.indices_3d[batch], self.patch_shape_, with_mean, with_std)
 
     def shuffle(self, permutation=None):
         if permutation is None:
@@ -171,9 +195,18 @@ class ImageDictFact(BaseEstimator):
         n_patches = patch_extractor.n_patches_
         self.patch_shape_ = patch_extractor.patch_shape_
 
-        init_patches = patch_extractor.partial_transform(batch=self.n_components)
-        init_patches = _flatten_patches(init_patches, with_std=with_std, with_mean=with_mean, copy=True)
-        self.dict_fact_.prepare(n_samples=n_patches, X=init_patches)
+        # device pipeline whenever the image is float32 / float64 (the dtype the reference's in-place scale_patches
+        # accepts) and the step's backend owns a GPU
+        probe = self.dict_fact_._make_backend()
+        on_device = hasattr(probe, 'image_patches') and image.dtype in (np.float32, np.float64)
+
+        def scaled(batch):
+            if on_device:
+                return patch_extractor.partial_transform_scaled(probe, batch, with_mean=with_mean, with_std=with_std)
+            return _flatten_patches(patch_extractor.partial_transform(batch=batch), with_mean=with_mean,
+                                    with_std=with_std, copy=True)
+
+        self.dict_fact_.prepare(n_samples=n_patches, X=scaled(slice(0, self.n_components)))
         for i in range(self.n_epochs):
             if i >= 1:
                 permutation = self.dict_fact_.shuffle()
@@ -185,9 +218,7 @@ class ImageDictFact(BaseEstimator):
                 reduction = 1 + (self.reduction - 1) / sqrt(i + 1)
                 self.dict_fact_.set_params(reduction=reduction)
             for buffer in buffers:
-                patches = patch_extractor.partial_transform(batch=buffer)
-                patches = _flatten_patches(patches, with_mean=with_mean, with_std=with_std, copy=True)
-                self.dict_fact_.partial_fit(patches, buffer)
+                self.dict_fact_.partial_fit(scaled(buffer), buffer)
         return self
 
     def _prep(self, patches):

@@ -129,7 +129,11 @@ class OracleBackend:
             st.B = np.ascontiguousarray(dB / b_global)
         orc.update_dict(st, pr, subset, w, order)
 
-    def transform(self, Xh, kw, G=None):
+    def transform(self, Xh, kw, G=None, to_host=True):
         pr = orc.SomfParams(code_alpha=kw['code_alpha'], code_l1_ratio=kw['code_l1_ratio'], code_pos=kw['code_pos'],
                             tol=kw['tol'], max_iter=kw['max_iter'])
         return orc.transform(pr, self.st.D, Xh, G)
+
+    def objective(self, Xh, code):
+        Xh = np.asarray(Xh)
+        return np.array([np.sum((Xh - code.dot(self.st.D)) ** 2), np.sum(np.abs(code)), np.sum(code ** 2)])

@@ -419,3 +419,33 @@ def test_rccl_single_rank_two_phase_equals_fused(red):
     mp.spawn(_rccl_rank_main, args=(port, kw, X, out), nprocs=1, join=True)
     for name in ('D', 'C', 'B', 'code'):
         assert_array_equal(out['fused'][name], out['rccl'][name], err_msg=name)
+
+
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-12), (np.float32, 1e-5)])
+def test_objective_on_device_chunked(dtype, tol):
+    """modl_objective_* (the three sums of dict_fact.py:108-112) against numpy, with a workspace that forces
+    several row chunks, a padded leading dimension of X, and bit-reproducibility."""
+    import ctypes as C
+    import torch
+    from modl_amd._lib import lib, check
+    from modl_amd.device import ptr, stream_ptr
+    rs = np.random.RandomState(0)
+    n, p, k = 301, 157, 11
+    X, D, code = rs.randn(n, p + 3).astype(dtype), rs.randn(k, p).astype(dtype), rs.randn(n, k).astype(dtype)
+    code[rs.rand(n, k) < 0.5] = 0
+    want = np.array([np.sum((X[:, :p].astype(np.float64) - code.astype(np.float64).dot(D.astype(np.float64))) ** 2),
+                     np.sum(np.abs(code.astype(np.float64))), np.sum(code.astype(np.float64) ** 2)])
+    dev = torch.device('cuda')
+    dX, dDt, dcode = torch.from_numpy(X).to(dev), torch.from_numpy(np.ascontiguousarray(D.T)).to(dev), torch.from_numpy(code).to(dev)
+    f = getattr(lib, 'modl_objective_' + ('f32' if dtype == np.float32 else 'f64'))
+    outs = []
+    for nbytes in (lib.modl_objective_workspace(0 if dtype == np.float32 else 1, n, p), 8 * 1024 + 64 * p * X.itemsize,
+                   8 * 1024 + 64 * p * X.itemsize):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = torch.full((3,), -1.0, dtype=torch.float64, device=dev)
+        check(f(ptr(dX), p + 3, n, p, ptr(dDt), k, ptr(dcode), ptr(ws), nbytes, ptr(out), stream_ptr(dev)))
+        outs.append(out.cpu().numpy())
+        assert np.all(np.abs(outs[-1] - want) < tol * want), (outs[-1], want)
+    assert np.array_equal(outs[1], outs[2])
+    ws = torch.empty(64, dtype=torch.uint8, device=dev)
+    assert f(ptr(dX), p + 3, n, p, ptr(dDt), k, ptr(dcode), ptr(ws), 64, ptr(out), stream_ptr(dev)) == -2      # MODL_ENOMEM

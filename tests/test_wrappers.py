@@ -174,3 +174,70 @@ def test_fmri_records_from_npy_files(tmp_path):
     b = fMRIDictFact(**kw).fit(recs)
     assert_array_equal(a.components_, b.components_)
     assert a.components_.dtype == np.float32
+
+
+# ---- the image patch pipeline either side of the step ------------------------------------------------
+def _clean_mask_bruteforce(image, x, y, z):
+    """image_fast.pyx:36-56 in plain Python loops, the y-for-z range of :46 included."""
+    H, W, C = image.shape
+    p, q, r = H - x + 1, W - y + 1, C - z + 1
+    take = np.ones((p, q, r), dtype=bool)
+    for pp, qq, rr in np.argwhere(image == -1):
+        for xx in range(max(0, pp - x + 1), min(p, pp + 1)):
+            for yy in range(max(0, qq - y + 1), min(q, qq + 1)):
+                for zz in range(max(0, rr - y + 1), min(r, rr + 1)):
+                    take[xx, yy, zz] = False
+    return np.argwhere(take)
+
+
+@pytest.mark.parametrize('shape,patch', [((12, 13, 2), (3, 4, 2)), ((9, 9, 1), (2, 2, 1)), ((8, 10, 6), (3, 2, 6)),
+                                         ((7, 7, 4), (2, 3, 2))])
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_clean_mask_and_fill_host_abi(shape, patch, dtype):
+    from numpy.lib.stride_tricks import sliding_window_view
+    from modl_amd.image import clean_mask, fill
+    rs = np.random.RandomState(3)
+    img = rs.rand(*shape).astype(dtype)
+    img[rs.rand(*shape) < 0.03] = -1
+    got = clean_mask(sliding_window_view(img, patch), img)
+    assert got.dtype == np.int64
+    assert_array_equal(got, _clean_mask_bruteforce(img, *patch))
+    p, q, r = 3, 4, 2
+    assert_array_equal(fill(p, q, r), np.c_[np.where(np.ones((p, q, r)))])        # image_fast.pyx:60
+    assert fill(0, 3, 1).shape == (0, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-13), (np.float32, 2e-6)])
+@pytest.mark.parametrize('shape,psize', [((40, 37, 1), (8, 8)), ((31, 33, 3), (6, 5)), ((20, 20, 70), (3, 3)),
+                                         ((64, 64, 1), (16, 16))])
+def test_device_patch_pipeline_matches_numpy(dtype, tol, shape, psize):
+    import torch
+    from modl_amd.dict_fact import HipBackend
+    from modl_amd.image import LazyCleanPatchExtractor, _flatten_patches
+    img = synth_image(*shape, seed=5, holes=True).astype(dtype)
+    img[2:2 + psize[0], 3:3 + psize[1], :] = 0.25                # a constant patch: zero norm after centring -> 1
+    ex = LazyCleanPatchExtractor(patch_size=psize, random_state=0, max_patches=700).fit(img)
+    be = HipBackend()
+    for with_mean, with_std in ((True, True), (False, True), (True, False), (False, False)):
+        want = _flatten_patches(ex.partial_transform(batch=slice(5, 600)), with_mean=with_mean, with_std=with_std, copy=True)
+        got = ex.partial_transform_scaled(be, slice(5, 600), with_mean=with_mean, with_std=with_std)
+        assert isinstance(got, torch.Tensor) and got.is_cuda and got.dtype == (torch.float32 if dtype == np.float32 else torch.float64)
+        got = got.cpu().numpy()
+        assert got.shape == want.shape
+        assert np.max(np.abs(got - want)) < tol * max(1.0, np.max(np.abs(want))), (with_mean, with_std)
+    if not (with_mean or with_std):
+        assert_array_equal(got, want)                                # a pure gather is exact
+
+
+@pytest.mark.gpu
+def test_device_patch_pipeline_golden():
+    """the reference's own extract + scale_patches output (tests/golden/make_golden.py) through the HIP launch"""
+    from modl_amd.dict_fact import HipBackend
+    from modl_amd.image import LazyCleanPatchExtractor
+    g = load_golden('image')
+    img = synth_image(12, 13, 2, seed=9, holes=True)
+    ex = LazyCleanPatchExtractor(patch_size=(3, 4), random_state=0).fit(img)
+    got = ex.partial_transform_scaled(HipBackend(), slice(None)).cpu().numpy()
+    want = g['extract/scaled'].reshape(got.shape)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-14)
