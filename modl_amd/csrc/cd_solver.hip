@@ -22,15 +22,21 @@
 //   * sparse (active set): a coordinate with w_ii == 0 whose update stays 0
 //     (|q_ii - H_ii| <= alpha) is a no-op of the reference's sweep (nothing is
 //     written, d_w_max / w_max are unaffected), and that test is evaluated for ALL
-//     coordinates at once (one compare + ballot per register), so the sweep jumps
-//     from one active coordinate to the next with s_ff1.  With l1-penalised codes
-//     most coordinates are inactive after the first sweep.  The row of the predicted
-//     next active coordinate is prefetched; a coordinate activated in between is
-//     picked up exactly (it only costs a synchronous load).
+//     coordinates at once (one compare + ballot per register).  The ordered list of
+//     the active coordinates is built once per sweep (prefix counts of the ballots,
+//     through LDS), their Gram rows are prefetched through a ring, and a coordinate
+//     that a step ACTIVATES ahead of the cursor is picked up exactly (the list is
+//     rebuilt from the cursor).  With l1-penalised codes most coordinates are
+//     inactive after the first sweeps: 0.23 us per active coordinate against
+//     14 us for a dense sweep at k = 256.
 // Both produce the reference's iterates bit for bit.  The five reductions of the
 // gap test are wave shuffles.  b independent problems -> b wavefronts, 4 per
 // workgroup.
 #include "kernels.hpp"
+#include <cstdlib>
+#ifndef MODL_CD_SPARSE_RING
+#define MODL_CD_SPARSE_RING 4          /* (tuning) ring depth of the sparse sweep for k <= 256 */
+#endif
 #include <utility>
 
 namespace modl {
@@ -203,46 +209,134 @@ __device__ __forceinline__ void cd_step(int L, int lane, T (&w)[KPL], T (&H)[KPL
     if (lane == L) w[C] = x;
 }
 
-template <typename T, int KPL, bool VEC, bool POSITIVE>
-__device__ __forceinline__ void cd_sparse_sweep(int lane, int k, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
-                                                const T (&inv)[KPL], unsigned long long (&m)[KPL],
-                                                const T *__restrict__ Q, T alpha) {
-    T rowA[KPL], rowB[KPL];
-    int next = cd_next<KPL>(m, 0);
-    if (next >= k) return;
-    load_row<T, KPL, VEC>(Q, next, k, lane, rowA);
-    while (true) {
-        const int ii = next;
-        const int pred = cd_next<KPL>(m, ii + 1);             // next active coordinate as of now
-        if (pred < k) load_row<T, KPL, VEC>(Q, pred, k, lane, rowB);
-        const int L = ii / KPL;
-        switch (ii % KPL) {
-#define MODL_CD_CASE(C)                                                                          \
-    case C:                                                                                      \
-        if constexpr (C < KPL) cd_step<T, KPL, C, POSITIVE>(L, lane, w, H, q, inv, rowA, alpha); \
+// One coordinate of a sparse sweep; the register index is resolved by a wave-uniform switch whose cases only form the
+// candidate, broadcast (w_new, w_old) and store the coefficient -- the k-wide update of H is common code behind it (a
+// switch around the whole step makes every case end in a dozen register moves).  !valid: a null step (both
+// multipliers 0, no lane selected), so that the unrolled ring needs no exit in the middle of a group.
+template <typename T, int KPL, bool POSITIVE>
+__device__ __forceinline__ void cd_coord_any(unsigned int ii, bool valid, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
+                                             const T (&inv)[KPL], const T (&row)[KPL], T alpha) {
+    const int L = (int)(ii / KPL);
+    const unsigned long long lm = (unsigned long long)valid << L;
+    T dn = 0, dold = 0;
+    switch (ii % KPL) {
+#define MODL_CD_CASE(C)                                                                                  \
+    case C:                                                                                              \
+        if constexpr (C < KPL) {                                                                         \
+            const T wv = w[C];                                                                           \
+            const T xv = cd_coordinate<T, POSITIVE>(H[C], wv, q[C], inv[C], row[C], alpha);              \
+            dn = bcast_lane(xv, L);                                                                      \
+            dold = bcast_lane(wv, L);                                                                    \
+            w[C] = __builtin_amdgcn_inverse_ballot_w64(lm) ? xv : wv;                                    \
+        }                                                                                                \
         break;
-            MODL_CD_CASE(0) MODL_CD_CASE(1) MODL_CD_CASE(2) MODL_CD_CASE(3) MODL_CD_CASE(4) MODL_CD_CASE(5)
-            MODL_CD_CASE(6) MODL_CD_CASE(7) MODL_CD_CASE(8) MODL_CD_CASE(9) MODL_CD_CASE(10) MODL_CD_CASE(11)
-            MODL_CD_CASE(12) MODL_CD_CASE(13) MODL_CD_CASE(14) MODL_CD_CASE(15)
+        MODL_CD_CASE(0) MODL_CD_CASE(1) MODL_CD_CASE(2) MODL_CD_CASE(3) MODL_CD_CASE(4) MODL_CD_CASE(5)
+        MODL_CD_CASE(6) MODL_CD_CASE(7) MODL_CD_CASE(8) MODL_CD_CASE(9) MODL_CD_CASE(10) MODL_CD_CASE(11)
+        MODL_CD_CASE(12) MODL_CD_CASE(13) MODL_CD_CASE(14) MODL_CD_CASE(15)
 #undef MODL_CD_CASE
-        }
-        cd_active<T, KPL, POSITIVE>(w, H, q, inv, alpha, m);
-        const int nn = cd_next<KPL>(m, ii + 1);
-        if (pred < k && nn >= pred) {
-            // the prediction holds, or the predicted coordinate went inactive (w == 0 there: a no-op step)
-            next = pred;
+    }
+    if (!valid) { dn = 0; dold = 0; }
 #pragma unroll
-            for (int r = 0; r < KPL; ++r) rowA[r] = rowB[r];
-        } else {
-            if (nn >= k) return;
-            next = nn;                                        // activated by this step: synchronous load
-            load_row<T, KPL, VEC>(Q, next, k, lane, rowA);
+    for (int r = 0; r < KPL; ++r) H[r] = fma(dn, row[r], fma(-dold, row[r], H[r]));   // as cd_coord
+}
+
+// lo[c] = the bits of the coordinates <= ii (coordinate L * KPL + c is bit L of mask c); ii may be -1
+template <int KPL>
+__device__ __forceinline__ void cd_low_masks(int ii, unsigned long long (&lo)[KPL]) {
+#pragma unroll
+    for (int c = 0; c < KPL; ++c) {
+        const int cnt = ii >= c ? (ii - c) / KPL + 1 : 0;     // lanes L with L * KPL + c <= ii
+        lo[c] = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+    }
+}
+
+// Gram rows of the next active coordinates in flight (register budget: R * KPL values)
+template <int KPL> constexpr int cd_sparse_ring() { return KPL <= 4 ? MODL_CD_SPARSE_RING : (KPL == 8 ? 4 : 2); }
+constexpr int kCdSparseRingMax = MODL_CD_SPARSE_RING > 4 ? MODL_CD_SPARSE_RING : 4;
+
+// A sparse sweep.  At one wavefront per SIMD the sweep is bound by its INSTRUCTION COUNT (an instruction issues every
+// ~5 cycles), so the per-coordinate work is kept minimal: the ordered list of the active coordinates is built ONCE
+// (prefix counts of the masks, through `list` in LDS), the rows of the next R list entries are in flight in
+// a ring with static slots (the loop is unrolled over the ring: a register copy would wait for the load it moves), and
+// after each step the only question asked is "did this step activate a coordinate that is not known yet?" -- one
+// compare + ballot + andn2 per register against `mq` (known active, or dead, or behind the cursor).  If so, the exact
+// masks are re-evaluated; an activation AHEAD of the cursor rebuilds the list from the cursor (rare after the first
+// sweeps), one behind it belongs to the next sweep.  A listed coordinate that went inactive meanwhile is a no-op step
+// (w == 0 there and the update stays 0: H and w unchanged).  So the coordinates that change anything are visited in
+// increasing order with the H of the moment, exactly as in the reference's sweep.
+template <typename T, int KPL, bool VEC, bool POSITIVE>
+__device__ __forceinline__ int cd_sparse_sweep(int lane, int k, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
+                                               const T (&inv)[KPL], unsigned long long (&m)[KPL],
+                                               const T *__restrict__ Q, T alpha, unsigned short *list) {
+    constexpr int R = cd_sparse_ring<KPL>(), NONE = 64 * KPL;
+    int start = 0;                                            // coordinates >= start remain to be visited
+    for (int rebuilds = 0;; ++rebuilds) {                     // returns the number of list rebuilds
+        unsigned long long lo[KPL], mq[KPL];
+        cd_low_masks<KPL>(start - 1, lo);
+        int n = 0, pos = 0;
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+            m[c] &= ~lo[c];
+            n += __builtin_popcountll(m[c]);
+            pos += __builtin_amdgcn_mbcnt_hi((unsigned int)(m[c] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m[c], 0u));
+            mq[c] = m[c] | lo[c] | __ballot(inv[c] == (T)0);   // listed, behind the cursor, or dead (never turns active)
         }
+        if (n == 0) return rebuilds;
+#pragma unroll
+        for (int c = 0; c < KPL; ++c)
+            if ((m[c] >> lane) & 1ull) list[pos++] = (unsigned short)(lane * KPL + c);
+        if (lane < 2 * R) list[n + lane] = (unsigned short)NONE;
+        __builtin_amdgcn_wave_barrier();                      // LDS operations of one wavefront complete in order
+
+        T ring[R][KPL];
+        int cq[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            cq[j] = __builtin_amdgcn_readfirstlane((int)list[j]);
+            load_row<T, KPL, VEC>(Q, cq[j] < k ? cq[j] : k - 1, k, lane, ring[j]);   // unconditional: no branch around a load
+        }
+        const unsigned short *lp = list + R;
+        unsigned int pending = *lp;                           // list entry of the next refill, read one step ahead
+        bool stop = false;                                    // an activation ahead of the cursor: rebuild from `start`
+        while (!stop && cq[0] < k) {                          // at the top of a group slot 0 holds the oldest entry
+            static_for<R>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                const bool valid = !stop && cq[s] < k;
+                const int ii = valid ? cq[s] : 0;
+                cd_coord_any<T, KPL, POSITIVE>((unsigned int)ii, valid, w, H, q, inv, ring[s], alpha);
+                unsigned long long nb = 0;
+#pragma unroll
+                for (int c = 0; c < KPL; ++c) {               // a superset of cd_active's "turns non-zero" test
+                    const T tmp = q[c] - H[c];
+                    nb |= __ballot(POSITIVE ? tmp > alpha : fabs(tmp) > alpha) & ~mq[c];
+                }
+                if (valid && nb != 0ull) {
+                    cd_active<T, KPL, POSITIVE>(w, H, q, inv, alpha, m);
+                    cd_low_masks<KPL>(ii, lo);
+                    unsigned long long ahead = 0;
+#pragma unroll
+                    for (int c = 0; c < KPL; ++c) ahead |= m[c] & ~lo[c] & ~mq[c];
+                    if (ahead != 0ull) {
+                        start = ii + 1;
+                        stop = true;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < KPL; ++c) mq[c] |= m[c] | lo[c];
+                    }
+                }
+                cq[s] = __builtin_amdgcn_readfirstlane((int)pending);
+                ++lp;
+                pending = *lp;
+                load_row<T, KPL, VEC>(Q, cq[s] < k ? cq[s] : k - 1, k, lane, ring[s]);
+            });
+        }
+        if (!stop) return rebuilds;
     }
 }
 
 template <typename T, int KPL, bool VEC, bool POSITIVE, bool PAD>
 __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
+    __shared__ unsigned short s_list[4][64 * KPL + 2 * kCdSparseRingMax];   // active coordinates of a sparse sweep, per wave
     const int lane = threadIdx.x & 63;
     const int smp = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (smp >= a.b) return;                        // whole wave exits together
@@ -335,7 +429,7 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
         w[c] = lv ? w[c] : (T)0;
     }
 
-    int n_iter = 0;
+    int n_iter = 0, churn = 0;
     for (; n_iter < a.max_iter; ++n_iter) {
         unsigned long long m[KPL];
         cd_active<T, KPL, POSITIVE>(w, H, q, inv, alpha, m);
@@ -345,8 +439,15 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
         T w0[KPL];                                 // a coefficient changes once per sweep: d_w_ii = |w - w0| (:380-384)
 #pragma unroll
         for (int r = 0; r < KPL; ++r) w0[r] = w[r];
-        if (6 * n_act > k) cd_dense_sweep<T, KPL, VEC, POSITIVE, PAD>(lane, k, w, H, q, inv, Q, alpha);   // a sparse step costs several dense coordinates
-        else cd_sparse_sweep<T, KPL, VEC, POSITIVE>(lane, k, w, H, q, inv, m, Q, alpha);
+        // a sparse step costs about four dense coordinates and a list rebuild (a coordinate activated ahead of the
+        // cursor) about eight sparse steps: while the active set keeps churning (e.g. a rank-deficient Gram matrix
+        // that never lets the sweeps settle) the sweeps stay dense
+        if (100 * (n_act + 8 * churn) > a.sparse_pct * k) {
+            cd_dense_sweep<T, KPL, VEC, POSITIVE, PAD>(lane, k, w, H, q, inv, Q, alpha);
+            churn >>= 1;
+        } else {
+            churn = cd_sparse_sweep<T, KPL, VEC, POSITIVE>(lane, k, w, H, q, inv, m, Q, alpha, s_list[threadIdx.x >> 6]);
+        }
         T dmx = 0, wmx = 0;                        // skipped coordinates do not count (:357): their w is 0 here
 #pragma unroll
         for (int r = 0; r < KPL; ++r) {
@@ -422,9 +523,12 @@ static void launch_cd_kpl(hipStream_t stream, const CdArgs<T> &a, dim3 grid, dim
 }
 
 template <typename T>
-int launch_cd(hipStream_t stream, const CdArgs<T> &a) {
-    if (a.b <= 0 || a.k <= 0) return MODL_OK;
-    if (a.k > 1024) return MODL_EINVAL;
+int launch_cd(hipStream_t stream, const CdArgs<T> &a0) {
+    if (a0.b <= 0 || a0.k <= 0) return MODL_OK;
+    if (a0.k > 1024) return MODL_EINVAL;
+    static const int sparse_pct = getenv("MODL_CD_SPARSE_PCT") ? atoi(getenv("MODL_CD_SPARSE_PCT")) : -1;   // (tuning)
+    CdArgs<T> a = a0;
+    if (sparse_pct >= 0) a.sparse_pct = sparse_pct;
     dim3 grid((unsigned)cdiv(a.b, 4)), block(256);
     if (a.k <= 64) launch_cd_kpl<T, 1>(stream, a, grid, block);
     else if (a.k <= 128) launch_cd_kpl<T, 2>(stream, a, grid, block);

@@ -22,6 +22,8 @@ struct CdArgs {
     int b, k;
     T alpha, beta, tol;
     int max_iter, positive;
+    int sparse_pct = 20;   // a sweep with at most sparse_pct % of the coordinates active runs as a sparse sweep
+                           // (measured at k = 256: a sparse step costs 0.23 us, a dense sweep 14.3 us (f32) / 18.9 us (f64))
 };
 template <typename T> int launch_cd(hipStream_t stream, const CdArgs<T> &a);
 template <typename T> int launch_row_norm2(hipStream_t stream, const T *X, int64_t ldx, int64_t p, int64_t b, T *out);
