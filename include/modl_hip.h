@@ -189,6 +189,27 @@ int modl_recsys_predict_f32(double *d_out, const int32_t *d_indices, const int32
                             int64_t n_rows, int k, const float *d_Dt, void *stream);
 int modl_recsys_predict_f64(double *d_out, const int32_t *d_indices, const int32_t *d_indptr, const double *d_code,
                             int64_t n_rows, int k, const double *d_Dt, void *stream);
+/* One minibatch of RecsysDictFact._single_batch_fit (recsys.py:147-165, 168-213) in ONE call: the batch's ratings are
+ * grouped by item on the host (batch order kept inside an item), staged through a pinned slot of the plan, and the
+ * codes, the per-item B_ update, the C_ update and the dictionary update on the union of the batch's items are
+ * launched on `stream`.  Asynchronous; the plan owns its staging slots and scratch.
+ *   h_* : the CSR matrix in host memory (int32 / T, as d_*), n_rows its number of rows;
+ *   h_rows[b] : the batch (row ids, in batch order);  h_order[k] : the atom order (numpy permutation, recsys.py:196);
+ *   w : _batch_weight;  n_iter : n_iter_ after this batch (w_B = min(1, w n_iter / feature_n_iter), :182).
+ * max_entries: the largest number of ratings one batch may hold. */
+typedef struct modl_recsys_plan modl_recsys_plan;
+int modl_recsys_plan_create(int dtype, int64_t p, int k, int64_t max_batch, int64_t max_entries, modl_recsys_plan **out);
+void modl_recsys_plan_destroy(modl_recsys_plan *plan);
+int modl_recsys_minibatch_f32(modl_recsys_plan *plan, const int32_t *h_indptr, const int32_t *h_indices, const float *h_data,
+                              int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const float *d_data,
+                              const int64_t *h_rows, int64_t b, const int64_t *h_order, double alpha, double w,
+                              double n_iter, float *d_Dt, float *d_Bt, float *d_C, float *d_code, float *d_comp_norm,
+                              int64_t *d_feature_n_iter, void *stream);
+int modl_recsys_minibatch_f64(modl_recsys_plan *plan, const int32_t *h_indptr, const int32_t *h_indices, const double *h_data,
+                              int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const double *d_data,
+                              const int64_t *h_rows, int64_t b, const int64_t *h_order, double alpha, double w,
+                              double n_iter, double *d_Dt, double *d_Bt, double *d_C, double *d_code,
+                              double *d_comp_norm, int64_t *d_feature_n_iter, void *stream);
 /* C = beta C + alpha rows^T rows, rows[b][k]  (recsys.py:159-160: beta = 1 - w, alpha = w / b) */
 int modl_gram_axpby_f32(const float *d_rows, int64_t b, int k, float *d_C, float beta, float alpha, void *stream);
 int modl_gram_axpby_f64(const double *d_rows, int64_t b, int k, double *d_C, double beta, double alpha, void *stream);

@@ -105,6 +105,8 @@ for _sfx, _ct in (('f32', C.c_float), ('f64', C.c_double)):
 for _sfx, _ct in (('f32', C.c_float), ('f64', C.c_double)):
     _sig('modl_recsys_codes_' + _sfx, C.c_int, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp)
     _sig('modl_recsys_update_B_' + _sfx, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _i64, _vp)
+    _sig('modl_recsys_minibatch_' + _sfx, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _f64, _f64, _f64,
+         _vp, _vp, _vp, _vp, _vp, _vp, _vp)
     _sig('modl_recsys_predict_' + _sfx, C.c_int, _vp, _vp, _vp, _vp, _i64, C.c_int, _vp, _vp)
     _sig('modl_gram_axpby_' + _sfx, C.c_int, _vp, _i64, C.c_int, _vp, _ct, _ct, _vp)
     _sig('modl_dict_update_' + _sfx, C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, C.c_int, C.c_int, C.c_int, _f64,
@@ -116,6 +118,8 @@ for _sfx, _ct in (('f32', C.c_float), ('f64', C.c_double)):
 _sig('modl_image_fill', C.c_int, _i64, _i64, _i64, _vp)
 _sig('modl_objective_workspace', _sz, C.c_int, _i64, _i64)
 _sig('modl_dict_update_workspace', _sz, C.c_int, _i64, C.c_int)
+_sig('modl_recsys_plan_create', C.c_int, C.c_int, _i64, C.c_int, _i64, _i64, _P(_vp))
+_sig('modl_recsys_plan_destroy', None, _vp)
 _sig('modl_predict_csr', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp)
 _sig('modl_somf_plan_create', C.c_int, _P(SomfDesc), _P(_vp))
 _sig('modl_somf_plan_destroy', None, _vp)

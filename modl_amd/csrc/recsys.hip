@@ -15,6 +15,9 @@
 // kernels of the dense path (csrc/bcd.hip blocked path is exactly that update).
 #include "gemm.hpp"
 #include "kernels.hpp"
+#include <algorithm>
+#include <cstring>
+#include <vector>
 
 namespace modl {
 
@@ -99,8 +102,8 @@ __global__ __launch_bounds__(256) void recsys_code_kernel(const T *Dt, int64_t p
 template <typename T>
 __global__ __launch_bounds__(256) void recsys_update_B_kernel(T *Bt, int k, int64_t *feature_n_iter, const int32_t *subset,
                                                               const int32_t *fptr, const int32_t *entry_sample,
-                                                              const T *entry_val, const T *code_b, double w_n_iter,
-                                                              int64_t u) {
+                                                              const T *entry_val, const T *code_b,
+                                                              const int64_t *code_rows, double w_n_iter, int64_t u) {
     const int lane = threadIdx.x & 63;
     const int64_t fi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (fi >= u) return;
@@ -112,7 +115,8 @@ __global__ __launch_bounds__(256) void recsys_update_B_kernel(T *Bt, int k, int6
         double wB = w_n_iter / (double)n;                    // :182-183
         wB = wB < 1.0 ? wB : 1.0;
         const double xw = (double)entry_val[e] * wB;
-        const T *cr = code_b + (int64_t)entry_sample[e] * k;
+        const int64_t cpos = entry_sample[e];                // position in the batch; code_rows: its row of code_
+        const T *cr = code_b + (code_rows ? code_rows[cpos] : cpos) * k;
         for (int c = lane; c < k; c += 64) {
             T b = (T)((double)brow[c] * (1.0 - wB));         // B_[:, subset] *= 1 - w_B
             b = (T)((double)b + (double)cr[c] * xw);          // += outer(code, X_subset * w_B)
@@ -160,6 +164,151 @@ template <typename T> struct EpiAxpbyC {
     }
 };
 
+
+// ---- one call per minibatch ---------------------------------------------------------------------------------------
+// The host side of recsys.py:147-165 for a batch of CSR rows: the batch's ratings grouped by item (counting sort, batch
+// order kept inside an item: two rows rating the same item do not commute in the B_ update), written with the row ids
+// and the atom order into a pinned slot, moved to HBM by a kernel reading the device-mapped slot (no copy-engine hop
+// between kernels), then the four launches of the step.  Nothing is synchronised: a ring of slots + events.
+constexpr int kRecsysSlots = 8;
+
+}  // namespace modl
+
+struct modl_recsys_plan {
+    int dtype = 0, k = 0;
+    int64_t p = 0, max_entries = 0, max_batch = 0;
+    char *h[modl::kRecsysSlots] = {nullptr};
+    char *hdev[modl::kRecsysSlots] = {nullptr};
+    hipEvent_t ev[modl::kRecsysSlots] = {nullptr};
+    bool used[modl::kRecsysSlots] = {false};
+    int slot = 0;
+    char *dstage = nullptr;
+    size_t stage_bytes = 0;
+    char *ws = nullptr;
+    size_t ws_bytes = 0;
+    std::vector<int32_t> cnt, touched;
+};
+
+namespace modl {
+
+struct RecsysLayout { size_t rows, order, subset, fptr, esample, eval, total; };
+static RecsysLayout recsys_layout(size_t tsz, int64_t b, int k, int64_t u, int64_t m) {
+    RecsysLayout L;
+    size_t o = 0;
+    L.rows = o; o = align_up(o + sizeof(int64_t) * (size_t)b, 16);
+    L.order = o; o = align_up(o + sizeof(int32_t) * (size_t)k, 16);
+    L.subset = o; o = align_up(o + sizeof(int32_t) * (size_t)u, 16);
+    L.fptr = o; o = align_up(o + sizeof(int32_t) * (size_t)(u + 1), 16);
+    L.esample = o; o = align_up(o + sizeof(int32_t) * (size_t)m, 16);
+    L.eval = o; o = align_up(o + tsz * (size_t)m, 16);
+    L.total = o;
+    return L;
+}
+
+__global__ __launch_bounds__(256) void recsys_stage_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+template <typename T>
+int recsys_minibatch(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_t *h_indices, const T *h_data,
+                     int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const T *d_data,
+                     const int64_t *h_rows, int64_t b, const int64_t *h_order, double alpha, double w, double n_iter,
+                     T *Dt, T *Bt, T *C, T *code, T *comp_norm, int64_t *feature_n_iter, hipStream_t st) {
+    const int k = pl->k;
+    if (b <= 0 || b > pl->max_batch) return MODL_EINVAL;
+    int64_t m = 0;
+    for (int64_t i = 0; i < b; ++i) {
+        const int64_t r = h_rows[i];
+        if (r < 0 || r >= n_rows) return MODL_EINVAL;
+        m += h_indptr[r + 1] - h_indptr[r];
+    }
+    if (m > pl->max_entries) return MODL_ENOMEM;
+    for (int i = 0; i < k; ++i)
+        if (h_order[i] < 0 || h_order[i] >= k) return MODL_EINVAL;
+    // items touched by the batch, ascending; entries per item
+    std::vector<int32_t> &cnt = pl->cnt, &touched = pl->touched;
+    touched.clear();
+    for (int64_t i = 0; i < b; ++i)
+        for (int32_t e = h_indptr[h_rows[i]]; e < h_indptr[h_rows[i] + 1]; ++e) {
+            const int32_t c = h_indices[e];
+            if (c < 0 || c >= pl->p) {
+                for (int32_t t : touched) cnt[t] = 0;
+                return MODL_EINVAL;
+            }
+            if (cnt[c]++ == 0) touched.push_back(c);
+        }
+    std::sort(touched.begin(), touched.end());
+    const int64_t u = (int64_t)touched.size();
+    const RecsysLayout L = recsys_layout(sizeof(T), b, k, u, m);
+    if (L.total > pl->stage_bytes) {
+        for (int32_t t : touched) cnt[t] = 0;
+        return MODL_ENOMEM;
+    }
+    const int slot = pl->slot;
+    pl->slot = (slot + 1) % kRecsysSlots;
+    if (pl->used[slot]) MODL_HIP(hipEventSynchronize(pl->ev[slot]));
+    char *h = pl->h[slot];
+    std::memcpy(h + L.rows, h_rows, sizeof(int64_t) * (size_t)b);
+    int32_t *ho = reinterpret_cast<int32_t *>(h + L.order);
+    for (int i = 0; i < k; ++i) ho[i] = (int32_t)h_order[i];
+    int32_t *hs = reinterpret_cast<int32_t *>(h + L.subset), *hf = reinterpret_cast<int32_t *>(h + L.fptr);
+    int32_t *hes = reinterpret_cast<int32_t *>(h + L.esample);
+    T *hev = reinterpret_cast<T *>(h + L.eval);
+    hf[0] = 0;
+    for (int64_t i = 0; i < u; ++i) {
+        hs[i] = touched[(size_t)i];
+        hf[i + 1] = hf[i] + cnt[touched[(size_t)i]];
+        cnt[touched[(size_t)i]] = hf[i];                    // becomes the write cursor of the item
+    }
+    for (int64_t i = 0; i < b; ++i)
+        for (int32_t e = h_indptr[h_rows[i]]; e < h_indptr[h_rows[i] + 1]; ++e) {
+            const int32_t at = cnt[h_indices[e]]++;
+            hes[at] = (int32_t)i;
+            hev[at] = h_data[e];
+        }
+    for (int32_t t : touched) cnt[t] = 0;
+    {
+        const size_t n16 = L.total / 16;
+        unsigned grid = (unsigned)((n16 + 255) / 256);
+        if (grid > 64) grid = 64;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(recsys_stage_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint4 *>(pl->hdev[slot]),
+                           reinterpret_cast<uint4 *>(pl->dstage), n16);
+        MODL_LAUNCH_CHECK();
+        MODL_HIP(hipEventRecord(pl->ev[slot], st));
+        pl->used[slot] = true;
+    }
+    const int64_t *d_rows = reinterpret_cast<const int64_t *>(pl->dstage + L.rows);
+    const int32_t *d_order = reinterpret_cast<const int32_t *>(pl->dstage + L.order);
+    const int32_t *d_subset = reinterpret_cast<const int32_t *>(pl->dstage + L.subset);
+    const int32_t *d_fptr = reinterpret_cast<const int32_t *>(pl->dstage + L.fptr);
+    const int32_t *d_es = reinterpret_cast<const int32_t *>(pl->dstage + L.esample);
+    const T *d_ev = reinterpret_cast<const T *>(pl->dstage + L.eval);
+    // codes of the batch's rows (recsys.py:176-181), written to code_[rows]
+    MODL_TRY(recsys_codes<T>(Dt, pl->p, k, d_indptr, d_indices, d_data, d_rows, nullptr, b, alpha, code, st));
+    if (u > 0) {                                             // :175, :182-185
+        hipLaunchKernelGGL((recsys_update_B_kernel<T>), dim3((unsigned)cdiv(u, 4)), dim3(256), 0, st, Bt, k, feature_n_iter,
+                           d_subset, d_fptr, d_es, d_ev, (const T *)code, d_rows, w * n_iter, u);
+        MODL_LAUNCH_CHECK();
+    }
+    {                                                        // :159-160  C_ = (1 - w) C_ + (w / b) code_[batch]^T code_[batch]
+        Operand A;
+        A.ptr = code; A.si = 1; A.sk = k; A.gk = gather64(d_rows);
+        EpiAxpbyC<T> epi{C, k, (T)(w / (double)b), (T)(1.0 - w)};
+        SplitWs none;
+        MODL_TRY((launch_gemm<T, EpiAxpbyC<T>>(st, A, A, k, k, b, epi, none, nullptr, 512, 1)));
+    }
+    if (u > 0) {                                             // :187-213
+        DictUpdateArgs<T> a;
+        a.Dt = Dt; a.Bt = Bt; a.C = C; a.comp_norm = comp_norm; a.subset = d_subset; a.order = d_order;
+        a.h_order = h_order; a.s = u; a.k = k; a.optimizer = 0; a.comp_pos = 0;
+        a.comp_l1_ratio = 0.0; a.w = w; a.step_size = 1.0; a.ws = pl->ws; a.ws_bytes = pl->ws_bytes;
+        int nl = 0;
+        MODL_TRY(dict_update<T>(st, a, &nl));
+    }
+    return MODL_OK;
+}
+
 }  // namespace modl
 
 using namespace modl;
@@ -183,7 +332,7 @@ extern "C" {
         if (u == 0) return MODL_OK;                                                                                 \
         hipLaunchKernelGGL((recsys_update_B_kernel<T>), dim3((unsigned)cdiv(u, 4)), dim3(256), 0, (hipStream_t)stream, \
                            d_Bt, k, d_feature_n_iter, d_subset, d_fptr, d_entry_sample, d_entry_val, d_code_b,        \
-                           w_times_n_iter, u);                                                                      \
+                           (const int64_t *)nullptr, w_times_n_iter, u);                                                                      \
         MODL_LAUNCH_CHECK();                                                                                        \
         return MODL_OK;                                                                                             \
     }                                                                                                               \
@@ -223,5 +372,69 @@ ABI_RECSYS(f64, double)
 #undef ABI_RECSYS
 
 size_t modl_dict_update_workspace(int dtype, int64_t s_max, int k) { return dict_update_workspace(dtype, s_max, k); }
+
+int modl_recsys_plan_create(int dtype, int64_t p, int k, int64_t max_batch, int64_t max_entries, modl_recsys_plan **out) {
+    if (!out || (dtype != MODL_F32 && dtype != MODL_F64) || p <= 0 || k <= 0 || max_batch <= 0 || max_entries < 0)
+        return MODL_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MODL_ENOGPU;
+    modl_recsys_plan *pl = new (std::nothrow) modl_recsys_plan();
+    if (!pl) return MODL_ENOMEM;
+    pl->dtype = dtype; pl->p = p; pl->k = k; pl->max_batch = max_batch; pl->max_entries = max_entries;
+    const size_t tsz = dtype == MODL_F32 ? 4 : 8;
+    const int64_t u_max = max_entries < p ? max_entries : p;
+    pl->stage_bytes = recsys_layout(tsz, max_batch, k, u_max, max_entries).total;
+    pl->ws_bytes = dict_update_workspace(dtype, p, k);
+    pl->cnt.assign((size_t)p, 0);
+    hipError_t e = hipMalloc((void **)&pl->dstage, pl->stage_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&pl->ws, pl->ws_bytes > 0 ? pl->ws_bytes : 16);
+    for (int i = 0; i < kRecsysSlots && e == hipSuccess; ++i) {
+        e = hipHostMalloc((void **)&pl->h[i], pl->stage_bytes, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&pl->hdev[i], pl->h[i], 0);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        modl_recsys_plan_destroy(pl);
+        return (int)e;
+    }
+    *out = pl;
+    return MODL_OK;
+}
+
+void modl_recsys_plan_destroy(modl_recsys_plan *pl) {
+    if (!pl) return;
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < kRecsysSlots; ++i) {
+        if (pl->ev[i]) (void)hipEventDestroy(pl->ev[i]);
+        if (pl->h[i]) (void)hipHostFree(pl->h[i]);
+    }
+    if (pl->dstage) (void)hipFree(pl->dstage);
+    if (pl->ws) (void)hipFree(pl->ws);
+    delete pl;
+}
+
+#define MODL_RECSYS_MB_ARGS_OK                                                                                       \
+    (pl && h_indptr && h_indices && h_data && d_indptr && d_indices && d_data && h_rows && h_order && d_Dt && d_Bt && \
+     d_C && d_code && d_comp_norm && d_feature_n_iter && n_rows >= 0)
+int modl_recsys_minibatch_f32(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_t *h_indices, const float *h_data,
+                              int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const float *d_data,
+                              const int64_t *h_rows, int64_t b, const int64_t *h_order, double alpha, double w,
+                              double n_iter, float *d_Dt, float *d_Bt, float *d_C, float *d_code, float *d_comp_norm,
+                              int64_t *d_feature_n_iter, void *stream) {
+    if (!MODL_RECSYS_MB_ARGS_OK || pl->dtype != MODL_F32) return MODL_EINVAL;
+    return recsys_minibatch<float>(pl, h_indptr, h_indices, h_data, n_rows, d_indptr, d_indices, d_data, h_rows, b, h_order,
+                                   alpha, w, n_iter, d_Dt, d_Bt, d_C, d_code, d_comp_norm, d_feature_n_iter,
+                                   (hipStream_t)stream);
+}
+int modl_recsys_minibatch_f64(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_t *h_indices, const double *h_data,
+                              int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const double *d_data,
+                              const int64_t *h_rows, int64_t b, const int64_t *h_order, double alpha, double w,
+                              double n_iter, double *d_Dt, double *d_Bt, double *d_C, double *d_code,
+                              double *d_comp_norm, int64_t *d_feature_n_iter, void *stream) {
+    if (!MODL_RECSYS_MB_ARGS_OK || pl->dtype != MODL_F64) return MODL_EINVAL;
+    return recsys_minibatch<double>(pl, h_indptr, h_indices, h_data, n_rows, d_indptr, d_indices, d_data, h_rows, b, h_order,
+                                    alpha, w, n_iter, d_Dt, d_Bt, d_C, d_code, d_comp_norm, d_feature_n_iter,
+                                    (hipStream_t)stream);
+}
 
 }  // extern "C"

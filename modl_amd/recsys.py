@@ -54,9 +54,14 @@ class _RecsysDevice:
         self.n, self.p = X.shape
         self.k = k
         dev = self.device
-        self.indptr = torch.from_numpy(X.indptr.astype(np.int32)).to(dev)
-        self.indices = torch.from_numpy(X.indices.astype(np.int32)).to(dev)
-        self.data = torch.from_numpy(np.ascontiguousarray(X.data, dtype=self.dtype)).to(dev)
+        self.plan, self.plan_batch = None, 0
+        # the CSR matrix on both sides: the host copy feeds the per-batch grouping, the device copy the kernels
+        self.h_indptr = np.ascontiguousarray(X.indptr, dtype=np.int32)
+        self.h_indices = np.ascontiguousarray(X.indices, dtype=np.int32)
+        self.h_data = np.ascontiguousarray(X.data, dtype=self.dtype)
+        self.indptr = torch.from_numpy(self.h_indptr).to(dev)
+        self.indices = torch.from_numpy(self.h_indices).to(dev)
+        self.data = torch.from_numpy(self.h_data).to(dev)
         td = torch_dtype(self.dtype)
         self.Dt = torch.zeros((self.p, k), dtype=td, device=dev)
         self.Bt = torch.zeros((self.p, k), dtype=td, device=dev)
@@ -85,43 +90,41 @@ class _RecsysDevice:
             check(f(ptr(self.Dt), self.p, self.k, ptr(self.indptr), ptr(self.indices), ptr(self.data), ptr(r), None,
                     len(rows), float(alpha), ptr(self.code), stream_ptr(self.device)), 'modl_recsys_codes')
 
-    def batch_update(self, X, batch, alpha, w, n_iter, order):
-        """One minibatch (recsys.py:147-165) for the CSR rows `batch` (in this order)."""
-        dev, k = self.device, self.k
-        self.codes(batch, alpha)
-        rows_t = torch.from_numpy(np.ascontiguousarray(batch, dtype=np.int64)).to(dev)
-        code_b = self.code.index_select(0, rows_t).contiguous()
-        # the batch's entries grouped by feature, in batch order inside a feature
-        starts, ends = X.indptr[batch], X.indptr[batch + 1]
-        lens = ends - starts
-        if lens.sum() > 0:
-            pos = np.repeat(np.arange(len(batch), dtype=np.int32), lens)
-            flat = np.concatenate([np.arange(s, e) for s, e in zip(starts, ends)])
-            cols = X.indices[flat]
-            o = np.argsort(cols, kind='stable')
-            subset, counts = np.unique(cols[o], return_counts=True)
-            fptr = np.zeros(len(subset) + 1, dtype=np.int32)
-            fptr[1:] = np.cumsum(counts)
-            t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
-            d_subset, d_fptr = t(subset, np.int32), t(fptr, np.int32)
-            d_es, d_ev = t(pos[o], np.int32), t(X.data[flat][o], self.dtype)
-            f = getattr(lib, 'modl_recsys_update_B_' + sfx(self.dtype))
-            check(f(ptr(self.Bt), k, ptr(self.feature_n_iter), ptr(d_subset), ptr(d_fptr), ptr(d_es), ptr(d_ev),
-                    ptr(code_b), float(w) * float(n_iter), len(subset), stream_ptr(dev)), 'modl_recsys_update_B')
-        else:
-            subset, d_subset = np.zeros(0, dtype=np.int32), None
-        ct = C.c_float if self.dtype == np.float32 else C.c_double
-        f = getattr(lib, 'modl_gram_axpby_' + sfx(self.dtype))
-        check(f(ptr(code_b), len(batch), k, ptr(self.C), ct(1 - w), ct(w / len(batch)), stream_ptr(dev)),
-              'modl_gram_axpby')
-        if len(subset):
-            d_order = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int32)).to(dev)
-            h_order = np.ascontiguousarray(order, dtype=np.int64)
-            f = getattr(lib, 'modl_dict_update_' + sfx(self.dtype))
-            check(f(ptr(self.Dt), ptr(self.Bt), ptr(self.C), ptr(self.comp_norm), ptr(d_subset), len(subset),
-                    ptr(d_order), h_order.ctypes.data_as(C.c_void_p), k, 0, 0, 0.0, float(w), 1.0, ptr(self.ws),
-                    self.ws_bytes, stream_ptr(dev)), 'modl_dict_update')
-            torch.cuda.synchronize(dev)          # h_order / staging tensors must outlive the launches
+    def batch_update(self, batch, alpha, w, n_iter, order):
+        """One minibatch (recsys.py:147-165) for the CSR rows `batch` (in this order): one asynchronous call
+        (modl_recsys_minibatch_*: host grouping of the batch's ratings by item, staging, codes, B_, C_, dictionary)."""
+        batch = np.ascontiguousarray(batch, dtype=np.int64)
+        order = np.ascontiguousarray(order, dtype=np.int64)
+        if self.plan is None or len(batch) > self.plan_batch:
+            self._make_plan(len(batch))
+        f = getattr(lib, 'modl_recsys_minibatch_' + sfx(self.dtype))
+        check(f(self.plan, self.h_indptr.ctypes.data_as(C.c_void_p), self.h_indices.ctypes.data_as(C.c_void_p),
+                self.h_data.ctypes.data_as(C.c_void_p), self.n, ptr(self.indptr), ptr(self.indices), ptr(self.data),
+                batch.ctypes.data_as(C.c_void_p), len(batch), order.ctypes.data_as(C.c_void_p), float(alpha), float(w),
+                float(n_iter), ptr(self.Dt), ptr(self.Bt), ptr(self.C), ptr(self.code), ptr(self.comp_norm),
+                ptr(self.feature_n_iter), stream_ptr(self.device)), 'modl_recsys_minibatch')
+
+    def _make_plan(self, batch_size):
+        self._free_plan()
+        # the largest number of ratings a batch of this size can hold: its batch_size longest rows
+        lens = np.sort(np.diff(self.h_indptr))[::-1]
+        max_entries = int(lens[:batch_size].sum())
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.modl_recsys_plan_create(dtype_id(self.dtype), self.p, self.k, batch_size, max_entries, C.byref(h)),
+                  'modl_recsys_plan_create')
+        self.plan, self.plan_batch = h, batch_size
+
+    def _free_plan(self):
+        if getattr(self, 'plan', None):
+            lib.modl_recsys_plan_destroy(self.plan)
+        self.plan, self.plan_batch = None, 0
+
+    def __del__(self):
+        try:
+            self._free_plan()
+        except Exception:
+            pass
 
     def predict(self, Xp):
         dev = self.device
@@ -226,7 +229,7 @@ class RecsysDictFact(BaseEstimator):
         self.n_iter_ += batch_size
         w = batch_weight(self.n_iter_, batch_size, self.learning_rate, 0)
         order = self.random_state.permutation(self.n_components)     # recsys.py:196 (drawn for every batch)
-        self._dev.batch_update(X, batch, self.alpha, w, self.n_iter_, order)
+        self._dev.batch_update(batch, self.alpha, w, self.n_iter_, order)
 
     def _refit(self):
         """recsys.py:254-265: ridge codes of every row with the current dictionary"""
