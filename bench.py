@@ -30,16 +30,19 @@ sys.path.insert(0, ROOT)
 K_COMP, P_FEAT, BATCH, CHUNK = 256, 10000, 256, 65536
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = 'r01_m_pmc_hbm_traffic.json'
+PMC_FILE = 'r01_n_pmc_hbm_traffic.json'
 DOM_KERNEL = {'dict_update': 'modl::bcd_block_kernel', 'code_solve': 'modl::cd_kernel', 'stats_gemm': 'modl::gemm_stats_pair_kernel',
               'code_gemm': 'modl::gemm_dense_pair_kernel<float, false', 'stats_apply': 'modl::stats_apply2_kernel'}
 
 
-def make_stream(n_rows, p, seed, device, k0=256, density=0.1, noise=0.1):
-    """M1 stream: X = (Z o M) Q / sqrt(density k0) + noise E  (unit-variance entries)."""
+def make_stream(n_rows, p, seed, device, k0=256, density=0.1, noise=0.1, row_seed=None):
+    """M1 stream: X = (Z o M) Q / sqrt(density k0) + noise E  (unit-variance entries).  The mixing matrix Q is drawn
+    from `seed` (the same on every rank), the rows from `row_seed` (one stream of rows per rank)."""
     import torch
     g = torch.Generator(device=device).manual_seed(seed)
     Q = torch.randn(k0, p, device=device, generator=g)
+    if row_seed is not None:
+        g = torch.Generator(device=device).manual_seed(row_seed)
     X = torch.empty(n_rows, p, device=device, dtype=torch.float32)
     step = 8192
     for r0 in range(0, n_rows, step):
@@ -92,10 +95,13 @@ def run_gpu(args, reduction, steps, warmup, rank, world, device, breakdown=True)
     from modl_amd import DictFact
     extra = min(steps, 50) if breakdown else 0
     n_rows = min(CHUNK, max(4096, (steps + warmup + extra) * BATCH))
-    X = make_stream(n_rows, P_FEAT, 1234 + rank, device)
+    X = make_stream(n_rows, P_FEAT, 1234, device, row_seed=None if world == 1 else 5000 + rank)
+    # the dictionary is initialised from the same rows on every rank (replicas stay identical: same init, same draws,
+    # all-reduced statistics)
+    X0 = X[:K_COMP] if world == 1 else make_stream(K_COMP, P_FEAT, 1234, device, row_seed=4999)
     est = DictFact(n_components=K_COMP, batch_size=BATCH, reduction=reduction, code_alpha=1.0, code_l1_ratio=1,
                    comp_l1_ratio=0, learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0)
-    est.prepare(n_samples=n_rows, X=X[:K_COMP])
+    est.prepare(n_samples=n_rows, X=X0)
     if getattr(args, 'force_reduce', False):                 # testing only: the N > 1 step with one rank
         est._two_phase = True
         est._force_reduce = True
@@ -151,6 +157,13 @@ def run_gpu(args, reduction, steps, warmup, rank, world, device, breakdown=True)
         dt = float(t.item())
     D = est.components_
     ok = bool(np.all(np.isfinite(D)))
+    run_gpu.replicas_identical = None
+    if world > 1:                                  # the replicas of the dictionary must agree bit for bit
+        chk = torch.stack([be.Dt.double().sum(), (be.Dt.double() ** 2).sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        run_gpu.replicas_identical = bool(torch.equal(lo, hi))
     return dt, prof, sweeps, ok, dom, prof_dom
 
 
@@ -269,6 +282,7 @@ def main():
                                            'the rest of the B increment all-reduced under the dictionary update)' % world),
                    roofline=roof, sections=sections, cd_sweeps_mean=sweeps, cd_sweeps_max=getattr(run_gpu, 'sweeps_max', None),
                    step_tflops=total_fl / (dt / args.steps) / 1e12, finite=ok,
+                   replicas_identical=getattr(run_gpu, 'replicas_identical', None),
                    host_enqueue_ms_per_step=getattr(run_gpu, 'host_ms_per_step', None))
     if args.also_r1:
         dt1, prof1, sw1, ok1, _, _ = run_gpu(args, 1.0, max(args.steps // 2, 10), max(args.warmup // 2, 2), rank, world, device,

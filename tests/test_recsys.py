@@ -99,3 +99,19 @@ def test_ref_dict_completion_missing():                       # test_recsys.py:6
     base = np.sqrt(np.mean((Xte.data - (np.repeat(mf.row_mean_, np.diff(Xte.indptr))
                                         + mf.col_mean_.take(Xte.indices))) ** 2))
     assert rmse < base
+
+
+def test_shuffle_split_partitions_the_entries():
+    """modl/utils/recsys/cross_validation.py:8-42: a partition of the stored entries, reproducible for a seed"""
+    import scipy.sparse as sp
+    from modl_amd.utils.recsys import ShuffleSplit, train_test_split
+    rs = np.random.RandomState(0)
+    X = sp.random(30, 20, density=0.3, random_state=rs, format='csr')
+    tr, te = train_test_split(X, train_size=0.75, random_state=3)
+    assert tr.shape == te.shape == X.shape and tr.nnz == int(0.75 * X.nnz) and tr.nnz + te.nnz == X.nnz
+    assert abs((tr + te) - X).sum() == 0 and tr.multiply(te).nnz == 0
+    ind = np.random.RandomState(3).permutation(X.nnz)                      # the reference's draw
+    coo = X.tocoo()
+    assert np.array_equal(tr.row, coo.row[ind[:tr.nnz]]) and np.array_equal(tr.data, coo.data[ind[:tr.nnz]])
+    splits = list(ShuffleSplit(n_iter=3, train_size=0.5, random_state=1).split(X))
+    assert len(splits) == 3 and (splits[0][0] != splits[1][0]).nnz > 0
