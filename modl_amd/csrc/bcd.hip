@@ -35,6 +35,7 @@
 #include "gemm.hpp"
 #include "gemm_dense.hpp"
 #include "kernels.hpp"
+#include <utility>
 #include <type_traits>
 
 namespace modl {
@@ -60,7 +61,7 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     L.nslab_max = cdiv(s_max > 0 ? s_max : 1, 32);      // the fused block kernel uses slabs of 32 or 64 rows
-    L.nwg_grad = 512;
+    L.nwg_grad = 2048;
     L.off_CP = take(tsz * (size_t)k * k);
     L.off_cdiag = take(tsz * (size_t)k);
     L.off_frozen = take(sizeof(int32_t) * (size_t)k);
@@ -954,7 +955,10 @@ __global__ __launch_bounds__(256) void atom_grad_kernel(const T *Dt, const T *Bt
     const int e0 = lane * KPL;
     T cc[KPL];
 #pragma unroll
-    for (int c = 0; c < KPL; ++c) cc[c] = (e0 + c < k) ? C[(int64_t)j * k + e0 + c] : (T)0;   // row j == column j
+    for (int c = 0; c < KPL; ++c) {                                     // row j == column j (unconditional, clamped loads)
+        const T cv = C[(int64_t)j * k + (e0 + c < k ? e0 + c : k - 1)];
+        cc[c] = (e0 + c < k) ? cv : (T)0;
+    }
     const T Cjj = C[(int64_t)j * k + j];
     const bool frozen = !(Cjj > (T)1e-20);
     double old = 0;
@@ -962,8 +966,7 @@ __global__ __launch_bounds__(256) void atom_grad_kernel(const T *Dt, const T *Bt
         const T *row = Dt + sub_row(subset, f) * k;
         double dot = 0;
 #pragma unroll
-        for (int c = 0; c < KPL; ++c)
-            if (e0 + c < k) dot += (double)row[e0 + c] * (double)cc[c];
+        for (int c = 0; c < KPL; ++c) dot += (double)row[e0 + c < k ? e0 + c : k - 1] * (double)cc[c];   // cc = 0 beyond k
         dot = wave_sum(dot);
         if (lane == 0) {
             const T dj = row[j];
@@ -987,7 +990,7 @@ constexpr int kProjEpt = 24;
 template <typename T>
 __device__ __forceinline__ void atom_project(T *u, T *ul, const double *partial_old, int nparts, T *Dt,
                                              const int32_t *subset, int64_t s, int k, int j, double rho, T *comp_norm,
-                                             double *red, unsigned long long *dbg = nullptr) {
+                                             double *red, unsigned long long *dbg = nullptr, double *level_hint = nullptr) {
     const bool in_regs = s <= (int64_t)kProjEpt * 256 && blockDim.x >= 256;
     const int nthr = in_regs ? 256 : (int)blockDim.x;
     if ((int)threadIdx.x >= nthr) return;
@@ -1003,7 +1006,8 @@ __device__ __forceinline__ void atom_project(T *u, T *ul, const double *partial_
     if (dbg && threadIdx.x == 0) dbg[7] = clock64();
     double nrm;
     if (in_regs) {                                                   // projected values go straight to the dictionary
-        nrm = block_enet_project_reg<T, kProjEpt>(u, Dt + j, subset, (int64_t)k, s, radius, rho, red, nthr, dbg);
+        nrm = block_enet_project_reg<T, kProjEpt>(u, Dt + j, subset, (int64_t)k, s, radius, rho, red, nthr, dbg,
+                                                  level_hint ? level_hint + j : nullptr);
     } else {
         nrm = block_enet_project<T>(w, 1, w, 1, s, radius, rho, red);
         __syncthreads();
@@ -1026,7 +1030,7 @@ template <typename T, int KPL>
 __global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, const T *C, const int32_t *subset, int64_t s,
                                                         int k, int j, int pos, double rho, T *u, double *partial_old,
                                                         T *comp_norm, unsigned int *counter, int u_in_lds,
-                                                        unsigned long long *dbg) {
+                                                        unsigned long long *dbg, double *level_hint) {
     extern __shared__ __attribute__((aligned(16))) char step_smem[];   // the s-vector for the projection, if it fits
     __shared__ double red[32];
     __shared__ int flag;
@@ -1035,7 +1039,10 @@ __global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, cons
     const int e0 = lane * KPL;
     T cc[KPL];
 #pragma unroll
-    for (int c = 0; c < KPL; ++c) cc[c] = (e0 + c < k) ? C[(int64_t)j * k + e0 + c] : (T)0;   // row j == column j
+    for (int c = 0; c < KPL; ++c) {                                     // row j == column j (unconditional, clamped loads)
+        const T cv = C[(int64_t)j * k + (e0 + c < k ? e0 + c : k - 1)];
+        cc[c] = (e0 + c < k) ? cv : (T)0;
+    }
     const T Cjj = C[(int64_t)j * k + j];
     const bool frozen = !(Cjj > (T)1e-20);
     double old = 0;
@@ -1047,8 +1054,7 @@ __global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, cons
         const T dj = row[j], bj = Bt[r + j];
         double dot = 0;
 #pragma unroll
-        for (int c = 0; c < KPL; ++c)
-            if (e0 + c < k) dot += (double)row[e0 + c] * (double)cc[c];
+        for (int c = 0; c < KPL; ++c) dot += (double)row[e0 + c < k ? e0 + c : k - 1] * (double)cc[c];   // cc = 0 beyond k
         dot = wave_sum(dot);
         if (lane == 0) {
             T val = dj;
@@ -1065,8 +1071,170 @@ __global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, cons
     if (!arrive_last(counter, gridDim.x, &flag)) return;
     const unsigned long long t2 = clock64();
     atom_project<T>(u, u_in_lds ? reinterpret_cast<T *>(step_smem) : nullptr, partial_old, (int)gridDim.x, Dt, subset, s, k, j,
-                    rho, comp_norm, red, dbg);
+                    rho, comp_norm, red, dbg, level_hint);
     if (dbg && threadIdx.x == 0) { dbg[0] = t0; dbg[1] = t1; dbg[2] = t2; dbg[3] = clock64(); }
+}
+
+// A GROUP of up to kAtomGroup consecutive atoms of the sweep in ONE launch.  Of the 23 us an atom costs with one launch
+// each, the launch boundary, the gradient row and the hand-off to the projecting workgroup are 60 %; they are shared by
+// the group.  Every workgroup evaluates, for its features, the numerators of the candidates of ALL atoms of the group
+// against the dictionary as it is at the start of the launch (one read of the dictionary row serves the group); the
+// last workgroup to arrive then projects the atoms one after the other, the numerator of atom a corrected for what the
+// atoms before it in the group just changed:
+//     num_a[f] -= sum_{a' < a} C[j_a', j_a] (D_new[j_a'][f] - D_old[j_a'][f])
+// which is exactly the difference between the gradient row of the sequential sweep and the stale one (the own term
+// C_jj D_old[j][f] does not depend on the other atoms).  Same update as atom_step_kernel up to the rounding of that
+// double-precision correction.  Needs the vector in the registers of the projecting workgroup (s <= kProjEpt * 256).
+constexpr int kAtomGroup = 4;
+struct AtomGroup { int j[kAtomGroup]; int n; };
+
+template <typename T, int KPL>
+__global__ __launch_bounds__(256) void atom_group_kernel(T *Dt, const T *Bt, const T *C, const int32_t *subset, int64_t s,
+                                                         int k, AtomGroup g, int pos, double rho, double *num, T *dold,
+                                                         double *partial_old, T *comp_norm, unsigned int *counter,
+                                                         double *level_hint) {
+    __shared__ double red[32];
+    __shared__ int flag;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int e0 = lane * KPL;
+    int ja[kAtomGroup];
+    T cc[kAtomGroup][KPL], Cjj[kAtomGroup];
+#pragma unroll
+    for (int a = 0; a < kAtomGroup; ++a) {
+        ja[a] = g.j[a < g.n ? a : 0];                                   // (a short last group repeats its first atom: not stored)
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+            const T cv = C[(int64_t)ja[a] * k + (e0 + c < k ? e0 + c : k - 1)];
+            cc[a][c] = (e0 + c < k) ? cv : (T)0;
+        }
+        Cjj[a] = C[(int64_t)ja[a] * k + ja[a]];
+    }
+    double old[kAtomGroup];
+#pragma unroll
+    for (int a = 0; a < kAtomGroup; ++a) old[a] = 0;
+    const int nwv = (int)(blockDim.x >> 6);
+    for (int64_t f = (int64_t)blockIdx.x * nwv + wid; f < s; f += (int64_t)gridDim.x * nwv) {
+        const int64_t r = sub_row(subset, f) * k;
+        const T *row = Dt + r;
+        T rv[KPL], dj[kAtomGroup], bj[kAtomGroup];
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) rv[c] = row[e0 + c < k ? e0 + c : k - 1];
+#pragma unroll
+        for (int a = 0; a < kAtomGroup; ++a) { dj[a] = row[ja[a]]; bj[a] = Bt[r + ja[a]]; }
+#pragma unroll
+        for (int a = 0; a < kAtomGroup; ++a) {
+            double dot = 0;
+#pragma unroll
+            for (int c = 0; c < KPL; ++c) dot += (double)rv[c] * (double)cc[a][c];
+            dot = wave_sum(dot);
+            if (lane == 0 && a < g.n) {
+                num[(int64_t)a * s + f] = ((double)bj[a] - dot) + (double)Cjj[a] * (double)dj[a];
+                dold[(int64_t)a * s + f] = dj[a];
+                const double ab = fabs((double)dj[a]);
+                old[a] += ab * (rho + (1.0 - rho) * ab);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < kAtomGroup; ++a) {
+        const double o = block_sum(old[a], red);
+        if (threadIdx.x == 0) partial_old[(int64_t)a * gridDim.x + blockIdx.x] = o;
+    }
+    if (!arrive_last(counter, gridDim.x, &flag)) return;
+
+    // ---- the last workgroup: the atoms of the group, in sweep order.  A single workgroup pays a full memory round trip
+    // for every dependent load, so nothing is fetched when it is needed: the scalars of the whole group come first (one
+    // trip), the numerators of atom a + 1 are in registers before atom a is projected (ping-pong register sets, the
+    // steps are unrolled), and what atom a changed is applied from registers to the prefetched numerators of atom a + 1
+    // and, read-modify-write, to those of the atoms after it.
+    const int nparts = (int)gridDim.x;
+    __shared__ double s_coef[kAtomGroup][kAtomGroup], s_cjj[kAtomGroup], s_cn[kAtomGroup], s_old[kAtomGroup];
+    if (threadIdx.x < kAtomGroup * kAtomGroup) {
+        const int b = threadIdx.x / kAtomGroup, a = threadIdx.x % kAtomGroup;
+        const int jb = g.j[b < g.n ? b : 0], jaa = g.j[a < g.n ? a : 0];   // (from the kernel arguments: a private array
+        s_coef[b][a] = (double)C[(int64_t)jb * k + jaa];                   //  indexed per thread would live in scratch)
+        if (b == 0) { s_cjj[a] = (double)C[(int64_t)jaa * k + jaa]; s_cn[a] = (double)comp_norm[jaa]; }
+    }
+    {
+        double o[kAtomGroup];
+#pragma unroll
+        for (int a = 0; a < kAtomGroup; ++a) {
+            o[a] = 0;
+            for (int i = threadIdx.x; i < nparts; i += 256) o[a] += partial_old[(int64_t)a * nparts + i];
+        }
+        block_sum2(o[0], o[1], red, 256);
+        block_sum2(o[2], o[3], red, 256);
+        if (threadIdx.x == 0) { s_old[0] = o[0]; s_old[1] = o[1]; s_old[2] = o[2]; s_old[3] = o[3]; }
+    }
+    int64_t dst[kProjEpt];
+    enet_scatter_offsets<kProjEpt>(subset, (int64_t)k, s, 256, dst);
+    double X[2][kProjEpt];
+    T Dd[2][kProjEpt];
+    auto load_atom = [&](int a, double (&xd)[kProjEpt], T (&dd)[kProjEpt]) {
+        const int ac = a < g.n ? a : g.n - 1;                            // always a valid slot: no branch around the loads
+#pragma unroll
+        for (int e = 0; e < kProjEpt; ++e) {
+            const int64_t i = threadIdx.x + (int64_t)e * 256;
+            const int64_t at = (int64_t)ac * s + (i < s ? i : s - 1);
+            xd[e] = num[at];
+            dd[e] = dold[at];
+        }
+    };
+    load_atom(0, X[0], Dd[0]);
+    load_atom(1, X[1], Dd[1]);
+    __syncthreads();                                                     // s_coef / s_cjj / s_cn / s_old
+    auto step = [&](auto A_) {
+        constexpr int a = decltype(A_)::value;
+        if (a >= g.n) return;                                            // workgroup-uniform
+        double (&x)[kProjEpt] = X[a & 1];
+        T (&dd)[kProjEpt] = Dd[a & 1];
+        const int j = g.j[a];
+        const double radius = (double)(T)(s_cn[a] + s_old[a]);          // comp_norm_[k] += subset_norm (:676-678)
+        const double cjj = s_cjj[a];
+        const bool frozen = !((T)cjj > (T)1e-20);
+#pragma unroll
+        for (int e = 0; e < kProjEpt; ++e) {
+            const int64_t i = threadIdx.x + (int64_t)e * 256;
+            T val = dd[e];
+            if (!frozen) val = (T)(x[e] / cjj);
+            if (pos && val < (T)0) val = 0;                              // dict_fact.py:684-685
+            x[e] = (i < s) ? (double)val : 0.0;
+        }
+        const double nrm = block_enet_project_vals<T, kProjEpt>(x, dst, Dt + j, s, radius, rho, red, 256, nullptr,
+                                                                level_hint ? level_hint + j : nullptr);
+        if (threadIdx.x == 0) comp_norm[j] = (T)(radius - nrm);         // :690-692
+        if (a + 1 < g.n) {
+            double (&xn)[kProjEpt] = X[(a + 1) & 1];
+            const double c1 = s_coef[a][(a + 1) % kAtomGroup];
+#pragma unroll
+            for (int e = 0; e < kProjEpt; ++e) {
+                x[e] -= (double)dd[e];                                   // what this atom changed (0 beyond s)
+                xn[e] -= c1 * x[e];
+            }
+#pragma unroll
+            for (int a2 = a + 2; a2 < kAtomGroup; ++a2) {                // the atoms after the next: read-modify-write
+                if (a2 < g.n) {
+                    const double c2 = s_coef[a][a2];
+                    double t[kProjEpt];
+#pragma unroll
+                    for (int e = 0; e < kProjEpt; ++e) {
+                        const int64_t i = threadIdx.x + (int64_t)e * 256;
+                        t[e] = num[(int64_t)a2 * s + (i < s ? i : s - 1)];
+                    }
+#pragma unroll
+                    for (int e = 0; e < kProjEpt; ++e) {
+                        const int64_t i = threadIdx.x + (int64_t)e * 256;
+                        if (i < s) num[(int64_t)a2 * s + i] = t[e] - c2 * x[e];   // read back by this same thread
+                    }
+                }
+            }
+            if (a + 2 < kAtomGroup) load_atom(a + 2, X[a & 1], Dd[a & 1]);   // lands while atom a + 1 is projected
+        }
+    };
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
 }
 
 // The whole sweep in ONE launch, by one workgroup, for TINY problems (u = the s-vector of the atom in flight
@@ -1373,18 +1541,50 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
         return MODL_OK;
     }
     int nwg = (int)cdiv(s, 4);                       // 4 waves per workgroup (the projection wants registers: 256 threads), one feature per wave while the grid lasts
+    static const int nwg_cap = getenv("MODL_NWG_GRAD") ? atoi(getenv("MODL_NWG_GRAD")) : 512;   // (tuning)
+    if (nwg > nwg_cap) nwg = nwg_cap;
     if (nwg > L.nwg_grad) nwg = (int)L.nwg_grad;
     if (nwg < 1) nwg = 1;
     unsigned int *counter = reinterpret_cast<unsigned int *>(reinterpret_cast<double *>(ws + L.off_Tp) + 2 * kResStride);
     MODL_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned int), stream));   // the last arriver re-arms it after each atom
     const size_t u_lds = (sizeof(T) * (size_t)s <= 60 * 1024) ? sizeof(T) * (size_t)s : 0;
+    // groups of atoms per launch while the vector fits the registers of the projecting workgroup and the group's
+    // scratch (numerators, old values, changes) fits the region of the sgd candidate matrix
+    static const bool no_group = getenv("MODL_NO_ATOM_GROUP") != nullptr;   // (diagnostics)
+    const size_t group_bytes = (size_t)kAtomGroup * (size_t)s * (sizeof(double) + sizeof(T));
+    if (!no_group && s <= (int64_t)kProjEpt * 256 && group_bytes + 64 <= sizeof(T) * (size_t)s * k && k <= 512 &&
+        (int64_t)kAtomGroup * nwg <= L.nwg_grad) {
+        char *gb = ws + L.off_Dnew;
+        double *num = reinterpret_cast<double *>(gb);
+        T *dold = reinterpret_cast<T *>(num + (size_t)kAtomGroup * s);
+        for (int t = 0; t < k; t += kAtomGroup) {
+            AtomGroup g;
+            g.n = (k - t < kAtomGroup) ? k - t : kAtomGroup;
+            for (int a = 0; a < kAtomGroup; ++a) {
+                const int64_t j = h_order[t + (a < g.n ? a : 0)];
+                if (j < 0 || j >= k) return MODL_EINVAL;
+                g.j[a] = (int)j;
+            }
+#define MODL_GROUP(KPL)                                                                                           \
+    hipLaunchKernelGGL((atom_group_kernel<T, KPL>), dim3(nwg), dim3(256), 0, stream, a.Dt, a.Bt, a.C, a.subset, s, k, g, \
+                       a.comp_pos, a.comp_l1_ratio, num, dold, pold, a.comp_norm, counter, a.level_hint)
+            if (k <= 64) MODL_GROUP(1);
+            else if (k <= 128) MODL_GROUP(2);
+            else if (k <= 256) MODL_GROUP(4);
+            else MODL_GROUP(8);
+#undef MODL_GROUP
+            MODL_LAUNCH_CHECK();
+            if (launches) *launches += 1;
+        }
+        return MODL_OK;
+    }
     for (int t = 0; t < k; ++t) {
         const int j = (int)h_order[t];
         if (j < 0 || j >= k) return MODL_EINVAL;
 #define MODL_STEP(KPL)                                                                                            \
     hipLaunchKernelGGL((atom_step_kernel<T, KPL>), dim3(nwg), dim3(256), u_lds, stream, a.Dt, a.Bt, a.C, a.subset, s, k, j, \
                        a.comp_pos, a.comp_l1_ratio, u, pold, a.comp_norm, counter, u_lds ? 1 : 0, \
-                       reinterpret_cast<unsigned long long *>(counter + kCounters))
+                       reinterpret_cast<unsigned long long *>(counter + kCounters), a.level_hint)
         if (k <= 64) MODL_STEP(1);
         else if (k <= 128) MODL_STEP(2);
         else if (k <= 256) MODL_STEP(4);

@@ -111,29 +111,43 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *red2, i
 // REGISTERS across the Michelot passes: a pass is a handful of compares and one block exchange instead of a scan
 // of the vector.  Four wavefronts (one per SIMD) beat sixteen here: the passes are reductions, and wavefronts
 // sharing a SIMD serialise them.  red2: >= 2 * nthreads / 64 doubles.
-template <typename T, int EPT>
-__device__ double block_enet_project_reg(const T *v, T *out, const int32_t *rows, int64_t row_stride, int64_t n,
-                                         double radius, double l1_ratio, double *red2, int nthreads,
-                                         unsigned long long *dbg = nullptr) {
-    // element i is written to out[(rows ? rows[i] : i) * row_stride]: the scatter indices are fetched together
-    // with the vector, so that the write-back is not a chain of index load -> store round trips
-    int64_t dst[EPT];
+// element i is written to out[(rows ? rows[i] : i) * row_stride]: the scatter offsets are fetched up front, together with
+// the vector, so that the write-back is not a chain of index load -> store round trips.
+// (Every load is UNCONDITIONAL, from a clamped index, the selection follows: a per-thread branch around a load makes the
+// compiler wait for that load on the spot, and 2 * EPT requests become as many serial memory round trips -- 22 k of the
+// 43 k cycles of a projection before this was removed.)
+template <int EPT>
+__device__ __forceinline__ void enet_scatter_offsets(const int32_t *rows, int64_t row_stride, int64_t n, int nthreads,
+                                                     int64_t (&dst)[EPT]) {
+    if (rows) {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int64_t i = threadIdx.x + (int64_t)e * nthreads;
-        dst[e] = (i < n) ? (rows ? (int64_t)rows[i] : i) * row_stride : 0;
+        for (int e = 0; e < EPT; ++e) {
+            const int64_t i = threadIdx.x + (int64_t)e * nthreads;
+            const int64_t r = (int64_t)rows[i < n ? i : n - 1];
+            dst[e] = (i < n) ? r * row_stride : 0;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int64_t i = threadIdx.x + (int64_t)e * nthreads;
+            dst[e] = (i < n) ? i * row_stride : 0;
+        }
     }
+}
+
+// The projection of the register-resident vector x (element threadIdx.x + e * nthreads in x[e], zeros beyond n; the values
+// are T-representable).  Writes the result to out[dst[e]] and LEAVES IT IN x; returns its enet norm (every thread).
+template <typename T, int EPT>
+__device__ __forceinline__ double block_enet_project_vals(double (&x)[EPT], const int64_t (&dst)[EPT], T *out, int64_t n, double radius,
+                                          double l1_ratio, double *red2, int nthreads, unsigned long long *dbg = nullptr,
+                                          double *level_io = nullptr) {
     if (!(radius > 0.0)) {                                   // enet.pyx:57-59 (radius == 0 -> zeros)
 #pragma unroll
-        for (int e = 0; e < EPT; ++e)
+        for (int e = 0; e < EPT; ++e) {
             if (threadIdx.x + (int64_t)e * nthreads < n) out[dst[e]] = 0;
+            x[e] = 0.0;
+        }
         return 0.0;
-    }
-    double x[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int64_t i = threadIdx.x + (int64_t)e * nthreads;
-        x[e] = (i < n) ? (double)v[i] : 0.0;
     }
     if (l1_ratio == 0.0) {                                   // enet.pyx:62-70, radius in squared-norm units
         double s = 0, dummy = 0;
@@ -144,7 +158,9 @@ __device__ double block_enet_project_reg(const T *v, T *out, const int32_t *rows
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int64_t i = threadIdx.x + (int64_t)e * nthreads;
-            if (i < n) out[dst[e]] = (T)x[e] / scale;
+            const T o = (T)x[e] / scale;
+            if (i < n) out[dst[e]] = o;
+            x[e] = (i < n) ? (double)o : 0.0;
         }
         return (s <= radius) ? s : radius;
     }
@@ -171,10 +187,68 @@ __device__ double block_enet_project_reg(const T *v, T *out, const int32_t *rows
         ax[e] = fabs(x[e]);
         term[e] = ax[e] * (1.0 + 0.5 * gamma * ax[e]);
     }
+    // WARM START (level_io: the level this atom ended with at its previous projection, 0 = none).  Michelot's
+    // iteration converges to the level l* from ANY starting level l0 <= l* (levels only rise, entries at or below a
+    // level <= l* are never in the final support), and it ends on the same support, hence on the same sums in the
+    // same order: identical bits.  l0 <= l* holds iff the thresholded vector at l0 still lies outside the ball,
+    // h(l0) = sum_{|x|>l0} u (1 + gamma u / 2) >= R with u = (|x| - l0) / (1 + l0 gamma) (h decreases in l); h(l0)
+    // follows from the sums of the first pass (plus sum |x| when gamma != 0), so the check costs nothing when it
+    // holds and one pass when it does not (cold restart from 0).  Between two minibatches an atom's level moves
+    // little: 8 passes -> 3 on the fMRI shape.
     double level = 0.0, prev_cnt = -1.0;
+    bool verify = false;
+    if (level_io) {
+        const double l0 = 0.9 * *level_io;
+        if (l0 > 0.0 && l0 < 1e300) { level = l0; verify = true; }
+    }
     for (int pass = 0; pass < 256; ++pass) {
         double S = 0, S1 = 0;
         int c0 = 0, c1 = 0;
+        if (verify) {                                        // first pass of a warm start
+            double P = 0;
+            if (gamma != 0.0) {
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) P += (ax[e] > level) ? ax[e] : 0.0;
+            }
+#pragma unroll
+            for (int e = 0; e < EPT; e += 2) {
+                const bool i0 = ax[e] > level, i1 = ax[e + 1] > level;
+                S += i0 ? term[e] : 0.0;
+                S1 += i1 ? term[e + 1] : 0.0;
+                c0 += i0 ? 1 : 0;
+                c1 += i1 ? 1 : 0;
+            }
+            S += S1;
+            double cnt = (double)(c0 + c1), dummy2 = 0;
+            block_sum2(S, cnt, red2, nthreads);
+            double h0;
+            if (gamma != 0.0) {
+                block_sum2(P, dummy2, red2, nthreads);
+                const double d = 1.0 + level * gamma;
+                const double sum_u = (P - cnt * level) / d;
+                const double sum_a2 = (S - P) / (0.5 * gamma);
+                const double sum_u2 = (sum_a2 - 2.0 * level * P + cnt * level * level) / (d * d);
+                h0 = sum_u + 0.5 * gamma * sum_u2;
+            } else {
+                h0 = S - cnt * level;
+            }
+            verify = false;
+            if (!(h0 >= R * (1.0 + 1e-9)) || cnt == 0.0) {   // the guess overshoots (or cannot be told apart): cold start
+                level = 0.0;
+                continue;
+            }
+            if (dbg && threadIdx.x == 0) { dbg[4] = pass + 1; dbg[5] = (unsigned long long)cnt; }
+            prev_cnt = cnt;
+            if (gamma != 0.0) {
+                const double qa = gamma * gamma * R + gamma * cnt * 0.5;
+                const double qd = 2.0 * R * gamma + cnt;
+                const double qc = R - S;
+                level = (-qd + sqrt(qd * qd - 4.0 * qa * qc)) / (2.0 * qa);
+            } else {
+                level = (S - R) / cnt;
+            }
+            continue;
+        }
 #pragma unroll
         for (int e = 0; e < EPT; e += 2) {                  // selects, no branches; two chains
             const bool i0 = ax[e] > level, i1 = ax[e + 1] > level;
@@ -199,6 +273,7 @@ __device__ double block_enet_project_reg(const T *v, T *out, const int32_t *rows
         }
     }
     if (dbg && threadIdx.x == 0) dbg[6] = clock64();
+    if (level_io && threadIdx.x == 0) *level_io = level;
     const double lT = (double)(T)level;
     const double den = 1.0 + lT * gamma;
     double nrm = 0;
@@ -209,11 +284,28 @@ __device__ double block_enet_project_reg(const T *v, T *out, const int32_t *rows
         pos = pos > 0 ? pos : 0;
         const T o = (T)(((x[e] >= 0) ? pos : -pos) / den);   // enet.pyx:121, sign(0) = +1
         if (i < n) out[dst[e]] = o;
-        const double a = (i < n) ? fabs((double)o) : 0.0;
+        x[e] = (i < n) ? (double)o : 0.0;
+        const double a = fabs(x[e]);
         nrm += a * (l1_ratio + (1.0 - l1_ratio) * a);
     }
     block_sum2(nrm, dummy, red2, nthreads);
     return nrm;
+}
+
+template <typename T, int EPT>
+__device__ double block_enet_project_reg(const T *v, T *out, const int32_t *rows, int64_t row_stride, int64_t n,
+                                         double radius, double l1_ratio, double *red2, int nthreads,
+                                         unsigned long long *dbg = nullptr, double *level_io = nullptr) {
+    int64_t dst[EPT];
+    enet_scatter_offsets<EPT>(rows, row_stride, n, nthreads, dst);
+    double x[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int64_t i = threadIdx.x + (int64_t)e * nthreads;
+        const T val = v[i < n ? i : n - 1];
+        x[e] = (i < n) ? (double)val : 0.0;
+    }
+    return block_enet_project_vals<T, EPT>(x, dst, out, n, radius, l1_ratio, red2, nthreads, dbg, level_io);
 }
 
 }  // namespace modl

@@ -88,6 +88,8 @@ struct DictUpdateArgs {
     void *ws;                 // scratch, dict_update_workspace() bytes
     size_t ws_bytes;
     StatsRider *rider = nullptr;   // optional (f32 fused path only)
+    double *level_hint = nullptr;  // optional [k], PERSISTENT across calls (zero-initialised): the soft-threshold level
+                                   // each atom's l1 / elastic-net projection ended with, warm start of the next one
 };
 size_t dict_update_workspace(int dtype, int64_t s_max, int k);
 size_t dict_update_stamps_offset(int dtype, int64_t s_max, int k);

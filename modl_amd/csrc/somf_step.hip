@@ -227,7 +227,7 @@ struct modl_somf_plan {
     // device arena
     char *dws = nullptr;
     size_t dws_bytes = 0;
-    size_t off_params, off_xnorm, off_Dx, off_H0, off_G, off_F, off_split, off_du, off_sweeps, off_Ds, off_Xs, off_codeb;
+    size_t off_params, off_xnorm, off_Dx, off_H0, off_G, off_F, off_split, off_du, off_sweeps, off_Ds, off_Xs, off_codeb, off_level;
     int last_b = 0;
     int64_t last_s = 0;
     size_t split_bytes, du_bytes, params_bytes;
@@ -756,6 +756,7 @@ int phase2(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         a.comp_l1_ratio = d.comp_l1_ratio; a.w = bt->w; a.step_size = d.step_size;
         a.ws = pl->dws + pl->off_du; a.ws_bytes = pl->du_bytes;
         a.rider = pl->ride_pending ? &pl->rider : nullptr;
+        a.level_hint = reinterpret_cast<double *>(pl->dws + pl->off_level);
         MODL_TRY(dict_update<T>(st, a, &ps.launches));
         if (pl->ride_pending && !pl->rider.consumed) {                 // this dictionary update has no fused path
             const StatsRider &R = pl->rider;
@@ -948,10 +949,12 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     pl->off_split = take(pl->split_bytes);
     pl->du_bytes = dict_update_workspace(desc->dtype, (int64_t)p, desc->k);
     pl->off_du = take(pl->du_bytes);
+    pl->off_level = take(sizeof(double) * k);   // per-atom projection levels (warm start of the next projection)
     pl->dws_bytes = o;
     hipError_t e = hipMalloc((void **)&pl->dws, pl->dws_bytes);
     if (e != hipSuccess) { delete pl; return (int)e; }
     e = hipMemset(pl->dws + pl->off_stamp, 0, sizeof(int32_t) * p);
+    if (e == hipSuccess) e = hipMemset(pl->dws + pl->off_level, 0, sizeof(double) * k);
     if (e != hipSuccess) { modl_somf_plan_destroy(pl); return (int)e; }
     for (int i = 0; i < kStageSlots; ++i) {
         e = hipHostMalloc((void **)&pl->hstage[i], align_up(pl->params_bytes, 16), hipHostMallocMapped);
