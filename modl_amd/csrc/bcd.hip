@@ -680,7 +680,8 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRider
             // the resolver's own inputs (atom index and norm budget of column x) and the tail of the records
             // (elements 512 ..) that the 256 worker threads do not cover
             const int x = lane & 31;
-            res_jj = (x < p.nb_prev) ? p.order[p.j0_prev + x] : 0;
+            const int res_jj_raw = p.order[p.j0_prev + ((x < p.nb_prev) ? x : 0)];   // (unconditional, clamped: no wait behind the load)
+            res_jj = (x < p.nb_prev) ? res_jj_raw : 0;
             const float budget_raw = p.norm_in[(x < p.nb_prev) ? p.j0_prev + x : 0];
             reduce_records_v2<kPackStride>(recs, nrec, 256 + lane, 256 + lane < kPackStride / 2, rsink);
             res_budget = (x < p.nb_prev) ? (double)budget_raw : 0.0;
@@ -718,8 +719,10 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRider
         float4 av[GW][RT];
         float4 va[NA];
         if (!fin) {
-            cdg = col_ok ? p.cdiag[p.j0 + col] : 1.f;
-            fz = col_ok ? p.frozen[p.j0 + col] : 0;
+            const float cdg_raw = p.cdiag[p.j0 + (col_ok ? col : 0)];   // (unconditional, clamped loads)
+            const int fz_raw = p.frozen[p.j0 + (col_ok ? col : 0)];
+            cdg = col_ok ? cdg_raw : 1.f;
+            fz = col_ok ? fz_raw : 0;
 #pragma unroll
             for (int q = 0; q < EPT; ++q) {
                 const int64_t f = f0 + rg + 8 * q;
@@ -772,7 +775,8 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRider
             for (int u = 0; u < RT; ++u) {
                 const int t = wid * RT + u, ft = t >> 1, jt = t & 1;
                 const int cj = jt * 16 + (lane & 15);
-                const int oc = (cj < p.nb_prev) ? p.order[p.j0_prev + cj] : 0;
+                const int oc_raw = p.order[p.j0_prev + ((cj < p.nb_prev) ? cj : 0)];
+                const int oc = (cj < p.nb_prev) ? oc_raw : 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t f = f0 + ft * 16 + (lane >> 4) + 4 * r;

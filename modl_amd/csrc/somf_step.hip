@@ -200,7 +200,10 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs<T> a) {
         const int i = id / a.gx, bx = id % a.gx;
         const T *row = a.X + (int64_t)i * a.ldx;
         for (int64_t f = (int64_t)bx * 256 + threadIdx.x; f < a.s_pad; f += (int64_t)a.gx * 256)
-            a.Xs[(int64_t)i * a.s_pad + f] = (f < a.s) ? row[a.subset[f]] : (T)0;
+        {
+            const T xv = row[a.subset[f < a.s ? f : a.s - 1]];          // (unconditional, clamped)
+            a.Xs[(int64_t)i * a.s_pad + f] = (f < a.s) ? xv : (T)0;
+        }
         return;
     }
     id -= a.n_cols;
