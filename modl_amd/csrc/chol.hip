@@ -94,8 +94,10 @@ __global__ __launch_bounds__(256) void chol_solve_kernel(const T *F, int64_t f_s
 #pragma unroll
     for (int c = 0; c < KPL; ++c) {
         const bool in = e0 + c < k;
-        y[c] = in ? r[e0 + c] : (T)0;
-        dg[c] = in ? Fm[(int64_t)(e0 + c) * k + (e0 + c)] : (T)1;
+        const int ec = in ? e0 + c : k - 1;
+        const T yv = r[ec], dv = Fm[(int64_t)ec * k + ec];
+        y[c] = in ? yv : (T)0;
+        dg[c] = in ? dv : (T)1;
     }
     const int n_li = (k + KPL - 1) / KPL;
     // forward: L y = rhs, column-oriented (row j of F right of the diagonal = column j of L)
@@ -106,7 +108,10 @@ __global__ __launch_bounds__(256) void chol_solve_kernel(const T *F, int64_t f_s
             const int j = li * KPL + c;
             const T *row = Fm + (int64_t)(j < k ? j : 0) * k;
 #pragma unroll
-            for (int c2 = 0; c2 < KPL; ++c2) rows[c][c2] = (e0 + c2 < k) ? row[e0 + c2] : (T)0;
+            for (int c2 = 0; c2 < KPL; ++c2) {               // unconditional clamped load, then the selection
+                const T rv = row[e0 + c2 < k ? e0 + c2 : k - 1];
+                rows[c][c2] = (e0 + c2 < k) ? rv : (T)0;
+            }
         }
 #pragma unroll
         for (int c = 0; c < KPL; ++c) {
@@ -128,7 +133,10 @@ __global__ __launch_bounds__(256) void chol_solve_kernel(const T *F, int64_t f_s
             const int j = li * KPL + c;
             const T *row = Fm + (int64_t)(j < k ? j : 0) * k;
 #pragma unroll
-            for (int c2 = 0; c2 < KPL; ++c2) rows[c][c2] = (e0 + c2 < k) ? row[e0 + c2] : (T)0;
+            for (int c2 = 0; c2 < KPL; ++c2) {               // unconditional clamped load, then the selection
+                const T rv = row[e0 + c2 < k ? e0 + c2 : k - 1];
+                rows[c][c2] = (e0 + c2 < k) ? rv : (T)0;
+            }
         }
 #pragma unroll
         for (int c = KPL - 1; c >= 0; --c) {
