@@ -167,6 +167,34 @@ def test_midsize_variants_vs_oracle(DictFact, oracle, variant):
         assert rel_fro(est.G_, st.G) < 1e-9
 
 
+@pytest.mark.parametrize('variant', ['fmri', 'fmri_pos', 'enet', 'nmf_l1'])
+@pytest.mark.parametrize('shape', ['groups', 'groups_ragged', 'per_atom'])
+def test_generic_dictionary_update_multi_workgroup_vs_oracle(DictFact, oracle, variant, shape):
+    """The l1 / elastic-net / positive-atom dictionary update beyond the tiny single-workgroup sweep (s k > 32 k):
+    `groups` = four atoms per launch (csrc/bcd.hip atom_group_kernel: shared gradient pass, corrections between the
+    atoms of a group, warm-started projections over several minibatches), `groups_ragged` = k not a multiple of 4 and a
+    ragged feature count, `per_atom` = more than 6144 sampled features (one launch per atom, atom_step_kernel)."""
+    extra = {
+        'fmri': dict(code_l1_ratio=0, comp_l1_ratio=1, code_alpha=1e-2),           # fmri.py:481-495
+        'fmri_pos': dict(code_l1_ratio=0, comp_l1_ratio=1, code_alpha=1e-2, comp_pos=True),
+        'enet': dict(comp_l1_ratio=0.4, code_l1_ratio=0.6, code_alpha=0.2),
+        'nmf_l1': dict(comp_pos=True, code_pos=True, comp_l1_ratio=0.7, code_alpha=0.1),
+    }[variant]
+    n, p, k, b, r = {'groups': (160, 3000, 72, 20, 2), 'groups_ragged': (160, 2501, 70, 20, 3),
+                     'per_atom': (100, 14000, 24, 20, 2)}[shape]
+    est, st = _one_step_pair(DictFact, oracle, np.float64, n=n, p=p, k=k, b=b, r=r, steps=4, **extra)
+    eD, eC = rel_fro(est.components_, st.D), rel_fro(est.code_[:80], st.code[:80])
+    assert eD < 1e-9 and eC < 1e-9, (variant, shape, eD, eC)
+    assert rel_fro(est.comp_norm_, st.comp_norm) < 1e-9 or np.allclose(est.comp_norm_, st.comp_norm, atol=1e-12)
+
+
+def test_generic_dictionary_update_f32_groups_vs_oracle(DictFact, oracle):
+    """f32, first minibatch from identical state, through the atom groups (k >= 20 needed for their scratch)"""
+    est, st = _one_step_pair(DictFact, oracle, np.float32, n=160, p=3000, k=72, b=20, r=2, steps=1,
+                             code_l1_ratio=0, comp_l1_ratio=1, code_alpha=1e-2)
+    assert rel_fro(est.components_, st.D) < 1e-5 and rel_fro(est.code_[:20], st.code[:20]) < 1e-5
+
+
 def test_full_size_step_properties(DictFact):
     """Size-independent properties at the metric's full shape (k = 256, p = 10000, b = 256, f32)."""
     import torch
