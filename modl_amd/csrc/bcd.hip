@@ -61,7 +61,7 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     L.nslab_max = cdiv(s_max > 0 ? s_max : 1, 32);      // the fused block kernel uses slabs of 32 or 64 rows
-    L.nwg_grad = 2048;
+    L.nwg_grad = 4096;
     L.off_CP = take(tsz * (size_t)k * k);
     L.off_cdiag = take(tsz * (size_t)k);
     L.off_frozen = take(sizeof(int32_t) * (size_t)k);
@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, cons
     if (dbg && threadIdx.x == 0) { dbg[0] = t0; dbg[1] = t1; dbg[2] = t2; dbg[3] = clock64(); }
 }
 
-// A GROUP of up to kAtomGroup consecutive atoms of the sweep in ONE launch.  Of the 23 us an atom costs with one launch
+// A GROUP of up to kAtomGroup (4) consecutive atoms of the sweep in ONE launch.  Of the 23 us an atom costs with one launch
 // each, the launch boundary, the gradient row and the hand-off to the projecting workgroup are 60 %; they are shared by
 // the group.  Every workgroup evaluates, for its features, the numerators of the candidates of ALL atoms of the group
 // against the dictionary as it is at the start of the launch (one read of the dictionary row serves the group); the
@@ -1089,7 +1089,14 @@ __global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, cons
 // which is exactly the difference between the gradient row of the sequential sweep and the stale one (the own term
 // C_jj D_old[j][f] does not depend on the other atoms).  Same update as atom_step_kernel up to the rounding of that
 // double-precision correction.  Needs the vector in the registers of the projecting workgroup (s <= kProjEpt * 256).
-constexpr int kAtomGroup = 4;
+#ifndef MODL_ATOM_GROUP
+#define MODL_ATOM_GROUP 4          /* (tuning) even; 8 spills the f32 kernel (8 inlined projections): 56 us per atom */
+#endif
+constexpr int kAtomGroup = MODL_ATOM_GROUP;
+template <int... As, class F>
+__device__ __forceinline__ void for_each_int(std::integer_sequence<int, As...>, F &&f) {
+    (f(std::integral_constant<int, As>{}), ...);
+}
 struct AtomGroup { int j[kAtomGroup]; int n; };
 
 template <typename T, int KPL>
@@ -1166,9 +1173,12 @@ __global__ __launch_bounds__(256) void atom_group_kernel(T *Dt, const T *Bt, con
             o[a] = 0;
             for (int i = threadIdx.x; i < nparts; i += 256) o[a] += partial_old[(int64_t)a * nparts + i];
         }
-        block_sum2(o[0], o[1], red, 256);
-        block_sum2(o[2], o[3], red, 256);
-        if (threadIdx.x == 0) { s_old[0] = o[0]; s_old[1] = o[1]; s_old[2] = o[2]; s_old[3] = o[3]; }
+#pragma unroll
+        for (int a = 0; a < kAtomGroup; a += 2) block_sum2(o[a], o[a + 1], red, 256);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int a = 0; a < kAtomGroup; ++a) s_old[a] = o[a];
+        }
     }
     int64_t dst[kProjEpt];
     enet_scatter_offsets<kProjEpt>(subset, (int64_t)k, s, 256, dst);
@@ -1235,10 +1245,7 @@ __global__ __launch_bounds__(256) void atom_group_kernel(T *Dt, const T *Bt, con
             if (a + 2 < kAtomGroup) load_atom(a + 2, X[a & 1], Dd[a & 1]);   // lands while atom a + 1 is projected
         }
     };
-    step(std::integral_constant<int, 0>{});
-    step(std::integral_constant<int, 1>{});
-    step(std::integral_constant<int, 2>{});
-    step(std::integral_constant<int, 3>{});
+    for_each_int(std::make_integer_sequence<int, kAtomGroup>{}, step);
 }
 
 // The whole sweep in ONE launch, by one workgroup, for TINY problems (u = the s-vector of the atom in flight
