@@ -5,9 +5,11 @@ IO and out of scope.  A record is what the
 reference's `MultiRawMasker` yields (modl/input_data/fmri/unmask.py:37-55): a
 2-D array (time points x voxels) or the path of a .npy file holding one."""
 import time
+from concurrent.futures import ThreadPoolExecutor
 from math import sqrt
 
 import numpy as np
+import torch
 from sklearn.base import BaseEstimator
 from sklearn.utils import check_random_state
 
@@ -33,6 +35,54 @@ def _flip(components):
         if np.sum(component < 0) > np.sum(component > 0):
             component *= -1
     return components
+
+
+class _RecordStager:
+    """Double-buffered record streaming: while a record is being fitted, a worker thread loads the
+    next one (np.load of the .npy file, the dtype conversion of fmri.py:533) into pinned host memory and copies it to
+    HBM on a side stream; the row permutation of fmri.py:535-541 is then a gather on the device.  Backends without a
+    GPU (the oracle-backed test backend) get the plain host path."""
+
+    def __init__(self, dict_fact, dtype):
+        be = dict_fact._backend
+        self.device = getattr(be, 'device', None)
+        self.on_gpu = self.device is not None and self.device.type == 'cuda'
+        self.dtype = np.dtype(dtype)
+        self.pool = ThreadPoolExecutor(1) if self.on_gpu else None
+        self.stream = torch.cuda.Stream(self.device) if self.on_gpu else None
+        self.pending = None
+
+    def _stage(self, record):
+        arr = np.asarray(_load(record))
+        if not self.on_gpu:
+            return arr.astype(self.dtype)
+        host = torch.empty(arr.shape, dtype=torch.float32 if self.dtype == np.float32 else torch.float64, pin_memory=True)
+        np.copyto(host.numpy(), arr, casting='unsafe')               # load + dtype conversion straight into pinned memory
+        with torch.cuda.stream(self.stream):
+            dev = host.to(self.device, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        return dev, done, host                                       # (host kept alive until the copy is consumed)
+
+    def prefetch(self, record):
+        self.pending = self.pool.submit(self._stage, record) if self.on_gpu else record
+
+    def take(self):
+        if not self.on_gpu:
+            return self._stage(self.pending)
+        dev, done, _host = self.pending.result()
+        torch.cuda.current_stream(self.device).wait_event(done)
+        return dev
+
+    def rows(self, data, permutation):
+        if not self.on_gpu:
+            return data[permutation]
+        idx = torch.from_numpy(np.ascontiguousarray(permutation, dtype=np.int64)).to(self.device)
+        return data.index_select(0, idx)
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)
 
 
 class fMRIDictFact(BaseEstimator):
@@ -94,6 +144,7 @@ class fMRIDictFact(BaseEstimator):
         dict_fact.prepare(n_samples=n_samples, n_features=n_voxels,
                           X=None if dict_init is None else dict_init.astype(dtype), dtype=dtype)
         self.cpu_time_, self.io_time_ = 0.0, 0.0
+        stager = _RecordStager(dict_fact, dtype)
         if n_records > 0:
             verbose_iter_ = np.linspace(0, n_records * self.n_epochs, self.verbose).tolist() if self.verbose else []
             current_n_records = 0
@@ -104,14 +155,17 @@ class fMRIDictFact(BaseEstimator):
                     reduction = 1 + (reduction - 1) / sqrt(i + 1)    # compounds across epochs (fmri.py:511-513)
                     dict_fact.set_params(reduction=reduction)
                 record_list = random_state.permutation(n_records)
-                for record in record_list:
+                stager.prefetch(records[record_list[0]])
+                for pos, record in enumerate(record_list):
                     if self.verbose and verbose_iter_ and current_n_records >= verbose_iter_[0]:
                         print('Record %i' % current_n_records)
                         if self.callback is not None:
                             self.callback(self, dict_fact, self.cpu_time_, self.io_time_)
                         verbose_iter_ = verbose_iter_[1:]
                     t0 = time.perf_counter()
-                    data = np.asarray(_load(records[record])).astype(dtype)
+                    data = stager.take()                             # staged while the previous record was fitted
+                    if pos + 1 < n_records:
+                        stager.prefetch(records[record_list[pos + 1]])
                     self.io_time_ += time.perf_counter() - t0
                     t0 = time.perf_counter()
                     permutation = random_state.permutation(data.shape[0])
@@ -119,9 +173,10 @@ class fMRIDictFact(BaseEstimator):
                         sample_indices = np.arange(indices_list[record], indices_list[record + 1])[permutation]
                     else:
                         sample_indices = None
-                    dict_fact.partial_fit(data[permutation], sample_indices=sample_indices)
+                    dict_fact.partial_fit(stager.rows(data, permutation), sample_indices=sample_indices)
                     current_n_records += 1
                     self.cpu_time_ += time.perf_counter() - t0
+        stager.close()
         self.dict_fact_ = dict_fact
         self.components_ = _flip(dict_fact.components_)
         self.coder_ = self._coder_class(dictionary=self.components_, code_alpha=self.alpha, code_l1_ratio=0).fit()

@@ -150,3 +150,20 @@ def test_get_sub_slice():
     assert_array_equal(get_sub_slice(a, b), np.arange(30, 40))
     assert_array_equal(get_sub_slice(None, b), np.arange(20, 30))
     assert_array_equal(get_sub_slice(np.arange(10, 100), b), np.arange(30, 40))
+
+
+def test_new_entry_points_validate_arguments_without_gpu(lib):
+    """host-only image helpers work on the CPU; device plans report the missing GPU instead of faking one"""
+    out = np.empty((6, 3), dtype=np.int64)
+    assert lib.modl_image_fill(1, 2, 3, out.ctypes.data_as(C.c_void_p)) == 0
+    assert_array_equal(out, np.c_[np.where(np.ones((1, 2, 3)))])
+    assert lib.modl_image_fill(-1, 2, 3, out.ctypes.data_as(C.c_void_p)) == -1
+    img = np.zeros((4, 4, 1))
+    n = C.c_int64()
+    assert lib.modl_image_clean_mask_f64(img.ctypes.data_as(C.c_void_p), 4, 4, 1, 5, 2, 1, None, C.byref(n)) == -1   # window > image
+    assert lib.modl_image_clean_mask_f64(img.ctypes.data_as(C.c_void_p), 4, 4, 1, 2, 2, 1, None, C.byref(n)) == 0 and n.value == 9
+    assert lib.modl_objective_workspace(0, 10, 100) >= 10 * 100 * 4
+    h = C.c_void_p()
+    assert lib.modl_recsys_plan_create(7, 10, 4, 2, 8, C.byref(h)) == -1                    # bad dtype
+    if lib.modl_device_count() == 0:
+        assert lib.modl_recsys_plan_create(1, 10, 4, 2, 8, C.byref(h)) == -4                # MODL_ENOGPU
