@@ -193,6 +193,15 @@ template <typename T> struct EpiBcdA {
         const int64_t e = sub_row(subset, f) * k + order[j0 + jj];
         a[f * kNB + jj] = frozen[j0 + jj] ? Dt[e] : (Bt[e] - v) / cdiag[j0 + jj];
     }
+    // the same with the operands fetched up front (gemm.hpp: epi_has_fetch)
+    struct Fetched { T d, b, cd; int32_t fz; };
+    __device__ __forceinline__ Fetched fetch(int64_t f, int64_t jj) const {
+        const int64_t e = sub_row(subset, f) * k + order[j0 + jj];
+        return Fetched{Dt[e], Bt[e], cdiag[j0 + jj], frozen[j0 + jj]};
+    }
+    __device__ __forceinline__ void finish(int64_t f, int64_t jj, T v, const Fetched &x) const {
+        a[f * kNB + jj] = x.fz ? x.d : (x.b - v) / x.cd;
+    }
 };
 
 template <typename T>

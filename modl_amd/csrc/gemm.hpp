@@ -17,6 +17,7 @@
 // gemm_reduce_kernel, so results are run-to-run deterministic.
 #pragma once
 #include "common.hpp"
+#include <type_traits>
 
 namespace modl {
 
@@ -62,6 +63,11 @@ template <> struct Mma<double> {
     static __device__ __forceinline__ int acc_row(int lane, int r) { return (lane >> 4) + 4 * r; }
     static __device__ __forceinline__ int acc_col(int lane, int) { return lane & 15; }
 };
+
+// an epilogue with `typedef ... Fetched; Fetched fetch(m, n) const; void finish(m, n, v, const Fetched &) const;` gets its
+// per-output operands requested for all outputs before any is consumed (see gemm_kernel)
+template <class Epi, class = void> struct epi_has_fetch { static constexpr bool value = false; };
+template <class Epi> struct epi_has_fetch<Epi, std::void_t<typename Epi::Fetched>> { static constexpr bool value = true; };
 
 template <typename T, int BI, int BK>
 __device__ __forceinline__ void stage_tile(T (*S)[BI + 1], const Operand &op, int64_t i0, int64_t I, int64_t k0,
@@ -132,6 +138,37 @@ __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, int64_t
     }
 
     const bool direct = (gridDim.z == 1);
+    if constexpr (epi_has_fetch<Epi>::value) {
+        // Epilogues that READ per-output operands (gathered rows, per-column scalars): every output's operands are
+        // requested first, unconditionally, from clamped coordinates (two dependent rounds at most: indices, then
+        // data), and only the stores are guarded.  With the loads inside the per-output guard each output pays its
+        // own serial memory round trips (16 outputs x 2 rounds per lane: 14 of the 29 us of the k x 32 product of
+        // the f64 dictionary update).
+        if (direct) {
+            typename Epi::Fetched fetched[RM][RN][MT::NACC];
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+#pragma unroll
+                    for (int r = 0; r < MT::NACC; ++r) {
+                        const int64_t m = m0 + wm * WTM + i * MT::TM + MT::acc_row(lane, r);
+                        const int64_t n = n0 + wn * WTN + j * MT::TN + MT::acc_col(lane, r);
+                        fetched[i][j][r] = epi.fetch(m < M ? m : M - 1, n < N ? n : N - 1);
+                    }
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+#pragma unroll
+                    for (int r = 0; r < MT::NACC; ++r) {
+                        const int64_t m = m0 + wm * WTM + i * MT::TM + MT::acc_row(lane, r);
+                        const int64_t n = n0 + wn * WTN + j * MT::TN + MT::acc_col(lane, r);
+                        if (m < M && n < N) epi.finish(m, n, acc[i][j][r], fetched[i][j][r]);
+                    }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < RM; ++i)
 #pragma unroll
