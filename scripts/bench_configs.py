@@ -1,10 +1,10 @@
 """Throughput of BASELINE.json's configs 2-4 on one MI355X, at the synthetic shapes of SURVEY.md 8(d)
 (C2 ImageDictFact 8x8 patches k=256; C3 fMRI-shaped records k=70 r=12; C4 MovieLens-10M-shaped CSR k=50).
 These are parity-test configurations, not bench lines (bench.py measures the headline metric); this script
-records what the wrappers deliver end to end (host loops included) and, with --cpu, the CPU oracle on a bounded
-prefix of the same inputs.
+records what the wrappers deliver end to end (host loops included).  The CPU oracle on a bounded prefix of the same
+inputs is timed by tests/diag/config_cpu_baselines.py (the oracle is test infrastructure: only tests/ runs it).
 
-    python scripts/bench_configs.py [--only c2,c3,c4] [--cpu] [--c4-batches 2000]
+    python scripts/bench_configs.py [--only c2,c3,c4] [--c4-batches 2000]
 Prints one JSON line per configuration."""
 import argparse
 import json
@@ -75,23 +75,6 @@ def c2(args):
     n = est.n_iter_
     out = dict(config='C2 ImageDictFact 512x512x1, 8x8 patches (p=64), k=256, b=100, r=10, l1 codes', patches=int(n),
                seconds=dt, samples_per_s=n / dt, finite=bool(np.all(np.isfinite(est.components_))))
-    if args.cpu:
-        from oracle import somf_oracle as orc
-        from modl_amd.image import LazyCleanPatchExtractor, _flatten_patches
-        ext = LazyCleanPatchExtractor(patch_size=(8, 8), random_state=0).fit(img)
-        m = min(ext.n_patches_, 20000)
-        P = _flatten_patches(ext.partial_transform(batch=slice(0, m)), copy=True)
-        pr = orc.SomfParams(n_components=256, batch_size=100, reduction=10, code_alpha=0.1, code_l1_ratio=1, comp_l1_ratio=0,
-                            learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0, tol=1e-2)
-        st = orc.prepare(pr, n_samples=m, X=P[:256])
-        t0, done = time.perf_counter(), 0
-        for r0 in range(0, m, 1000):
-            orc.partial_fit(st, pr, P[r0:r0 + 1000], np.arange(r0, min(m, r0 + 1000)))
-            done = min(m, r0 + 1000)
-            if time.perf_counter() - t0 > args.cpu_budget:
-                break
-        out['cpu_oracle'] = dict(samples_per_s=done / (time.perf_counter() - t0), sample='%d patches' % done,
-                                 cores=os.cpu_count())
     return out
 
 
@@ -109,14 +92,6 @@ def c3(args):
     out = dict(config='C3 fMRI-shaped: %d records x 176 x p=60000 f32, k=70, r=12, b=20, ridge codes, l1 atoms' % len(recs),
                samples=int(n), seconds=dt, samples_per_s=n / dt, io_s=est.io_time_, fit_s=est.cpu_time_,
                finite=bool(np.all(np.isfinite(est.components_))))
-    if args.cpu:
-        from oracle import wrappers_oracle as wo
-        m = max(1, min(len(recs), 4))
-        t0 = time.perf_counter()
-        wo.fmri_fit(recs[:m], method='masked', n_components=70, reduction=12, batch_size=20, alpha=1e-3, learning_rate=0.92,
-                    dict_init=init, random_state=0, n_epochs=1)
-        out['cpu_oracle'] = dict(samples_per_s=m * 176 / (time.perf_counter() - t0), sample='%d records' % m,
-                                 cores=os.cpu_count())
     return out
 
 
@@ -140,21 +115,12 @@ def c4(args):
                       % (X.shape[0], X.shape[1], X.nnz, n_rows),
                samples=int(n_rows), ratings=int(Xs.nnz), seconds=dt, samples_per_s=n_rows / dt, ratings_per_s=Xs.nnz / dt,
                train_rmse=float(score), score_s=time.perf_counter() - t0, gen_s=gen_s)
-    if args.cpu:
-        from oracle import wrappers_oracle as wo
-        m = min(n_rows, 1500)
-        t0 = time.perf_counter()
-        wo.recsys_fit(Xs[:m], alpha=1, beta=.1, n_components=50, learning_rate=.95, batch_size=10, n_epochs=1, random_state=0,
-                      detrend=True)
-        out['cpu_oracle'] = dict(samples_per_s=m / (time.perf_counter() - t0), sample='%d rows' % m, cores=os.cpu_count())
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='c2,c3,c4')
-    ap.add_argument('--cpu', action='store_true')
-    ap.add_argument('--cpu-budget', type=float, default=15.0)
     ap.add_argument('--c2-patches', type=int, default=None)
     ap.add_argument('--c3-records', type=int, default=40)
     ap.add_argument('--c4-batches', type=int, default=7000)

@@ -1,6 +1,6 @@
 """f32 parity diagnostics: GPU f32 vs oracle f32 vs oracle f64 on one minibatch from identical state."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from modl_amd import DictFact
 from oracle import somf_oracle as orc
