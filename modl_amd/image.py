@@ -231,6 +231,14 @@ class ImageDictFact(BaseEstimator):
     def score(self, patches):
         return self.dict_fact_.score(self._prep(patches))
 
+    def stage_test_patches(self, patches):
+        """Scaled, flattened test patches as a tensor on the estimator's device: `score_staged` then evaluates the
+        objective without any host copy of the test set or of the dictionary (scoring callbacks, image.py:202-225)."""
+        return self.dict_fact_._backend.stage_X(self._prep(patches))
+
+    def score_staged(self, staged):
+        return self.dict_fact_.score(staged)
+
     @property
     def n_iter_(self):
         return self.dict_fact_.n_iter_
@@ -260,7 +268,14 @@ class DictionaryScorer:
 
     def __call__(self, dict_fact):
         t0 = time.perf_counter()
-        score = dict_fact.score(self.test_data)
+        if hasattr(dict_fact, 'stage_test_patches'):
+            # the test set is scaled and uploaded once per (estimator, setting); every later call scores it in HBM
+            key = (id(dict_fact), getattr(dict_fact, 'setting', None))
+            if getattr(self, '_staged_key', None) != key:
+                self._staged, self._staged_key = dict_fact.stage_test_patches(self.test_data), key
+            score = dict_fact.score_staged(self._staged)
+        else:
+            score = dict_fact.score(self.test_data)
         self.test_time += time.perf_counter() - t0
         self.time.append(time.perf_counter() - self.start_time - self.test_time)
         self.score.append(score)

@@ -241,3 +241,31 @@ def test_device_patch_pipeline_golden():
     got = ex.partial_transform_scaled(HipBackend(), slice(None)).cpu().numpy()
     want = g['extract/scaled'].reshape(got.shape)
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-14)
+
+
+def _scorer_case(host):
+    from modl_amd.image import DictionaryScorer, LazyCleanPatchExtractor
+    img = synth_image(30, 30, 1, seed=2)
+    test = LazyCleanPatchExtractor(patch_size=(6, 6), random_state=1, max_patches=40).fit(synth_image(20, 20, 1, seed=3)).transform()
+    scorer = DictionaryScorer(test)
+    est = _image_estimator(host)(patch_size=(6, 6), n_components=5, batch_size=20, alpha=0.05, random_state=0, max_patches=200,
+                                 reduction=2, verbose=4, callback=scorer)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        est.fit(img)
+    assert len(scorer.score) >= 2 and np.all(np.isfinite(scorer.score)) and scorer.iter == sorted(scorer.iter)
+    # the staged (device-resident) scoring path gives what score() on the host patches gives
+    final = est.score(test)
+    assert abs(est.score_staged(est.stage_test_patches(test)) - final) <= 1e-12 * abs(final)
+    return scorer
+
+
+def test_dictionary_scorer_host_logic():
+    _scorer_case(host=True)                                  # image.py:202-225 driven through verbose callbacks
+
+
+@pytest.mark.gpu
+def test_dictionary_scorer_gpu_resident_test_set():
+    import torch
+    scorer = _scorer_case(host=False)
+    assert isinstance(scorer._staged, torch.Tensor) and scorer._staged.is_cuda
