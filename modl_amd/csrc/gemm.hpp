@@ -230,8 +230,10 @@ struct SplitWs {      // scratch for split-K partial tiles
 // 64x64 (2x2 waves, more workgroups for mid-size outputs), "tall" 128x32 (4x1 waves, for the narrow
 // N = 32 products of the blocked dictionary update).
 template <typename T> struct TileCfg;
-template <> struct TileCfg<float> { static constexpr int BK = 16, RB = 2, RS = 1, RT = 1; };
-template <> struct TileCfg<double> { static constexpr int BK = 16, RB = 4, RS = 2, RT = 2; };
+// BKT: K-tile of the tall configuration.  Its products are short and launched one workgroup per 128 rows: every K-tile
+// is a full memory round trip (no prefetch in this kernel), so fewer, deeper K-tiles (41 KB of LDS in f64).
+template <> struct TileCfg<float> { static constexpr int BK = 16, BKT = 32, RB = 2, RS = 1, RT = 1; };
+template <> struct TileCfg<double> { static constexpr int BK = 16, BKT = 32, RB = 4, RS = 2, RT = 2; };
 
 // target_wgs: how many workgroups we would like in flight (256 CUs, a few per CU)
 template <typename T, class Epi>
@@ -256,7 +258,8 @@ int launch_gemm(hipStream_t stream, const Operand &A, const Operand &B, int64_t 
         if (splits < 1) splits = 1;
     }
     const int64_t Kp = K > 0 ? K : 1;
-    const int64_t kps = cdiv(cdiv(Kp, splits), C::BK) * C::BK;
+    const int bk = (cfg == 2) ? C::BKT : C::BK;
+    const int64_t kps = cdiv(cdiv(Kp, splits), bk) * bk;
     splits = cdiv(Kp, kps);
     dim3 grid((unsigned)tn, (unsigned)tm, (unsigned)splits);
     T *partial = static_cast<T *>(ws.ptr);
@@ -267,7 +270,7 @@ int launch_gemm(hipStream_t stream, const Operand &A, const Operand &B, int64_t 
         hipLaunchKernelGGL((gemm_kernel<T, C::RS, C::RS, 2, 2, C::BK, Epi>), grid, dim3(256), 0, stream, A, B, M, N, K,
                            kps, partial, epi);
     else
-        hipLaunchKernelGGL((gemm_kernel<T, C::RT, C::RT, 4, 1, C::BK, Epi>), grid, dim3(256), 0, stream, A, B, M, N, K,
+        hipLaunchKernelGGL((gemm_kernel<T, C::RT, C::RT, 4, 1, C::BKT, Epi>), grid, dim3(256), 0, stream, A, B, M, N, K,
                            kps, partial, epi);
     MODL_LAUNCH_CHECK();
     if (launches) ++*launches;
