@@ -69,9 +69,48 @@ template <> struct Mma<double> {
 template <class Epi, class = void> struct epi_has_fetch { static constexpr bool value = false; };
 template <class Epi> struct epi_has_fetch<Epi, std::void_t<typename Epi::Fetched>> { static constexpr bool value = true; };
 
+// Staging of a tile whose rows mostly exist (tall configuration only), without a gather on the contraction index: the
+// gather mode is resolved OUTSIDE the loops and every lane loads, from clamped coordinates, in two straight-line rounds
+// (all index loads, then all data loads), the selection of zeros follows.  The general staging below keeps its loads
+// behind per-thread branches (and the gather functor's own), after each of which the compiler waits for the load: 2
+// serial memory round trips per element, 20 us of the 27 us of a 350 x 32 x 50 product.
+template <typename T, int BI, int BK, int GI>
+__device__ __forceinline__ void stage_tile_dense(T (*S)[BI + 1], const Operand &op, int64_t i0, int64_t I, int64_t k0,
+                                                 int64_t k_end) {
+    const T *base = static_cast<const T *>(op.ptr);
+    constexpr int NL = BI * BK / 256;
+    static_assert(BI * BK % 256 == 0, "tile elements per thread");
+    const bool walk_i = op.si == 1;                            // workgroup-uniform
+    int64_t off[NL];
+#pragma unroll
+    for (int t = 0; t < NL; ++t) {
+        const int e = threadIdx.x + t * 256;
+        const int il = walk_i ? e % BI : e / BK, kl = walk_i ? e / BI : e % BK;
+        const int64_t i = i0 + il, kk = k0 + kl;
+        const int64_t ic = i < I ? i : I - 1, kc = kk < k_end ? kk : k_end - 1;
+        const int64_t gi = GI == 0 ? ic : (GI == 1 ? (int64_t)op.gi.i32[ic] : op.gi.i64[ic]);
+        off[t] = gi * op.si + kc * op.sk;
+    }
+    T v[NL];
+#pragma unroll
+    for (int t = 0; t < NL; ++t) v[t] = base[off[t]];
+#pragma unroll
+    for (int t = 0; t < NL; ++t) {
+        const int e = threadIdx.x + t * 256;
+        const int il = walk_i ? e % BI : e / BK, kl = walk_i ? e / BI : e % BK;
+        S[kl][il] = (i0 + il < I && k0 + kl < k_end) ? v[t] : (T)0;
+    }
+}
+
 template <typename T, int BI, int BK>
 __device__ __forceinline__ void stage_tile(T (*S)[BI + 1], const Operand &op, int64_t i0, int64_t I, int64_t k0,
-                                           int64_t k_end) {
+                                           int64_t k_end, bool dense = false) {
+    if (dense && op.gk.identity()) {                           // workgroup-uniform
+        if (op.gi.i32) stage_tile_dense<T, BI, BK, 1>(S, op, i0, I, k0, k_end);
+        else if (op.gi.i64) stage_tile_dense<T, BI, BK, 2>(S, op, i0, I, k0, k_end);
+        else stage_tile_dense<T, BI, BK, 0>(S, op, i0, I, k0, k_end);
+        return;
+    }
     const T *base = static_cast<const T *>(op.ptr);
     constexpr int kElems = BI * BK;
     if (op.si == 1) {   // free index contiguous: lanes walk i
@@ -117,9 +156,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, int64_t
 #pragma unroll
             for (int r = 0; r < MT::NACC; ++r) acc[i][j][r] = 0;
 
+    // tall configuration (short products, one workgroup per 128 rows): tiles at least half full take the dense staging
+    constexpr bool kTall = (WGM == 4 && WGN == 1);
+    const bool denseA = kTall && 2 * (M - m0) >= BM, denseB = kTall && 2 * (N - n0) >= BN;
     for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
-        stage_tile<T, BM, BK>(As, A, m0, M, k0, k_end);
-        stage_tile<T, BN, BK>(Bs, B, n0, N, k0, k_end);
+        stage_tile<T, BM, BK>(As, A, m0, M, k0, k_end, denseA);
+        stage_tile<T, BN, BK>(Bs, B, n0, N, k0, k_end, denseB);
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < BK; kk += MT::TK) {
