@@ -215,25 +215,36 @@ __global__ __launch_bounds__(256) void bcd_gram_kernel(const T *a, const T *Dt, 
     const int i = threadIdx.x / 8, jb = (threadIdx.x % 8) * 4;
     double acc[4] = {0, 0, 0, 0};
     const int col = threadIdx.x % kNB, rg = threadIdx.x / kNB;   // for the old-atom norms
+    const int ocol = order[j0 + (col < nb ? col : 0)];
     double d2 = 0;
     for (int64_t c0 = f_begin; c0 < f_end; c0 += 64) {
         __syncthreads();
+        // (unconditional loads from clamped rows, selection afterwards: a per-thread branch around a load makes the
+        // compiler wait for it on the spot -- the old-atom norms below were 24 serial round trips per chunk)
+#pragma unroll
         for (int e = threadIdx.x; e < 64 * kNB; e += 256) {
             const int r = e / kNB, c = e % kNB;
-            As[r][c] = (c0 + r < f_end && c < nb) ? a[(c0 + r) * kNB + c] : (T)0;
+            const T ld = a[((c0 + r < f_end) ? c0 + r : f_end - 1) * kNB + c];
+            As[r][c] = (c0 + r < f_end && c < nb) ? ld : (T)0;
         }
-        __syncthreads();
         const int rows = (int)((f_end - c0 < 64) ? f_end - c0 : 64);
+        int64_t srow[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) srow[t] = sub_row(subset, (rg + 8 * t < rows) ? c0 + rg + 8 * t : f_end - 1);
+        T xo[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) xo[t] = Dt[srow[t] * k + ocol];
+        __syncthreads();
         for (int r = 0; r < rows; ++r) {
             const double ai = (double)As[r][i];
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] += ai * (double)As[r][jb + q];
         }
-        if (col < nb)
-            for (int r = rg; r < rows; r += 8) {
-                const double x = (double)Dt[sub_row(subset, c0 + r) * k + order[j0 + col]];
-                d2 += x * x;
-            }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const double x = (double)xo[t];
+            if (col < nb && rg + 8 * t < rows) d2 += x * x;
+        }
     }
     d2red[rg][col] = d2;
     __syncthreads();
@@ -532,7 +543,10 @@ __device__ __forceinline__ void apply_row(const T *ar, const double *Tps, T *row
                                           int jg) {
     double av[kNB];
 #pragma unroll
-    for (int m = 0; m < kNB; ++m) av[m] = (m < nb) ? (double)ar[m] : 0.0;   // columns >= nb were never written
+    for (int m = 0; m < kNB; ++m) {                                          // columns >= nb were never written:
+        const T ld = ar[m];                                                  // loaded all the same (no branch around
+        av[m] = (m < nb) ? (double)ld : 0.0;                                 // the load), then replaced by zeros
+    }
     for (int j = jg; j < nb; j += NSTR) {
         double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
 #pragma unroll
