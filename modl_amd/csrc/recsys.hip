@@ -35,14 +35,31 @@ __global__ __launch_bounds__(256) void recsys_code_kernel(const T *Dt, int64_t p
     const int nnz = end - beg;
     if (nnz == 0) return;                                   // recsys.py:170: rows without ratings keep their code
     for (int e = threadIdx.x; e < k * k + k; e += 256) G[e] = 0;   // G and rhs are contiguous
+    int *ids = reinterpret_cast<int *>(xv + 32);              // [32] item ids of the chunk
     for (int c0 = 0; c0 < nnz; c0 += 32) {
         const int nc = (nnz - c0 < 32) ? nnz - c0 : 32;
         __syncthreads();
-        for (int e = threadIdx.x; e < nc * k; e += 256) {
-            const int j = e / k, c = e % k;
-            rows[j * k + c] = Dt[(int64_t)indices[beg + c0 + j] * k + c];
+        // the chunk's item ids and ratings first (one round trip), then its dictionary rows with every load of a
+        // thread in flight together (unconditional, clamped; a dependent id -> row chain per element made the staging
+        // a dozen serial round trips per chunk)
+        if (threadIdx.x < 32) {
+            const int e = beg + c0 + (threadIdx.x < nc ? (int)threadIdx.x : nc - 1);
+            ids[threadIdx.x] = indices[e];
+            xv[threadIdx.x] = data[e];
         }
-        if (threadIdx.x < nc) xv[threadIdx.x] = data[beg + c0 + threadIdx.x];
+        __syncthreads();
+        const int tot = nc * k;
+        for (int e0 = threadIdx.x; e0 < tot; e0 += 4 * 256) {
+            T ld[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * 256 < tot ? e0 + u * 256 : tot - 1;
+                ld[u] = Dt[(int64_t)ids[e / k] * k + e % k];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + u * 256 < tot) rows[e0 + u * 256] = ld[u];     // rows[j * k + c], e = j * k + c
+        }
         __syncthreads();
         for (int e = threadIdx.x; e < k * k; e += 256) {
             const int a = e / k, c = e % k;
@@ -59,18 +76,20 @@ __global__ __launch_bounds__(256) void recsys_code_kernel(const T *Dt, int64_t p
     __syncthreads();
     const T ridge = (T)(alpha * (double)nnz / (double)p);   // alpha / reduction, reduction = p / |S_i| (:175,179)
     for (int a = threadIdx.x; a < k; a += 256) G[a * k + a] += ridge;
-    __syncthreads();
-    // Cholesky G = L L^T in place (symmetric storage), then L y = rhs, L^T x = y
+    // Cholesky G = L L^T in place (symmetric storage; the diagonal of L goes to dg so that nobody overwrites an entry
+    // others still read: two barriers per column instead of three), then L y = rhs, L^T x = y with ONE barrier per
+    // step (every thread forms the pivot value itself; results go to their own arrays).  Same operations in the same
+    // order as the textbook loops: identical bits.
+    T *dg = rows, *ys = rows + k, *xs = rows + 2 * k;       // (the staging buffer is free now: 32 k >= 3 k)
     for (int j = 0; j < k; ++j) {
-        __syncthreads();
+        __syncthreads();                                    // trailing update of column j - 1 (or the ridge) done
         const T d = sqrt(G[j * k + j]);
-        __syncthreads();
         for (int i = j + 1 + threadIdx.x; i < k; i += 256) {
             const T l = G[j * k + i] / d;
             G[j * k + i] = l;
             G[i * k + j] = l;
         }
-        if (threadIdx.x == 0) G[j * k + j] = d;
+        if (threadIdx.x == 0) dg[j] = d;
         __syncthreads();
         const int n = k - j - 1;
         for (int e = threadIdx.x; e < n * n; e += 256) {
@@ -81,21 +100,19 @@ __global__ __launch_bounds__(256) void recsys_code_kernel(const T *Dt, int64_t p
     }
     __syncthreads();
     for (int j = 0; j < k; ++j) {                          // forward
-        if (threadIdx.x == 0) rhs[j] = rhs[j] / G[j * k + j];
-        __syncthreads();
-        const T yj = rhs[j];
+        const T yj = rhs[j] / dg[j];
         for (int i = j + 1 + threadIdx.x; i < k; i += 256) rhs[i] = fma(-yj, G[j * k + i], rhs[i]);
+        if (threadIdx.x == 0) ys[j] = yj;
         __syncthreads();
     }
     for (int j = k - 1; j >= 0; --j) {                     // backward
-        if (threadIdx.x == 0) rhs[j] = rhs[j] / G[j * k + j];
-        __syncthreads();
-        const T xj = rhs[j];
-        for (int i = threadIdx.x; i < j; i += 256) rhs[i] = fma(-xj, G[j * k + i], rhs[i]);
+        const T xj = ys[j] / dg[j];
+        for (int i = threadIdx.x; i < j; i += 256) ys[i] = fma(-xj, G[j * k + i], ys[i]);
+        if (threadIdx.x == 0) xs[j] = xj;
         __syncthreads();
     }
     T *out = code + (code_rows ? code_rows[blockIdx.x] : r) * k;
-    for (int a = threadIdx.x; a < k; a += 256) out[a] = rhs[a];
+    for (int a = threadIdx.x; a < k; a += 256) out[a] = xs[a];
 }
 
 // One wavefront per touched feature; entries of that feature in batch order.
@@ -146,7 +163,7 @@ template <typename T>
 int recsys_codes(const T *Dt, int64_t p, int k, const int32_t *indptr, const int32_t *indices, const T *data,
                  const int64_t *row_ids, const int64_t *code_rows, int64_t b, double alpha, T *code, hipStream_t st) {
     if (b <= 0) return MODL_OK;
-    const size_t lds = sizeof(T) * ((size_t)k * k + k + 32 * (size_t)k + 32) + 16;
+    const size_t lds = sizeof(T) * ((size_t)k * k + k + 32 * (size_t)k + 32) + 32 * sizeof(int) + 16;
     if (lds > 160 * 1024) return MODL_EINVAL;
     MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&recsys_code_kernel<T>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
