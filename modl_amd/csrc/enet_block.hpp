@@ -166,21 +166,7 @@ __device__ __forceinline__ double block_enet_project_vals(double (&x)[EPT], cons
     }
     const double gamma = 2.0 / l1_ratio - 2.0;
     const double R = radius / l1_ratio;
-    double tot = 0, dummy = 0;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const double a = fabs(x[e]);
-        tot += a * (1.0 + 0.5 * gamma * a);
-    }
-    block_sum2(tot, dummy, red2, nthreads);
-    if (tot <= R) {                                          // inside the ball: copy
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int64_t i = threadIdx.x + (int64_t)e * nthreads;
-            if (i < n) out[dst[e]] = (T)x[e];
-        }
-        return tot * l1_ratio;
-    }
+    double dummy = 0;
     double ax[EPT], term[EPT];                              // |x| and its contribution, computed once
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -191,28 +177,25 @@ __device__ __forceinline__ double block_enet_project_vals(double (&x)[EPT], cons
     // iteration converges to the level l* from ANY starting level l0 <= l* (levels only rise, entries at or below a
     // level <= l* are never in the final support), and it ends on the same support, hence on the same sums in the
     // same order: identical bits.  l0 <= l* holds iff the thresholded vector at l0 still lies outside the ball,
-    // h(l0) = sum_{|x|>l0} u (1 + gamma u / 2) >= R with u = (|x| - l0) / (1 + l0 gamma) (h decreases in l); h(l0)
-    // follows from the sums of the first pass (plus sum |x| when gamma != 0), so the check costs nothing when it
-    // holds and one pass when it does not (cold restart from 0).  Between two minibatches an atom's level moves
-    // little: 8 passes -> 3 on the fMRI shape.
+    // h(l0) = sum_{|x|>l0} u (1 + gamma u / 2) >= R with u = (|x| - l0) / (1 + l0 gamma) (h decreases in l, and
+    // h(0) is the norm of the vector itself: a verified guess also settles the inside-the-ball test); h(l0) follows
+    // from the sums of the first Michelot pass (plus sum |x| when gamma != 0), so the check costs nothing when it holds
+    // and one pass when it does not (cold start).  Between two minibatches an atom's level moves little: 8 passes -> 3
+    // on the fMRI shape.
     double level = 0.0, prev_cnt = -1.0;
-    bool verify = false;
+    bool warm = false;
     if (level_io) {
         const double l0 = 0.9 * *level_io;
-        if (l0 > 0.0 && l0 < 1e300) { level = l0; verify = true; }
-    }
-    for (int pass = 0; pass < 256; ++pass) {
-        double S = 0, S1 = 0;
-        int c0 = 0, c1 = 0;
-        if (verify) {                                        // first pass of a warm start
-            double P = 0;
+        if (l0 > 0.0 && l0 < 1e300) {
+            double S = 0, S1 = 0, P = 0;
+            int c0 = 0, c1 = 0;
             if (gamma != 0.0) {
 #pragma unroll
-                for (int e = 0; e < EPT; ++e) P += (ax[e] > level) ? ax[e] : 0.0;
+                for (int e = 0; e < EPT; ++e) P += (ax[e] > l0) ? ax[e] : 0.0;
             }
 #pragma unroll
             for (int e = 0; e < EPT; e += 2) {
-                const bool i0 = ax[e] > level, i1 = ax[e + 1] > level;
+                const bool i0 = ax[e] > l0, i1 = ax[e + 1] > l0;
                 S += i0 ? term[e] : 0.0;
                 S1 += i1 ? term[e + 1] : 0.0;
                 c0 += i0 ? 1 : 0;
@@ -224,31 +207,46 @@ __device__ __forceinline__ double block_enet_project_vals(double (&x)[EPT], cons
             double h0;
             if (gamma != 0.0) {
                 block_sum2(P, dummy2, red2, nthreads);
-                const double d = 1.0 + level * gamma;
-                const double sum_u = (P - cnt * level) / d;
+                const double d = 1.0 + l0 * gamma;
+                const double sum_u = (P - cnt * l0) / d;
                 const double sum_a2 = (S - P) / (0.5 * gamma);
-                const double sum_u2 = (sum_a2 - 2.0 * level * P + cnt * level * level) / (d * d);
+                const double sum_u2 = (sum_a2 - 2.0 * l0 * P + cnt * l0 * l0) / (d * d);
                 h0 = sum_u + 0.5 * gamma * sum_u2;
             } else {
-                h0 = S - cnt * level;
+                h0 = S - cnt * l0;
             }
-            verify = false;
-            if (!(h0 >= R * (1.0 + 1e-9)) || cnt == 0.0) {   // the guess overshoots (or cannot be told apart): cold start
-                level = 0.0;
-                continue;
+            if (h0 >= R * (1.0 + 1e-9) && cnt != 0.0) {      // (otherwise the guess overshoots, or cannot be told apart)
+                warm = true;
+                if (dbg && threadIdx.x == 0) { dbg[4] = 1; dbg[5] = (unsigned long long)cnt; }
+                prev_cnt = cnt;
+                if (gamma != 0.0) {
+                    const double qa = gamma * gamma * R + gamma * cnt * 0.5;
+                    const double qd = 2.0 * R * gamma + cnt;
+                    const double qc = R - S;
+                    level = (-qd + sqrt(qd * qd - 4.0 * qa * qc)) / (2.0 * qa);
+                } else {
+                    level = (S - R) / cnt;
+                }
             }
-            if (dbg && threadIdx.x == 0) { dbg[4] = pass + 1; dbg[5] = (unsigned long long)cnt; }
-            prev_cnt = cnt;
-            if (gamma != 0.0) {
-                const double qa = gamma * gamma * R + gamma * cnt * 0.5;
-                const double qd = 2.0 * R * gamma + cnt;
-                const double qc = R - S;
-                level = (-qd + sqrt(qd * qd - 4.0 * qa * qc)) / (2.0 * qa);
-            } else {
-                level = (S - R) / cnt;
-            }
-            continue;
         }
+    }
+    if (!warm) {
+        double tot = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) tot += term[e];
+        block_sum2(tot, dummy, red2, nthreads);
+        if (tot <= R) {                                      // inside the ball: copy
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int64_t i = threadIdx.x + (int64_t)e * nthreads;
+                if (i < n) out[dst[e]] = (T)x[e];
+            }
+            return tot * l1_ratio;
+        }
+    }
+    for (int pass = 0; pass < 256; ++pass) {
+        double S = 0, S1 = 0;
+        int c0 = 0, c1 = 0;
 #pragma unroll
         for (int e = 0; e < EPT; e += 2) {                  // selects, no branches; two chains
             const bool i0 = ax[e] > level, i1 = ax[e + 1] > level;
