@@ -21,16 +21,15 @@ template <typename T>
 __device__ void cholesky_inplace(T *W, int k) {
     // right-looking, symmetric trailing update so every access is row-contiguous
     for (int j = 0; j < k; ++j) {
-        __syncthreads();
+        __syncthreads();                                   // trailing update of column j - 1 done
         const T d = sqrt(W[(int64_t)j * k + j]);
-        __syncthreads();
         for (int i = j + 1 + threadIdx.x; i < k; i += blockDim.x) {
             const T l = W[(int64_t)j * k + i] / d;
             W[(int64_t)j * k + i] = l;
             W[(int64_t)i * k + j] = l;
         }
-        if (threadIdx.x == 0) W[(int64_t)j * k + j] = d;
-        __syncthreads();
+        __syncthreads();                                   // scaled row visible; every read of W[j][j] is behind us,
+        if (threadIdx.x == 0) W[(int64_t)j * k + j] = d;   // so the pivot can go in now (two barriers per column, not three)
         const int n = k - j - 1;
         const T *lrow = W + (int64_t)j * k + (j + 1);
         for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
