@@ -6,15 +6,23 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one SOMF minibatch (code solve, statistics, dictionary update) of
-256 rows per GPU.  The synthetic stream M1 of SURVEY.md §8(d) is generated on
-the device and is resident in HBM when the timed region starts.  With N > 1 every
-rank works on its own rows of a global minibatch of N*256 rows and the statistics
-increment is all-reduced over RCCL before each dictionary update (weak scaling).
+256 rows per GPU.  The synthetic stream M1 of SURVEY.md §8(d) is produced on the
+device, chunk by chunk (65 536 rows), by a counter-based generator: block j of
+8192 rows is a pure function of (seed, rank, j).  NO ROW IS EVER FITTED TWICE:
+chunk c + 1 is generated on a side stream while chunk c is being fitted, and the
+estimator follows the streaming protocol of the reference (`partial_fit(chunk)`
+with sample_indices = None: row i of a chunk warm-starts from `code_[i]`, the
+code of row i of the PREVIOUS chunk - dict_fact.py:313-337).  The chunks the
+timed region reads are resident in HBM when it starts.  With N > 1 every rank
+fits its own rows of a global minibatch of N*256 rows and the statistics increment
+is all-reduced over RCCL before each dictionary update (weak scaling).
 
-Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).  The
-`cpu_baseline` leg times the CPU oracle (oracle/somf_oracle.py: numpy + OpenBLAS
-for the contractions, C for the solver/projection — the reference's algorithm and
-operation order) on a bounded prefix of the same stream on the host cores.
+Rank 0 prints ONE JSON line.  `value` is the driver-timed run (W warm-up steps
+from a fresh dictionary, then exactly K steps).  `steady_state` holds, from the
+same process, >= 2000 fresh-row steps after a 500-step burn-in for reduction = 10
+AND reduction = 1 (OMF), each with its `cd_sweeps_mean`.  The `cpu_baseline` leg
+times the CPU oracle (oracle/somf_oracle.py: the reference's algorithm and
+operation order) on a bounded prefix of the same rows on the host cores.
 """
 import argparse
 import json
@@ -27,36 +35,111 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-K_COMP, P_FEAT, BATCH, CHUNK = 256, 10000, 256, 65536
+K_COMP, P_FEAT, BATCH, CHUNK, BLOCK = 256, 10000, 256, 65536, 8192
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = 'r01_o_pmc_hbm_traffic.json'
+PMC_FILE = 'r02_pmc_hbm_traffic.json'
 DOM_KERNEL = {'dict_update': 'modl::bcd_block_kernel', 'code_solve': 'modl::cd_kernel', 'stats_gemm': 'modl::gemm_stats_pair_kernel',
               'code_gemm': 'modl::gemm_dense_pair_kernel<float, false', 'stats_apply': 'modl::stats_apply2_kernel'}
+# the calibration of the CPU port against the real reference, measured in the build container
+# (scripts/calibrate_cpu_baseline.py -> profiles/r02_cpu_calibration.json)
+CALIBRATION_FILE = 'r02_cpu_calibration.json'
 
 
-def make_stream(n_rows, p, seed, device, k0=256, density=0.1, noise=0.1, row_seed=None):
-    """M1 stream: X = (Z o M) Q / sqrt(density k0) + noise E  (unit-variance entries).  The mixing matrix Q is drawn
-    from `seed` (the same on every rank), the rows from `row_seed` (one stream of rows per rank)."""
-    import torch
-    g = torch.Generator(device=device).manual_seed(seed)
-    Q = torch.randn(k0, p, device=device, generator=g)
-    if row_seed is not None:
-        g = torch.Generator(device=device).manual_seed(row_seed)
-    X = torch.empty(n_rows, p, device=device, dtype=torch.float32)
-    step = 8192
-    for r0 in range(0, n_rows, step):
-        r1 = min(n_rows, r0 + step)
-        Z = torch.randn(r1 - r0, k0, device=device, generator=g)
-        M = (torch.rand(r1 - r0, k0, device=device, generator=g) < density).float()
-        X[r0:r1] = (Z * M) @ Q / (density * k0) ** 0.5 + noise * torch.randn(r1 - r0, p, device=device, generator=g)
-    return X
+class M1Stream:
+    """Stream M1: X = (Z o M) Q / sqrt(density k0) + noise E, unit-variance entries.
+
+    Counter-based: the mixing matrix Q is a function of `seed` (the same on every rank), block j (BLOCK rows) of rank
+    `rank` a function of (seed, rank, j) - torch's Philox generator re-seeded per block - so any block can be produced
+    independently and in any order.  `chunk(c)` returns chunk c in one of two HBM buffers and starts producing chunk
+    c + 1 into the other one on a side stream (only if the run still needs it)."""
+
+    def __init__(self, p, seed, device, rank=0, k0=256, density=0.1, noise=0.1, chunk_rows=CHUNK):
+        import torch
+        self.torch = torch
+        self.p, self.seed, self.device, self.rank = p, seed, device, rank
+        self.k0, self.density, self.noise, self.chunk_rows = k0, density, noise, chunk_rows
+        g = torch.Generator(device=device).manual_seed(seed)
+        self.Q = torch.randn(k0, p, device=device, generator=g) / (density * k0) ** 0.5
+        self.gen = torch.Generator(device=device)
+        self.cuda = device.type == 'cuda'
+        self.buf = [None, None]
+        self.have = [-1, -1]                       # chunk held (or being produced) by each buffer
+        if self.cuda:
+            self.side = torch.cuda.Stream(device=device)
+            self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+            self.free = [None, None]
+        self.generated_rows = 0
+
+    def block_into(self, out, j):
+        """rows [j * BLOCK, j * BLOCK + len(out)) of this rank's stream"""
+        torch = self.torch
+        n = out.shape[0]
+        self.gen.manual_seed((self.seed * 1000003 + self.rank) * 1000003 + j)
+        Z = torch.randn(n, self.k0, device=self.device, generator=self.gen)
+        M = torch.rand(n, self.k0, device=self.device, generator=self.gen) < self.density
+        torch.randn(out.shape, device=self.device, generator=self.gen, out=out)
+        out.mul_(self.noise)
+        out.addmm_(Z * M, self.Q)
+        self.generated_rows += n
+
+    def rows(self, r0, r1):
+        """a fresh tensor with rows [r0, r1) (r0 on a block boundary)"""
+        assert r0 % BLOCK == 0
+        out = self.torch.empty(r1 - r0, self.p, device=self.device, dtype=self.torch.float32)
+        for a in range(r0, r1, BLOCK):
+            self.block_into(out[a - r0:min(a + BLOCK, r1) - r0], a // BLOCK)
+        return out
+
+    def _produce(self, c, slot):
+        torch = self.torch
+        if self.buf[slot] is None:
+            self.buf[slot] = torch.empty(self.chunk_rows, self.p, device=self.device, dtype=torch.float32)
+        self.have[slot] = c
+        r0 = c * self.chunk_rows
+        for a in range(0, self.chunk_rows, BLOCK):
+            self.block_into(self.buf[slot][a:a + BLOCK], (r0 + a) // BLOCK)
+
+    def chunk(self, c, prefetch_next=True):
+        torch = self.torch
+        slot = c % 2
+        if not self.cuda:
+            if self.have[slot] != c:
+                self._produce(c, slot)
+            return self.buf[slot]
+        main = torch.cuda.current_stream(self.device)
+        if self.have[slot] != c:                                   # not prefetched: produce it now
+            self._launch(c, slot, main)
+        main.wait_event(self.ready[slot])
+        if prefetch_next and self.have[1 - slot] != c + 1:
+            self._launch(c + 1, 1 - slot, main)
+        return self.buf[slot]
+
+    def _launch(self, c, slot, main):
+        torch = self.torch
+        if self.buf[slot] is None:                                 # allocate on the main stream's pool
+            self.buf[slot] = torch.empty(self.chunk_rows, self.p, device=self.device, dtype=torch.float32)
+        if self.free[slot] is not None:
+            self.side.wait_event(self.free[slot])                  # the fit has finished reading the old chunk
+        else:
+            self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            self._produce(c, slot)
+            self.ready[slot].record(self.side)
+
+    def release(self, c):
+        """the main stream has enqueued its last read of chunk c"""
+        if self.cuda:
+            ev = self.torch.cuda.Event()
+            ev.record(self.torch.cuda.current_stream(self.device))
+            self.free[c % 2] = ev
 
 
 def step_flops(k, p, b, s, sweeps, ride=False):
     """Algorithmic flops of one minibatch (SURVEY.md §8d work model, blocked dictionary update).
-    ride: the single-GPU step with a proper feature subset — the statistics section only carries the head
-    (C increment + sampled rows of the B increment); the p x k product rides along the dictionary update's launches."""
+    ride: the single-GPU step with a proper feature subset - the statistics section only carries the head
+    (C increment + sampled rows of the B increment); the p x k product rides along the dictionary update's launches
+    (`dict_update` = `bcd` + `b_inc`, reported separately as `dict_update_own` / `dict_update_rider`)."""
     dx = 2.0 * b * s * k
     gram = 2.0 * k * k * s
     h0 = 2.0 * b * k * k
@@ -66,9 +149,10 @@ def step_flops(k, p, b, s, sweeps, ride=False):
     bcd = 2.0 * k * k * s
     if ride:
         return dict(code_gemm=dx + gram, code_solve=h0 + cd, stats_gemm=c_inc + 2.0 * b * k * s,
-                    stats_apply=3.0 * (k * k + p * k), dict_update=bcd + b_inc)
+                    stats_apply=3.0 * (k * k + p * k), dict_update=bcd + b_inc, dict_update_own=bcd,
+                    dict_update_rider=b_inc)
     return dict(code_gemm=dx + gram, code_solve=h0 + cd, stats_gemm=c_inc + b_inc, stats_apply=3.0 * (k * k + p * k),
-                dict_update=bcd)
+                dict_update=bcd, dict_update_own=bcd, dict_update_rider=0.0)
 
 
 def step_bytes(k, p, b, s, e=4, ride=False):
@@ -86,120 +170,224 @@ def step_bytes(k, p, b, s, e=4, ride=False):
                 dict_update=e * (k * k + 3 * s * k))
 
 
-def run_gpu(args, reduction, steps, warmup, rank, world, device, breakdown=True):
-    """Warm-up (all sections timed -> picks the dominant one), the timed region (HIP events around the
-    dominant section only: every timed section costs two event records, i.e. a stream bubble of a few
-    microseconds each), then an untimed pass with all sections timed for the breakdown."""
-    import torch
-    import torch.distributed as dist
-    from modl_amd import DictFact
-    extra = min(steps, 50) if breakdown else 0
-    n_rows = min(CHUNK, max(4096, (steps + warmup + extra) * BATCH))
-    X = make_stream(n_rows, P_FEAT, 1234, device, row_seed=None if world == 1 else 5000 + rank)
-    # the dictionary is initialised from the same rows on every rank (replicas stay identical: same init, same draws,
-    # all-reduced statistics)
-    X0 = X[:K_COMP] if world == 1 else make_stream(K_COMP, P_FEAT, 1234, device, row_seed=4999)
-    est = DictFact(n_components=K_COMP, batch_size=BATCH, reduction=reduction, code_alpha=1.0, code_l1_ratio=1,
-                   comp_l1_ratio=0, learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0)
-    est.prepare(n_samples=n_rows, X=X0)
-    if getattr(args, 'force_reduce', False):                 # testing only: the N > 1 step with one rank
-        est._two_phase = True
-        est._force_reduce = True
+class Run:
+    """One estimator fitted on the fresh stream: `fit(n)` consumes the next n minibatches."""
 
-    def run(nsteps, start_step):
+    def __init__(self, args, reduction, rank, world, device, total_steps):
+        import torch
+        from modl_amd import DictFact
+        self.torch, self.world, self.device = torch, world, device
+        self.stream = M1Stream(P_FEAT, 1234, device, rank=rank)
+        self.total_rows = total_steps * BATCH
+        # the dictionary is initialised from the same rows on every rank (replicas stay identical: same init, same
+        # draws, all-reduced statistics): the first 256 rows of rank 0's stream
+        X0 = M1Stream(P_FEAT, 1234, device, rank=0).rows(0, K_COMP) if rank != 0 else None
+        self.est = DictFact(n_components=K_COMP, batch_size=BATCH, reduction=reduction, code_alpha=1.0, code_l1_ratio=1,
+                            comp_l1_ratio=0, learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0)
+        first = self.stream.chunk(0, prefetch_next=self.total_rows > CHUNK)
+        self.est.prepare(n_samples=CHUNK, X=first[:K_COMP] if X0 is None else X0)
+        if getattr(args, 'force_reduce', False):                 # testing only: the N > 1 step with one rank
+            self.est._two_phase = True
+            self.est._force_reduce = True
+        self.be = self.est._backend
+        self.row = 0                                              # next unseen row of the stream
+        self.enqueue_s = 0.0
+
+    def fit(self, nsteps):
+        """fits the next nsteps minibatches; returns without synchronising"""
         done = 0
         while done < nsteps:
-            r0 = ((start_step + done) * BATCH) % n_rows
-            todo = min(nsteps - done, (n_rows - r0) // BATCH)
-            est.partial_fit(X[r0:r0 + todo * BATCH], np.arange(r0, r0 + todo * BATCH))
+            c, r0 = divmod(self.row, CHUNK)
+            todo = min(nsteps - done, (CHUNK - r0) // BATCH)
+            more = self.total_rows > (c + 1) * CHUNK
+            Xc = self.stream.chunk(c, prefetch_next=more)
+            t0 = time.perf_counter()
+            # sample_indices = chunk-local positions: what partial_fit(chunk) with sample_indices=None uses
+            self.est.partial_fit(Xc[r0:r0 + todo * BATCH], np.arange(r0, r0 + todo * BATCH), _sync=False)
+            self.enqueue_s += time.perf_counter() - t0
+            self.row += todo * BATCH
             done += todo
+            if r0 + todo * BATCH == CHUNK:
+                self.stream.release(c)
 
-    be = est._backend
-    # the dominant section is picked on the LAST quarter of the warm-up (the first minibatches of a fresh
-    # dictionary need several times more solver sweeps than the steady state)
-    w_head = warmup - max(warmup // 4, 1) if warmup >= 4 else warmup
-    run(w_head, 0)
-    be.prof_enable(True)
-    be.prof_reset()
-    run(warmup - w_head, w_head)
-    torch.cuda.synchronize()
-    pre = be.prof_get()
-    dom = max(pre, key=lambda n: pre[n]['ms']) if warmup - w_head > 0 and pre else 'dict_update'
-    be.prof_enable(False)
-    be.prof_enable(True, sections=[dom])
-    be.prof_reset()
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+def timed(run, steps, world):
+    """barrier + synchronize, exactly `steps` minibatches, synchronize + barrier; max over ranks"""
+    import torch
+    import torch.distributed as dist
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    run.sync()
+    run.enqueue_s = 0.0
     t0 = time.perf_counter()
-    run(steps, warmup)
-    run_gpu.host_ms_per_step = (time.perf_counter() - t0) / steps * 1e3   # host time to ENQUEUE a step
-    torch.cuda.synchronize()
+    run.fit(steps)
+    enq = run.enqueue_s
+    run.sync()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    prof_dom = be.prof_get()[dom]
-    be.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], device=run.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, enq
+
+
+def run_gpu(args, reduction, steps, warmup, rank, world, device, breakdown=True):
+    """Warm-up (all sections timed on its last quarter -> picks the dominant one), the timed region (HIP events around
+    the dominant section only: every timed section costs two event records, i.e. a stream bubble of a few microseconds
+    each), then an untimed pass with all sections timed for the breakdown."""
+    import torch
+    import torch.distributed as dist
+    extra = min(steps, 50) if breakdown else 0
+    run = Run(args, reduction, rank, world, device, steps + warmup + extra)
+    be = run.be
+    w_head = warmup - max(warmup // 4, 1) if warmup >= 4 else warmup
+    run.fit(w_head)
+    pre, dom = {}, 'dict_update'
+    if breakdown:
+        be.prof_enable(True)
+        be.prof_reset()
+    run.fit(warmup - w_head)
+    run.sync()
+    if breakdown:
+        pre = be.prof_get()
+        if warmup - w_head > 0 and pre:
+            dom = max(pre, key=lambda n: pre[n]['ms'])
+        be.prof_enable(False)
+        be.prof_enable(True, sections=[dom])
+        be.prof_reset()
+    dt, enq = timed(run, steps, world)
+    res = dict(dt=dt, enqueue_ms_per_step=enq / steps * 1e3, dom=dom, prof_dom=None, prof={})
+    if breakdown:
+        res['prof_dom'] = be.prof_get()[dom]
+        be.prof_enable(False)
     lsw = be.last_sweeps()
-    sweeps = float(lsw.mean())
-    run_gpu.sweeps_max = int(lsw.max())
-    prof = {}
+    res['sweeps'], res['sweeps_max'] = float(lsw.mean()), int(lsw.max())
     if extra:
         be.prof_enable(True)
         be.prof_reset()
-        run(extra, warmup + steps)
-        torch.cuda.synchronize()
-        prof = be.prof_get()
+        run.fit(extra)
+        run.sync()
+        res['prof'] = be.prof_get()
         be.prof_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    D = est.components_
-    ok = bool(np.all(np.isfinite(D)))
-    run_gpu.replicas_identical = None
+    res['finite'] = bool(torch.isfinite(be.Dt).all().item())
+    res['replicas_identical'] = None
     if world > 1:                                  # the replicas of the dictionary must agree bit for bit
         chk = torch.stack([be.Dt.double().sum(), (be.Dt.double() ** 2).sum()])
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        run_gpu.replicas_identical = bool(torch.equal(lo, hi))
-    return dt, prof, sweeps, ok, dom, prof_dom
+        res['replicas_identical'] = bool(torch.equal(lo, hi))
+    res['rows_generated'] = run.stream.generated_rows
+    res['rows_fitted'] = run.row
+    return res
 
 
-def cpu_baseline(reduction, budget_s=20.0):
-    """CPU oracle on a bounded prefix of the same stream, all host cores for BLAS."""
+def steady_state(args, reduction, rank, world, device, steps, burn_in):
+    """>= 2000 fresh-row minibatches after a burn-in, no events on the stream."""
     import torch
+    run = Run(args, reduction, rank, world, device, steps + burn_in)
+    run.fit(burn_in)
+    dt, enq = timed(run, steps, world)
+    lsw = run.be.last_sweeps()
+    return dict(reduction=reduction, steps=steps, burn_in=burn_in, value=steps * BATCH * world / dt, unit='samples/s',
+                ms_per_step=dt / steps * 1e3, host_enqueue_ms_per_step=enq / steps * 1e3,
+                cd_sweeps_mean=float(lsw.mean()), cd_sweeps_max=int(lsw.max()),
+                finite=bool(torch.isfinite(run.be.Dt).all().item()), rows_fitted=run.row,
+                rows='fresh (no row fitted twice; chunk-local warm starts from the previous chunk)')
+
+
+def cpu_baseline(X, reduction, budget_s=20.0, threads=None):
+    """CPU oracle on a bounded prefix of the same rows (X: host array, the first rows of rank 0's stream)."""
     from oracle import somf_oracle as orc
     cores = os.cpu_count() or 1
-    n_rows = 40 * BATCH                 # bounded sample: the loop below stops after budget_s seconds
-    X = make_stream(n_rows, P_FEAT, 1234, torch.device('cpu')).numpy()
+    threads = threads or min(cores, 32)             # 256-wide GEMMs do not scale past a few dozen threads
+    from contextlib import nullcontext
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads, user_api='blas')
+    except Exception:                               # pragma: no cover
+        limiter, threads = nullcontext(), cores
+    n_rows = X.shape[0]
     pr = orc.SomfParams(n_components=K_COMP, batch_size=BATCH, reduction=reduction, code_alpha=1.0, code_l1_ratio=1,
                         comp_l1_ratio=0, learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0)
-    st = orc.prepare(pr, n_samples=n_rows, X=X[:K_COMP])
-    done, t0 = 0, time.perf_counter()
-    for r0 in range(0, n_rows, BATCH):
-        orc.partial_fit(st, pr, X[r0:r0 + BATCH], np.arange(r0, r0 + BATCH))
-        done += BATCH
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return dict(value=done / dt, unit='samples/s', cores=cores, kind='port',
-                sample='first %d rows of stream M1 (p=%d, k=%d, b=%d, reduction=%g), %.1f s; numpy/OpenBLAS threads=%d '
-                       'for the contractions, single-thread C for the CD solver and projections'
-                       % (done, P_FEAT, K_COMP, BATCH, reduction, dt, cores))
+    with limiter:
+        st = orc.prepare(pr, n_samples=n_rows, X=X[:K_COMP])
+        done, t0 = 0, time.perf_counter()
+        for r0 in range(0, n_rows, BATCH):
+            orc.partial_fit(st, pr, X[r0:r0 + BATCH], np.arange(r0, r0 + BATCH))
+            done += BATCH
+            if time.perf_counter() - t0 > budget_s:
+                break
+        dt = time.perf_counter() - t0
+    out = dict(value=done / dt, unit='samples/s', cores=threads, kind='port',
+               sample='first %d rows of stream M1 (p=%d, k=%d, b=%d, reduction=%g), %.1f s; numpy/OpenBLAS with %d threads '
+                      '(of %d host cores) for the contractions, single-thread C for the CD solver and projections'
+                      % (done, P_FEAT, K_COMP, BATCH, reduction, dt, threads, cores))
+    try:                                            # speed of this port relative to the real reference (build container)
+        cal = json.load(open(os.path.join(ROOT, 'profiles', CALIBRATION_FILE)))
+        out['calibration'] = cal.get('summary', cal)
+    except (OSError, ValueError):
+        out['calibration'] = None
+    return out
+
+
+def roofline_of(dom, prof_dom, fl, by, reduction):
+    if not prof_dom or prof_dom['calls'] <= 0:
+        return None
+    ms = prof_dom['ms'] / prof_dom['calls']
+    nl = prof_dom['launches'] / prof_dom['calls']
+    gflops, gbs = fl[dom] / ms / 1e6, by[dom] / ms / 1e6
+    ai = fl[dom] / by[dom]
+    if ai * PEAK_HBM_GBS / 1e3 > PEAK_MFMA_F32_TFLOPS:       # ridge of the f32 roofline
+        roof = dict(bound='mfma', kernel=dom, achieved=gflops / 1e3, peak=PEAK_MFMA_F32_TFLOPS,
+                    unit='TFLOP/s', frac=gflops / 1e3 / PEAK_MFMA_F32_TFLOPS, traffic=None)
+    else:
+        roof = dict(bound='hbm', kernel=dom, achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s',
+                    frac=gbs / PEAK_HBM_GBS, traffic=None)
+    roof['ms_per_step'] = ms
+    roof['launches_per_step'] = nl
+    roof['avg_launch_ms'] = ms / max(nl, 1)
+    roof['algorithmic_per_launch'] = dict(flops=fl[dom] / max(nl, 1), bytes=by[dom] / max(nl, 1))
+    if dom == 'dict_update':
+        # the launches of the dictionary update also carry the p x k statistics product of the rows that were not
+        # sampled (it rides on the compute units the update leaves idle): the two shares of `achieved`, separately
+        own, rider = fl['dict_update_own'], fl['dict_update_rider']
+        roof['split'] = dict(block_coordinate_update=dict(flops_per_step=own, achieved=own / ms / 1e9,
+                                                          frac=own / ms / 1e9 / PEAK_MFMA_F32_TFLOPS),
+                             riding_statistics_product=dict(flops_per_step=rider, achieved=rider / ms / 1e9,
+                                                            frac=rider / ms / 1e9 / PEAK_MFMA_F32_TFLOPS))
+    if dom == 'code_solve':
+        roof['note'] = ('coordinate descent is a VALU kernel (no MFMA) bound by the dependency chain of k x sweeps '
+                        'sequential coordinate steps per sample; the MFMA peak is the compute roof by convention')
+    # HBM traffic per launch of the section's main kernel: from the committed rocprofv3 --pmc passes of this round
+    # (FETCH_SIZE and WRITE_SIZE need separate profiler passes and cannot be collected from inside this process)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', PMC_FILE)))
+        kern = [k_ for k_ in pmc if k_.startswith(DOM_KERNEL.get(dom, '?'))]
+        if kern and abs(reduction - 10.0) < 1e-9:
+            e = pmc[kern[0]]
+            roof['traffic'] = e.get('fetch_bytes_corrected', 0.0) + e.get('write_bytes', 0.0)
+            roof['traffic_source'] = ('OFFLINE: profiles/%s (rocprofv3 --pmc passes of bench.py at reduction=10): %s, '
+                                      'FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per launch' % (PMC_FILE, kern[0]))
+    except (OSError, ValueError):
+        pass
+    return roof
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    # the first few hundred minibatches of a fresh dictionary need several times more solver sweeps than the steady
-    # state: the default warm-up covers them (the whole default run takes ~3 s of GPU time + the CPU baseline)
     ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=500)
     ap.add_argument('--reduction', type=float, default=10.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--also-r1', action='store_true', help='also time reduction=1 (OMF) and report it under "also"')
+    ap.add_argument('--steady-steps', type=int, default=2000, help='fresh-row steps of each steady_state record (0: skip)')
+    ap.add_argument('--steady-burn-in', type=int, default=500)
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to test the N > 1 path)')
     ap.add_argument('--force-reduce', action='store_true',
                     help='testing only: run the multi-GPU step (two phases + RCCL all-reduces) even with one rank')
@@ -225,12 +413,17 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    dt, prof, sweeps, ok, dom, prof_dom = run_gpu(args, args.reduction, args.steps, args.warmup, rank, world, device)
+    res = run_gpu(args, args.reduction, args.steps, args.warmup, rank, world, device)
+    steady = []
+    if args.steady_steps > 0:
+        for r in (10.0, 1.0):
+            steady.append(steady_state(args, r, rank, world, device, args.steady_steps, args.steady_burn_in))
     out = None
     if rank == 0:
+        dt, sweeps, dom, prof = res['dt'], res['sweeps'], res['dom'], res['prof']
         samples = args.steps * BATCH * world
         s_mean = P_FEAT / args.reduction
-        ride = world == 1 and args.reduction > 1 and not args.force_reduce and not os.environ.get('MODL_NO_RIDER')
+        ride = world == 1 and args.reduction > 1 and not args.force_reduce
         fl = step_flops(K_COMP, P_FEAT, BATCH, s_mean, sweeps, ride=ride)
         by = step_bytes(K_COMP, P_FEAT, BATCH, s_mean, ride=ride)
         sections = {}
@@ -240,60 +433,30 @@ def main():
             ms = e['ms'] / e['calls']
             sections[name] = dict(ms_per_step=ms, launches_per_step=e['launches'] / e['calls'],
                                   gflops=fl[name] / ms / 1e6, gbs=by[name] / ms / 1e6)
-        # roofline of the dominant section, from the events recorded INSIDE the timed region
-        roof = None
-        if prof_dom['calls'] > 0:
-            ms = prof_dom['ms'] / prof_dom['calls']
-            nl = prof_dom['launches'] / prof_dom['calls']
-            gflops, gbs = fl[dom] / ms / 1e6, by[dom] / ms / 1e6
-            ai = fl[dom] / by[dom]
-            if ai * PEAK_HBM_GBS / 1e3 > PEAK_MFMA_F32_TFLOPS:       # ridge of the f32 roofline
-                roof = dict(bound='mfma', kernel=dom, achieved=gflops / 1e3, peak=PEAK_MFMA_F32_TFLOPS,
-                            unit='TFLOP/s', frac=gflops / 1e3 / PEAK_MFMA_F32_TFLOPS, traffic=None)
-            else:
-                roof = dict(bound='hbm', kernel=dom, achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s',
-                            frac=gbs / PEAK_HBM_GBS, traffic=None)
-            roof['ms_per_step'] = ms
-            roof['launches_per_step'] = nl
-            roof['avg_launch_ms'] = ms / max(nl, 1)
-            roof['algorithmic_per_launch'] = dict(flops=fl[dom] / max(nl, 1), bytes=by[dom] / max(nl, 1))
-            # HBM traffic per launch of the section's main kernel: from the committed rocprofv3 --pmc passes
-            # (FETCH_SIZE and WRITE_SIZE need separate passes and cannot be collected from inside this process)
-            try:
-                pmc = json.load(open(os.path.join(ROOT, 'profiles', PMC_FILE)))
-                kern = [k_ for k_ in pmc if k_.startswith(DOM_KERNEL.get(dom, '?'))]
-                if kern and abs(args.reduction - 10.0) < 1e-9:
-                    e = pmc[kern[0]]
-                    roof['traffic'] = e.get('fetch_bytes_corrected', 0.0) + e.get('write_bytes', 0.0)
-                    roof['traffic_source'] = 'profiles/%s: %s, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per launch' % (
-                        PMC_FILE, kern[0])
-            except (OSError, ValueError):
-                pass
-        total_fl = sum(fl.values())
+        roof = roofline_of(dom, res['prof_dom'], fl, by, args.reduction)
+        total_fl = sum(fl[n] for n in ('code_gemm', 'code_solve', 'stats_gemm', 'dict_update'))
         out = dict(metric='samples/sec through DictFact.partial_fit at k=256, p=10k', value=samples / dt,
                    unit='samples/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None,
                    dtype='f32', data='synthetic',
-                   config=dict(workload='M1 stream: %d-row resident chunk x p=%d f32, n_components=%d, batch_size=%d/GPU, '
-                                        'reduction=%g, code_alpha=1 (l1 codes), l2 atoms, learning_rate=0.92, '
-                                        'masked/masked' % (CHUNK, P_FEAT, K_COMP, BATCH, args.reduction),
+                   config=dict(workload='M1 stream (SURVEY 8d): fresh rows only, produced on the device in %d-row chunks by a '
+                                        'counter-based generator (no row fitted twice; chunk-local warm starts), p=%d f32, '
+                                        'n_components=%d, batch_size=%d/GPU, reduction=%g, code_alpha=1 (l1 codes), l2 atoms, '
+                                        'learning_rate=0.92, masked/masked; timed from a fresh dictionary after the warm-up steps'
+                                        % (CHUNK, P_FEAT, K_COMP, BATCH, args.reduction),
                                reduction=args.reduction, global_batch=BATCH * world,
-                               parallelism='dp%d (row-sharded minibatch; all-reduce of the C increment and the sampled rows of the B increment, '
-                                           'the rest of the B increment all-reduced under the dictionary update)' % world),
-                   roofline=roof, sections=sections, cd_sweeps_mean=sweeps, cd_sweeps_max=getattr(run_gpu, 'sweeps_max', None),
-                   step_tflops=total_fl / (dt / args.steps) / 1e12, finite=ok,
-                   replicas_identical=getattr(run_gpu, 'replicas_identical', None),
-                   host_enqueue_ms_per_step=getattr(run_gpu, 'host_ms_per_step', None))
-    if args.also_r1:
-        dt1, prof1, sw1, ok1, _, _ = run_gpu(args, 1.0, max(args.steps // 2, 10), max(args.warmup // 2, 2), rank, world, device,
-                                             breakdown=False)
-        if rank == 0:
-            n1 = max(args.steps // 2, 10)
-            out['also'] = dict(reduction_1=dict(value=n1 * BATCH * world / dt1, ms_per_step=dt1 / n1 * 1e3,
-                                                cd_sweeps_mean=sw1, finite=ok1))
-    if rank == 0:
+                               parallelism='dp%d (row-sharded minibatch; all-reduce of the C increment and of the sampled rows '
+                                           'of the B increment before each dictionary update; every rank keeps its own partial '
+                                           'B_ for the rows that were not sampled)' % world),
+                   roofline=roof, sections=sections, cd_sweeps_mean=sweeps, cd_sweeps_max=res['sweeps_max'],
+                   step_tflops=total_fl / (dt / args.steps) / 1e12, finite=res['finite'],
+                   replicas_identical=res['replicas_identical'],
+                   host_enqueue_ms_per_step=res['enqueue_ms_per_step'],
+                   rows=dict(fitted=res['rows_fitted'], generated=res['rows_generated']),
+                   steady_state=steady)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.reduction)
+            Xh = M1Stream(P_FEAT, 1234, device, rank=0).rows(0, 40 * BATCH).cpu().numpy()
+            out['cpu_baseline'] = cpu_baseline(Xh, args.reduction)
         else:
             out['cpu_baseline'] = None
     if world > 1 or args.force_reduce:

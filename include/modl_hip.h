@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MODL_ABI_VERSION 1
+#define MODL_ABI_VERSION 2
 
 #define MODL_OK 0
 #define MODL_EINVAL (-1)   /* bad argument */
@@ -52,10 +52,19 @@ extern "C" {
 #define MODL_OPT_VARIATIONAL 0
 #define MODL_OPT_SGD 1
 
+/* modl_somf_desc.flags (diagnostics; 0 in production) */
+#define MODL_FLAG_NO_RIDER 1      /* the B_ update of the rows that were not sampled runs as its own launch */
+#define MODL_FLAG_GEMM_STAMPS 2   /* the head statistics product leaves shader-clock stamps (modl_somf_debug_gemm_stamps) */
+
 int modl_abi_version(void);
 /* number of visible HIP devices (0 without a GPU); never fails */
 int modl_device_count(void);
 const char *modl_error_string(int code);
+/* process-wide diagnostics switches (the test-suite forces code paths with them; nothing reads the environment).
+ * MODL_DEBUG_CD_SPARSE_PCT: value >= 0 = share of active coordinates (percent) below which a coordinate-descent
+ * sweep runs as an active-set sweep (0: always dense, 100: always sparse), -1 = the default rule. */
+#define MODL_DEBUG_CD_SPARSE_PCT 1
+int modl_debug_set(int what, int64_t value);
 
 /* ------------------------------------------------------------------------- *
  * Host-side RNG — replaces modl/utils/randomkit/random_fast.pyx (RandomState,
@@ -250,14 +259,14 @@ typedef struct modl_somf_desc {
     double tol;
     double step_size;
     int32_t max_batch;      /* largest minibatch this plan will see */
-    int32_t reserved;
+    int32_t flags;          /* MODL_FLAG_* (diagnostics), 0 otherwise */
 } modl_somf_desc;
 
 /* device state of one estimator (allocated by the caller; all T = dtype) */
 typedef struct modl_somf_state {
     void *d_Dt;          /* [p][k]  components_.T */
-    void *d_Bt;          /* [p][k]  B_.T */
-    void *d_C;           /* [k][k]  C_ */
+    void *d_Bt;          /* [p][k]  B_.T  (several GPUs: this rank's partial sum, B_ = sum over ranks) */
+    void *d_C;           /* [k][k]  C_    (several GPUs: this rank's partial sum) */
     void *d_code;        /* [n_samples][k] code_ */
     void *d_comp_norm;   /* [k] comp_norm_ */
     void *d_G;           /* [k][k] G_ (G_agg == full), else NULL */
@@ -289,40 +298,28 @@ void modl_somf_plan_destroy(modl_somf_plan *plan);
  * dict_fact.py:339-357).  k, p, dtype, n_samples, max_batch must not change. */
 int modl_somf_plan_update(modl_somf_plan *plan, const modl_somf_desc *desc);
 
-/* number of T elements of the statistics increment buffer (k*k + 2*p*k):
- *   [ code^T code (k*k) | rows of X^T code of the SAMPLED features, compact (p*k slots, s*k used) | X^T code (p*k) ] */
-int64_t modl_somf_delta_elems(const modl_somf_desc *desc);
+/* One GPU: the whole minibatch step (codes, C_/B_ update in the epilogues of the increment products, dictionary
+ * update).  Asynchronous on `stream`. */
+int modl_somf_step(modl_somf_plan *plan, const modl_somf_state *st, const modl_somf_batch *bt, void *stream);
 
-/* Phase 1 (per rank): code solve for the minibatch rows (writes d_code rows),
- * then the increments (layout above, feature-major, NOT yet divided by the batch
- * size).  With several GPUs the caller sums d_delta over the ranks as
- * modl_somf_delta_split says: the head before phase 2, the tail (the bulk) at
- * the latest before modl_somf_apply_rest — i.e. under the dictionary update. */
+/* Several GPUs (one process per GPU, the rows of a global minibatch of b_global rows split over the ranks; every
+ * rank passes the same subset / order / w).  The recursions C_ <- (1 - w) C_ + (w / b_global) code^T code and
+ * B_ <- (1 - w) B_ + (w / b_global) code^T X are linear in the increments, so every rank keeps its own PARTIAL
+ * statistics (st->d_C, st->d_Bt: C_ = sum over ranks, B_ likewise) and only what the dictionary update reads is
+ * exchanged - the HEAD  [ C_r (k*k) | the rows of B_r of the sampled features, compact (s*k) ]:
+ *   1. modl_somf_code_and_partials : codes of the rank's rows, update of its partial statistics, head -> d_head;
+ *   2. the caller sums d_head[0 .. modl_somf_head_elems) over the ranks (ncclAllReduce / RCCL, in place);
+ *   3. modl_somf_apply_and_update_dict : the dictionary update from the summed head, identical on every rank
+ *      (replicas of the dictionary stay bit-identical).
+ * d_head holds modl_somf_delta_elems() = k*k + p*k elements of T (a minibatch without a subset array carries all
+ * p rows of B_r).  With one rank and no reduction the two calls give the same bits as modl_somf_step. */
+int64_t modl_somf_delta_elems(const modl_somf_desc *desc);
 int modl_somf_code_and_partials(modl_somf_plan *plan, const modl_somf_state *st, const modl_somf_batch *bt,
-                                void *d_delta, void *stream);
-/* How to reduce the increments of the LAST phase 1 over the ranks:
- *   d_delta[0 .. *head_elems)                      needed by phase 2 (C increment + sampled rows of the B increment);
- *   d_delta[*tail_offset .. + *tail_elems)         the full B increment.  *tail_before_phase2 == 0: only
- *   modl_somf_apply_rest reads it (sum it asynchronously);  == 1: the minibatch had no proper feature subset,
- *   phase 2 applies it itself and it must be summed before phase 2. */
-int modl_somf_delta_split(const modl_somf_plan *plan, int64_t *head_elems, int64_t *tail_offset, int64_t *tail_elems,
-                          int *tail_before_phase2);
-/* Phase 1b (per rank): when the last phase 1 wrote only the HEAD of the increment (a minibatch with a proper
- * feature subset: the head comes from its own small product over the gathered columns), this computes the bulk,
- * the p x k product X^T code, into d_delta[*tail_offset ..).  Call it right after STARTING the all-reduce of the
- * head, so that the product runs while the head travels; a no-op when nothing is pending.  `bt` is the batch of
- * the last phase 1.  modl_somf_apply_rest returns MODL_ESTATE if the bulk is still pending. */
-int modl_somf_bulk_partials(modl_somf_plan *plan, const modl_somf_batch *bt, void *d_delta, void *stream);
-/* Phase 2 (identical on every rank): C_/B_ update from d_delta with weight w /
- * b_global (B_: the sampled rows only when the increments were split), then the
- * block-coordinate dictionary update on the subset. */
+                                void *d_head, void *stream);
+/* elements of the head written by the LAST modl_somf_code_and_partials (MODL_ESTATE if none is pending) */
+int modl_somf_head_elems(const modl_somf_plan *plan, int64_t *head_elems);
 int modl_somf_apply_and_update_dict(modl_somf_plan *plan, const modl_somf_state *st,
-                                    const modl_somf_batch *bt, const void *d_delta, void *stream);
-/* Phase 3 (identical on every rank): the rows of B_ that phase 2 left out (no-op when nothing is pending). */
-int modl_somf_apply_rest(modl_somf_plan *plan, const modl_somf_state *st, const void *d_delta, void *stream);
-/* all phases back to back (one GPU): the C_/B_ update rides in the epilogues of the increment products */
-int modl_somf_step(modl_somf_plan *plan, const modl_somf_state *st, const modl_somf_batch *bt, void *d_delta,
-                   void *stream);
+                                    const modl_somf_batch *bt, const void *d_head, void *stream);
 
 /* G_ = D D^T (prepare / set_params(G_agg='full'), dict_fact.py:355,477) */
 int modl_somf_full_gram(modl_somf_plan *plan, const void *d_Dt, void *d_G, void *stream);

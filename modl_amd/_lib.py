@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libmodl_hip.so')
 
 MODL_F32, MODL_F64 = 0, 1
+FLAG_NO_RIDER, FLAG_GEMM_STAMPS = 1, 2          # modl_somf_desc.flags (diagnostics)
+DEBUG_CD_SPARSE_PCT = 1                         # modl_debug_set
 AGG = {'masked': 0, 'full': 1, 'average': 2}
 OPT = {'variational': 0, 'sgd': 1}
 
@@ -25,7 +27,7 @@ class SomfDesc(C.Structure):
                 ('G_agg', C.c_int32), ('Dx_agg', C.c_int32), ('optimizer', C.c_int32), ('code_pos', C.c_int32),
                 ('comp_pos', C.c_int32), ('max_iter', C.c_int32), ('code_alpha', C.c_double),
                 ('code_l1_ratio', C.c_double), ('comp_l1_ratio', C.c_double), ('tol', C.c_double),
-                ('step_size', C.c_double), ('max_batch', C.c_int32), ('reserved', C.c_int32)]
+                ('step_size', C.c_double), ('max_batch', C.c_int32), ('flags', C.c_int32)]
 
 
 class SomfState(C.Structure):
@@ -72,6 +74,7 @@ def _sig(name, restype, *argtypes):
 _sig('modl_abi_version', C.c_int)
 _sig('modl_device_count', C.c_int)
 _sig('modl_error_string', C.c_char_p, C.c_int)
+_sig('modl_debug_set', C.c_int, C.c_int, _i64)
 _sig('modl_rk_create', C.c_int, _u64, _P(_vp))
 _sig('modl_rk_destroy', None, _vp)
 _sig('modl_rk_seed', C.c_int, _vp, _u64)
@@ -127,10 +130,8 @@ _sig('modl_somf_plan_update', C.c_int, _vp, _P(SomfDesc))
 _sig('modl_somf_delta_elems', _i64, _P(SomfDesc))
 _sig('modl_somf_code_and_partials', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
 _sig('modl_somf_apply_and_update_dict', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
-_sig('modl_somf_step', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
-_sig('modl_somf_apply_rest', C.c_int, _vp, _P(SomfState), _vp, _vp)
-_sig('modl_somf_bulk_partials', C.c_int, _vp, _P(SomfBatch), _vp, _vp)
-_sig('modl_somf_delta_split', C.c_int, _vp, _P(_i64), _P(_i64), _P(_i64), _P(C.c_int))
+_sig('modl_somf_step', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp)
+_sig('modl_somf_head_elems', C.c_int, _vp, _P(_i64))
 _sig('modl_somf_full_gram', C.c_int, _vp, _vp, _vp, _vp)
 _sig('modl_somf_transform', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp)
 _sig('modl_somf_debug_stamps', C.c_int, _vp, _vp)

@@ -1411,7 +1411,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         double *CA[2] = {Tp, Tp + kResStride};
         unsigned int *counter = reinterpret_cast<unsigned int *>(Tp + 2 * kResStride);
         const bool fused = std::is_same<T, float>::value && (k % 4 == 0) && k <= 512;
-        static const int64_t rt1_max = getenv("MODL_RT1_MAX") ? atoll(getenv("MODL_RT1_MAX")) : MODL_RT1_MAX;   // (tuning)
+        constexpr int64_t rt1_max = MODL_RT1_MAX;
         const int RT = (s <= rt1_max || k > 256) ? 1 : 2;        // k > 256: 64-row tiles would spill registers
         const int nslab = fused ? (int)cdiv(s, 32 * RT) : (int)cdiv(s, kGramRows);
         const int GPW = (k <= 256) ? 8 : 16;
@@ -1462,7 +1462,6 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                 ride_tiles = rid.P.tn * rid.P.tm;
                 // as few carrier launches as the idle compute units allow (a tile needs a compute unit to itself for
                 // most of a block step; more tiles than free units would queue and stretch the launch)
-                static const int ride_launches = getenv("MODL_RIDER_LAUNCHES") ? atoi(getenv("MODL_RIDER_LAUNCHES")) : 0;   // (tuning)
                 static const int ncu = [] {                             // one process per GPU: queried once
                     int dev = 0;
                     hipDeviceProp_t prop;
@@ -1472,7 +1471,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                 }();
                 const int free_cu = (ncu - nslab > 64) ? ncu - nslab : 64;
                 const int nblk_all = (int)cdiv(k, kNB);
-                int carriers = ride_launches > 0 ? ride_launches : (int)cdiv(ride_tiles, free_cu);
+                int carriers = (int)cdiv(ride_tiles, free_cu);
                 if (carriers > nblk_all) carriers = nblk_all;
                 if (carriers < 1) carriers = 1;
                 ride_per = (int)cdiv(ride_tiles, carriers);
@@ -1575,8 +1574,7 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
         return MODL_OK;
     }
     int nwg = (int)cdiv(s, 4);                       // 4 waves per workgroup (the projection wants registers: 256 threads), one feature per wave while the grid lasts
-    static const int nwg_cap = getenv("MODL_NWG_GRAD") ? atoi(getenv("MODL_NWG_GRAD")) : 512;   // (tuning)
-    if (nwg > nwg_cap) nwg = nwg_cap;
+    if (nwg > 512) nwg = 512;
     if (nwg > L.nwg_grad) nwg = (int)L.nwg_grad;
     if (nwg < 1) nwg = 1;
     unsigned int *counter = reinterpret_cast<unsigned int *>(reinterpret_cast<double *>(ws + L.off_Tp) + 2 * kResStride);
@@ -1584,9 +1582,8 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
     const size_t u_lds = (sizeof(T) * (size_t)s <= 60 * 1024) ? sizeof(T) * (size_t)s : 0;
     // groups of atoms per launch while the vector fits the registers of the projecting workgroup and the group's
     // scratch (numerators, old values, changes) fits the region of the sgd candidate matrix
-    static const bool no_group = getenv("MODL_NO_ATOM_GROUP") != nullptr;   // (diagnostics)
     const size_t group_bytes = (size_t)kAtomGroup * (size_t)s * (sizeof(double) + sizeof(T));
-    if (!no_group && s <= (int64_t)kProjEpt * 256 && group_bytes + 64 <= sizeof(T) * (size_t)s * k && k <= 512 &&
+    if (s <= (int64_t)kProjEpt * 256 && group_bytes + 64 <= sizeof(T) * (size_t)s * k && k <= 512 &&
         (int64_t)kAtomGroup * nwg <= L.nwg_grad) {
         char *gb = ws + L.off_Dnew;
         double *num = reinterpret_cast<double *>(gb);

@@ -33,7 +33,7 @@
 // gap test are wave shuffles.  b independent problems -> b wavefronts, 4 per
 // workgroup.
 #include "kernels.hpp"
-#include <cstdlib>
+#include <atomic>
 #ifndef MODL_CD_SPARSE_RING
 #define MODL_CD_SPARSE_RING 4          /* (tuning) ring depth of the sparse sweep for k <= 256 */
 #endif
@@ -522,12 +522,15 @@ static void launch_cd_kpl(hipStream_t stream, const CdArgs<T> &a, dim3 grid, dim
 #undef MODL_CD_LAUNCH
 }
 
+// diagnostics (modl_debug_set): >= 0 overrides CdArgs::sparse_pct for every launch of this process
+std::atomic<int> g_cd_sparse_pct{-1};
+
 template <typename T>
 int launch_cd(hipStream_t stream, const CdArgs<T> &a0) {
     if (a0.b <= 0 || a0.k <= 0) return MODL_OK;
     if (a0.k > 1024) return MODL_EINVAL;
-    static const int sparse_pct = getenv("MODL_CD_SPARSE_PCT") ? atoi(getenv("MODL_CD_SPARSE_PCT")) : -1;   // (tuning)
     CdArgs<T> a = a0;
+    const int sparse_pct = g_cd_sparse_pct.load(std::memory_order_relaxed);   // diagnostics: modl_debug_set
     if (sparse_pct >= 0) a.sparse_pct = sparse_pct;
     dim3 grid((unsigned)cdiv(a.b, 4)), block(256);
     if (a.k <= 64) launch_cd_kpl<T, 1>(stream, a, grid, block);
@@ -590,3 +593,11 @@ template int launch_row_norm2<float>(hipStream_t, const float *, int64_t, int64_
 template int launch_row_norm2<double>(hipStream_t, const double *, int64_t, int64_t, int64_t, double *);
 
 }  // namespace modl
+
+extern "C" int modl_debug_set(int what, int64_t value) {
+    if (what == MODL_DEBUG_CD_SPARSE_PCT) {
+        modl::g_cd_sparse_pct.store((int)value, std::memory_order_relaxed);
+        return MODL_OK;
+    }
+    return MODL_EINVAL;
+}

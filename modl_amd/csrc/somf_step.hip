@@ -12,8 +12,11 @@
 //   Bt [p][k]  surrogate statistic B_.T, same layout;
 //   C  [k][k]  surrogate statistic C_ (bitwise symmetric by construction);
 //   code [n][k], G_ [k][k], Dx_average_ [n][k], G_average_ [n][k][k] as in the reference.
-// A step is two phases so that several GPUs can all-reduce the statistics
-// increment [code^T code | X^T code] between them (RCCL, done by the caller).
+// With several GPUs a step is two phases: every rank keeps its own PARTIAL statistics
+// (C_ = sum_r C_r, B_ = sum_r B_r: both recursions are linear in the increments), phase 1
+// updates them from the rank's rows and writes the head [C_r | rows of B_r of the sampled
+// features]; the caller sums the head over the ranks (RCCL) and phase 2 runs the identical
+// dictionary update on every rank from the summed head.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -51,98 +54,32 @@ template <typename T> struct EpiDxAverage {   // dict_fact.py:596-601
     }
 };
 
-// C = beta C + (wt d) / b ;  the same for Bt (dict_fact.py:559-575)
-// both statistics in one launch: blocks [0, nblk0) -> C, the rest -> Bt
-template <typename T>
-__global__ __launch_bounds__(256) void stats_apply2_kernel(T *C, int64_t n0, int nblk0, T *Bt, int64_t n1, const T *delta,
-                                                           int64_t gap, T beta, T wt, T bdiv, int replace) {
-    T *dst;
-    const T *src;
-    int64_t n, e, stride;
-    if ((int)blockIdx.x < nblk0) {
-        dst = C; src = delta; n = n0;
-        e = (int64_t)blockIdx.x * 256 + threadIdx.x; stride = (int64_t)nblk0 * 256;
-    } else {
-        dst = Bt; src = delta + n0 + gap; n = n1;        // gap: the compact sampled-row block of the split protocol
-        e = (int64_t)((int)blockIdx.x - nblk0) * 256 + threadIdx.x; stride = (int64_t)((int)gridDim.x - nblk0) * 256;
-    }
-    for (; e < n; e += stride) {
-        const T d = src[e];
-        if (replace) dst[e] = d / bdiv;
-        else dst[e] = dst[e] * beta + (wt * d) / bdiv;
-    }
-}
-
-// the same update as a GEMM epilogue (single-GPU step: the increments never travel through HBM)
+// C <- (1 - w) C + (w / b) v ; the same for Bt (dict_fact.py:559-575) as a GEMM epilogue: the increments never
+// travel through HBM.  `mirror` (two-phase step): the updated value is also written to the head buffer.
 template <typename T> struct EpiStats {
     static constexpr bool rmw = true;
-    T *out; int64_t ld; T beta, wt, bdiv; int replace;
+    T *out; int64_t ld; T beta, wt, bdiv; int replace; T *mirror;
     __device__ __forceinline__ T load(int64_t m, int64_t n) const { return out[m * ld + n]; }   // unconditional
     __device__ __forceinline__ void store(int64_t m, int64_t n, T v, T old) const {
-        out[m * ld + n] = replace ? v / bdiv : old * beta + (wt * v) / bdiv;
+        const T nv = replace ? v / bdiv : old * beta + (wt * v) / bdiv;
+        out[m * ld + n] = nv;
+        if (mirror) mirror[m * ld + n] = nv;
     }
     __device__ __forceinline__ void operator()(int64_t m, int64_t n, T v) const { store(m, n, v, load(m, n)); }
 };
 
-// ... for the sampled rows only: product row m is feature rows[m]
+// ... for the sampled rows only: product row m is feature rows[m]; the mirror is compact (row m)
 template <typename T> struct EpiStatsRows {
     static constexpr bool rmw = true;
-    T *out; int64_t ld; const int32_t *rows; T beta, wt, bdiv; int replace;
+    T *out; int64_t ld; const int32_t *rows; T beta, wt, bdiv; int replace; T *mirror;
     __device__ __forceinline__ T load(int64_t m, int64_t n) const { return out[(int64_t)rows[m] * ld + n]; }
     __device__ __forceinline__ void store(int64_t m, int64_t n, T v, T old) const {
-        out[(int64_t)rows[m] * ld + n] = replace ? v / bdiv : old * beta + (wt * v) / bdiv;
+        const T nv = replace ? v / bdiv : old * beta + (wt * v) / bdiv;
+        out[(int64_t)rows[m] * ld + n] = nv;
+        if (mirror) mirror[m * ld + n] = nv;
     }
     __device__ __forceinline__ void operator()(int64_t m, int64_t n, T v) const { store(m, n, v, load(m, n)); }
 };
-
-// Two-phase (multi-GPU) protocol with a sampled subset: the B increment is also written, for the sampled
-// features only, into a compact block right behind the C increment, so that what the dictionary update needs
-// can be all-reduced first and the bulk of the B increment can be summed UNDER the dictionary update.
-// stamp[f] == step marks the features sampled in this minibatch, pos[f] their index in the subset.
-template <typename T> struct EpiStoreSplit {
-    T *out; int64_t ld; const int32_t *stamp; const int32_t *pos; int32_t step; T *compact;
-    __device__ __forceinline__ void operator()(int64_t m, int64_t n, T v) const {
-        out[m * ld + n] = v;
-        if (stamp[m] == step) compact[(int64_t)pos[m] * ld + n] = v;
-    }
-};
-// C and the SAMPLED rows of Bt from the head of the increment buffer: blocks [0, nblk0) -> C, block nblk0 + i
-// -> feature subset[i]
-template <typename T>
-__global__ __launch_bounds__(256) void stats_apply_head_kernel(T *C, int64_t n0, int nblk0, T *Bt, const int32_t *subset,
-                                                               int k, const T *delta, T beta, T wt, T bdiv, int replace) {
-    if ((int)blockIdx.x < nblk0) {
-        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n0; e += (int64_t)nblk0 * 256) {
-            const T d = delta[e];
-            if (replace) C[e] = d / bdiv;
-            else C[e] = C[e] * beta + (wt * d) / bdiv;
-        }
-    } else {
-        const int i = (int)blockIdx.x - nblk0;
-        T *dst = Bt + (int64_t)subset[i] * k;
-        const T *src = delta + n0 + (int64_t)i * k;
-        for (int c = threadIdx.x; c < k; c += 256) {
-            const T d = src[c];
-            if (replace) dst[c] = d / bdiv;
-            else dst[c] = dst[c] * beta + (wt * d) / bdiv;
-        }
-    }
-}
-// every row of Bt that was NOT sampled in minibatch `step`
-template <typename T>
-__global__ __launch_bounds__(256) void stats_apply_rest_kernel(T *Bt, const T *dB, const int32_t *stamp, int32_t step,
-                                                               int64_t p, int k, T beta, T wt, T bdiv, int replace) {
-    for (int64_t f = blockIdx.x; f < p; f += gridDim.x) {
-        if (stamp[f] == step) continue;
-        T *dst = Bt + f * k;
-        const T *src = dB + f * k;
-        for (int c = threadIdx.x; c < k; c += 256) {
-            const T d = src[c];
-            if (replace) dst[c] = d / bdiv;
-            else dst[c] = dst[c] * beta + (wt * d) / bdiv;
-        }
-    }
-}
 
 // Everything the code step gathers, in ONE launch: squared row norms of the minibatch, the sampled
 // dictionary rows Ds = Dt[subset], the sampled minibatch columns Xs = X[:, subset], the minibatch's code rows.
@@ -226,6 +163,7 @@ using namespace modl;
 
 struct modl_somf_plan {
     modl_somf_desc d;
+    int device = 0;                    // the HIP device the plan was created on: every entry point makes it current
     size_t tsz;
     // device arena
     char *dws = nullptr;
@@ -248,18 +186,13 @@ struct modl_somf_plan {
     std::vector<int64_t> h_order_copy;
     // profiling
     bool prof = false;
-    bool stats_fused = false;          // the last phase 1 applied the statistics in its epilogues
-    bool split_now = false;            // the last phase 1 wrote the compact sampled-row block (two-phase protocol)
-    bool rest_pending = false;         // phase 2 left the non-sampled rows of Bt to modl_somf_apply_rest
-    bool bulk_pending = false;         // phase 1 wrote only the head of the increment (C + sampled rows of B): the
-                                       // p x k product is left to modl_somf_bulk_partials (runs under the head's all-reduce)
-    const void *bulk_cb = nullptr;     // the minibatch's code rows (compact) for that product
+    bool head_pending = false;         // the last phase 1 was the two-phase one: phase 2 reads C and the sampled rows
+                                       // of B from the (summed) head instead of the rank's partial statistics
+    int64_t head_elems = 0;            // k*k + (rows of B in the head) * k
+    void *Bsum = nullptr;              // [p][k] (lazily allocated): the summed rows of B_, scattered for the dictionary update
     bool ride_pending = false;         // single-GPU step: the B_ update of the rows that were not sampled rides along
     StatsRider rider{};                // the dictionary update (see StatsRider)
-    double rest_beta = 0, rest_wt = 0, rest_bdiv = 1;
-    int rest_replace = 0;
     int32_t step_id = 0;
-    int64_t last_s_phase1 = 0;
     size_t off_stamp = 0, off_pos = 0, off_gstamps = 0;
     unsigned prof_mask = ~0u;          // sections that record events
     std::vector<hipEvent_t> pev;       // 2 * kProfPool events
@@ -470,14 +403,17 @@ int stats_pair(hipStream_t st, const DenseOperand &A0, const DenseOperand &B0, i
     return launch_gemm_dense<T, Epi1>(st, A1, B1, M1, N1, K, e1, sws, launches);
 }
 
-// fuse_stats: apply the statistics update in the epilogue of the increment products (single-GPU step)
+// Codes of the minibatch, then the statistics update C <- (1 - w) C + (w / b_global) code^T code (the same for B_)
+// in the epilogues of the increment products.  two_phase: the updated C and the updated rows of B_ that the
+// dictionary update will read are also written to the head buffer `delta` = [C (k*k) | rows of Bt (compact)].
 template <typename T>
 int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch *bt, T *delta, hipStream_t st,
-           bool fuse_stats = false) {
+           bool two_phase) {
     const modl_somf_desc &d = pl->d;
     const int k = d.k, b = bt->b;
     const int64_t p = d.p, s = bt->s;
-    if (!stt || !stt->d_Dt || !stt->d_code || !delta) return MODL_EINVAL;
+    if (!stt || !stt->d_Dt || !stt->d_code || (two_phase && !delta)) return MODL_EINVAL;
+    if (!stt->d_Bt || !stt->d_C || bt->b_global <= 0) return MODL_EINVAL;
     if (d.G_agg == MODL_AGG_FULL && !stt->d_G) return MODL_EINVAL;
     if (d.G_agg == MODL_AGG_AVERAGE && !stt->d_G_average) return MODL_EINVAL;
     if (d.Dx_agg == MODL_AGG_AVERAGE && !stt->d_Dx_average) return MODL_EINVAL;
@@ -510,9 +446,9 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
 
     T *ws_split = reinterpret_cast<T *>(sws.ptr);
     const size_t ws_elems = sws.bytes / sizeof(T);
-    bool head_first = false, ride = false;
-    pl->bulk_pending = false;
+    bool ride = false;
     pl->ride_pending = false;
+    pl->head_pending = false;
     {   // ---- Dx, G  (dict_fact.py:588-620)
         ProfScope ps(pl, st, SEC_CODE_GEMM);
         // compaction: gather once, contract dense.  Ds = Dt[subset] (whole 1 KiB feature rows),
@@ -527,26 +463,18 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         pa.s_pad = s_pad; pa.Xs = Xsb; pa.gx = (int)std::min<int64_t>(cdiv(s_pad, 256), 64);
         pa.n_cols = (need_sub && d.Dx_agg != MODL_AGG_FULL) ? pa.gx * b : 0;
         pa.code = code; pa.idx = d_idx; pa.codeb = codeb; pa.n_code = (cd_on_compact && d_idx) ? b : 0;
-        // two-phase protocol: mark the sampled features so that the B increment can be split (see EpiStoreSplit)
         const bool proper = need_sub && s > 0 && s < p;               // a proper subset, gathered
-        pl->split_now = !fuse_stats && proper;
-        // single-GPU step: only the sampled rows of B_ are needed by the dictionary update -> the rest of the B_
-        // update is deferred and rides along its launches
-        static const bool no_rider = getenv("MODL_NO_RIDER") != nullptr;   // (diagnostics)
-        ride = fuse_stats && proper && d.Dx_agg != MODL_AGG_FULL && !no_rider;
-        if (pl->split_now || ride) pl->step_id = (pl->step_id == 0x7fffffff) ? 1 : pl->step_id + 1;
-        pa.stamp = (pl->split_now || ride) ? reinterpret_cast<int32_t *>(pl->dws + pl->off_stamp) : nullptr;
+        // only the sampled rows of B_ are needed by the dictionary update -> the rest of the B_ update is deferred
+        // and rides along its launches; the sampled features are stamped so that the rider leaves them alone
+        ride = proper && d.Dx_agg != MODL_AGG_FULL && !(d.flags & MODL_FLAG_NO_RIDER);
+        if (ride) pl->step_id = (pl->step_id == 0x7fffffff) ? 1 : pl->step_id + 1;
+        pa.stamp = ride ? reinterpret_cast<int32_t *>(pl->dws + pl->off_stamp) : nullptr;
         pa.pos = reinterpret_cast<int32_t *>(pl->dws + pl->off_pos);
         pa.step = pl->step_id;
-        pl->last_s_phase1 = s;
         if (need_sub) {
             Dsrc = Dsb;
             if (d.Dx_agg != MODL_AGG_FULL) { Xsrc = Xsb; ldxs = s_pad; }
         }
-        // with the sampled columns of X gathered anyway, the head of the increment comes from its own small
-        // product and the p x k product is deferred (see modl_somf_bulk_partials); the stamps still tell
-        // modl_somf_apply_rest which rows phase 2 has already updated
-        head_first = pl->split_now && Xsrc == Xsb;
         const int n_prep = pa.n_norm + pa.n_rows + pa.n_cols + pa.n_code;
         if (n_prep > 0) {
             hipLaunchKernelGGL((prep_kernel<T>), dim3((unsigned)n_prep), dim3(256), 0, st, pa);
@@ -626,7 +554,7 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
             }
         }
     }
-    {   // ---- statistics increments: delta = [ code^T code | X^T code ], one launch for both products
+    {   // ---- statistics: C_ and B_ updated in the epilogues of code^T code and X^T code, one launch for both products
         ProfScope ps(pl, st, SEC_STATS_GEMM);
         if (!cd_on_compact && d_idx) {
             hipLaunchKernelGGL((gather_rows_T_kernel<T, int64_t>), dim3((unsigned)b), dim3(256), 0, st, code, (int64_t)k,
@@ -638,110 +566,75 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         Cd.ptr = cb; Cd.si = 1; Cd.sk = k;                              // element (i = atom, kk = sample)
         DenseOperand Xo;
         Xo.ptr = X; Xo.si = 1; Xo.sk = bt->ldx;                         // element (i = feature, kk = sample)
-        pl->stats_fused = false;
         DenseOperand Xso;
         Xso.ptr = Xsb; Xso.si = 1; Xso.sk = s_pad;                      // element (i = sampled feature, kk = sample)
-        if (fuse_stats) {
-            if (!stt->d_Bt || !stt->d_C || bt->b_global <= 0) return MODL_EINVAL;
-            const int replace = d.optimizer == MODL_OPT_SGD;
-            const T beta = (T)(1.0 - bt->w), wt = (T)bt->w, bdiv = (T)bt->b_global;
-            EpiStats<T> eC{static_cast<T *>(stt->d_C), k, beta, wt, bdiv, replace};
-            if (ride) {
-                // C_ and the SAMPLED rows of B_ now (one small paired launch over the gathered columns of X) ...
-                EpiStatsRows<T> eBs{static_cast<T *>(stt->d_Bt), k, d_subset, beta, wt, bdiv, replace};
-                static const bool gstamps = getenv("MODL_GEMM_STAMPS") != nullptr;   // (diagnostics)
-                MODL_TRY((stats_pair<T>(st, Cd, Cd, k, k, eC, Xso, Cd, s, k, eBs, b, sws, &ps.launches,
-                                        gstamps ? reinterpret_cast<unsigned long long *>(pl->dws + pl->off_gstamps) : nullptr)));
-                // ... the other rows while the dictionary update runs
-                StatsRider &R = pl->rider;
-                R.X = X; R.ldx = bt->ldx; R.code = cb; R.b = b; R.p = p; R.Bt = stt->d_Bt;
-                R.stamp = reinterpret_cast<const int32_t *>(pl->dws + pl->off_stamp); R.step = pl->step_id;
-                R.beta = (double)beta; R.wt = (double)wt; R.bdiv = (double)bdiv; R.replace = replace; R.consumed = 0;
-                pl->ride_pending = true;
-            } else {
-                EpiStats<T> eB{static_cast<T *>(stt->d_Bt), k, beta, wt, bdiv, replace};
-                MODL_TRY((stats_pair<T>(st, Cd, Cd, k, k, eC, Xo, Cd, p, k, eB, b, sws, &ps.launches)));
-            }
-            pl->stats_fused = true;
+        const int replace = d.optimizer == MODL_OPT_SGD;
+        const T beta = (T)(1.0 - bt->w), wt = (T)bt->w, bdiv = (T)bt->b_global;
+        T *Bt = static_cast<T *>(stt->d_Bt);
+        // two-phase step: the head [ C | rows of Bt the dictionary update reads, compact ] is mirrored into `delta`
+        T *mC = two_phase ? delta : nullptr, *mB = two_phase ? delta + (size_t)k * k : nullptr;
+        EpiStats<T> eC{static_cast<T *>(stt->d_C), k, beta, wt, bdiv, replace, mC};
+        if (ride) {
+            // C_ and the SAMPLED rows of B_ now (one small paired launch over the gathered columns of X) ...
+            EpiStatsRows<T> eBs{Bt, k, d_subset, beta, wt, bdiv, replace, mB};
+            const bool gstamps = (d.flags & MODL_FLAG_GEMM_STAMPS) != 0;      // (diagnostics)
+            MODL_TRY((stats_pair<T>(st, Cd, Cd, k, k, eC, Xso, Cd, s, k, eBs, b, sws, &ps.launches,
+                                    gstamps ? reinterpret_cast<unsigned long long *>(pl->dws + pl->off_gstamps) : nullptr)));
+            // ... the other rows while the dictionary update runs
+            StatsRider &R = pl->rider;
+            R.X = X; R.ldx = bt->ldx; R.code = cb; R.b = b; R.p = p; R.Bt = stt->d_Bt;
+            R.stamp = reinterpret_cast<const int32_t *>(pl->dws + pl->off_stamp); R.step = pl->step_id;
+            R.beta = (double)beta; R.wt = (double)wt; R.bdiv = (double)bdiv; R.replace = replace; R.consumed = 0;
+            pl->ride_pending = true;
         } else {
-            // layout of the increment buffer: [ dC (k*k) | dB rows of the sampled features, compact (p*k slots) | dB (p*k) ]
-            T *dC = delta, *dBs = delta + (size_t)k * k, *dB = delta + (size_t)k * k + (size_t)p * k;
-            EpiStore<T> epiC{dC, k, (T)1};
-            if (head_first) {
-                // head only: [ dC | dB rows of the sampled features ] = [ code^T code | Xs^T code ]
-                EpiStore<T> epiBs{dBs, k, (T)1};
-                MODL_TRY((stats_pair<T>(st, Cd, Cd, k, k, epiC, Xso, Cd, s, k, epiBs, b, sws, &ps.launches)));
-                pl->bulk_pending = true;
-                pl->bulk_cb = cb;
-            } else if (pl->split_now) {
-                EpiStoreSplit<T> epiB{dB, k, reinterpret_cast<const int32_t *>(pl->dws + pl->off_stamp),
-                                      reinterpret_cast<const int32_t *>(pl->dws + pl->off_pos), pl->step_id, dBs};
-                MODL_TRY((stats_pair<T>(st, Cd, Cd, k, k, epiC, Xo, Cd, p, k, epiB, b, sws, &ps.launches)));
-            } else {
-                EpiStore<T> epiB{dB, k, (T)1};
-                MODL_TRY((stats_pair<T>(st, Cd, Cd, k, k, epiC, Xo, Cd, p, k, epiB, b, sws, &ps.launches)));
+            // every row of B_ in this launch; without a subset array the head carries all of them
+            EpiStats<T> eB{Bt, k, beta, wt, bdiv, replace, d_subset ? nullptr : mB};
+            MODL_TRY((stats_pair<T>(st, Cd, Cd, k, k, eC, Xo, Cd, p, k, eB, b, sws, &ps.launches)));
+            if (two_phase && d_subset && s > 0) {
+                hipLaunchKernelGGL((gather_rows_T_kernel<T, int32_t>), dim3((unsigned)s), dim3(256), 0, st, Bt, (int64_t)k,
+                                   d_subset, s, s, (int64_t)k, mB, (int64_t)k);
+                MODL_LAUNCH_CHECK();
+                ++ps.launches;
             }
+        }
+        if (two_phase) {
+            pl->head_pending = true;
+            pl->head_elems = (int64_t)k * k + (d_subset ? s : p) * (int64_t)k;
         }
     }
     return MODL_OK;
 }
 
-// The p x k product X^T code of the two-phase protocol, deferred so that it runs while the head of the increment
-// is being all-reduced.
+// The dictionary update (dict_fact.py:650-715).  After a two-phase phase 1, `head` = [ C | rows of B_ ] summed over
+// the ranks: C is read from it, the rows of B_ are scattered into a plan-owned [p][k] array (the rank's own B_ keeps
+// its partial sums) - without a subset array the head IS that array.
 template <typename T>
-int bulk_partials_impl(modl_somf_plan *pl, const modl_somf_batch *bt, T *delta, hipStream_t st) {
-    if (!pl->bulk_pending) return MODL_OK;
-    if (!bt || !bt->d_X || !delta) return MODL_EINVAL;
-    const int k = pl->d.k, b = bt->b;
-    const int64_t p = pl->d.p;
-    ProfScope ps(pl, st, SEC_STATS_GEMM);
-    DenseOperand Cd;
-    Cd.ptr = static_cast<const T *>(pl->bulk_cb); Cd.si = 1; Cd.sk = k;
-    DenseOperand Xo;
-    Xo.ptr = static_cast<const T *>(bt->d_X); Xo.si = 1; Xo.sk = bt->ldx;
-    T *dB = delta + (size_t)k * k + (size_t)p * k;
-    EpiStore<T> epiB{dB, k, (T)1};
-    SplitWs sws{pl->dws + pl->off_split, pl->split_bytes};
-    MODL_TRY((stats_pair<T>(st, Cd, Cd, 0, 0, epiB, Xo, Cd, p, k, epiB, b, sws, &ps.launches)));
-    pl->bulk_pending = false;
-    return MODL_OK;
-}
-
-template <typename T>
-int phase2(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch *bt, const T *delta, hipStream_t st) {
+int phase2(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch *bt, const T *head, hipStream_t st) {
     const modl_somf_desc &d = pl->d;
     const int k = d.k;
     const int64_t p = d.p, s = bt->s;
     if (!pl->staged) return MODL_ESTATE;
-    if (!stt || !stt->d_Dt || !stt->d_Bt || !stt->d_C || !stt->d_comp_norm || !delta) return MODL_EINVAL;
-    if (bt->b_global <= 0) return MODL_EINVAL;
+    if (!stt || !stt->d_Dt || !stt->d_Bt || !stt->d_C || !stt->d_comp_norm) return MODL_EINVAL;
+    if (pl->head_pending && !head) return MODL_EINVAL;
     char *P = pl->dws + pl->off_params;
     const int32_t *d_subset = pl->has_subset ? reinterpret_cast<const int32_t *>(P + pl->po_subset) : nullptr;
     const int32_t *d_order = reinterpret_cast<const int32_t *>(P + pl->po_order);
     T *Dt = static_cast<T *>(stt->d_Dt);
     T *Bt = static_cast<T *>(stt->d_Bt);
-    T *Cm = static_cast<T *>(stt->d_C);
-    {
+    const T *Bu = Bt, *Cu = static_cast<const T *>(stt->d_C);
+    if (pl->head_pending) {
         ProfScope ps(pl, st, SEC_STATS_APPLY);
-        const int replace = d.optimizer == MODL_OPT_SGD;
-        const T beta = (T)(1.0 - bt->w), wt = (T)bt->w, bdiv = (T)bt->b_global;
-        if (!pl->stats_fused) {
-            const int nb0 = (int)std::min<int64_t>(cdiv((int64_t)k * k, 256), 256);
-            if (pl->split_now) {     // C and the sampled rows of Bt now; the rest in modl_somf_apply_rest
-                hipLaunchKernelGGL((stats_apply_head_kernel<T>), dim3((unsigned)(nb0 + s)), dim3(256), 0, st, Cm, (int64_t)k * k,
-                                   nb0, Bt, d_subset, k, delta, beta, wt, bdiv, replace);
-                MODL_LAUNCH_CHECK();
-                pl->rest_pending = true;
-                pl->rest_beta = (double)beta; pl->rest_wt = (double)wt; pl->rest_bdiv = (double)bdiv; pl->rest_replace = replace;
-            } else {
-                const int nb1 = (int)std::min<int64_t>(cdiv(p * k, 256), 2048);
-                hipLaunchKernelGGL((stats_apply2_kernel<T>), dim3((unsigned)(nb0 + nb1)), dim3(256), 0, st, Cm, (int64_t)k * k, nb0,
-                                   Bt, p * k, delta, (int64_t)p * k, beta, wt, bdiv, replace);
-                MODL_LAUNCH_CHECK();
-            }
+        Cu = head;
+        Bu = head + (size_t)k * k;
+        if (d_subset && s > 0) {
+            if (!pl->Bsum) MODL_HIP(hipMalloc(&pl->Bsum, pl->tsz * (size_t)p * k));
+            hipLaunchKernelGGL((scatter_rows_T_kernel<T, int32_t>), dim3((unsigned)s), dim3(256), 0, st,
+                               static_cast<T *>(pl->Bsum), (int64_t)k, d_subset, s, (int64_t)k, head + (size_t)k * k, (int64_t)k);
+            MODL_LAUNCH_CHECK();
             ps.launches += 1;
+            Bu = static_cast<const T *>(pl->Bsum);
         }
-        pl->stats_fused = false;
+        pl->head_pending = false;
     }
     {
         ProfScope ps(pl, st, SEC_DICT);
@@ -753,7 +646,7 @@ int phase2(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         }
         pl->last_s = s;
         DictUpdateArgs<T> a;
-        a.Dt = Dt; a.Bt = Bt; a.C = Cm; a.comp_norm = static_cast<T *>(stt->d_comp_norm);
+        a.Dt = Dt; a.Bt = Bu; a.C = Cu; a.comp_norm = static_cast<T *>(stt->d_comp_norm);
         a.subset = d_subset; a.order = d_order; a.h_order = pl->h_order_copy.data();
         a.s = s; a.k = k; a.optimizer = d.optimizer; a.comp_pos = d.comp_pos;
         a.comp_l1_ratio = d.comp_l1_ratio; a.w = bt->w; a.step_size = d.step_size;
@@ -862,21 +755,6 @@ int enet_regression_abi(const T *G, int64_t g_stride, T *Dx, const T *X, int64_t
 
 }  // namespace
 
-template <typename T>
-static int apply_rest_impl(modl_somf_plan *pl, const modl_somf_state *stt, const T *delta, hipStream_t st) {
-    if (!pl->rest_pending) return MODL_OK;
-    if (!stt || !stt->d_Bt || !delta) return MODL_EINVAL;
-    const int k = pl->d.k;
-    const int64_t p = pl->d.p;
-    hipLaunchKernelGGL((stats_apply_rest_kernel<T>), dim3((unsigned)std::min<int64_t>(p, 4096)), dim3(256), 0, st,
-                       static_cast<T *>(stt->d_Bt), delta + (size_t)k * k + (size_t)p * k,
-                       reinterpret_cast<const int32_t *>(pl->dws + pl->off_stamp), pl->step_id, p, k, (T)pl->rest_beta,
-                       (T)pl->rest_wt, (T)pl->rest_bdiv, pl->rest_replace);
-    MODL_LAUNCH_CHECK();
-    pl->rest_pending = false;
-    return MODL_OK;
-}
-
 extern "C" {
 
 int modl_device_count(void) {
@@ -913,7 +791,7 @@ ABI_REG(f64, double)
 
 int64_t modl_somf_delta_elems(const modl_somf_desc *desc) {
     if (!desc) return 0;
-    return (int64_t)desc->k * desc->k + 2 * desc->p * (int64_t)desc->k;     // [dC | dB sampled rows, compact | dB]
+    return (int64_t)desc->k * desc->k + desc->p * (int64_t)desc->k;         // [C | rows of Bt, compact]
 }
 
 int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
@@ -924,6 +802,7 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     modl_somf_plan *pl = new (std::nothrow) modl_somf_plan();
     if (!pl) return MODL_ENOMEM;
     pl->d = *desc;
+    (void)hipGetDevice(&pl->device);
     pl->tsz = desc->dtype == MODL_F32 ? 4 : 8;
     const size_t t = pl->tsz;
     const size_t k = (size_t)desc->k, b = (size_t)desc->max_batch, p = (size_t)desc->p;
@@ -972,6 +851,7 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
 void modl_somf_plan_destroy(modl_somf_plan *pl) {
     if (!pl) return;
     if (pl->dws) (void)hipFree(pl->dws);
+    if (pl->Bsum) (void)hipFree(pl->Bsum);
     for (int i = 0; i < kStageSlots; ++i) {
         if (pl->hstage[i]) (void)hipHostFree(pl->hstage[i]);
         if (pl->hev[i]) (void)hipEventDestroy(pl->hev[i]);
@@ -994,55 +874,52 @@ int modl_somf_plan_update(modl_somf_plan *pl, const modl_somf_desc *desc) {
 
 #define DISPATCH(pl, CALLF, CALLD) ((pl)->d.dtype == MODL_F32 ? (CALLF) : (CALLD))
 
-int modl_somf_code_and_partials(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt, void *d_delta,
+// makes the plan's device current for the duration of an entry point (a caller may hold several estimators on
+// several devices; launching into another device's stream fails with "invalid resource handle")
+struct DeviceScope {
+    int prev = -1;
+    explicit DeviceScope(const modl_somf_plan *pl) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != pl->device && hipSetDevice(pl->device) == hipSuccess) prev = cur;
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int modl_somf_code_and_partials(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt, void *d_head,
                                 void *stream) {
     if (!pl || !bt) return MODL_EINVAL;
-    return DISPATCH(pl, phase1<float>(pl, st, bt, static_cast<float *>(d_delta), (hipStream_t)stream),
-                    phase1<double>(pl, st, bt, static_cast<double *>(d_delta), (hipStream_t)stream));
+    DeviceScope dev(pl);
+    return DISPATCH(pl, phase1<float>(pl, st, bt, static_cast<float *>(d_head), (hipStream_t)stream, true),
+                    phase1<double>(pl, st, bt, static_cast<double *>(d_head), (hipStream_t)stream, true));
 }
 
-int modl_somf_apply_and_update_dict(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt,
-                                    const void *d_delta, void *stream) {
-    if (!pl || !bt) return MODL_EINVAL;
-    return DISPATCH(pl, phase2<float>(pl, st, bt, static_cast<const float *>(d_delta), (hipStream_t)stream),
-                    phase2<double>(pl, st, bt, static_cast<const double *>(d_delta), (hipStream_t)stream));
-}
-
-int modl_somf_bulk_partials(modl_somf_plan *pl, const modl_somf_batch *bt, void *d_delta, void *stream) {
-    if (!pl) return MODL_EINVAL;
-    return DISPATCH(pl, bulk_partials_impl<float>(pl, bt, static_cast<float *>(d_delta), (hipStream_t)stream),
-                    bulk_partials_impl<double>(pl, bt, static_cast<double *>(d_delta), (hipStream_t)stream));
-}
-
-int modl_somf_apply_rest(modl_somf_plan *pl, const modl_somf_state *st, const void *d_delta, void *stream) {
-    if (!pl) return MODL_EINVAL;
-    if (pl->bulk_pending) return MODL_ESTATE;                           // the bulk of the increment was never computed
-    return DISPATCH(pl, apply_rest_impl<float>(pl, st, static_cast<const float *>(d_delta), (hipStream_t)stream),
-                    apply_rest_impl<double>(pl, st, static_cast<const double *>(d_delta), (hipStream_t)stream));
-}
-
-int modl_somf_delta_split(const modl_somf_plan *pl, int64_t *head_elems, int64_t *tail_offset, int64_t *tail_elems,
-                          int *tail_before_phase2) {
-    if (!pl || !head_elems || !tail_offset || !tail_elems || !tail_before_phase2) return MODL_EINVAL;
-    const int64_t k = pl->d.k, p = pl->d.p;
-    *head_elems = k * k + (pl->split_now ? pl->last_s_phase1 * k : 0);
-    *tail_offset = k * k + p * k;
-    *tail_elems = p * k;
-    *tail_before_phase2 = pl->split_now ? 0 : 1;
+int modl_somf_head_elems(const modl_somf_plan *pl, int64_t *head_elems) {
+    if (!pl || !head_elems) return MODL_EINVAL;
+    if (!pl->head_pending) return MODL_ESTATE;
+    *head_elems = pl->head_elems;
     return MODL_OK;
 }
 
-int modl_somf_step(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt, void *d_delta,
-                   void *stream) {
-    // single-GPU step: the statistics update rides in the epilogues of the increment products
+int modl_somf_apply_and_update_dict(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt,
+                                    const void *d_head, void *stream) {
     if (!pl || !bt) return MODL_EINVAL;
-    MODL_TRY(DISPATCH(pl, phase1<float>(pl, st, bt, static_cast<float *>(d_delta), (hipStream_t)stream, true),
-                      phase1<double>(pl, st, bt, static_cast<double *>(d_delta), (hipStream_t)stream, true)));
-    return modl_somf_apply_and_update_dict(pl, st, bt, d_delta, stream);
+    DeviceScope dev(pl);
+    return DISPATCH(pl, phase2<float>(pl, st, bt, static_cast<const float *>(d_head), (hipStream_t)stream),
+                    phase2<double>(pl, st, bt, static_cast<const double *>(d_head), (hipStream_t)stream));
+}
+
+int modl_somf_step(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt, void *stream) {
+    // one GPU: both phases back to back, nothing travels through a head buffer
+    if (!pl || !bt) return MODL_EINVAL;
+    DeviceScope dev(pl);
+    MODL_TRY(DISPATCH(pl, phase1<float>(pl, st, bt, nullptr, (hipStream_t)stream, false),
+                      phase1<double>(pl, st, bt, nullptr, (hipStream_t)stream, false)));
+    return modl_somf_apply_and_update_dict(pl, st, bt, nullptr, stream);
 }
 
 int modl_somf_full_gram(modl_somf_plan *pl, const void *d_Dt, void *d_G, void *stream) {
     if (!pl || !d_Dt || !d_G) return MODL_EINVAL;
+    DeviceScope dev(pl);
     int nl = 0;
     if (pl->d.dtype == MODL_F32) {
         EpiStore<float> epi{static_cast<float *>(d_G), pl->d.k, 1.0f};
@@ -1058,6 +935,7 @@ int modl_somf_transform(modl_somf_plan *pl, const void *d_Dt, const void *d_G, c
                         void *d_code_out, void *stream) {
     if (!pl || !d_Dt || !d_X || !d_code_out || n < 0 || ldx < pl->d.p) return MODL_EINVAL;
     if (n == 0) return MODL_OK;
+    DeviceScope dev(pl);
     return DISPATCH(pl,
                     transform_impl<float>(pl, static_cast<const float *>(d_Dt), static_cast<const float *>(d_G),
                                           static_cast<const float *>(d_X), ldx, n, static_cast<float *>(d_code_out),

@@ -51,7 +51,8 @@ class HipBackend:
     def __init__(self, device=None):
         self.device = torch.device(device) if device is not None else default_device()
         self.plan = None
-        self.delta = None
+        self.head = None
+        self.flags = 0            # modl_somf_desc.flags (diagnostics)
 
     # -- allocation ---------------------------------------------------------
     def allocate(self, desc_kwargs, n_samples, p, k, dtype):
@@ -66,7 +67,7 @@ class HipBackend:
         self.Dx_average = z(n_samples, k) if desc_kwargs['Dx_agg'] == 'average' else None
         self.G_average = z(n_samples, k, k) if desc_kwargs['G_agg'] == 'average' else None
         self._make_plan(desc_kwargs)
-        self.delta = torch.zeros(k * k + 2 * p * k, dtype=td, device=dev)   # [dC | dB sampled rows, compact | dB]
+        self.head = None          # [C | rows of Bt, compact]: allocated by the first two-phase (multi-GPU) step
 
     def _desc(self, kw):
         d = SomfDesc()
@@ -77,6 +78,7 @@ class HipBackend:
         d.code_alpha, d.code_l1_ratio = float(kw['code_alpha']), float(kw['code_l1_ratio'])
         d.comp_l1_ratio, d.tol, d.step_size = float(kw['comp_l1_ratio']), float(kw['tol']), float(kw['step_size'])
         d.max_batch = int(kw['max_batch'])
+        d.flags = int(getattr(self, 'flags', 0))
         return d
 
     def _make_plan(self, kw):
@@ -134,6 +136,9 @@ class HipBackend:
 
     def get_dictionary(self):
         return transpose_to(self.Dt, self.p, self.k).cpu().numpy()
+
+    def broadcast_dictionary(self, dist):
+        dist.broadcast(self.Dt, src=0)
 
     def set_B(self, B):
         self.Bt = transpose_to(to_device(B, self.device, dtype=self.dtype), self.k, self.p)
@@ -221,40 +226,30 @@ class HipBackend:
         return bt, keep
 
     def phase1(self, Xh, batch, idx, subset, order, w_sample, w, reduction, b_global):
+        """Several GPUs, per rank: codes, update of the rank's partial statistics; returns the head
+        [C_r | rows of B_r of the sampled features] that the caller sums over the ranks."""
         bt, keep = self._batch(Xh, batch, idx, subset, order, w_sample, w, reduction, b_global)
         st = self._state()
-        check(lib.modl_somf_code_and_partials(self.plan, C.byref(st), C.byref(bt), ptr(self.delta),
+        if self.head is None:
+            self.head = torch.zeros(self.k * self.k + self.p * self.k, dtype=torch_dtype(self.dtype), device=self.device)
+        check(lib.modl_somf_code_and_partials(self.plan, C.byref(st), C.byref(bt), ptr(self.head),
                                               stream_ptr(self.device)), 'modl_somf_code_and_partials')
         self._pending = (bt, keep)
-        return self.delta
+        n = C.c_int64()
+        check(lib.modl_somf_head_elems(self.plan, C.byref(n)), 'modl_somf_head_elems')
+        return self.head[:n.value]
 
     def step(self, Xh, batch, idx, subset, order, w_sample, w, reduction, b_global):
-        """Both phases in one call (single GPU): the statistics update rides in the GEMM epilogues."""
+        """The whole minibatch in one call (single GPU): the statistics update rides in the GEMM epilogues."""
         bt, keep = self._batch(Xh, batch, idx, subset, order, w_sample, w, reduction, b_global)
         st = self._state()
-        check(lib.modl_somf_step(self.plan, C.byref(st), C.byref(bt), ptr(self.delta), stream_ptr(self.device)),
-              'modl_somf_step')
+        check(lib.modl_somf_step(self.plan, C.byref(st), C.byref(bt), stream_ptr(self.device)), 'modl_somf_step')
 
-    def delta_split(self):
-        """(head_elems, tail_offset, tail_elems, tail_before_phase2) of the increments of the last phase 1."""
-        h, o, n, f = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
-        check(lib.modl_somf_delta_split(self.plan, C.byref(h), C.byref(o), C.byref(n), C.byref(f)), 'modl_somf_delta_split')
-        return h.value, o.value, n.value, bool(f.value)
-
-    def bulk_partials(self, delta):
-        """The p x k product the last phase 1 deferred (no-op otherwise); runs under the head's all-reduce."""
-        bt, keep = self._pending
-        check(lib.modl_somf_bulk_partials(self.plan, C.byref(bt), ptr(delta), stream_ptr(self.device)),
-              'modl_somf_bulk_partials')
-
-    def apply_rest(self, delta):
-        st = self._state()
-        check(lib.modl_somf_apply_rest(self.plan, C.byref(st), ptr(delta), stream_ptr(self.device)), 'modl_somf_apply_rest')
-
-    def phase2(self, delta):
+    def phase2(self, head):
+        """The dictionary update from the summed head (identical on every rank)."""
         bt, keep = self._pending
         st = self._state()
-        check(lib.modl_somf_apply_and_update_dict(self.plan, C.byref(st), C.byref(bt), ptr(delta),
+        check(lib.modl_somf_apply_and_update_dict(self.plan, C.byref(st), C.byref(bt), ptr(self.head),
                                                   stream_ptr(self.device)), 'modl_somf_apply_and_update_dict')
         self._pending = None
 
@@ -377,7 +372,28 @@ class CodingMixin(TransformerMixin):
         return float((sq_res / 2 + regul) / Xh.shape[0])
 
 
-def _state_property(name, getter=None, setter=None):
+def _dist():
+    """torch.distributed when a process group with more than one rank is up, else None"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
+
+
+def _sum_over_ranks(arr, device):
+    """Several GPUs: C_ and B_ are kept as per-rank partial sums; the attribute is their sum (a collective: every
+    rank has to read it)."""
+    dist = _dist()
+    if dist is None or arr is None:
+        return arr
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    if dist.get_backend() == 'nccl':
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def _state_property(name, getter=None, setter=None, summed=False):
     def fget(self):
         be = self.__dict__.get('_backend')
         if be is None or getattr(be, 'Dt', None) is None:
@@ -385,7 +401,7 @@ def _state_property(name, getter=None, setter=None):
         val = getter(be) if getter else be.get(name)
         if val is None:
             raise AttributeError(name)
-        return val
+        return _sum_over_ranks(val, be.device) if summed else val
 
     def fset(self, value):
         be = self.__dict__.get('_backend')
@@ -428,8 +444,8 @@ class DictFact(CodingMixin, BaseEstimator):
 
     # device-resident attributes of the reference (dict_fact.py:225-249)
     components_ = _state_property('components_', lambda be: be.get_dictionary(), lambda be, v: be.set_dictionary(v))
-    B_ = _state_property('B_', lambda be: be.get_B(), lambda be, v: be.set_B(v))
-    C_ = _state_property('C')
+    B_ = _state_property('B_', lambda be: be.get_B(), lambda be, v: be.set_B(v), summed=True)
+    C_ = _state_property('C', summed=True)
     code_ = _state_property('code')
     comp_norm_ = _state_property('comp_norm')
     G_ = _state_property('G')
@@ -453,8 +469,11 @@ class DictFact(CodingMixin, BaseEstimator):
             Xh = self._backend.take_rows(Xh, permutation)
         return self
 
-    def partial_fit(self, X, sample_indices=None):
-        """dict_fact.py:313-337.  X: numpy array or device tensor (n, n_features)."""
+    def partial_fit(self, X, sample_indices=None, _sync=True):
+        """dict_fact.py:313-337.  X: numpy array or device tensor (n, n_features).
+        `_sync=False` (not part of the reference's surface) returns as soon as the minibatches are enqueued on
+        the stream, so that a streaming caller can overlap the production of its next chunk; `time_` then only
+        counts the host time."""
         X = _as_float_array(X)
         be = self._backend
         Xh = be.stage_X(X)
@@ -464,9 +483,13 @@ class DictFact(CodingMixin, BaseEstimator):
             be.update_plan(self._plan_kwargs(self.batch_size))
         t0 = time.perf_counter()
         self._cb_time = 0.0
-        for batch in gen_batches(Xh.shape[0], self.batch_size):
-            self._single_batch_fit(Xh, batch, get_sub_slice(sample_indices, batch))
-        be.synchronize()
+        batches = list(gen_batches(Xh.shape[0], self.batch_size))
+        b_global = self._global_batch_sizes(Xh.shape[0], len(batches))
+        for t, batch in enumerate(batches):
+            self._single_batch_fit(Xh, batch, get_sub_slice(sample_indices, batch),
+                                   b_global=None if b_global is None else b_global[t])
+        if _sync:
+            be.synchronize()
         self.time_ += time.perf_counter() - t0 - self._cb_time
         return self
 
@@ -532,6 +555,14 @@ class DictFact(CodingMixin, BaseEstimator):
         be.allocate(self._plan_kwargs(self.batch_size), n_samples, n_features, k, dtype)
 
         self.random_state = check_random_state(self.random_state)
+        dist = _dist()
+        if dist is not None:
+            # every rank has to draw the same feature subsets, atom orders and seeds: all of them continue rank 0's
+            # generator (with random_state=None each process would otherwise seed itself from the OS)
+            state = [self.random_state.get_state()]
+            dist.broadcast_object_list(state, src=0)
+            self.random_state = np.random.RandomState()
+            self.random_state.set_state(state[0])
         if X is None:
             D = np.empty((k, n_features), dtype=dtype)
             D[:, :] = self.random_state.randn(k, n_features)
@@ -543,6 +574,8 @@ class DictFact(CodingMixin, BaseEstimator):
             D[D <= 0] = -D[D <= 0]
         be.set_dictionary(D)
         be.scale_atoms(self.comp_l1_ratio, 1.0)
+        if dist is not None:
+            be.broadcast_dictionary(dist)                  # replicas start from rank 0's atoms, bit for bit
         self.labels_ = np.arange(n_samples)
         if self.G_agg == 'full':
             be.full_gram()
@@ -563,16 +596,30 @@ class DictFact(CodingMixin, BaseEstimator):
             self.callback(self)
 
     def _world(self):
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return dist.get_world_size()
-        return 1
+        dist = _dist()
+        return dist.get_world_size() if dist is not None else 1
 
-    def _all_reduce(self, delta, async_op=False):
+    def _all_reduce(self, head):
         import torch.distributed as dist
-        return dist.all_reduce(delta, op=dist.ReduceOp.SUM, async_op=async_op)
+        return dist.all_reduce(head, op=dist.ReduceOp.SUM)
 
-    def _single_batch_fit(self, Xh, batch, sample_indices):
+    def _global_batch_sizes(self, n_local, n_batches):
+        """Several ranks: rows of the global minibatch t = sum over the ranks of their t-th local batch (the last one
+        may be ragged).  Every rank must run the same number of minibatches - the collectives of a step would
+        otherwise wait for ever - which is checked here, once per partial_fit."""
+        dist = _dist()
+        if dist is None:
+            return None
+        counts = [None] * dist.get_world_size()
+        dist.all_gather_object(counts, int(n_local))
+        b = self.batch_size
+        nb = [int(ceil(c / b)) for c in counts]
+        if len(set(nb)) != 1:
+            raise ValueError('partial_fit: the ranks hold %s rows, i.e. %s minibatches of %d rows: every rank must '
+                             'run the same number of minibatches' % (counts, nb, b))
+        return [sum(min(b, c - t * b) for c in counts) for t in range(n_batches)]
+
+    def _single_batch_fit(self, Xh, batch, sample_indices, b_global=None):
         """One SOMF iteration (dict_fact.py:495-526)."""
         if self.verbose and self.verbose_iter_ and self.n_iter_ >= self.verbose_iter_[0]:
             tc = time.perf_counter()
@@ -584,7 +631,8 @@ class DictFact(CodingMixin, BaseEstimator):
         world = self._world()
         subset = self.feature_sampler_.yield_subset(self.reduction)
         batch_size = batch.stop - batch.start
-        b_global = batch_size * world
+        if b_global is None:
+            b_global = batch_size * world
         self.n_iter_ += b_global
         self.sample_n_iter_[sample_indices] += 1
         w_sample = None
@@ -596,32 +644,12 @@ class DictFact(CodingMixin, BaseEstimator):
         if world == 1 and hasattr(be, 'step') and not getattr(self, '_two_phase', False):
             be.step(Xh, batch, sample_indices, subset, order, w_sample, w, self.reduction, b_global)
             return
-        delta = be.phase1(Xh, batch, sample_indices, subset, order, w_sample, w, self.reduction, b_global)
-        if not hasattr(be, 'delta_split'):
-            if world > 1:
-                self._all_reduce(delta)
-            be.phase2(delta)
-            return
-        # What the dictionary update needs (C increment + sampled rows of the B increment: the HEAD, written by
-        # its own small product) is summed first, and the p x k product X^T code is computed WHILE the head is
-        # travelling; the bulk is then summed asynchronously, under the dictionary update, and applied afterwards.
-        head, toff, tn, tail_first = be.delta_split()
-        reduce = world > 1 or getattr(self, '_force_reduce', False)   # (the latter: single-rank RCCL test of this path)
-        work_head = work = None
-        if reduce:
-            if tail_first:                                   # no proper subset: phase 2 needs everything
-                self._all_reduce(delta[toff:toff + tn])
-                self._all_reduce(delta[:head])
-            else:
-                work_head = self._all_reduce(delta[:head], async_op=True)
-        be.bulk_partials(delta)
-        if work_head is not None:
-            work_head.wait()
-            work = self._all_reduce(delta[toff:toff + tn], async_op=True)
-        be.phase2(delta)
-        if work is not None:
-            work.wait()
-        be.apply_rest(delta)
+        # Several ranks: every rank keeps its own partial C_ / B_ (both recursions are linear in the increments);
+        # only what the dictionary update reads - C_ and the sampled rows of B_ - is summed over the ranks.
+        head = be.phase1(Xh, batch, sample_indices, subset, order, w_sample, w, self.reduction, b_global)
+        if world > 1 or getattr(self, '_force_reduce', False):       # (the latter: single-rank RCCL test of this path)
+            self._all_reduce(head)
+        be.phase2(head)
 
     # ---------------------------------------------------------------- pickle
     def __getstate__(self):

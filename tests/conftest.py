@@ -30,3 +30,29 @@ def oracle():
     from oracle import somf_oracle
     somf_oracle.lib()
     return somf_oracle
+
+
+def m1_rows(n, p, seed=1234, k0=256, density=0.1, noise=0.1):
+    """Twin of tests/golden/make_golden.py::m1_rows: the float32 input of the headline fixture (M1 recipe,
+    SURVEY 8d, numpy's legacy generator), regenerated instead of stored."""
+    rs = np.random.RandomState(seed)
+    Q = rs.randn(k0, p)
+    Z = rs.randn(n, k0) * (rs.rand(n, k0) < density)
+    X = Z.dot(Q) / np.sqrt(density * k0) + noise * rs.randn(n, p)
+    return np.ascontiguousarray(X.astype(np.float32))
+
+
+HEADLINE_KW = dict(n_components=256, batch_size=256, code_alpha=1.0, code_l1_ratio=1, comp_l1_ratio=0,
+                   learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0)
+
+
+def headline_observables(D, C, B, comp_norm):
+    """the aggregates tests/golden/traj_headline.npz keeps of a final state"""
+    D64 = np.asarray(D, dtype=np.float64)
+    return dict(D_rownorm2=np.sum(D64 ** 2, axis=1), D_colsum=np.sum(D64, axis=0), C_final=np.asarray(C),
+                B_head=np.asarray(B)[:, :32], comp_norm=np.asarray(comp_norm))
+
+
+def subset_checksum(subset):
+    s = np.asarray(subset).astype(np.int64)
+    return int(np.sum(s * np.arange(1, len(s) + 1)))

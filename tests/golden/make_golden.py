@@ -464,6 +464,75 @@ def gen_image():
     save('image', **out)
 
 
+def m1_rows(n, p, seed=1234, k0=256, density=0.1, noise=0.1):
+    """Rows of the M1 recipe from numpy's legacy generator, float32: the headline fixture's input is
+    regenerated by the tests from this same function (tests/conftest.py holds the twin), never stored."""
+    rs = np.random.RandomState(seed)
+    Q = rs.randn(k0, p)
+    Z = rs.randn(n, k0) * (rs.rand(n, k0) < density)
+    X = Z.dot(Q) / np.sqrt(density * k0) + noise * rs.randn(n, p)
+    return np.ascontiguousarray(X.astype(np.float32))
+
+
+def gen_headline():
+    """The metric's shape from the REAL reference: k = 256, p = 10 000, b = 256, l1 codes, l2 atoms,
+    reduction in {1, 10}, f32 and f64 (the f64 runs read the SAME float32 rows, cast), 4 minibatches through
+    prepare + partial_fit (dict_fact.py:313-337).  Heads and aggregates only: D[:, :64] after every minibatch,
+    the first 32 code rows of every minibatch, C_, B_[:, :32], the squared row norms and the column sums of the
+    final dictionary (sensitive to every entry), the subset lengths and the first 64 indices of every subset."""
+    from modl.decomposition.dict_fact import DictFact
+    n, p, k, b = 1024, 10000, 256, 256
+    X32 = m1_rows(n, p)
+    out = {}
+
+    class Recorder(DictFact):
+        def _single_batch_fit(self, X, sample_indices):
+            smp = self.feature_sampler_
+            box = {}
+
+            class Proxy:
+                def yield_subset(_, r):
+                    s_ = np.asarray(smp.yield_subset(r)).copy()
+                    box['subset'] = s_
+                    return s_
+            self.feature_sampler_ = Proxy()
+            try:
+                DictFact._single_batch_fit(self, X, sample_indices)
+            finally:
+                self.feature_sampler_ = smp
+            rec = self._rec
+            rec['subset_len'].append(len(box['subset']))
+            rec['subset_head'].append(box['subset'][:64].copy())
+            rec['subset_sum'].append(int(np.sum(box['subset'].astype(np.int64) * np.arange(1, len(box['subset']) + 1))))
+            rec['code_head'].append(self.code_[sample_indices[:32]].copy())
+            rec['D_head'].append(self.components_[:, :64].copy())
+
+    for dt, dn in ((np.float32, 'f32'), (np.float64, 'f64')):
+        X = np.ascontiguousarray(X32.astype(dt))
+        for r in (1, 10):
+            est = Recorder(n_components=k, batch_size=b, reduction=r, code_alpha=1.0, code_l1_ratio=1, comp_l1_ratio=0,
+                           learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0)
+            est._rec = dict(subset_len=[], subset_head=[], subset_sum=[], code_head=[], D_head=[])
+            est.prepare(n_samples=n, X=X)
+            est.partial_fit(X)
+            name = 'm1_r%d_%s/' % (r, dn)
+            rec = est._rec
+            out[name + 'subset_len'] = np.array(rec['subset_len'], dtype=np.int64)
+            out[name + 'subset_head'] = np.stack(rec['subset_head']).astype(np.int64)
+            out[name + 'subset_sum'] = np.array(rec['subset_sum'], dtype=np.int64)
+            out[name + 'code_head'] = np.stack(rec['code_head'])
+            out[name + 'D_head'] = np.stack(rec['D_head'])
+            D = est.components_
+            out[name + 'D_rownorm2'] = np.sum(D.astype(np.float64) ** 2, axis=1)
+            out[name + 'D_colsum'] = np.sum(D.astype(np.float64), axis=0)
+            out[name + 'C_final'] = est.C_.copy()
+            out[name + 'B_head'] = est.B_[:, :32].copy()
+            out[name + 'comp_norm'] = est.comp_norm_.copy()
+            out[name + 'n_iter'] = np.array(est.n_iter_)
+    out['shape'] = np.array([n, p, k, b])
+    save('traj_headline', **out)
+
+
 if __name__ == '__main__':
     build_reference()
     sys.path.insert(0, SCRATCH)
@@ -476,3 +545,4 @@ if __name__ == '__main__':
     gen_traj()
     gen_recsys()
     gen_image()
+    gen_headline()

@@ -100,25 +100,20 @@ class OracleBackend:
     def synchronize(self):
         pass
 
-    # the step, split like the device step
+    def broadcast_dictionary(self, dist):
+        t = torch.from_numpy(self.st.D)                      # shares memory with st.D
+        dist.broadcast(t, src=0)
+
+    # the step, split like the device step: st.C / st.B are this rank's PARTIAL statistics
     def phase1(self, Xh, batch, idx, subset, order, w_sample, w, reduction, b_global):
         X = Xh[batch]
         self.pr.reduction = reduction
         ws = w_sample if w_sample is not None else np.ones(X.shape[0], dtype=self.dtype)
-        orc.compute_code(self.st, self.pr, X, idx, ws, np.asarray(subset))
+        subset = np.asarray(subset)
+        orc.compute_code(self.st, self.pr, X, idx, ws, subset)
         code = self.st.code[idx]
-        self._pending = (np.asarray(subset), np.asarray(order), w, b_global)
-        delta = np.concatenate([code.T.dot(code).ravel(), X.T.dot(code).ravel()])      # [k*k | p*k feature-major]
-        self.delta = torch.from_numpy(delta.astype(self.dtype))
-        return self.delta
-
-    def phase2(self, delta):
-        subset, order, w, b_global = self._pending
-        d = delta.numpy()
-        k, p = self.k, self.p
-        dC = d[:k * k].reshape(k, k)
-        dB = d[k * k:].reshape(p, k).T
         st, pr = self.st, self.pr
+        dC, dB = code.T.dot(code), code.T.dot(X)
         if pr.optimizer == 'variational':                    # dict_fact.py:559-575 with the global batch size
             st.C *= 1 - w
             st.C += w * dC / b_global
@@ -127,7 +122,22 @@ class OracleBackend:
         else:
             st.C = dC / b_global
             st.B = np.ascontiguousarray(dB / b_global)
+        self._pending = (subset, np.asarray(order), w)
+        head = np.concatenate([st.C.ravel(), np.ascontiguousarray(st.B[:, subset].T).ravel()])   # [k*k | s*k feature-major]
+        self.head = torch.from_numpy(head.astype(self.dtype))
+        return self.head
+
+    def phase2(self, head):
+        subset, order, w = self._pending
+        d = head.numpy()
+        k = self.k
+        st, pr = self.st, self.pr
+        C_own, B_own = st.C, st.B
+        st.C = d[:k * k].reshape(k, k).copy()                # the summed statistics, for the dictionary update only
+        st.B = B_own.copy()
+        st.B[:, subset] = d[k * k:].reshape(len(subset), k).T
         orc.update_dict(st, pr, subset, w, order)
+        st.C, st.B = C_own, B_own
 
     def transform(self, Xh, kw, G=None, to_host=True):
         pr = orc.SomfParams(code_alpha=kw['code_alpha'], code_l1_ratio=kw['code_l1_ratio'], code_pos=kw['code_pos'],

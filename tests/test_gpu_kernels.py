@@ -105,16 +105,19 @@ def test_cd_sparse_regime_vs_oracle(fast, oracle, dt, k, b, p, alpha):
     _sparse_regime_check(fast, oracle, dt, k, b, p, alpha)
 
 
-def test_cd_always_sparse_sweeps_subprocess():
-    """The same checks with every sweep forced through the active-set path (MODL_CD_SPARSE_PCT=100 is read once per
-    process, hence the child process): dense and sparse sweeps produce the same iterates."""
-    import os, subprocess, sys
-    from .conftest import ROOT
-    env = dict(os.environ, MODL_CD_SPARSE_PCT='100')
-    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', 'tests/test_gpu_kernels.py', '-k',
-                        'test_cd_sparse_regime_vs_oracle or test_cd_vs_oracle_sweeps_and_codes or test_cd_and_ridge_golden'],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+@pytest.mark.parametrize('pct', [100, 0])
+def test_cd_forced_sweep_kind(fast, oracle, pct):
+    """The same checks with every sweep forced through the active-set path (100) or the dense path (0) -
+    modl_debug_set(MODL_DEBUG_CD_SPARSE_PCT): dense and sparse sweeps produce the same iterates."""
+    from modl_amd._lib import lib, check, DEBUG_CD_SPARSE_PCT
+    check(lib.modl_debug_set(DEBUG_CD_SPARSE_PCT, pct))
+    try:
+        for dt in (np.float32, np.float64):
+            for case in _SPARSE_CASES:
+                _sparse_regime_check(fast, oracle, dt, *case)
+        test_cd_and_ridge_golden(fast)
+    finally:
+        check(lib.modl_debug_set(DEBUG_CD_SPARSE_PCT, -1))
 
 
 @pytest.mark.parametrize('dt', [np.float32, np.float64])

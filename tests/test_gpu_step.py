@@ -68,7 +68,13 @@ def test_trajectory_small_golden(DictFact, name):
         if (name + '/G_final') in g:
             assert rel_fro(est.G_, g[name + '/G_final']) < tol
     else:
-        assert rel_fro(est.components_, g[name + '/D_final']) < 1e-3
+        # f32 end state (two epochs): float summation order is unpinned, so the yardstick is the
+        # reference's OWN f32 noise - its f32 run against its f64 run of the same case - not a flat tolerance
+        ref64 = name[:-3] + 'f64'
+        for key, val in (('D_final', est.components_), ('code_final', est.code_), ('C_final', est.C_)):
+            noise = rel_fro(g[name + '/' + key], g[ref64 + '/' + key])
+            err = rel_fro(val, g[ref64 + '/' + key])
+            assert err <= 2 * noise + 1e-5, (key, err, noise)
     assert est.n_iter_ == int(g[name + '/n_iter'])
 
 
@@ -148,6 +154,51 @@ def test_headline_shape_f32_vs_oracle(DictFact, oracle, r):
         assert err_gpu <= 1.5 * noise_ref + 1e-6, (step, err_gpu, noise_ref)
         if same.all():
             assert rel_fro(est.components_, s64.D) <= 1.5 * rel_fro(s32.D, s64.D) + 1e-6
+
+
+@pytest.mark.parametrize('r', [1, 10])
+@pytest.mark.parametrize('dn', ['f64', 'f32'])
+def test_headline_full_shape_golden_and_oracle(DictFact, oracle, dn, r):
+    """The metric's FULL shape (k = 256, p = 10 000, b = 256, l1 codes, l2 atoms), 4 minibatches, against what the
+    REAL reference produced (tests/golden/traj_headline.npz) and against the oracle run next to it: subset draws
+    bit-exact; f64 <= 1e-9 on every minibatch; f32 <= 1e-5 (the north star's bound) on EVERY minibatch for codes
+    and dictionary, with the share of samples whose sweep count equals the oracle's reported."""
+    from .conftest import m1_rows, HEADLINE_KW, headline_observables, subset_checksum
+    g = load_golden('traj_headline')
+    n, p, k, b = (int(v) for v in g['shape'])
+    dt = np.float32 if dn == 'f32' else np.float64
+    X = np.ascontiguousarray(m1_rows(n, p).astype(dt))
+    name = 'm1_r%d_%s/' % (r, dn)
+    est = DictFact(reduction=r, **HEADLINE_KW)
+    est.prepare(n_samples=n, X=X)
+    rec = Recorder(est)
+    pr = oracle.SomfParams(reduction=r, **HEADLINE_KW)
+    st = oracle.prepare(pr, n_samples=n, X=X)
+    st.sweeps = []
+    tol = 1e-9 if dn == 'f64' else 1e-5
+    agree = []
+    for t in range(n // b):
+        rows = slice(t * b, (t + 1) * b)
+        idx = np.arange(rows.start, rows.stop)
+        est.partial_fit(X[rows], idx)
+        oracle.partial_fit(st, pr, X[rows], idx)
+        agree.append(float(np.mean(est._backend.last_sweeps() == st.sweeps[-1])))
+        code, D = est.code_[rows], est.components_
+        e_code, e_D = rel_fro(code[:32], g[name + 'code_head'][t]), rel_fro(D[:, :64], g[name + 'D_head'][t])
+        assert e_code < tol and e_D < tol, (t, e_code, e_D, agree)
+        assert rel_fro(code, st.code[rows]) < tol and rel_fro(D, st.D) < tol, (t, agree)      # all rows / entries
+    print('sweep agreement with the oracle per minibatch (%s, r=%d): %s' % (dn, r, agree))
+    assert min(agree) >= (1.0 if dn == 'f64' else 0.98), agree
+    assert_array_equal([len(s_) for s_ in rec.subsets], g[name + 'subset_len'])
+    assert_array_equal(np.stack([s_[:64] for s_ in rec.subsets]), g[name + 'subset_head'])
+    assert_array_equal([subset_checksum(s_) for s_ in rec.subsets], g[name + 'subset_sum'])
+    obs = headline_observables(est.components_, est.C_, est.B_, est.comp_norm_)
+    for key, val in obs.items():
+        if key == 'comp_norm':
+            assert np.allclose(val, g[name + key], atol=10 * tol)
+        else:
+            assert rel_fro(val, g[name + key]) < tol, key
+    assert est.n_iter_ == int(g[name + 'n_iter'])
 
 
 @pytest.mark.parametrize('variant', ['fmri', 'nmf', 'enet', 'sgd', 'full', 'average'])
@@ -247,8 +298,8 @@ def test_wide_dictionaries_f32_vs_oracle(DictFact, oracle, k, p, b, red):
 
 @pytest.mark.parametrize('agg', [('masked', 'masked'), ('full', 'full'), ('average', 'average')])
 def test_two_phase_equals_fused_step(DictFact, agg):
-    """modl_somf_code_and_partials + modl_somf_apply_and_update_dict (the multi-GPU split, increments through
-    `delta`) and modl_somf_step (statistics applied in the GEMM epilogues) give the same bits."""
+    """modl_somf_code_and_partials + modl_somf_apply_and_update_dict (the multi-GPU split: the dictionary update
+    reads C_ and the sampled rows of B_ from the head buffer) and modl_somf_step give the same bits."""
     rng = np.random.RandomState(3)
     X = rng.randn(300, 96).astype(np.float32)
     out = []
@@ -400,6 +451,125 @@ def test_two_rank_gpu_equals_double_batch(oracle, variant):
     assert_array_equal(out[0]['D'], out[1]['D'])               # replicas stay bit-identical
 
 
+def _gpu_rank_main_big(rank, world, port, kw, dtype_name, seeds, b, steps, p, out):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from modl_amd import DictFact as DF
+        from tests.conftest import m1_rows
+        dt = np.dtype(dtype_name)
+        X0 = m1_rows(b * steps, p, seed=seeds[0]).astype(dt)
+        X = X0 if rank == 0 else m1_rows(b * steps, p, seed=seeds[rank]).astype(dt)
+        est = DF(**kw)
+        est.prepare(n_samples=X.shape[0], X=X0)
+        est.partial_fit(X)
+        D = est.components_
+        out[rank] = dict(D_head=D[:, :128].copy(), D_sum=float(D.astype(np.float64).sum()),
+                         D_sq=float((D.astype(np.float64) ** 2).sum()), D_bytes=D.tobytes()[:1 << 16],
+                         C=est.C_, B_head=est.B_[:, :64].copy(), n_iter=est.n_iter_)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('dtype_name,r', [('float64', 10), ('float32', 10), ('float64', 1)])
+def test_two_rank_gpu_headline_shape(oracle, dtype_name, r):
+    """World size 2 at the metric's shape (k = 256, p = 10 000, 128 rows per rank, 3 minibatches): both phases through
+    the C-ABI, the head [C_r | sampled rows of B_r] summed over gloo, the rest of B_ kept as per-rank partial sums
+    (f32: riding on the dictionary update's launches).  R ranks with local batch b == one rank with batch R b on the
+    concatenated rows (f64: <= 1e-10; f32: the first minibatch... 1e-5 over all three), replicas bit-identical."""
+    import socket
+    import torch.multiprocessing as mp
+    from .conftest import m1_rows, HEADLINE_KW
+    b, steps, p = 128, 3, 10000
+    kw = dict(HEADLINE_KW, batch_size=b, reduction=r)
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    seeds = (1234, 4321)
+    mp.spawn(_gpu_rank_main_big, args=(2, port, kw, dtype_name, seeds, b, steps, p, out), nprocs=2, join=True)
+    dt = np.dtype(dtype_name)
+    X0, X1 = m1_rows(b * steps, p, seed=seeds[0]).astype(dt), m1_rows(b * steps, p, seed=seeds[1]).astype(dt)
+    Xc = np.concatenate([np.concatenate([X0[t * b:(t + 1) * b], X1[t * b:(t + 1) * b]]) for t in range(steps)])
+    pr = oracle.SomfParams(**dict(kw, batch_size=2 * b))
+    st = oracle.prepare(pr, n_samples=Xc.shape[0], X=X0)
+    oracle.partial_fit(st, pr, Xc)
+    tol = 1e-10 if dt == np.float64 else 1e-5
+    for rk in (0, 1):
+        assert rel_fro(out[rk]['D_head'], st.D[:, :128]) < tol, (rk, rel_fro(out[rk]['D_head'], st.D[:, :128]))
+        assert rel_fro(out[rk]['C'], st.C) < tol
+        assert rel_fro(out[rk]['B_head'], st.B[:, :64]) < tol
+        assert out[rk]['n_iter'] == st.n_iter
+    for key in ('D_sum', 'D_sq', 'D_bytes'):                    # replicas stay bit-identical
+        assert out[0][key] == out[1][key], key
+    assert_array_equal(out[0]['D_head'], out[1]['D_head'])
+
+
+def test_bench_two_ranks_share_gpu():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), both ranks on the
+    only GPU of the box over gloo: the JSON line must come out, with bit-identical replicas."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '12', '--warmup', '4',
+           '--share-gpu', '--backend', 'gloo', '--steady-steps', '0']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    rec = json.loads(line)
+    assert rec['n_gpus'] == 2 and rec['replicas_identical'] is True and rec['finite'] is True
+    assert rec['config']['global_batch'] == 512 and rec['value'] > 0
+
+
+def test_c5_shape_step_properties(DictFact):
+    """BASELINE config 5's per-GPU shape (p = 200 000 features, k = 256, b = 256, reduction = 12, f32) through both
+    the single-GPU step and the two-phase (multi-GPU) step: finite, only sampled columns move, atoms stay in the l2
+    ball, run-to-run identical, and the two variants agree bit for bit."""
+    import torch
+    k, p, b, n, red = 256, 200000, 256, 768, 12
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    Z = torch.randn(n, 64, device='cuda', generator=gen) * (torch.rand(n, 64, device='cuda', generator=gen) < 0.1)
+    X = (Z @ torch.randn(64, p, device='cuda', generator=gen)) / (0.1 * 64) ** 0.5 \
+        + 0.1 * torch.randn(n, p, device='cuda', generator=gen)
+    X = X.float().contiguous()
+    runs = []
+    for two_phase in (False, False, True):
+        est = DictFact(n_components=k, batch_size=b, reduction=red, code_alpha=1.0, learning_rate=0.92, random_state=0)
+        est._two_phase = two_phase
+        est.prepare(n_samples=n, X=X[:k])
+        D0 = est._backend.Dt.clone()
+        rec = Recorder(est)
+        est.partial_fit(X[:2 * b])
+        D1 = est._backend.Dt
+        touched = torch.from_numpy(np.unique(np.concatenate(rec.subsets))).cuda()
+        moved = (D1 != D0).any(dim=1)
+        assert bool(moved[touched].any()) and int(moved.sum()) <= touched.numel()      # only sampled features move
+        mask = torch.ones(p, dtype=torch.bool, device='cuda')
+        mask[touched] = False
+        assert not bool(moved[mask].any())
+        assert bool(torch.isfinite(D1).all()) and bool(torch.isfinite(est._backend.code[:2 * b]).all())
+        assert float((D1.double() ** 2).sum(dim=0).max()) <= 1 + 1e-4                  # atoms stay in the l2 ball
+        runs.append((D1.clone(), est._backend.code[:2 * b].clone(), est._backend.C.clone(), est._backend.Bt.clone()))
+        assert all(abs(len(s_) - p / red) < 6 * (p / red) ** 0.5 for s_ in rec.subsets)
+    for a, c in zip(runs[0], runs[1]):
+        assert torch.equal(a, c)                                                        # run-to-run deterministic
+    for a, c in zip(runs[0], runs[2]):
+        assert torch.equal(a, c)                                                        # two-phase == single-GPU step
+
+
 # ---- the same protocol over RCCL itself: one rank (a 1-GPU box), every all-reduce of the step really issued ------
 def _rccl_rank_main(rank, port, kw, X, out):
     import os
@@ -417,7 +587,7 @@ def _rccl_rank_main(rank, port, kw, X, out):
             est = DF(**kw)
             if name == 'rccl':
                 est._two_phase = True
-                est._force_reduce = True                         # head all-reduce + async tail all-reduce + wait
+                est._force_reduce = True                         # the head really goes through an RCCL all-reduce
             est.prepare(n_samples=X.shape[0], X=X)
             est.partial_fit(X)
             res[name] = dict(D=est.components_, C=est.C_, B=est.B_, code=est.code_)
@@ -428,10 +598,10 @@ def _rccl_rank_main(rank, port, kw, X, out):
 
 @pytest.mark.parametrize('red', [4, 1])
 def test_rccl_single_rank_two_phase_equals_fused(red):
-    """The multi-GPU step (phase 1, RCCL all-reduce of the head, asynchronous all-reduce of the bulk under the
-    dictionary update, apply_rest) on the nccl backend with one rank: summing over one rank is the identity, so the
-    result must equal the fused single-GPU step bit for bit — this checks stream ordering between the HIP
-    kernels and RCCL's own stream on a 1-GPU box."""
+    """The multi-GPU step (phase 1 with the head mirrored, RCCL all-reduce of the head, dictionary update from the
+    summed head) on the nccl backend with one rank: summing over one rank is the identity, so the result must equal
+    the single-GPU step bit for bit - this checks stream ordering between the HIP kernels and RCCL's own stream on a
+    1-GPU box."""
     import socket
     import torch.multiprocessing as mp
     rs = np.random.RandomState(11)

@@ -108,3 +108,51 @@ def test_two_rank_gloo_equals_double_batch(variant, oracle):
     codes = np.concatenate([np.concatenate([out[0]['code'][t * b:(t + 1) * b], out[1]['code'][t * b:(t + 1) * b]])
                             for t in range(steps)])
     assert rel_fro(codes, st.code) < 1e-10
+
+
+def _rank_main_unseeded(rank, world, port, kw, X_parts, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        est = _host_estimator()(**kw)
+        X = X_parts[rank]
+        est.prepare(n_samples=X.shape[0], X=X)                  # every rank offers ITS OWN rows: rank 0's atoms win
+        try:
+            est.partial_fit(X)
+            out[rank] = dict(D=est.components_, C=est.C_, B=est.B_, n_iter=est.n_iter_, err=None)
+        except ValueError as e:
+            out[rank] = dict(err=str(e))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_unseeded_ragged_replicas_identical():
+    """random_state=None (each process would seed itself from the OS), different initial rows per rank and a ragged
+    last minibatch (4 + 1 rows): prepare() makes every rank continue rank 0's generator and start from rank 0's
+    atoms, partial_fit weighs every minibatch with the true global batch size."""
+    rs = np.random.RandomState(4)
+    b, p, k = 8, 24, 4
+    X0 = rs.randn(44, 6).dot(rs.randn(6, p))
+    X1 = rs.randn(41, 6).dot(rs.randn(6, p))
+    kw = dict(n_components=k, batch_size=b, reduction=2, random_state=None, learning_rate=0.9, code_alpha=0.1)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rank_main_unseeded, args=(2, _free_port(), kw, [X0, X1], out), nprocs=2, join=True)
+    assert out[0]['err'] is None and out[1]['err'] is None
+    assert_array_equal(out[0]['D'], out[1]['D'])
+    assert_array_equal(out[0]['C'], out[1]['C'])               # the attribute is the sum over the ranks on every rank
+    assert_array_equal(out[0]['B'], out[1]['B'])
+    assert out[0]['n_iter'] == out[1]['n_iter'] == 85
+    assert np.all(np.isfinite(out[0]['D']))
+
+
+def test_two_rank_unequal_batch_counts_raise():
+    rs = np.random.RandomState(4)
+    X0, X1 = rs.randn(40, 12), rs.randn(17, 12)                 # 5 and 3 minibatches of 8 rows
+    kw = dict(n_components=3, batch_size=8, random_state=0)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rank_main_unseeded, args=(2, _free_port(), kw, [X0, X1], out), nprocs=2, join=True)
+    for r in (0, 1):
+        assert out[r]['err'] and 'same number of minibatches' in out[r]['err']

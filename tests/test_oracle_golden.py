@@ -255,3 +255,48 @@ def test_trajectory_config1(oracle):
     assert rel_fro(st.C, g['c1/C_final']) < 1e-9
     assert rel_fro(st.code[:64], g['c1/code_final_head']) < 1e-9
     assert st.n_iter == int(g['c1/n_iter'])
+
+
+@pytest.mark.parametrize('r', [1, 10])
+@pytest.mark.parametrize('dn', ['f64', 'f32'])
+def test_trajectory_headline_shape(oracle, dn, r):
+    """The metric's shape recorded from the REAL reference (k = 256, p = 10 000, b = 256, 4 minibatches,
+    tests/golden/traj_headline.npz): draws bit-exact; f64 everything <= 1e-9; f32 the first minibatch <= 1e-5 and the
+    later ones within the reference's own f32-vs-f64 distance (float summation order is unpinned)."""
+    from .conftest import m1_rows, HEADLINE_KW, headline_observables, subset_checksum
+    g = load_golden('traj_headline')
+    n, p, k, b = (int(v) for v in g['shape'])
+    dt = np.float32 if dn == 'f32' else np.float64
+    X = np.ascontiguousarray(m1_rows(n, p).astype(dt))
+    name = 'm1_r%d_%s/' % (r, dn)
+    pr = oracle.SomfParams(reduction=r, **HEADLINE_KW)
+    st = oracle.prepare(pr, n_samples=n, X=X)
+    st.trace = []
+    D_heads = []
+    for t in range(n // b):
+        oracle.partial_fit(st, pr, X[t * b:(t + 1) * b], np.arange(t * b, (t + 1) * b))
+        D_heads.append(st.D[:, :64].copy())
+    tr = st.trace
+    assert_array_equal([len(t['subset']) for t in tr], g[name + 'subset_len'])
+    assert_array_equal(np.stack([t['subset'][:64] for t in tr]), g[name + 'subset_head'])
+    assert_array_equal([subset_checksum(t['subset']) for t in tr], g[name + 'subset_sum'])
+    code_heads = np.stack([t['code'][:32] for t in tr])
+    obs = headline_observables(st.D, st.C, st.B, st.comp_norm)
+    if dn == 'f64':
+        assert rel_fro(code_heads, g[name + 'code_head']) < 1e-9
+        assert rel_fro(np.stack(D_heads), g[name + 'D_head']) < 1e-9
+        for key, val in obs.items():
+            if key == 'comp_norm':                           # leftover budgets: rounding residue around 0
+                assert np.allclose(val, g[name + key], atol=1e-9)
+            else:
+                assert rel_fro(val, g[name + key]) < 1e-9, key
+    else:
+        ref64 = 'm1_r%d_f64/' % r
+        assert rel_fro(code_heads[0], g[name + 'code_head'][0]) < 1e-5
+        assert rel_fro(D_heads[0], g[name + 'D_head'][0]) < 1e-5
+        for t in range(1, n // b):                           # within the reference's own f32 noise (+ margin)
+            noise_c = rel_fro(g[name + 'code_head'][t], g[ref64 + 'code_head'][t])
+            noise_D = rel_fro(g[name + 'D_head'][t], g[ref64 + 'D_head'][t])
+            assert rel_fro(code_heads[t], g[ref64 + 'code_head'][t]) <= 2 * noise_c + 1e-5, t
+            assert rel_fro(D_heads[t], g[ref64 + 'D_head'][t]) <= 2 * noise_D + 1e-5, t
+    assert st.n_iter == int(g[name + 'n_iter'])
