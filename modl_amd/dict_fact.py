@@ -15,6 +15,7 @@ all-reduced (RCCL over xGMI when the backend is ``nccl``) between the two
 phases; all ranks then perform the identical dictionary update.
 """
 import ctypes as C
+import os
 import time
 from math import ceil
 
@@ -53,6 +54,7 @@ class HipBackend:
         self.plan = None
         self.head = None
         self.flags = 0            # modl_somf_desc.flags (diagnostics)
+        self._pid = os.getpid()   # a forked child must never release the parent's device objects
 
     # -- allocation ---------------------------------------------------------
     def allocate(self, desc_kwargs, n_samples, p, k, dtype):
@@ -106,12 +108,18 @@ class HipBackend:
         check(lib.modl_somf_plan_update(self.plan, C.byref(d)), 'modl_somf_plan_update')
 
     def release_plan(self):
+        if getattr(self, '_pid', None) != os.getpid():
+            self.plan = None
+            return
         if getattr(self, 'plan', None):
             lib.modl_somf_plan_destroy(self.plan)
             self.plan = None
 
     def release_all(self):
         self.release_plan()
+        if getattr(self, '_pid', None) != os.getpid():
+            self.tplan = None
+            return
         if getattr(self, 'tplan', None):
             lib.modl_somf_plan_destroy(self.tplan)
             self.tplan = None

@@ -5,6 +5,7 @@ reference (`_single_sample_update`, recsys.py:168-185) runs as batched GPU
 kernels (csrc/recsys.hip), the dictionary update reuses the dense path's
 block-coordinate kernels."""
 import ctypes as C
+import os
 from math import log, ceil
 
 import numpy as np
@@ -110,13 +111,15 @@ class _RecsysDevice:
         lens = np.sort(np.diff(self.h_indptr))[::-1]
         max_entries = int(lens[:batch_size].sum())
         h = C.c_void_p()
+        self._pid = os.getpid()
         with torch.cuda.device(self.device):
             check(lib.modl_recsys_plan_create(dtype_id(self.dtype), self.p, self.k, batch_size, max_entries, C.byref(h)),
                   'modl_recsys_plan_create')
         self.plan, self.plan_batch = h, batch_size
 
     def _free_plan(self):
-        if getattr(self, 'plan', None):
+        # (a forked child - e.g. multiprocessing's helpers - must never release the parent's device objects)
+        if getattr(self, 'plan', None) and getattr(self, '_pid', os.getpid()) == os.getpid():
             lib.modl_recsys_plan_destroy(self.plan)
         self.plan, self.plan_batch = None, 0
 

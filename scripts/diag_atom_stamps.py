@@ -6,7 +6,7 @@ from modl_amd import DictFact
 from modl_amd._lib import lib, check
 dev = torch.device('cuda')
 p, n, b, k = 60000, 400, 50, 70
-X = bench.make_stream(n, p, 3, dev, k0=64)
+X = bench.M1Stream(p, 3, dev, k0=64).rows(0, n)
 est = DictFact(n_components=k, batch_size=b, reduction=12, code_alpha=1e-3, code_l1_ratio=0, comp_l1_ratio=1.0, learning_rate=0.92, random_state=0)
 est.prepare(n_samples=n, X=X[:k]); est.partial_fit(X[:200], np.arange(200))
 out = (C.c_ulonglong * 32)()

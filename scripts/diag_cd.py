@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from modl_amd import DictFact
 dev = torch.device('cuda')
-X = bench.make_stream(8192, bench.P_FEAT, 1234, dev)
+X = bench.M1Stream(bench.P_FEAT, 1234, dev).rows(0, 8192)
 for red in (10.0, 1.0):
     est = DictFact(n_components=256, batch_size=256, reduction=red, code_alpha=1.0, code_l1_ratio=1, comp_l1_ratio=0,
                    learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0)

@@ -7,7 +7,7 @@ import bench
 from modl_amd import DictFact
 dev = torch.device('cuda')
 p, n, b, k = 60000, 1000, 50, 70
-X = bench.make_stream(n, p, 3, dev, k0=64)
+X = bench.M1Stream(p, 3, dev, k0=64).rows(0, n)
 for l1 in (1.0, 0.0):
     est = DictFact(n_components=k, batch_size=b, reduction=12, code_alpha=1e-3, code_l1_ratio=0, comp_l1_ratio=l1,
                    learning_rate=0.92, random_state=0)

@@ -7,7 +7,7 @@ import bench
 from modl_amd import DictFact
 dev = torch.device('cuda')
 p, n = 200000, 2048
-X = bench.make_stream(n, p, 7, dev)
+X = bench.M1Stream(p, 7, dev).rows(0, n)
 est = DictFact(n_components=256, batch_size=256, reduction=12, code_alpha=1.0, learning_rate=0.92, random_state=0)
 est.prepare(n_samples=n, X=X[:256])
 est.partial_fit(X[:512], np.arange(512))

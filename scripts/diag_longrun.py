@@ -7,7 +7,7 @@ import bench
 from modl_amd import DictFact
 dev = torch.device('cuda')
 n = 65536
-X = bench.make_stream(n + 1024, bench.P_FEAT, 99, dev)
+X = bench.M1Stream(bench.P_FEAT, 99, dev).rows(0, n + 1024)
 Xtest = X[n:]
 est = DictFact(n_components=256, batch_size=256, reduction=10, code_alpha=1.0, learning_rate=0.92, random_state=0)
 est.prepare(n_samples=n, X=X[:256])

@@ -5,7 +5,7 @@ import bench
 from modl_amd import DictFact
 from modl_amd._lib import lib, check
 dev = torch.device('cuda')
-X = bench.make_stream(4096, 10000, 1234, dev)
+X = bench.M1Stream(10000, 1234, dev).rows(0, 4096)
 for r in (10, 1):
     est = DictFact(n_components=256, batch_size=256, reduction=r, code_alpha=1.0, learning_rate=0.92, random_state=0)
     est.prepare(n_samples=4096, X=X[:256])

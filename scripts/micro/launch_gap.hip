@@ -67,15 +67,62 @@ __global__ __launch_bounds__(320) void k_persistent(unsigned int *ticket, double
     if (threadIdx.x == 0) { cycles[blockIdx.x] = t1 - t0; if (acc == 1.2345) rec[0] = acc; }
 }
 
+// keeps the stream busy for `ticks` of the 100 MHz wall clock, so that the launches enqueued behind it are all in
+// the queue when they start: the chain is then timed on the GPU side (the host needs ~3 us per hipLaunchKernelGGL,
+// which is what a chain of EMPTY kernels measures otherwise)
+__global__ void k_blocker(unsigned long long ticks, float *buf) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (ticks == 1) buf[0] = 0;
+}
+
 static float chain_us(int n, const std::function<void(int)> &launch) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 20; ++i) launch(i);
     hipDeviceSynchronize();
+    hipLaunchKernelGGL(k_blocker, dim3(1), dim3(64), 0, 0, (unsigned long long)(n * 6 * 100 + 200000), (float *)nullptr);   // 6 us per launch + 2 ms
     hipEventRecord(e0);
     for (int i = 0; i < n; ++i) launch(i);
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     return ms * 1e3f / n;
+}
+
+// dependent-issue latency of the VALU: the same dependent chain as a loop (small code) and fully unrolled (every
+// instruction fetched once: instruction-cache / fetch bound?)
+__global__ __launch_bounds__(64) void k_chain_loop(float *buf, float x0, int n, unsigned long long *cyc) {
+    float x = x0 + threadIdx.x;
+    const unsigned long long t0 = clock64();
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+        x = __builtin_fmaf(x, 1.0001f, 0.5f); x = __builtin_fmaf(x, 0.9999f, 0.25f); x = __builtin_fmaf(x, 1.0002f, 0.125f); x = __builtin_fmaf(x, 0.9998f, 0.0625f);
+        x = __builtin_fmaf(x, 1.0001f, 0.5f); x = __builtin_fmaf(x, 0.9999f, 0.25f); x = __builtin_fmaf(x, 1.0002f, 0.125f); x = __builtin_fmaf(x, 0.9998f, 0.0625f);
+    }
+    const unsigned long long t1 = clock64();
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    if (x == 12345.678f) buf[threadIdx.x] = x;
+}
+template <int N>
+__global__ __launch_bounds__(64) void k_chain_unrolled(float *buf, float x0, unsigned long long *cyc) {
+    float x = x0 + threadIdx.x;
+    const unsigned long long t0 = clock64();
+#pragma unroll
+    for (int i = 0; i < N; ++i) x = __builtin_fmaf(x, 1.0001f + (i & 7) * 1e-6f, 0.5f);
+    const unsigned long long t1 = clock64();
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    if (x == 12345.678f) buf[threadIdx.x] = x;
+}
+__global__ __launch_bounds__(64) void k_chain_f64_loop(double *buf, double x0, int n, unsigned long long *cyc) {
+    double x = x0 + threadIdx.x;
+    const unsigned long long t0 = clock64();
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+        x = __builtin_fma(x, 1.0001, 0.5); x = __builtin_fma(x, 0.9999, 0.25); x = __builtin_fma(x, 1.0002, 0.125); x = __builtin_fma(x, 0.9998, 0.0625);
+        x = __builtin_fma(x, 1.0001, 0.5); x = __builtin_fma(x, 0.9999, 0.25); x = __builtin_fma(x, 1.0002, 0.125); x = __builtin_fma(x, 0.9998, 0.0625);
+    }
+    const unsigned long long t1 = clock64();
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    if (x == 12345.678) buf[threadIdx.x] = x;
 }
 
 #include <functional>
@@ -102,6 +149,28 @@ int main() {
         float us = chain_us(N, [&](int i) { hipLaunchKernelGGL((k_code<3000>), dim3(32), dim3(64), 0, 0, buf, 1.0f, i); });
         float us2 = chain_us(N, [&](int i) { hipLaunchKernelGGL((k_code<30>), dim3(32), dim3(64), 0, 0, buf, 1.0f, i); });
         printf("chain k_code: 6000 dependent fma straight-line (48 KB of code) %.2f us, 60 fma %.2f us per launch  (6000 fma at 2.4 GHz, 4-8 cycles each: 10-20 us)\n", us, us2);
+    }
+    {
+        unsigned long long *cyc; CK(hipMalloc(&cyc, 64 * 8));
+        unsigned long long h[4];
+        for (int rep = 0; rep < 2; ++rep) {
+            hipLaunchKernelGGL(k_chain_loop, dim3(1), dim3(64), 0, 0, buf, 1.0f, 1000, cyc);
+            CK(hipDeviceSynchronize()); CK(hipMemcpy(&h[0], cyc, 8, hipMemcpyDeviceToHost));
+            hipLaunchKernelGGL((k_chain_unrolled<8000>), dim3(1), dim3(64), 0, 0, buf, 1.0f, cyc);
+            CK(hipDeviceSynchronize()); CK(hipMemcpy(&h[1], cyc, 8, hipMemcpyDeviceToHost));
+            hipLaunchKernelGGL(k_chain_f64_loop, dim3(1), dim3(64), 0, 0, (double *)buf, 1.0, 1000, cyc);
+            CK(hipDeviceSynchronize()); CK(hipMemcpy(&h[2], cyc, 8, hipMemcpyDeviceToHost));
+            printf("dependent fma chain, one wave (clock64 ticks per fma): f32 loop %.2f, f32 unrolled x8000 (64 KB of code) %.2f, f64 loop %.2f\n",
+                   (double)h[0] / 8000, (double)h[1] / 8000, (double)h[2] / 8000);
+        }
+        // clock64 vs wall clock: how many clock64 ticks per microsecond?
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_chain_loop, dim3(1), dim3(64), 0, 0, buf, 1.0f, 200000, cyc);
+        hipEventRecord(e1); CK(hipDeviceSynchronize());
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        CK(hipMemcpy(&h[0], cyc, 8, hipMemcpyDeviceToHost));
+        printf("clock64: %.1f ticks per us (kernel of %.1f us)\n", (double)h[0] / (ms * 1e3), ms * 1e3);
     }
     {   // gap between the last instruction of launch i and the first of launch i + 1, on the 100 MHz wall clock
         const int M = 512;
