@@ -3,10 +3,17 @@ fMRI estimator (modl/decomposition/fmri.py:423-546 `_compute_components`, :549-5
 `_flip`, :364-367 the ridge `Coder`) without the nilearn masking layer, which is
 IO and out of scope.  A record is what the
 reference's `MultiRawMasker` yields (modl/input_data/fmri/unmask.py:37-55): a
-2-D array (time points x voxels) or the path of a .npy file holding one."""
+2-D array (time points x voxels) or the path of a .npy file holding one.
+
+The reference's loop rebinds `method` to the dict of aggregation modes (fmri.py:460), so its later tests on the
+method NAME - the 'gram' switch to G_agg='full' / Dx_agg='average' at epoch 5 (:508), the shrinking reduction of
+'reducing ratio' (:511-513) and the per-record sample_indices of 'average' / 'gram' (:535-539) - never fire.  The
+default here reproduces that EFFECTIVE behaviour (same results as the reference on the same inputs, pinned by
+tests/golden/fmri.npz); `intended_schedules=True` runs what the code was written to do."""
 import time
 from concurrent.futures import ThreadPoolExecutor
 from math import sqrt
+from os.path import join
 
 import numpy as np
 import torch
@@ -93,7 +100,8 @@ class fMRIDictFact(BaseEstimator):
 
     def __init__(self, method='masked', step_size=1, n_components=20, n_epochs=1, alpha=0.1, dict_init=None,
                  random_state=None, batch_size=20, reduction=1, learning_rate=1, positive=False, verbose=0,
-                 callback=None, n_jobs=1):
+                 callback=None, n_jobs=1, intended_schedules=False):
+        self.intended_schedules = intended_schedules
         self.method = method
         self.step_size = step_size
         self.n_components = n_components
@@ -148,10 +156,11 @@ class fMRIDictFact(BaseEstimator):
         if n_records > 0:
             verbose_iter_ = np.linspace(0, n_records * self.n_epochs, self.verbose).tolist() if self.verbose else []
             current_n_records = 0
+            named = self.method if self.intended_schedules else None      # fmri.py:460 (see the module docstring)
             for i in range(self.n_epochs):
-                if self.method == 'gram' and i == 5:
+                if named == 'gram' and i == 5:
                     dict_fact.set_params(G_agg='full', Dx_agg='average')
-                if self.method == 'reducing ratio':
+                if named == 'reducing ratio':
                     reduction = 1 + (reduction - 1) / sqrt(i + 1)    # compounds across epochs (fmri.py:511-513)
                     dict_fact.set_params(reduction=reduction)
                 record_list = random_state.permutation(n_records)
@@ -169,7 +178,7 @@ class fMRIDictFact(BaseEstimator):
                     self.io_time_ += time.perf_counter() - t0
                     t0 = time.perf_counter()
                     permutation = random_state.permutation(data.shape[0])
-                    if self.method in ['average', 'gram']:
+                    if named in ['average', 'gram']:
                         sample_indices = np.arange(indices_list[record], indices_list[record + 1])[permutation]
                     else:
                         sample_indices = None
@@ -192,3 +201,56 @@ class fMRIDictFact(BaseEstimator):
         scores = np.array([self.coder_.score(a) for a in arrays])
         lens = np.array([a.shape[0] for a in arrays])
         return np.sum(scores * lens) / np.sum(lens)
+
+
+class rfMRIDictionaryScorer:
+    """Callback computing the test objective along a fit (fmri.py:588-633), on raw 2-D test records.
+
+    The test records are staged in HBM ONCE (first call: np.load / dtype conversion, one upload per record) and
+    every later call scores them where they are - codes from the current dictionary (`DictFact.score`: transform +
+    the three sums of the objective on the device), so neither the test set nor the dictionary crosses the host
+    link again; three doubles per record come back.  Signature of the reference: `scorer(masker, dict_fact,
+    cpu_time, io_time)`; the first argument (the masker there, the fMRIDictFact here) is not used for raw records.
+    `artifact_dir`: `info.pkl` as in the reference (:621-625) and the flipped maps as `components_<n_iter>.npy`
+    (the reference writes a NIfTI image through the masker, which is out of scope)."""
+
+    def __init__(self, test_records, test_confounds=None, info=None, artifact_dir=None):
+        self.start_time = time.perf_counter()
+        self.test_records = test_records
+        self.test_confounds = test_confounds             # kept for signature compatibility; raw records carry none
+        self.test_time = 0
+        self.score = []
+        self.iter = []
+        self.time = []
+        self.cpu_time = []
+        self.io_time = []
+        self.info = info
+        self.artifact_dir = artifact_dir
+
+    def _stage(self, dict_fact):
+        be = dict_fact._backend
+        self.data = [be.stage_X(np.ascontiguousarray(np.asarray(_load(r)), dtype=be.dtype)) for r in self.test_records]
+        self.lengths = np.array([d.shape[0] for d in self.data])
+
+    def __call__(self, masker, dict_fact, cpu_time, io_time):
+        test_time = time.perf_counter()
+        if not hasattr(self, 'data'):
+            self._stage(dict_fact)
+        scores = np.array([dict_fact.score(data) for data in self.data])
+        score = np.sum(scores * self.lengths) / np.sum(self.lengths)
+        self.test_time += time.perf_counter() - test_time
+        this_time = time.perf_counter() - self.start_time - self.test_time
+        self.score.append(score)
+        self.time.append(this_time)
+        self.cpu_time.append(cpu_time)
+        self.io_time.append(io_time)
+        self.iter.append(dict_fact.n_iter_)
+        if self.info is not None:
+            self.info['time'] = self.cpu_time
+            self.info['score'] = self.score
+            self.info['iter'] = self.iter
+            if self.artifact_dir is not None:
+                from joblib import dump
+                dump(self.info, join(self.artifact_dir, 'info.pkl'))
+        if self.artifact_dir is not None:
+            np.save(join(self.artifact_dir, 'components_%i.npy' % dict_fact.n_iter_), _flip(dict_fact.components_))

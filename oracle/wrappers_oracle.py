@@ -2,10 +2,13 @@
 wrapper loops that feed the hot path, built on oracle/somf_oracle.py.
 
   fmri_fit        : modl/decomposition/fmri.py:423-546 (_compute_components) + :549-556 (_flip),
-                    on raw 2-D records (the reference's masking layer needs nilearn, absent here:
-                    this loop is pinned by its kwargs table :440-463,481-495 and streaming order
-                    :514,532-541 only — "parity unpinned" for the wrapper itself, the DictFact
-                    calls underneath are pinned by tests/golden).
+                    on raw 2-D records.  PINNED by tests/golden/fmri.npz, recorded from the reference's
+                    own two functions (taken out of fmri.py at run time by make_golden.gen_fmri and run
+                    against stand-ins for the nilearn masking layer).  fmri.py:460 rebinds `method` to the
+                    dict of aggregation modes, so the tests on the method NAME at :508 ('gram' switch at
+                    epoch 5), :511 ('reducing ratio') and :535 (sample_indices for 'average' / 'gram')
+                    never fire in the reference: `intended_schedules=False` (default) restates that
+                    EFFECTIVE behaviour, True what the code was meant to do.
   recsys_*        : modl/decomposition/recsys.py (pinned by tests/golden/recsys.npz).
 """
 from math import sqrt
@@ -22,7 +25,7 @@ FMRI_METHODS = {'masked': ('masked', 'masked'), 'dictionary only': ('full', 'ful
 
 
 def fmri_fit(records, method='masked', step_size=1, n_components=20, n_epochs=1, alpha=0.1, dict_init=None,
-             random_state=None, batch_size=20, reduction=1, learning_rate=1, positive=False):
+             random_state=None, batch_size=20, reduction=1, learning_rate=1, positive=False, intended_schedules=False):
     if dict_init is not None:
         dict_init = np.asarray(dict_init)[:n_components]
         n_components = dict_init.shape[0]
@@ -42,19 +45,20 @@ def fmri_fit(records, method='masked', step_size=1, n_components=20, n_epochs=1,
                         random_state=rng)
     st = orc.prepare(pr, n_samples=int(idx[-1]) + 1, n_features=records[0].shape[1],
                      X=None if dict_init is None else dict_init.astype(dtype), dtype=dtype)
+    named = method if intended_schedules else None          # fmri.py:460: the name is gone after the rebinding
     for i in range(n_epochs):
-        if method == 'gram' and i == 5:
+        if named == 'gram' and i == 5:
             pr.G_agg, pr.Dx_agg = 'full', 'average'
             st.G = st.D.dot(st.D.T)
             if st.Dx_average is None:
                 st.Dx_average = np.zeros((st.code.shape[0], n_components), dtype=dtype)
-        if method == 'reducing ratio':
+        if named == 'reducing ratio':
             reduction = 1 + (reduction - 1) / sqrt(i + 1)
             pr.reduction = reduction
         for record in rng.permutation(len(records)):
             data = records[record].astype(dtype)
             perm = rng.permutation(data.shape[0])
-            si = np.arange(idx[record], idx[record + 1])[perm] if method in ('average', 'gram') else None
+            si = np.arange(idx[record], idx[record + 1])[perm] if named in ('average', 'gram') else None
             orc.partial_fit(st, pr, data[perm], sample_indices=si)
     D = st.D.copy()
     for comp in D:

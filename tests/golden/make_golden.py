@@ -533,6 +533,89 @@ def gen_headline():
     save('traj_headline', **out)
 
 
+def gen_fmri():
+    """The record loop of the reference's fMRI estimator (decomposition/fmri.py:423-556) from the REAL reference.
+    fmri.py cannot be imported here (nilearn / nibabel are absent), so the two functions of the loop -
+    `_compute_components` and `_flip` - are taken out of the reference's source AT RUN TIME (ast, from
+    /root/reference; nothing of it is written anywhere) and executed against stand-ins for the masking / IO layer,
+    which is out of scope: a masker whose `transform` returns the 2-D record it is given (the `MultiRawMasker`
+    contract, input_data/fmri/unmask.py:37-55), `_lazy_scan` answering with the records' lengths and dtype, and a
+    `check_niimg` stand-in that only serves `n_voxels`.  Everything numerical is the reference's own code, with its
+    own DictFact.  NB the loop rebinds `method` to the dict of aggregation modes (:460), so its three later tests on
+    the method NAME (:508, :511, :535) never fire: no switch at epoch 5, no shrinking reduction, and
+    sample_indices is always None - the fixture records that EFFECTIVE behaviour."""
+    import ast
+    import contextlib
+    import io
+    import itertools
+    import time
+    from math import log, sqrt
+    from sklearn.utils import check_random_state
+    from modl.decomposition.dict_fact import DictFact
+    src = open(os.path.join(REF, 'decomposition', 'fmri.py')).read()
+    tree = ast.parse(src)
+    wanted = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ('_compute_components', '_flip')]
+    assert len(wanted) == 2
+    mod = ast.Module(body=wanted, type_ignores=[])
+
+    class _Mask:
+        def __init__(self, p):
+            self.p = p
+
+        def get_data(self):
+            return np.ones(self.p)
+
+    class _Masker:
+        def __init__(self, p):
+            self.mask_img_ = _Mask(p)
+
+        def _check_fitted(self):
+            pass
+
+        def transform(self, img, confounds=None):
+            return img
+
+    ns = dict(np=np, itertools=itertools, time=time, sqrt=sqrt, log=log, check_random_state=check_random_state,
+              DictFact=DictFact, check_niimg=lambda m: m,
+              _check_dict_init=lambda dict_init, mask_img=None, n_components=None: dict_init,
+              _lazy_scan=lambda imgs: ([im.shape[0] for im in imgs], imgs[0].dtype))
+    exec(compile(mod, '<reference fmri.py, extracted>', 'exec'), ns)
+    compute = ns['_compute_components']
+
+    out = {}
+    cases = []
+    rs = np.random.RandomState(0)
+    p, k, n_rec, T = 120, 4, 5, 30
+    maps = np.zeros((k, p))
+    for j in range(k):
+        maps[j, j * 30:(j + 1) * 30] = 1.0
+    for dt, dn in ((np.float64, 'f64'), (np.float32, 'f32')):
+        records = []
+        for r_ in range(n_rec):
+            L = rs.randn(T, k)
+            rec = L.dot(maps) + 0.01 * rs.randn(T, p)
+            rec -= rec.mean(1, keepdims=True)
+            rec /= rec.std(1, keepdims=True)
+            records.append(np.ascontiguousarray(rec.astype(dt)))
+        dict_init = (maps + rs.randn(k, p)).astype(dt)
+        out['records_' + dn] = np.stack(records)
+        out['dict_init_' + dn] = dict_init
+        for method, extra in (('masked', dict(n_epochs=2, reduction=3)), ('average', dict(n_epochs=2, reduction=3)),
+                              ('gram', dict(n_epochs=7, reduction=3)), ('reducing ratio', dict(n_epochs=3, reduction=4)),
+                              ('dictionary only', dict(n_epochs=1)), ('sgd', dict(n_epochs=1, step_size=0.05)),
+                              ('masked_pos', dict(n_epochs=2, reduction=3, positive=True))):
+            kw = dict(alpha=1e-3, reduction=1, learning_rate=0.92, n_components=k, batch_size=10, random_state=0)
+            kw.update(extra)
+            m = method.split('_')[0]
+            with contextlib.redirect_stdout(io.StringIO()):
+                comp = compute(_Masker(p), records, dict_init=dict_init.copy(), method=m, **kw)
+            name = '%s_%s' % (method.replace(' ', '-'), dn)
+            out[name + '/components'] = comp
+            cases.append(name)
+    out['cases'] = np.array(cases)
+    save('fmri', **out)
+
+
 if __name__ == '__main__':
     build_reference()
     sys.path.insert(0, SCRATCH)
@@ -546,3 +629,4 @@ if __name__ == '__main__':
     gen_recsys()
     gen_image()
     gen_headline()
+    gen_fmri()

@@ -123,9 +123,61 @@ def _fmri_records(dtype=np.float64, n_records=5, length=30, p=120, k=4, seed=0):
     return recs, dict_init
 
 
+# (the last three: what fmri.py:508-539 was WRITTEN to do - off in the reference, see modl_amd/fmri.py)
 FMRI_CASES = [dict(method='masked', reduction=3, n_epochs=2), dict(method='average', reduction=2, n_epochs=2),
               dict(method='dictionary only', n_epochs=1), dict(method='reducing ratio', reduction=4, n_epochs=3),
-              dict(method='masked', reduction=2, n_epochs=1, positive=True), dict(method='gram', reduction=2, n_epochs=7)]
+              dict(method='masked', reduction=2, n_epochs=1, positive=True), dict(method='gram', reduction=2, n_epochs=7),
+              dict(method='average', reduction=2, n_epochs=2, intended_schedules=True),
+              dict(method='reducing ratio', reduction=4, n_epochs=3, intended_schedules=True),
+              dict(method='gram', reduction=2, n_epochs=7, intended_schedules=True)]
+
+
+FMRI_GOLDEN_KW = {'masked': dict(n_epochs=2, reduction=3), 'average': dict(n_epochs=2, reduction=3),
+                  'gram': dict(n_epochs=7, reduction=3), 'reducing-ratio': dict(n_epochs=3, reduction=4),
+                  'dictionary-only': dict(n_epochs=1), 'sgd': dict(n_epochs=1, step_size=0.05),
+                  'masked_pos': dict(n_epochs=2, reduction=3, positive=True)}
+
+
+def _fmri_golden_case(name):
+    """kwargs + records of a case of tests/golden/fmri.npz (mirrors make_golden.gen_fmri)."""
+    g = load_golden('fmri')
+    method, dn = name.rsplit('_', 1)
+    kw = dict(alpha=1e-3, reduction=1, learning_rate=0.92, n_components=4, batch_size=10, random_state=0)
+    kw.update(FMRI_GOLDEN_KW[method])
+    kw['method'] = method.split('_')[0].replace('-', ' ')
+    recs = [np.ascontiguousarray(r) for r in g['records_' + dn]]
+    return kw, recs, g['dict_init_' + dn], g[name + '/components'], dn
+
+
+def _fmri_golden_names():
+    return [str(c) for c in load_golden('fmri')['cases']]
+
+
+@pytest.mark.parametrize('name', _fmri_golden_names())
+def test_fmri_loop_oracle_vs_reference_golden(name):
+    """The oracle's restatement of the record loop against what the reference's OWN `_compute_components` produced
+    (tests/golden/fmri.npz): 'gram' over 7 epochs and 'reducing ratio' included, i.e. the schedules that the
+    reference's rebinding of `method` (fmri.py:460) turns off."""
+    from oracle import wrappers_oracle
+    kw, recs, dict_init, want, dn = _fmri_golden_case(name)
+    D, _ = wrappers_oracle.fmri_fit(recs, dict_init=dict_init, **kw)
+    assert rel_fro(D, want) < (1e-9 if dn == 'f64' else 2e-4), name
+
+
+@pytest.mark.parametrize('name', [n for n in _fmri_golden_names() if n.endswith('f64')])
+def test_fmri_loop_host_logic_vs_reference_golden(name):
+    kw, recs, dict_init, want, dn = _fmri_golden_case(name)
+    est = _fmri_estimator(True)(dict_init=dict_init, **kw).fit(recs)
+    assert rel_fro(est.components_, want) < 1e-9, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', _fmri_golden_names())
+def test_fmri_loop_gpu_vs_reference_golden(name):
+    """fMRIDictFact on the GPU path against the reference's own record loop."""
+    kw, recs, dict_init, want, dn = _fmri_golden_case(name)
+    est = _fmri_estimator(False)(dict_init=dict_init, **kw).fit(recs)
+    assert rel_fro(est.components_, want) < (1e-9 if dn == 'f64' else 2e-4), name
 
 
 def _check_fmri_case(kw, host, with_init=True):
@@ -145,7 +197,10 @@ def _check_fmri_case(kw, host, with_init=True):
         assert np.sum(comp < 0) <= np.sum(comp > 0)
 
 
-@pytest.mark.parametrize('kw', FMRI_CASES, ids=lambda kw: kw['method'] + ('_pos' if kw.get('positive') else ''))
+_fmri_id = lambda kw: kw['method'] + ('_pos' if kw.get('positive') else '') + ('_intended' if kw.get('intended_schedules') else '')
+
+
+@pytest.mark.parametrize('kw', FMRI_CASES, ids=_fmri_id)
 def test_fmri_dict_fact_host_logic(kw):
     _check_fmri_case(kw, host=True)
 
@@ -155,7 +210,7 @@ def test_fmri_random_init_host_logic():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('kw', FMRI_CASES, ids=lambda kw: kw['method'] + ('_pos' if kw.get('positive') else ''))
+@pytest.mark.parametrize('kw', FMRI_CASES, ids=_fmri_id)
 def test_fmri_dict_fact_gpu(kw):
     _check_fmri_case(kw, host=False)
 
@@ -269,3 +324,52 @@ def test_dictionary_scorer_gpu_resident_test_set():
     import torch
     scorer = _scorer_case(host=False)
     assert isinstance(scorer._staged, torch.Tensor) and scorer._staged.is_cuda
+
+
+def _check_fmri_scorer(host, tmp_path):
+    """rfMRIDictionaryScorer (fmri.py:588-633) on raw records: called along the fit through `verbose` / `callback`,
+    test records staged once, length-weighted mean of DictFact.score; checked against the oracle's objective."""
+    from modl_amd.fmri import rfMRIDictionaryScorer
+    from oracle import somf_oracle as orc
+    recs, dict_init = _fmri_records(n_records=6)
+    train, test = recs[:4], [recs[4], recs[5][:17]]
+    info = {}
+    scorer = rfMRIDictionaryScorer(test, info=info, artifact_dir=str(tmp_path))
+    est = _fmri_estimator(host)(n_components=4, alpha=1e-2, batch_size=10, learning_rate=0.92, random_state=0,
+                                dict_init=dict_init, method='masked', reduction=2, n_epochs=2, verbose=4, callback=scorer)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        est.fit(train)
+    assert len(scorer.score) >= 3 and len(scorer.iter) == len(scorer.score) == len(scorer.cpu_time)
+    assert scorer.iter == sorted(scorer.iter) and np.all(np.isfinite(scorer.score))
+    staged = scorer.data
+    scorer(None, est.dict_fact_, 0.0, 0.0)                       # one more call on the final dictionary
+    assert scorer.data is staged                                 # the test set is staged once
+    pr = orc.SomfParams(code_alpha=1e-2, code_l1_ratio=0)
+    D = est.dict_fact_.components_
+    want = sum(orc.score(pr, D, t) * t.shape[0] for t in test) / sum(t.shape[0] for t in test)
+    assert abs(scorer.score[-1] - want) < 1e-9 * abs(want)
+    assert info['score'] is scorer.score and info['iter'][-1] == est.dict_fact_.n_iter_
+    import os
+    saved = np.load(os.path.join(str(tmp_path), 'components_%i.npy' % est.dict_fact_.n_iter_))
+    assert_array_equal(saved, est.components_)                   # the flipped maps
+    assert os.path.exists(os.path.join(str(tmp_path), 'info.pkl'))
+
+
+def test_fmri_scorer_host_logic(tmp_path):
+    _check_fmri_scorer(True, tmp_path)
+
+
+@pytest.mark.gpu
+def test_fmri_scorer_gpu(tmp_path):
+    _check_fmri_scorer(False, tmp_path)
+    import torch
+    from modl_amd.fmri import rfMRIDictionaryScorer
+    recs, dict_init = _fmri_records(np.float32, n_records=3)
+    scorer = rfMRIDictionaryScorer(recs[2:])
+    est = _fmri_estimator(False)(n_components=4, alpha=1e-2, batch_size=10, random_state=0, dict_init=dict_init,
+                                 reduction=2, verbose=2, callback=scorer)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        est.fit(recs[:2])
+    assert all(isinstance(d, torch.Tensor) and d.is_cuda for d in scorer.data)      # resident in HBM
