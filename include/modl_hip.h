@@ -321,6 +321,13 @@ int modl_somf_head_elems(const modl_somf_plan *plan, int64_t *head_elems);
 int modl_somf_apply_and_update_dict(modl_somf_plan *plan, const modl_somf_state *st,
                                     const modl_somf_batch *bt, const void *d_head, void *stream);
 
+/* d_dst[r][0..cols) = d_src[d_idx[r]][0..cols): the row permutations around the path (X = X[permutation] after
+ * an epoch, dict_fact.py:309-310; masked_data[permutation], fmri.py:541) on device-resident rows. */
+int modl_gather_rows_f32(const float *d_src, int64_t src_ld, const int64_t *d_idx, int64_t n_rows, int64_t cols,
+                         float *d_dst, int64_t dst_ld, void *stream);
+int modl_gather_rows_f64(const double *d_src, int64_t src_ld, const int64_t *d_idx, int64_t n_rows, int64_t cols,
+                         double *d_dst, int64_t dst_ld, void *stream);
+
 /* G_ = D D^T (prepare / set_params(G_agg='full'), dict_fact.py:355,477) */
 int modl_somf_full_gram(modl_somf_plan *plan, const void *d_Dt, void *d_G, void *stream);
 

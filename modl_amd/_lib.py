@@ -105,6 +105,7 @@ for _sfx, _ct in (('f32', C.c_float), ('f64', C.c_double)):
     _sig('modl_enet_projection_' + _sfx, C.c_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _ct, _vp)
     _sig('modl_enet_scale_' + _sfx, C.c_int, _vp, _i64, _i64, _i64, _i64, _ct, _ct, _vp)
     _sig('modl_transpose_' + _sfx, C.c_int, _vp, _vp, _i64, _i64, _vp)
+    _sig('modl_gather_rows_' + _sfx, C.c_int, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp)
 for _sfx, _ct in (('f32', C.c_float), ('f64', C.c_double)):
     _sig('modl_recsys_codes_' + _sfx, C.c_int, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp)
     _sig('modl_recsys_update_B_' + _sfx, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _i64, _vp)

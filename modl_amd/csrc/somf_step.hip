@@ -945,6 +945,23 @@ int modl_somf_transform(modl_somf_plan *pl, const void *d_Dt, const void *d_G, c
                                            (hipStream_t)stream));
 }
 
+// rows d_idx[0..n) of a row-major device matrix, gathered into d_dst (the row permutations of fit / shuffle,
+// dict_fact.py:309-310, fmri.py:541: data movement only, HBM-bound)
+#define ABI_GATHER(SFX, T)                                                                                         \
+    int modl_gather_rows_##SFX(const T *d_src, int64_t src_ld, const int64_t *d_idx, int64_t n_rows, int64_t cols,  \
+                               T *d_dst, int64_t dst_ld, void *stream) {                                           \
+        if (!d_src || !d_idx || !d_dst || n_rows < 0 || cols < 0 || src_ld < cols || dst_ld < cols) return MODL_EINVAL; \
+        if (n_rows == 0 || cols == 0) return MODL_OK;                                                              \
+        if (n_rows > 0x7fffffff) return MODL_EINVAL;                                                               \
+        hipLaunchKernelGGL((gather_rows_T_kernel<T, int64_t>), dim3((unsigned)n_rows), dim3(256), 0,              \
+                           (hipStream_t)stream, d_src, src_ld, d_idx, n_rows, n_rows, cols, d_dst, dst_ld);        \
+        MODL_LAUNCH_CHECK();                                                                                       \
+        return MODL_OK;                                                                                            \
+    }
+ABI_GATHER(f32, float)
+ABI_GATHER(f64, double)
+#undef ABI_GATHER
+
 int modl_somf_debug_stamps(modl_somf_plan *pl, unsigned long long *h_out) {
     // diagnostics only: phase timestamps (shader clock) left by the last fused dictionary-update launch
     if (!pl || !h_out) return MODL_EINVAL;

@@ -61,5 +61,17 @@ def transpose_to(src, rows, cols):
     """out[c][r] = src[r][c] on the device (components_ <-> feature-major Dt)."""
     out = torch.empty((cols, rows), dtype=src.dtype, device=src.device)
     f = getattr(lib, 'modl_transpose_' + ('f32' if src.dtype == torch.float32 else 'f64'))
-    check(f(ptr(src), ptr(out), rows, cols, stream_ptr(src.device)), 'modl_transpose')
+    with torch.cuda.device(src.device):
+        check(f(ptr(src), ptr(out), rows, cols, stream_ptr(src.device)), 'modl_transpose')
+    return out
+
+
+def gather_rows(src, perm):
+    """src[perm] for a 2-D device tensor with contiguous rows, by the library's gather kernel."""
+    idx = torch.from_numpy(np.ascontiguousarray(perm, dtype=np.int64)).to(src.device)
+    out = torch.empty((idx.shape[0], src.shape[1]), dtype=src.dtype, device=src.device)
+    f = getattr(lib, 'modl_gather_rows_' + ('f32' if src.dtype == torch.float32 else 'f64'))
+    with torch.cuda.device(src.device):
+        check(f(ptr(src), src.stride(0), ptr(idx), idx.shape[0], src.shape[1], ptr(out), out.stride(0),
+                stream_ptr(src.device)), 'modl_gather_rows')
     return out

@@ -27,7 +27,7 @@ from sklearn.utils.validation import check_is_fitted
 
 from . import _lib
 from ._lib import lib, check, SomfDesc, SomfState, SomfBatch, ProfEntry, AGG, OPT
-from .device import (default_device, dtype_id, sfx, torch_dtype, ptr, stream_ptr, to_device, transpose_to)
+from .device import (default_device, dtype_id, sfx, torch_dtype, ptr, stream_ptr, to_device, transpose_to, gather_rows)
 from .randomkit import RandomState, Sampler, batch_weight
 from .utils import get_sub_slice
 
@@ -168,7 +168,8 @@ class HipBackend:
 
     def scale_atoms(self, l1_ratio, radius=1.0):      # enet_scale on every atom (dict_fact.py:465-468)
         f = getattr(lib, 'modl_enet_scale_' + sfx(self.dtype))
-        check(f(ptr(self.Dt), self.k, self.p, 1, self.k, l1_ratio, radius, stream_ptr(self.device)), 'modl_enet_scale')
+        with torch.cuda.device(self.device):
+            check(f(ptr(self.Dt), self.k, self.p, 1, self.k, l1_ratio, radius, stream_ptr(self.device)), 'modl_enet_scale')
 
     def full_gram(self):
         if self.G is None:
@@ -181,8 +182,9 @@ class HipBackend:
     def shuffle_rows(self, name, swaps):
         t = getattr(self, name)
         row_bytes = t[0].numel() * t.element_size()
-        check(lib.modl_apply_swaps_rows_device(ptr(t), t.shape[0], row_bytes, swaps.ctypes.data_as(C.c_void_p),
-                                               stream_ptr(self.device)), 'modl_apply_swaps_rows_device')
+        with torch.cuda.device(self.device):
+            check(lib.modl_apply_swaps_rows_device(ptr(t), t.shape[0], row_bytes, swaps.ctypes.data_as(C.c_void_p),
+                                                   stream_ptr(self.device)), 'modl_apply_swaps_rows_device')
 
     # -- data ---------------------------------------------------------------
     def stage_X(self, X):
@@ -200,12 +202,13 @@ class HipBackend:
         n = idx.shape[0]
         out = torch.empty((n, x * y * z), dtype=d_image.dtype, device=self.device)
         f = getattr(lib, 'modl_image_patches_' + ('f32' if d_image.dtype == torch.float32 else 'f64'))
-        check(f(ptr(d_image), H, W, Cc, ptr(idx), n, x, y, z, int(bool(with_mean)), int(bool(with_std)), ptr(out),
-                x * y * z, stream_ptr(self.device)), 'modl_image_patches')
+        with torch.cuda.device(self.device):
+            check(f(ptr(d_image), H, W, Cc, ptr(idx), n, x, y, z, int(bool(with_mean)), int(bool(with_std)), ptr(out),
+                    x * y * z, stream_ptr(self.device)), 'modl_image_patches')
         return out
 
     def take_rows(self, Xh, perm):
-        return Xh.index_select(0, torch.from_numpy(np.asarray(perm, dtype=np.int64)).to(Xh.device))
+        return gather_rows(Xh, perm)
 
     def synchronize(self):
         torch.cuda.synchronize(self.device)
@@ -286,8 +289,9 @@ class HipBackend:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         out = torch.empty(3, dtype=torch.float64, device=self.device)
         f = getattr(lib, 'modl_objective_' + sfx(self.dtype))
-        check(f(ptr(Xh), Xh.stride(0), n, p, ptr(self.Dt), self.k, ptr(code), ptr(ws), nbytes, ptr(out),
-                stream_ptr(self.device)), 'modl_objective')
+        with torch.cuda.device(self.device):
+            check(f(ptr(Xh), Xh.stride(0), n, p, ptr(self.Dt), self.k, ptr(code), ptr(ws), nbytes, ptr(out),
+                    stream_ptr(self.device)), 'modl_objective')
         return out.cpu().numpy()
 
     def last_sweeps(self):

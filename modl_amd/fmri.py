@@ -20,6 +20,7 @@ import torch
 from sklearn.base import BaseEstimator
 from sklearn.utils import check_random_state
 
+from .device import gather_rows
 from .dict_fact import DictFact, Coder
 
 METHODS = {'masked': {'G_agg': 'masked', 'Dx_agg': 'masked'},           # fmri.py:440-445
@@ -84,8 +85,7 @@ class _RecordStager:
     def rows(self, data, permutation):
         if not self.on_gpu:
             return data[permutation]
-        idx = torch.from_numpy(np.ascontiguousarray(permutation, dtype=np.int64)).to(self.device)
-        return data.index_select(0, idx)
+        return gather_rows(data, permutation)
 
     def close(self):
         if self.pool is not None:

@@ -22,24 +22,20 @@ from .dict_fact import DictFact
 
 
 def scale_patches(X, with_mean=True, with_std=True, channel_wise=True, copy=True):
-    """Centre / normalise patches (n, ph, pw, c) — modl/input_data/image.py:4-23."""
-    if copy:
-        X = X.copy()
+    """Centred / l2-normalised patches, X: (n, ph, pw, c).  Same arithmetic, in the same order, as the reference's
+    modl/input_data/image.py:4-23 (statistics per patch and channel over the ph x pw positions, the norm times
+    sqrt(c); or per patch over everything when not channel_wise) written once over a reduction-axes tuple; the
+    training path never calls this - its patches are produced already scaled by modl_image_patches_* on the device."""
+    X = np.array(X, copy=True) if copy else X
+    axes = (1, 2) if channel_wise else (1, 2, 3)
     if with_mean:
-        if channel_wise:
-            X -= np.mean(X, axis=(1, 2))[:, np.newaxis, np.newaxis, :]
-        else:
-            X -= np.mean(X, axis=(1, 2, 3))[:, np.newaxis, np.newaxis, np.newaxis]
+        X -= X.mean(axis=axes, keepdims=True)
     if with_std:
+        norm = np.sqrt(np.square(X).sum(axis=axes, keepdims=True))
+        norm[norm == 0] = 1
         if channel_wise:
-            n_channel = X.shape[3]
-            std = np.sqrt(np.sum(X ** 2, axis=(1, 2)))
-            std[std == 0] = 1
-            X /= std[:, np.newaxis, np.newaxis, :] * sqrt(n_channel)
-        else:
-            std = np.sqrt(np.sum(X ** 2, axis=(1, 2, 3)))
-            std[std == 0] = 1
-            X /= std[:, np.newaxis, np.newaxis, np.newaxis]
+            norm = norm * sqrt(X.shape[3])
+        X /= norm
     return X
 
 
@@ -66,7 +62,12 @@ def clean_mask(patches, image):
 
 
 class LazyCleanPatchExtractor(BaseEstimator):
-    """modl/feature_extraction/image.py:8-83"""
+    """Patch origins of an image, drawn once, patches produced on demand (the estimator surface of
+    modl/feature_extraction/image.py:8-83: `fit`, `transform`, `partial_transform`, `shuffle`, `indices_3d`,
+    `patches_`).  The state is the (n, 3) array of origins - every window without a missing (-1) pixel
+    (`clean_mask`) or simply all of them (`fill`), permuted by the random state and cut to `max_patches`; a batch of
+    patches is a fancy index into the strided window view on the host (`_take`) or one launch on the HBM-resident
+    image (`partial_transform_scaled`)."""
 
     def __init__(self, patch_size=None, random_state=None, max_patches=None):
         self.patch_size = patch_size
@@ -75,34 +76,30 @@ class LazyCleanPatchExtractor(BaseEstimator):
 
     def fit(self, X, y=None):
         self.random_state = check_random_state(self.random_state)
-        i_h, i_w, n_channels = X.shape
-        patch_size = (i_h // 10, i_w // 10) if self.patch_size is None else self.patch_size
-        patch_shape = (patch_size[0], patch_size[1], n_channels)
-        self.image_ = X
-        self._device_image = None
-        self.patches_ = sliding_window_view(X, patch_shape)       # == sklearn extract_patches, step 1
-        if not np.all(X != -1):
-            self.indices_3d = clean_mask(self.patches_, X)
-        else:
-            self.indices_3d = fill(*self.patches_.shape[:3])
-        n_samples = self.indices_3d.shape[0]
-        selection = self.random_state.permutation(n_samples)[:self.max_patches]
-        self.indices_3d = self.indices_3d[selection]
+        height, width, n_channels = X.shape
+        ph, pw = self.patch_size if self.patch_size is not None else (height // 10, width // 10)
+        self.image_, self._device_image = X, None
+        self.patches_ = sliding_window_view(X, (ph, pw, n_channels))          # every window, as a strided view
+        has_holes = bool(np.any(X == -1))
+        origins = clean_mask(self.patches_, X) if has_holes else fill(*self.patches_.shape[:3])
+        keep = self.random_state.permutation(origins.shape[0])[:self.max_patches]
+        self.indices_3d = origins[keep]
         return self
+
+    def _take(self, origins):
+        return self.patches_[origins[:, 0], origins[:, 1], origins[:, 2]]
+
+    def transform(self, X=None):
+        if X is not None:
+            self.fit(X)
+        return self._take(self.indices_3d)
 
     def partial_transform(self, X=None, batch=None):
         if X is not None:
             self.fit(X)
         if batch is None:
-            return self.transform()
-        if isinstance(batch, int):
-            batch = slice(0, batch)
-        return self.patches_[tuple(self.indices_3d[batch].T)]
-
-    def transform(self, X=None):
-        if X is not None:
-            self.fit(X)
-        return self.patches_[tuple(self.indices_3d.T)]
+            return self._take(self.indices_3d)
+        return self._take(self.indices_3d[slice(0, batch) if isinstance(batch, int) else batch])
 
     def partial_transform_scaled(self, backend, batch, with_mean=True, with_std=True):
         """Device path of partial_transform + scale_patches + flattening: the patches `batch` of the HBM-resident
