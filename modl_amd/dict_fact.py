@@ -324,6 +324,60 @@ class HipBackend:
                 for i in range(n.value)}
 
 
+HOST_CHUNK_BYTES = 1 << 28      # host input larger than this is streamed to HBM in chunks of about this size
+
+
+class _HostChunks:
+    """Streams a host array (numpy / np.memmap, possibly larger than HBM) to the device in chunks of whole
+    minibatches: while chunk c is being fitted, a worker thread copies chunk c + 1 into pinned memory and starts its
+    upload on a side stream (two pinned + two device buffers).  The repeated-`partial_fit` streaming contract of the
+    reference (dict_fact.py:313-337) without ever holding X on the device."""
+
+    def __init__(self, be, X, rows_per_chunk):
+        from concurrent.futures import ThreadPoolExecutor
+        self.X, self.rows, self.device = X, int(rows_per_chunk), be.device
+        td = torch_dtype(be.dtype)
+        self.n = X.shape[0]
+        self.n_chunks = (self.n + self.rows - 1) // self.rows
+        rows = min(self.rows, self.n)
+        self.pinned = [torch.empty((rows, X.shape[1]), dtype=td, pin_memory=True) for _ in range(2)]
+        self.dev = [torch.empty((rows, X.shape[1]), dtype=td, device=self.device) for _ in range(2)]
+        self.copied = [None, None]        # event: the upload out of pinned[i] / into dev[i] has finished
+        self.consumed = [None, None]      # event: the fit has finished reading dev[i]
+        self.stream = torch.cuda.Stream(self.device)
+        self.pool = ThreadPoolExecutor(1)
+
+    def _stage(self, c):
+        i = c % 2
+        r0, r1 = c * self.rows, min(self.n, (c + 1) * self.rows)
+        if self.copied[i] is not None:
+            self.copied[i].synchronize()                  # the pinned buffer is free again
+        host = self.pinned[i][:r1 - r0]
+        np.copyto(host.numpy(), self.X[r0:r1], casting='same_kind')
+        with torch.cuda.stream(self.stream):
+            if self.consumed[i] is not None:
+                self.stream.wait_event(self.consumed[i])  # the device buffer is free again
+            self.dev[i][:r1 - r0].copy_(host, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.copied[i] = ev
+        return r0, r1
+
+    def __iter__(self):
+        pending = self.pool.submit(self._stage, 0)
+        for c in range(self.n_chunks):
+            r0, r1 = pending.result()
+            if c + 1 < self.n_chunks:
+                pending = self.pool.submit(self._stage, c + 1)
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(self.copied[c % 2])
+            yield r0, self.dev[c % 2][:r1 - r0]
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self.consumed[c % 2] = ev
+        self.pool.shutdown(wait=True)
+
+
 class _DeviceRows:
     """Adapter so RandomState.shuffle_with_trace can permute device-resident rows."""
 
@@ -486,20 +540,31 @@ class DictFact(CodingMixin, BaseEstimator):
         `_sync=False` (not part of the reference's surface) returns as soon as the minibatches are enqueued on
         the stream, so that a streaming caller can overlap the production of its next chunk; `time_` then only
         counts the host time."""
-        X = _as_float_array(X)
         be = self._backend
-        Xh = be.stage_X(X)
-        if Xh.shape[1] != be.p:
-            raise ValueError('X has %d features, expected %d' % (Xh.shape[1], be.p))
+        if not (isinstance(X, np.memmap) and X.dtype == be.dtype and X.flags.c_contiguous):
+            X = _as_float_array(X)                           # (a memmap of the right type is left on disk)
+        if X.shape[1] != be.p:
+            raise ValueError('X has %d features, expected %d' % (X.shape[1], be.p))
         if self.batch_size > be._desc_kw['max_batch']:
             be.update_plan(self._plan_kwargs(self.batch_size))
         t0 = time.perf_counter()
         self._cb_time = 0.0
-        batches = list(gen_batches(Xh.shape[0], self.batch_size))
-        b_global = self._global_batch_sizes(Xh.shape[0], len(batches))
-        for t, batch in enumerate(batches):
-            self._single_batch_fit(Xh, batch, get_sub_slice(sample_indices, batch),
-                                   b_global=None if b_global is None else b_global[t])
+        n = X.shape[0]
+        batches = list(gen_batches(n, self.batch_size))
+        b_global = self._global_batch_sizes(n, len(batches))
+        # host input that does not fit a chunk is streamed: pinned, double-buffered chunks of whole minibatches
+        chunk_rows = getattr(self, '_host_chunk_rows', None) or \
+            max(1, HOST_CHUNK_BYTES // max(1, X.shape[1] * be.dtype.itemsize))
+        chunk_rows = max(self.batch_size, chunk_rows // self.batch_size * self.batch_size)
+        streamed = not isinstance(X, torch.Tensor) and hasattr(be, 'plan') and n > chunk_rows
+        chunks = _HostChunks(be, X, chunk_rows) if streamed else [(0, be.stage_X(X))]
+        t = 0
+        for r0, Xh in chunks:
+            for batch in gen_batches(Xh.shape[0], self.batch_size):
+                whole = slice(r0 + batch.start, r0 + batch.stop)
+                self._single_batch_fit(Xh, batch, get_sub_slice(sample_indices, whole),
+                                       b_global=None if b_global is None else b_global[t])
+                t += 1
         if _sync:
             be.synchronize()
         self.time_ += time.perf_counter() - t0 - self._cb_time

@@ -314,6 +314,37 @@ def test_two_phase_equals_fused_step(DictFact, agg):
         assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize('source', ['ndarray', 'memmap'])
+def test_partial_fit_streams_host_input_in_chunks(DictFact, tmp_path, source):
+    """A host array larger than one chunk goes to HBM in pinned, double-buffered chunks of whole minibatches
+    (dict_fact.py:313-337 is the streaming contract): three chunks + a ragged last minibatch must give the bits of
+    the run with X resident on the device."""
+    import torch
+    rs = np.random.RandomState(2)
+    b, p, k = 32, 300, 12
+    n = 5 * b + 7
+    X = (rs.randn(n, 20) @ rs.randn(20, p) + 0.3 * rs.randn(n, p)).astype(np.float32)
+    if source == 'memmap':
+        path = str(tmp_path / 'X.npy')
+        np.save(path, X)
+        Xin = np.load(path, mmap_mode='r')
+    else:
+        Xin = X
+    kw = dict(n_components=k, batch_size=b, reduction=3, code_alpha=0.2, learning_rate=0.9, random_state=0)
+    res = []
+    for streamed in (False, True):
+        est = DictFact(**kw)
+        est.prepare(n_samples=n, X=X)
+        if streamed:
+            est._host_chunk_rows = 2 * b
+            est.partial_fit(Xin)
+        else:
+            est.partial_fit(torch.from_numpy(X).cuda())
+        res.append((est.components_, est.code_.copy(), est.C_, est.B_, est.n_iter_))
+    for a, c in zip(res[0], res[1]):
+        assert_array_equal(a, c)
+
+
 # ---- the reference's own functional tests (modl/decomposition/tests/test_dict_fact.py) ----------
 solver_dict = {'masked': {'Dx_agg': 'masked', 'G_agg': 'masked'}, 'gram': {'Dx_agg': 'masked', 'G_agg': 'full'},
                'average': {'Dx_agg': 'masked', 'G_agg': 'masked'}, 'full': {'Dx_agg': 'full', 'G_agg': 'full'}}
