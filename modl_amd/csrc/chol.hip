@@ -13,9 +13,27 @@
 // symmetrically, F[i][j] = L[max(i,j)][min(i,j)], so that both substitutions read
 // row j of F contiguously.  The substitutions run one right-hand side per
 // wavefront with the same register layout as the coordinate-descent solver.
+// Wide systems (k > 512, e.g. the 1024 maps of the reference's HCP experiment, exps/hcp/decompose_hcp.py:50-60): a
+// right-looking BLOCKED factorisation over the whole chip - per 64-column block one small workgroup factors the
+// diagonal block in LDS and inverts it, the panel below it and the symmetric trailing update are matrix-core
+// products (launch_gemm) - and blocked substitutions for all right-hand sides at once, the diagonal blocks applied
+// through their inverses (two products per block and direction).
+#include <algorithm>
+
+#include "gemm.hpp"
 #include "kernels.hpp"
 
 namespace modl {
+
+// code[idx[r]] (or code[r]) <- rows[r]
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_rows_any_kernel(T *dst, int64_t ld, const int64_t *idx, int n_rows, int cols,
+                                                               const T *src) {
+    const int r = blockIdx.x;
+    if (r >= n_rows) return;
+    T *d = dst + (idx ? idx[r] : (int64_t)r) * ld;
+    for (int c = threadIdx.x; c < cols; c += 256) d[c] = src[(int64_t)r * cols + c];
+}
 
 template <typename T>
 __device__ void cholesky_inplace(T *W, int k) {
@@ -173,5 +191,149 @@ int launch_chol_solve(hipStream_t stream, const T *F, int64_t f_stride, T *rhs, 
 }
 template int launch_chol_solve<float>(hipStream_t, const float *, int64_t, float *, int, int, float *, const int64_t *);
 template int launch_chol_solve<double>(hipStream_t, const double *, int64_t, double *, int, int, double *, const int64_t *);
+
+
+// ---- wide systems: blocked factorisation / substitutions ----------------------------------------------------
+constexpr int kCholNB = 64;
+
+// out(i, r) -> W[row0 + i][col0 + r] and its mirror image (the factor is stored symmetrically)
+template <typename T> struct EpiPanelSym {
+    T *W; int64_t ld, row0, col0;
+    __device__ __forceinline__ void operator()(int64_t m, int64_t n, T v) const {
+        W[(row0 + m) * ld + col0 + n] = v;
+        W[(col0 + n) * ld + row0 + m] = v;
+    }
+};
+
+// factor the nb x nb diagonal block at (j0, j0) of W in LDS, write it back (symmetric storage) and write the
+// inverse of its lower-triangular factor to Linv[nb][nb] (row-major, zeros above the diagonal)
+template <typename T>
+__global__ __launch_bounds__(256) void chol_diag_block_kernel(T *W, int k, int j0, int nb, T *Linv) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T *Ls = reinterpret_cast<T *>(smem_raw);
+    T *Xs = Ls + kCholNB * kCholNB;
+    for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) Ls[e] = W[(int64_t)(j0 + e / nb) * k + j0 + e % nb];
+    __syncthreads();
+    cholesky_inplace<T>(Ls, nb);
+    for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) W[(int64_t)(j0 + e / nb) * k + j0 + e % nb] = Ls[e];
+    // column t of the inverse: forward substitution of L x = e_t (thread t; x lives in column t of Xs)
+    const int t = threadIdx.x;
+    if (t < nb) {
+        for (int i = 0; i < nb; ++i) {
+            T acc = (i == t) ? (T)1 : (T)0;
+            for (int m = t; m < i; ++m) acc = fma(-Ls[i * nb + m], Xs[m * nb + t], acc);
+            Xs[i * nb + t] = (i < t) ? (T)0 : acc / Ls[i * nb + i];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) Linv[e] = Xs[e];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void chol_load_kernel(const T *g, T *W, int k, T alpha) {
+    const int64_t n = (int64_t)k * k, stride = (int64_t)gridDim.x * 256;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {
+        T v = g[e];
+        if (e / k == e % k) v += alpha;
+        W[e] = v;
+    }
+}
+
+// F <- factor of (g + alpha I), Linv <- inverses of its diagonal blocks ([ceil(k / 64)][64 * 64])
+template <typename T>
+int cholesky_blocked(hipStream_t stream, const T *g, T *F, T *Linv, int k, T alpha) {
+    MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_diag_block_kernel<T>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kCholNB * kCholNB * (int)sizeof(T)));
+    hipLaunchKernelGGL((chol_load_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv((int64_t)k * k, 256), 2048)), dim3(256), 0,
+                       stream, g, F, k, alpha);
+    MODL_LAUNCH_CHECK();
+    SplitWs none;
+    for (int j0 = 0, blk = 0; j0 < k; j0 += kCholNB, ++blk) {
+        const int nb = std::min(kCholNB, k - j0);
+        T *Li = Linv + (size_t)blk * kCholNB * kCholNB;
+        hipLaunchKernelGGL((chol_diag_block_kernel<T>), dim3(1), dim3(256), 2 * kCholNB * kCholNB * sizeof(T), stream, F, k, j0,
+                           nb, Li);
+        MODL_LAUNCH_CHECK();
+        const int64_t rest = k - j0 - nb;
+        if (rest <= 0) break;
+        // panel: L[i][r] = sum_c A[i][j0 + c] Linv[r][c]  (in place: a workgroup reads its own rows before it writes them)
+        Operand A, B;
+        A.ptr = F + (size_t)(j0 + nb) * k + j0; A.si = k; A.sk = 1;
+        B.ptr = Li; B.si = nb; B.sk = 1;
+        EpiPanelSym<T> ep{F, k, j0 + nb, j0};
+        MODL_TRY((launch_gemm<T, EpiPanelSym<T>>(stream, A, B, rest, nb, nb, ep, none, nullptr, 512, 1)));
+        // trailing update: W[i][m] -= sum_r L[i][r] L[m][r]  (both triangles: the storage stays symmetric)
+        Operand P;
+        P.ptr = F + (size_t)(j0 + nb) * k + j0; P.si = k; P.sk = 1;
+        EpiAxpby<T> et{F + (size_t)(j0 + nb) * k + (j0 + nb), k, (T)-1, (T)1};
+        MODL_TRY((launch_gemm<T, EpiAxpby<T>>(stream, P, P, rest, rest, nb, et, none, nullptr, 512, 1)));
+    }
+    return MODL_OK;
+}
+
+// rhs[b][k] <- solutions of F F^T x = rhs (in place), block substitutions on the matrix cores
+template <typename T>
+int chol_solve_blocked(hipStream_t stream, const T *F, const T *Linv, T *rhs, int b, int k) {
+    SplitWs none;
+    const int nblk = (int)cdiv(k, kCholNB);
+    for (int blk = 0; blk < nblk; ++blk) {                             // forward: L y = rhs
+        const int j0 = blk * kCholNB, nb = std::min(kCholNB, k - j0);
+        const T *Li = Linv + (size_t)blk * kCholNB * kCholNB;
+        Operand R, B;
+        R.ptr = rhs + j0; R.si = k; R.sk = 1;                          // (s, c) -> rhs[s][j0 + c]
+        B.ptr = Li; B.si = nb; B.sk = 1;                               // (r, c) -> Linv[r][c]
+        EpiStore<T> ey{rhs + j0, k, (T)1};
+        MODL_TRY((launch_gemm<T, EpiStore<T>>(stream, R, B, b, nb, nb, ey, none, nullptr, 512, 1)));
+        const int64_t rest = k - j0 - nb;
+        if (rest <= 0) break;
+        Operand Lp;
+        Lp.ptr = F + (size_t)(j0 + nb) * k + j0; Lp.si = k; Lp.sk = 1;  // (m, r) -> L[j0 + nb + m][j0 + r]
+        EpiAxpby<T> eu{rhs + j0 + nb, k, (T)-1, (T)1};
+        MODL_TRY((launch_gemm<T, EpiAxpby<T>>(stream, R, Lp, b, rest, nb, eu, none, nullptr, 512, 1)));
+    }
+    for (int blk = nblk - 1; blk >= 0; --blk) {                        // backward: L^T x = y
+        const int j0 = blk * kCholNB, nb = std::min(kCholNB, k - j0);
+        const T *Li = Linv + (size_t)blk * kCholNB * kCholNB;
+        Operand R, B;
+        R.ptr = rhs + j0; R.si = k; R.sk = 1;
+        B.ptr = Li; B.si = 1; B.sk = nb;                               // (r, c) -> Linv[c][r]
+        EpiStore<T> ex{rhs + j0, k, (T)1};
+        MODL_TRY((launch_gemm<T, EpiStore<T>>(stream, R, B, b, nb, nb, ex, none, nullptr, 512, 1)));
+        if (j0 == 0) break;
+        Operand Lr;
+        Lr.ptr = F + j0; Lr.si = k; Lr.sk = 1;                          // (m, r) -> L[j0 + r][m] = F[m][j0 + r]
+        EpiAxpby<T> eu{rhs, k, (T)-1, (T)1};
+        MODL_TRY((launch_gemm<T, EpiAxpby<T>>(stream, R, Lr, b, j0, nb, eu, none, nullptr, 512, 1)));
+    }
+    return MODL_OK;
+}
+
+size_t chol_wide_scratch_elems(int k) { return k > 512 ? (size_t)cdiv(k, kCholNB) * kCholNB * kCholNB : 0; }
+
+// The ridge solve for k > 512: shared Gram (f_stride == 0: one factorisation, all right-hand sides at once) or one
+// Gram per sample (a factorisation and a single right-hand side each - as slow, relatively, as the reference's b
+// separate posv calls, dict_fact_fast.pyx:82-94).  F: k*k (or b*k*k is NOT needed: one factor is reused), Linv:
+// chol_wide_scratch_elems(k).  Solutions are left in rhs and scattered to code rows idx.
+template <typename T>
+int ridge_solve_wide(hipStream_t stream, const T *G, int64_t g_stride, const int64_t *h_gidx, T *F, T *Linv, T *rhs, int b,
+                     int k, T alpha, T *code, const int64_t *d_idx) {
+    if (g_stride == 0) {
+        MODL_TRY(cholesky_blocked<T>(stream, G, F, Linv, k, alpha));
+        MODL_TRY(chol_solve_blocked<T>(stream, F, Linv, rhs, b, k));
+    } else {
+        for (int i = 0; i < b; ++i) {
+            const T *g = G + (h_gidx ? h_gidx[i] : (int64_t)i) * g_stride;
+            MODL_TRY(cholesky_blocked<T>(stream, g, F, Linv, k, alpha));
+            MODL_TRY(chol_solve_blocked<T>(stream, F, Linv, rhs + (size_t)i * k, 1, k));
+        }
+    }
+    hipLaunchKernelGGL((scatter_rows_any_kernel<T>), dim3((unsigned)b), dim3(256), 0, stream, code, (int64_t)k, d_idx, b, k, rhs);
+    MODL_LAUNCH_CHECK();
+    return MODL_OK;
+}
+template int ridge_solve_wide<float>(hipStream_t, const float *, int64_t, const int64_t *, float *, float *, float *, int, int,
+                                     float, float *, const int64_t *);
+template int ridge_solve_wide<double>(hipStream_t, const double *, int64_t, const int64_t *, double *, double *, double *, int,
+                                      int, double, double *, const int64_t *);
 
 }  // namespace modl

@@ -40,6 +40,15 @@ template <typename T>
 int launch_chol_solve(hipStream_t stream, const T *F, int64_t f_stride, T *rhs, int b, int k, T *code,
                       const int64_t *idx);
 
+// wide systems (k > 512): blocked factorisation + substitutions on the matrix cores.  G: shared (g_stride == 0) or
+// one Gram per sample at G + h_gidx[i] * g_stride (HOST index array, or null = i); F: k*k scratch; Linv:
+// chol_wide_scratch_elems(k) scratch; rhs[b][k]: right-hand sides, overwritten by the solutions, which are also
+// written to code rows d_idx (device, or null = row i).
+size_t chol_wide_scratch_elems(int k);
+template <typename T>
+int ridge_solve_wide(hipStream_t stream, const T *G, int64_t g_stride, const int64_t *h_gidx, T *F, T *Linv, T *rhs, int b,
+                     int k, T alpha, T *code, const int64_t *d_idx);
+
 // ---- enet.hip ---------------------------------------------------------------
 template <typename T>
 int launch_enet_norm(hipStream_t stream, const T *v, int64_t rows, int64_t n, int64_t ld, int64_t inc, T l1_ratio,

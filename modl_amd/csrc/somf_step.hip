@@ -168,7 +168,7 @@ struct modl_somf_plan {
     // device arena
     char *dws = nullptr;
     size_t dws_bytes = 0;
-    size_t off_params, off_xnorm, off_Dx, off_H0, off_G, off_F, off_split, off_du, off_sweeps, off_Ds, off_Xs, off_codeb, off_level;
+    size_t off_params, off_xnorm, off_Dx, off_H0, off_G, off_F, off_Linv, off_split, off_du, off_sweeps, off_Ds, off_Xs, off_codeb, off_level;
     int last_b = 0;
     int64_t last_s = 0;
     size_t split_bytes, du_bytes, params_bytes;
@@ -224,7 +224,6 @@ int validate_desc(const modl_somf_desc *d) {
     if (d->optimizer != MODL_OPT_VARIATIONAL && d->optimizer != MODL_OPT_SGD) return MODL_EINVAL;
     if (!(d->code_l1_ratio >= 0.0 && d->code_l1_ratio <= 1.0)) return MODL_EINVAL;
     if (!(d->comp_l1_ratio >= 0.0 && d->comp_l1_ratio <= 1.0)) return MODL_EINVAL;
-    if (d->code_l1_ratio == 0.0 && d->k > 512) return MODL_EINVAL;
     return MODL_OK;
 }
 
@@ -338,9 +337,22 @@ int gram_of_rows(modl_somf_plan *pl, hipStream_t st, const T *Dt, const int32_t 
 template <typename T>
 int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride, const int64_t *g_idx, T *Dx,
                 const T *xnorm2, T *code, const int64_t *d_idx, int b, int32_t *d_sweeps, int *nl, T *H0buf, T *Fbuf,
-                T *scatter_dst = nullptr, const int64_t *scatter_idx = nullptr) {
+                T *scatter_dst = nullptr, const int64_t *scatter_idx = nullptr, const int64_t *h_gidx = nullptr) {
     const modl_somf_desc &d = pl->d;
     const int k = d.k;
+    if (d.code_l1_ratio == 0.0 && k > 512) {                          // wide ridge systems: blocked, on the matrix cores
+        if (g_stride && g_idx && !h_gidx) return MODL_EINVAL;         // per-sample Grams are walked from the host
+        T *Linv = reinterpret_cast<T *>(pl->dws + pl->off_Linv);
+        MODL_TRY(ridge_solve_wide<T>(st, G, g_stride, h_gidx, Fbuf, Linv, Dx, b, k, (T)d.code_alpha, code, d_idx));
+        *nl += 2;
+        if (scatter_dst) {
+            hipLaunchKernelGGL((scatter_rows_T_kernel<T, int64_t>), dim3((unsigned)b), dim3(256), 0, st, scatter_dst,
+                               (int64_t)k, scatter_idx, (int64_t)b, (int64_t)k, Dx, (int64_t)k);
+            MODL_LAUNCH_CHECK();
+            ++*nl;
+        }
+        return MODL_OK;
+    }
     if (d.code_l1_ratio == 0.0) {                                     // ridge: dict_fact_fast.pyx:82-94, 174-197
         const int nmat = g_stride ? b : 1;
         MODL_TRY(launch_cholesky<T>(st, G, g_stride, g_idx, Fbuf, k, (T)d.code_alpha, nmat));
@@ -543,7 +555,7 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         if (d.G_agg == MODL_AGG_AVERAGE) {                            // per-sample Gram = rows idx of G_average_
             const T *Gavg = static_cast<const T *>(stt->d_G_average);
             MODL_TRY(solve_codes<T>(pl, st, Gavg, (int64_t)k * k, d_idx, Dx, xnorm, code, d_idx, b, d_sweeps,
-                                    &ps.launches, H0, Fbuf));
+                                    &ps.launches, H0, Fbuf, nullptr, nullptr, bt->h_sample_idx));
         } else {
             const T *G = (d.G_agg == MODL_AGG_FULL) ? static_cast<const T *>(stt->d_G) : Gbuf;
             if (cd_on_compact) {     // solve on the compact rows, the solver also writes code_[idx]
@@ -726,8 +738,11 @@ int enet_regression_abi(const T *G, int64_t g_stride, T *Dx, const T *X, int64_t
     T *xnorm = reinterpret_cast<T *>(w);
     T *H0 = reinterpret_cast<T *>(w + align_up(sizeof(T) * (size_t)b, 256));
     T *F = reinterpret_cast<T *>(w + align_up(sizeof(T) * (size_t)b, 256) + align_up(sizeof(T) * (size_t)b * k, 256));
+    if (l1_ratio == 0 && k > 512) {
+        T *Linv = F + (size_t)k * k;
+        return ridge_solve_wide<T>(st, G, g_stride, nullptr, F, Linv, Dx, (int)b, (int)k, alpha, code, d_indices);
+    }
     if (l1_ratio == 0) {
-        if (k > 512) return MODL_EINVAL;
         const int nmat = g_stride ? (int)b : 1;
         MODL_TRY(launch_cholesky<T>(st, G, g_stride, nullptr, F, (int)k, alpha, nmat));
         return launch_chol_solve<T>(st, F, g_stride ? k * k : 0, Dx, (int)b, (int)k, code, d_indices);
@@ -767,7 +782,7 @@ size_t modl_enet_regression_workspace(int dtype, int64_t b, int64_t k, int multi
     const size_t t = dtype == MODL_F32 ? 4 : 8;
     if (b < 0 || k < 0) return 0;
     return align_up(t * (size_t)b, 256) + align_up(t * (size_t)b * k, 256) +
-           align_up(t * (size_t)k * k * (multi_gram ? (size_t)b : 1), 256);
+           align_up(t * ((size_t)k * k * ((multi_gram && k <= 512) ? (size_t)b : 1) + modl::chol_wide_scratch_elems((int)k)), 256);
 }
 
 #define ABI_REG(SFX, T)                                                                                            \
@@ -823,7 +838,8 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     pl->off_pos = take(sizeof(int32_t) * p);   // ... and its index in that minibatch's subset
     pl->off_gstamps = take(sizeof(unsigned long long) * 8);   // diagnostics (modl_somf_debug_gemm_stamps)
     const bool per_sample = desc->G_agg == MODL_AGG_AVERAGE;
-    pl->off_F = take(t * k * k * (per_sample ? b : 1));                // Cholesky factors (one per sample for G_average_)
+    pl->off_F = take(t * k * k * ((per_sample && k <= 512) ? b : 1)); // Cholesky factors (one per sample for G_average_)
+    pl->off_Linv = take(t * chol_wide_scratch_elems(desc->k));        // inverted diagonal blocks (wide ridge systems)
     // split-K partial tiles: the largest split product is max(b, k) x k (Dx, Gram, C increment) with
     // up to 64 splits; the p x k product (B increment) has >= 512 tiles at p >= 8k and is not split
     pl->split_bytes = t * std::max(b, k) * k * 64;

@@ -58,6 +58,9 @@ class HipBackend:
 
     # -- allocation ---------------------------------------------------------
     def allocate(self, desc_kwargs, n_samples, p, k, dtype):
+        if k > 1024:
+            raise ValueError('modl_amd supports n_components <= 1024 (the code solvers keep a sample\'s %d coefficients in '
+                             'the registers of one wavefront); got %d' % (1024, k))
         self.dtype = np.dtype(dtype)
         self.k, self.p, self.n = k, p, n_samples
         td, dev = torch_dtype(dtype), self.device

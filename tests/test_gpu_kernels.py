@@ -223,3 +223,32 @@ def test_predict_csr_matches_dense(oracle):
     oracle.predict_csr(exp, X.indices, X.indptr, P, Q)
     np.testing.assert_allclose(data.cpu().numpy(), exp, rtol=1e-13)
     np.testing.assert_allclose(exp, P.dot(Q)[mask], rtol=1e-13)
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+@pytest.mark.parametrize('k', [520, 1024])
+def test_ridge_wide_systems_vs_oracle(fast, oracle, dt, k):
+    """k > 512 (the reference's HCP experiment runs fMRIDictFact - ridge codes - at n_components = 1024,
+    exps/hcp/decompose_hcp.py:50-60): blocked Cholesky + blocked substitutions on the matrix cores, shared Gram and
+    one Gram per sample, against LAPACK posv through the oracle."""
+    rs = np.random.RandomState(k)
+    b, p = 7, k + 200
+    D = rs.randn(k, p).astype(dt)
+    X = np.ascontiguousarray(rs.randn(b, p).astype(dt))
+    G = np.ascontiguousarray((D.dot(D.T) / p).astype(dt))
+    G = (G + G.T) / 2
+    Dx = np.ascontiguousarray((X.dot(D.T) / p).astype(dt))
+    idx = np.arange(b, dtype=np.int64)[::-1].copy()
+    alpha = 0.1
+    c1, c2 = np.ones((b + 2, k), dtype=dt), np.ones((b + 2, k), dtype=dt)
+    fast._enet_regression_single_gram(G, Dx.copy(), X, c1, idx, 0.0, alpha, False, 1e-2, 100)
+    oracle.enet_regression_single_gram(G, Dx.copy(), X, c2, idx, 0.0, alpha, False, 1e-2, 100)
+    tol = 2e-4 if dt == np.float32 else 1e-9
+    assert rel_fro(c1, c2) < tol, (k, rel_fro(c1, c2))
+    assert np.all(c1[b:] == 1)
+    Gm = np.ascontiguousarray(np.stack([G * (1 + 0.05 * j) for j in range(3)]).astype(dt))
+    c1, c2 = np.ones((3, k), dtype=dt), np.ones((3, k), dtype=dt)
+    i3 = np.arange(3, dtype=np.int64)
+    fast._enet_regression_multi_gram(Gm.copy(), Dx[:3].copy(), X[:3], c1, i3, 0.0, alpha, False, 1e-2, 100)
+    oracle.enet_regression_multi_gram(Gm.copy(), Dx[:3].copy(), X[:3], c2, i3, 0.0, alpha, False, 1e-2, 100)
+    assert rel_fro(c1, c2) < tol, (k, rel_fro(c1, c2))

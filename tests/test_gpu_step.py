@@ -218,6 +218,17 @@ def test_midsize_variants_vs_oracle(DictFact, oracle, variant):
         assert rel_fro(est.G_, st.G) < 1e-9
 
 
+@pytest.mark.parametrize('agg', ['masked', 'average'])
+def test_wide_ridge_estimator_vs_oracle(DictFact, oracle, agg):
+    """fMRIDictFact's configuration (ridge codes, l1 atoms) at n_components = 600 > 512 through the estimator:
+    the blocked ridge solve inside the minibatch step (shared Gram, and one Gram per sample for 'average')."""
+    extra = dict(code_l1_ratio=0, comp_l1_ratio=1, code_alpha=1e-2, G_agg=agg, Dx_agg=agg)
+    b = 12 if agg == 'masked' else 4
+    est, st = _one_step_pair(DictFact, oracle, np.float64, n=640, p=900, k=600, b=b, r=2, steps=2, **extra)
+    eD, eC = rel_fro(est.components_, st.D), rel_fro(est.code_[:2 * b], st.code[:2 * b])
+    assert eD < 1e-9 and eC < 1e-9, (agg, eD, eC)
+
+
 @pytest.mark.parametrize('variant', ['fmri', 'fmri_pos', 'enet', 'nmf_l1'])
 @pytest.mark.parametrize('shape', ['groups', 'groups_ragged', 'per_atom'])
 def test_generic_dictionary_update_multi_workgroup_vs_oracle(DictFact, oracle, variant, shape):
