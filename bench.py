@@ -258,7 +258,9 @@ def run_gpu(args, reduction, steps, warmup, rank, world, device, breakdown=True)
         if warmup - w_head > 0 and pre:
             dom = max(pre, key=lambda n: pre[n]['ms'])
         be.prof_enable(False)
-        be.prof_enable(True, sections=[dom])
+        # events around the dominant section only, and on one minibatch in four: an event pair is a stream bubble
+        # of ~9 us (scripts/step_timeline.py on a rocprofv3 trace), i.e. 3 % of a step if every step paid it
+        be.prof_enable(True, sections=[dom], every=4 if steps >= 16 else 1)
         be.prof_reset()
     dt, enq = timed(run, steps, world)
     res = dict(dt=dt, enqueue_ms_per_step=enq / steps * 1e3, dom=dom, prof_dom=None, prof={})

@@ -394,6 +394,9 @@ typedef struct modl_prof_entry {
     int64_t calls;       /* timed regions accumulated */
 } modl_prof_entry;
 int modl_somf_prof_enable(modl_somf_plan *plan, int enable);
+/* record the section events on every `every`-th minibatch only (each recorded section costs two event records, a
+ * stream bubble of several microseconds: sampling keeps the timed region undisturbed) */
+int modl_somf_prof_stride(modl_somf_plan *plan, int every);
 int modl_somf_prof_get(modl_somf_plan *plan, modl_prof_entry *out, int cap, int *n_out);
 int modl_somf_prof_reset(modl_somf_plan *plan);
 

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <sched.h>
 #include <new>
 #include <vector>
 
@@ -177,8 +178,9 @@ struct modl_somf_plan {
     // pinned staging ring
     char *hstage[kStageSlots] = {nullptr};
     char *hstage_dev[kStageSlots] = {nullptr};   // device-side addresses of the pinned slots
-    hipEvent_t hev[kStageSlots] = {nullptr};
-    bool hev_used[kStageSlots] = {false};
+    // slot protection without a stream event (a hipEventRecord between two kernels costs ~5 us of bubble, measured):
+    // the staging kernel acknowledges a slot by writing its use count into the slot's last 8 bytes (host memory)
+    unsigned long long slot_uses[kStageSlots] = {0};
     int slot = 0;
     // currently staged batch
     bool staged = false;
@@ -195,6 +197,8 @@ struct modl_somf_plan {
     int32_t step_id = 0;
     size_t off_stamp = 0, off_pos = 0, off_gstamps = 0;
     unsigned prof_mask = ~0u;          // sections that record events
+    int prof_stride = 1;               // ... on every prof_stride-th minibatch only (an event pair costs ~9 us of bubble)
+    long prof_step = 0;
     std::vector<hipEvent_t> pev;       // 2 * kProfPool events
     std::vector<int> psec, plaunch;
     int pcount = 0;
@@ -234,6 +238,7 @@ struct ProfScope {
     int launches = 0;
     ProfScope(modl_somf_plan *p, hipStream_t s, int section) : pl(p), st(s), sec(section) {
         if (!pl->prof || !((pl->prof_mask >> section) & 1u)) return;
+        if (pl->prof_stride > 1 && (pl->prof_step % pl->prof_stride) != 0) return;
         if (pl->pcount >= kProfPool) return;           // pool full until the next prof_get/reset
         idx = pl->pcount++;
         (void)hipEventRecord(pl->pev[2 * idx], st);
@@ -262,8 +267,31 @@ int prof_flush(modl_somf_plan *pl) {
 // Parameter block: pinned host slot -> HBM by a kernel that reads the (device-mapped) pinned memory over
 // the host link.  A hipMemcpyAsync here would hop to the copy engine and back between two kernels of the
 // same stream, which costs several times the kernel floor.
-__global__ __launch_bounds__(256) void stage_params_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+// ONE workgroup copies the USED ranges of the slot (sample indices, subset, order, sample weights: a few KB of the
+// p-sized block); when all its loads have landed the slot may be overwritten by the host, which thread 0 tells it
+// by writing the slot's use count into the acknowledgement word of the slot itself (host memory, system scope).
+struct StageRanges { unsigned int off16[4], n16[4]; };
+__global__ __launch_bounds__(1024) void stage_params_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, StageRanges rg,
+                                                            unsigned long long *ack, unsigned long long use) {
+    constexpr int kMax = 4;                                      // 4 x 1024 x 16 B = 64 KB per round of loads
+    for (int r = 0; r < 4; ++r) {
+        const size_t n16 = rg.n16[r], o = rg.off16[r];
+        for (size_t base = 0; base < n16; base += (size_t)kMax * 1024) {
+            uint4 v[kMax];
+#pragma unroll
+            for (int u = 0; u < kMax; ++u) {                      // all loads of the round first (clamped, no branch)
+                const size_t e = base + threadIdx.x + (size_t)u * 1024;
+                v[u] = src[o + (e < n16 ? e : n16 - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < kMax; ++u) {
+                const size_t e = base + threadIdx.x + (size_t)u * 1024;
+                if (e < n16) dst[o + e] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(ack, use, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // copy the per-batch host arrays into the device parameter block through a pinned slot
@@ -276,8 +304,16 @@ int stage_batch(modl_somf_plan *pl, const modl_somf_batch *bt, hipStream_t st) {
     if ((d.G_agg == MODL_AGG_AVERAGE || d.Dx_agg == MODL_AGG_AVERAGE) && !bt->h_w_sample) return MODL_EINVAL;
     const int slot = pl->slot;
     pl->slot = (slot + 1) % kStageSlots;
-    if (pl->hev_used[slot]) MODL_HIP(hipEventSynchronize(pl->hev[slot]));
     char *h = pl->hstage[slot];
+    {   // the previous use of this slot (kStageSlots minibatches ago) must have been read by its staging kernel
+        volatile unsigned long long *ack = reinterpret_cast<volatile unsigned long long *>(h + align_up(pl->params_bytes, 16));
+        for (long spins = 0; *ack < pl->slot_uses[slot]; ++spins) {
+            if (spins > 64) {                                  // (rare: the host is 8 minibatches ahead of the device)
+                if (hipStreamQuery(st) == hipSuccess && *ack < pl->slot_uses[slot]) return MODL_ESTATE;
+                sched_yield();
+            }
+        }
+    }
     pl->has_idx = bt->h_sample_idx != nullptr;
     if (pl->has_idx) {
         for (int i = 0; i < bt->b; ++i)
@@ -305,15 +341,22 @@ int stage_batch(modl_somf_plan *pl, const modl_somf_batch *bt, hipStream_t st) {
     }
     if (bt->h_w_sample) std::memcpy(h + pl->po_wsample, bt->h_w_sample, pl->tsz * (size_t)bt->b);
     {
-        const size_t n16 = (pl->params_bytes + 15) / 16;
-        unsigned grid = (unsigned)((n16 + 255) / 256);
-        if (grid > 64) grid = 64;
-        hipLaunchKernelGGL(stage_params_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint4 *>(pl->hstage_dev[slot]),
-                           reinterpret_cast<uint4 *>(pl->dws + pl->off_params), n16);
+        // the sections of the block start on 64-byte boundaries (params_layout): whole 16-byte words of each
+        StageRanges rg;
+        auto range = [&](int i, size_t off, size_t bytes) {
+            rg.off16[i] = (unsigned int)(off / 16);
+            rg.n16[i] = (unsigned int)((bytes + 15) / 16);
+        };
+        range(0, pl->po_idx, pl->has_idx ? sizeof(int64_t) * (size_t)bt->b : 0);
+        range(1, pl->po_subset, pl->has_subset ? sizeof(int32_t) * (size_t)bt->s : 0);
+        range(2, pl->po_order, sizeof(int32_t) * (size_t)d.k);
+        range(3, pl->po_wsample, bt->h_w_sample ? pl->tsz * (size_t)bt->b : 0);
+        const unsigned long long use = ++pl->slot_uses[slot];
+        hipLaunchKernelGGL(stage_params_kernel, dim3(1), dim3(1024), 0, st, reinterpret_cast<const uint4 *>(pl->hstage_dev[slot]),
+                           reinterpret_cast<uint4 *>(pl->dws + pl->off_params), rg,
+                           reinterpret_cast<unsigned long long *>(pl->hstage_dev[slot] + align_up(pl->params_bytes, 16)), use);
         MODL_LAUNCH_CHECK();
     }
-    MODL_HIP(hipEventRecord(pl->hev[slot], st));
-    pl->hev_used[slot] = true;
     pl->staged = true;
     return MODL_OK;
 }
@@ -430,6 +473,7 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
     if (d.G_agg == MODL_AGG_AVERAGE && !stt->d_G_average) return MODL_EINVAL;
     if (d.Dx_agg == MODL_AGG_AVERAGE && !stt->d_Dx_average) return MODL_EINVAL;
     MODL_TRY(stage_batch<T>(pl, bt, st));
+    ++pl->prof_step;
     char *P = pl->dws + pl->off_params;
     const int64_t *d_idx = pl->has_idx ? reinterpret_cast<const int64_t *>(P + pl->po_idx) : nullptr;
     const int32_t *d_subset = pl->has_subset ? reinterpret_cast<const int32_t *>(P + pl->po_subset) : nullptr;
@@ -855,9 +899,9 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     if (e == hipSuccess) e = hipMemset(pl->dws + pl->off_level, 0, sizeof(double) * k);
     if (e != hipSuccess) { modl_somf_plan_destroy(pl); return (int)e; }
     for (int i = 0; i < kStageSlots; ++i) {
-        e = hipHostMalloc((void **)&pl->hstage[i], align_up(pl->params_bytes, 16), hipHostMallocMapped);
+        e = hipHostMalloc((void **)&pl->hstage[i], align_up(pl->params_bytes, 16) + 64, hipHostMallocMapped);   // + acknowledgement word
         if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&pl->hstage_dev[i], pl->hstage[i], 0);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->hev[i], hipEventDisableTiming);
+        if (e == hipSuccess) std::memset(pl->hstage[i] + align_up(pl->params_bytes, 16), 0, 64);
         if (e != hipSuccess) { modl_somf_plan_destroy(pl); return (int)e; }
     }
     *out = pl;
@@ -870,7 +914,6 @@ void modl_somf_plan_destroy(modl_somf_plan *pl) {
     if (pl->Bsum) (void)hipFree(pl->Bsum);
     for (int i = 0; i < kStageSlots; ++i) {
         if (pl->hstage[i]) (void)hipHostFree(pl->hstage[i]);
-        if (pl->hev[i]) (void)hipEventDestroy(pl->hev[i]);
     }
     for (hipEvent_t ev : pl->pev) (void)hipEventDestroy(ev);
     delete pl;
@@ -1017,6 +1060,12 @@ int modl_somf_prof_enable(modl_somf_plan *pl, int enable) {
     if (!enable && pl->prof) MODL_TRY(prof_flush(pl));
     pl->prof = enable != 0;
     pl->prof_mask = (enable == 1 || enable == 0) ? ~0u : ((unsigned)enable >> 1);
+    return MODL_OK;
+}
+
+int modl_somf_prof_stride(modl_somf_plan *pl, int every) {
+    if (!pl || every < 1) return MODL_EINVAL;
+    pl->prof_stride = every;
     return MODL_OK;
 }
 

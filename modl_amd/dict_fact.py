@@ -307,8 +307,10 @@ class HipBackend:
     # -- profiling ------------------------------------------------------------
     PROF_SECTIONS = ('code_gemm', 'code_solve', 'stats_gemm', 'stats_apply', 'dict_update')
 
-    def prof_enable(self, on=True, sections=None):
-        """Time the step's sections with HIP events; `sections` restricts the events to the named ones."""
+    def prof_enable(self, on=True, sections=None, every=1):
+        """Time the step's sections with HIP events; `sections` restricts the events to the named ones, `every`
+        to one minibatch in `every`."""
+        check(lib.modl_somf_prof_stride(self.plan, int(every)))
         flag = int(bool(on))
         if on and sections is not None:
             flag = 0

@@ -177,7 +177,15 @@ def test_fmri_loop_gpu_vs_reference_golden(name):
     """fMRIDictFact on the GPU path against the reference's own record loop."""
     kw, recs, dict_init, want, dn = _fmri_golden_case(name)
     est = _fmri_estimator(False)(dict_init=dict_init, **kw).fit(recs)
-    assert rel_fro(est.components_, want) < (1e-9 if dn == 'f64' else 2e-4), name
+    got = est.components_
+    if dn == 'f32':
+        # _flip (fmri.py:549-556) turns a map over when it has more negative than positive entries: on sparse f32
+        # maps that count can tie up to rounding, so f32 maps are compared up to that sign (f64 exactly)
+        for comp, ref in zip(got, want):
+            assert np.sum(comp < 0) <= np.sum(comp > 0)
+            if np.linalg.norm(comp + ref) < np.linalg.norm(comp - ref):
+                comp *= -1
+    assert rel_fro(got, want) < (1e-9 if dn == 'f64' else 2e-4), name
 
 
 def _check_fmri_case(kw, host, with_init=True):
