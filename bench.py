@@ -222,9 +222,10 @@ def timed(run, steps, world):
         dist.barrier()
     run.sync()
     run.enqueue_s = 0.0
+    run.be.host_wait_ms()
     t0 = time.perf_counter()
     run.fit(steps)
-    enq = run.enqueue_s
+    enq = run.enqueue_s - run.be.host_wait_ms() * 1e-3     # net of the time the host waited for the device (8-deep ring)
     run.sync()
     if world > 1:
         dist.barrier()
@@ -292,11 +293,20 @@ def run_gpu(args, reduction, steps, warmup, rank, world, device, breakdown=True)
 def steady_state(args, reduction, rank, world, device, steps, burn_in):
     """>= 2000 fresh-row minibatches after a burn-in, no events on the stream."""
     import torch
-    run = Run(args, reduction, rank, world, device, steps + burn_in)
+    run = Run(args, reduction, rank, world, device, steps + burn_in + 48)
     run.fit(burn_in)
     dt, enq = timed(run, steps, world)
     lsw = run.be.last_sweeps()
-    return dict(reduction=reduction, steps=steps, burn_in=burn_in, value=steps * BATCH * world / dt, unit='samples/s',
+    be = run.be                                               # section breakdown: 48 more minibatches, outside the timed region
+    be.prof_enable(True)
+    be.prof_reset()
+    run.fit(48)
+    run.sync()
+    prof = be.prof_get()
+    be.prof_enable(False)
+    sections = {n: dict(ms_per_step=e['ms'] / e['calls'], launches_per_step=e['launches'] / e['calls'])
+                for n, e in prof.items() if e['calls']}
+    return dict(reduction=reduction, sections=sections, steps=steps, burn_in=burn_in, value=steps * BATCH * world / dt, unit='samples/s',
                 ms_per_step=dt / steps * 1e3, host_enqueue_ms_per_step=enq / steps * 1e3,
                 cd_sweeps_mean=float(lsw.mean()), cd_sweeps_max=int(lsw.max()),
                 finite=bool(torch.isfinite(run.be.Dt).all().item()), rows_fitted=run.row,
@@ -388,6 +398,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=500)
     ap.add_argument('--reduction', type=float, default=10.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-breakdown', action='store_true', help='no HIP events at all on the stream (for kernel-trace timelines)')
     ap.add_argument('--steady-steps', type=int, default=2000, help='fresh-row steps of each steady_state record (0: skip)')
     ap.add_argument('--steady-burn-in', type=int, default=500)
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to test the N > 1 path)')
@@ -415,7 +426,7 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    res = run_gpu(args, args.reduction, args.steps, args.warmup, rank, world, device)
+    res = run_gpu(args, args.reduction, args.steps, args.warmup, rank, world, device, breakdown=not args.no_breakdown)
     steady = []
     if args.steady_steps > 0:
         for r in (10.0, 1.0):

@@ -394,6 +394,9 @@ typedef struct modl_prof_entry {
     int64_t calls;       /* timed regions accumulated */
 } modl_prof_entry;
 int modl_somf_prof_enable(modl_somf_plan *plan, int enable);
+/* host time (ms) the calls of this plan have spent waiting for a free staging slot, i.e. for the device: the
+ * host runs at most 8 minibatches ahead.  Host enqueue time minus this is what the host itself needs. */
+int modl_somf_host_wait_ms(modl_somf_plan *plan, double *out, int reset);
 /* record the section events on every `every`-th minibatch only (each recorded section costs two event records, a
  * stream bubble of several microseconds: sampling keeps the timed region undisturbed) */
 int modl_somf_prof_stride(modl_somf_plan *plan, int every);

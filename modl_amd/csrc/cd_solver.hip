@@ -16,9 +16,8 @@
 //   * dense: the update formula of a coordinate is evaluated by EVERY lane on its
 //     own coefficient (the values of the other lanes are discarded), so no scalar
 //     has to be fetched before the arithmetic; the only cross-lane traffic is the
-//     difference w_new - w_old of the owning lane, read with v_readlane after it, then
-//     the k-wide update H <- fma(w_new - w_old, Q_ii, H) (v_pk_fma_f32): the reference's two
-//     axpy passes (:361-365, :375-378) as one.
+//     pair (w_new, w_old) of the owning lane, read with v_readlane after it, then
+//     the k-wide update H <- fma(w_new, Q_ii, fma(-w_old, Q_ii, H)) (v_pk_fma_f32).
 //     Rows are prefetched through a ring of 8 row buffers;
 //   * sparse (active set): a coordinate with w_ii == 0 whose update stays 0
 //     (|q_ii - H_ii| <= alpha) is a no-op of the reference's sweep (nothing is
@@ -30,7 +29,7 @@
 //     rebuilt from the cursor).  With l1-penalised codes most coordinates are
 //     inactive after the first sweeps: 0.23 us per active coordinate against
 //     14 us for a dense sweep at k = 256.
-// Both kinds of sweep produce the same iterates as each other.  The five reductions of the
+// Both produce the reference's iterates bit for bit.  The five reductions of the
 // gap test are wave shuffles.  b independent problems -> b wavefronts, 4 per
 // workgroup.
 #include "kernels.hpp"
@@ -103,12 +102,9 @@ __device__ __forceinline__ void cd_coord(int L, T (&w)[KPL], T (&H)[KPL], const 
                                          const T (&row)[KPL], T alpha) {
     const T wv = w[C];
     const T xv = cd_coordinate<T, POSITIVE>(H[C], wv, q[C], inv[C], row[C], alpha);
-    // H <- H - w_old Q[ii] + w_new Q[ii] (:361-365, :375-378) as ONE axpy with the difference: one broadcast and
-    // KPL fma instead of two and 2 KPL (the sweep is bound by its instruction count); H is the running product Q w
-    // either way, the two forms differ by one rounding per element
-    const T dd = bcast_lane(xv - wv, L);
+    const T dn = bcast_lane(xv, L), dold = bcast_lane(wv, L);
 #pragma unroll
-    for (int r = 0; r < KPL; ++r) H[r] = fma(dd, row[r], H[r]);
+    for (int r = 0; r < KPL; ++r) H[r] = fma(dn, row[r], fma(-dold, row[r], H[r]));   // :361-365, :375-378
     w[C] = __builtin_amdgcn_inverse_ballot_w64(1ull << L) ? xv : wv;   // lane L only (scalar mask)
 }
 
@@ -208,9 +204,8 @@ __device__ __forceinline__ void cd_step(int L, int lane, T (&w)[KPL], T (&H)[KPL
     const T h = bcast_lane(H[C], L), wo = bcast_lane(w[C], L), qq = bcast_lane(q[C], L), ri = bcast_lane(inv[C], L);
     const T Qcc = bcast_lane(row[C], L);
     const T x = cd_coordinate<T, POSITIVE>(h, wo, qq, ri, Qcc, alpha);
-    const T dd = x - wo;
 #pragma unroll
-    for (int r = 0; r < KPL; ++r) H[r] = fma(dd, row[r], H[r]);
+    for (int r = 0; r < KPL; ++r) H[r] = fma(x, row[r], fma(-wo, row[r], H[r]));
     if (lane == L) w[C] = x;
 }
 
@@ -223,14 +218,15 @@ __device__ __forceinline__ void cd_coord_any(unsigned int ii, bool valid, T (&w)
                                              const T (&inv)[KPL], const T (&row)[KPL], T alpha) {
     const int L = (int)(ii / KPL);
     const unsigned long long lm = (unsigned long long)valid << L;
-    T dd = 0;
+    T dn = 0, dold = 0;
     switch (ii % KPL) {
 #define MODL_CD_CASE(C)                                                                                  \
     case C:                                                                                              \
         if constexpr (C < KPL) {                                                                         \
             const T wv = w[C];                                                                           \
             const T xv = cd_coordinate<T, POSITIVE>(H[C], wv, q[C], inv[C], row[C], alpha);              \
-            dd = bcast_lane(xv - wv, L);                                                                 \
+            dn = bcast_lane(xv, L);                                                                      \
+            dold = bcast_lane(wv, L);                                                                    \
             w[C] = __builtin_amdgcn_inverse_ballot_w64(lm) ? xv : wv;                                    \
         }                                                                                                \
         break;
@@ -239,9 +235,9 @@ __device__ __forceinline__ void cd_coord_any(unsigned int ii, bool valid, T (&w)
         MODL_CD_CASE(12) MODL_CD_CASE(13) MODL_CD_CASE(14) MODL_CD_CASE(15)
 #undef MODL_CD_CASE
     }
-    if (!valid) dd = 0;
+    if (!valid) { dn = 0; dold = 0; }
 #pragma unroll
-    for (int r = 0; r < KPL; ++r) H[r] = fma(dd, row[r], H[r]);   // as cd_coord
+    for (int r = 0; r < KPL; ++r) H[r] = fma(dn, row[r], fma(-dold, row[r], H[r]));   // as cd_coord
 }
 
 // lo[c] = the bits of the coordinates <= ii (coordinate L * KPL + c is bit L of mask c); ii may be -1

@@ -18,6 +18,7 @@
 // features]; the caller sums the head over the ranks (RCCL) and phase 2 runs the identical
 // dictionary update on every rank from the summed head.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <sched.h>
@@ -181,6 +182,7 @@ struct modl_somf_plan {
     // slot protection without a stream event (a hipEventRecord between two kernels costs ~5 us of bubble, measured):
     // the staging kernel acknowledges a slot by writing its use count into the slot's last 8 bytes (host memory)
     unsigned long long slot_uses[kStageSlots] = {0};
+    double wait_ms = 0;                // host time spent waiting for a staging slot (the host is kStageSlots ahead)
     int slot = 0;
     // currently staged batch
     bool staged = false;
@@ -307,11 +309,15 @@ int stage_batch(modl_somf_plan *pl, const modl_somf_batch *bt, hipStream_t st) {
     char *h = pl->hstage[slot];
     {   // the previous use of this slot (kStageSlots minibatches ago) must have been read by its staging kernel
         volatile unsigned long long *ack = reinterpret_cast<volatile unsigned long long *>(h + align_up(pl->params_bytes, 16));
-        for (long spins = 0; *ack < pl->slot_uses[slot]; ++spins) {
-            if (spins > 64) {                                  // (rare: the host is 8 minibatches ahead of the device)
-                if (hipStreamQuery(st) == hipSuccess && *ack < pl->slot_uses[slot]) return MODL_ESTATE;
-                sched_yield();
+        if (*ack < pl->slot_uses[slot]) {                      // the host is kStageSlots minibatches ahead of the device
+            const auto t0 = std::chrono::steady_clock::now();
+            for (long spins = 0; *ack < pl->slot_uses[slot]; ++spins) {
+                if (spins > 64) {
+                    if (hipStreamQuery(st) == hipSuccess && *ack < pl->slot_uses[slot]) return MODL_ESTATE;
+                    sched_yield();
+                }
             }
+            pl->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
     }
     pl->has_idx = bt->h_sample_idx != nullptr;
@@ -1060,6 +1066,13 @@ int modl_somf_prof_enable(modl_somf_plan *pl, int enable) {
     if (!enable && pl->prof) MODL_TRY(prof_flush(pl));
     pl->prof = enable != 0;
     pl->prof_mask = (enable == 1 || enable == 0) ? ~0u : ((unsigned)enable >> 1);
+    return MODL_OK;
+}
+
+int modl_somf_host_wait_ms(modl_somf_plan *pl, double *out, int reset) {
+    if (!pl || !out) return MODL_EINVAL;
+    *out = pl->wait_ms;
+    if (reset) pl->wait_ms = 0;
     return MODL_OK;
 }
 

@@ -318,6 +318,12 @@ class HipBackend:
                 flag |= 1 << (self.PROF_SECTIONS.index(name) + 1)
         check(lib.modl_somf_prof_enable(self.plan, flag))
 
+    def host_wait_ms(self, reset=True):
+        """host time spent waiting for the device (a free staging slot) since the last reset"""
+        out = C.c_double()
+        check(lib.modl_somf_host_wait_ms(self.plan, C.byref(out), int(reset)))
+        return out.value
+
     def prof_reset(self):
         check(lib.modl_somf_prof_reset(self.plan))
 
