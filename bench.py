@@ -189,6 +189,7 @@ class Run:
         if getattr(args, 'force_reduce', False):                 # testing only: the N > 1 step with one rank
             self.est._two_phase = True
             self.est._force_reduce = True
+        self.est._native_rccl = bool(getattr(args, 'native_rccl', False))
         self.be = self.est._backend
         self.row = 0                                              # next unseen row of the stream
         self.enqueue_s = 0.0
@@ -404,6 +405,9 @@ def main():
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to test the N > 1 path)')
     ap.add_argument('--force-reduce', action='store_true',
                     help='testing only: run the multi-GPU step (two phases + RCCL all-reduces) even with one rank')
+    ap.add_argument('--native-rccl', action='store_true',
+                    help='N > 1: the all-reduce issued by the library itself (modl_somf_step_dist, RCCL on the compute stream) '
+                         'instead of torch.distributed')
     ap.add_argument('--share-gpu', action='store_true', help='testing only: every rank uses cuda:0 (needs --backend gloo)')
     args = ap.parse_args()
 

@@ -41,6 +41,8 @@ extern "C" {
 #define MODL_ENOMEM (-2)   /* workspace too small / allocation failed */
 #define MODL_ESTATE (-3)   /* object used in the wrong state */
 #define MODL_ENOGPU (-4)   /* no HIP device available */
+#define MODL_ENORCCL (-5)  /* librccl.so could not be loaded (modl_comm_*) */
+#define MODL_ERCCL (-6)    /* an RCCL call failed */
 
 #define MODL_F32 0
 #define MODL_F64 1
@@ -320,6 +322,22 @@ int modl_somf_code_and_partials(modl_somf_plan *plan, const modl_somf_state *st,
 int modl_somf_head_elems(const modl_somf_plan *plan, int64_t *head_elems);
 int modl_somf_apply_and_update_dict(modl_somf_plan *plan, const modl_somf_state *st,
                                     const modl_somf_batch *bt, const void *d_head, void *stream);
+
+/* The same exchange inside the library: an RCCL communicator (one per process / GPU, as the north star's
+ * "RCCL all-reduce of A_ and B_ over xGMI") and the whole multi-GPU minibatch as ONE call, everything enqueued on
+ * one stream.  librccl.so is resolved at run time (dlopen), MODL_ENORCCL if it is not there.
+ *   rank 0: modl_comm_unique_id(&id); ship the 128 bytes to the other ranks (MPI, a file, torch.distributed ...);
+ *   every rank, with its GPU current: modl_comm_create(&id, rank, world, &comm)   (collective);
+ *   per minibatch: modl_somf_step_dist(plan, &st, &bt, comm, stream);  bt.b_global = rows of the global minibatch. */
+typedef struct { char bytes[128]; } modl_comm_id;          /* ncclUniqueId */
+typedef struct modl_comm modl_comm;
+int modl_comm_unique_id(modl_comm_id *out);
+int modl_comm_create(const modl_comm_id *id, int rank, int world, modl_comm **out);
+void modl_comm_destroy(modl_comm *comm);
+/* in-place sum over the ranks of n elements (dtype MODL_F32 / MODL_F64) of a device buffer, on `stream` */
+int modl_comm_all_reduce_sum(modl_comm *comm, void *d_buf, int64_t n, int dtype, void *stream);
+int modl_somf_step_dist(modl_somf_plan *plan, const modl_somf_state *st, const modl_somf_batch *bt, modl_comm *comm,
+                        void *stream);
 
 /* d_dst[r][0..cols) = d_src[d_idx[r]][0..cols): the row permutations around the path (X = X[permutation] after
  * an epoch, dict_fact.py:309-310; masked_data[permutation], fmri.py:541) on device-resident rows. */

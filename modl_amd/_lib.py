@@ -133,6 +133,11 @@ _sig('modl_somf_code_and_partials', C.c_int, _vp, _P(SomfState), _P(SomfBatch), 
 _sig('modl_somf_apply_and_update_dict', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
 _sig('modl_somf_step', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp)
 _sig('modl_somf_head_elems', C.c_int, _vp, _P(_i64))
+_sig('modl_comm_unique_id', C.c_int, _vp)
+_sig('modl_comm_create', C.c_int, _vp, C.c_int, C.c_int, _P(_vp))
+_sig('modl_comm_destroy', None, _vp)
+_sig('modl_comm_all_reduce_sum', C.c_int, _vp, _vp, _i64, C.c_int, _vp)
+_sig('modl_somf_step_dist', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
 _sig('modl_somf_full_gram', C.c_int, _vp, _vp, _vp, _vp)
 _sig('modl_somf_transform', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp)
 _sig('modl_somf_debug_stamps', C.c_int, _vp, _vp)

@@ -290,6 +290,8 @@ const char *modl_error_string(int code) {
         case MODL_ENOMEM: return "out of memory / workspace too small";
         case MODL_ESTATE: return "invalid state";
         case MODL_ENOGPU: return "no HIP device";
+        case MODL_ENORCCL: return "librccl.so could not be loaded";
+        case MODL_ERCCL: return "RCCL call failed";
         default: return code > 0 ? "HIP runtime error (hipError_t)" : "unknown error";
     }
 }

@@ -21,6 +21,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <sched.h>
 #include <new>
 #include <vector>
@@ -194,6 +195,7 @@ struct modl_somf_plan {
                                        // of B from the (summed) head instead of the rank's partial statistics
     int64_t head_elems = 0;            // k*k + (rows of B in the head) * k
     void *Bsum = nullptr;              // [p][k] (lazily allocated): the summed rows of B_, scattered for the dictionary update
+    void *own_head = nullptr;          // [k*k + p*k] (lazily allocated): the head buffer of modl_somf_step_dist
     bool ride_pending = false;         // single-GPU step: the B_ update of the rows that were not sampled rides along
     StatsRider rider{};                // the dictionary update (see StatsRider)
     int32_t step_id = 0;
@@ -918,6 +920,7 @@ void modl_somf_plan_destroy(modl_somf_plan *pl) {
     if (!pl) return;
     if (pl->dws) (void)hipFree(pl->dws);
     if (pl->Bsum) (void)hipFree(pl->Bsum);
+    if (pl->own_head) (void)hipFree(pl->own_head);
     for (int i = 0; i < kStageSlots; ++i) {
         if (pl->hstage[i]) (void)hipHostFree(pl->hstage[i]);
     }
@@ -980,6 +983,92 @@ int modl_somf_step(modl_somf_plan *pl, const modl_somf_state *st, const modl_som
     MODL_TRY(DISPATCH(pl, phase1<float>(pl, st, bt, nullptr, (hipStream_t)stream, false),
                       phase1<double>(pl, st, bt, nullptr, (hipStream_t)stream, false)));
     return modl_somf_apply_and_update_dict(pl, st, bt, nullptr, stream);
+}
+
+// ---- the collective inside the library: RCCL through its C API, resolved at run time -------------------------------
+// (librccl.so is looked up with dlopen: a process that already holds RCCL - e.g. through torch.distributed - gets that
+// same copy; nothing links against it, so the library loads and every single-GPU entry point works without RCCL)
+namespace {
+struct RcclApi {
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, modl_comm_id, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    bool ok = false;
+};
+RcclApi &rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.handle) break;
+        }
+        if (!a.handle) return a;
+        a.GetUniqueId = reinterpret_cast<int (*)(void *)>(dlsym(a.handle, "ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<int (*)(void **, int, modl_comm_id, int)>(dlsym(a.handle, "ncclCommInitRank"));
+        a.CommDestroy = reinterpret_cast<int (*)(void *)>(dlsym(a.handle, "ncclCommDestroy"));
+        a.AllReduce = reinterpret_cast<int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)>(
+            dlsym(a.handle, "ncclAllReduce"));
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce;
+        return a;
+    }();
+    return api;
+}
+constexpr int kNcclSum = 0, kNcclFloat32 = 7, kNcclFloat64 = 8;      // rccl.h: ncclRedOp_t / ncclDataType_t
+}  // namespace
+
+struct modl_comm {
+    void *nccl = nullptr;
+    int rank = 0, world = 1;
+};
+
+int modl_comm_unique_id(modl_comm_id *out) {
+    if (!out) return MODL_EINVAL;
+    if (!rccl().ok) return MODL_ENORCCL;
+    return rccl().GetUniqueId(out) == 0 ? MODL_OK : MODL_ERCCL;
+}
+
+int modl_comm_create(const modl_comm_id *id, int rank, int world, modl_comm **out) {
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) return MODL_EINVAL;
+    *out = nullptr;
+    if (!rccl().ok) return MODL_ENORCCL;
+    modl_comm *c = new (std::nothrow) modl_comm();
+    if (!c) return MODL_ENOMEM;
+    c->rank = rank; c->world = world;
+    if (rccl().CommInitRank(&c->nccl, world, *id, rank) != 0) { delete c; return MODL_ERCCL; }
+    *out = c;
+    return MODL_OK;
+}
+
+void modl_comm_destroy(modl_comm *c) {
+    if (!c) return;
+    if (c->nccl && rccl().ok) (void)rccl().CommDestroy(c->nccl);
+    delete c;
+}
+
+int modl_comm_all_reduce_sum(modl_comm *c, void *d_buf, int64_t n, int dtype, void *stream) {
+    if (!c || !c->nccl || !d_buf || n < 0 || (dtype != MODL_F32 && dtype != MODL_F64)) return MODL_EINVAL;
+    if (n == 0) return MODL_OK;
+    return rccl().AllReduce(d_buf, d_buf, (size_t)n, dtype == MODL_F32 ? kNcclFloat32 : kNcclFloat64, kNcclSum, c->nccl,
+                            (hipStream_t)stream) == 0 ? MODL_OK : MODL_ERCCL;
+}
+
+int modl_somf_step_dist(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt, modl_comm *comm,
+                        void *stream) {
+    // several GPUs, everything on ONE stream: phase 1 (partial statistics + head), ncclAllReduce of the head in
+    // place, phase 2 (dictionary update from the summed head) - no cross-stream event anywhere
+    if (!pl || !bt || !comm) return MODL_EINVAL;
+    DeviceScope dev(pl);
+    if (!pl->own_head) {
+        const size_t n = (size_t)pl->d.k * pl->d.k + (size_t)pl->d.p * pl->d.k;
+        MODL_HIP(hipMalloc(&pl->own_head, pl->tsz * n));
+    }
+    MODL_TRY(DISPATCH(pl, phase1<float>(pl, st, bt, static_cast<float *>(pl->own_head), (hipStream_t)stream, true),
+                      phase1<double>(pl, st, bt, static_cast<double *>(pl->own_head), (hipStream_t)stream, true)));
+    MODL_TRY(modl_comm_all_reduce_sum(comm, pl->own_head, pl->head_elems, pl->d.dtype, stream));
+    return DISPATCH(pl, phase2<float>(pl, st, bt, static_cast<const float *>(pl->own_head), (hipStream_t)stream),
+                    phase2<double>(pl, st, bt, static_cast<const double *>(pl->own_head), (hipStream_t)stream));
 }
 
 int modl_somf_full_gram(modl_somf_plan *pl, const void *d_Dt, void *d_G, void *stream) {

@@ -121,8 +121,11 @@ class HipBackend:
     def release_all(self):
         self.release_plan()
         if getattr(self, '_pid', None) != os.getpid():
-            self.tplan = None
+            self.tplan = self.comm = None
             return
+        if getattr(self, 'comm', None):
+            lib.modl_comm_destroy(self.comm)
+            self.comm = None
         if getattr(self, 'tplan', None):
             lib.modl_somf_plan_destroy(self.tplan)
             self.tplan = None
@@ -258,6 +261,30 @@ class HipBackend:
         bt, keep = self._batch(Xh, batch, idx, subset, order, w_sample, w, reduction, b_global)
         st = self._state()
         check(lib.modl_somf_step(self.plan, C.byref(st), C.byref(bt), stream_ptr(self.device)), 'modl_somf_step')
+
+    def native_comm(self, dist):
+        """An RCCL communicator owned by the library (modl_comm_*): rank 0 draws the unique id, torch.distributed
+        only ships its 128 bytes."""
+        if getattr(self, 'comm', None) is None:
+            ident = (C.c_char * 128)()
+            if dist.get_rank() == 0:
+                check(lib.modl_comm_unique_id(ident), 'modl_comm_unique_id')
+            box = [bytes(ident.raw)]
+            if dist.get_world_size() > 1:
+                dist.broadcast_object_list(box, src=0)
+            ident = C.create_string_buffer(box[0], 128)
+            h = C.c_void_p()
+            with torch.cuda.device(self.device):
+                check(lib.modl_comm_create(ident, dist.get_rank(), dist.get_world_size(), C.byref(h)), 'modl_comm_create')
+            self.comm = h
+        return self.comm
+
+    def step_dist(self, comm, Xh, batch, idx, subset, order, w_sample, w, reduction, b_global):
+        """Several GPUs, ONE call: phase 1, ncclAllReduce of the head, phase 2 - all on the current stream."""
+        bt, keep = self._batch(Xh, batch, idx, subset, order, w_sample, w, reduction, b_global)
+        st = self._state()
+        check(lib.modl_somf_step_dist(self.plan, C.byref(st), C.byref(bt), comm, stream_ptr(self.device)),
+              'modl_somf_step_dist')
 
     def phase2(self, head):
         """The dictionary update from the summed head (identical on every rank)."""
@@ -782,6 +809,12 @@ class DictFact(CodingMixin, BaseEstimator):
             return
         # Several ranks: every rank keeps its own partial C_ / B_ (both recursions are linear in the increments);
         # only what the dictionary update reads - C_ and the sampled rows of B_ - is summed over the ranks.
+        if getattr(self, '_native_rccl', False) and hasattr(be, 'step_dist'):
+            # the exchange inside the library (modl_somf_step_dist): RCCL called directly, on the compute stream
+            import torch.distributed as dist
+            be.step_dist(be.native_comm(dist), Xh, batch, sample_indices, subset, order, w_sample, w, self.reduction,
+                         b_global)
+            return
         head = be.phase1(Xh, batch, sample_indices, subset, order, w_sample, w, self.reduction, b_global)
         if world > 1 or getattr(self, '_force_reduce', False):       # (the latter: single-rank RCCL test of this path)
             self._all_reduce(head)

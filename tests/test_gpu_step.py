@@ -625,11 +625,12 @@ def _rccl_rank_main(rank, port, kw, X, out):
     try:
         from modl_amd import DictFact as DF
         res = {}
-        for name in ('fused', 'rccl'):
+        for name in ('fused', 'rccl', 'native'):
             est = DF(**kw)
-            if name == 'rccl':
+            if name != 'fused':
                 est._two_phase = True
                 est._force_reduce = True                         # the head really goes through an RCCL all-reduce
+                est._native_rccl = name == 'native'              # ... issued by torch.distributed / by the library itself
             est.prepare(n_samples=X.shape[0], X=X)
             est.partial_fit(X)
             res[name] = dict(D=est.components_, C=est.C_, B=est.B_, code=est.code_)
@@ -659,6 +660,7 @@ def test_rccl_single_rank_two_phase_equals_fused(red):
     mp.spawn(_rccl_rank_main, args=(port, kw, X, out), nprocs=1, join=True)
     for name in ('D', 'C', 'B', 'code'):
         assert_array_equal(out['fused'][name], out['rccl'][name], err_msg=name)
+        assert_array_equal(out['fused'][name], out['native'][name], err_msg='native ' + name)   # modl_somf_step_dist
 
 
 @pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-12), (np.float32, 1e-5)])
