@@ -305,33 +305,44 @@ __device__ __forceinline__ void reduce_records(const double *rec, int n, Sink si
 // version above, 12 wavefront-loads per record, kept the texture unit busy for ~6 k cycles at 32 records; this one
 // needs 5 (four worker wavefronts + the first lanes of the resolver wavefront for the tail of the record).
 // Same summation order, same bits.
-template <int STRIDE, typename Sink>
-__device__ __forceinline__ void reduce_records_v2(const double *rec, int n, int e2, bool valid, Sink sink) {
+template <int STRIDE, int CH, typename Sink>
+__device__ __forceinline__ void reduce_records_chunks(const double *rec, int n, int e2, bool valid, Sink sink) {
     static_assert(STRIDE % 2 == 0, "records are read as double2");
+    static_assert(CH == 16 || CH == 32, "chunks of 16 or 32 records");
     typedef double d2v __attribute__((ext_vector_type(2)));
     const d2v *base = reinterpret_cast<const d2v *>(rec) + (valid ? e2 : 0);
     d2v tot = {0.0, 0.0};
-    for (int z0 = 0; z0 < n; z0 += 16) {
-        d2v v[16];
+    for (int z0 = 0; z0 < n; z0 += CH) {
+        d2v v[CH];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < CH; ++u) {
             const int z = (z0 + u < n) ? z0 + u : n - 1;
             v[u] = base[(int64_t)z * (STRIDE / 2)];
         }
         __builtin_amdgcn_sched_barrier(0);           // all requests first: one memory round trip
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < CH; ++u) {
             v[u].x = (z0 + u < n) ? v[u].x : 0.0;
             v[u].y = (z0 + u < n) ? v[u].y : 0.0;
         }
-        const d2v c = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
-                      (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
-        tot += c;
+#pragma unroll
+        for (int h = 0; h < CH; h += 16) {           // the association of 16 records per round, whatever CH
+            const d2v c = (((v[h + 0] + v[h + 1]) + (v[h + 2] + v[h + 3])) + ((v[h + 4] + v[h + 5]) + (v[h + 6] + v[h + 7]))) +
+                          (((v[h + 8] + v[h + 9]) + (v[h + 10] + v[h + 11])) + ((v[h + 12] + v[h + 13]) + (v[h + 14] + v[h + 15])));
+            tot += c;
+        }
     }
     if (valid) {
         sink(2 * e2, tot.x);
         sink(2 * e2 + 1, tot.y);
     }
+}
+// 17 - 32 records (up to 32 workgroups without pre-summed groups: the metric's shape at reduction 10) in ONE memory
+// round trip; otherwise rounds of 16.  Same sums, same bits either way.
+template <int STRIDE, typename Sink>
+__device__ __forceinline__ void reduce_records_v2(const double *rec, int n, int e2, bool valid, Sink sink) {
+    if (n > 16 && n <= 32) reduce_records_chunks<STRIDE, 32>(rec, n, e2, valid, sink);
+    else reduce_records_chunks<STRIDE, 16>(rec, n, e2, valid, sink);
 }
 struct SinkLds {
     double (*M)[kNB + 1]; double *D2;
@@ -1443,7 +1454,10 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             base.coef_all = coef_all; base.norm_in = reinterpret_cast<const float *>(ws + L.off_norm_in);
             base.norm_out = reinterpret_cast<float *>(a.comp_norm); base.counter = counter;
             base.stamps = reinterpret_cast<unsigned long long *>(counter + kCounters); base.s = s; base.k = k;
-            base.group = (nslab + 31) / 32 > kGroup ? (nslab + 31) / 32 : kGroup;
+            // up to kCounters workgroups: every workgroup sums all records itself in (B) - the pre-summing tail (a
+            // release fence + a serial reduction behind the slowest workgroup of a group) costs more than the second
+            // round of record loads it saves (measured at 32 workgroups: 17.7 -> 15.9 us per launch); beyond, groups
+            base.group = nslab <= kCounters ? nslab : ((nslab + 31) / 32 > kGroup ? (nslab + 31) / 32 : kGroup);
             base.Dt_out = reinterpret_cast<float *>(a.Dt); base.subset = a.subset;
         }
         // deferred statistics product riding along (launches 1 .. nblk carry cdiv(tiles, nblk) tiles each)

@@ -277,22 +277,23 @@ int prof_flush(modl_somf_plan *pl) {
 struct StageRanges { unsigned int off16[4], n16[4]; };
 __global__ __launch_bounds__(1024) void stage_params_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, StageRanges rg,
                                                             unsigned long long *ack, unsigned long long use) {
+    // the ranges as ONE index space, every load of a round requested before the first store: the reads cross the
+    // host link (a few microseconds each way), so a round of loads per range would be four round trips instead of one
     constexpr int kMax = 4;                                      // 4 x 1024 x 16 B = 64 KB per round of loads
-    for (int r = 0; r < 4; ++r) {
-        const size_t n16 = rg.n16[r], o = rg.off16[r];
-        for (size_t base = 0; base < n16; base += (size_t)kMax * 1024) {
-            uint4 v[kMax];
+    const size_t c1 = rg.n16[0], c2 = c1 + rg.n16[1], c3 = c2 + rg.n16[2], total = c3 + rg.n16[3];
+    for (size_t base = 0; base < total; base += (size_t)kMax * 1024) {
+        uint4 v[kMax];
+        size_t at[kMax];
 #pragma unroll
-            for (int u = 0; u < kMax; ++u) {                      // all loads of the round first (clamped, no branch)
-                const size_t e = base + threadIdx.x + (size_t)u * 1024;
-                v[u] = src[o + (e < n16 ? e : n16 - 1)];
-            }
-#pragma unroll
-            for (int u = 0; u < kMax; ++u) {
-                const size_t e = base + threadIdx.x + (size_t)u * 1024;
-                if (e < n16) dst[o + e] = v[u];
-            }
+        for (int u = 0; u < kMax; ++u) {
+            size_t e = base + threadIdx.x + (size_t)u * 1024;
+            e = e < total ? e : total - 1;                        // (clamped, no branch around the load)
+            at[u] = e < c1 ? rg.off16[0] + e : (e < c2 ? rg.off16[1] + (e - c1) : (e < c3 ? rg.off16[2] + (e - c2) : rg.off16[3] + (e - c3)));
+            v[u] = src[at[u]];
         }
+#pragma unroll
+        for (int u = 0; u < kMax; ++u)
+            if (base + threadIdx.x + (size_t)u * 1024 < total) dst[at[u]] = v[u];
     }
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(ack, use, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
