@@ -1,22 +1,35 @@
 #!/bin/bash
 # Regenerates the round's profile artifacts on the GPU box (run through gpurun from the repo root):
-#   bash scripts/make_profiles.sh r01_m
+#   bash scripts/make_profiles.sh r02
 # writes gpurun_out/<tag>_*; copy what is to be judged into profiles/.
-TAG=${1:-r01_x}
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 mkdir -p $OUT /tmp/w
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench.err
-rm -rf /tmp/w/kt; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/w/kt -o t -- python3 $R/bench.py --steps 300 --warmup 100 --no-cpu-baseline > /tmp/w/kt.log 2>&1
-python3 $R/scripts/prof_summary.py $(find /tmp/w/kt -name "*.db" | head -1) 0.5 > $OUT/${TAG}_kernel_trace_bench_r10.txt 2>&1
+# the bench lines: the defaults, and the driver's arguments
+python3 $R/bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
+python3 $R/bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_args.json 2> $OUT/${TAG}_bench_driver_args.err
+# kernel trace of the headline step (reduction 10, then 1): no events on the stream, fresh rows
+for r in 10 1; do
+  rm -rf /tmp/w/kt$r
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/w/kt$r -o t -- python3 $R/bench.py --reduction $r --steps 600 --warmup 400 --no-cpu-baseline --steady-steps 0 --no-breakdown > /tmp/w/kt$r.log 2>&1
+  DB=$(find /tmp/w/kt$r -name "*.db" | head -1)
+  { echo "rocprofv3 --kernel-trace --stats -- python3 bench.py --reduction $r --steps 600 --warmup 400 --no-cpu-baseline --steady-steps 0 --no-breakdown   (second half of the trace)"; python3 $R/scripts/prof_summary.py $DB 0.5; } > $OUT/${TAG}_kernel_trace_bench_r$r.txt 2>&1
+  python3 $R/scripts/step_timeline.py $DB 1 > $OUT/${TAG}_step_timeline_r$r.txt 2>&1
+done
+# HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes
 DBS=""
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/w/pmc_$c; timeout 600 rocprofv3 --kernel-trace --pmc $c -d /tmp/w/pmc_$c -o t -- python3 $R/bench.py --steps 100 --warmup 40 --no-cpu-baseline > /tmp/w/pmc_$c.log 2>&1
+  rm -rf /tmp/w/pmc_$c; timeout 600 rocprofv3 --kernel-trace --pmc $c -d /tmp/w/pmc_$c -o t -- python3 $R/bench.py --steps 100 --warmup 40 --no-cpu-baseline --steady-steps 0 --no-breakdown > /tmp/w/pmc_$c.log 2>&1
   DBS="$DBS $(find /tmp/w/pmc_$c -name '*.db' | head -1)"
 done
 python3 $R/scripts/pmc_summary.py $DBS --json $OUT/${TAG}_pmc_hbm_traffic.json > $OUT/${TAG}_pmc_hbm_traffic.txt 2>&1
 SQC="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS"
-rm -rf /tmp/w/sq; timeout 600 rocprofv3 --kernel-trace --pmc $SQC -d /tmp/w/sq -o t -- python3 $R/bench.py --steps 100 --warmup 40 --no-cpu-baseline > /tmp/w/sq.log 2>&1
+rm -rf /tmp/w/sq; timeout 600 rocprofv3 --kernel-trace --pmc $SQC -d /tmp/w/sq -o t -- python3 $R/bench.py --steps 100 --warmup 40 --no-cpu-baseline --steady-steps 0 --no-breakdown > /tmp/w/sq.log 2>&1
 { echo "rocprofv3 --kernel-trace --pmc $SQC"; echo "(averages over the counter-instance rows of all dispatches; SQ_* cycle counters are in quad-cycles; use the RATIOS)"; echo; python3 $R/scripts/pmc_summary.py $(find /tmp/w/sq -name '*.db' | head -1); } > $OUT/${TAG}_pmc_sq_counters.txt 2>&1
+# config 5's per-GPU shape (p = 200 000, k = 256, b = 256, reduction 12): section times + kernel trace
+python3 $R/scripts/diag_hcp_shape.py > $OUT/${TAG}_c5_shape_sections.txt 2>&1
+rm -rf /tmp/w/c5; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/w/c5 -o t -- python3 $R/scripts/diag_hcp_shape.py > /tmp/w/c5.log 2>&1
+{ tail -8 /tmp/w/c5.log; python3 $R/scripts/prof_summary.py $(find /tmp/w/c5 -name "*.db" | head -1) 0.3; } > $OUT/${TAG}_c5_shape_kernel_trace.txt 2>&1
 ls -la $OUT | grep $TAG

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Kernel traces + host profiles of BASELINE configs 2-4 (scripts/bench_configs.py) on the GPU box:
 #   bash scripts/prof_configs.sh r01_n     -> gpurun_out/<tag>_cfg_*.txt
-TAG=${1:-r01_x}
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 mkdir -p $OUT /tmp/w

@@ -387,3 +387,78 @@ def test_fmri_scorer_gpu(tmp_path):
     with contextlib.redirect_stdout(io.StringIO()):
         est.fit(recs[:2])
     assert all(isinstance(d, torch.Tensor) and d.is_cuda for d in scorer.data)      # resident in HBM
+
+
+# ---- BASELINE configs 2-4 at their real shapes, GPU estimator against the same wrapper loop driven
+# ---- with the oracle's kernels (tests/oracle_backend.py) on a bounded prefix of the input ---------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('channels', [1, 3])
+def test_config2_image_shape_parity(channels):
+    """C2: ImageDictFact, 8 x 8 patches (p = 64 / 192), n_components = 256, b = 100, reduction 10, l1 codes, f64
+    (image.py:34-50 defaults).  k = 256 >> s ~ 6 sampled features: the Gram matrix has rank ~6 and every sample runs
+    into max_iter = 100 sweeps - that regime THROUGH the estimator, 5 minibatches + a shuffled second epoch."""
+    img = synth_image(64, 64, channels, seed=4)
+    kw = dict(patch_size=(8, 8), n_components=256, method='masked', setting='dictionary learning', random_state=0,
+              n_epochs=2, max_patches=500)
+    a = _image_estimator(False)(**kw).fit(img)
+    b = _image_estimator(True)(**kw).fit(img)
+    assert a.n_iter_ == b.n_iter_ == 1000
+    eD, eC = rel_fro(a.components_, b.components_), rel_fro(a.dict_fact_.code_, b.dict_fact_.code_)
+    assert eD < 1e-8 and eC < 1e-8, (eD, eC)
+    assert int(a.dict_fact_._backend.last_sweeps().max()) == 100          # the max_iter regime was really exercised
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-8), (np.float32, 5e-4)])
+def test_config3_fmri_shape_parity(dtype, tol):
+    """C3: fMRIDictFact on 2 records x 176 rows x p = 60 000 voxels, n_components = 70, reduction 12, b = 20, ridge
+    codes + l1 atoms (fmri.py:481-495; f32 is the config's dtype): s = 5000 sampled features -> the atom groups of
+    csrc/bcd.hip (four atoms per launch, register-resident projections)."""
+    rs = np.random.RandomState(0)
+    k, p = 70, 60000
+    maps = np.zeros((k, p))
+    for j in range(k):
+        maps[j, j * (p // k):(j + 1) * (p // k)] = 1.0
+    recs = []
+    for _ in range(2):
+        R = rs.randn(176, k).dot(maps) + 0.01 * rs.randn(176, p)
+        R -= R.mean(axis=1, keepdims=True)
+        R /= R.std(axis=1, keepdims=True)
+        recs.append(np.ascontiguousarray(R.astype(dtype)))
+    init = (maps + rs.randn(k, p)).astype(dtype)
+    kw = dict(method='masked', n_components=k, reduction=12, batch_size=20, alpha=1e-3, learning_rate=0.92,
+              dict_init=init, random_state=0, n_epochs=1)
+    a = _fmri_estimator(False)(**kw).fit(recs)
+    b = _fmri_estimator(True)(**kw).fit(recs)
+    eD = rel_fro(a.dict_fact_.components_, b.dict_fact_.components_)
+    eC = rel_fro(a.dict_fact_.code_, b.dict_fact_.code_)
+    assert eD < tol and eC < tol, (eD, eC)
+
+
+@pytest.mark.gpu
+def test_config4_recsys_shape_parity():
+    """C4: RecsysDictFact, n_components = 50, b = 10, detrend, learning_rate .95 (examples/predict_recsys.py:41-45)
+    on MovieLens-10M-shaped rows (10 677 items, power-law degrees, ~140 ratings per row): 400 rows, against the
+    oracle's restatement of recsys.py (pinned by tests/golden/recsys.npz)."""
+    import scipy.sparse as sp
+    from modl_amd.recsys import RecsysDictFact
+    from oracle import wrappers_oracle as wo
+    rs = np.random.RandomState(0)
+    n_users, n_items = 400, 10677
+    pi = 1.0 / np.arange(1, n_items + 1) ** 0.9
+    pi /= pi.sum()
+    rows, cols = [], []
+    for u in range(n_users):
+        deg = int(np.clip(rs.pareto(1.5) * 60 + 20, 20, 1500))
+        cols.append(rs.choice(n_items, size=deg, replace=False, p=pi))
+        rows.append(np.full(deg, u))
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    vals = rs.randint(1, 11, size=len(rows)) / 2.0
+    X = sp.csr_matrix((vals, (rows, cols)), shape=(n_users, n_items))
+    kw = dict(n_components=50, alpha=1, beta=.1, batch_size=10, detrend=True, learning_rate=.95, n_epochs=1,
+              random_state=0)
+    est = RecsysDictFact(**kw).fit(X)
+    fit = wo.recsys_fit(X, **kw)
+    eD, eC = rel_fro(est.components_, fit['D']), rel_fro(est.code_, fit['code'])
+    assert eD < 1e-8 and eC < 1e-8, (eD, eC)
+    assert rel_fro(est.predict(X).data, wo.recsys_predict(fit, X, True)) < 1e-8
