@@ -405,7 +405,8 @@ def test_config2_image_shape_parity(channels):
     assert a.n_iter_ == b.n_iter_ == 1000
     eD, eC = rel_fro(a.components_, b.components_), rel_fro(a.dict_fact_.code_, b.dict_fact_.code_)
     assert eD < 1e-8 and eC < 1e-8, (eD, eC)
-    assert int(a.dict_fact_._backend.last_sweeps().max()) == 100          # the max_iter regime was really exercised
+    if channels == 1:                                        # s ~ 6 << k: the max_iter regime was really exercised
+        assert int(a.dict_fact_._backend.last_sweeps().max()) == 100
 
 
 @pytest.mark.gpu
