@@ -92,7 +92,10 @@ __device__ __forceinline__ T cd_coordinate(T h, T wo, T qq, T ri, T Qcc, T alpha
     return (tmp - cl) * ri;
 }
 
-constexpr int kCdRing = 8;       // Gram rows in flight in the dense sweep (an L2 hit costs several coordinates)
+// Gram rows in flight in the dense sweep.  A row comes from L2 (the 256 KB matrix does not fit a compute unit's L1):
+// ~600 ns, i.e. more than 8 coordinates of ~45 ns - with 8 rows in flight the wave stalled on every row (30 % of
+// its cycles at s_waitcnt); 16 cover the latency (code solve 90.5 -> 84.5 us at the metric's shape), 32 buy nothing.
+constexpr int kCdRing = 16;
 
 // One coordinate ii = L * KPL + C of a dense sweep.  A zero diagonal skips the coordinate (:357): its
 // working coefficient is 0 and so is its step (inv = 0), both multipliers vanish and H is unchanged bit
@@ -128,6 +131,9 @@ __device__ __forceinline__ void cd_dense_sweep(int lane, int k, T (&w)[KPL], T (
         typedef T vec_t __attribute__((ext_vector_type(V)));
         constexpr int K = 64 * KPL;                                   // VEC: k == 64 * KPL, the row stride is a constant
         const T *next = Q + (int64_t)kCdRing * K + lane * KPL;       // this lane's slice of row ii + kCdRing
+        // (the compiler waits for ALL outstanding rows at the top of every iteration of this loop - s_waitcnt vmcnt(0)
+        // behind the back edge, i.e. also for the row requested one coordinate earlier; unrolling the K / U groups
+        // gives exact waits but 25 KB of straight-line code per sweep that ran 45 % SLOWER, measured)
         for (int g = 0; g < groups; ++g) {
             static_for<U>([&](auto J) {
                 constexpr int j = decltype(J)::value;

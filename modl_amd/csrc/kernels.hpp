@@ -16,7 +16,7 @@ struct CdArgs {
     T *code;               // [n][k]
     const int64_t *idx;    // [b] or null (identity)
     T *code2 = nullptr;    // optional second destination: code2[idx2[i]] = solution i
-    int g_pad_rows = 0;    // rows readable behind G (shared Gram only): >= 8 lets the row prefetch run unclamped
+    int g_pad_rows = 0;    // rows readable behind G (shared Gram only): >= 16 lets the row prefetch run unclamped
     const int64_t *idx2 = nullptr;
     int32_t *sweeps;       // [b] or null
     int b, k;

@@ -426,7 +426,7 @@ int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride
     a.G = G; a.g_stride = g_stride; a.g_idx = g_idx; a.Dx = Dx; a.xnorm2 = xnorm2; a.H0 = H0; a.code = code;
     a.idx = d_idx;
     a.code2 = scatter_dst; a.idx2 = scatter_idx;
-    a.g_pad_rows = (G == reinterpret_cast<const T *>(pl->dws + pl->off_G)) ? 8 : 0;
+    a.g_pad_rows = (G == reinterpret_cast<const T *>(pl->dws + pl->off_G)) ? 16 : 0;
     a.sweeps = d_sweeps; a.b = b; a.k = k;
     a.alpha = (T)((T)d.code_alpha * (T)d.code_l1_ratio);
     a.beta = (T)((double)(T)d.code_alpha * (1.0 - (double)(T)d.code_l1_ratio));
@@ -882,7 +882,7 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     pl->off_sweeps = take(sizeof(int32_t) * b);
     pl->off_Dx = take(t * b * k);
     pl->off_H0 = take(t * b * k);
-    pl->off_G = take(t * (k + 8) * k);         // 8 readable rows behind the Gram: the solver's row prefetch runs unclamped
+    pl->off_G = take(t * (k + 16) * k);        // 16 readable rows behind the Gram: the solver's row prefetch runs unclamped
     const size_t p_pad = align_up(p, 4);
     pl->off_Ds = take(t * p_pad * k);          // compacted sampled dictionary rows
     pl->off_Xs = take(t * b * p_pad);          // compacted sampled minibatch columns
@@ -986,6 +986,8 @@ int modl_somf_step(modl_somf_plan *pl, const modl_somf_state *st, const modl_som
     return modl_somf_apply_and_update_dict(pl, st, bt, nullptr, stream);
 }
 
+}  // extern "C"
+
 // ---- the collective inside the library: RCCL through its C API, resolved at run time -------------------------------
 // (librccl.so is looked up with dlopen: a process that already holds RCCL - e.g. through torch.distributed - gets that
 // same copy; nothing links against it, so the library loads and every single-GPU entry point works without RCCL)
@@ -1018,6 +1020,8 @@ RcclApi &rccl() {
 }
 constexpr int kNcclSum = 0, kNcclFloat32 = 7, kNcclFloat64 = 8;      // rccl.h: ncclRedOp_t / ncclDataType_t
 }  // namespace
+
+extern "C" {
 
 struct modl_comm {
     void *nccl = nullptr;
