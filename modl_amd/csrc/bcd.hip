@@ -34,6 +34,7 @@
 #include "enet_block.hpp"
 #include "gemm.hpp"
 #include "gemm_dense.hpp"
+#include "gemm_wide.hpp"
 #include "kernels.hpp"
 #include <utility>
 #include <type_traits>
@@ -637,8 +638,10 @@ struct BcdBlockArgs {
 // and at the metric's shape (s = 1000) 32 of the 256 are busy with it, mostly waiting for the resolver wave: the
 // tiles a launch carries run on the other ones, a few microseconds each, and are done before the block step is.
 struct BcdRiderArgs {
-    DenseProblem<float, EpiStatsSkip<float>> P;
-    int t0 = 0, t1 = 0;             // tiles [t0, t1) of P ride with this launch
+    DenseProblem<float, EpiStatsSkip<float>> P;   // 32 x 32 tiles (gemm_stats_tile) ...
+    WideProblem<EpiStatsSkip<float>> W;           // ... or k-wide tiles of `wide` features (gemm_wide_tile): X fetched once
+    int wide = 0;                   // 0: P; 32 / 64: W with that many features per tile
+    int t0 = 0, t1 = 0;             // tiles [t0, t1) ride with this launch
     int nslab = 0;                  // workgroups of the block step proper
 };
 
@@ -646,7 +649,9 @@ __device__ __forceinline__ void bcd_rider_tile(const BcdRiderArgs &r, char *smem
     if (threadIdx.x >= 256) return;                  // the product uses four waves
     const int id = (int)blockIdx.x - r.nslab + r.t0;
     if (id >= r.t1) return;
-    gemm_stats_tile<EpiStatsSkip<float>>(r.P, id, smem);     // the very tile of gemm_stats_pair_kernel: same bits
+    if (r.wide == 64) gemm_wide_tile<64, EpiStatsSkip<float>>(r.W, id, smem);
+    else if (r.wide == 32) gemm_wide_tile<32, EpiStatsSkip<float>>(r.W, id, smem);
+    else gemm_stats_tile<EpiStatsSkip<float>>(r.P, id, smem);     // the very tile of gemm_stats_pair_kernel: same bits
 }
 
 template <int RT, int GPW>   // 32 * RT features per workgroup; GPW contraction groups (8 atoms) per worker wave
@@ -1472,8 +1477,15 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             EpiStatsSkip<float> epi{static_cast<float *>(R.Bt), k, R.stamp, R.step, (float)R.beta, (float)R.wt,
                                     (float)R.bdiv, R.replace};
             rid.P = plan_stats<EpiStatsSkip<float>>(Xo, Cd, R.p, k, R.b, epi);
-            if (rid.P.ok && R.p > 0) {
-                ride_tiles = rid.P.tn * rid.P.tm;
+            // k-wide tiles (X fetched once) for LARGE feature counts only: at p = 10 000 the 32 x 32 tiles fit into the
+            // shadow of the block step (8 launches x 313 tiles: 139 us), 313 wide tiles of 32 features stretch the
+            // launches (154 us, measured); at p = 200 000 the product is what the launches wait for, and there the wide
+            // tiles win (dictionary update 1.38 -> 0.93 ms)
+            const int wbm = 64;
+            if (cdiv(R.p, 64) >= 1024) rid.W = plan_wide<64, EpiStatsSkip<float>>(Xo, Cd, R.p, k, R.b, epi);
+            rid.wide = rid.W.ok ? wbm : 0;
+            if ((rid.P.ok || rid.wide) && R.p > 0) {
+                ride_tiles = rid.wide ? rid.W.tm * rid.W.tn : rid.P.tn * rid.P.tm;
                 // as few carrier launches as the idle compute units allow (a tile needs a compute unit to itself for
                 // most of a block step; more tiles than free units would queue and stretch the launch)
                 static const int ncu = [] {                             // one process per GPU: queried once
@@ -1492,6 +1504,12 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                 a.rider->consumed = 1;
             }
         }
+        // a launch that carries k-wide tiles needs their LDS (one workgroup per compute unit then)
+        auto lds_bytes = [&](int extra) {
+            size_t n = bcd_block_lds(GPW, RT);
+            if (extra > 0 && rid.wide) n = std::max(n, rid.wide == 64 ? wide_lds_bytes<64>() : wide_lds_bytes<32>());
+            return n;
+        };
         auto ride = [&](BcdRiderArgs &r) {                             // the next share of tiles; returns their number
             r = rid;
             r.t0 = ride_next;
@@ -1510,7 +1528,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                 ba.j0 = j0; ba.nb = nb; ba.j0_prev = j0_prev; ba.nb_prev = blk_i ? nb_prev : 0;
                 BcdRiderArgs r = rid;
                 const int extra = blk_i ? ride(r) : 0;                 // (launch 0 is short: no resolver)
-                hipLaunchKernelGGL(blk, dim3(nslab + extra), dim3(320), bcd_block_lds(GPW, RT), stream, ba, r);
+                hipLaunchKernelGGL(blk, dim3(nslab + extra), dim3(320), lds_bytes(extra), stream, ba, r);
                 MODL_LAUNCH_CHECK();
                 ++nl;
             } else {
@@ -1545,7 +1563,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             BcdRiderArgs r = rid;
             ride_per = ride_tiles - ride_next;                         // whatever is left
             const int extra = ride(r);
-            hipLaunchKernelGGL(blk, dim3(nslab + extra), dim3(320), bcd_block_lds(GPW, RT), stream, ba, r);
+            hipLaunchKernelGGL(blk, dim3(nslab + extra), dim3(320), lds_bytes(extra), stream, ba, r);
             MODL_LAUNCH_CHECK();
             nl += 1;
         } else {
