@@ -203,14 +203,33 @@ struct RandomStream {
     void draw_swaps(int64_t n, int64_t *sw) {
         for (int64_t i = n - 1; i > 0; --i) sw[i] = static_cast<int64_t>(gen.bounded(static_cast<uint64_t>(i)));
     }
-    void shuffle(int64_t *x, int64_t n) {
+    // The reference draws every swap target first and swaps afterwards (random_fast.pyx:93-111); a target does not
+    // depend on the array, so drawing and swapping in one pass gives the same permutation from the same draws.  The
+    // rejection mask (the smallest all-ones mask >= i, randomkit.c:268-276) only changes when i crosses a power of
+    // two: it is carried along instead of being rebuilt per element (the subset draw is ~8 ns per feature of pure
+    // host time per minibatch: 1.6 ms at p = 200 000).
+    template <typename E>
+    void shuffle(E *x, int64_t n) {
         if (n < 2) return;
-        scratch_.resize(static_cast<size_t>(n));
-        draw_swaps(n, scratch_.data());
-        for (int64_t i = n - 1; i > 0; --i) std::swap(x[i], x[scratch_[i]]);
+        if (static_cast<uint64_t>(n - 1) > 0xffffffffull) {          // 64-bit targets: the general path
+            scratch_.resize(static_cast<size_t>(n));
+            draw_swaps(n, scratch_.data());
+            for (int64_t i = n - 1; i > 0; --i) std::swap(x[i], x[scratch_[i]]);
+            return;
+        }
+        uint32_t mask = static_cast<uint32_t>(n - 1);
+        for (int sh = 1; sh < 32; sh <<= 1) mask |= mask >> sh;
+        for (int64_t i = n - 1; i > 0; --i) {
+            const uint32_t hi = static_cast<uint32_t>(i);
+            while ((mask >> 1) >= hi) mask >>= 1;
+            uint32_t v;
+            do v = gen.next() & mask; while (v > hi);
+            std::swap(x[i], x[v]);
+        }
     }
-    void permutation(int64_t *out, int64_t n) {
-        for (int64_t i = 0; i < n; ++i) out[i] = i;
+    template <typename E>
+    void permutation(E *out, int64_t n) {
+        for (int64_t i = 0; i < n; ++i) out[i] = static_cast<E>(i);
         shuffle(out, n);
     }
 
@@ -248,7 +267,7 @@ public:
                 // bring the unseen tail to the front, swap the displaced head in behind it and
                 // reshuffle everything after the tail
                 std::copy(box_.begin(), box_.begin() + left, tmp_.begin());
-                std::memmove(box_.data(), box_.data() + lo_, sizeof(int64_t) * static_cast<size_t>(left));
+                std::memmove(box_.data(), box_.data() + lo_, sizeof(int32_t) * static_cast<size_t>(left));
                 std::copy(tmp_.begin(), tmp_.begin() + left, box_.begin() + lo_);
                 rs_.shuffle(box_.data() + left, range_ - left);
                 lo_ = 0;
@@ -256,14 +275,14 @@ public:
             hi_ = lo_ + len;
         }
         const int64_t n = hi_ - lo_;
-        if (n > 0) std::memcpy(out, box_.data() + lo_, sizeof(int64_t) * static_cast<size_t>(n));
+        for (int64_t i = 0; i < n; ++i) out[i] = box_[static_cast<size_t>(lo_ + i)];
         return n;
     }
 
     RandomStream rs_;
     int64_t range_;
     bool rand_size_, replacement_;
-    std::vector<int64_t> box_, tmp_;
+    std::vector<int32_t> box_, tmp_;   // feature indices (range <= 2^31 - 1): half the cache footprint of the int64 box
     int64_t lo_ = 0, hi_ = 0;
 };
 
@@ -368,7 +387,8 @@ int modl_sampler_get(modl_sampler *s, int64_t *range, int64_t *lim_inf, int64_t 
     if (range) *range = s->fs.range_;
     if (lim_inf) *lim_inf = s->fs.lo_;
     if (lim_sup) *lim_sup = s->fs.hi_;
-    if (h_box) std::memcpy(h_box, s->fs.box_.data(), sizeof(int64_t) * static_cast<size_t>(s->fs.range_));
+    if (h_box)
+        for (int64_t i = 0; i < s->fs.range_; ++i) static_cast<int64_t *>(h_box)[i] = s->fs.box_[static_cast<size_t>(i)];
     return MODL_OK;
 }
 size_t modl_sampler_state_bytes(const modl_sampler *s) {
@@ -384,8 +404,8 @@ int modl_sampler_get_state(const modl_sampler *s, void *h_buf, size_t bytes) {
     std::memcpy(hd.key, s->fs.rs_.gen.key_, sizeof(hd.key));
     hd.bc = s->fs.rs_.bc;
     std::memcpy(h_buf, &hd, sizeof(hd));
-    std::memcpy(static_cast<char *>(h_buf) + sizeof(hd), s->fs.box_.data(),
-                sizeof(int64_t) * static_cast<size_t>(s->fs.range_));
+    int64_t *box = reinterpret_cast<int64_t *>(static_cast<char *>(h_buf) + sizeof(hd));   // (the blob keeps int64 entries)
+    for (int64_t i = 0; i < s->fs.range_; ++i) box[i] = s->fs.box_[static_cast<size_t>(i)];
     return MODL_OK;
 }
 int modl_sampler_set_state(modl_sampler *s, const void *h_buf, size_t bytes) {
@@ -398,8 +418,8 @@ int modl_sampler_set_state(modl_sampler *s, const void *h_buf, size_t bytes) {
     s->fs.rs_.gen.pos_ = hd.pos;
     std::memcpy(s->fs.rs_.gen.key_, hd.key, sizeof(hd.key));
     s->fs.rs_.bc = hd.bc;
-    std::memcpy(s->fs.box_.data(), static_cast<const char *>(h_buf) + sizeof(hd),
-                sizeof(int64_t) * static_cast<size_t>(s->fs.range_));
+    const int64_t *box = reinterpret_cast<const int64_t *>(static_cast<const char *>(h_buf) + sizeof(hd));
+    for (int64_t i = 0; i < s->fs.range_; ++i) s->fs.box_[static_cast<size_t>(i)] = static_cast<int32_t>(box[i]);
     return MODL_OK;
 }
 
