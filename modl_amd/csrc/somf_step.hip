@@ -93,13 +93,17 @@ template <typename T> struct PrepArgs {
     int64_t s_pad; T *Xs; int gx; int n_cols;                                 // n_cols = gx * b or 0
     const T *code; const int64_t *idx; T *codeb; int n_code;                  // n_code = b or 0
     int32_t *stamp, *pos; int32_t step;                                       // stamp[subset[i]] = step, pos[subset[i]] = i
+    int fuse_cols;        // the row-norm workgroups also gather the sampled columns of their row (n_cols == 0 then)
 };
 template <typename T>
 __global__ __launch_bounds__(256) void prep_kernel(PrepArgs<T> a) {
     __shared__ double red[4];
+    extern __shared__ __attribute__((aligned(16))) char prep_row_raw[];     // fuse_cols: the staged row (p elements)
     int id = (int)blockIdx.x;
     if (id < a.n_norm) {                                 // dict_fact_fast.pyx:334 uses dot(y, y)
         const T *x = a.X + (int64_t)id * a.ldx;
+        T *rowl = reinterpret_cast<T *>(prep_row_raw);
+        const bool stage = a.fuse_cols != 0;              // (workgroup-uniform; implies 16-byte aligned rows)
         constexpr int V = 16 / sizeof(T);
         typedef T vec_t __attribute__((ext_vector_type(V)));
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
@@ -109,6 +113,10 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs<T> a) {
         int64_t f = threadIdx.x;
         for (; f + 768 < nv; f += 1024) {
             const vec_t a0 = xv[f], a1 = xv[f + 256], a2 = xv[f + 512], a3 = xv[f + 768];
+            if (stage) {
+                vec_t *rl = reinterpret_cast<vec_t *>(rowl);
+                rl[f] = a0; rl[f + 256] = a1; rl[f + 512] = a2; rl[f + 768] = a3;
+            }
 #pragma unroll
             for (int c = 0; c < V; ++c) {
                 s0 += (double)a0[c] * (double)a0[c];
@@ -119,13 +127,28 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs<T> a) {
         }
         for (; f < nv; f += 256) {
             const vec_t a0 = xv[f];
+            if (stage) reinterpret_cast<vec_t *>(rowl)[f] = a0;
 #pragma unroll
             for (int c = 0; c < V; ++c) s0 += (double)a0[c] * (double)a0[c];
         }
-        for (int64_t e = nv * V + threadIdx.x; e < a.p; e += 256) s1 += (double)x[e] * (double)x[e];
+        for (int64_t e = nv * V + threadIdx.x; e < a.p; e += 256) {
+            if (stage) rowl[e] = x[e];
+            s1 += (double)x[e] * (double)x[e];
+        }
         double sum = (s0 + s1) + (s2 + s3);
-        sum = block_sum(sum, red);
+        sum = block_sum(sum, red);                        // (its barriers also publish the staged row)
         if (threadIdx.x == 0) a.xnorm[id] = (T)sum;
+        if (stage) {
+            // Xs[id][:] = X[id][subset] from the row in LDS: the minibatch is read from HBM once (a gather of 4-byte
+            // elements straight from memory drags a whole cache line in for every sampled column: 32 MB per
+            // minibatch for 1 MB of values at the metric's shape)
+            T *dst = a.Xs + (int64_t)id * a.s_pad;
+            for (int64_t c = threadIdx.x; c < a.s_pad; c += 256) {
+                const int32_t col = a.subset[c < a.s ? c : a.s - 1];
+                const T v = rowl[col];
+                dst[c] = (c < a.s) ? v : (T)0;
+            }
+        }
         return;
     }
     id -= a.n_norm;
@@ -534,6 +557,12 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         pa.Dt = Dt; pa.subset = d_subset; pa.s = s; pa.k = k; pa.Ds = Dsb; pa.n_rows = need_sub ? (int)s : 0;
         pa.s_pad = s_pad; pa.Xs = Xsb; pa.gx = (int)std::min<int64_t>(cdiv(s_pad, 256), 64);
         pa.n_cols = (need_sub && d.Dx_agg != MODL_AGG_FULL) ? pa.gx * b : 0;
+        // the column gather rides with the row norms when a row fits in LDS next to nothing else (<= 64 KB) and the
+        // rows are 16-byte aligned
+        const size_t row_bytes = sizeof(T) * (size_t)p;
+        pa.fuse_cols = (pa.n_cols > 0 && pa.n_norm == b && row_bytes <= 64 * 1024 &&
+                        reinterpret_cast<uintptr_t>(X) % 16 == 0 && (bt->ldx * sizeof(T)) % 16 == 0) ? 1 : 0;
+        if (pa.fuse_cols) pa.n_cols = 0;
         pa.code = code; pa.idx = d_idx; pa.codeb = codeb; pa.n_code = (cd_on_compact && d_idx) ? b : 0;
         const bool proper = need_sub && s > 0 && s < p;               // a proper subset, gathered
         // only the sampled rows of B_ are needed by the dictionary update -> the rest of the B_ update is deferred
@@ -549,7 +578,7 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         }
         const int n_prep = pa.n_norm + pa.n_rows + pa.n_cols + pa.n_code;
         if (n_prep > 0) {
-            hipLaunchKernelGGL((prep_kernel<T>), dim3((unsigned)n_prep), dim3(256), 0, st, pa);
+            hipLaunchKernelGGL((prep_kernel<T>), dim3((unsigned)n_prep), dim3(256), pa.fuse_cols ? row_bytes : 0, st, pa);
             MODL_LAUNCH_CHECK();
             ++ps.launches;
         }
