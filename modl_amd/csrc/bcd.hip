@@ -650,7 +650,7 @@ __device__ __forceinline__ void bcd_rider_tile(const BcdRiderArgs &r, char *smem
     const int id = (int)blockIdx.x - r.nslab + r.t0;
     if (id >= r.t1) return;
     if (r.wide == 64) gemm_wide_tile<64, EpiStatsSkip<float>>(r.W, id, smem);
-    else if (r.wide == 32) gemm_wide_tile<32, EpiStatsSkip<float>>(r.W, id, smem);
+    else if (r.wide == 32) gemm_wide_tile<32, EpiStatsSkip<float>, 128>(r.W, id, smem);
     else gemm_stats_tile<EpiStatsSkip<float>>(r.P, id, smem);     // the very tile of gemm_stats_pair_kernel: same bits
 }
 
@@ -1477,12 +1477,13 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             EpiStatsSkip<float> epi{static_cast<float *>(R.Bt), k, R.stamp, R.step, (float)R.beta, (float)R.wt,
                                     (float)R.bdiv, R.replace};
             rid.P = plan_stats<EpiStatsSkip<float>>(Xo, Cd, R.p, k, R.b, epi);
-            // k-wide tiles (X fetched once) for LARGE feature counts only: at p = 10 000 the 32 x 32 tiles fit into the
-            // shadow of the block step (8 launches x 313 tiles: 139 us), 313 wide tiles of 32 features stretch the
-            // launches (154 us, measured); at p = 200 000 the product is what the launches wait for, and there the wide
-            // tiles win (dictionary update 1.38 -> 0.93 ms)
-            const int wbm = 64;
-            if (cdiv(R.p, 64) >= 1024) rid.W = plan_wide<64, EpiStatsSkip<float>>(Xo, Cd, R.p, k, R.b, epi);
+            // wide tiles keep their X tile in LDS for many atoms: 64 features x all 256 atoms (X fetched once) when the
+            // product is what the launches wait for (p >= 65 536: dictionary update 1.38 -> 0.93 ms at p = 200 000);
+            // 32 features x 128 atoms (X fetched twice instead of eight times) otherwise - small enough to stay in the
+            // shadow of the block step
+            const int wbm = (cdiv(R.p, 64) >= 1024) ? 64 : 32;
+            if (wbm == 64) rid.W = plan_wide<64, EpiStatsSkip<float>>(Xo, Cd, R.p, k, R.b, epi);
+            else if (R.p >= 2048) rid.W = plan_wide<32, EpiStatsSkip<float>, 128>(Xo, Cd, R.p, k, R.b, epi);
             rid.wide = rid.W.ok ? wbm : 0;
             if ((rid.P.ok || rid.wide) && R.p > 0) {
                 ride_tiles = rid.wide ? rid.W.tm * rid.W.tn : rid.P.tn * rid.P.tm;
@@ -1507,7 +1508,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         // a launch that carries k-wide tiles needs their LDS (one workgroup per compute unit then)
         auto lds_bytes = [&](int extra) {
             size_t n = bcd_block_lds(GPW, RT);
-            if (extra > 0 && rid.wide) n = std::max(n, rid.wide == 64 ? wide_lds_bytes<64>() : wide_lds_bytes<32>());
+            if (extra > 0 && rid.wide) n = std::max(n, rid.wide == 64 ? wide_lds_bytes<64>() : wide_lds_bytes<32, 128>());
             return n;
         };
         auto ride = [&](BcdRiderArgs &r) {                             // the next share of tiles; returns their number

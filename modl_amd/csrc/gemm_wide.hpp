@@ -20,14 +20,14 @@
 
 namespace modl {
 
-constexpr int kWideBN = 256, kWideBK = 32, kWideKmax = 256;
+constexpr int kWideBK = 32, kWideKmax = 256;
 // LDS row padding of 16 floats: a fragment read takes 4 consecutive rows x 16 consecutive floats; with a row stride of
 // 16 (mod 32) banks the four rows fall on banks 0-15 / 16-31 alternately (2 lanes per bank, the minimum for 64 lanes);
 // a stride of 4 (mod 32) makes it a 4-way conflict
 constexpr int kWidePad = 16;
 
-template <int BM> constexpr size_t wide_lds_bytes() {
-    return sizeof(float) * ((size_t)kWideKmax * (BM + kWidePad) + 2 * (size_t)kWideBK * (kWideBN + kWidePad));
+template <int BM, int BN = 256> constexpr size_t wide_lds_bytes() {
+    return sizeof(float) * ((size_t)kWideKmax * (BM + kWidePad) + 2 * (size_t)kWideBK * (BN + kWidePad));
 }
 
 template <class Epi> struct WideProblem {
@@ -36,19 +36,19 @@ template <class Epi> struct WideProblem {
     int64_t M = 0;
     int N = 0, K = 0;
     Epi epi;
-    int tm = 0, tn = 0;                              // feature tiles, atom chunks of 256
+    int tm = 0, tn = 0;                              // feature tiles, atom chunks of BN
     bool ok = false;
 };
 
 // eligible: 16-byte aligned operands, M, N multiples of 4, K <= 256
-template <int BM, class Epi>
+template <int BM, class Epi, int BN = 256>
 WideProblem<Epi> plan_wide(const DenseOperand &A, const DenseOperand &B, int64_t M, int64_t N, int64_t K, const Epi &epi) {
     WideProblem<Epi> P;
     P.epi = epi;
     P.X = static_cast<const float *>(A.ptr); P.ldx = A.sk;
     P.Cd = static_cast<const float *>(B.ptr); P.ldc = B.sk;
     P.M = M; P.N = (int)N; P.K = (int)K;
-    P.tm = (int)cdiv(M, BM); P.tn = (int)cdiv(N, kWideBN);
+    P.tm = (int)cdiv(M, BM); P.tn = (int)cdiv(N, BN);
     P.ok = A.si == 1 && B.si == 1 && M > 0 && N > 0 && K > 0 && K <= kWideKmax && M % 4 == 0 && N % 4 == 0 &&
            A.sk % 4 == 0 && B.sk % 4 == 0 && reinterpret_cast<uintptr_t>(A.ptr) % 16 == 0 &&
            reinterpret_cast<uintptr_t>(B.ptr) % 16 == 0;
@@ -56,9 +56,11 @@ WideProblem<Epi> plan_wide(const DenseOperand &A, const DenseOperand &B, int64_t
 }
 
 // one tile (256 threads: callers with larger workgroups retire the other threads first)
-template <int BM, class Epi>
+// BN atoms per tile (256: every atom of the metric's shape, X fetched once; 128: twice, half the tile time): each of
+// the 4 wavefronts takes BN / 4 atoms
+template <int BM, class Epi, int BN = 256>
 __device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int tile, char *smem) {
-    constexpr int BN = kWideBN, BK = kWideBK, TI = BM / 16, TJ = 4;
+    constexpr int BK = kWideBK, TI = BM / 16, WN = BN / 4, TJ = WN / 16;
     constexpr int NA = kWideKmax * BM / 4 / 256;           // float4 of the X tile per thread
     constexpr int NB = BK * BN / 4 / 256;                  // float4 of a code tile per thread (8)
     typedef float f4v __attribute__((ext_vector_type(4)));
@@ -123,7 +125,7 @@ __device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int ti
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t m = m0 + 16 * ti + 4 * (lane >> 4) + r;
-                    const int n = n0 + 64 * wid + 16 * tj + (lane & 15);
+                    const int n = n0 + WN * wid + 16 * tj + (lane & 15);
                     old[ti][tj][r] = P.epi.load(m < M ? m : M - 1, n < N ? n : N - 1);
                 }
     };
@@ -146,7 +148,7 @@ __device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int ti
 #pragma unroll
             for (int ti = 0; ti < TI; ++ti) af[ti] = As[kt * BK + kr][16 * ti + (lane & 15)];
 #pragma unroll
-            for (int tj = 0; tj < TJ; ++tj) bf[tj] = Bs[buf][kr][64 * wid + 16 * tj + (lane & 15)];
+            for (int tj = 0; tj < TJ; ++tj) bf[tj] = Bs[buf][kr][WN * wid + 16 * tj + (lane & 15)];
 #pragma unroll
             for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -164,7 +166,7 @@ __device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int ti
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t m = m0 + 16 * ti + 4 * (lane >> 4) + r;
-                const int n = n0 + 64 * wid + 16 * tj + (lane & 15);
+                const int n = n0 + WN * wid + 16 * tj + (lane & 15);
                 if (m < M && n < N) {
                     if constexpr (kRmw) P.epi.store(m, n, acc[ti][tj][r], old[ti][tj][r]);
                     else P.epi(m, n, acc[ti][tj][r]);
