@@ -175,7 +175,7 @@ __device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int ti
 }
 
 // the small problem (code^T code -> C_, 32 x 32 tiles of gemm_stats_tile) and the wide one in ONE launch
-template <int BM, class Epi0, class Epi1>
+template <int BM, class Epi0, class Epi1, int BN = 256>
 __global__ __launch_bounds__(256) void gemm_stats_wide_pair_kernel(DenseProblem<float, Epi0> P0, WideProblem<Epi1> P1) {
     extern __shared__ __attribute__((aligned(16))) char wide_smem[];
     int id = (int)blockIdx.x;
@@ -186,16 +186,16 @@ __global__ __launch_bounds__(256) void gemm_stats_wide_pair_kernel(DenseProblem<
     }
     id -= t0;
     if (id >= P1.tm * P1.tn) return;
-    gemm_wide_tile<BM, Epi1>(P1, id, wide_smem);
+    gemm_wide_tile<BM, Epi1, BN>(P1, id, wide_smem);
 }
 
-template <int BM, class Epi0, class Epi1>
+template <int BM, class Epi0, class Epi1, int BN = 256>
 int launch_gemm_stats_wide_pair(hipStream_t stream, const DenseProblem<float, Epi0> &P0, const WideProblem<Epi1> &P1,
                                 int *launches = nullptr) {
     const int total = P0.tn * P0.tm + P1.tm * P1.tn;
     if (total <= 0) return MODL_OK;
-    constexpr size_t lds = wide_lds_bytes<BM>() > kStatsLds ? wide_lds_bytes<BM>() : kStatsLds;
-    auto kern = gemm_stats_wide_pair_kernel<BM, Epi0, Epi1>;
+    constexpr size_t lds = wide_lds_bytes<BM, BN>() > kStatsLds ? wide_lds_bytes<BM, BN>() : kStatsLds;
+    auto kern = gemm_stats_wide_pair_kernel<BM, Epi0, Epi1, BN>;
     MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, stream, P0, P1);
     MODL_LAUNCH_CHECK();

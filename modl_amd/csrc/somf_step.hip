@@ -476,7 +476,7 @@ int stats_pair(hipStream_t st, const DenseOperand &A0, const DenseOperand &B0, i
         if (P0.ok && cdiv(M1, 64) >= 1024 && !dbg) {
             auto W = plan_wide<64, Epi1>(A1, B1, M1, N1, K, e1);
             if (W.ok) return launch_gemm_stats_wide_pair<64, Epi0, Epi1>(st, P0, W, launches);
-        }
+        }   // (32 x 128 wide tiles as their own launch at p = 10 000: 40 us against 28 us for the 32 x 32 tiles, measured)
         auto P1 = plan_stats<Epi1>(A1, B1, M1, N1, K, e1);
         if (P0.ok && P1.ok) {
             P1.dbg = dbg;
