@@ -649,8 +649,7 @@ __device__ __forceinline__ void bcd_rider_tile(const BcdRiderArgs &r, char *smem
     if (threadIdx.x >= 256) return;                  // the product uses four waves
     const int id = (int)blockIdx.x - r.nslab + r.t0;
     if (id >= r.t1) return;
-    if (r.wide == 64) gemm_wide_tile<64, EpiStatsSkip<float>>(r.W, id, smem);
-    else if (r.wide == 32) gemm_wide_tile<32, EpiStatsSkip<float>, 128>(r.W, id, smem);
+    if (r.wide == 32) gemm_wide_tile<32, EpiStatsSkip<float>, 128>(r.W, id, smem);
     else gemm_stats_tile<EpiStatsSkip<float>>(r.P, id, smem);     // the very tile of gemm_stats_pair_kernel: same bits
 }
 
@@ -1477,13 +1476,11 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             EpiStatsSkip<float> epi{static_cast<float *>(R.Bt), k, R.stamp, R.step, (float)R.beta, (float)R.wt,
                                     (float)R.bdiv, R.replace};
             rid.P = plan_stats<EpiStatsSkip<float>>(Xo, Cd, R.p, k, R.b, epi);
-            // wide tiles keep their X tile in LDS for many atoms: 64 features x all 256 atoms (X fetched once) when the
-            // product is what the launches wait for (p >= 65 536: dictionary update 1.38 -> 0.93 ms at p = 200 000);
-            // 32 features x 128 atoms (X fetched twice instead of eight times) otherwise - small enough to stay in the
-            // shadow of the block step
-            const int wbm = (cdiv(R.p, 64) >= 1024) ? 64 : 32;
-            if (wbm == 64) rid.W = plan_wide<64, EpiStatsSkip<float>>(Xo, Cd, R.p, k, R.b, epi);
-            else if (R.p >= 2048) rid.W = plan_wide<32, EpiStatsSkip<float>, 128>(Xo, Cd, R.p, k, R.b, epi);
+            // wide tiles (gemm_wide.hpp) keep their X tile in LDS for 128 atoms: X is fetched twice instead of eight
+            // times, and a tile is still short enough for the shadow of a block step.  (Very large feature counts do
+            // not ride at all: somf_step.hip runs their product as its own k-wide launch.)
+            const int wbm = 32;
+            if (R.p >= 2048) rid.W = plan_wide<32, EpiStatsSkip<float>, 128>(Xo, Cd, R.p, k, R.b, epi);
             rid.wide = rid.W.ok ? wbm : 0;
             if ((rid.P.ok || rid.wide) && R.p > 0) {
                 ride_tiles = rid.wide ? rid.W.tm * rid.W.tn : rid.P.tn * rid.P.tm;
@@ -1508,7 +1505,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         // a launch that carries k-wide tiles needs their LDS (one workgroup per compute unit then)
         auto lds_bytes = [&](int extra) {
             size_t n = bcd_block_lds(GPW, RT);
-            if (extra > 0 && rid.wide) n = std::max(n, rid.wide == 64 ? wide_lds_bytes<64>() : wide_lds_bytes<32, 128>());
+            if (extra > 0 && rid.wide) n = std::max(n, wide_lds_bytes<32, 128>());
             return n;
         };
         auto ride = [&](BcdRiderArgs &r) {                             // the next share of tiles; returns their number

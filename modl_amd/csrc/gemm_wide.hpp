@@ -26,8 +26,8 @@ constexpr int kWideBK = 32, kWideKmax = 256;
 // a stride of 4 (mod 32) makes it a 4-way conflict
 constexpr int kWidePad = 16;
 
-template <int BM, int BN = 256> constexpr size_t wide_lds_bytes() {
-    return sizeof(float) * ((size_t)kWideKmax * (BM + kWidePad) + 2 * (size_t)kWideBK * (BN + kWidePad));
+template <int BM, int BN = 256, int BK = kWideBK, int PAD = kWidePad> constexpr size_t wide_lds_bytes() {
+    return sizeof(float) * ((size_t)kWideKmax * (BM + PAD) + 2 * (size_t)BK * (BN + PAD));
 }
 
 template <class Epi> struct WideProblem {
@@ -58,15 +58,14 @@ WideProblem<Epi> plan_wide(const DenseOperand &A, const DenseOperand &B, int64_t
 // one tile (256 threads: callers with larger workgroups retire the other threads first)
 // BN atoms per tile (256: every atom of the metric's shape, X fetched once; 128: twice, half the tile time): each of
 // the 4 wavefronts takes BN / 4 atoms
-template <int BM, class Epi, int BN = 256>
+template <int BM, class Epi, int BN = 256, int BK = kWideBK, int PAD = kWidePad>
 __device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int tile, char *smem) {
-    constexpr int BK = kWideBK, TI = BM / 16, WN = BN / 4, TJ = WN / 16;
+    constexpr int TI = BM / 16, WN = BN / 4, TJ = WN / 16;
     constexpr int NA = kWideKmax * BM / 4 / 256;           // float4 of the X tile per thread
     constexpr int NB = BK * BN / 4 / 256;                  // float4 of a code tile per thread (8)
     typedef float f4v __attribute__((ext_vector_type(4)));
-    float (*As)[BM + kWidePad] = reinterpret_cast<float (*)[BM + kWidePad]>(smem);
-    float (*Bs)[BK][BN + kWidePad] =
-        reinterpret_cast<float (*)[BK][BN + kWidePad]>(smem + sizeof(float) * kWideKmax * (BM + kWidePad));
+    float (*As)[BM + PAD] = reinterpret_cast<float (*)[BM + PAD]>(smem);
+    float (*Bs)[BK][BN + PAD] = reinterpret_cast<float (*)[BK][BN + PAD]>(smem + sizeof(float) * kWideKmax * (BM + PAD));
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int bm = tile % P.tm, bn = tile / P.tm;
     const int64_t m0 = (int64_t)bm * BM;
@@ -175,7 +174,7 @@ __device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int ti
 }
 
 // the small problem (code^T code -> C_, 32 x 32 tiles of gemm_stats_tile) and the wide one in ONE launch
-template <int BM, class Epi0, class Epi1, int BN = 256>
+template <int BM, class Epi0, class Epi1, int BN = 256, int BK = kWideBK, int PAD = kWidePad>
 __global__ __launch_bounds__(256) void gemm_stats_wide_pair_kernel(DenseProblem<float, Epi0> P0, WideProblem<Epi1> P1) {
     extern __shared__ __attribute__((aligned(16))) char wide_smem[];
     int id = (int)blockIdx.x;
@@ -186,16 +185,16 @@ __global__ __launch_bounds__(256) void gemm_stats_wide_pair_kernel(DenseProblem<
     }
     id -= t0;
     if (id >= P1.tm * P1.tn) return;
-    gemm_wide_tile<BM, Epi1, BN>(P1, id, wide_smem);
+    gemm_wide_tile<BM, Epi1, BN, BK, PAD>(P1, id, wide_smem);
 }
 
-template <int BM, class Epi0, class Epi1, int BN = 256>
+template <int BM, class Epi0, class Epi1, int BN = 256, int BK = kWideBK, int PAD = kWidePad>
 int launch_gemm_stats_wide_pair(hipStream_t stream, const DenseProblem<float, Epi0> &P0, const WideProblem<Epi1> &P1,
                                 int *launches = nullptr) {
     const int total = P0.tn * P0.tm + P1.tm * P1.tn;
     if (total <= 0) return MODL_OK;
-    constexpr size_t lds = wide_lds_bytes<BM, BN>() > kStatsLds ? wide_lds_bytes<BM, BN>() : kStatsLds;
-    auto kern = gemm_stats_wide_pair_kernel<BM, Epi0, Epi1, BN>;
+    constexpr size_t lds = wide_lds_bytes<BM, BN, BK, PAD>() > kStatsLds ? wide_lds_bytes<BM, BN, BK, PAD>() : kStatsLds;
+    auto kern = gemm_stats_wide_pair_kernel<BM, Epi0, Epi1, BN, BK, PAD>;
     MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, stream, P0, P1);
     MODL_LAUNCH_CHECK();

@@ -471,11 +471,14 @@ int stats_pair(hipStream_t st, const DenseOperand &A0, const DenseOperand &B0, i
                const SplitWs &sws, int *launches, unsigned long long *dbg = nullptr) {
     if constexpr (std::is_same<T, float>::value) {
         auto P0 = plan_stats<Epi0>(A0, B0, M0, N0, K, e0);
-        // a VERY tall second problem (the whole p x k product at p >= 65 536): k-wide tiles, X read once (gemm_wide.hpp);
-        // at p = 10 000 the 32 x 32 tiles are faster (27 us against 37 us: ten times the workgroups to hide latency)
+        // a VERY tall second problem (the whole p x k product at p >= 65 536): k-wide tiles, X read once (gemm_wide.hpp),
+        // 32 features x 256 atoms with a 16-sample code tile: 70 KB of LDS, TWO workgroups per compute unit, so one
+        // stages its X tile / runs its epilogue while the other is on the matrix cores (67 TFLOP/s at p = 200 000;
+        // 64 features, one workgroup per compute unit: 56); at p = 10 000 the 32 x 32 tiles are faster (27 us against
+        // 37 us: ten times the workgroups to hide latency)
         if (P0.ok && cdiv(M1, 64) >= 1024 && !dbg) {
-            auto W = plan_wide<64, Epi1>(A1, B1, M1, N1, K, e1);
-            if (W.ok) return launch_gemm_stats_wide_pair<64, Epi0, Epi1>(st, P0, W, launches);
+            auto W = plan_wide<32, Epi1>(A1, B1, M1, N1, K, e1);
+            if (W.ok) return launch_gemm_stats_wide_pair<32, Epi0, Epi1, 256, 16, 4>(st, P0, W, launches);
         }   // (32 x 128 wide tiles as their own launch at p = 10 000: 40 us against 28 us for the 32 x 32 tiles, measured)
         auto P1 = plan_stats<Epi1>(A1, B1, M1, N1, K, e1);
         if (P0.ok && P1.ok) {
@@ -567,7 +570,10 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         const bool proper = need_sub && s > 0 && s < p;               // a proper subset, gathered
         // only the sampled rows of B_ are needed by the dictionary update -> the rest of the B_ update is deferred
         // and rides along its launches; the sampled features are stamped so that the rider leaves them alone
-        ride = proper && d.Dx_agg != MODL_AGG_FULL && !(d.flags & MODL_FLAG_NO_RIDER);
+        // (not for very large feature counts: at p = 200 000 the p x k product is 26 GFLOP, the launches of the
+        // dictionary update would wait for their riders - it runs as its own k-wide launch instead, X read once:
+        // 0.39 + 0.39 ms against 0.94 ms riding, measured)
+        ride = proper && d.Dx_agg != MODL_AGG_FULL && !(d.flags & MODL_FLAG_NO_RIDER) && cdiv(p, 64) < 1024;
         if (ride) pl->step_id = (pl->step_id == 0x7fffffff) ? 1 : pl->step_id + 1;
         pa.stamp = ride ? reinterpret_cast<int32_t *>(pl->dws + pl->off_stamp) : nullptr;
         pa.pos = reinterpret_cast<int32_t *>(pl->dws + pl->off_pos);

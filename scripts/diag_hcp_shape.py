@@ -10,6 +10,9 @@ p, n = 200000, 2048
 X = bench.M1Stream(p, 7, dev).rows(0, n)
 est = DictFact(n_components=256, batch_size=256, reduction=12, code_alpha=1.0, learning_rate=0.92, random_state=0)
 est.prepare(n_samples=n, X=X[:256])
+if len(sys.argv) > 1:                                   # diagnostics: modl_somf_desc.flags (1 = no rider)
+    est._backend.flags = int(sys.argv[1])
+    est._backend.update_plan(est._plan_kwargs(256))
 est.partial_fit(X[:512], np.arange(512))
 torch.cuda.synchronize()
 t0 = time.perf_counter()
