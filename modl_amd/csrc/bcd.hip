@@ -1427,13 +1427,26 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         unsigned int *counter = reinterpret_cast<unsigned int *>(Tp + 2 * kResStride);
         const bool fused = std::is_same<T, float>::value && (k % 4 == 0) && k <= 512;
         constexpr int64_t rt1_max = MODL_RT1_MAX;
-        const int RT = (s <= rt1_max || k > 256) ? 1 : 2;        // k > 256: 64-row tiles would spill registers
+        int RT = (s <= rt1_max || k > 256) ? 1 : 2;              // k > 256: 64-row tiles would spill registers
+        {   // one workgroup per compute unit (registers): a grid that is a few workgroups larger than the chip runs in
+            // two rounds, i.e. every block launch takes twice as long (s = 16.7 k: 261 workgroups of 64 features ->
+            // 174 of 96 features)
+            static const int ncu_blk = [] {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                    return prop.multiProcessorCount;
+                return 256;
+            }();
+            if (RT == 2 && cdiv(s, 64) > ncu_blk && cdiv(s, 96) <= ncu_blk) RT = 3;
+        }
         const int nslab = fused ? (int)cdiv(s, 32 * RT) : (int)cdiv(s, kGramRows);
         const int GPW = (k <= 256) ? 8 : 16;
         void (*blk)(BcdBlockArgs, BcdRiderArgs) = nullptr;
         T *DsP = reinterpret_cast<T *>(ws + L.off_Dnew), *BsP = reinterpret_cast<T *>(ws + L.off_BsP), *CPP = CP;
         if (fused) {
-            blk = (RT == 1) ? (GPW == 8 ? bcd_block_kernel<1, 8> : bcd_block_kernel<1, 16>) : bcd_block_kernel<2, 8>;
+            blk = (RT == 1) ? (GPW == 8 ? bcd_block_kernel<1, 8> : bcd_block_kernel<1, 16>)
+                            : (RT == 2 ? bcd_block_kernel<2, 8> : bcd_block_kernel<3, 8>);
             MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(blk), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024));
             hipLaunchKernelGGL((bcd_setup_kernel<T>), dim3((unsigned)(kNB + k + s)), dim3(256), 0, stream, a.C, a.order, k, CPP,
