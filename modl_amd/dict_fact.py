@@ -70,7 +70,20 @@ class HipBackend:
         self.comp_norm = z(k)
         self.G = z(k, k) if desc_kwargs['G_agg'] == 'full' else None
         self.Dx_average = z(n_samples, k) if desc_kwargs['Dx_agg'] == 'average' else None
-        self.G_average = z(n_samples, k, k) if desc_kwargs['G_agg'] == 'average' else None
+        self.G_average = None
+        if desc_kwargs['G_agg'] == 'average':
+            # n k^2 elements (a disk memmap in the reference, dict_fact.py:431-439): in HBM while it fits next to
+            # everything else, otherwise in pinned host memory that the kernels read and write over the host link
+            # (the b Gram matrices of a minibatch: 2 b k^2 elements per minibatch, 2.4 ms at b = k = 256)
+            nbytes = n_samples * k * k * self.dtype.itemsize
+            free = torch.cuda.mem_get_info(dev)[0] if dev.type == 'cuda' else 0
+            on_host = getattr(self, 'g_average_on_host', None)
+            if on_host is None:
+                on_host = nbytes > 0.6 * free
+            if on_host:
+                self.G_average = torch.zeros((n_samples, k, k), dtype=td, pin_memory=True)
+            else:
+                self.G_average = z(n_samples, k, k)
         self._make_plan(desc_kwargs)
         self.head = None          # [C | rows of Bt, compact]: allocated by the first two-phase (multi-GPU) step
 
@@ -162,7 +175,12 @@ class HipBackend:
 
     def get(self, name):
         t = getattr(self, name)
-        return None if t is None else t.cpu().numpy()
+        if t is None:
+            return None
+        if t.device.type == 'cpu':                 # host-resident state the kernels write (G_average_): let them finish
+            self.synchronize()
+            return t.numpy().copy()
+        return t.cpu().numpy()
 
     def set(self, name, value):
         cur = getattr(self, name)

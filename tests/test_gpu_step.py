@@ -356,6 +356,26 @@ def test_partial_fit_streams_host_input_in_chunks(DictFact, tmp_path, source):
         assert_array_equal(a, c)
 
 
+def test_g_average_in_pinned_host_memory(DictFact):
+    """G_average_ (n k^2 elements; a disk memmap in the reference, dict_fact.py:431-439) does not have to fit in HBM:
+    kept in pinned host memory, read and written by the kernels over the host link, the fit gives the bits of the run
+    with the array in HBM (two epochs: its rows are shuffled in place too)."""
+    from modl_amd.dict_fact import HipBackend
+    kw, X, dt = small_case_params('agg_average_average_f64')
+
+    class HostG(DictFact):
+        def _make_backend(self):
+            be = HipBackend(getattr(self, 'device', None))
+            be.g_average_on_host = True
+            return be
+    a = DictFact(**kw).fit(X)
+    b = HostG(**kw).fit(X)
+    assert b._backend.G_average.device.type == 'cpu' and b._backend.G_average.is_pinned()
+    assert_array_equal(a.components_, b.components_)
+    assert_array_equal(a.code_, b.code_)
+    assert_array_equal(a.G_average_, b.G_average_)
+
+
 # ---- the reference's own functional tests (modl/decomposition/tests/test_dict_fact.py) ----------
 solver_dict = {'masked': {'Dx_agg': 'masked', 'G_agg': 'masked'}, 'gram': {'Dx_agg': 'masked', 'G_agg': 'full'},
                'average': {'Dx_agg': 'masked', 'G_agg': 'masked'}, 'full': {'Dx_agg': 'full', 'G_agg': 'full'}}
