@@ -78,8 +78,7 @@ class M1Stream:
         self.gen.manual_seed((self.seed * 1000003 + self.rank) * 1000003 + j)
         Z = torch.randn(n, self.k0, device=self.device, generator=self.gen)
         M = torch.rand(n, self.k0, device=self.device, generator=self.gen) < self.density
-        torch.randn(out.shape, device=self.device, generator=self.gen, out=out)
-        out.mul_(self.noise)
+        out.normal_(0.0, self.noise, generator=self.gen)           # noise E, in place (one pass over the block)
         out.addmm_(Z * M, self.Q)
         self.generated_rows += n
 
