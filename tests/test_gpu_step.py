@@ -356,6 +356,36 @@ def test_partial_fit_streams_host_input_in_chunks(DictFact, tmp_path, source):
         assert_array_equal(a, c)
 
 
+@pytest.mark.parametrize('k,b,red', [(32, 64, 4), (72, 50, 1)])
+def test_wide_statistics_tile(DictFact, oracle, k, b, red):
+    """p >= 65 536 features: the p x k statistics product runs as its own k-wide launch (csrc/gemm_wide.hpp: 32 features
+    x all atoms per tile, X read once) instead of riding on the dictionary update; p not a multiple of the tile, k < 256
+    (masked atoms), a ragged minibatch (K = 50 samples: zero-filled rows of the staged X tile).
+    The kernel itself: after the FIRST minibatch (w = 1) B_ = code^T X / b exactly - checked against that product of the
+    GPU's own codes in f64, every row.  The step around it: dictionary and codes against the f32 oracle within the
+    reference's own f32 noise (f32 oracle vs f64 oracle: the code products contract over up to 65 604 features)."""
+    p = 65604
+    rs = np.random.RandomState(k)
+    n = max(2 * b, k)
+    X = (rs.randn(n, 24) @ rs.randn(24, p) / 5 + 0.5 * rs.randn(n, p)).astype(np.float32)
+    kw = dict(n_components=k, batch_size=b, reduction=red, code_alpha=0.3, learning_rate=0.9, random_state=0)
+    est = DictFact(**kw)
+    est.prepare(n_samples=n, X=X)
+    est.partial_fit(X[:b], np.arange(b))
+    code = est.code_[:b].astype(np.float64)
+    assert rel_fro(est.B_, code.T @ X[:b].astype(np.float64) / b) < 2e-6
+    assert rel_fro(est.C_, code.T @ code / b) < 2e-6
+    st = {}
+    for dt in (np.float32, np.float64):
+        pr = oracle.SomfParams(**kw)
+        st[dt] = oracle.prepare(pr, n_samples=n, X=X.astype(dt))
+        oracle.partial_fit(st[dt], pr, X[:b].astype(dt), np.arange(b))
+    for got, name in ((est.components_, 'D'), (est.code_[:b], 'code')):
+        ref32, ref64 = getattr(st[np.float32], name)[:got.shape[0]], getattr(st[np.float64], name)[:got.shape[0]]
+        noise = rel_fro(ref32, ref64)
+        assert rel_fro(got, ref64) <= 2 * noise + 1e-5, (name, rel_fro(got, ref64), noise)
+
+
 def test_g_average_in_pinned_host_memory(DictFact):
     """G_average_ (n k^2 elements; a disk memmap in the reference, dict_fact.py:431-439) does not have to fit in HBM:
     kept in pinned host memory, read and written by the kernels over the host link, the fit gives the bits of the run
