@@ -440,9 +440,16 @@ class _SubsetsAhead:
     per minibatch and depends on nothing but the sampler's own state, so the draws - same generator, same order -
     can run ahead (ctypes releases the GIL around the call)."""
 
+    _pool_pid = None
+    _pool = None          # one worker thread for the whole process, started at first use (a thread per partial_fit
+                          # call costs ~0.1 ms, which shows in short calls)
+
     def __init__(self, sampler, reduction, n, depth=8):
         import queue
-        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        if _SubsetsAhead._pool is None or _SubsetsAhead._pool_pid != os.getpid():     # (threads do not survive a fork)
+            _SubsetsAhead._pool = ThreadPoolExecutor(1, thread_name_prefix='modl-subsets')
+            _SubsetsAhead._pool_pid = os.getpid()
         self.q = queue.Queue(maxsize=depth)
         self.stop = False
 
@@ -451,11 +458,16 @@ class _SubsetsAhead:
                 for _ in range(n):
                     if self.stop:
                         return
-                    self.q.put(sampler.yield_subset(reduction))
+                    item = sampler.yield_subset(reduction)
+                    while not self.stop:                     # (a bounded put, so that close() can always end the task)
+                        try:
+                            self.q.put(item, timeout=0.05)
+                            break
+                        except queue.Full:
+                            pass
             except BaseException as e:                       # handed to the consumer
                 self.q.put(e)
-        self.thread = threading.Thread(target=work, daemon=True)
-        self.thread.start()
+        self.task = _SubsetsAhead._pool.submit(work)
 
     def next(self):
         item = self.q.get()
@@ -465,12 +477,7 @@ class _SubsetsAhead:
 
     def close(self):
         self.stop = True
-        while self.thread.is_alive():                        # unblock a producer waiting on a full queue
-            try:
-                self.q.get_nowait()
-            except Exception:
-                pass
-            self.thread.join(timeout=0.001)
+        self.task.result()                                   # the worker is free for the next call
 
 
 class _DeviceRows:
