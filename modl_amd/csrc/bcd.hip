@@ -1137,7 +1137,9 @@ __device__ __forceinline__ void for_each_int(std::integer_sequence<int, As...>, 
 }
 struct AtomGroup { int j[kAtomGroup]; int n; };
 
-template <typename T, int KPL>
+// EPT: elements of the s-vector per thread of the projecting workgroup (s <= 256 EPT; the passes cost EPT selects each,
+// so the smallest that fits is used; elements beyond s are zeros: the sums and their order do not depend on EPT)
+template <typename T, int KPL, int EPT>
 __global__ __launch_bounds__(256) void atom_group_kernel(T *Dt, const T *Bt, const T *C, const int32_t *subset, int64_t s,
                                                          int k, AtomGroup g, int pos, double rho, double *num, T *dold,
                                                          double *partial_old, T *comp_norm, unsigned int *counter,
@@ -1218,14 +1220,14 @@ __global__ __launch_bounds__(256) void atom_group_kernel(T *Dt, const T *Bt, con
             for (int a = 0; a < kAtomGroup; ++a) s_old[a] = o[a];
         }
     }
-    int64_t dst[kProjEpt];
-    enet_scatter_offsets<kProjEpt>(subset, (int64_t)k, s, 256, dst);
-    double X[2][kProjEpt];
-    T Dd[2][kProjEpt];
-    auto load_atom = [&](int a, double (&xd)[kProjEpt], T (&dd)[kProjEpt]) {
+    int64_t dst[EPT];
+    enet_scatter_offsets<EPT>(subset, (int64_t)k, s, 256, dst);
+    double X[2][EPT];
+    T Dd[2][EPT];
+    auto load_atom = [&](int a, double (&xd)[EPT], T (&dd)[EPT]) {
         const int ac = a < g.n ? a : g.n - 1;                            // always a valid slot: no branch around the loads
 #pragma unroll
-        for (int e = 0; e < kProjEpt; ++e) {
+        for (int e = 0; e < EPT; ++e) {
             const int64_t i = threadIdx.x + (int64_t)e * 256;
             const int64_t at = (int64_t)ac * s + (i < s ? i : s - 1);
             xd[e] = num[at];
@@ -1238,28 +1240,31 @@ __global__ __launch_bounds__(256) void atom_group_kernel(T *Dt, const T *Bt, con
     auto step = [&](auto A_) {
         constexpr int a = decltype(A_)::value;
         if (a >= g.n) return;                                            // workgroup-uniform
-        double (&x)[kProjEpt] = X[a & 1];
-        T (&dd)[kProjEpt] = Dd[a & 1];
+        double (&x)[EPT] = X[a & 1];
+        T (&dd)[EPT] = Dd[a & 1];
         const int j = g.j[a];
         const double radius = (double)(T)(s_cn[a] + s_old[a]);          // comp_norm_[k] += subset_norm (:676-678)
         const double cjj = s_cjj[a];
         const bool frozen = !((T)cjj > (T)1e-20);
+        // one reciprocal, then products: a double-precision division is a dozen instructions (v_div_scale, v_rcp_f64,
+        // Newton steps, v_div_fmas, v_div_fixup), 24 of them per thread and atom were ~1.5 us of a 14 us atom step
+        const double icjj = 1.0 / cjj;
 #pragma unroll
-        for (int e = 0; e < kProjEpt; ++e) {
+        for (int e = 0; e < EPT; ++e) {
             const int64_t i = threadIdx.x + (int64_t)e * 256;
             T val = dd[e];
-            if (!frozen) val = (T)(x[e] / cjj);
+            if (!frozen) val = (T)(x[e] * icjj);
             if (pos && val < (T)0) val = 0;                              // dict_fact.py:684-685
             x[e] = (i < s) ? (double)val : 0.0;
         }
-        const double nrm = block_enet_project_vals<T, kProjEpt>(x, dst, Dt + j, s, radius, rho, red, 256, nullptr,
+        const double nrm = block_enet_project_vals<T, EPT>(x, dst, Dt + j, s, radius, rho, red, 256, nullptr,
                                                                 level_hint ? level_hint + j : nullptr);
         if (threadIdx.x == 0) comp_norm[j] = (T)(radius - nrm);         // :690-692
         if (a + 1 < g.n) {
-            double (&xn)[kProjEpt] = X[(a + 1) & 1];
+            double (&xn)[EPT] = X[(a + 1) & 1];
             const double c1 = s_coef[a][(a + 1) % kAtomGroup];
 #pragma unroll
-            for (int e = 0; e < kProjEpt; ++e) {
+            for (int e = 0; e < EPT; ++e) {
                 x[e] -= (double)dd[e];                                   // what this atom changed (0 beyond s)
                 xn[e] -= c1 * x[e];
             }
@@ -1267,14 +1272,14 @@ __global__ __launch_bounds__(256) void atom_group_kernel(T *Dt, const T *Bt, con
             for (int a2 = a + 2; a2 < kAtomGroup; ++a2) {                // the atoms after the next: read-modify-write
                 if (a2 < g.n) {
                     const double c2 = s_coef[a][a2];
-                    double t[kProjEpt];
+                    double t[EPT];
 #pragma unroll
-                    for (int e = 0; e < kProjEpt; ++e) {
+                    for (int e = 0; e < EPT; ++e) {
                         const int64_t i = threadIdx.x + (int64_t)e * 256;
                         t[e] = num[(int64_t)a2 * s + (i < s ? i : s - 1)];
                     }
 #pragma unroll
-                    for (int e = 0; e < kProjEpt; ++e) {
+                    for (int e = 0; e < EPT; ++e) {
                         const int64_t i = threadIdx.x + (int64_t)e * 256;
                         if (i < s) num[(int64_t)a2 * s + i] = t[e] - c2 * x[e];   // read back by this same thread
                     }
@@ -1639,14 +1644,21 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
                 if (j < 0 || j >= k) return MODL_EINVAL;
                 g.j[a] = (int)j;
             }
-#define MODL_GROUP(KPL)                                                                                           \
-    hipLaunchKernelGGL((atom_group_kernel<T, KPL>), dim3(nwg), dim3(256), 0, stream, a.Dt, a.Bt, a.C, a.subset, s, k, g, \
+#define MODL_GROUP_E(KPL, EPT)                                                                                    \
+    hipLaunchKernelGGL((atom_group_kernel<T, KPL, EPT>), dim3(nwg), dim3(256), 0, stream, a.Dt, a.Bt, a.C, a.subset, s, k, g, \
                        a.comp_pos, a.comp_l1_ratio, num, dold, pold, a.comp_norm, counter, a.level_hint)
+#define MODL_GROUP(KPL)                                                                                           \
+    do {                                                                                                          \
+        if (s <= 12 * 256) MODL_GROUP_E(KPL, 12);                                                                 \
+        else if (s <= 20 * 256) MODL_GROUP_E(KPL, 20);                                                            \
+        else MODL_GROUP_E(KPL, kProjEpt);                                                                         \
+    } while (0)
             if (k <= 64) MODL_GROUP(1);
             else if (k <= 128) MODL_GROUP(2);
             else if (k <= 256) MODL_GROUP(4);
             else MODL_GROUP(8);
 #undef MODL_GROUP
+#undef MODL_GROUP_E
             MODL_LAUNCH_CHECK();
             if (launches) *launches += 1;
         }

@@ -102,8 +102,28 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *red2, i
     __syncthreads();
     if (lane == 0) { red2[2 * wid] = a; red2[2 * wid + 1] = b; }
     __syncthreads();
+    if (nw == 4) {
+        // four wavefronts (every register-resident projection): the four partial sums as broadcast reads, added in
+        // the association of the wave reduction, (r0 + r1) + (r2 + r3) - same bits, a quarter of its instructions
+        a = (red2[0] + red2[2]) + (red2[4] + red2[6]);
+        b = (red2[1] + red2[3]) + (red2[5] + red2[7]);
+        return;
+    }
     a = wave_sum(lane < nw ? red2[2 * lane] : 0.0);
     b = wave_sum(lane < nw ? red2[2 * lane + 1] : 0.0);
+}
+// one block-wide sum (the same exchange, without a second value travelling along)
+__device__ __forceinline__ void block_sum1(double &a, double *red2, int nthreads) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (nthreads + 63) >> 6;
+    a = wave_sum(a);
+    __syncthreads();
+    if (lane == 0) red2[2 * wid] = a;
+    __syncthreads();
+    if (nw == 4) {
+        a = (red2[0] + red2[2]) + (red2[4] + red2[6]);
+        return;
+    }
+    a = wave_sum(lane < nw ? red2[2 * lane] : 0.0);
 }
 
 // The same projection for vectors of at most EPT * nthreads elements (unit-stride input), run by the first
@@ -150,10 +170,10 @@ __device__ __forceinline__ double block_enet_project_vals(double (&x)[EPT], cons
         return 0.0;
     }
     if (l1_ratio == 0.0) {                                   // enet.pyx:62-70, radius in squared-norm units
-        double s = 0, dummy = 0;
+        double s = 0;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) s += x[e] * x[e];
-        block_sum2(s, dummy, red2, nthreads);
+        block_sum1(s, red2, nthreads);
         const T scale = (s <= radius) ? (T)1 : (T)sqrt(s / radius);
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
@@ -166,7 +186,6 @@ __device__ __forceinline__ double block_enet_project_vals(double (&x)[EPT], cons
     }
     const double gamma = 2.0 / l1_ratio - 2.0;
     const double R = radius / l1_ratio;
-    double dummy = 0;
     double ax[EPT], term[EPT];                              // |x| and its contribution, computed once
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -202,11 +221,11 @@ __device__ __forceinline__ double block_enet_project_vals(double (&x)[EPT], cons
                 c1 += i1 ? 1 : 0;
             }
             S += S1;
-            double cnt = (double)(c0 + c1), dummy2 = 0;
+            double cnt = (double)(c0 + c1);
             block_sum2(S, cnt, red2, nthreads);
             double h0;
             if (gamma != 0.0) {
-                block_sum2(P, dummy2, red2, nthreads);
+                block_sum1(P, red2, nthreads);
                 const double d = 1.0 + l0 * gamma;
                 const double sum_u = (P - cnt * l0) / d;
                 const double sum_a2 = (S - P) / (0.5 * gamma);
@@ -234,7 +253,7 @@ __device__ __forceinline__ double block_enet_project_vals(double (&x)[EPT], cons
         double tot = 0;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) tot += term[e];
-        block_sum2(tot, dummy, red2, nthreads);
+        block_sum1(tot, red2, nthreads);
         if (tot <= R) {                                      // inside the ball: copy
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
@@ -273,20 +292,20 @@ __device__ __forceinline__ double block_enet_project_vals(double (&x)[EPT], cons
     if (dbg && threadIdx.x == 0) dbg[6] = clock64();
     if (level_io && threadIdx.x == 0) *level_io = level;
     const double lT = (double)(T)level;
-    const double den = 1.0 + lT * gamma;
+    const double inv_den = 1.0 / (1.0 + lT * gamma);       // one division (exactly 1 for l1 atoms, gamma = 0), EPT products
     double nrm = 0;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int64_t i = threadIdx.x + (int64_t)e * nthreads;
         double pos = fabs(x[e]) - lT;
         pos = pos > 0 ? pos : 0;
-        const T o = (T)(((x[e] >= 0) ? pos : -pos) / den);   // enet.pyx:121, sign(0) = +1
+        const T o = (T)(((x[e] >= 0) ? pos : -pos) * inv_den);   // enet.pyx:121, sign(0) = +1
         if (i < n) out[dst[e]] = o;
         x[e] = (i < n) ? (double)o : 0.0;
         const double a = fabs(x[e]);
         nrm += a * (l1_ratio + (1.0 - l1_ratio) * a);
     }
-    block_sum2(nrm, dummy, red2, nthreads);
+    block_sum1(nrm, red2, nthreads);
     return nrm;
 }
 
