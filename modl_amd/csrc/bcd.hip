@@ -72,7 +72,7 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     L.off_Tp = take(sizeof(double) * 2 * (kNB * kNB + kNB) + 256 + 512);  // two CA records (ping-pong) + arrival counters + debug stamps
     L.off_u = take(tsz * (size_t)s_max);
     L.off_pold = take(sizeof(double) * (size_t)L.nwg_grad);
-    L.off_Dnew = take(tsz * (size_t)s_max * k);                       // sgd only, but sized once
+    L.off_Dnew = take(tsz * (size_t)(cdiv(s_max > 0 ? s_max : 1, 32) * 32) * k);   // sgd / the packed dictionary (whole tiles of 32 rows)
     L.off_colp = take(sizeof(double) * (size_t)L.nslab_max * k);
     L.off_BsP = take(tsz * (size_t)s_max * k);                        // packed B rows (packed D shares off_Dnew)
     L.off_gpartial = take(sizeof(double) * 2 * (size_t)kCounters * (kNB * kNB + kNB));   // group sums (two-level reduction), ping-pong
@@ -90,6 +90,13 @@ size_t dict_update_workspace(int dtype, int64_t s_max, int k) {
 }
 
 __device__ __forceinline__ int64_t sub_row(const int32_t *subset, int64_t f) { return subset ? (int64_t)subset[f] : f; }
+// Element (sampled feature f, sweep position c) of the PACKED dictionary of the fused block kernel, stored in the order
+// its matrix-core A operands are read: tiles of 32 features x 4 atoms, 512 contiguous bytes each, so the 16-byte-per-lane
+// operand load of a wavefront (lane = feature, 4 consecutive atoms; the two halves of the wave take adjacent atom
+// groups) is ONE contiguous kilobyte instead of 64 separate rows (k % 4 == 0).
+__device__ __forceinline__ int64_t dfrag(int64_t f, int c, int k) {
+    return ((f >> 5) * (int64_t)(k >> 2) + (c >> 2)) * 128 + ((f & 31) << 2) + (c & 3);
+}
 
 // ---------------------------------------------------------------- blocked path
 template <typename T>
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_
         const int64_t f = id, src = sub_row(subset, f) * k;
         for (int jj = threadIdx.x; jj < k; jj += 256) {
             const int o = order[jj];
-            DsP[f * k + jj] = Dt[src + o];
+            DsP[dfrag(f, jj, k)] = Dt[src + o];
             BsP[f * k + jj] = Bt[src + o];
         }
     }
@@ -530,6 +537,180 @@ __device__ __forceinline__ void resolve_wave(const double (*M)[kNB + 1], const d
     }
 }
 
+// ---- The same recursion on TWO wavefronts (fused block kernel).  One wavefront is bound by its instruction count:
+// of the ~430 cycles per atom only ~200 are the dependency chain z_j -> |u_j|^2 -> alpha_j (32-lane dot: 4 DPP stages
+// + 2 swaps = 144 cycles, rsqrt + Newton + min = 47; scripts/micro/chain_lat.hip), the rest are the partial sums
+// sum_{i<j} c_ji S[i] of the rows ahead and the coefficient reads they need.  So a CHAIN wave keeps the chain and the
+// two nearest terms (i = j - 1 on the chain, i = j - 2 beside it), and a HELPER wave on another SIMD keeps a running
+// P_m = (e_m | M[:,m]) - sum_{i <= m-3} c_mi S[i] for every row m, right-looking: when S[i] arrives it first completes
+// and publishes P_{i+3}, then updates the rows behind it.  The two talk through LDS mailboxes (rings of 8 slots, one
+// monotonic counter each: data store, then counter store - the LDS executes a wavefront's operations in order - and
+// the reader requests counter, then data, in ONE round trip, one step before it needs them).  The helper has two chain
+// steps (~600 cycles) to turn S[i] into P_{i+3}: one LDS round trip each way (~76 cycles) + one fma.
+// Waiting is a spin on LDS; both wavefronts belong to one workgroup, hence are resident together.
+typedef __attribute__((address_space(3))) volatile double lds_vf64;   // (a generic volatile pointer would turn into
+typedef __attribute__((address_space(3))) volatile int lds_vi32;      //  flat accesses with a wait behind each)
+constexpr int kMbox = 8;                                               // mailbox slots (steps in flight <= 3)
+struct ResolveMail {
+    double *Pm, *Zm;        // [kMbox][64]
+    int *pcount, *zcount;   // rows published by the helper / S rows published by the chain wave
+};
+
+template <typename T>
+__device__ __forceinline__ void resolve_chain(const double *D2, const double *Cs, int jj_x, double budget_x, int nb,
+                                              T *norm_out, double *scr, const ResolveMail &mb,
+                                              unsigned long long *stamps = nullptr) {
+    const int lane = threadIdx.x & 63, x = lane & 31;
+    const bool lower = lane < 32;
+    lds_vf64 *Pm = (lds_vf64 *)mb.Pm;
+    lds_vf64 *Zm = (lds_vf64 *)mb.Zm;
+    lds_vi32 *pcount = (lds_vi32 *)mb.pcount;
+    lds_vi32 *zcount = (lds_vi32 *)mb.zcount;
+    const double rad_x = budget_x + D2[x];                                       // budget + old squared norm
+    const bool live_x = (rad_x > 0.0) && (x < nb);
+    if (lower) {
+        scr[2 * x] = live_x ? sqrt(rad_x) : 0.0;                                 // sqrt(radius_j) ...
+        scr[2 * x + 1] = live_x ? 1.0 : 0.0;                                     // ... and the cap of alpha_j
+    }
+    if (stamps && lane == 0) { stamps[8] = clock64() + (unsigned long long)(rad_x * 0); stamps[21] = 0; stamps[22] = 0; }
+    double al_prev = 0.0, q_prev = 0.0, z_prev = 0.0, Z1 = 0.0, Z2 = 0.0;        // Z1 = S[j-1], Z2 = S[j-2] (| Y)
+    int rn = *pcount;
+    double Pn = Pm[lane];
+    while (__builtin_amdgcn_readfirstlane(rn) < 1) { rn = *pcount; Pn = Pm[lane]; }
+    double srn = scr[0], capn = scr[1], c2n = 0.0, c1n = Cs[1 * kNB + 0];
+    // A REAL loop over groups of kMbox steps (static mailbox slots inside a group; everything else the steps address
+    // advances with the group): 3.6 KB of code instead of 15 KB of straight-line code that is executed once - the block
+    // kernel is ~85 KB, more than the instruction cache, and the first steps of the unrolled form ran at 670 cycles
+    // per atom while the other wavefronts were streaming their own code, 360 afterwards.  The boundary cases are
+    // data-driven: step 0 publishes a dummy row under count 0 and multiplies S[-2] = 0 by a finite word in front of
+    // Cs; the last step requests row 32, which the helper "publishes" (count 33) together with row 31.
+    const double *csr = Cs;                                  // row j of the coefficients
+    const double *scj = scr;                                 // (sqrt(radius_j), cap_j)
+    double *sco = scr + 2 * kNB;                             // (alpha_j, |u_j|^2)
+#pragma unroll 1
+    for (int jb = 0; jb < kNB; jb += kMbox) {
+        if (stamps && lane == 0 && jb > 0) stamps[8 + jb / 8] = clock64();
+#pragma unroll
+        for (int u = 0; u < kMbox; ++u) {
+            const int j = jb + u;
+            if (stamps && lane == 0 && jb == 0) stamps[24 + u] = clock64();
+            const double P = Pn, sr = srn, cap = capn, c2 = c2n, c1 = c1n;
+            {                                                // S[j-1] | Y[j-1] -> helper (and the apply step)
+                const double Zp = al_prev * z_prev;
+                Zm[((u + kMbox - 1) % kMbox) * 64 + lane] = Zp;
+                *zcount = j;
+                Z2 = Z1; Z1 = Zp;
+            }
+            {                                                // everything step j + 1 needs from LDS is requested now
+                rn = *pcount;
+                Pn = Pm[((u + 1) % kMbox) * 64 + lane];
+                srn = scj[2 * (u + 1)]; capn = scj[2 * (u + 1) + 1];
+                c2n = csr[(u + 1) * kNB + u - 1];            // c_{j+1,j-1}
+                c1n = csr[(u + 2) * kNB + u + 1];            // c_{j+2,j+1}
+            }
+            const double part = __builtin_fma(-c2, Z2, P);   // row j: P_j holds the terms i <= j - 3
+            const double z = __builtin_fma(-al_prev, q_prev, part);
+            double t, w;
+            halves(z, t, w);
+            double pr = t * w;                               // both halves hold the same products
+            pr += dpp_perm<0xB1>(pr);
+            pr += dpp_perm<0x4E>(pr);
+            pr += dpp_perm<0x141>(pr);
+            pr += dpp_perm<0x140>(pr);
+            double r0, r1;
+            lane_swap<true>(pr, r0, r1);
+            const double nrm = r0 + r1;                      // every lane: |u_j|^2
+            const double q = c1 * z;                         // c_{j+1,j} z_j
+            const double y = __builtin_amdgcn_rsq(nrm);
+            const double r = __builtin_fma(-(0.5 * y), nrm * y, 0.5);
+            const double yn = __builtin_fma(y, r, y);
+            double al;
+            const double sy = sr * yn;
+            asm("v_min_f64 %0, %1, %2" : "=v"(al) : "v"(sy), "v"(cap));
+            sco[2 * u] = al;
+            sco[2 * u + 1] = nrm;
+            al_prev = al; q_prev = q; z_prev = z;
+            __builtin_amdgcn_sched_barrier(0);               // (the check below waits for the LDS: not inside the chain)
+            if (__builtin_expect(__builtin_amdgcn_readfirstlane(rn) < j + 2, 0)) {
+                do {
+                    rn = *pcount;
+                    Pn = Pm[((u + 1) % kMbox) * 64 + lane];
+                } while (__builtin_amdgcn_readfirstlane(rn) < j + 2);
+            }
+        }
+        csr += kMbox * (kNB + 1);
+        scj += 2 * kMbox;
+        sco += 2 * kMbox;
+    }
+    Zm[((kNB - 1) % kMbox) * 64 + lane] = al_prev * z_prev;
+    *zcount = kNB;
+    if (lower && norm_out && x < nb) {
+        const double al = scr[2 * kNB + 2 * x], nrm = scr[2 * kNB + 2 * x + 1];
+        norm_out[jj_x] = (T)(rad_x - al * al * nrm);
+    }
+}
+
+// CsT[i][m] = Cs[m][i]: the coefficients that multiply S[i], contiguous in m
+__device__ __forceinline__ void resolve_helper(const double (*M)[kNB + 1], const double *CsT, double *CAout,
+                                               int ca_stride, const ResolveMail &mb) {
+    const int lane = threadIdx.x & 63, x = lane & 31;
+    const bool lower = lane < 32;
+    lds_vf64 *Pm = (lds_vf64 *)mb.Pm;
+    lds_vf64 *Zm = (lds_vf64 *)mb.Zm;
+    lds_vi32 *pcount = (lds_vi32 *)mb.pcount;
+    lds_vi32 *zcount = (lds_vi32 *)mb.zcount;
+    const double hmask = lower ? 0.0 : 1.0;
+    double P[kNB];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        P[m] = __builtin_fma(hmask, M[x][m], (lower && x == m) ? 1.0 : 0.0);   // e_m | M[:,m]
+        Pm[m * 64 + lane] = P[m];
+    }
+    *pcount = 3;
+#pragma unroll
+    for (int m = 3; m < kNB; ++m) {
+        P[m] = __builtin_fma(hmask, M[x][m], (lower && x == m) ? 1.0 : 0.0);
+        asm volatile("" : "+v"(P[m]));                        // (computed HERE: the compiler otherwise sinks every update
+        if (m % 8 == 7) __builtin_amdgcn_sched_barrier(0);    //  of a row to the row's first use - the left-looking form -
+    }                                                         //  and keeps all coefficients and S rows live: spills)
+    // the coefficients that multiply S[i] (CsT row i) are requested one iteration ahead: no LDS round trip between the
+    // arrival of S[i] and the updates
+    double cc[kNB], cn[kNB];
+#pragma unroll
+    for (int m = 3; m < kNB; ++m) cc[m] = CsT[m];
+#pragma unroll
+    for (int i = 0; i < kNB; ++i) {
+        if (i + 1 < kNB) {
+#pragma unroll
+            for (int m = i + 4; m < kNB; ++m) cn[m] = CsT[(i + 1) * kNB + m];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int ready = *zcount;
+        double Zi = Zm[(i % kMbox) * 64 + lane];
+        while (__builtin_amdgcn_readfirstlane(ready) < i + 1) {
+            ready = *zcount;
+            Zi = Zm[(i % kMbox) * 64 + lane];
+        }
+        // (scheduler fences and pinned results: left alone, the compiler sinks every update of a row to the row's first
+        // use - the left-looking form - and keeps all coefficients and S rows live: spills)
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 3 < kNB) {                                   // the most urgent row first
+            P[i + 3] = __builtin_fma(-cc[i + 3], Zi, P[i + 3]);
+            Pm[((i + 3) % kMbox) * 64 + lane] = P[i + 3];
+            *pcount = (i + 3 == kNB - 1) ? kNB + 1 : i + 4;  // (+ the row the chain wave's last step asks for)
+        }
+        if (lower) CAout[i * ca_stride + x] = Zi;            // S[i] for the apply step
+#pragma unroll
+        for (int m = i + 4; m < kNB; ++m) {
+            P[m] = __builtin_fma(-cc[m], Zi, P[m]);
+            asm volatile("" : "+v"(P[m]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = i + 4; m < kNB; ++m) cc[m] = cn[m];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bcd_resolve_kernel(const double *partial, int nslab, const double *coef_all,
                                                           const int32_t *order, int k, int j0, int nb, T *comp_norm,
@@ -654,7 +835,11 @@ __device__ __forceinline__ void bcd_rider_tile(const BcdRiderArgs &r, char *smem
 }
 
 template <int RT, int GPW>   // 32 * RT features per workgroup; GPW contraction groups (8 atoms) per worker wave
-__global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
+// (waves per SIMD pinned to the two a 384-thread workgroup needs: with the recursion on two lean wavefronts the
+// largest register need of the kernel fell under 170, and the scheduler, now aiming at three waves per SIMD, serialised
+// the workers' ~100 operand loads - one round trip each, 35 k cycles - to stay there)
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
     constexpr int RB = 32 * RT;
     constexpr int EPT = RB / 8;                      // epilogue elements per thread
     constexpr int DLS = kNB + 4;                     // row stride of the Delta tile (16-byte aligned rows)
@@ -672,14 +857,21 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRider
     float *As = red + 4 * RB * (kNB + 1);                                      // [RB][NB + 1]
     float *Dl = As + RB * (kNB + 1) + ((4 - (RB * (kNB + 1)) % 4) % 4);        // [RB][DLS] Delta of the previous block
     int *flag = reinterpret_cast<int *>(Dl + RB * DLS);
+    double *CsT = reinterpret_cast<double *>(flag + 4);                        // [NB][NB] Cs transposed (resolve_helper)
+    ResolveMail mail;
+    mail.Pm = CsT + kNB * kNB;                                                 // [kMbox][64]
+    mail.Zm = mail.Pm + kMbox * 64;                                            // [kMbox][64]
+    mail.pcount = flag + 1;
+    mail.zcount = flag + 2;
     float *Ap = red;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if ((int)blockIdx.x >= rider.nslab) {
         bcd_rider_tile(rider, smem_raw);
         return;
     }
-    const bool worker = wid < 4;
+    const bool worker = wid < 4;                     // wave 4: the chain of the recursion, wave 5: its helper
     const bool has_prev = p.nb_prev > 0, fin = p.nb == 0;
+    if (tid == 0) { *mail.pcount = 0; *mail.zcount = 0; }
     const int64_t f0 = (int64_t)blockIdx.x * RB;
     const int nwg = rider.nslab, gsz = p.group, ngroups = (nwg + gsz - 1) / gsz;
     unsigned long long *st = (p.stamps && blockIdx.x == 0 && !fin) ? p.stamps : nullptr;
@@ -712,9 +904,11 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRider
                 const bool ok = p.j0_prev + e / kNB < k;
                 Cs[e] = ok ? cf[q].x : 0.0;
                 Cs[e + 1] = ok ? cf[q].y : 0.0;
+                CsT[(e % kNB) * kNB + e / kNB] = ok ? cf[q].x : 0.0;
+                CsT[(e % kNB + 1) * kNB + e / kNB] = ok ? cf[q].y : 0.0;
             }
             if (st && tid == 0) st[17] = clock64();
-        } else {
+        } else if (wid == 4) {
             // the resolver's own inputs (atom index and norm budget of column x) and the tail of the records
             // (elements 512 ..) that the 256 worker threads do not cover
             const int x = lane & 31;
@@ -739,20 +933,45 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRider
     float bq[4] = {0.f, 0.f, 0.f, 0.f};
     f16v acc[RT];
     if (!worker) {
-        if (has_prev)
-            resolve_wave<float>(reinterpret_cast<const double (*)[kNB + 1]>(Ms), D2s, Cs, res_jj, res_budget, p.nb_prev,
-                                blockIdx.x == 0 ? p.norm_out : nullptr, CAs, kCaStride, d2red, st);
-        if (st && lane == 0) st[2] = clock64();
-    } else {
+        // The two wavefronts of the recursion leave through their own copy of the remaining barriers: nothing of the
+        // workers' state is live across their code (a common tail made the register allocator carry the workers'
+        // accumulators and epilogue operands through the recursion - and spill the helper's running sums).  A
+        // hardware barrier counts wavefronts, not program counters.
+        __builtin_amdgcn_s_setprio(3);               // the recursion is the critical path: issue before the workers' loads
+        if (wid == 4) {
+            if (has_prev)
+                resolve_chain<float>(D2s, Cs, res_jj, res_budget, p.nb_prev, blockIdx.x == 0 ? p.norm_out : nullptr,
+                                     d2red, mail, st);
+            if (st && lane == 0) st[2] = clock64();
+        } else if (has_prev) {
+            resolve_helper(reinterpret_cast<const double (*)[kNB + 1]>(Ms), CsT, CAs, kCaStride, mail);
+            if (st && lane == 0) st[14] = clock64();
+        }
+        lds_barrier();                                                                // ---- barrier 2
+        if (fin) return;
+        lds_barrier();                                                                // ---- barrier 3
+        lds_barrier();                                                                // ---- barrier 4
+        lds_barrier();                                                                // ---- barrier 5
+        if (ngroups > 1) {
+            const int g = (int)blockIdx.x / gsz;
+            const int gsize = (nwg - g * gsz < gsz) ? nwg - g * gsz : gsz;
+            if (!arrive_last(p.counter + 1 + g, (unsigned int)gsize, flag)) return;
+            if (wid == 4)
+                reduce_records_v2<kPackStride>(p.rec_out + (int64_t)g * gsz * kPackStride, gsize, 256 + lane,
+                                               256 + lane < kPackStride / 2, SinkGlobal{p.grec_out + (int64_t)g * kPackStride});
+        }
+        return;
+    }
+    {
         // every global load of the workers, requested at once: epilogue operands, the coefficient block as
         // MFMA B fragments (straight from L2: two 128-byte rows per wave instruction, no LDS staging and
         // therefore no barrier in the resolver's shadow), the dictionary rows as A fragments, the previous
         // block's old values and a-tile
         // The resolver wave shares SIMD 0 with worker wave 0; back-to-back MFMAs of that wave would slow the
         // recursion down (measured: +5 k cycles), so for k <= 256 the product is split over waves 1-3 only.
-        constexpr int PW0 = (GPW == 8) ? 1 : 0;                      // first wave that takes part in the product
-        constexpr int GW = (GPW == 8) ? 11 : GPW;                    // contraction groups (8 atoms) per product wave
-        const bool pwave = wid >= PW0;
+        constexpr int PW0 = (GPW == 8) ? (RT == 1 ? 2 : 1) : 0;      // first wave that takes part in the product
+        constexpr int GW = (GPW == 8) ? (RT == 1 ? 16 : 11) : GPW;   // contraction groups (8 atoms) per product wave
+        const bool pwave = __builtin_amdgcn_readfirstlane(wid) >= PW0;   // (wave-uniform for the compiler too)
         float bfr[GW][4];
         float4 av[GW][RT];
         float4 va[NA];
@@ -766,22 +985,29 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRider
                 const int64_t f = f0 + rg + 8 * q;
                 const bool ok = col_ok && f < p.s;
                 const int64_t el = ok ? f * k + p.j0 + col : 0;
-                const float bv = p.Bt[el], dv = p.Dt[el];
+                const float bv = p.Bt[el], dv = p.Dt[ok ? dfrag(f, p.j0 + col, k) : 0];
                 eB[q] = ok ? bv : 0.f;
                 eD[q] = ok ? dv : 0.f;
             }
             const bool cok = (lane & 31) < p.nb;
             const float *cpc = p.CP + p.j0 + (cok ? (lane & 31) : 0);
+            const float *cp0 = p.CP + p.j0;
+            const unsigned lane_off = cok ? (unsigned)(lane & 31) : 0u;
+            // (wave-uniform branch: a wave outside the product requests none of its operands - wave 0 shares its SIMD
+            // with the resolver, and the ~100 address computations + requests below took the recursion's issue slots
+            // for its first 16 steps: ~530 cycles per atom instead of ~430)
+            if (pwave)
 #pragma unroll
             for (int g = 0; g < GW; ++g) {
                 const int kb = ((wid - PW0) * GW + g) * 8 + 4 * h;  // this lane's 4 consecutive atoms
+                // 32-bit element offsets from one uniform base (k <= 512): two instructions of address arithmetic per
+                // request instead of eight with a 64-bit multiply (92 cycles per request, measured).  k % 4 == 0, so
+                // kb < k covers kb + u < k; any valid address serves the masked-out lanes.
+                const unsigned rb = (kb < k ? (unsigned)kb * (unsigned)k : 0u) + lane_off;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool ok = pwave && cok && kb + u < k;
-                    const float v = cpc[(int64_t)(ok ? kb + u : 0) * k];
-                    bfr[g][u] = ok ? v : 0.f;
-                }
-            }
+                for (int u = 0; u < 4; ++u) bfr[g][u] = cp0[rb + (unsigned)u * (unsigned)k];   // (masked below, behind
+            }                                                        // the scheduler fence: a select next to its load has
+                                                                     // been compiled into load - wait - select, 44 round trips)
             if (has_prev) {   // rank-32 correction: wave w contracts the previous block's atoms 8w .. 8w+7
                 const int jb = wid * 8 + 4 * h;
 #pragma unroll
@@ -792,17 +1018,17 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRider
                 }
             }
             // dictionary rows -> MFMA A operands, the wave's whole contraction range in flight at once
+            if (pwave)
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 int64_t f = f0 + t * 32 + (lane & 31);
                 if (f >= p.s) f = p.s - 1;               // clamped: results of padded rows are discarded
-                const float *rowp = p.Dt + f * k;
+                const float *rowp = p.Dt + dfrag(f, 0, k);
 #pragma unroll
                 for (int g = 0; g < GW; ++g) {
                     const int kb = ((wid - PW0) * GW + g) * 8 + 4 * h;
-                    const bool ok = pwave && kb + 3 < k;
-                    const float4 v = *reinterpret_cast<const float4 *>(rowp + (ok ? kb : 0));
-                    av[g][t] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const bool ok = kb + 3 < k;
+                    av[g][t] = *reinterpret_cast<const float4 *>(rowp + (ok ? kb : 0) * 32);   // (masked below)
                 }
             }
         }
@@ -819,7 +1045,7 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRider
                 for (int r = 0; r < 4; ++r) {
                     const int64_t f = f0 + ft * 16 + (lane >> 4) + 4 * r;
                     const bool live = f < p.s && cj < p.nb_prev;
-                    const float dv = p.Dt[live ? f * k + p.j0_prev + cj : 0];
+                    const float dv = p.Dt[live ? dfrag(f, p.j0_prev + cj, k) : 0];
                     dold[u][r] = live ? dv : 0.f;
                     orow[u][r] = (live ? sub_row(p.subset, f) : 0) * k + oc;
                 }
@@ -834,6 +1060,7 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRider
         }
         __builtin_amdgcn_sched_barrier(0);
         if (st && tid == 0) st[13] = clock64();
+        if (st && tid == 64) st[20] = clock64();
         if (!fin) {
 #pragma unroll
             for (int t = 0; t < RT; ++t)
@@ -842,8 +1069,13 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRider
             if (pwave)
 #pragma unroll
             for (int g = 0; g < GW; ++g) {
+                const int kb = ((wid - PW0) * GW + g) * 8 + 4 * h;
+                const bool cok = (lane & 31) < p.nb;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bfr[g][u] = (cok && kb + u < k) ? bfr[g][u] : 0.f;
 #pragma unroll
                 for (int t = 0; t < RT; ++t) {
+                    if (!(kb + 3 < k)) av[g][t] = make_float4(0.f, 0.f, 0.f, 0.f);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].x, bfr[g][0], acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].y, bfr[g][1], acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].z, bfr[g][2], acc[t], 0, 0, 0);
@@ -865,6 +1097,9 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRider
             }
         }
         if (st && tid == 0) st[3] = clock64();
+        if (st && tid == 64) st[15] = clock64();
+        if (st && tid == 128) st[18] = clock64();
+        if (st && tid == 192) st[19] = clock64();
     }
     lds_barrier();                                                                    // ---- barrier 2
     if (st && tid == 0) st[4] = clock64();
@@ -889,7 +1124,7 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRider
                 const bool live = f < p.s && cj < p.nb_prev;
                 const float dnew = (float)dn[r];
                 if (live) {
-                    p.Dt[f * k + p.j0_prev + cj] = dnew;
+                    p.Dt[dfrag(f, p.j0_prev + cj, k)] = dnew;
                     p.Dt_out[orow[u][r]] = dnew;             // final: no unpack pass
                 }
                 Dl[frow * DLS + cj] = live ? dnew - dold[u][r] : 0.f;
@@ -974,8 +1209,7 @@ __global__ __launch_bounds__(320) void bcd_block_kernel(BcdBlockArgs p, BcdRider
         if (!arrive_last(p.counter + 1 + g, (unsigned int)gsize, flag)) return;
         const double *grecs = p.rec_out + (int64_t)g * gsz * kPackStride;
         const SinkGlobal gsink{p.grec_out + (int64_t)g * kPackStride};
-        if (worker) reduce_records_v2<kPackStride>(grecs, gsize, tid, true, gsink);
-        else reduce_records_v2<kPackStride>(grecs, gsize, 256 + lane, 256 + lane < kPackStride / 2, gsink);
+        reduce_records_v2<kPackStride>(grecs, gsize, tid, true, gsink);       // (the record's tail: wave 4, above)
     }
 }
 
@@ -983,8 +1217,9 @@ static size_t bcd_block_lds(int gpw, int RT) {
     const int kpad = gpw * 32, RB = 32 * RT;
     const size_t dbl = (size_t)kNB * (kNB + 1) + kNB + kNB * kNB + (size_t)kNB * kCaStride + 8 * kNB;
     const size_t fl = 4 * (size_t)RB * (kNB + 1) + RB * (kNB + 1) + 4 + RB * (kNB + 4) + 4;
+    const size_t mail = (size_t)kNB * kNB + 2 * kMbox * 64;     // Cs transposed + the two mailboxes of the recursion
     (void)kpad;
-    return dbl * 8 + fl * 4 + 16;
+    return dbl * 8 + fl * 4 + 16 + mail * 8 + 16;
 }
 
 // ---------------------------------------------------------------- generic path
@@ -1548,7 +1783,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                 ba.j0 = j0; ba.nb = nb; ba.j0_prev = j0_prev; ba.nb_prev = blk_i ? nb_prev : 0;
                 BcdRiderArgs r = rid;
                 const int extra = blk_i ? ride(r) : 0;                 // (launch 0 is short: no resolver)
-                hipLaunchKernelGGL(blk, dim3(nslab + extra), dim3(320), lds_bytes(extra), stream, ba, r);
+                hipLaunchKernelGGL(blk, dim3(nslab + extra), dim3(384), lds_bytes(extra), stream, ba, r);
                 MODL_LAUNCH_CHECK();
                 ++nl;
             } else {
@@ -1583,7 +1818,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             BcdRiderArgs r = rid;
             ride_per = ride_tiles - ride_next;                         // whatever is left
             const int extra = ride(r);
-            hipLaunchKernelGGL(blk, dim3(nslab + extra), dim3(320), lds_bytes(extra), stream, ba, r);
+            hipLaunchKernelGGL(blk, dim3(nslab + extra), dim3(384), lds_bytes(extra), stream, ba, r);
             MODL_LAUNCH_CHECK();
             nl += 1;
         } else {
