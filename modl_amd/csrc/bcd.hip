@@ -385,6 +385,27 @@ struct SinkLdsPacked {   // packed record -> full symmetric matrix
         M[j][i] = v;
     }
 };
+// packed record -> the rows the recursion's helper starts from: Base[m][lane] = e_m[lane] for lanes 0-31 (written
+// once per launch by the helper wave) and M[lane - 32][m] for lanes 32-63
+struct SinkBasePacked {
+    double *Base; double *D2;    // Base: [NB][64]
+    __device__ __forceinline__ void operator()(int e, double v) const {
+        int i, j;
+        if (e < kTri) {
+            SinkLdsPacked::untri(e, i, j);
+        } else if (e < kTri + 256) {
+            i = (e - kTri) >> 4; j = 16 + ((e - kTri) & 15);
+        } else if (e < 2 * kTri + 256) {
+            SinkLdsPacked::untri(e - kTri - 256, i, j);
+            i += 16; j += 16;
+        } else {
+            D2[e - 2 * kTri - 256] = v;
+            return;
+        }
+        Base[j * 64 + 32 + i] = v;
+        Base[i * 64 + 32 + j] = v;
+    }
+};
 struct SinkGlobal {
     double *dst;
     __device__ __forceinline__ void operator()(int e, double v) const { dst[e] = v; }
@@ -651,7 +672,7 @@ __device__ __forceinline__ void resolve_chain(const double *D2, const double *Cs
 }
 
 // CsT[i][m] = Cs[m][i]: the coefficients that multiply S[i], contiguous in m
-__device__ __forceinline__ void resolve_helper(const double (*M)[kNB + 1], const double *CsT, double *CAout,
+__device__ __forceinline__ void resolve_helper(const double *Base, const double *CsT, double *CAout,
                                                int ca_stride, const ResolveMail &mb) {
     const int lane = threadIdx.x & 63, x = lane & 31;
     const bool lower = lane < 32;
@@ -659,30 +680,28 @@ __device__ __forceinline__ void resolve_helper(const double (*M)[kNB + 1], const
     lds_vf64 *Zm = (lds_vf64 *)mb.Zm;
     lds_vi32 *pcount = (lds_vi32 *)mb.pcount;
     lds_vi32 *zcount = (lds_vi32 *)mb.zcount;
-    const double hmask = lower ? 0.0 : 1.0;
-    double P[kNB];
+    double P[kNB];                                           // e_m | M[:,m]: one conflict-free read per row
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-        P[m] = __builtin_fma(hmask, M[x][m], (lower && x == m) ? 1.0 : 0.0);   // e_m | M[:,m]
+        P[m] = Base[m * 64 + lane];
         Pm[m * 64 + lane] = P[m];
     }
     *pcount = 3;
 #pragma unroll
-    for (int m = 3; m < kNB; ++m) {
-        P[m] = __builtin_fma(hmask, M[x][m], (lower && x == m) ? 1.0 : 0.0);
-        asm volatile("" : "+v"(P[m]));                        // (computed HERE: the compiler otherwise sinks every update
-        if (m % 8 == 7) __builtin_amdgcn_sched_barrier(0);    //  of a row to the row's first use - the left-looking form -
-    }                                                         //  and keeps all coefficients and S rows live: spills)
+    for (int m = 3; m < kNB; ++m) P[m] = Base[m * 64 + lane];
     // the coefficients that multiply S[i] (CsT row i) are requested one iteration ahead: no LDS round trip between the
-    // arrival of S[i] and the updates
-    double cc[kNB], cn[kNB];
+    // arrival of S[i] and the updates; as 16-byte pairs from one base register (an 8-byte-aligned start makes the
+    // compiler emit ds_read2_b64 with an address register set up per request: two extra instructions each)
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const d2v *CsT2 = reinterpret_cast<const d2v *>(CsT);   // [NB][NB / 2]
+    d2v cc[kNB / 2], cn[kNB / 2];
 #pragma unroll
-    for (int m = 3; m < kNB; ++m) cc[m] = CsT[m];
+    for (int h = 1; h < kNB / 2; ++h) cc[h] = CsT2[h];
 #pragma unroll
     for (int i = 0; i < kNB; ++i) {
         if (i + 1 < kNB) {
 #pragma unroll
-            for (int m = i + 4; m < kNB; ++m) cn[m] = CsT[(i + 1) * kNB + m];
+            for (int h = (i + 4) / 2; h < kNB / 2; ++h) cn[h] = CsT2[(i + 1) * (kNB / 2) + h];
         }
         __builtin_amdgcn_sched_barrier(0);
         int ready = *zcount;
@@ -695,19 +714,19 @@ __device__ __forceinline__ void resolve_helper(const double (*M)[kNB + 1], const
         // use - the left-looking form - and keeps all coefficients and S rows live: spills)
         __builtin_amdgcn_sched_barrier(0);
         if (i + 3 < kNB) {                                   // the most urgent row first
-            P[i + 3] = __builtin_fma(-cc[i + 3], Zi, P[i + 3]);
+            P[i + 3] = __builtin_fma(-cc[(i + 3) / 2][(i + 3) % 2], Zi, P[i + 3]);
             Pm[((i + 3) % kMbox) * 64 + lane] = P[i + 3];
             *pcount = (i + 3 == kNB - 1) ? kNB + 1 : i + 4;  // (+ the row the chain wave's last step asks for)
         }
         if (lower) CAout[i * ca_stride + x] = Zi;            // S[i] for the apply step
 #pragma unroll
         for (int m = i + 4; m < kNB; ++m) {
-            P[m] = __builtin_fma(-cc[m], Zi, P[m]);
+            P[m] = __builtin_fma(-cc[m / 2][m % 2], Zi, P[m]);
             asm volatile("" : "+v"(P[m]));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = i + 4; m < kNB; ++m) cc[m] = cn[m];
+        for (int h = (i + 4) / 2; h < kNB / 2; ++h) cc[h] = cn[h];
     }
 }
 
@@ -848,8 +867,8 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int k = p.k;
     // LDS carve (all from the dynamic region, 16-byte aligned pieces)
-    double *Ms = reinterpret_cast<double *>(smem_raw);                        // [NB][NB + 1]
-    double *D2s = Ms + kNB * (kNB + 1);                                        // [NB]
+    double *Ms = reinterpret_cast<double *>(smem_raw);                        // [NB][64] Base rows (SinkBasePacked)
+    double *D2s = Ms + kNB * 64;                                               // [NB]
     double *Cs = D2s + kNB;                                                    // [NB][NB] recursion coefficients
     double *CAs = Cs + kNB * kNB;                                              // [NB][kCaStride] S of the previous block
     double *d2red = CAs + kNB * kCaStride;                                     // [8][NB]
@@ -884,7 +903,7 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
     if (has_prev) {
         const double *recs = (ngroups > 1) ? p.grec_in : p.rec_in;
         const int nrec = (ngroups > 1) ? ngroups : nwg;
-        const SinkLdsPacked rsink{reinterpret_cast<double (*)[kNB + 1]>(Ms), D2s};
+        const SinkBasePacked rsink{Ms, D2s};
         if (worker) {
             if (st && tid == 0) st[16] = clock64();
             // the recursion coefficients of the block, Cs[j][i] = coef_all[j0_prev + j][i] (a contiguous block of 1024
@@ -917,6 +936,12 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
             const float budget_raw = p.norm_in[(x < p.nb_prev) ? p.j0_prev + x : 0];
             reduce_records_v2<kPackStride>(recs, nrec, 256 + lane, 256 + lane < kPackStride / 2, rsink);
             res_budget = (x < p.nb_prev) ? (double)budget_raw : 0.0;
+        } else {
+#pragma unroll
+            for (int q = 0; q < kNB * 32 / 64; ++q) {        // the identity half of the Base rows
+                const int e = lane + 64 * q, m = e >> 5, xx = e & 31;
+                Ms[m * 64 + xx] = (m == xx) ? 1.0 : 0.0;
+            }
         }
     }
     __syncthreads();                                                                  // ---- barrier 1
@@ -944,7 +969,7 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
                                      d2red, mail, st);
             if (st && lane == 0) st[2] = clock64();
         } else if (has_prev) {
-            resolve_helper(reinterpret_cast<const double (*)[kNB + 1]>(Ms), CsT, CAs, kCaStride, mail);
+            resolve_helper(Ms, CsT, CAs, kCaStride, mail);
             if (st && lane == 0) st[14] = clock64();
         }
         lds_barrier();                                                                // ---- barrier 2
@@ -1215,7 +1240,7 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
 
 static size_t bcd_block_lds(int gpw, int RT) {
     const int kpad = gpw * 32, RB = 32 * RT;
-    const size_t dbl = (size_t)kNB * (kNB + 1) + kNB + kNB * kNB + (size_t)kNB * kCaStride + 8 * kNB;
+    const size_t dbl = (size_t)kNB * 64 + kNB + kNB * kNB + (size_t)kNB * kCaStride + 8 * kNB;
     const size_t fl = 4 * (size_t)RB * (kNB + 1) + RB * (kNB + 1) + 4 + RB * (kNB + 4) + 4;
     const size_t mail = (size_t)kNB * kNB + 2 * kMbox * 64;     // Cs transposed + the two mailboxes of the recursion
     (void)kpad;
