@@ -63,7 +63,7 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     L.nslab_max = cdiv(s_max > 0 ? s_max : 1, 32);      // the fused block kernel uses slabs of 32 or 64 rows
     L.nwg_grad = 4096;
-    L.off_CP = take(tsz * (size_t)k * k);
+    L.off_CP = take(tsz * (size_t)(cdiv(k, 32) * 32) * k);            // (fused path: fragment order, whole tiles of 32 columns)
     L.off_cdiag = take(tsz * (size_t)k);
     L.off_frozen = take(sizeof(int32_t) * (size_t)k);
     L.off_coef = take(sizeof(double) * (size_t)kNB * k);
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_
         for (int jj = threadIdx.x; jj < k; jj += 256) {
             T v = C[(int64_t)om * k + order[jj]];
             if (mp / kNB == jj / kNB && mp <= jj) v = 0;
-            CPP[(int64_t)mp * k + jj] = v;
+            CPP[dfrag(jj, mp, k)] = v;                   // fragment order: (target position, 4 consecutive source atoms)
         }
         return;
     }
@@ -593,7 +593,7 @@ __device__ __forceinline__ void resolve_chain(const double *D2, const double *Cs
         scr[2 * x] = live_x ? sqrt(rad_x) : 0.0;                                 // sqrt(radius_j) ...
         scr[2 * x + 1] = live_x ? 1.0 : 0.0;                                     // ... and the cap of alpha_j
     }
-    if (stamps && lane == 0) { stamps[8] = clock64() + (unsigned long long)(rad_x * 0); stamps[21] = 0; stamps[22] = 0; }
+    if (stamps && lane == 0) { stamps[8] = clock64() + (unsigned long long)(rad_x * 0); }
     double al_prev = 0.0, q_prev = 0.0, z_prev = 0.0, Z1 = 0.0, Z2 = 0.0;        // Z1 = S[j-1], Z2 = S[j-2] (| Y)
     int rn = *pcount;
     double Pn = Pm[lane];
@@ -953,7 +953,7 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
     const int h = lane >> 5;
     constexpr int NA = RB * (kNB / 4) / 256;
     float dold[RT][4];
-    int64_t orow[RT][4];            // destination of the applied values in the real dictionary
+    int ocr[RT], subr[RT][4];       // destination of the applied values in the real dictionary: column, sampled row
     float bq[4] = {0.f, 0.f, 0.f, 0.f};
     f16v acc[RT];
     if (!worker) {
@@ -961,7 +961,7 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
         // workers' state is live across their code (a common tail made the register allocator carry the workers'
         // accumulators and epilogue operands through the recursion - and spill the helper's running sums).  A
         // hardware barrier counts wavefronts, not program counters.
-        __builtin_amdgcn_s_setprio(3);               // the recursion is the critical path: issue before the workers' loads
+        __builtin_amdgcn_s_setprio(3);               // the recursion is the critical path: issue before the workers. loads
         if (wid == 4) {
             if (has_prev)
                 resolve_chain<float>(D2s, Cs, res_jj, res_budget, p.nb_prev, blockIdx.x == 0 ? p.norm_out : nullptr,
@@ -1000,22 +1000,20 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
         float4 av[GW][RT];
         float4 va[NA];
         if (!fin) {
-            const float cdg_raw = p.cdiag[p.j0 + (col_ok ? col : 0)];   // (unconditional, clamped loads)
-            const int fz_raw = p.frozen[p.j0 + (col_ok ? col : 0)];
-            cdg = col_ok ? cdg_raw : 1.f;
-            fz = col_ok ? fz_raw : 0;
+            // (unconditional, clamped requests; every mask is applied behind the scheduler fence below: a select next to
+            //  its load makes the compiler wait for the round trip on the spot, and three such waits sat in here)
+            cdg = p.cdiag[p.j0 + (col_ok ? col : 0)];
+            fz = p.frozen[p.j0 + (col_ok ? col : 0)];
 #pragma unroll
             for (int q = 0; q < EPT; ++q) {
                 const int64_t f = f0 + rg + 8 * q;
                 const bool ok = col_ok && f < p.s;
                 const int64_t el = ok ? f * k + p.j0 + col : 0;
-                const float bv = p.Bt[el], dv = p.Dt[ok ? dfrag(f, p.j0 + col, k) : 0];
-                eB[q] = ok ? bv : 0.f;
-                eD[q] = ok ? dv : 0.f;
+                eB[q] = p.Bt[el];
+                eD[q] = p.Dt[ok ? dfrag(f, p.j0 + col, k) : 0];
             }
             const bool cok = (lane & 31) < p.nb;
-            const float *cpc = p.CP + p.j0 + (cok ? (lane & 31) : 0);
-            const float *cp0 = p.CP + p.j0;
+            const float *cp0 = p.CP + dfrag(p.j0, 0, k);            // the block's 32 columns (j0 is a multiple of 32)
             const unsigned lane_off = cok ? (unsigned)(lane & 31) : 0u;
             // (wave-uniform branch: a wave outside the product requests none of its operands - wave 0 shares its SIMD
             // with the resolver, and the ~100 address computations + requests below took the recursion's issue slots
@@ -1027,19 +1025,17 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
                 // 32-bit element offsets from one uniform base (k <= 512): two instructions of address arithmetic per
                 // request instead of eight with a 64-bit multiply (92 cycles per request, measured).  k % 4 == 0, so
                 // kb < k covers kb + u < k; any valid address serves the masked-out lanes.
-                const unsigned rb = (kb < k ? (unsigned)kb * (unsigned)k : 0u) + lane_off;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) bfr[g][u] = cp0[rb + (unsigned)u * (unsigned)k];   // (masked below, behind
-            }                                                        // the scheduler fence: a select next to its load has
-                                                                     // been compiled into load - wait - select, 44 round trips)
+                // (the coefficient matrix is stored in fragment order too, bcd_setup_kernel: this lane's four atoms are
+                //  one 16-byte word, a wavefront's request one contiguous kilobyte; k % 4 == 0, so kb < k covers
+                //  kb + u < k.  Masked below, behind the scheduler fence: a select next to its load has been compiled
+                //  into load - wait - select, one round trip per request)
+                const float4 b4 = *reinterpret_cast<const float4 *>(cp0 + dfrag(lane_off, kb < k ? kb : 0, k));
+                bfr[g][0] = b4.x; bfr[g][1] = b4.y; bfr[g][2] = b4.z; bfr[g][3] = b4.w;
+            }
             if (has_prev) {   // rank-32 correction: wave w contracts the previous block's atoms 8w .. 8w+7
                 const int jb = wid * 8 + 4 * h;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool ok = cok && jb + u < p.nb_prev;
-                    const float v = cpc[(int64_t)(ok ? p.j0_prev + jb + u : 0) * k];
-                    bq[u] = ok ? v : 0.f;
-                }
+                const float4 q4 = *reinterpret_cast<const float4 *>(cp0 + dfrag(lane_off, jb < p.nb_prev ? p.j0_prev + jb : 0, k));
+                bq[0] = q4.x; bq[1] = q4.y; bq[2] = q4.z; bq[3] = q4.w;
             }
             // dictionary rows -> MFMA A operands, the wave's whole contraction range in flight at once
             if (pwave)
@@ -1063,15 +1059,17 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
             for (int u = 0; u < RT; ++u) {
                 const int t = wid * RT + u, ft = t >> 1, jt = t & 1;
                 const int cj = jt * 16 + (lane & 15);
-                const int oc_raw = p.order[p.j0_prev + ((cj < p.nb_prev) ? cj : 0)];
-                const int oc = (cj < p.nb_prev) ? oc_raw : 0;
+                const int32_t *sub_src = p.subset ? p.subset : p.order;   // (any readable words when there is no subset)
+                ocr[u] = p.order[p.j0_prev + ((cj < p.nb_prev) ? cj : 0)];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t f = f0 + ft * 16 + (lane >> 4) + 4 * r;
                     const bool live = f < p.s && cj < p.nb_prev;
-                    const float dv = p.Dt[live ? dfrag(f, p.j0_prev + cj, k) : 0];
-                    dold[u][r] = live ? dv : 0.f;
-                    orow[u][r] = (live ? sub_row(p.subset, f) : 0) * k + oc;
+                    dold[u][r] = p.Dt[live ? dfrag(f, p.j0_prev + cj, k) : 0];
+                    // (unconditional request - a branch on the null subset made the compiler wait behind each of these,
+                    //  four round trips before the remaining operands were even requested; the destination offsets are
+                    //  formed in (D))
+                    subr[u][r] = sub_src[(p.subset && live) ? f : 0];
                 }
             }
 #pragma unroll
@@ -1083,13 +1081,52 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (!fin) {                                  // the masks of the requests above
+            cdg = col_ok ? cdg : 1.f;
+            fz = col_ok ? fz : 0;
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+                const bool ok = col_ok && f0 + rg + 8 * q < p.s;
+                eB[q] = ok ? eB[q] : 0.f;
+                eD[q] = ok ? eD[q] : 0.f;
+            }
+            if (has_prev) {
+                const bool cok = (lane & 31) < p.nb;
+                const int jb = wid * 8 + 4 * h;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bq[u] = (cok && jb + u < p.nb_prev) ? bq[u] : 0.f;
+            }
+        }
+        if (has_prev) {
+#pragma unroll
+            for (int u = 0; u < RT; ++u) {
+                const int t = wid * RT + u, ft = t >> 1, jt = t & 1;
+                const int cj = jt * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t f = f0 + ft * 16 + (lane >> 4) + 4 * r;
+                    dold[u][r] = (f < p.s && cj < p.nb_prev) ? dold[u][r] : 0.f;
+                }
+            }
+        }
         if (st && tid == 0) st[13] = clock64();
         if (st && tid == 64) st[20] = clock64();
+        if (st && tid == 128) st[21] = clock64();            // product wave 2: operands requested
         if (!fin) {
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            // one 32-feature tile per wave (RT == 1): the four products of a contraction group go to four accumulators -
+            // a v_mfma_f32_32x32x2_f32 issues every 16-21 cycles but its result takes 64 (scripts/micro/mfma_rate.hip).
+            // (What this section really waits for is its operands: a compute unit draws ~27 bytes per cycle from the
+            // fabric, and the workgroup asks for 134 KB of records, then 64 KB of operands, every launch.)
+            constexpr bool kFourAcc = (RT == 1);
+            f16v accx[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accx[q][r] = 0.f;
             if (pwave)
 #pragma unroll
             for (int g = 0; g < GW; ++g) {
@@ -1100,13 +1137,25 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
 #pragma unroll
                 for (int t = 0; t < RT; ++t) {
                     if (!(kb + 3 < k)) av[g][t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].x, bfr[g][0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].y, bfr[g][1], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].z, bfr[g][2], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].w, bfr[g][3], acc[t], 0, 0, 0);
+                    if (kFourAcc) {
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].x, bfr[g][0], acc[t], 0, 0, 0);
+                        accx[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].y, bfr[g][1], accx[0], 0, 0, 0);
+                        accx[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].z, bfr[g][2], accx[1], 0, 0, 0);
+                        accx[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].w, bfr[g][3], accx[2], 0, 0, 0);
+                    } else {
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].x, bfr[g][0], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].y, bfr[g][1], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].z, bfr[g][2], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].w, bfr[g][3], acc[t], 0, 0, 0);
+                    }
                 }
             }
+            if (kFourAcc && pwave) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] = (acc[0][r] + accx[0][r]) + (accx[1][r] + accx[2][r]);
+            }
         }
+        if (st && tid == 128) st[22] = clock64();            // product wave 2: product issued
         if (has_prev) {                              // a-tile of the previous block -> LDS for (D)
 #pragma unroll
             for (int q = 0; q < NA; ++q) {
@@ -1149,7 +1198,7 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
                 const float dnew = (float)dn[r];
                 if (live) {
                     p.Dt[dfrag(f, p.j0_prev + cj, k)] = dnew;
-                    p.Dt_out[orow[u][r]] = dnew;             // final: no unpack pass
+                    p.Dt_out[(p.subset ? (int64_t)subr[u][r] : f) * k + ocr[u]] = dnew;   // final: no unpack pass
                 }
                 Dl[frow * DLS + cj] = live ? dnew - dold[u][r] : 0.f;
             }

@@ -27,6 +27,6 @@ for r in (10, 1):
         print('   %-56s %8d' % (n, v))
     print('   helper wave done %d, product wave 1 loads requested %d, done %d, wave 2 done %d, wave 3 done %d (after barrier 1)' % (o[14] - o[1], o[20] - o[1], o[15] - o[1], o[18] - o[1], o[19] - o[1]))
     print('   first steps (cycles after barrier 1):', [int(o[24 + u] - o[1]) for u in range(8)])
-    print('   chain wave: %d polls failed, steps that waited: %s' % (out[21], bin(out[22])))
+    print('   product wave 2: operands requested %d, product issued %d (after barrier 1)' % (o[21] - o[1], o[22] - o[1]))
     print('   B detail: entry -> record loads start %d, records summed + in LDS %d, barrier 1 %d' % (o[16] - o[0], o[17] - o[16], o[1] - o[17]))
     print('   resolve: setup %d  steps 0-7 %d  8-15 %d  16-23 %d  24-31+stores %d' % (o[8] - o[1], o[9] - o[8], o[10] - o[9], o[11] - o[10], o[2] - o[11]))
