@@ -119,12 +119,14 @@ __device__ __forceinline__ void cd_coord(int L, T (&w)[KPL], T (&H)[KPL], const 
 // address is ONE 64-bit add per coordinate on a per-lane pointer (instead of min / mul / add on the scalar
 // unit plus the lane offset: the wave spends 2/3 of its cycles issuing instructions, every one counts).
 template <typename T, int KPL, bool VEC, bool POSITIVE, bool PAD>
-__device__ __forceinline__ void cd_dense_sweep(int lane, int k, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
+__device__ __forceinline__ void cd_dense_sweep(int lane, int kq, int k, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
                                                const T (&inv)[KPL], const T *__restrict__ Q, T alpha) {
+    // kq: row stride of Q; k: coordinates to visit (VEC: a multiple of U, the rows up to it exist - zero rows of a
+    // padded Gram are dead coordinates, inv = 0)
     constexpr int U = KPL > kCdRing ? KPL : kCdRing;
     T ring[kCdRing][KPL];
 #pragma unroll
-    for (int j = 0; j < kCdRing; ++j) load_row<T, KPL, VEC>(Q, j < k ? j : k - 1, k, lane, ring[j]);
+    for (int j = 0; j < kCdRing; ++j) load_row<T, KPL, VEC>(Q, j < k ? j : k - 1, kq, lane, ring[j]);
     const int groups = k / U;
     if constexpr (PAD && VEC) {
         constexpr int V = (KPL * sizeof(T) >= 16) ? (int)(16 / sizeof(T)) : KPL;
@@ -159,7 +161,7 @@ __device__ __forceinline__ void cd_dense_sweep(int lane, int k, T (&w)[KPL], T (
             cd_coord<T, KPL, j % KPL, POSITIVE>(g * (U / KPL) + j / KPL, w, H, q, inv, ring[j % kCdRing], alpha);
             __builtin_amdgcn_sched_barrier(0);
             const int nx = (ii + kCdRing < k) ? ii + kCdRing : k - 1;
-            load_row<T, KPL, VEC>(Q, nx, k, lane, ring[j % kCdRing]);
+            load_row<T, KPL, VEC>(Q, nx, kq, lane, ring[j % kCdRing]);
             __builtin_amdgcn_sched_barrier(0);
         });
     }
@@ -169,7 +171,7 @@ __device__ __forceinline__ void cd_dense_sweep(int lane, int k, T (&w)[KPL], T (
             constexpr int j = decltype(J)::value;
             if (j < tail) {
                 cd_coord<T, KPL, j % KPL, POSITIVE>((done + j) / KPL, w, H, q, inv, ring[j % kCdRing], alpha);
-                if (j + kCdRing < tail) load_row<T, KPL, VEC>(Q, done + j + kCdRing, k, lane, ring[j % kCdRing]);
+                if (j + kCdRing < tail) load_row<T, KPL, VEC>(Q, done + j + kCdRing, kq, lane, ring[j % kCdRing]);
             }
         });
     }
@@ -271,7 +273,7 @@ constexpr int kCdSparseRingMax = MODL_CD_SPARSE_RING > 4 ? MODL_CD_SPARSE_RING :
 // (w == 0 there and the update stays 0: H and w unchanged).  So the coordinates that change anything are visited in
 // increasing order with the H of the moment, exactly as in the reference's sweep.
 template <typename T, int KPL, bool VEC, bool POSITIVE>
-__device__ __forceinline__ int cd_sparse_sweep(int lane, int k, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
+__device__ __forceinline__ int cd_sparse_sweep(int lane, int kq, int k, T (&w)[KPL], T (&H)[KPL], const T (&q)[KPL],
                                                const T (&inv)[KPL], unsigned long long (&m)[KPL],
                                                const T *__restrict__ Q, T alpha, unsigned short *list) {
     constexpr int R = cd_sparse_ring<KPL>(), NONE = 64 * KPL;
@@ -299,7 +301,7 @@ __device__ __forceinline__ int cd_sparse_sweep(int lane, int k, T (&w)[KPL], T (
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             cq[j] = __builtin_amdgcn_readfirstlane((int)list[j]);
-            load_row<T, KPL, VEC>(Q, cq[j] < k ? cq[j] : k - 1, k, lane, ring[j]);   // unconditional: no branch around a load
+            load_row<T, KPL, VEC>(Q, cq[j] < k ? cq[j] : k - 1, kq, lane, ring[j]);   // unconditional: no branch around a load
         }
         const unsigned short *lp = list + R;
         unsigned int pending = *lp;                           // list entry of the next refill, read one step ahead
@@ -333,7 +335,7 @@ __device__ __forceinline__ int cd_sparse_sweep(int lane, int k, T (&w)[KPL], T (
                 cq[s] = __builtin_amdgcn_readfirstlane((int)pending);
                 ++lp;
                 pending = *lp;
-                load_row<T, KPL, VEC>(Q, cq[s] < k ? cq[s] : k - 1, k, lane, ring[s]);
+                load_row<T, KPL, VEC>(Q, cq[s] < k ? cq[s] : k - 1, kq, lane, ring[s]);
             });
         }
         if (!stop) return rebuilds;
@@ -347,6 +349,9 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
     const int smp = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (smp >= a.b) return;                        // whole wave exits together
     const int k = a.k;
+    const int kq = a.ldg ? a.ldg : k;              // row stride of the Gram matrix
+    constexpr int UU = KPL > kCdRing ? KPL : kCdRing;
+    const int kc = VEC ? (k + UU - 1) / UU * UU : k;   // coordinates a dense pass visits (VEC: the padding is dead)
     const T *__restrict__ Q = a.G + (a.g_idx ? a.g_idx[smp] : (int64_t)smp) * a.g_stride;
     const int64_t row_out = a.idx ? a.idx[smp] : (int64_t)smp;
     T *wptr = a.code + row_out * k;
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
     for (int c = 0; c < KPL; ++c) {
         const bool in = e0 + c < k;
         const int e = in ? e0 + c : 0;
-        const T wv = wptr[e], qv = qptr[e], dv = Q[(int64_t)e * k + e];
+        const T wv = wptr[e], qv = qptr[e], dv = Q[(int64_t)e * kq + e];
         w[c] = in ? wv : (T)0;
         q[c] = in ? qv : (T)0;
         const T dg = in ? dv : (T)0;
@@ -384,12 +389,12 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
         constexpr int U = KPL > kCdRing ? KPL : kCdRing;
         T ring[kCdRing][KPL];
 #pragma unroll
-        for (int j = 0; j < kCdRing; ++j) load_row<T, KPL, VEC>(Q, j < k ? j : k - 1, k, lane, ring[j]);
+        for (int j = 0; j < kCdRing; ++j) load_row<T, KPL, VEC>(Q, j < k ? j : k - 1, kq, lane, ring[j]);
         if constexpr (PAD && VEC) {
             constexpr int V = (KPL * sizeof(T) >= 16) ? (int)(16 / sizeof(T)) : KPL;
             typedef T vec_t __attribute__((ext_vector_type(V)));
-            const T *next = Q + (int64_t)kCdRing * k + lane * KPL;
-            for (int j0 = 0; j0 < k; j0 += U) {
+            const T *next = Q + (int64_t)kCdRing * kq + lane * KPL;
+            for (int j0 = 0; j0 < kc; j0 += U) {
                 static_for<U>([&](auto J) {
                     constexpr int j = decltype(J)::value;
                     const T wj = bcast_lane(w[j % KPL], (j0 / KPL + j / KPL) & 63);
@@ -403,12 +408,12 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
 #pragma unroll
                         for (int c = 0; c < V; ++c) ring[j % kCdRing][v * V + c] = x[c];
                     }
-                    next += k;
+                    next += kq;
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
         } else {
-            for (int j0 = 0; j0 < k; j0 += U) {
+            for (int j0 = 0; j0 < kc; j0 += U) {
                 static_for<U>([&](auto J) {
                     constexpr int j = decltype(J)::value;
                     const int jj = j0 + j;
@@ -417,8 +422,8 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
 #pragma unroll
                     for (int c2 = 0; c2 < KPL; ++c2) H[c2] = fma(wj, ring[j % kCdRing][c2], H[c2]);
                     __builtin_amdgcn_sched_barrier(0);
-                    const int nx = (jj + kCdRing < k) ? jj + kCdRing : k - 1;
-                    load_row<T, KPL, VEC>(Q, nx, k, lane, ring[j % kCdRing]);
+                    const int nx = (jj + kCdRing < kc) ? jj + kCdRing : kc - 1;
+                    load_row<T, KPL, VEC>(Q, nx, kq, lane, ring[j % kCdRing]);
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
@@ -449,10 +454,10 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
         // cursor) about eight sparse steps: while the active set keeps churning (e.g. a rank-deficient Gram matrix
         // that never lets the sweeps settle) the sweeps stay dense
         if (100 * (n_act + 8 * churn) > a.sparse_pct * k) {
-            cd_dense_sweep<T, KPL, VEC, POSITIVE, PAD>(lane, k, w, H, q, inv, Q, alpha);
+            cd_dense_sweep<T, KPL, VEC, POSITIVE, PAD>(lane, kq, kc, w, H, q, inv, Q, alpha);
             churn >>= 1;
         } else {
-            churn = cd_sparse_sweep<T, KPL, VEC, POSITIVE>(lane, k, w, H, q, inv, m, Q, alpha, s_list[threadIdx.x >> 6]);
+            churn = cd_sparse_sweep<T, KPL, VEC, POSITIVE>(lane, kq, k, w, H, q, inv, m, Q, alpha, s_list[threadIdx.x >> 6]);
         }
         T dmx = 0, wmx = 0;                        // skipped coordinates do not count (:357): their w is 0 here
 #pragma unroll
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(256) void cd_kernel(CdArgs<T> a) {
 template <typename T, int KPL>
 static void launch_cd_kpl(hipStream_t stream, const CdArgs<T> &a, dim3 grid, dim3 block) {
     constexpr size_t kRowAlign = (KPL * sizeof(T) >= 16) ? 16 : KPL * sizeof(T);
-    const bool vec = (a.k == 64 * KPL) && (reinterpret_cast<uintptr_t>(a.G) % kRowAlign == 0) &&
+    const bool vec = ((a.ldg ? a.ldg : a.k) == 64 * KPL) && (reinterpret_cast<uintptr_t>(a.G) % kRowAlign == 0) &&
                      ((a.g_stride * sizeof(T)) % kRowAlign == 0);
     const bool pad = vec && a.g_pad_rows >= kCdRing && a.g_stride == 0;
 #define MODL_CD_LAUNCH(VEC, POS, PAD) hipLaunchKernelGGL((cd_kernel<T, KPL, VEC, POS, PAD>), grid, block, 0, stream, a)
@@ -550,6 +555,25 @@ int launch_cd(hipStream_t stream, const CdArgs<T> &a0) {
 
 template int launch_cd<float>(hipStream_t, const CdArgs<float> &);
 template int launch_cd<double>(hipStream_t, const CdArgs<double> &);
+
+// Any number of coefficients on the vectorised kernel: the element-wise row loader of the general kernel costs 4.6x at
+// k = 200 and 40x at k = 320 (385 us / 3.6 ms per minibatch of 256 against 84 us at k = 256, measured), so a shared Gram
+// whose size is not 64 / 128 / 256 / 512 / 1024 is copied into a zero-padded matrix of that stride; the padding is dead
+// coordinates (zero diagonal), which the sweeps skip bit for bit.
+int cd_padded_ld(int k) { return k <= 64 ? 64 : (k <= 128 ? 128 : (k <= 256 ? 256 : (k <= 512 ? 512 : 1024))); }
+template <typename T>
+__global__ __launch_bounds__(256) void cd_pad_gram_kernel(const T *G, int k, T *Gp, int ldg) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < k; c += 256) Gp[(int64_t)r * ldg + c] = G[(int64_t)r * k + c];
+}
+template <typename T>
+int launch_cd_pad_gram(hipStream_t stream, const T *G, int k, T *Gp, int ldg) {
+    hipLaunchKernelGGL((cd_pad_gram_kernel<T>), dim3(k), dim3(256), 0, stream, G, k, Gp, ldg);
+    MODL_LAUNCH_CHECK();
+    return MODL_OK;
+}
+template int launch_cd_pad_gram<float>(hipStream_t, const float *, int, float *, int);
+template int launch_cd_pad_gram<double>(hipStream_t, const double *, int, double *, int);
 
 // squared row norms: out[i] = sum_f X[i][f]^2   (dict_fact_fast.pyx:334 uses dot(y, y))
 template <typename T>

@@ -17,6 +17,9 @@ struct CdArgs {
     const int64_t *idx;    // [b] or null (identity)
     T *code2 = nullptr;    // optional second destination: code2[idx2[i]] = solution i
     int g_pad_rows = 0;    // rows readable behind G (shared Gram only): >= 16 lets the row prefetch run unclamped
+    int ldg = 0;           // row stride of G (0: k).  A shared Gram padded with zeros to ldg = 64 * ceil(k / 64 rounded to
+                           // a power of two) columns and ldg + 16 rows runs the vectorised kernel whatever k is
+                           // (launch_cd_pad_gram / cd_padded_ld)
     const int64_t *idx2 = nullptr;
     int32_t *sweeps;       // [b] or null
     int b, k;
@@ -26,6 +29,9 @@ struct CdArgs {
                            // (measured at k = 256: a sparse step costs 0.23 us, a dense sweep 14.3 us (f32) / 18.9 us (f64))
 };
 template <typename T> int launch_cd(hipStream_t stream, const CdArgs<T> &a);
+int cd_padded_ld(int k);   // the row stride the vectorised solver wants for k coefficients (k itself when it fits already)
+// Gp[ldg + 16][ldg] (zero-filled once by the caller) <- G[k][k]
+template <typename T> int launch_cd_pad_gram(hipStream_t stream, const T *G, int k, T *Gp, int ldg);
 template <typename T> int launch_row_norm2(hipStream_t stream, const T *X, int64_t ldx, int64_t p, int64_t b, T *out);
 
 // ---- chol.hip ---------------------------------------------------------------

@@ -195,6 +195,7 @@ struct modl_somf_plan {
     // device arena
     char *dws = nullptr;
     size_t dws_bytes = 0;
+    size_t off_Gpad = 0; int ld_gpad = 0;   // zero-padded copy of a shared Gram whose size the vectorised solver does not take as is
     size_t off_params, off_xnorm, off_Dx, off_H0, off_G, off_F, off_Linv, off_split, off_du, off_sweeps, off_Ds, off_Xs, off_codeb, off_level;
     int last_b = 0;
     int64_t last_s = 0;
@@ -451,6 +452,12 @@ int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride
     a.idx = d_idx;
     a.code2 = scatter_dst; a.idx2 = scatter_idx;
     a.g_pad_rows = (G == reinterpret_cast<const T *>(pl->dws + pl->off_G)) ? 16 : 0;
+    if (!g_stride && pl->ld_gpad) {              // any k on the vectorised kernel (cd_solver.hip: cd_padded_ld)
+        T *Gp = reinterpret_cast<T *>(pl->dws + pl->off_Gpad);
+        MODL_TRY(launch_cd_pad_gram<T>(st, G, k, Gp, pl->ld_gpad));
+        ++*nl;
+        a.G = Gp; a.ldg = pl->ld_gpad; a.g_pad_rows = 16;
+    }
     a.sweeps = d_sweeps; a.b = b; a.k = k;
     a.alpha = (T)((T)d.code_alpha * (T)d.code_l1_ratio);
     a.beta = (T)((double)(T)d.code_alpha * (1.0 - (double)(T)d.code_l1_ratio));
@@ -857,6 +864,14 @@ int enet_regression_abi(const T *G, int64_t g_stride, T *Dx, const T *X, int64_t
     a.G = G; a.g_stride = g_stride; a.g_idx = nullptr; a.Dx = Dx; a.xnorm2 = xnorm; a.H0 = H0p; a.code = code;
     a.idx = d_indices;
     a.sweeps = d_sweeps; a.b = (int)b; a.k = (int)k;
+    if (!g_stride && k <= 1024 && cd_padded_ld((int)k) != (int)k) {     // any k on the vectorised kernel: padded copy at the
+        const int kq = cd_padded_ld((int)k);                            // end of the caller's workspace
+        const size_t gp_bytes = align_up(sizeof(T) * ((size_t)kq + 16) * kq, 256);
+        T *Gp = reinterpret_cast<T *>(w + need - gp_bytes);
+        MODL_HIP(hipMemsetAsync(Gp, 0, gp_bytes, st));
+        MODL_TRY(launch_cd_pad_gram<T>(st, G, (int)k, Gp, kq));
+        a.G = Gp; a.ldg = kq; a.g_pad_rows = 16;
+    }
     a.alpha = alpha * l1_ratio;
     a.beta = (T)((double)alpha * (1.0 - (double)l1_ratio));
     a.tol = tol; a.max_iter = max_iter; a.positive = positive;
@@ -876,8 +891,10 @@ int modl_device_count(void) {
 size_t modl_enet_regression_workspace(int dtype, int64_t b, int64_t k, int multi_gram) {
     const size_t t = dtype == MODL_F32 ? 4 : 8;
     if (b < 0 || k < 0) return 0;
+    const size_t kq = (!multi_gram && k > 0 && k <= 1024) ? (size_t)modl::cd_padded_ld((int)k) : 0;   // padded shared Gram (cd_padded_ld)
     return align_up(t * (size_t)b, 256) + align_up(t * (size_t)b * k, 256) +
-           align_up(t * ((size_t)k * k * ((multi_gram && k <= 512) ? (size_t)b : 1) + modl::chol_wide_scratch_elems((int)k)), 256);
+           align_up(t * ((size_t)k * k * ((multi_gram && k <= 512) ? (size_t)b : 1) + modl::chol_wide_scratch_elems((int)k)), 256) +
+           ((kq && kq != (size_t)k) ? align_up(t * (kq + 16) * kq, 256) : 0);
 }
 
 #define ABI_REG(SFX, T)                                                                                            \
@@ -925,6 +942,10 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     pl->off_Dx = take(t * b * k);
     pl->off_H0 = take(t * b * k);
     pl->off_G = take(t * (k + 16) * k);        // 16 readable rows behind the Gram: the solver's row prefetch runs unclamped
+    if (desc->code_l1_ratio != 0.0 && cd_padded_ld(desc->k) != desc->k) {
+        pl->ld_gpad = cd_padded_ld(desc->k);
+        pl->off_Gpad = take(t * ((size_t)pl->ld_gpad + 16) * pl->ld_gpad);
+    }
     const size_t p_pad = align_up(p, 4);
     pl->off_Ds = take(t * p_pad * k);          // compacted sampled dictionary rows
     pl->off_Xs = take(t * b * p_pad);          // compacted sampled minibatch columns
@@ -948,6 +969,7 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     if (e != hipSuccess) { delete pl; return (int)e; }
     e = hipMemset(pl->dws + pl->off_stamp, 0, sizeof(int32_t) * p);
     if (e == hipSuccess) e = hipMemset(pl->dws + pl->off_level, 0, sizeof(double) * k);
+    if (e == hipSuccess && pl->ld_gpad) e = hipMemset(pl->dws + pl->off_Gpad, 0, t * ((size_t)pl->ld_gpad + 16) * pl->ld_gpad);
     if (e != hipSuccess) { modl_somf_plan_destroy(pl); return (int)e; }
     for (int i = 0; i < kStageSlots; ++i) {
         e = hipHostMalloc((void **)&pl->hstage[i], align_up(pl->params_bytes, 16) + 64, hipHostMallocMapped);   // + acknowledgement word

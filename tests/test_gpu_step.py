@@ -307,6 +307,23 @@ def test_wide_dictionaries_f32_vs_oracle(DictFact, oracle, k, p, b, red):
     assert rel_fro(est.C_, st.C) < 1e-5 and rel_fro(est.B_, st.B) < 1e-5
 
 
+@pytest.mark.parametrize('k', [200, 320, 70])
+def test_any_number_of_atoms_runs_the_vectorised_solver_f64(DictFact, oracle, k):
+    """A shared Gram whose size is not 64 / 128 / 256 / 512 / 1024 is solved from a zero-padded copy (cd_padded_ld):
+    the padding is dead coordinates, so in f64 two minibatches agree with the oracle to 1e-10 and every sample takes
+    the oracle's number of sweeps."""
+    est, pr, st, X = _make_pair(DictFact, oracle, np.float64, n=max(256, k), p=1500, k=k, b=96, r=3, seed=0)
+    st.sweeps = []
+    for step in range(2):
+        rows = slice(96 * step, 96 * (step + 1))
+        est.partial_fit(X[rows], np.arange(rows.start, rows.stop))
+        oracle.partial_fit(st, pr, X[rows], np.arange(rows.start, rows.stop))
+        assert_array_equal(est._backend.last_sweeps(), np.asarray(st.sweeps[-1]))
+    errs = (rel_fro(est.components_, st.D), rel_fro(est.code_[:192], st.code[:192]), rel_fro(est.B_, st.B),
+            rel_fro(est.C_, st.C))
+    assert max(errs) < 1e-10, (k, errs)
+
+
 @pytest.mark.parametrize('agg', [('masked', 'masked'), ('full', 'full'), ('average', 'average')])
 def test_two_phase_equals_fused_step(DictFact, agg):
     """modl_somf_code_and_partials + modl_somf_apply_and_update_dict (the multi-GPU split: the dictionary update
