@@ -63,20 +63,21 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     L.nslab_max = cdiv(s_max > 0 ? s_max : 1, 32);      // the fused block kernel uses slabs of 32 or 64 rows
     L.nwg_grad = 4096;
-    L.off_CP = take(tsz * (size_t)(cdiv(k, 32) * 32) * k);            // (fused path: fragment order, whole tiles of 32 columns)
-    L.off_cdiag = take(tsz * (size_t)k);
-    L.off_frozen = take(sizeof(int32_t) * (size_t)k);
-    L.off_coef = take(sizeof(double) * (size_t)kNB * k);
+    const size_t k4 = (size_t)cdiv(k, 4) * 4;                         // the fused path pads the atoms to a multiple of 4
+    L.off_CP = take(tsz * (size_t)(cdiv(k, 32) * 32) * k4);           // (fused path: fragment order, whole tiles of 32 columns)
+    L.off_cdiag = take(tsz * k4);
+    L.off_frozen = take(sizeof(int32_t) * k4);
+    L.off_coef = take(sizeof(double) * (size_t)kNB * k4);
     L.off_a = take(tsz * (size_t)s_max * kNB);
     L.off_partial = take(sizeof(double) * 2 * (size_t)L.nslab_max * (kNB * kNB + kNB));   // two record buffers (ping-pong)
     L.off_Tp = take(sizeof(double) * 2 * (kNB * kNB + kNB) + 256 + 512);  // two CA records (ping-pong) + arrival counters + debug stamps
     L.off_u = take(tsz * (size_t)s_max);
     L.off_pold = take(sizeof(double) * (size_t)L.nwg_grad);
-    L.off_Dnew = take(tsz * (size_t)(cdiv(s_max > 0 ? s_max : 1, 32) * 32) * k);   // sgd / the packed dictionary (whole tiles of 32 rows)
+    L.off_Dnew = take(tsz * (size_t)(cdiv(s_max > 0 ? s_max : 1, 32) * 32) * k4);  // sgd / the packed dictionary (whole tiles of 32 rows)
     L.off_colp = take(sizeof(double) * (size_t)L.nslab_max * k);
-    L.off_BsP = take(tsz * (size_t)s_max * k);                        // packed B rows (packed D shares off_Dnew)
+    L.off_BsP = take(tsz * (size_t)s_max * k4);                       // packed B rows (packed D shares off_Dnew)
     L.off_gpartial = take(sizeof(double) * 2 * (size_t)kCounters * (kNB * kNB + kNB));   // group sums (two-level reduction), ping-pong
-    L.off_norm_in = take(tsz * (size_t)k);
+    L.off_norm_in = take(tsz * k4);
     L.total = o;
     return L;
 }
@@ -145,26 +146,30 @@ __global__ __launch_bounds__(256) void bcd_prepare_kernel(const T *C, const int3
 // blocks [NB + k, NB + k + s): the sampled rows gathered in sweep order, DsP[f][jj] = Dt[subset[f]][order[jj]]
 // and BsP likewise — every later access of the block kernels is a plain contiguous row.
 template <typename T>
-__global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_t *order, int k, T *CPP, T *cdiag,
+__global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_t *order, int k, int kp, T *CPP, T *cdiag,
                                                         int32_t *frozen, double *coef_all, unsigned int *counter,
                                                         const T *comp_norm, T *norm_in, const T *Dt, const T *Bt,
                                                         const int32_t *subset, int64_t s, T *DsP, T *BsP) {
+    // kp = k rounded up to a multiple of 4: the packed arrays carry kp - k dead atoms (zero columns, frozen), so that the
+    // 16-byte fragments of the block kernel exist for every number of atoms
     int id = (int)blockIdx.x;
     if (id < kNB) {
         const int m = id;
         if (m == 0) {
             if (threadIdx.x < kCounters) counter[threadIdx.x] = 0;
-            for (int j = threadIdx.x; j < k; j += 256) {
-                norm_in[j] = comp_norm[order[j]];     // in SWEEP order: the resolver reads its budgets without a dependent load
-                const T d = C[(int64_t)order[j] * k + order[j]];
-                cdiag[j] = d;
+            for (int j = threadIdx.x; j < kp; j += 256) {
+                const bool real = j < k;
+                const int oj = real ? order[j] : 0;
+                norm_in[j] = real ? comp_norm[oj] : (T)0;   // in SWEEP order: the resolver reads its budgets without a dependent load
+                const T d = real ? C[(int64_t)oj * k + oj] : (T)0;
+                cdiag[j] = real ? d : (T)1;
                 frozen[j] = !(d > (T)1e-20);          // dict_fact.py:681 "else do not update"
             }
         }
-        for (int jj = threadIdx.x; jj < k; jj += 256) {
+        for (int jj = threadIdx.x; jj < kp; jj += 256) {
             const int jl = jj % kNB, jb0 = jj - jl;
             double c = 0;
-            if (m < jl && jb0 + m < k) {
+            if (jj < k && m < jl && jb0 + m < k) {
                 const int oi = order[jb0 + m], oj = order[jj];
                 const T d = C[(int64_t)oj * k + oj];
                 if (d > (T)1e-20) c = (double)C[(int64_t)oi * k + oj] / (double)d;
@@ -174,22 +179,23 @@ __global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_
         return;
     }
     id -= kNB;
-    if (id < k) {
-        const int mp = id, om = order[mp];
-        for (int jj = threadIdx.x; jj < k; jj += 256) {
-            T v = C[(int64_t)om * k + order[jj]];
+    if (id < kp) {
+        const int mp = id, om = mp < k ? order[mp] : 0;
+        for (int jj = threadIdx.x; jj < kp; jj += 256) {
+            T v = (mp < k && jj < k) ? C[(int64_t)om * k + order[jj]] : (T)0;
             if (mp / kNB == jj / kNB && mp <= jj) v = 0;
-            CPP[dfrag(jj, mp, k)] = v;                   // fragment order: (target position, 4 consecutive source atoms)
+            CPP[dfrag(jj, mp, kp)] = v;                  // fragment order: (target position, 4 consecutive source atoms)
         }
         return;
     }
-    id -= k;
+    id -= kp;
     if (id < s) {
         const int64_t f = id, src = sub_row(subset, f) * k;
-        for (int jj = threadIdx.x; jj < k; jj += 256) {
-            const int o = order[jj];
-            DsP[dfrag(f, jj, k)] = Dt[src + o];
-            BsP[f * k + jj] = Bt[src + o];
+        for (int jj = threadIdx.x; jj < kp; jj += 256) {
+            const bool real = jj < k;
+            const int o = real ? order[jj] : 0;
+            DsP[dfrag(f, jj, kp)] = real ? Dt[src + o] : (T)0;
+            BsP[f * kp + jj] = real ? Bt[src + o] : (T)0;
         }
     }
 }
@@ -829,7 +835,8 @@ struct BcdBlockArgs {
     unsigned int *counter;
     unsigned long long *stamps;     // optional phase timestamps of workgroup 0 (diagnostics)
     int64_t s;
-    int k, j0, nb, j0_prev, nb_prev, group;
+    int k, j0, nb, j0_prev, nb_prev, group;   // k: atoms of the PACKED arrays (a multiple of 4, dead atoms behind the real ones)
+    int kout;                                 // row stride of Dt_out: the real number of atoms
 };
 
 // Riding along (see StatsRider in kernels.hpp): the workgroups behind the first `nslab` ones each take one 32 x 32
@@ -1198,7 +1205,7 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
                 const float dnew = (float)dn[r];
                 if (live) {
                     p.Dt[dfrag(f, p.j0_prev + cj, k)] = dnew;
-                    p.Dt_out[(p.subset ? (int64_t)subr[u][r] : f) * k + ocr[u]] = dnew;   // final: no unpack pass
+                    p.Dt_out[(p.subset ? (int64_t)subr[u][r] : f) * p.kout + ocr[u]] = dnew;   // final: no unpack pass
                 }
                 Dl[frow * DLS + cj] = live ? dnew - dold[u][r] : 0.f;
             }
@@ -1742,7 +1749,8 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         double *coef_all = reinterpret_cast<double *>(ws + L.off_coef);
         double *CA[2] = {Tp, Tp + kResStride};
         unsigned int *counter = reinterpret_cast<unsigned int *>(Tp + 2 * kResStride);
-        const bool fused = std::is_same<T, float>::value && (k % 4 == 0) && k <= 512;
+        const bool fused = std::is_same<T, float>::value && k <= 512;
+        const int kp = (int)cdiv(k, 4) * 4;                      // atoms of the packed arrays (dead ones behind the k real)
         constexpr int64_t rt1_max = MODL_RT1_MAX;
         int RT = (s <= rt1_max || k > 256) ? 1 : 2;              // k > 256: 64-row tiles would spill registers
         {   // one workgroup per compute unit (registers): a grid that is a few workgroups larger than the chip runs in
@@ -1758,7 +1766,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             if (RT == 2 && cdiv(s, 64) > ncu_blk && cdiv(s, 96) <= ncu_blk) RT = 3;
         }
         const int nslab = fused ? (int)cdiv(s, 32 * RT) : (int)cdiv(s, kGramRows);
-        const int GPW = (k <= 256) ? 8 : 16;
+        const int GPW = (kp <= 256) ? 8 : 16;
         void (*blk)(BcdBlockArgs, BcdRiderArgs) = nullptr;
         T *DsP = reinterpret_cast<T *>(ws + L.off_Dnew), *BsP = reinterpret_cast<T *>(ws + L.off_BsP), *CPP = CP;
         if (fused) {
@@ -1766,7 +1774,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                             : (RT == 2 ? bcd_block_kernel<2, 8> : bcd_block_kernel<3, 8>);
             MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(blk), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024));
-            hipLaunchKernelGGL((bcd_setup_kernel<T>), dim3((unsigned)(kNB + k + s)), dim3(256), 0, stream, a.C, a.order, k, CPP,
+            hipLaunchKernelGGL((bcd_setup_kernel<T>), dim3((unsigned)(kNB + kp + s)), dim3(256), 0, stream, a.C, a.order, k, kp, CPP,
                                cdiag, frozen, coef_all, counter, a.comp_norm, reinterpret_cast<T *>(ws + L.off_norm_in), a.Dt,
                                a.Bt, a.subset, s, DsP, BsP);
             MODL_LAUNCH_CHECK();
@@ -1787,7 +1795,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             base.frozen = frozen; base.order = a.order; base.a = reinterpret_cast<float *>(abuf);
             base.coef_all = coef_all; base.norm_in = reinterpret_cast<const float *>(ws + L.off_norm_in);
             base.norm_out = reinterpret_cast<float *>(a.comp_norm); base.counter = counter;
-            base.stamps = reinterpret_cast<unsigned long long *>(counter + kCounters); base.s = s; base.k = k;
+            base.stamps = reinterpret_cast<unsigned long long *>(counter + kCounters); base.s = s; base.k = kp; base.kout = k;
             // up to kCounters workgroups: every workgroup sums all records itself in (B) - the pre-summing tail (a
             // release fence + a serial reduction behind the slowest workgroup of a group) costs more than the second
             // round of record loads it saves (measured at 32 workgroups: 17.7 -> 15.9 us per launch); beyond, groups

@@ -25,6 +25,8 @@
 
 namespace modl {
 
+constexpr size_t kCholLdsBytes = 160 * 1024 - 512;   // the matrix of the one-workgroup kernel lives in LDS up to this size
+
 // code[idx[r]] (or code[r]) <- rows[r]
 template <typename T>
 __global__ __launch_bounds__(256) void scatter_rows_any_kernel(T *dst, int64_t ld, const int64_t *idx, int n_rows, int cols,
@@ -83,9 +85,9 @@ int launch_cholesky(hipStream_t stream, const T *G, int64_t g_stride, const int6
     if (nmat <= 0 || k <= 0) return MODL_OK;
     const size_t bytes = (size_t)k * k * sizeof(T);
     const int threads = k <= 64 ? 256 : 1024;
-    if (bytes <= 96 * 1024) {
+    if (bytes <= kCholLdsBytes) {
         MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cholesky_kernel<T, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCholLdsBytes));
         hipLaunchKernelGGL((cholesky_kernel<T, true>), dim3(nmat), dim3(threads), bytes, stream, G, g_stride, g_idx, F,
                            k, alpha);
     } else {
@@ -308,7 +310,11 @@ int chol_solve_blocked(hipStream_t stream, const T *F, const T *Linv, T *rhs, in
     return MODL_OK;
 }
 
-size_t chol_wide_scratch_elems(int k) { return k > 512 ? (size_t)cdiv(k, kCholNB) * kCholNB * kCholNB : 0; }
+size_t chol_wide_scratch_elems(int k) { return k > 128 ? (size_t)cdiv(k, kCholNB) * kCholNB * kCholNB : 0; }
+// A SHARED Gram that does not fit the one-workgroup factorisation's LDS goes the blocked way whatever k is: from
+// global memory that kernel pays two memory round trips per column (1.7 ms at k = 256, measured - the whole minibatch
+// with l1 codes takes 0.25 ms).  One Gram per sample stays with one workgroup per sample up to k = 512.
+bool chol_blocked(int k, size_t tsz, bool shared) { return k > 512 || (shared && (size_t)k * k * tsz > kCholLdsBytes); }
 
 // The ridge solve for k > 512: shared Gram (f_stride == 0: one factorisation, all right-hand sides at once) or one
 // Gram per sample (a factorisation and a single right-hand side each - as slow, relatively, as the reference's b

@@ -51,6 +51,7 @@ int launch_chol_solve(hipStream_t stream, const T *F, int64_t f_stride, T *rhs, 
 // chol_wide_scratch_elems(k) scratch; rhs[b][k]: right-hand sides, overwritten by the solutions, which are also
 // written to code rows d_idx (device, or null = row i).
 size_t chol_wide_scratch_elems(int k);
+bool chol_blocked(int k, size_t tsz, bool shared);   // which ridge systems take the blocked factorisation
 template <typename T>
 int ridge_solve_wide(hipStream_t stream, const T *G, int64_t g_stride, const int64_t *h_gidx, T *F, T *Linv, T *rhs, int b,
                      int k, T alpha, T *code, const int64_t *d_idx);

@@ -417,7 +417,7 @@ int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride
                 T *scatter_dst = nullptr, const int64_t *scatter_idx = nullptr, const int64_t *h_gidx = nullptr) {
     const modl_somf_desc &d = pl->d;
     const int k = d.k;
-    if (d.code_l1_ratio == 0.0 && k > 512) {                          // wide ridge systems: blocked, on the matrix cores
+    if (d.code_l1_ratio == 0.0 && chol_blocked(k, sizeof(T), g_stride == 0)) {   // blocked, on the matrix cores
         if (g_stride && g_idx && !h_gidx) return MODL_EINVAL;         // per-sample Grams are walked from the host
         T *Linv = reinterpret_cast<T *>(pl->dws + pl->off_Linv);
         MODL_TRY(ridge_solve_wide<T>(st, G, g_stride, h_gidx, Fbuf, Linv, Dx, b, k, (T)d.code_alpha, code, d_idx));
@@ -840,7 +840,7 @@ int enet_regression_abi(const T *G, int64_t g_stride, T *Dx, const T *X, int64_t
     T *xnorm = reinterpret_cast<T *>(w);
     T *H0 = reinterpret_cast<T *>(w + align_up(sizeof(T) * (size_t)b, 256));
     T *F = reinterpret_cast<T *>(w + align_up(sizeof(T) * (size_t)b, 256) + align_up(sizeof(T) * (size_t)b * k, 256));
-    if (l1_ratio == 0 && k > 512) {
+    if (l1_ratio == 0 && chol_blocked((int)k, sizeof(T), g_stride == 0)) {
         T *Linv = F + (size_t)k * k;
         return ridge_solve_wide<T>(st, G, g_stride, nullptr, F, Linv, Dx, (int)b, (int)k, alpha, code, d_indices);
     }

@@ -8,7 +8,7 @@ import numpy as np, torch
 import bench
 from modl_amd import DictFact
 dev = torch.device('cuda')
-shapes = ((512, 10000, 10), (384, 10000, 10), (256, 40000, 10), (256, 100000, 12), (128, 10000, 10), (320, 10000, 10), (200, 10000, 10))
+shapes = ((512, 10000, 10), (384, 10000, 10), (256, 40000, 10), (256, 100000, 12), (128, 10000, 10), (320, 10000, 10), (200, 10000, 10), (250, 10000, 10), (70, 10000, 10))
 if len(sys.argv) > 2:
     shapes = (shapes[int(sys.argv[2])],)
 for (k, p, r) in shapes:
