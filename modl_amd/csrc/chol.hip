@@ -209,27 +209,84 @@ template <typename T> struct EpiPanelSym {
 
 // factor the nb x nb diagonal block at (j0, j0) of W in LDS, write it back (symmetric storage) and write the
 // inverse of its lower-triangular factor to Linv[nb][nb] (row-major, zeros above the diagonal)
+// Diagonal block of the blocked factorisation on ONE wavefront, entirely in registers: lane i owns row i of the block (kCholNB values).  Column j: the pivot
+// by v_readlane, every lane writes its own l_i = a_i[j] / d to LDS - by symmetry that is also the scaled row j every
+// lane needs for its rank-1 update - reads it back as broadcast 16-byte words and updates its row: no workgroup
+// barrier, no integer division per element (a 256-thread version with two barriers per column took 2.5 us per column, 162 us per
+// block, 57 % of a ridge minibatch at k = 256).  Then L^-1 column by column (lane t owns column t), the rows of L
+// as LDS broadcasts.  Rows / columns beyond nb are an identity, so ragged blocks need no special case.
 template <typename T>
-__global__ __launch_bounds__(256) void chol_diag_block_kernel(T *W, int k, int j0, int nb, T *Linv) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T *Ls = reinterpret_cast<T *>(smem_raw);
-    T *Xs = Ls + kCholNB * kCholNB;
-    for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) Ls[e] = W[(int64_t)(j0 + e / nb) * k + j0 + e % nb];
-    __syncthreads();
-    cholesky_inplace<T>(Ls, nb);
-    for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) W[(int64_t)(j0 + e / nb) * k + j0 + e % nb] = Ls[e];
-    // column t of the inverse: forward substitution of L x = e_t (thread t; x lives in column t of Xs)
-    const int t = threadIdx.x;
-    if (t < nb) {
-        for (int i = 0; i < nb; ++i) {
-            T acc = (i == t) ? (T)1 : (T)0;
-            for (int m = t; m < i; ++m) acc = fma(-Ls[i * nb + m], Xs[m * nb + t], acc);
-            Xs[i * nb + t] = (i < t) ? (T)0 : acc / Ls[i * nb + i];
-        }
+__global__ __launch_bounds__(64) void chol_diag_wave_kernel(T *W, int k, int j0, int nb, T *Linv) {
+    constexpr int N = kCholNB;
+    // (one struct: `col` at LDS offset 0, so that its broadcast reads are immediate offsets from one base register -
+    // with the array behind Ls the compiler kept a base register per pair of reads and spilled)
+    struct Lds { T col[N]; T invd[N]; T L[N][N + 1]; };     // invd: 1 / L[i][i]
+    __shared__ __attribute__((aligned(16))) Lds lds;
+    T (&col)[N] = lds.col;
+    T (&invd)[N] = lds.invd;
+    T (&Ls)[N][N + 1] = lds.L;
+    const int lane = threadIdx.x;
+    // the block -> LDS, row by row (coalesced; an identity beyond nb), then row `lane` -> registers
+    for (int r = 0; r < N; ++r) {
+        const bool in = r < nb && lane < nb;
+        const T v = W[(int64_t)(j0 + (in ? r : 0)) * k + j0 + (in ? lane : 0)];
+        Ls[r][lane] = in ? v : ((r == lane) ? (T)1 : (T)0);
     }
-    __syncthreads();
-    for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) Linv[e] = Xs[e];
+    __builtin_amdgcn_wave_barrier();
+    T a[N];
+#pragma unroll
+    for (int m = 0; m < N; ++m) a[m] = Ls[lane][m];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        // (scheduler fences per column: in one basic block of 64 unrolled columns the scheduler hoists the LDS reads
+        // of many columns and spills - 1400 scratch accesses, 127 us per block)
+        __builtin_amdgcn_sched_barrier(0);
+        const T d = sqrt(bcast_lane(a[j], j));
+        const T id = (T)1 / d;                             // one division per column (wave-uniform), products after it
+        const T l = a[j] * id;                             // lane i: L[i][j] (lanes < j hold already final values there)
+        col[lane] = l;
+        if (lane == j) invd[j] = id;
+        __builtin_amdgcn_wave_barrier();                   // (LDS operations of one wavefront complete in order)
+        a[j] = (lane == j) ? d : l;
+#pragma unroll
+        for (int m = j + 1; m < N; ++m) {                  // rows <= j: garbage in columns > j, never read
+            a[m] = fma(-l, col[m], a[m]);
+            asm volatile("" : "+v"(a[m]));                 // (computed HERE: the compiler otherwise sinks every update to
+        }                                                  //  the column that reads it and keeps 64 columns of operands live)
+        __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // L (lower triangle of row `lane` in a[0 .. lane]) -> LDS, then the symmetric block back to memory
+#pragma unroll
+    for (int m = 0; m < N; ++m) Ls[lane][m] = (m <= lane) ? a[m] : (T)0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < nb) {
+        T *row = W + (int64_t)(j0 + lane) * k + j0;
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+            if (m < nb) row[m] = (m <= lane) ? Ls[lane][m] : Ls[m][lane];
+    }
+    // X = L^-1: lane t owns column t; x_i = ([i == t] - sum_{m < i} L[i][m] x_m) / L[i][i]  (zero above the diagonal)
+    T x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        T acc = (lane == i) ? (T)1 : (T)0;
+        const T *Lr = &Ls[i][0];
+#pragma unroll
+        for (int m = 0; m < i; ++m) acc = fma(-Lr[m], x[m], acc);
+        x[i] = acc * invd[i];
+        asm volatile("" : "+v"(x[i]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (lane < nb) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (i < nb) Linv[i * nb + lane] = x[i];
+    }
 }
+
 
 template <typename T>
 __global__ __launch_bounds__(256) void chol_load_kernel(const T *g, T *W, int k, T alpha) {
@@ -244,8 +301,6 @@ __global__ __launch_bounds__(256) void chol_load_kernel(const T *g, T *W, int k,
 // F <- factor of (g + alpha I), Linv <- inverses of its diagonal blocks ([ceil(k / 64)][64 * 64])
 template <typename T>
 int cholesky_blocked(hipStream_t stream, const T *g, T *F, T *Linv, int k, T alpha) {
-    MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_diag_block_kernel<T>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kCholNB * kCholNB * (int)sizeof(T)));
     hipLaunchKernelGGL((chol_load_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv((int64_t)k * k, 256), 2048)), dim3(256), 0,
                        stream, g, F, k, alpha);
     MODL_LAUNCH_CHECK();
@@ -253,8 +308,7 @@ int cholesky_blocked(hipStream_t stream, const T *g, T *F, T *Linv, int k, T alp
     for (int j0 = 0, blk = 0; j0 < k; j0 += kCholNB, ++blk) {
         const int nb = std::min(kCholNB, k - j0);
         T *Li = Linv + (size_t)blk * kCholNB * kCholNB;
-        hipLaunchKernelGGL((chol_diag_block_kernel<T>), dim3(1), dim3(256), 2 * kCholNB * kCholNB * sizeof(T), stream, F, k, j0,
-                           nb, Li);
+        hipLaunchKernelGGL((chol_diag_wave_kernel<T>), dim3(1), dim3(64), 0, stream, F, k, j0, nb, Li);
         MODL_LAUNCH_CHECK();
         const int64_t rest = k - j0 - nb;
         if (rest <= 0) break;
@@ -311,10 +365,13 @@ int chol_solve_blocked(hipStream_t stream, const T *F, const T *Linv, T *rhs, in
 }
 
 size_t chol_wide_scratch_elems(int k) { return k > 128 ? (size_t)cdiv(k, kCholNB) * kCholNB * kCholNB : 0; }
-// A SHARED Gram that does not fit the one-workgroup factorisation's LDS goes the blocked way whatever k is: from
-// global memory that kernel pays two memory round trips per column (1.7 ms at k = 256, measured - the whole minibatch
-// with l1 codes takes 0.25 ms).  One Gram per sample stays with one workgroup per sample up to k = 512.
-bool chol_blocked(int k, size_t tsz, bool shared) { return k > 512 || (shared && (size_t)k * k * tsz > kCholLdsBytes); }
+// A SHARED Gram beyond ~160 atoms goes the blocked way whatever k is: the one-workgroup kernel pays two barriers per column
+// (two memory round trips per column once the matrix no longer fits its LDS: 1.7 ms at k = 256, measured - the whole
+// minibatch with l1 codes takes 0.25 ms).  One Gram per sample stays with one workgroup per sample up to k = 512.
+bool chol_blocked(int k, size_t tsz, bool shared) {
+    // measured (minibatch of 256, ridge codes): k = 150 0.50 ms in one workgroup / 0.60 blocked, k = 200 0.87 / 0.80
+    return k > 512 || (shared && (k > 160 || (size_t)k * k * tsz > kCholLdsBytes));
+}
 
 // The ridge solve for k > 512: shared Gram (f_stride == 0: one factorisation, all right-hand sides at once) or one
 // Gram per sample (a factorisation and a single right-hand side each - as slow, relatively, as the reference's b
