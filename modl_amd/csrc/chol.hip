@@ -227,10 +227,18 @@ __global__ __launch_bounds__(64) void chol_diag_wave_kernel(T *W, int k, int j0,
     T (&Ls)[N][N + 1] = lds.L;
     const int lane = threadIdx.x;
     // the block -> LDS, row by row (coalesced; an identity beyond nb), then row `lane` -> registers
-    for (int r = 0; r < N; ++r) {
-        const bool in = r < nb && lane < nb;
-        const T v = W[(int64_t)(j0 + (in ? r : 0)) * k + j0 + (in ? lane : 0)];
-        Ls[r][lane] = in ? v : ((r == lane) ? (T)1 : (T)0);
+    // (two passes, both unrolled: all requests first - as one loop the compiler waits for every row's round trip in turn,
+    // 64 of them)
+    {
+        T raw[N];
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            const bool in = r < nb && lane < nb;
+            raw[r] = W[(int64_t)(j0 + (in ? r : 0)) * k + j0 + (in ? lane : 0)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < N; ++r) Ls[r][lane] = (r < nb && lane < nb) ? raw[r] : ((r == lane) ? (T)1 : (T)0);
     }
     __builtin_amdgcn_wave_barrier();
     T a[N];
