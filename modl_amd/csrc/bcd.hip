@@ -1456,9 +1456,15 @@ struct AtomGroup { int j[kAtomGroup]; int n; };
 // so the smallest that fits is used; elements beyond s are zeros: the sums and their order do not depend on EPT)
 template <typename T, int KPL, int EPT>
 __global__ __launch_bounds__(256) void atom_group_kernel(T *Dt, const T *Bt, const T *C, const int32_t *subset, int64_t s,
-                                                         int k, AtomGroup g, int pos, double rho, double *num, T *dold,
+                                                         int k, AtomGroup g, AtomGroup gp, const T *stage_in, T *stage_out,
+                                                         int pos, double rho, double *num, T *dold,
                                                          double *partial_old, T *comp_norm, unsigned int *counter,
                                                          double *level_hint) {
+    // The projected atoms leave the lone projecting workgroup as COMPACT rows (stage_out[a][feature], coalesced): written
+    // straight into the dictionary they were 20 scattered 4-byte stores per thread and atom, one cache line per lane -
+    // 10 of the 55 us of a group at the fMRI shape (measured).  The many workgroups of the NEXT launch put them where
+    // they belong while they read their dictionary rows anyway (gp, stage_in: the previous group of this sweep);
+    // atom_stage_flush_kernel does it for the last group.
     __shared__ double red[32];
     __shared__ int flag;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -1482,11 +1488,21 @@ __global__ __launch_bounds__(256) void atom_group_kernel(T *Dt, const T *Bt, con
     for (int64_t f = (int64_t)blockIdx.x * nwv + wid; f < s; f += (int64_t)gridDim.x * nwv) {
         const int64_t r = sub_row(subset, f) * k;
         const T *row = Dt + r;
-        T rv[KPL], dj[kAtomGroup], bj[kAtomGroup];
+        T rv[KPL], dj[kAtomGroup], bj[kAtomGroup], pv[kAtomGroup];
 #pragma unroll
         for (int c = 0; c < KPL; ++c) rv[c] = row[e0 + c < k ? e0 + c : k - 1];
 #pragma unroll
         for (int a = 0; a < kAtomGroup; ++a) { dj[a] = row[ja[a]]; bj[a] = Bt[r + ja[a]]; }
+#pragma unroll
+        for (int a = 0; a < kAtomGroup; ++a) pv[a] = stage_in[(int64_t)(a < gp.n ? a : 0) * s + f];   // (unconditional)
+#pragma unroll
+        for (int a = 0; a < kAtomGroup; ++a) {
+            if (a < gp.n) {                                              // the previous group's atoms: into the row
+#pragma unroll
+                for (int c = 0; c < KPL; ++c) rv[c] = (e0 + c == gp.j[a]) ? pv[a] : rv[c];
+                if (lane == 0) Dt[r + gp.j[a]] = pv[a];
+            }
+        }
 #pragma unroll
         for (int a = 0; a < kAtomGroup; ++a) {
             double dot = 0;
@@ -1518,8 +1534,9 @@ __global__ __launch_bounds__(256) void atom_group_kernel(T *Dt, const T *Bt, con
     // EVERY load of the prologue is requested before the first barrier - the scatter offsets, the numerators of the
     // first two atoms, the old-norm partials - so that the lone workgroup pays ONE memory round trip for them, not one
     // per stage (7.4 us of a 54 us group before, measured with clock stamps)
-    int64_t dst[EPT];
-    enet_scatter_offsets<EPT>(subset, (int64_t)k, s, 256, dst);
+    int64_t dst[EPT];                                                    // (compact: feature i of the staged row)
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) dst[e] = threadIdx.x + (int64_t)e * 256;
     double X[2][EPT];
     T Dd[2][EPT];
     auto load_atom = [&](int a, double (&xd)[EPT], T (&dd)[EPT]) {
@@ -1576,8 +1593,8 @@ __global__ __launch_bounds__(256) void atom_group_kernel(T *Dt, const T *Bt, con
             if (pos && val < (T)0) val = 0;                              // dict_fact.py:684-685
             x[e] = (i < s) ? (double)val : 0.0;
         }
-        const double nrm = block_enet_project_vals<T, EPT>(x, dst, Dt + j, s, radius, rho, red, 256, nullptr,
-                                                                level_hint ? level_hint + j : nullptr);
+        const double nrm = block_enet_project_vals<T, EPT>(x, dst, stage_out + (int64_t)a * s, s, radius, rho, red, 256,
+                                                           nullptr, level_hint ? level_hint + j : nullptr);
         if (threadIdx.x == 0) comp_norm[j] = (T)(radius - nrm);         // :690-692
         if (a + 1 < g.n) {
             double (&xn)[EPT] = X[(a + 1) & 1];
@@ -1616,6 +1633,18 @@ __global__ __launch_bounds__(256) void atom_group_kernel(T *Dt, const T *Bt, con
 // launches.  Its thread-per-row reads are uncoalesced, so anything larger uses one multi-workgroup launch
 // per atom (atom_step_kernel).  Same arithmetic as atom_grad_kernel + atom_project_kernel (the dot product is accumulated
 // in double, sequentially over the atoms instead of lane-wise).
+// the last group's staged atoms -> dictionary
+template <typename T>
+__global__ __launch_bounds__(256) void atom_stage_flush_kernel(T *Dt, const int32_t *subset, int64_t s, int k, AtomGroup g,
+                                                               const T *stage) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= s) return;
+    const int64_t r = sub_row(subset, f) * k;
+#pragma unroll
+    for (int a = 0; a < kAtomGroup; ++a)
+        if (a < g.n) Dt[r + g.j[a]] = stage[(int64_t)a * s + f];
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void atom_sweep_kernel(T *Dt, const T *Bt, const T *C, const int32_t *subset,
                                                           const int32_t *order, int64_t s, int k, int pos, double rho,
@@ -1950,13 +1979,18 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
     const size_t u_lds = (sizeof(T) * (size_t)s <= 60 * 1024) ? sizeof(T) * (size_t)s : 0;
     // groups of atoms per launch while the vector fits the registers of the projecting workgroup and the group's
     // scratch (numerators, old values, changes) fits the region of the sgd candidate matrix
-    const size_t group_bytes = (size_t)kAtomGroup * (size_t)s * (sizeof(double) + sizeof(T));
+    const size_t group_bytes = (size_t)kAtomGroup * (size_t)s * (sizeof(double) + 3 * sizeof(T));   // + two staged groups
     if (s <= (int64_t)kProjEpt * 256 && group_bytes + 64 <= sizeof(T) * (size_t)s * k && k <= 512 &&
         (int64_t)kAtomGroup * nwg <= L.nwg_grad) {
         char *gb = ws + L.off_Dnew;
         double *num = reinterpret_cast<double *>(gb);
         T *dold = reinterpret_cast<T *>(num + (size_t)kAtomGroup * s);
-        for (int t = 0; t < k; t += kAtomGroup) {
+        T *stage[2] = {dold + (size_t)kAtomGroup * s, dold + (size_t)2 * kAtomGroup * s};
+        AtomGroup gp;                                 // the group whose projected atoms are staged (none yet)
+        gp.n = 0;
+        for (int a = 0; a < kAtomGroup; ++a) gp.j[a] = 0;
+        int gi = 0;
+        for (int t = 0; t < k; t += kAtomGroup, ++gi) {
             AtomGroup g;
             g.n = (k - t < kAtomGroup) ? k - t : kAtomGroup;
             for (int a = 0; a < kAtomGroup; ++a) {
@@ -1966,7 +2000,8 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
             }
 #define MODL_GROUP_E(KPL, EPT)                                                                                    \
     hipLaunchKernelGGL((atom_group_kernel<T, KPL, EPT>), dim3(nwg), dim3(256), 0, stream, a.Dt, a.Bt, a.C, a.subset, s, k, g, \
-                       a.comp_pos, a.comp_l1_ratio, num, dold, pold, a.comp_norm, counter, a.level_hint)
+                       gp, stage[(gi + 1) & 1], stage[gi & 1], a.comp_pos, a.comp_l1_ratio, num, dold, pold, a.comp_norm,  \
+                       counter, a.level_hint)
 #define MODL_GROUP(KPL)                                                                                           \
     do {                                                                                                          \
         if (s <= 12 * 256) MODL_GROUP_E(KPL, 12);                                                                 \
@@ -1981,7 +2016,12 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
 #undef MODL_GROUP_E
             MODL_LAUNCH_CHECK();
             if (launches) *launches += 1;
+            gp = g;
         }
+        hipLaunchKernelGGL((atom_stage_flush_kernel<T>), dim3((unsigned)cdiv(s, 256)), dim3(256), 0, stream, a.Dt, a.subset, s,
+                           k, gp, stage[(gi + 1) & 1]);
+        MODL_LAUNCH_CHECK();
+        if (launches) *launches += 1;
         return MODL_OK;
     }
     for (int t = 0; t < k; ++t) {
