@@ -358,7 +358,8 @@ int modl_somf_transform(modl_somf_plan *plan, const void *d_Dt, const void *d_G,
  * (0 for the ridge branch).  Synchronises `stream`. */
 int modl_somf_last_sweeps(modl_somf_plan *plan, int32_t *h_out, int cap, int *n_out, void *stream);
 
-/* diagnostics: 32 shader-clock stamps of the last fused dictionary-update block launch, h_out[32] (synchronises the device) */
+/* diagnostics: 48 shader-clock stamps of the last fused dictionary-update block launch (40 ..: the first riding tile),
+ * h_out[48] (synchronises the device) */
 int modl_somf_debug_stamps(modl_somf_plan *plan, unsigned long long *h_out);
 
 /* diagnostics (env MODL_GEMM_STAMPS=1): h_out[8] = shader-clock stamps of one tile of the head statistics product:

@@ -849,13 +849,14 @@ struct BcdRiderArgs {
     int wide = 0;                   // 0: P; 32 / 64: W with that many features per tile
     int t0 = 0, t1 = 0;             // tiles [t0, t1) ride with this launch
     int nslab = 0;                  // workgroups of the block step proper
+    unsigned long long *dbg = nullptr;   // diagnostics: stamps of the first riding tile of a launch
 };
 
 __device__ __forceinline__ void bcd_rider_tile(const BcdRiderArgs &r, char *smem) {
     if (threadIdx.x >= 256) return;                  // the product uses four waves
     const int id = (int)blockIdx.x - r.nslab + r.t0;
     if (id >= r.t1) return;
-    if (r.wide == 32) gemm_wide_tile<32, EpiStatsSkip<float>, 128>(r.W, id, smem);
+    if (r.wide == 32) gemm_wide_tile<32, EpiStatsSkip<float>, 128>(r.W, id, smem, (id == r.t0 && r.dbg) ? r.dbg : nullptr);
     else gemm_stats_tile<EpiStatsSkip<float>>(r.P, id, smem);     // the very tile of gemm_stats_pair_kernel: same bits
 }
 
@@ -1834,6 +1835,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         // deferred statistics product riding along (launches 1 .. nblk carry cdiv(tiles, nblk) tiles each)
         BcdRiderArgs rid;
         rid.nslab = nslab;
+        if (fused) rid.dbg = reinterpret_cast<unsigned long long *>(counter + kCounters) + 40;
         int ride_tiles = 0, ride_per = 0, ride_next = 0;
         if (fused && a.rider) {
             const StatsRider &R = *a.rider;

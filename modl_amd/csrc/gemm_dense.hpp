@@ -32,6 +32,11 @@ struct DenseOperand {
 // load(m, n) -> old value and store(m, n, v, old); operator() stays (split-K reduction, generic kernel).
 template <class E, class = void> struct EpiIsRmw : std::false_type {};
 template <class E> struct EpiIsRmw<E, std::void_t<decltype(E::rmw)>> : std::true_type {};
+// what load() hands to store(): the old value, or a struct carrying more (EpiStatsSkip: the row's stamp, so that store()
+// has nothing left to fetch - a load inside store() was a memory round trip per element)
+template <class E, typename T, class = void> struct EpiOldT { typedef T type; };
+template <class E, typename T> struct EpiOldT<E, T, std::void_t<typename E::Old>> { typedef typename E::Old type; };
+template <class E, typename T> using EpiOld = typename EpiOldT<E, T>::type;
 
 template <typename T> struct Vec4;   // 16-byte vector of T
 template <> struct Vec4<float> { typedef float4 type; static constexpr int N = 4; };
@@ -116,7 +121,7 @@ __device__ __forceinline__ void gemm_tile_epilogue(typename MT::acc_t (&acc)[RM]
         // read-modify-write epilogues: ALL the old values are requested first, then everything is stored (element by
         // element the compiler has to keep each load behind the previous store, which might alias it)
         if (direct) {
-            T old[RM][RN][MT::NACC];
+            EpiOld<Epi, T> old[RM][RN][MT::NACC];
 #pragma unroll
             for (int i = 0; i < RM; ++i)
 #pragma unroll
@@ -295,7 +300,7 @@ __device__ __forceinline__ void gemm_dense_tile_rk(const DenseOperand &A, const 
     }
     // a read-modify-write epilogue's old values do not depend on the product: requested now, with the operands
     constexpr bool kRmw = EpiIsRmw<Epi>::value;
-    T old[RM][RN][MT::NACC];
+    EpiOld<Epi, T> old[RM][RN][MT::NACC];
     if constexpr (kRmw) {
         if (nsplit == 1) {
 #pragma unroll

@@ -59,7 +59,8 @@ WideProblem<Epi> plan_wide(const DenseOperand &A, const DenseOperand &B, int64_t
 // BN atoms per tile (256: every atom of the metric's shape, X fetched once; 128: twice, half the tile time): each of
 // the 4 wavefronts takes BN / 4 atoms
 template <int BM, class Epi, int BN = 256, int BK = kWideBK, int PAD = kWidePad>
-__device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int tile, char *smem) {
+__device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int tile, char *smem, unsigned long long *dbg = nullptr) {
+    if (dbg && threadIdx.x == 0) dbg[0] = clock64();   // diagnostics (scripts/diag_stamps.py): phases of one tile
     constexpr int TI = BM / 16, WN = BN / 4, TJ = WN / 16;
     constexpr int NA = kWideKmax * BM / 4 / 256;           // float4 of the X tile per thread
     constexpr int NB = BK * BN / 4 / 256;                  // float4 of a code tile per thread (8)
@@ -115,7 +116,7 @@ __device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int ti
     // one more round trip behind 13 us of matrix-core work
     constexpr bool kRmw = EpiIsRmw<Epi>::value;
     constexpr bool kEarlyOld = kRmw && BM <= 32;
-    float old[TI][TJ][4];
+    EpiOld<Epi, float> old[TI][TJ][4];
     auto request_old = [&]() {
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti)
@@ -129,8 +130,10 @@ __device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int ti
                 }
     };
     if constexpr (kEarlyOld) request_old();
+    if (dbg && threadIdx.x == 0) dbg[1] = clock64();
     store_b(0);
     gemm_lds_barrier();
+    if (dbg && threadIdx.x == 0) dbg[2] = clock64();
 
     f4v acc[TI][TJ];
 #pragma unroll
@@ -157,6 +160,7 @@ __device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int ti
         if (kt + 1 < nkt) store_b(buf ^ 1);               // last read in step kt - 1, before that step's barrier
         gemm_lds_barrier();
     }
+    if (dbg && threadIdx.x == 0) dbg[3] = clock64();
     if constexpr (kRmw && !kEarlyOld) request_old();
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
@@ -171,6 +175,7 @@ __device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int ti
                     else P.epi(m, n, acc[ti][tj][r]);
                 }
             }
+    if (dbg && threadIdx.x == 0) dbg[4] = clock64();
 }
 
 // the small problem (code^T code -> C_, 32 x 32 tiles of gemm_stats_tile) and the wide one in ONE launch

@@ -1207,7 +1207,7 @@ int modl_somf_debug_stamps(modl_somf_plan *pl, unsigned long long *h_out) {
     if (!pl || !h_out) return MODL_EINVAL;
     MODL_HIP(hipDeviceSynchronize());
     const size_t off = modl::dict_update_stamps_offset(pl->d.dtype, pl->last_s, pl->d.k);
-    MODL_HIP(hipMemcpy(h_out, pl->dws + pl->off_du + off, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    MODL_HIP(hipMemcpy(h_out, pl->dws + pl->off_du + off, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return MODL_OK;
 }
 

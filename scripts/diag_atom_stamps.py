@@ -9,7 +9,7 @@ p, n, b, k = 60000, 400, 50, 70
 X = bench.M1Stream(p, 3, dev, k0=64).rows(0, n)
 est = DictFact(n_components=k, batch_size=b, reduction=12, code_alpha=1e-3, code_l1_ratio=0, comp_l1_ratio=1.0, learning_rate=0.92, random_state=0)
 est.prepare(n_samples=n, X=X[:k]); est.partial_fit(X[:200], np.arange(200))
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 48)()
 check(lib.modl_somf_debug_stamps(est._backend.plan, out))
 o = [int(v) for v in out[:8]]
 print('   projection: start +%d, Michelot loop until +%d (%d passes, %d active), end +%d' % (o[7]-o[2], o[6]-o[2], o[4], o[5], o[3]-o[2]))

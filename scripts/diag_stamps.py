@@ -10,7 +10,7 @@ for r in (10, 1):
     est = DictFact(n_components=256, batch_size=256, reduction=r, code_alpha=1.0, learning_rate=0.92, random_state=0)
     est.prepare(n_samples=4096, X=X[:256])
     est.partial_fit(X[:2048])
-    out = (C.c_ulonglong * 32)()
+    out = (C.c_ulonglong * 48)()
     check(lib.modl_somf_debug_stamps(est._backend.plan, out))
     o = [float(v) for v in out]
     print('r=%g cycles (workgroup 0, last full block launch): total %d' % (r, o[12] - o[0]))
@@ -28,5 +28,7 @@ for r in (10, 1):
     print('   helper wave done %d, product wave 1 loads requested %d, done %d, wave 2 done %d, wave 3 done %d (after barrier 1)' % (o[14] - o[1], o[20] - o[1], o[15] - o[1], o[18] - o[1], o[19] - o[1]))
     print('   first steps (cycles after barrier 1):', [int(o[24 + u] - o[1]) for u in range(8)])
     print('   product wave 2: operands requested %d, product issued %d (after barrier 1)' % (o[21] - o[1], o[22] - o[1]))
+    if r == 10:
+        print('   first riding tile of the last carrier launch: requests issued %d, first operands in LDS %d, contraction %d, epilogue %d (cycles)' % (out[41] - out[40], out[42] - out[40], out[43] - out[42], out[44] - out[43]))
     print('   B detail: entry -> record loads start %d, records summed + in LDS %d, barrier 1 %d' % (o[16] - o[0], o[17] - o[16], o[1] - o[17]))
     print('   resolve: setup %d  steps 0-7 %d  8-15 %d  16-23 %d  24-31+stores %d' % (o[8] - o[1], o[9] - o[8], o[10] - o[9], o[11] - o[10], o[2] - o[11]))
