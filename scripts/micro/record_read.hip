@@ -1,0 +1,105 @@
+// Micro-benchmark: how fast can ONE workgroup per compute unit pull the 30 Gram records (4480 B each, 134 KB) that every
+// block-step workgroup of the dictionary update sums at the top of a launch?  32 workgroups, records written by a previous
+// launch (so they come from memory / the fabric, as in the real chain).  Variants: (a) 16-byte loads into registers, all 30
+// in flight per lane, 5 wavefronts (the product's form); (b) the same with 8 wavefronts; (c) LDS DMA
+// (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16), 90 KB per pass.
+// Build: hipcc -O3 --offload-arch=gfx950 scripts/micro/record_read.hip -o scripts/micro/record_read
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+constexpr int NREC = 30, STRIDE = 560;   // doubles per record
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+__global__ void k_write(double *rec, int it) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < NREC * STRIDE) rec[i] = (double)(i % 97) + it;
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_read_regs(const double *rec, double *out, unsigned long long *cyc) {
+    const int tid = threadIdx.x;
+    const unsigned long long t0 = clock64();
+    constexpr int PAIRS = STRIDE / 2, PER = (PAIRS + 64 * WAVES - 1) / (64 * WAVES);
+    d2v tot[PER];
+    d2v v[PER][NREC];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int e2 = tid + 64 * WAVES * q;
+        const d2v *base = reinterpret_cast<const d2v *>(rec) + (e2 < PAIRS ? e2 : 0);
+#pragma unroll
+        for (int u = 0; u < NREC; ++u) v[q][u] = base[(size_t)u * (STRIDE / 2)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        tot[q] = d2v{0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < NREC; ++u) tot[q] += v[q][u];
+    }
+    double s = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) s += tot[q].x + tot[q].y;
+    out[blockIdx.x * blockDim.x + tid] = s;
+    __syncthreads();
+    const unsigned long long t1 = clock64();
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+// LDS DMA: records [r0, r1) land in LDS as they are; every wave takes 1 KB pieces round-robin
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_read_dma(const double *rec, double *out, unsigned long long *cyc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const unsigned long long t0 = clock64();
+    constexpr int RPP = 20;                                   // records per pass (90 KB of LDS)
+    double tot0 = 0, tot1 = 0;
+    for (int r0 = 0; r0 < NREC; r0 += RPP) {
+        const int nr = (NREC - r0 < RPP) ? NREC - r0 : RPP;
+        const int bytes = nr * STRIDE * 8, pieces = (bytes + 1023) / 1024;
+        const char *src = reinterpret_cast<const char *>(rec + (size_t)r0 * STRIDE);
+        for (int pc = wid; pc < pieces; pc += WAVES) {
+            const int off = pc * 1024 + lane * 16;
+            const int offc = off + 16 <= bytes ? off : bytes - 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + offc),
+                                             (__attribute__((address_space(3))) void *)(smem + pc * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const double *L = reinterpret_cast<const double *>(smem);
+        for (int e = tid; e < STRIDE; e += 64 * WAVES)
+            for (int u = 0; u < nr; ++u) { tot0 += L[u * STRIDE + e]; }
+        tot1 += tot0 * 0;
+        __syncthreads();
+    }
+    out[blockIdx.x * blockDim.x + tid] = tot0 + tot1;
+    __syncthreads();
+    const unsigned long long t1 = clock64();
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <class F> int timeit(const char *name, F launch, double *rec, unsigned long long *cyc) {
+    unsigned long long best = ~0ull, h[32];
+    for (int r = 0; r < 6; ++r) {
+        hipLaunchKernelGGL(k_write, dim3((NREC * STRIDE + 255) / 256), dim3(256), 0, 0, rec, r);
+        launch();
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost));
+        unsigned long long m = 0;
+        for (int w = 0; w < 32; ++w) m = h[w] > m ? h[w] : m;
+        if (m < best) best = m;
+    }
+    printf("%-70s %8llu cycles (slowest of 32 workgroups, best of 6)\n", name, best);
+    return 0;
+}
+
+int main() {
+    double *rec, *out; unsigned long long *cyc;
+    CK(hipMalloc(&rec, NREC * STRIDE * 8)); CK(hipMalloc(&out, 32 * 512 * 8)); CK(hipMalloc(&cyc, 32 * 8));
+    timeit("16-byte loads into registers, 5 wavefronts", [&] { hipLaunchKernelGGL(k_read_regs<5>, dim3(32), dim3(320), 0, 0, rec, out, cyc); }, rec, cyc);
+    timeit("16-byte loads into registers, 8 wavefronts", [&] { hipLaunchKernelGGL(k_read_regs<8>, dim3(32), dim3(512), 0, 0, rec, out, cyc); }, rec, cyc);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_read_dma<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_read_dma<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    timeit("LDS DMA (global_load_lds 16 B), 4 wavefronts, 20 + 10 records", [&] { hipLaunchKernelGGL(k_read_dma<4>, dim3(32), dim3(256), 92 * 1024, 0, rec, out, cyc); }, rec, cyc);
+    timeit("LDS DMA (global_load_lds 16 B), 8 wavefronts, 20 + 10 records", [&] { hipLaunchKernelGGL(k_read_dma<8>, dim3(32), dim3(512), 92 * 1024, 0, rec, out, cyc); }, rec, cyc);
+    return 0;
+}
