@@ -77,10 +77,28 @@ __global__ __launch_bounds__(64 * WAVES) void k_read_dma(const double *rec, doub
     if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+__global__ void k_dirty(float *buf, size_t n, int it) {     // a predecessor that leaves n floats dirty, scattered like the applied columns
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) buf[(i * 67) % n] = (float)(i + it);
+}
+// 64 KB of straight-line code on every compute unit: evicts the instruction caches, as the 85 KB block kernel does to
+// itself from one launch to the next
+template <int N>
+__global__ __launch_bounds__(64) void k_pollute(float *buf, float x0) {
+    float x = x0 + threadIdx.x, y = 1.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { x = __builtin_fmaf(x, 1.0001f + i * 1e-7f, y); y = __builtin_fmaf(y, 0.9999f, x * 1e-9f); }
+    if (x == 12345.678f) buf[threadIdx.x] = x + y;
+}
+static bool g_pollute = false;
+static float *g_dirty = nullptr;
+static size_t g_dirty_n = 0;
 template <class F> int timeit(const char *name, F launch, double *rec, unsigned long long *cyc) {
     unsigned long long best = ~0ull, h[32];
     for (int r = 0; r < 6; ++r) {
+        if (g_dirty_n) hipLaunchKernelGGL(k_dirty, dim3((unsigned)((g_dirty_n + 255) / 256)), dim3(256), 0, 0, g_dirty, g_dirty_n, r);
         hipLaunchKernelGGL(k_write, dim3((NREC * STRIDE + 255) / 256), dim3(256), 0, 0, rec, r);
+        if (g_pollute) hipLaunchKernelGGL(k_pollute<4000>, dim3(512), dim3(64), 0, 0, g_dirty, 1.0f + r);
         launch();
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost));
@@ -96,6 +114,17 @@ int main() {
     double *rec, *out; unsigned long long *cyc;
     CK(hipMalloc(&rec, NREC * STRIDE * 8)); CK(hipMalloc(&out, 32 * 512 * 8)); CK(hipMalloc(&cyc, 32 * 8));
     timeit("16-byte loads into registers, 5 wavefronts", [&] { hipLaunchKernelGGL(k_read_regs<5>, dim3(32), dim3(320), 0, 0, rec, out, cyc); }, rec, cyc);
+    CK(hipMalloc(&g_dirty, (size_t)16 << 20));
+    for (size_t n : {(size_t)0, (size_t)128 << 10, (size_t)1 << 20, (size_t)4 << 20}) {
+        g_dirty_n = n;
+        char nm[128];
+        snprintf(nm, sizeof nm, "   ... 5 wavefronts, predecessor leaves %zu KB dirty", n * 4 / 1024);
+        timeit(nm, [&] { hipLaunchKernelGGL(k_read_regs<5>, dim3(32), dim3(320), 0, 0, rec, out, cyc); }, rec, cyc);
+    }
+    g_dirty_n = 0;
+    g_pollute = true;
+    timeit("   ... 5 wavefronts, instruction caches evicted before the launch", [&] { hipLaunchKernelGGL(k_read_regs<5>, dim3(32), dim3(320), 0, 0, rec, out, cyc); }, rec, cyc);
+    g_pollute = false;
     timeit("16-byte loads into registers, 8 wavefronts", [&] { hipLaunchKernelGGL(k_read_regs<8>, dim3(32), dim3(512), 0, 0, rec, out, cyc); }, rec, cyc);
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_read_dma<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_read_dma<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
