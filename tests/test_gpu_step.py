@@ -287,11 +287,12 @@ def test_full_size_step_properties(DictFact):
     assert_array_equal(runs[0][1], runs[1][1])
 
 
-@pytest.mark.parametrize('k,p,b,red', [(320, 1200, 64, 2), (512, 700, 48, 1), (40, 333, 32, 3)])
+@pytest.mark.parametrize('k,p,b,red', [(320, 1200, 64, 2), (512, 700, 48, 1), (40, 333, 32, 3), (250, 1200, 64, 2), (70, 2001, 96, 3)])
 def test_wide_dictionaries_f32_vs_oracle(DictFact, oracle, k, p, b, red):
     """k > 256 (two registers of coefficients per lane in the solver, 16 contraction groups per wave in the
-    fused dictionary update), k not a multiple of 32, p not a multiple of 4: first minibatch from identical
-    state, f32, against the f32 oracle."""
+    fused dictionary update), k not a multiple of 32, k not a multiple of 4 (dead atoms pad the packed arrays of the
+    fused update, the dense products stage their misaligned operands element by element, the solver runs on a
+    zero-padded Gram), p not a multiple of 4: first minibatch from identical state, f32, against the f32 oracle."""
     rs = np.random.RandomState(11)
     n = max(2 * b, k)                                 # prepare() takes its initial atoms from the first k rows
     X = (rs.randn(n, 96) @ rs.randn(96, p) / 10 + 0.5 * rs.randn(n, p)).astype(np.float32)
