@@ -121,10 +121,10 @@ def test_cd_forced_sweep_kind(fast, oracle, pct):
 
 
 @pytest.mark.parametrize('dt', [np.float32, np.float64])
-@pytest.mark.parametrize('k', [50, 70, 200, 256])
+@pytest.mark.parametrize('k', [50, 70, 161, 200, 256, 330, 511])
 def test_ridge_vs_oracle(fast, oracle, dt, k):
     rs = np.random.RandomState(k)
-    b, p = 20, 400
+    b, p = 20, max(400, k + 100)        # full-rank Gram: the f32 bound below is cond(G + aI) * eps
     D = rs.randn(k, p).astype(dt)
     X = np.ascontiguousarray(rs.randn(b, p).astype(dt))
     G = np.ascontiguousarray((D.dot(D.T) / p).astype(dt))
