@@ -632,10 +632,14 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         if (want_G && A.si != 1) {
             EpiStore<T> epiG{Gbuf, k, red};
             const size_t half = ws_elems / 2;
-            auto PG = plan_dense<T, EpiStore<T>>(Dg, Dg, k, k, s, epiG, ws_split + half, ws_elems - half);
+            // the two products share the chip: 2 workgroups per compute unit in total (256 each) - with 512 each the
+            // split-K partials double and the minibatch at reduction 1 takes 0.352 instead of 0.344 ms (same box),
+            // with 192 or 384 each 0.354 / 0.358 ms
+            constexpr int kPairTarget = 256;
+            auto PG = plan_dense<T, EpiStore<T>>(Dg, Dg, k, k, s, epiG, ws_split + half, ws_elems - half, kPairTarget);
             if (d.Dx_agg == MODL_AGG_AVERAGE) {
                 EpiDxAverage<T> epi{Dx, static_cast<T *>(stt->d_Dx_average), d_idx, d_wsample, k, scale};
-                auto PD = plan_dense<T, EpiDxAverage<T>>(A, B, b, k, Kdim, epi, ws_split, half);
+                auto PD = plan_dense<T, EpiDxAverage<T>>(A, B, b, k, Kdim, epi, ws_split, half, kPairTarget);
                 if (PD.ok && PG.ok) {
                     MODL_TRY((launch_gemm_dense_pair<T, false, true, EpiDxAverage<T>, true, true, EpiStore<T>>(st, PD, PG,
                                                                                                                 &ps.launches)));
@@ -643,7 +647,7 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
                 }
             } else {
                 EpiStore<T> epi{Dx, k, scale};
-                auto PD = plan_dense<T, EpiStore<T>>(A, B, b, k, Kdim, epi, ws_split, half);
+                auto PD = plan_dense<T, EpiStore<T>>(A, B, b, k, Kdim, epi, ws_split, half, kPairTarget);
                 if (PD.ok && PG.ok) {
                     MODL_TRY((launch_gemm_dense_pair<T, false, true, EpiStore<T>, true, true, EpiStore<T>>(st, PD, PG,
                                                                                                             &ps.launches)));

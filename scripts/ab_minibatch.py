@@ -7,8 +7,9 @@ import numpy as np, torch
 import bench
 from modl_amd import DictFact
 dev = torch.device('cuda')
+RED = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0          # python scripts/ab_minibatch.py [reduction]
 X = bench.M1Stream(10000, 1234, dev).rows(0, 256 * 1400)
-est = DictFact(n_components=256, batch_size=256, reduction=10, code_alpha=1.0, learning_rate=0.92, random_state=0)
+est = DictFact(n_components=256, batch_size=256, reduction=RED, code_alpha=1.0, learning_rate=0.92, random_state=0)
 est.prepare(n_samples=65536, X=X[:256])
 est.partial_fit(X[:256 * 400], np.arange(256 * 400) % 65536)
 ts = []
