@@ -4,6 +4,7 @@
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W      (no launcher: starts its N ranks itself, see self_launch)
 
 One "step" = one SOMF minibatch (code solve, statistics, dictionary update) of
 256 rows per GPU.  The synthetic stream M1 of SURVEY.md §8(d) is produced on the
@@ -415,6 +416,49 @@ def roofline_of(dom, prof_dom, fl, by, reduction):
     return roof
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script as child processes (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set),
+    relay rank 0's stdout - whose last line is the JSON line - and return the worst exit status.  If a rank dies the
+    others are ended (they would wait in a collective for ever)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                     # a free rendezvous port
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+                       'HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    lines = []
+
+    def relay():
+        for raw in procs[0].stdout:
+            lines.append(raw.decode(errors='replace'))
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    status, alive = 0, set(range(n))
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0:
+                status = status or rc
+                for o in alive:                    # exactly the processes started above, by pid
+                    procs[o].terminate()
+        time.sleep(0.05)
+    t.join(timeout=10)
+    sys.stdout.write(''.join(lines))
+    sys.stdout.flush()
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -434,14 +478,19 @@ def main():
     ap.add_argument('--share-gpu', action='store_true', help='testing only: every rank uses cuda:0 (needs --backend gloo)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and ('WORLD_SIZE' not in os.environ or (
+            os.environ['WORLD_SIZE'] == '1' and 'TORCHELASTIC_RUN_ID' not in os.environ and 'RANK' not in os.environ)):
+        # launched plainly (`python bench.py --gpus N`): this process becomes the launcher.  It has not touched the
+        # GPU (no torch import, no library load) and never does: the ranks are CHILD processes, never an exec.
+        raise SystemExit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
+    if args.gpus != world:                         # a launcher decided otherwise: its world size is what runs
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d; running %d rank(s)\n' % (args.gpus, world, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
     if args.share_gpu:

@@ -644,6 +644,25 @@ def test_bench_two_ranks_share_gpu():
     assert rec['config']['global_batch'] == 512 and rec['value'] > 0
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher (the way the driver starts `--gpus 1`): the parent starts the two
+    ranks itself before anything touches the GPU and relays rank 0's line as its own last stdout line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--share-gpu', '--backend', 'gloo',
+           '--steps', '12', '--warmup', '4', '--steady-steps', '0']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    last = r.stdout.strip().splitlines()[-1]
+    rec = json.loads(last)                                           # the JSON line is the LAST line of stdout
+    assert rec['n_gpus'] == 2 and rec['replicas_identical'] is True and rec['finite'] is True
+    assert rec['config']['global_batch'] == 512 and rec['value'] > 0
+
+
 def test_c5_shape_step_properties(DictFact):
     """BASELINE config 5's per-GPU shape (p = 200 000 features, k = 256, b = 256, reduction = 12, f32) through both
     the single-GPU step and the two-phase (multi-GPU) step: finite, only sampled columns move, atoms stay in the l2

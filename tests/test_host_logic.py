@@ -156,3 +156,20 @@ def test_two_rank_unequal_batch_counts_raise():
     mp.spawn(_rank_main_unseeded, args=(2, _free_port(), kw, [X0, X1], out), nprocs=2, join=True)
     for r in (0, 1):
         assert out[r]['err'] and 'same number of minibatches' in out[r]['err']
+
+
+def test_bench_self_launch_relays_failure_without_hanging():
+    """`python bench.py --gpus 2` with no launcher starts its two ranks itself.  Without a GPU every rank refuses to
+    run (no CPU fallback); the launcher must come back with that status instead of raising its own error or hanging,
+    and must not have imported torch or the library itself (it forks the ranks before anything touches the GPU)."""
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present: covered by test_bench_launches_its_own_ranks')
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--steady-steps', '0'], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert r.stderr.count('bench.py needs a GPU') == 2, r.stderr[-2000:]      # both ranks were started
+    assert 'must be launched with' not in r.stderr
