@@ -396,8 +396,15 @@ class _HostChunks:
         self.n = X.shape[0]
         self.n_chunks = (self.n + self.rows - 1) // self.rows
         rows = min(self.rows, self.n)
-        self.pinned = [torch.empty((rows, X.shape[1]), dtype=td, pin_memory=True) for _ in range(2)]
-        self.dev = [torch.empty((rows, X.shape[1]), dtype=td, device=self.device) for _ in range(2)]
+        # the two pinned and the two device buffers are kept on the backend across partial_fit calls (a pinned
+        # allocation of 256 MB costs tens of milliseconds)
+        cache = getattr(be, '_host_chunk_buffers', None)
+        if cache is None or cache[0] != (rows, X.shape[1], td):
+            cache = ((rows, X.shape[1], td),
+                     [torch.empty((rows, X.shape[1]), dtype=td, pin_memory=True) for _ in range(2)],
+                     [torch.empty((rows, X.shape[1]), dtype=td, device=self.device) for _ in range(2)])
+            be._host_chunk_buffers = cache
+        self.pinned, self.dev = cache[1], cache[2]
         self.copied = [None, None]        # event: the upload out of pinned[i] / into dev[i] has finished
         self.consumed = [None, None]      # event: the fit has finished reading dev[i]
         self.stream = torch.cuda.Stream(self.device)
@@ -420,18 +427,25 @@ class _HostChunks:
         return r0, r1
 
     def __iter__(self):
-        pending = self.pool.submit(self._stage, 0)
-        for c in range(self.n_chunks):
-            r0, r1 = pending.result()
-            if c + 1 < self.n_chunks:
-                pending = self.pool.submit(self._stage, c + 1)
-            main = torch.cuda.current_stream(self.device)
-            main.wait_event(self.copied[c % 2])
-            yield r0, self.dev[c % 2][:r1 - r0]
-            ev = torch.cuda.Event()
-            ev.record(main)
-            self.consumed[c % 2] = ev
-        self.pool.shutdown(wait=True)
+        try:
+            pending = self.pool.submit(self._stage, 0)
+            for c in range(self.n_chunks):
+                r0, r1 = pending.result()
+                if c + 1 < self.n_chunks:
+                    pending = self.pool.submit(self._stage, c + 1)
+                main = torch.cuda.current_stream(self.device)
+                main.wait_event(self.copied[c % 2])
+                yield r0, self.dev[c % 2][:r1 - r0]
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self.consumed[c % 2] = ev
+        finally:
+            # also on an error in a minibatch (or a generator that is dropped half way): no worker thread, no upload
+            # out of the pinned buffers and no fit reading the device buffers may outlive the call - the buffers are
+            # reused by the next one
+            self.pool.shutdown(wait=True)
+            self.stream.synchronize()
+            torch.cuda.current_stream(self.device).synchronize()
 
 
 class _SubsetsAhead:
@@ -452,6 +466,17 @@ class _SubsetsAhead:
             _SubsetsAhead._pool_pid = os.getpid()
         self.q = queue.Queue(maxsize=depth)
         self.stop = False
+        self.sampler, self.reduction = sampler, reduction
+        self.state0 = sampler.__getstate__()                 # to rewind the draws nobody consumed (see close())
+        self.drawn = self.consumed = 0
+
+        def put(item):                                       # a bounded put, so that close() can always end the task
+            while not self.stop:
+                try:
+                    self.q.put(item, timeout=0.05)
+                    return
+                except queue.Full:
+                    pass
 
         def work():
             try:
@@ -459,25 +484,30 @@ class _SubsetsAhead:
                     if self.stop:
                         return
                     item = sampler.yield_subset(reduction)
-                    while not self.stop:                     # (a bounded put, so that close() can always end the task)
-                        try:
-                            self.q.put(item, timeout=0.05)
-                            break
-                        except queue.Full:
-                            pass
+                    self.drawn += 1
+                    put(item)
             except BaseException as e:                       # handed to the consumer
-                self.q.put(e)
+                put(e)
         self.task = _SubsetsAhead._pool.submit(work)
 
     def next(self):
         item = self.q.get()
         if isinstance(item, BaseException):
             raise item
+        self.consumed += 1
         return item
 
     def close(self):
+        """Ends the worker (it is free for the next call).  If the consumer stopped early - an error in a minibatch -
+        the sampler has drawn subsets nobody used: it is rewound and re-plays exactly the consumed draws, so that a
+        retry continues the reference's MT19937 subset stream (sampler.pyx:41-70) where the last FITTED minibatch
+        left it."""
         self.stop = True
-        self.task.result()                                   # the worker is free for the next call
+        self.task.result()
+        if self.drawn != self.consumed:
+            self.sampler.restore(self.state0)
+            for _ in range(self.consumed):
+                self.sampler.yield_subset(self.reduction)
 
 
 class _DeviceRows:
@@ -561,7 +591,18 @@ def _sum_over_ranks(arr, device):
     return t.cpu().numpy()
 
 
-def _state_property(name, getter=None, setter=None, summed=False):
+def _rank0_share(value):
+    """Several ranks: a statistic that is kept as per-rank partial sums is SET by giving rank 0 the value and every
+    other rank zeros, so that the sum over the ranks is the value (and not world x value)."""
+    dist = _dist()
+    if dist is None or dist.get_rank() == 0:
+        return value
+    return np.zeros_like(np.asarray(value))
+
+
+def _state_property(name, getter=None, setter=None, summed=False, local=False):
+    """summed: the attribute of a statistic kept as per-rank partial sums (C_, B_) - reading it is a COLLECTIVE with
+    several ranks (every rank has to read it); `local=True` gives the non-collective twin (this rank's partial sum)."""
     def fget(self):
         be = self.__dict__.get('_backend')
         if be is None or getattr(be, 'Dt', None) is None:
@@ -569,12 +610,15 @@ def _state_property(name, getter=None, setter=None, summed=False):
         val = getter(be) if getter else be.get(name)
         if val is None:
             raise AttributeError(name)
-        return _sum_over_ranks(val, be.device) if summed else val
+        return _sum_over_ranks(val, be.device) if summed and not local else val
 
     def fset(self, value):
         be = self.__dict__.get('_backend')
         if be is None:
             raise AttributeError('%s can only be set after prepare()' % name)
+        if summed:
+            value = _rank0_share(value)
+            self.__dict__['_stats_on_rank0'] = False      # (true again after the next consolidate_statistics())
         (setter(be, value) if setter else be.set(name, value))
     return property(fget, fset)
 
@@ -612,8 +656,13 @@ class DictFact(CodingMixin, BaseEstimator):
 
     # device-resident attributes of the reference (dict_fact.py:225-249)
     components_ = _state_property('components_', lambda be: be.get_dictionary(), lambda be, v: be.set_dictionary(v))
+    # Several ranks: C_ and B_ live as per-rank partial sums.  `B_` / `C_` are the sums over the ranks -
+    # a COLLECTIVE read, every rank must perform it; `local_B_` / `local_C_` are this rank's share, no communication
+    # (after consolidate_statistics() rank 0's share is the whole statistic).  Setting one puts the value on rank 0.
     B_ = _state_property('B_', lambda be: be.get_B(), lambda be, v: be.set_B(v), summed=True)
     C_ = _state_property('C', summed=True)
+    local_B_ = _state_property('B_', lambda be: be.get_B(), lambda be, v: be.set_B(v), summed=True, local=True)
+    local_C_ = _state_property('C', summed=True, local=True)
     code_ = _state_property('code')
     comp_norm_ = _state_property('comp_norm')
     G_ = _state_property('G')
@@ -844,6 +893,8 @@ class DictFact(CodingMixin, BaseEstimator):
             return
         # Several ranks: every rank keeps its own partial C_ / B_ (both recursions are linear in the increments);
         # only what the dictionary update reads - C_ and the sampled rows of B_ - is summed over the ranks.
+        if world > 1:
+            self._stats_on_rank0 = False
         if getattr(self, '_native_rccl', False) and hasattr(be, 'step_dist'):
             # the exchange inside the library (modl_somf_step_dist): RCCL called directly, on the compute stream
             import torch.distributed as dist
@@ -855,27 +906,76 @@ class DictFact(CodingMixin, BaseEstimator):
             self._all_reduce(head)
         be.phase2(head)
 
+    # ------------------------------------------------- several ranks: state
+    def consolidate_statistics(self):
+        """COLLECTIVE (every rank calls it; a no-op with one rank).  With several ranks `C_` and `B_` are kept as
+        per-rank partial sums; this sums them over the ranks, leaves the sums on rank 0 and zeros on the others - the
+        sum over the ranks, which is all the next minibatch uses, is unchanged - so that rank 0's state IS the
+        reference's state (dict_fact.py:116-124): a pickle written on rank 0 afterwards can be loaded anywhere."""
+        dist = _dist()
+        if dist is None:
+            return self
+        be, rank0 = self._backend, dist.get_rank() == 0
+        on_device = dist.get_backend() == 'nccl' and isinstance(getattr(be, 'Bt', None), torch.Tensor)
+        if on_device:
+            be.synchronize()
+            for t in (be.C, be.Bt):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                if not rank0:
+                    t.zero_()
+        else:
+            C_sum, B_sum = _sum_over_ranks(be.get('C'), be.device), _sum_over_ranks(be.get_B(), be.device)
+            be.set('C', C_sum if rank0 else np.zeros_like(C_sum))
+            be.set_B(B_sum if rank0 else np.zeros_like(B_sum))
+        self._stats_on_rank0 = True
+        return self
+
     # ---------------------------------------------------------------- pickle
     def __getstate__(self):
+        """Pickling is LOCAL (no collective: `if rank == 0: pickle.dump(est)` must not hang).  With several ranks the
+        pickle therefore holds this rank's share of C_ / B_, and says so: unless consolidate_statistics() ran right
+        before on every rank (then rank 0's share is the whole statistic), loading it anywhere but on the same rank
+        of a world of the same size raises."""
         state = dict(self.__dict__)
         be = state.pop('_backend', None)
+        state.pop('_subsets', None)
         if be is not None and getattr(be, 'Dt', None) is not None:
             be.synchronize()
+            dist = _dist()
+            world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
+            whole = world == 1 or (rank == 0 and bool(state.get('_stats_on_rank0', False)))
+            if not whole:
+                import warnings
+                warnings.warn('pickling rank %d of %d: C_ and B_ are per-rank partial sums; call '
+                              'consolidate_statistics() on every rank first and pickle on rank 0 to get a checkpoint '
+                              'that loads elsewhere' % (rank, world))
             state['_saved'] = dict(
                 dtype=str(be.dtype), n=be.n, p=be.p, k=be.k, components_=be.get_dictionary(), B_=be.get_B(),
                 C=be.get('C'), code=be.get('code'), comp_norm=be.get('comp_norm'), G=be.get('G'),
-                Dx_average=be.get('Dx_average'), G_average=be.get('G_average'))
+                Dx_average=be.get('Dx_average'), G_average=be.get('G_average'),
+                partial_of=None if whole else (rank, world))
+        state.pop('_stats_on_rank0', None)
         return state
 
     def __setstate__(self, state):
         saved = state.pop('_saved', None)
         self.__dict__.update(state)
         if saved is not None:
+            dist = _dist()
+            world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
+            part = saved.get('partial_of')
+            if part is not None and tuple(part) != (rank, world):
+                raise ValueError('this pickle holds the share of rank %d of %d of the statistics C_ / B_ (it was written '
+                                 'without consolidate_statistics()); it can only be loaded by that rank of a world of '
+                                 'that size, not by rank %d of %d' % (part[0], part[1], rank, world))
             self._backend = be = self._make_backend()
             be.allocate(self._plan_kwargs(self.batch_size), saved['n'], saved['p'], saved['k'], np.dtype(saved['dtype']))
             be.set_dictionary(saved['components_'])
-            be.set_B(saved['B_'])
-            for name in ('C', 'code', 'comp_norm', 'G', 'Dx_average', 'G_average'):
+            # a whole statistic loaded by several ranks goes to rank 0 (zeros elsewhere): the sum over the ranks is it
+            be.set_B(saved['B_'] if part is not None else _rank0_share(saved['B_']))
+            be.set('C', saved['C'] if part is not None else _rank0_share(saved['C']))
+            self._stats_on_rank0 = part is None and world > 1
+            for name in ('code', 'comp_norm', 'G', 'Dx_average', 'G_average'):
                 if saved[name] is not None:
                     be.set(name, saved[name])
 

@@ -155,6 +155,11 @@ class Sampler:
         check(lib.modl_sampler_get_state(self._h, _p(buf), nbytes))
         return dict(range=self.range, rand_size=self.rand_size, replacement=self.replacement, blob=buf)
 
+    def restore(self, st):
+        """rewind THIS sampler to a state taken from it with __getstate__ (no new handle)"""
+        blob = np.ascontiguousarray(st['blob'])
+        check(lib.modl_sampler_set_state(self._h, _p(blob), blob.nbytes))
+
     def __setstate__(self, st):
         self.__init__(st['range'], st['rand_size'], st['replacement'], 0)
         blob = np.ascontiguousarray(st['blob'])
