@@ -467,7 +467,8 @@ class _SubsetsAhead:
         self.q = queue.Queue(maxsize=depth)
         self.stop = False
         self.sampler, self.reduction = sampler, reduction
-        self.state0 = sampler.__getstate__()                 # to rewind the draws nobody consumed (see close())
+        # to rewind the draws nobody consumed (see close()); a stand-in sampler without `restore` is left as it is
+        self.state0 = sampler.__getstate__() if hasattr(sampler, 'restore') else None
         self.drawn = self.consumed = 0
 
         def put(item):                                       # a bounded put, so that close() can always end the task
@@ -504,7 +505,7 @@ class _SubsetsAhead:
         left it."""
         self.stop = True
         self.task.result()
-        if self.drawn != self.consumed:
+        if self.drawn != self.consumed and self.state0 is not None:
             self.sampler.restore(self.state0)
             for _ in range(self.consumed):
                 self.sampler.yield_subset(self.reduction)

@@ -282,3 +282,34 @@ def test_two_rank_setters_set_the_sum():
     for r in (0, 1):
         assert_array_equal(out[r]['B'], out[r]['v'])
         assert_array_equal(out[r]['C'], np.eye(3))
+
+
+def test_failed_minibatch_rewinds_the_subset_lookahead():
+    """The feature subsets of the coming minibatches are drawn ahead on a worker thread.  When a minibatch fails, the
+    draws nobody consumed must not be lost: after the error the sampler continues the reference's MT19937 subset
+    stream (sampler.pyx:41-70) right behind the last subset that reached a minibatch."""
+    rs = np.random.RandomState(7)
+    X = rs.randn(96, 20)
+    kw = dict(n_components=4, batch_size=8, reduction=2, random_state=0, code_alpha=0.1)
+    clean = HostDictFact(**kw)
+    clean.prepare(n_samples=96, X=X)
+    seen = []
+    orig = clean.feature_sampler_.yield_subset
+    for _ in range(12):
+        seen.append(orig(2))                                   # the stream itself: 12 subsets
+    est = HostDictFact(**kw)
+    est.prepare(n_samples=96, X=X)
+    calls = []
+    real_fit = est._single_batch_fit.__func__
+
+    def failing(self, Xh, batch, idx, b_global=None):
+        if len(calls) == 3:
+            calls.append('boom')
+            raise RuntimeError('boom')
+        calls.append(batch.start)
+        return real_fit(self, Xh, batch, idx, b_global=b_global)
+    est._single_batch_fit = failing.__get__(est)
+    with pytest.raises(RuntimeError):
+        est.partial_fit(X, np.arange(96))                      # 12 minibatches, the 4th fails before it draws
+    # three subsets were consumed: the next draw is the fourth of the stream, whatever the worker had drawn ahead
+    assert_array_equal(est.feature_sampler_.yield_subset(2), seen[3])
