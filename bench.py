@@ -171,9 +171,11 @@ def step_flops(k, p, b, s, sweeps, ride=False):
     b_inc = 2.0 * b * k * p
     bcd = 2.0 * k * k * s
     if ride:
+        # the sampled rows of the B increment (2 b k s) are in `stats_gemm`; the rider carries the other p - s rows
+        rider = 2.0 * b * k * (p - s)
         return dict(code_gemm=dx + gram, code_solve=h0 + cd, stats_gemm=c_inc + 2.0 * b * k * s,
-                    stats_apply=3.0 * (k * k + p * k), dict_update=bcd + b_inc, dict_update_own=bcd,
-                    dict_update_rider=b_inc)
+                    stats_apply=3.0 * (k * k + p * k), dict_update=bcd + rider, dict_update_own=bcd,
+                    dict_update_rider=rider)
     return dict(code_gemm=dx + gram, code_solve=h0 + cd, stats_gemm=c_inc + b_inc, stats_apply=3.0 * (k * k + p * k),
                 dict_update=bcd, dict_update_own=bcd, dict_update_rider=0.0)
 
@@ -262,36 +264,36 @@ def timed(run, steps, world):
     return dt, enq
 
 
+ROOF_SECTIONS = ('dict_update', 'code_solve')      # the two sections that can dominate the step: both are timed
+
+
 def run_gpu(args, reduction, steps, warmup, rank, world, device, breakdown=True):
-    """Warm-up (all sections timed on its last quarter -> picks the dominant one), the timed region (HIP events around
-    the dominant section only: every timed section costs two event records, i.e. a stream bubble of a few microseconds
-    each), then an untimed pass with all sections timed for the breakdown."""
+    """Warm-up, the timed region (HIP events around `dict_update` and `code_solve` only, on one minibatch in four:
+    every timed section costs two event records, i.e. a stream bubble of a few microseconds each), then an untimed
+    pass with all sections timed for the breakdown.  The roofline line is the section with the larger time OVER THE
+    TIMED REGION (not over a warm-up minibatch: the line means the same thing whatever --warmup is)."""
     import torch
     import torch.distributed as dist
     extra = min(steps, 50) if breakdown else 0
     run = Run(args, reduction, rank, world, device, steps + warmup + extra)
     be = run.be
-    w_head = warmup - max(warmup // 4, 1) if warmup >= 4 else warmup
-    run.fit(w_head)
-    pre, dom = {}, 'dict_update'
-    if breakdown:
-        be.prof_enable(True)
-        be.prof_reset()
-    run.fit(warmup - w_head)
+    run.fit(warmup)
     run.sync()
+    dom = 'dict_update'
     if breakdown:
-        pre = be.prof_get()
-        if warmup - w_head > 0 and pre:
-            dom = max(pre, key=lambda n: pre[n]['ms'])
-        be.prof_enable(False)
-        # events around the dominant section only, and on one minibatch in four: an event pair is a stream bubble
-        # of ~9 us (scripts/step_timeline.py on a rocprofv3 trace), i.e. 3 % of a step if every step paid it
-        be.prof_enable(True, sections=[dom], every=4 if steps >= 16 else 1)
+        # events around two sections, on one minibatch in four: an event pair is a stream bubble of ~9 us
+        # (scripts/step_timeline.py on a rocprofv3 trace), i.e. ~2 % of a step this way
+        be.prof_enable(True, sections=list(ROOF_SECTIONS), every=4 if steps >= 16 else 1)
         be.prof_reset()
     dt, enq = timed(run, steps, world)
-    res = dict(dt=dt, enqueue_ms_per_step=enq / steps * 1e3, dom=dom, prof_dom=None, prof={})
+    res = dict(dt=dt, enqueue_ms_per_step=enq / steps * 1e3, dom=dom, prof_dom=None, prof_timed={}, prof={})
     if breakdown:
-        res['prof_dom'] = be.prof_get()[dom]
+        got = be.prof_get()
+        res['prof_timed'] = {n: got[n] for n in ROOF_SECTIONS if n in got and got[n]['calls'] > 0}
+        if res['prof_timed']:
+            dom = max(res['prof_timed'], key=lambda n: res['prof_timed'][n]['ms'] / res['prof_timed'][n]['calls'])
+        res['dom'] = dom
+        res['prof_dom'] = res['prof_timed'].get(dom)
         be.prof_enable(False)
     lsw = be.last_sweeps()
     res['sweeps'], res['sweeps_max'] = float(lsw.mean()), int(lsw.max())
@@ -373,6 +375,11 @@ def cpu_baseline(X, reduction, budget_s=20.0, threads=None):
     return out
 
 
+def survey_flops_per_sample(k, p, b, s, sweeps):
+    """2ks (Dx) + 2kp (B_) + 2k^2 (C_) + 4k^2 n_sw (CD) + (2k^2 s [G] + 2k^2 s [C_ D_sub] + 4k^2 s [2k gers]) / b"""
+    return 2.0 * k * s + 2.0 * k * p + 2.0 * k * k + 4.0 * k * k * sweeps + 8.0 * k * k * s / b
+
+
 def roofline_of(dom, prof_dom, fl, by, reduction):
     if not prof_dom or prof_dom['calls'] <= 0:
         return None
@@ -399,8 +406,9 @@ def roofline_of(dom, prof_dom, fl, by, reduction):
                              riding_statistics_product=dict(flops_per_step=rider, achieved=rider / ms / 1e9,
                                                             frac=rider / ms / 1e9 / PEAK_MFMA_F32_TFLOPS))
     if dom == 'code_solve':
-        roof['note'] = ('coordinate descent is a VALU kernel (no MFMA) bound by the dependency chain of k x sweeps '
-                        'sequential coordinate steps per sample; the MFMA peak is the compute roof by convention')
+        roof['note'] = ('coordinate descent is a VALU kernel (no MFMA): `peak` is the f32 VECTOR rate, which equals the f32 '
+                        'matrix rate on this part (157.3 TFLOP/s); the kernel is bound by the dependency chain of k x sweeps '
+                        'sequential coordinate steps per sample, not by either (informational)')
     # HBM traffic per launch of the section's main kernel: from the committed rocprofv3 --pmc passes of this round
     # (FETCH_SIZE and WRITE_SIZE need separate profiler passes and cannot be collected from inside this process)
     try:
@@ -524,6 +532,15 @@ def main():
                                   gflops=fl[name] / ms / 1e6, gbs=by[name] / ms / 1e6)
         roof = roofline_of(dom, res['prof_dom'], fl, by, args.reduction)
         total_fl = sum(fl[n] for n in ('code_gemm', 'code_solve', 'stats_gemm', 'dict_update'))
+        if roof is not None:
+            # the other candidate, measured over the same timed region, and the step as a whole by SURVEY §8d's model
+            other = [n for n in ROOF_SECTIONS if n != dom and n in res['prof_timed']]
+            roof['other_section'] = roofline_of(other[0], res['prof_timed'][other[0]], fl, by, args.reduction) if other else None
+            fps = survey_flops_per_sample(K_COMP, P_FEAT, BATCH, s_mean, sweeps)
+            tf = samples / dt * fps / 1e12
+            roof['whole_step'] = dict(flops_per_sample=fps, achieved=tf, unit='TFLOP/s', frac=tf / PEAK_MFMA_F32_TFLOPS / world,
+                                      note='SURVEY 8(d) work model of the REFERENCE algorithm at the measured sweep count '
+                                           '(it counts the 4k^2 s of ger updates the blocked dictionary update does not perform)')
         out = dict(metric='samples/sec through DictFact.partial_fit at k=256, p=10k', value=samples / dt,
                    unit='samples/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None,

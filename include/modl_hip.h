@@ -64,8 +64,13 @@ int modl_device_count(void);
 const char *modl_error_string(int code);
 /* process-wide diagnostics switches (the test-suite forces code paths with them; nothing reads the environment).
  * MODL_DEBUG_CD_SPARSE_PCT: value >= 0 = share of active coordinates (percent) below which a coordinate-descent
- * sweep runs as an active-set sweep (0: always dense, 100: always sparse), -1 = the default rule. */
+ * sweep runs as an active-set sweep (0: always dense, 100: always sparse), -1 = the default rule.
+ * MODL_DEBUG_CD_SPLIT: 1 (default) = shared-Gram solves with 64 < k <= 512 run the two-wavefront solver
+ * (cd_split.hip), 0 = the one-wavefront solver everywhere (the two are bit-identical; the tests compare them). */
 #define MODL_DEBUG_CD_SPARSE_PCT 1
+#define MODL_DEBUG_CD_SPLIT 2
+#define MODL_DEBUG_CD_SPLIT_DIAG 4   /* timing experiments on the two-wavefront solver (WRONG results; cd_split.hip) */
+#define MODL_DEBUG_CD_STAMPS 3   /* value = device pointer to 1024 uint64 (0: off): shader-clock stamps of sample 0 of the two-wavefront solver */
 int modl_debug_set(int what, int64_t value);
 
 /* ------------------------------------------------------------------------- *

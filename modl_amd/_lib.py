@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'libmodl_hip.so')
 MODL_F32, MODL_F64 = 0, 1
 FLAG_NO_RIDER, FLAG_GEMM_STAMPS = 1, 2          # modl_somf_desc.flags (diagnostics)
 DEBUG_CD_SPARSE_PCT = 1                         # modl_debug_set
+DEBUG_CD_SPLIT = 2
 AGG = {'masked': 0, 'full': 1, 'average': 2}
 OPT = {'variational': 0, 'sgd': 1}
 

@@ -33,6 +33,7 @@
 // gap test are wave shuffles.  b independent problems -> b wavefronts, 4 per
 // workgroup.
 #include "kernels.hpp"
+#include "cd_common.hpp"
 #include <atomic>
 #ifndef MODL_CD_SPARSE_RING
 #define MODL_CD_SPARSE_RING 4          /* (tuning) ring depth of the sparse sweep for k <= 256 */
@@ -40,16 +41,6 @@
 #include <utility>
 
 namespace modl {
-
-// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>)
-template <int... Js, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Js...>, F &&f) {
-    (f(std::integral_constant<int, Js>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
-}
 
 // Row loader: coefficients lane * KPL .. lane * KPL + KPL - 1 of row ii in r[].  VEC (k == 64 * KPL, 16-byte
 // aligned rows): 16-byte loads; otherwise element loads with a clamped address and a select — no branches
@@ -75,21 +66,6 @@ __device__ __forceinline__ void load_row(const T *__restrict__ Q, int ii, int k,
             r[c] = e < k ? v : (T)0;
         }
     }
-}
-
-__device__ __forceinline__ float clamp3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
-__device__ __forceinline__ double clamp3(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
-
-// One coordinate (dict_fact_fast.pyx:354-386), elementwise or on wave-uniform scalars; returns the new
-// coefficient.
-template <typename T, bool POSITIVE>
-__device__ __forceinline__ T cd_coordinate(T h, T wo, T qq, T ri, T Qcc, T alpha) {
-    const T Hii = fma(-wo, Qcc, h);                            // H[ii] after "H -= w_ii * Q[ii]" (:361-365)
-    const T tmp = qq - Hii;                                    // :367
-    // :372 soft threshold sign(tmp) max(|tmp| - alpha, 0) as tmp - clamp(tmp, -alpha, alpha): the same
-    // rounded difference, two operations shorter (a zero result may carry the other sign)
-    const T cl = POSITIVE ? (tmp < alpha ? tmp : alpha) : clamp3(tmp, -alpha, alpha);
-    return (tmp - cl) * ri;
 }
 
 // Gram rows in flight in the dense sweep.  A row comes from L2 (the 256 KB matrix does not fit a compute unit's L1):
@@ -535,6 +511,9 @@ static void launch_cd_kpl(hipStream_t stream, const CdArgs<T> &a, dim3 grid, dim
 
 // diagnostics (modl_debug_set): >= 0 overrides CdArgs::sparse_pct for every launch of this process
 std::atomic<int> g_cd_sparse_pct{-1};
+std::atomic<int> g_cd_split{1};
+extern std::atomic<unsigned long long *> g_cd_stamps;   // cd_split.hip
+extern std::atomic<int> g_cd_split_diag;
 
 template <typename T>
 int launch_cd(hipStream_t stream, const CdArgs<T> &a0) {
@@ -543,6 +522,10 @@ int launch_cd(hipStream_t stream, const CdArgs<T> &a0) {
     CdArgs<T> a = a0;
     const int sparse_pct = g_cd_sparse_pct.load(std::memory_order_relaxed);   // diagnostics: modl_debug_set
     if (sparse_pct >= 0) a.sparse_pct = sparse_pct;
+    // a shared Gram matrix with k > 64: a workgroup per sample, the chain on one wavefront and the k-wide update on
+    // another (cd_split.hip); bit-identical to cd_kernel, which keeps the per-sample Gram matrices, k <= 64 and
+    // k > 512 (diagnostics: modl_debug_set(MODL_DEBUG_CD_SPLIT, 0) forces cd_kernel)
+    if (g_cd_split.load(std::memory_order_relaxed) && cd_split_applies<T>(a)) return launch_cd_split<T>(stream, a);
     dim3 grid((unsigned)cdiv(a.b, 4)), block(256);
     if (a.k <= 64) launch_cd_kpl<T, 1>(stream, a, grid, block);
     else if (a.k <= 128) launch_cd_kpl<T, 2>(stream, a, grid, block);
@@ -627,6 +610,18 @@ template int launch_row_norm2<double>(hipStream_t, const double *, int64_t, int6
 extern "C" int modl_debug_set(int what, int64_t value) {
     if (what == MODL_DEBUG_CD_SPARSE_PCT) {
         modl::g_cd_sparse_pct.store((int)value, std::memory_order_relaxed);
+        return MODL_OK;
+    }
+    if (what == MODL_DEBUG_CD_STAMPS) {
+        modl::g_cd_stamps.store(reinterpret_cast<unsigned long long *>((uintptr_t)value));
+        return MODL_OK;
+    }
+    if (what == MODL_DEBUG_CD_SPLIT_DIAG) {
+        modl::g_cd_split_diag.store((int)value);
+        return MODL_OK;
+    }
+    if (what == MODL_DEBUG_CD_SPLIT) {
+        modl::g_cd_split.store((int)value, std::memory_order_relaxed);
         return MODL_OK;
     }
     return MODL_EINVAL;

@@ -29,6 +29,9 @@ struct CdArgs {
                            // (measured at k = 256: a sparse step costs 0.23 us, a dense sweep 14.3 us (f32) / 18.9 us (f64))
 };
 template <typename T> int launch_cd(hipStream_t stream, const CdArgs<T> &a);
+// cd_split.hip: the same solver with the chain and the k-wide update on two wavefronts (shared Gram, 64 < k <= 512)
+template <typename T> bool cd_split_applies(const CdArgs<T> &a);
+template <typename T> int launch_cd_split(hipStream_t stream, const CdArgs<T> &a);
 int cd_padded_ld(int k);   // the row stride the vectorised solver wants for k coefficients (k itself when it fits already)
 // Gp[ldg + 16][ldg] (zero-filled once by the caller) <- G[k][k]
 template <typename T> int launch_cd_pad_gram(hipStream_t stream, const T *G, int k, T *Gp, int ldg);
