@@ -288,12 +288,26 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
         // one coordinate: H <- fma(w_new, Q_i, fma(-w_old, Q_i, H)) on this wave's entries, then the next request
         auto step = [&](T (&row)[KU], T dn, T dold, const T *nextp) {
             if constexpr ((diag & 16) == 0) {
+                // every result is pinned where it is computed: left alone, the compiler sinks the whole chain of
+                // updates to its first use (the block's end) and keeps every row and pair live until then: hundreds of
+                // spills.  f32 pairs go through v_pk_fma_f32 (half the issue slots of this wave's busiest loop).
+                if constexpr (sizeof(T) == 4 && KU % 2 == 0) {
+                    typedef float f2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int r = 0; r < KU; ++r) {
-                    H[r] = fma(dn, row[r], fma(-dold, row[r], H[r]));
-                    // pinned where it is computed: left alone, the compiler sinks the whole chain of updates to its
-                    // first use (the block's end) and keeps every row and pair live until then: hundreds of spills
-                    asm volatile("" : "+v"(H[r]));
+                    for (int r = 0; r < KU; r += 2) {
+                        f2v h = {H[r], H[r + 1]};
+                        const f2v q2 = {row[r], row[r + 1]}, mo = {-dold, -dold}, pn2 = {dn, dn};
+                        h = __builtin_elementwise_fma(pn2, q2, __builtin_elementwise_fma(mo, q2, h));
+                        asm volatile("" : "+v"(h));
+                        H[r] = h[0];
+                        H[r + 1] = h[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < KU; ++r) {
+                        H[r] = fma(dn, row[r], fma(-dold, row[r], H[r]));
+                        asm volatile("" : "+v"(H[r]));
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -301,30 +315,25 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
             __builtin_amdgcn_sched_barrier(0);
         };
         // One chunk of 8 coordinates starting at coordinate c8 of the block (ring slots s0 ..): the chain wave publishes
-        // in eights.  The waits are assembly blocks, the ring slots static: straight-line code.  (`fine`: the chunk
-        // arrives as 4 + 1 + 1 + 1 + 1.  Publishing a block's last coordinates one by one was measured SLOWER: every
+        // in eights, the last eight of a block as 4 + 4 (`halves`).  The waits are assembly blocks, the ring slots
+        // static: straight-line code.  (Publishing a block's last coordinates one by one was measured SLOWER: every
         // single coordinate costs this wave two LDS round trips - counter, then pair - ~300 cycles against the 62 the
-        // chain needs for it; the block's H was out 1500 cycles after the chain's last coordinate instead of ~650.)
-        auto chunk = [&](auto S0, int cbase, int c8, int fine, auto &&next_of) {
+        // chain needs for it; the block's H was out 1500 cycles after the chain's last coordinate instead of 1200.)
+        auto chunk = [&](auto S0, int cbase, int c8, int halves, auto &&next_of) {
             constexpr int s0 = decltype(S0)::value;
             T pn[8], po[8];
-            ready = spin_until(ready, s_cnt, cbase + c8 + (fine ? 4 : 8));
+            ready = spin_until(ready, s_cnt, cbase + c8 + (halves ? 4 : 8));
 #pragma unroll
             for (int i = 0; i < 4; ++i) SplitPair<T>::load(pairs + (c8 + i) * PW, pn[i], po[i]);
-            if (!fine) {
-#pragma unroll
-                for (int i = 4; i < 8; ++i) SplitPair<T>::load(pairs + (c8 + i) * PW, pn[i], po[i]);
-            }
             static_for<4>([&](auto I) {
                 constexpr int i = decltype(I)::value;
                 step(ring[s0 + i], pn[i], po[i], next_of(s0 + i));
             });
+            ready = spin_until(ready, s_cnt, cbase + c8 + 8);
+#pragma unroll
+            for (int i = 4; i < 8; ++i) SplitPair<T>::load(pairs + (c8 + i) * PW, pn[i], po[i]);
             static_for<4>([&](auto I) {
                 constexpr int i = 4 + decltype(I)::value;
-                if (fine) {
-                    ready = spin_until(ready, s_cnt, cbase + c8 + i + 1);
-                    SplitPair<T>::load(pairs + (c8 + i) * PW, pn[i], po[i]);
-                }
                 step(ring[s0 + i], pn[i], po[i], next_of(s0 + i));
             });
         };
@@ -352,7 +361,19 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                         if constexpr (c8 == 32) { if (uh == 0) MODL_STAMP(512); }
                         // (the slot of coordinate c of the sweep is c % R; it is refilled with row (c + R) mod K)
                         auto row_after = [&](int c) { return mine + (int64_t)((c + R) % K) * K; };
-                        {
+                        if constexpr (c8 == 56) {                                // the block's last chunk comes as 4 + 4
+                            static_for<2>([&](auto HH) {
+                                constexpr int h4 = decltype(HH)::value * 4;
+                                T pn[4], po[4];
+                                ready = spin_until(ready, s_cnt, base + c8 + h4 + 4);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) SplitPair<T>::load(pairs + (c8 + h4 + i) * PW, pn[i], po[i]);
+                                static_for<4>([&](auto I) {
+                                    constexpr int i = decltype(I)::value;
+                                    step(ring[(cs + h4 + i) % R], pn[i], po[i], row_after(cs + h4 + i));
+                                });
+                            });
+                        } else {
                             T pn[8], po[8];
                             ready = spin_until(ready, s_cnt, base + c8 + 8);
 #pragma unroll
@@ -376,7 +397,7 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                 if (__builtin_amdgcn_readfirstlane(ready) == kStop) asm volatile("s_endpgm");
                 for (int h = 0; h < len; h += 32) {
                     if (uh == 0) MODL_STAMP(512);
-                    const int fine = 0;                                  // (see below: single coordinates cost more than they save)
+                    const int fine = (h + 32 >= len) ? 1 : 0;           // the block's last chunk comes as 4 + 4
                     static_for<32 / R>([&](auto GG) {
                         constexpr int gg = decltype(GG)::value;
                         const T *next = mine + (int64_t)nrow * K;
@@ -483,6 +504,16 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                     Hb = fma(dn, qd[i], tH);                                   // :375-378
                     w[bI] = write_lane<L>(w[bI], dn);
                     if constexpr (g < 7) doldn[i] = bcast_lane(wob, (g + 1) * 8 + i);   // (off the chain: fills its gaps)
+                    // the block's last eight are published as 4 + 4: the update waves then have four coordinates left
+                    // when the chain needs the next block's H
+                    if constexpr ((g == 7 || (!FULL && g == 3)) && i == 3) {
+                        if (!(diag & 4) && (g == 7 || (!FULL && len == 32))) {
+                            SplitPair<T>::store(pairs + lane * PW, w[bI], wob);
+                            asm volatile("" ::: "memory");
+                            *prog = base + L + 1;
+                            asm volatile("" ::: "memory");
+                        }
+                    }
                 });
                 if (!(diag & 4)) {                               // publish: every 8 coordinates
                     SplitPair<T>::store(pairs + lane * PW, w[bI], wob);

@@ -252,3 +252,37 @@ def test_ridge_wide_systems_vs_oracle(fast, oracle, dt, k):
     fast._enet_regression_multi_gram(Gm.copy(), Dx[:3].copy(), X[:3], c1, i3, 0.0, alpha, False, 1e-2, 100)
     oracle.enet_regression_multi_gram(Gm.copy(), Dx[:3].copy(), X[:3], c2, i3, 0.0, alpha, False, 1e-2, 100)
     assert rel_fro(c1, c2) < tol, (k, rel_fro(c1, c2))
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+@pytest.mark.parametrize('k,b,p,alpha', [(256, 48, 600, 0.3), (200, 33, 400, 0.2), (128, 40, 300, 0.3), (100, 17, 200, 0.3),
+                                         (512, 12, 700, 0.3), (330, 9, 600, 0.3), (256, 24, 12, 0.05), (250, 30, 64, 0.1)])
+def test_cd_two_solvers_are_bit_identical(fast, dt, k, b, p, alpha):
+    """The four-wavefront solver (csrc/cd_split.hip: chain / update waves / tile loader, shared Gram, 64 < k <= 512)
+    performs, on every entry of H, the operations of the one-wavefront solver (csrc/cd_solver.hip) in the same order:
+    codes and sweep counts must be IDENTICAL bit for bit - full and padded k, both stopping rules, positivity, a
+    singular Gram matrix running into max_iter.  (modl_debug_set(MODL_DEBUG_CD_SPLIT, 0) forces the one-wavefront
+    solver; every other test of this file runs whichever the library picks, i.e. the new one where it applies.)"""
+    from modl_amd._lib import lib, check, DEBUG_CD_SPLIT
+    rs = np.random.RandomState(k + b)
+    D = rs.randn(k, p).astype(dt)
+    D /= np.sqrt((D ** 2).sum(1))[:, None]
+    X = np.ascontiguousarray(((rs.randn(b, k) * (rs.rand(b, k) < 0.1)).dot(D) + 0.1 * rs.randn(b, p)).astype(dt))
+    G = np.ascontiguousarray(D.dot(D.T).astype(dt))
+    G = (G + G.T) / 2
+    Dx = np.ascontiguousarray(X.dot(D.T).astype(dt))
+    idx = rs.permutation(b + 5)[:b].astype(np.int64)
+    for l1, pos, mi in ((1.0, False, 100), (0.7, True, 30)):
+        out = {}
+        try:
+            for split in (0, 1):
+                check(lib.modl_debug_set(DEBUG_CD_SPLIT, split))
+                code = np.ones((b + 5, k), dtype=dt)
+                sw = np.zeros(b, dtype=np.int32)
+                fast._enet_regression_single_gram(G, Dx.copy(), X, code, idx, l1, alpha, pos, 1e-2, mi, sweeps=sw)
+                out[split] = (code, sw)
+        finally:
+            check(lib.modl_debug_set(DEBUG_CD_SPLIT, 1))
+        np.testing.assert_array_equal(out[0][1], out[1][1])
+        np.testing.assert_array_equal(out[0][0], out[1][0])
+        assert out[0][1].max() > 1
