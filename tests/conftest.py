@@ -56,3 +56,14 @@ def headline_observables(D, C, B, comp_norm):
 def subset_checksum(subset):
     s = np.asarray(subset).astype(np.int64)
     return int(np.sum(s * np.arange(1, len(s) + 1)))
+
+
+def assert_within_f32_noise(got32, ref32, ref64, what=''):
+    """The f32 parity rule of this suite: float summation order is unpinned, so an f32 result is held to
+    the REFERENCE ALGORITHM'S OWN f32 noise on the same input - `ref32` (the reference / the pinned oracle in f32)
+    against `ref64` (the same in f64) - not to a flat tolerance: err(got32, ref64) <= 2 noise + 1e-5."""
+    ref64 = np.asarray(ref64, dtype=np.float64)
+    noise = rel_fro(np.asarray(ref32, dtype=np.float64), ref64)
+    err = rel_fro(np.asarray(got32, dtype=np.float64), ref64)
+    assert err <= 2 * noise + 1e-5, (what, err, noise)
+    return err, noise

@@ -161,7 +161,8 @@ def test_fmri_loop_oracle_vs_reference_golden(name):
     from oracle import wrappers_oracle
     kw, recs, dict_init, want, dn = _fmri_golden_case(name)
     D, _ = wrappers_oracle.fmri_fit(recs, dict_init=dict_init, **kw)
-    assert rel_fro(D, want) < (1e-9 if dn == 'f64' else 2e-4), name
+    # (f32: the oracle reproduces the reference's f32 maps bit for bit on this BLAS; 1e-6 leaves room for another one)
+    assert rel_fro(D, want) < (1e-9 if dn == 'f64' else 1e-6), name
 
 
 @pytest.mark.parametrize('name', [n for n in _fmri_golden_names() if n.endswith('f64')])
@@ -184,14 +185,28 @@ def test_fmri_loop_gpu_vs_reference_golden(name):
         # fixture bit for bit) - the f64 twin of this case is held to 1e-9 above
         assert np.all(np.isfinite(got)) and all(np.sum(c < 0) <= np.sum(c > 0) for c in got)
         return
-    if dn == 'f32':
+    if dn == 'f64':
+        assert rel_fro(got, want) < 1e-9, name
+        return
+    # f32: float summation order is unpinned, so the yardstick is the reference's OWN f32 noise - its f32
+    # maps (the fixture) against the f64 run of the same rows (the oracle, which is pinned to the reference) - not a
+    # flat tolerance: err(GPU f32, f64) <= 2 noise + 1e-5, as tests/test_gpu_step.py does for the trajectories.
+    from oracle import wrappers_oracle
+    D64, _ = wrappers_oracle.fmri_fit([r.astype(np.float64) for r in recs], dict_init=dict_init.astype(np.float64), **kw)
+
+    def upto_flip(maps):
         # _flip (fmri.py:549-556) turns a map over when it has more negative than positive entries: on sparse f32
-        # maps that count can tie up to rounding, so f32 maps are compared up to that sign (f64 exactly)
-        for comp, ref in zip(got, want):
-            assert np.sum(comp < 0) <= np.sum(comp > 0)
+        # maps that count can tie up to rounding, so f32 maps are compared up to that sign
+        out = np.array(maps, dtype=np.float64)
+        for comp, ref in zip(out, D64):
             if np.linalg.norm(comp + ref) < np.linalg.norm(comp - ref):
                 comp *= -1
-    assert rel_fro(got, want) < (1e-9 if dn == 'f64' else 2e-4), name
+        return out
+    for comp in got:
+        assert np.sum(comp < 0) <= np.sum(comp > 0)
+    noise = rel_fro(upto_flip(want), D64)
+    err = rel_fro(upto_flip(got), D64)
+    assert err <= 2 * noise + 1e-5, (name, err, noise)
 
 
 def _check_fmri_case(kw, host, with_init=True):
@@ -409,12 +424,7 @@ def test_config2_image_shape_parity(channels):
         assert int(a.dict_fact_._backend.last_sweeps().max()) == 100
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-8), (np.float32, 5e-4)])
-def test_config3_fmri_shape_parity(dtype, tol):
-    """C3: fMRIDictFact on 2 records x 176 rows x p = 60 000 voxels, n_components = 70, reduction 12, b = 20, ridge
-    codes + l1 atoms (fmri.py:481-495; f32 is the config's dtype): s = 5000 sampled features -> the atom groups of
-    csrc/bcd.hip (four atoms per launch, register-resident projections)."""
+def _config3_records(dtype):
     rs = np.random.RandomState(0)
     k, p = 70, 60000
     maps = np.zeros((k, p))
@@ -428,12 +438,33 @@ def test_config3_fmri_shape_parity(dtype, tol):
         recs.append(np.ascontiguousarray(R.astype(dtype)))
     init = (maps + rs.randn(k, p)).astype(dtype)
     kw = dict(method='masked', n_components=k, reduction=12, batch_size=20, alpha=1e-3, learning_rate=0.92,
-              dict_init=init, random_state=0, n_epochs=1)
-    a = _fmri_estimator(False)(**kw).fit(recs)
-    b = _fmri_estimator(True)(**kw).fit(recs)
-    eD = rel_fro(a.dict_fact_.components_, b.dict_fact_.components_)
-    eC = rel_fro(a.dict_fact_.code_, b.dict_fact_.code_)
-    assert eD < tol and eC < tol, (eD, eC)
+              random_state=0, n_epochs=1)
+    return recs, init, kw
+
+
+@pytest.mark.gpu
+def test_config3_fmri_shape_parity():
+    """C3: fMRIDictFact on 2 records x 176 rows x p = 60 000 voxels, n_components = 70, reduction 12, b = 20, ridge
+    codes + l1 atoms (fmri.py:481-495; f32 is the config's dtype): s = 5000 sampled features -> the atom groups of
+    csrc/bcd.hip (four atoms per launch, register-resident projections).  f64 against the same loop driven with the
+    oracle's kernels: <= 1e-8.  f32 (on the same float32 rows) is held to the REFERENCE ALGORITHM'S OWN f32 noise -
+    the oracle's f32 run against its f64 run of those rows - not to a flat tolerance:
+    err(GPU f32, f64) <= 2 noise + 1e-5 on dictionary and codes."""
+    recs32, init32, kw = _config3_records(np.float32)
+    recs64 = [r.astype(np.float64) for r in recs32]
+    init64 = init32.astype(np.float64)
+    ref64 = _fmri_estimator(True)(dict_init=init64, **kw).fit(recs64)        # oracle kernels, f64
+    gpu64 = _fmri_estimator(False)(dict_init=init64, **kw).fit(recs64)
+    eD = rel_fro(gpu64.dict_fact_.components_, ref64.dict_fact_.components_)
+    eC = rel_fro(gpu64.dict_fact_.code_, ref64.dict_fact_.code_)
+    assert eD < 1e-8 and eC < 1e-8, (eD, eC)
+    ref32 = _fmri_estimator(True)(dict_init=init32, **kw).fit(recs32)        # oracle kernels, f32: the yardstick
+    gpu32 = _fmri_estimator(False)(dict_init=init32, **kw).fit(recs32)
+    for what, get in (('dictionary', lambda e: e.dict_fact_.components_), ('codes', lambda e: e.dict_fact_.code_)):
+        want = get(ref64)
+        noise = rel_fro(get(ref32).astype(np.float64), want)
+        err = rel_fro(get(gpu32).astype(np.float64), want)
+        assert err <= 2 * noise + 1e-5, (what, err, noise)
 
 
 @pytest.mark.gpu
