@@ -33,12 +33,7 @@ public:
 
     uint32_t next() {
         if (pos_ >= kN) refill();
-        uint32_t y = key_[pos_++];
-        y ^= y >> 11;
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= y >> 18;
-        return y;
+        return out_[pos_++];
     }
 
     // uniform integer in [0, hi] by masked rejection; hi == 0 consumes nothing
@@ -65,15 +60,37 @@ public:
     }
 
     uint32_t key_[kN];
-    int32_t pos_ = kN;
+    int32_t pos_ = kN;              // outputs of the current block of 624 consumed so far (kN: none left)
+
+    // after the state (key_, pos_) has been set from outside (pickling): the tempered outputs of the current block
+    void restore() { temper(); }
 
 private:
+    uint32_t out_[kN];              // tempered outputs of the current block (a pure function of key_)
+
+    static uint32_t twist(uint32_t hi, uint32_t lo, uint32_t far) {
+        const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+        return far ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+    }
+    // The state update in three branch-free runs (no modulo in the index: the loops vectorise - the distance to
+    // the element a run depends on is 227 or more) and the tempering of the whole block at once: the subset draw
+    // is a shuffle of all p feature indices per minibatch, i.e. p outputs (2.7 -> 1.x ms at p = 200 000).
     void refill() {
-        for (int i = 0; i < kN; ++i) {
-            const uint32_t y = (key_[i] & 0x80000000u) | (key_[(i + 1) % kN] & 0x7fffffffu);
-            key_[i] = key_[(i + kM) % kN] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        }
+        for (int i = 0; i < kN - kM; ++i) key_[i] = twist(key_[i], key_[i + 1], key_[i + kM]);
+        for (int i = kN - kM; i < kN - 1; ++i) key_[i] = twist(key_[i], key_[i + 1], key_[i + kM - kN]);
+        key_[kN - 1] = twist(key_[kN - 1], key_[0], key_[kM - 1]);
+        temper();
         pos_ = 0;
+    }
+    void temper() {
+        for (int i = 0; i < kN; ++i) {
+            uint32_t y = key_[i];
+            y ^= y >> 11;
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= y >> 18;
+            out_[i] = y;
+        }
     }
 };
 
@@ -219,12 +236,28 @@ struct RandomStream {
         }
         uint32_t mask = static_cast<uint32_t>(n - 1);
         for (int sh = 1; sh < 32; sh <<= 1) mask |= mask >> sh;
-        for (int64_t i = n - 1; i > 0; --i) {
-            const uint32_t hi = static_cast<uint32_t>(i);
-            while ((mask >> 1) >= hi) mask >>= 1;
-            uint32_t v;
-            do v = gen.next() & mask; while (v > hi);
-            std::swap(x[i], x[v]);
+        // Targets are drawn in runs of up to kRun swaps, then applied (same draws, same swaps, same order: a target
+        // does not depend on the array).  The draw loop has NO data-dependent branch: the rejection test of the masked
+        // draw (randomkit.c:268-276) accepts with a probability between 1/2 and 1 that no predictor can follow - every
+        // output is stored, and the cursor and the bound only move when it was accepted (2.7 -> 1.x ms per draw at
+        // p = 200 000, where the subset draw is what the host spends per minibatch).
+        constexpr int kRun = 256;
+        uint32_t tgt[kRun + 1];
+        int64_t i = n - 1;
+        while (i > 0) {
+            const int run = static_cast<int>(i < kRun ? i : kRun);
+            uint32_t hi = static_cast<uint32_t>(i);
+            int cnt = 0;
+            while (cnt < run) {
+                while ((mask >> 1) >= hi) mask >>= 1;                 // (changes log2(n) times in all)
+                const uint32_t v = gen.next() & mask;
+                const uint32_t ok = v <= hi ? 1u : 0u;
+                tgt[cnt] = v;
+                cnt += static_cast<int>(ok);
+                hi -= ok;
+            }
+            for (int j = 0; j < run; ++j) std::swap(x[i - j], x[tgt[j]]);
+            i -= run;
         }
     }
     template <typename E>
@@ -417,6 +450,7 @@ int modl_sampler_set_state(modl_sampler *s, const void *h_buf, size_t bytes) {
     s->fs.rand_size_ = hd.rand_size != 0; s->fs.replacement_ = hd.replacement != 0;
     s->fs.rs_.gen.pos_ = hd.pos;
     std::memcpy(s->fs.rs_.gen.key_, hd.key, sizeof(hd.key));
+    s->fs.rs_.gen.restore();
     s->fs.rs_.bc = hd.bc;
     const int64_t *box = reinterpret_cast<const int64_t *>(static_cast<const char *>(h_buf) + sizeof(hd));
     for (int64_t i = 0; i < s->fs.range_; ++i) s->fs.box_[static_cast<size_t>(i)] = static_cast<int32_t>(box[i]);

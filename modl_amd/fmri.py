@@ -203,6 +203,70 @@ class fMRIDictFact(BaseEstimator):
         return np.sum(scores * lens) / np.sum(lens)
 
 
+class fMRICoder(BaseEstimator):
+    """Loadings / objective of raw records on a FIXED set of maps: the reference's fMRICoder (fmri.py:371-402 over
+    fMRICoderMixin.fit / score / transform, :76-164) on masked 2-D records (arrays or .npy paths, the MultiRawMasker
+    contract of input_data/fmri/unmask.py:37-55) - the masking arguments are dropped as for fMRIDictFact, the rest of
+    the constructor is the reference's.  `dictionary`: (n_components, n_voxels) array, or a .npy path."""
+
+    _coder_class = Coder
+
+    def __init__(self, dictionary, alpha=0.1, transform_batch_size=None, n_components=None, n_jobs=1, verbose=0):
+        self.dictionary = dictionary
+        self.alpha = alpha
+        self.transform_batch_size = transform_batch_size
+        self.n_components = n_components
+        self.n_jobs = n_jobs
+        self.verbose = verbose
+
+    def fit(self, records=None, y=None):
+        """fmri.py:76-93: the maps are `dictionary` (its first n_components rows, _check_dict_init :405-420); nothing is
+        learned.  Returns self (the reference's mixin returns None: a slip, sklearn's contract kept here)."""
+        D = np.asarray(_load(self.dictionary))
+        if D.ndim != 2:
+            raise ValueError('dictionary must be (n_components, n_voxels), got shape %s' % (D.shape,))
+        if self.n_components is not None:
+            D = D[:self.n_components]
+        if D.dtype not in (np.float32, np.float64):
+            D = D.astype(np.float64)
+        self.components_ = np.ascontiguousarray(D)
+        self.coder_ = self._coder_class(dictionary=self.components_, code_alpha=self.alpha, code_l1_ratio=0).fit()
+        return self
+
+    def _records(self, records):
+        if isinstance(records, str) or (isinstance(records, np.ndarray) and records.ndim == 2):
+            records = [records]                                      # one record (fmri.py:117, :150)
+        return records
+
+    def _rows(self, record):
+        X = np.asarray(_load(record))
+        if X.shape[1] != self.components_.shape[1]:
+            raise ValueError('record has %d voxels, the maps have %d' % (X.shape[1], self.components_.shape[1]))
+        return np.ascontiguousarray(X, dtype=self.components_.dtype)
+
+    def transform(self, records):
+        """Loadings of each record, one (n_samples, n_components) array per record (fmri.py:131-164).  A record is
+        coded in slices of transform_batch_size rows when that is set (the codes of a row do not depend on the others)."""
+        if not hasattr(self, 'coder_'):
+            raise ValueError('fMRICoder is not fitted: call fit() first')
+        out = []
+        for rec in self._records(records):
+            X = self._rows(rec)
+            step = self.transform_batch_size or X.shape[0] or 1
+            parts = [self.coder_.transform(X[a:a + step]) for a in range(0, X.shape[0], step)]
+            out.append(np.concatenate(parts) if parts else np.zeros((0, self.components_.shape[0]), dtype=X.dtype))
+        return out
+
+    def score(self, records):
+        """Length-weighted mean of the objective over the records (fmri.py:95-129); lower is a better fit."""
+        if not hasattr(self, 'coder_'):
+            raise ValueError('fMRICoder is not fitted: call fit() first')
+        arrays = [self._rows(r) for r in self._records(records)]
+        scores = np.array([self.coder_.score(a) for a in arrays])
+        lens = np.array([a.shape[0] for a in arrays])
+        return float(np.sum(scores * lens) / np.sum(lens))
+
+
 class rfMRIDictionaryScorer:
     """Callback computing the test objective along a fit (fmri.py:588-633), on raw 2-D test records.
 

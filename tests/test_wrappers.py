@@ -494,3 +494,36 @@ def test_config4_recsys_shape_parity():
     eD, eC = rel_fro(est.components_, fit['D']), rel_fro(est.code_, fit['code'])
     assert eD < 1e-8 and eC < 1e-8, (eD, eC)
     assert rel_fro(est.predict(X).data, wo.recsys_predict(fit, X, True)) < 1e-8
+
+
+@pytest.mark.gpu
+def test_fmri_coder_on_raw_records(tmp_path):
+    """fMRICoder (fmri.py:371-402): fixed maps, loadings and objective of raw records - ridge codes (code_l1_ratio = 0,
+    fmri.py:89-92), so the loadings have a closed form: (D D^T + alpha I)^-1 D x.  A record given as an array and as a
+    .npy path, coded whole and in slices of transform_batch_size rows; the score is the length-weighted mean of the
+    objective (fmri.py:120-129)."""
+    from modl_amd.fmri import fMRICoder
+    rs = np.random.RandomState(3)
+    k, p, alpha = 6, 500, 0.3
+    D = rs.randn(k + 2, p)
+    recs = [rs.randn(n, p) for n in (37, 20, 5)]
+    path = str(tmp_path / 'rec1.npy')
+    np.save(path, recs[1])
+    coder = fMRICoder(D, alpha=alpha, n_components=k).fit()
+    assert coder.components_.shape == (k, p)
+    Dk = D[:k]
+    want = [np.linalg.solve(Dk.dot(Dk.T) + alpha * np.eye(k), Dk.dot(X.T)).T for X in recs]
+    got = coder.transform([recs[0], path, recs[2]])
+    for g_, w_ in zip(got, want):
+        assert g_.shape == w_.shape and rel_fro(g_, w_) < 1e-9
+    sliced = fMRICoder(D, alpha=alpha, n_components=k, transform_batch_size=8).fit().transform(recs)
+    for a, b in zip(sliced, got):
+        assert rel_fro(a, b) < 1e-12                                  # (rows are coded independently)
+    assert rel_fro(coder.transform(recs[0])[0], want[0]) < 1e-9      # a single record, not in a list
+    obj = [(0.5 * np.sum((X - c.dot(Dk)) ** 2) + alpha * 0.5 * np.sum(c ** 2)) / X.shape[0] for X, c in zip(recs, want)]
+    lens = np.array([X.shape[0] for X in recs])
+    assert abs(coder.score(recs) - np.sum(np.array(obj) * lens) / lens.sum()) < 1e-9 * abs(obj[0])
+    with pytest.raises(ValueError):
+        coder.transform([rs.randn(4, p + 1)])
+    # f32 maps stay f32
+    assert fMRICoder(D.astype(np.float32), alpha=alpha).fit().transform(recs[2].astype(np.float32))[0].dtype == np.float32
