@@ -620,6 +620,88 @@ def test_two_rank_gpu_headline_shape(oracle, dtype_name, r):
     assert_array_equal(out[0]['D_head'], out[1]['D_head'])
 
 
+def _gpu_rank_main_c5(rank, world, port, kw, dtype_name, seeds, nrows, p, out):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from modl_amd import DictFact as DF
+        from tests.conftest import m1_rows
+        dt = np.dtype(dtype_name)
+        X0 = m1_rows(max(nrows[0], kw['n_components']), p, seed=seeds[0]).astype(dt)
+        X = X0[:nrows[0]] if rank == 0 else m1_rows(nrows[rank], p, seed=seeds[rank]).astype(dt)
+        est = DF(**kw)
+        est.prepare(n_samples=X.shape[0], X=X0)
+        est.partial_fit(X)
+        D = est.components_
+        out[rank] = dict(D_head=D[:, :256].copy(), D_tail=D[:, -256:].copy(), D_sum=float(D.astype(np.float64).sum()),
+                         D_sq=float((D.astype(np.float64) ** 2).sum()), D_bytes=D.tobytes()[:1 << 16],
+                         C=est.C_, B_head=est.local_B_[:, :64].copy(), n_iter=est.n_iter_)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('dtype_name,k,ragged', [('float32', 256, False), ('float64', 64, False), ('float64', 64, True)])
+def test_two_rank_gpu_c5_shape(oracle, dtype_name, k, ragged):
+    """World size 2 at BASELINE config 5's per-GPU shape (p = 200 000 features, reduction 12: s ~ 16 700 sampled
+    features, the 17 MB head [C_r | sampled rows of B_r] summed over gloo, the wide statistics launch, 96-feature
+    workgroups in the dictionary update), 64 rows per rank, two minibatches - the second one ragged in the third
+    case (40 + 25 rows: weighed with the true global batch size).  R ranks == one rank with the concatenated
+    minibatches: f64 (k = 64) <= 1e-10; f32 (k = 256) within the reference algorithm's own f32 noise (the oracle in
+    f32 against the oracle in f64 on the same rows); replicas bit-identical."""
+    import socket
+    import torch.multiprocessing as mp
+    from .conftest import m1_rows, HEADLINE_KW, assert_within_f32_noise
+    b, p = 64, 200000
+    nrows = (b + 40, b + 25) if ragged else (2 * b, 2 * b)
+    kw = dict(HEADLINE_KW, n_components=k, batch_size=b, reduction=12)
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    seeds = (1234, 4321)
+    mp.spawn(_gpu_rank_main_c5, args=(2, port, kw, dtype_name, seeds, nrows, p, out), nprocs=2, join=True)
+    dt = np.dtype(dtype_name)
+    X0 = m1_rows(max(nrows[0], k), p, seed=seeds[0])
+    X1 = m1_rows(nrows[1], p, seed=seeds[1])
+    parts = [(X0[:b], X1[:b]), (X0[b:nrows[0]], X1[b:nrows[1]])]
+
+    def one_rank(dtype):
+        pr = oracle.SomfParams(**dict(kw, batch_size=4 * b))            # (one call = one global minibatch)
+        st = oracle.prepare(pr, n_samples=nrows[0] + nrows[1], X=X0.astype(dtype))
+        row = 0
+        for a, c in parts:
+            Xt = np.concatenate([a, c]).astype(dtype)
+            oracle.partial_fit(st, pr, Xt, np.arange(row, row + Xt.shape[0]))
+            row += Xt.shape[0]
+        return st
+    st64 = one_rank(np.float64)
+    st32 = one_rank(np.float32) if dt == np.float32 else None
+    for rk in (0, 1):
+        got = out[rk]
+        assert got['n_iter'] == st64.n_iter == nrows[0] + nrows[1]
+        for name, val, ref in (('D_head', got['D_head'], lambda s_: s_.D[:, :256]), ('D_tail', got['D_tail'], lambda s_: s_.D[:, -256:]),
+                               ('C', got['C'], lambda s_: s_.C)):
+            if dt == np.float64:
+                assert rel_fro(val, ref(st64)) < 1e-10, (rk, name, rel_fro(val, ref(st64)))
+            else:
+                assert_within_f32_noise(val, ref(st32), ref(st64), (rk, name))
+    # the partial sums of B_ (local_B_: no collective) add up to the one-rank statistic
+    B_sum = out[0]['B_head'].astype(np.float64) + out[1]['B_head'].astype(np.float64)
+    if dt == np.float64:
+        assert rel_fro(B_sum, st64.B[:, :64]) < 1e-10
+    else:
+        assert_within_f32_noise(B_sum, st32.B[:, :64], st64.B[:, :64], 'B')
+    for key in ('D_sum', 'D_sq', 'D_bytes'):                    # replicas stay bit-identical
+        assert out[0][key] == out[1][key], key
+    assert_array_equal(out[0]['D_head'], out[1]['D_head'])
+    assert_array_equal(out[0]['D_tail'], out[1]['D_tail'])
+
+
 def test_bench_two_ranks_share_gpu():
     """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), both ranks on the
     only GPU of the box over gloo: the JSON line must come out, with bit-identical replicas."""
