@@ -1,8 +1,8 @@
 #!/bin/bash
 # Regenerates the round's profile artifacts on the GPU box (run through gpurun from the repo root):
-#   bash scripts/make_profiles.sh r02
+#   bash scripts/make_profiles.sh r03
 # writes gpurun_out/<tag>_*; copy what is to be judged into profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 mkdir -p $OUT /tmp/w
@@ -32,4 +32,7 @@ rm -rf /tmp/w/sq; timeout 600 rocprofv3 --kernel-trace --pmc $SQC -d /tmp/w/sq -
 python3 $R/scripts/diag_hcp_shape.py > $OUT/${TAG}_c5_shape_sections.txt 2>&1
 rm -rf /tmp/w/c5; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/w/c5 -o t -- python3 $R/scripts/diag_hcp_shape.py > /tmp/w/c5.log 2>&1
 { tail -8 /tmp/w/c5.log; python3 $R/scripts/prof_summary.py $(find /tmp/w/c5 -name "*.db" | head -1) 0.3; } > $OUT/${TAG}_c5_shape_kernel_trace.txt 2>&1
+ls -la $OUT | grep $TAG
+# BASELINE configs 2-4: GPU throughput, the CPU oracle on a bounded prefix, the dominant section's roofline fraction
+timeout 900 python3 $R/tests/diag/bench_configs_full.py > $OUT/${TAG}_bench_configs.jsonl 2> $OUT/${TAG}_bench_configs.err
 ls -la $OUT | grep $TAG
