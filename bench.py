@@ -40,8 +40,8 @@ sys.path.insert(0, ROOT)
 K_COMP, P_FEAT, BATCH, CHUNK, BLOCK = 256, 10000, 256, 65536, 8192
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = 'r02_pmc_hbm_traffic.json'
-DOM_KERNEL = {'dict_update': 'modl::bcd_block_kernel', 'code_solve': 'modl::cd_kernel', 'stats_gemm': 'modl::gemm_stats_pair_kernel',
+PMC_FILE = 'r03_pmc_hbm_traffic.json'
+DOM_KERNEL = {'dict_update': 'modl::bcd_block_kernel', 'code_solve': 'modl::cd_split_kernel', 'stats_gemm': 'modl::gemm_stats_pair_kernel',
               'code_gemm': 'modl::gemm_dense_pair_kernel<float, false', 'stats_apply': 'modl::stats_apply2_kernel'}
 # the calibration of the CPU port against the real reference, measured in the build container
 # (scripts/calibrate_cpu_baseline.py -> profiles/r02_cpu_calibration.json)

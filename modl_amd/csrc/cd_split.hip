@@ -318,7 +318,12 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
         // in eights, the last eight of a block as 4 + 4 (`halves`).  The waits are assembly blocks, the ring slots
         // static: straight-line code.  (Publishing a block's last coordinates one by one was measured SLOWER: every
         // single coordinate costs this wave two LDS round trips - counter, then pair - ~300 cycles against the 62 the
-        // chain needs for it; the block's H was out 1500 cycles after the chain's last coordinate instead of 1200.)
+        // chain needs for it; the block's H was out 1500 cycles after the chain's last coordinate instead of 1200.
+        // Also measured and NOT kept: a look-ahead - the update waves hand over H after a block's first 40 coordinates
+        // and the chain wave applies the last 24 steps to the next block's entries itself (a strip of rows fetched by
+        // the tile loader; same bits).  The wait only moved: the update waves run ~1100 cycles (18 coordinates) behind,
+        // so their snapshot "after 40" is not there when the chain reaches coordinate 40, and the 24 extra steps cost
+        // the chain as much as the wait they were meant to remove (block 5200 cycles against 4870).)
         auto chunk = [&](auto S0, int cbase, int c8, int halves, auto &&next_of) {
             constexpr int s0 = decltype(S0)::value;
             T pn[8], po[8];
