@@ -40,7 +40,7 @@ extern "C" {
 #define MODL_EINVAL (-1)   /* bad argument */
 #define MODL_ENOMEM (-2)   /* workspace too small / allocation failed */
 #define MODL_ESTATE (-3)   /* object used in the wrong state */
-#define MODL_ENOGPU (-4)   /* no HIP device available */
+#define MODL_ENOGPU (-4)   /* no HIP device available, or not a gfx950-class part (160 KiB of LDS per compute unit) */
 #define MODL_ENORCCL (-5)  /* librccl.so could not be loaded (modl_comm_*) */
 #define MODL_ERCCL (-6)    /* an RCCL call failed */
 

@@ -341,7 +341,7 @@ const char *modl_error_string(int code) {
         case MODL_EINVAL: return "invalid argument";
         case MODL_ENOMEM: return "out of memory / workspace too small";
         case MODL_ESTATE: return "invalid state";
-        case MODL_ENOGPU: return "no HIP device";
+        case MODL_ENOGPU: return "no HIP device (or one with less than 160 KiB of LDS per compute unit)";
         case MODL_ENORCCL: return "librccl.so could not be loaded";
         case MODL_ERCCL: return "RCCL call failed";
         default: return code > 0 ? "HIP runtime error (hipError_t)" : "unknown error";

@@ -225,6 +225,7 @@ struct modl_somf_plan {
     // slot protection without a stream event (a hipEventRecord between two kernels costs ~5 us of bubble, measured):
     // the staging kernel acknowledges a slot by writing its use count into the slot's last 8 bytes (host memory)
     unsigned long long slot_uses[kStageSlots] = {0};
+    hipStream_t slot_stream[kStageSlots] = {nullptr};      // the stream of each slot's last use (its acknowledgement comes from there)
     double wait_ms = 0;                // host time spent waiting for a staging slot (the host is kStageSlots ahead)
     int slot = 0;
     // currently staged batch
@@ -358,7 +359,11 @@ int stage_batch(modl_somf_plan *pl, const modl_somf_batch *bt, hipStream_t st) {
             const auto t0 = std::chrono::steady_clock::now();
             for (long spins = 0; *ack < pl->slot_uses[slot]; ++spins) {
                 if (spins > 64) {
-                    if (hipStreamQuery(st) == hipSuccess && *ack < pl->slot_uses[slot]) return MODL_ESTATE;
+                    // the acknowledgement comes from the stream the slot was LAST USED on - not necessarily the current
+                    // one (a caller that switches streams between minibatches): only if THAT stream has drained and
+                    // the word is still missing is the state broken
+                    hipStream_t last = pl->slot_stream[slot];
+                    if (hipStreamQuery(last) == hipSuccess && *ack < pl->slot_uses[slot]) return MODL_ESTATE;
                     sched_yield();
                 }
             }
@@ -403,6 +408,7 @@ int stage_batch(modl_somf_plan *pl, const modl_somf_batch *bt, hipStream_t st) {
         range(2, pl->po_order, sizeof(int32_t) * (size_t)d.k);
         range(3, pl->po_wsample, bt->h_w_sample ? pl->tsz * (size_t)bt->b : 0);
         const unsigned long long use = ++pl->slot_uses[slot];
+        pl->slot_stream[slot] = st;
         hipLaunchKernelGGL(stage_params_kernel, dim3(1), dim3(1024), 0, st, reinterpret_cast<const uint4 *>(pl->hstage_dev[slot]),
                            reinterpret_cast<uint4 *>(pl->dws + pl->off_params), rg,
                            reinterpret_cast<unsigned long long *>(pl->hstage_dev[slot] + align_up(pl->params_bytes, 16)), use);
@@ -947,6 +953,13 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     *out = nullptr;
     MODL_TRY(validate_desc(desc));
     if (modl_device_count() <= 0) return MODL_ENOGPU;
+    {   // the kernels are sized for gfx950's 160 KiB of LDS per compute unit (chol.hip, bcd.hip, cd_split.hip declare up to
+        // that much): on a part with less they could not launch - refuse here, with a code, instead of failing later
+        int dev = 0, lds = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || lds < 160 * 1024)
+            return MODL_ENOGPU;
+    }
     modl_somf_plan *pl = new (std::nothrow) modl_somf_plan();
     if (!pl) return MODL_ENOMEM;
     pl->d = *desc;
