@@ -87,6 +87,10 @@ int modl_rk_randint(modl_rk *rk, uint64_t high, int64_t *out);/* random_fast.pyx
 int modl_rk_double(modl_rk *rk, double *out);                 /* rk_double, randomkit.c:292 */
 int modl_rk_binomial(modl_rk *rk, int64_t n, double p, int64_t *out); /* random_fast.pyx:146 -> distributions.c:442 */
 int modl_rk_permutation(modl_rk *rk, int64_t n, int64_t *h_out);      /* random_fast.pyx:79 */
+/* raw MT19937 state (key[624], pos), the layout of numpy's legacy RandomState.get_state()[1:3]: a modl_rk loaded with
+ * numpy's state continues numpy's stream (legacy permutation(n) == modl_rk_permutation: dict_fact.py:672) */
+int modl_rk_get_mt_state(const modl_rk *rk, uint32_t *h_key624, int32_t *pos);
+int modl_rk_set_mt_state(modl_rk *rk, const uint32_t *h_key624, int32_t pos);
 int modl_rk_shuffle_i64(modl_rk *rk, int64_t *h_x, int64_t n);        /* random_fast.pyx:87 (1-D) */
 /* random_fast.pyx:127: draws one swap sequence; h_trace[n] receives the
  * permutation, h_swaps[n] the swap targets to replay on other arrays. */
@@ -308,6 +312,23 @@ int modl_somf_plan_update(modl_somf_plan *plan, const modl_somf_desc *desc);
 /* One GPU: the whole minibatch step (codes, C_/B_ update in the epilogues of the increment products, dictionary
  * update).  Asynchronous on `stream`. */
 int modl_somf_step(modl_somf_plan *plan, const modl_somf_state *st, const modl_somf_batch *bt, void *stream);
+
+/* The per-minibatch HOST loop of partial_fit / _single_batch_fit (dict_fact.py:331-337, 495-526) behind the boundary:
+ * n_rows rows of d_X in minibatches of batch_size (the last one may be ragged), for each of them
+ *   subset  = sampler.yield_subset(reduction)                      (:507)
+ *   n_iter += b_global ; w = _batch_weight(n_iter, b_global, learning_rate, 0)   (:510, :515)
+ *   order   = the legacy permutation(k) of `order_rng`               (:672; load it with numpy's state, see
+ *                                                                     modl_rk_set_mt_state, and read the state back)
+ *   modl_somf_step (comm == NULL) or modl_somf_step_dist (comm != NULL)
+ * - the same draws in the same order as the Python loop, so the same bits.  h_sample_idx: n_rows rows of code_ or
+ * NULL (0 .. n_rows-1); h_b_global: rows of each GLOBAL minibatch (several ranks) or NULL (== this rank's).
+ * Plans with *_agg == average need the per-sample weights the caller keeps (sample_n_iter_): MODL_EINVAL - use the
+ * per-minibatch calls.  Asynchronous on `stream` (blocks only on the 8-deep staging ring). */
+struct modl_comm;
+int modl_somf_partial_fit_chunk(modl_somf_plan *plan, const modl_somf_state *st, const void *d_X, int64_t ldx,
+                                int64_t n_rows, int32_t batch_size, const int64_t *h_sample_idx, modl_sampler *sampler,
+                                modl_rk *order_rng, int64_t *n_iter, double learning_rate, double reduction,
+                                const int64_t *h_b_global, struct modl_comm *comm, void *stream);
 
 /* Several GPUs (one process per GPU, the rows of a global minibatch of b_global rows split over the ranks; every
  * rank passes the same subset / order / w).  The recursions C_ <- (1 - w) C_ + (w / b_global) code^T code and

@@ -84,6 +84,8 @@ _sig('modl_rk_randint', C.c_int, _vp, _u64, _P(_i64))
 _sig('modl_rk_double', C.c_int, _vp, _P(_f64))
 _sig('modl_rk_binomial', C.c_int, _vp, _i64, _f64, _P(_i64))
 _sig('modl_rk_permutation', C.c_int, _vp, _i64, _vp)
+_sig('modl_rk_get_mt_state', C.c_int, _vp, _vp, _P(C.c_int32))
+_sig('modl_rk_set_mt_state', C.c_int, _vp, _vp, C.c_int32)
 _sig('modl_rk_shuffle_i64', C.c_int, _vp, _vp, _i64)
 _sig('modl_rk_shuffle_trace', C.c_int, _vp, _i64, _vp, _vp)
 _sig('modl_apply_swaps_rows', C.c_int, _vp, _i64, _sz, _vp)
@@ -133,6 +135,8 @@ _sig('modl_somf_delta_elems', _i64, _P(SomfDesc))
 _sig('modl_somf_code_and_partials', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
 _sig('modl_somf_apply_and_update_dict', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
 _sig('modl_somf_step', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp)
+_sig('modl_somf_partial_fit_chunk', C.c_int, _vp, _P(SomfState), _vp, _i64, _i64, C.c_int32, _vp, _vp, _vp, _P(_i64), _f64,
+     _f64, _vp, _vp, _vp)
 _sig('modl_somf_head_elems', C.c_int, _vp, _P(_i64))
 _sig('modl_comm_unique_id', C.c_int, _vp)
 _sig('modl_comm_create', C.c_int, _vp, C.c_int, C.c_int, _P(_vp))

@@ -367,6 +367,23 @@ int modl_rk_binomial(modl_rk *rk, int64_t n, double p, int64_t *out) {
     *out = rk->rs.binomial(n, p);
     return MODL_OK;
 }
+/* The generator's raw MT19937 state (key[624], pos: outputs of the current block already consumed, 624 = none left) -
+ * the layout of numpy's legacy RandomState.get_state()[1:3].  numpy's legacy permutation(n) is shuffle(arange(n)) with
+ * the same masked-rejection draws as randomkit's (legacy random_interval == rk_interval), so a modl_rk loaded with
+ * numpy's state continues numpy's stream: the atom order of dict_fact.py:672 can be drawn on this side of the ABI. */
+int modl_rk_get_mt_state(const modl_rk *rk, uint32_t *h_key624, int32_t *pos) {
+    if (!rk || !h_key624 || !pos) return MODL_EINVAL;
+    std::memcpy(h_key624, rk->rs.gen.key_, sizeof(uint32_t) * modl::Mt19937::kN);
+    *pos = rk->rs.gen.pos_;
+    return MODL_OK;
+}
+int modl_rk_set_mt_state(modl_rk *rk, const uint32_t *h_key624, int32_t pos) {
+    if (!rk || !h_key624 || pos < 0 || pos > modl::Mt19937::kN) return MODL_EINVAL;
+    std::memcpy(rk->rs.gen.key_, h_key624, sizeof(uint32_t) * modl::Mt19937::kN);
+    rk->rs.gen.pos_ = pos;
+    rk->rs.gen.restore();
+    return MODL_OK;
+}
 int modl_rk_permutation(modl_rk *rk, int64_t n, int64_t *h_out) {
     if (!rk || n < 0 || (n > 0 && !h_out)) return MODL_EINVAL;
     rk->rs.permutation(h_out, n);

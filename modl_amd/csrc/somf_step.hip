@@ -1174,6 +1174,50 @@ int modl_somf_step_dist(modl_somf_plan *pl, const modl_somf_state *st, const mod
                     phase2<double>(pl, st, bt, static_cast<const double *>(pl->own_head), (hipStream_t)stream));
 }
 
+int modl_somf_partial_fit_chunk(modl_somf_plan *pl, const modl_somf_state *st, const void *d_X, int64_t ldx, int64_t n_rows,
+                                int32_t batch_size, const int64_t *h_sample_idx, modl_sampler *sampler, modl_rk *order_rng,
+                                int64_t *n_iter, double learning_rate, double reduction, const int64_t *h_b_global,
+                                modl_comm *comm, void *stream) {
+    if (!pl || !st || !d_X || !sampler || !order_rng || !n_iter || n_rows < 0 || batch_size <= 0) return MODL_EINVAL;
+    const modl_somf_desc &d = pl->d;
+    if (batch_size > d.max_batch || ldx < d.p || !(reduction >= 1.0)) return MODL_EINVAL;
+    if (d.G_agg == MODL_AGG_AVERAGE || d.Dx_agg == MODL_AGG_AVERAGE) return MODL_EINVAL;   // (needs the caller's w_sample)
+    std::vector<int64_t> subset((size_t)std::max<int64_t>(d.p, 1)), order((size_t)d.k);
+    const char *X = static_cast<const char *>(d_X);
+    int64_t t = 0;
+    for (int64_t r0 = 0; r0 < n_rows; r0 += batch_size, ++t) {
+        const int32_t b = (int32_t)std::min<int64_t>(batch_size, n_rows - r0);
+        int64_t s = 0;
+        MODL_TRY(modl_sampler_yield_subset(sampler, reduction, subset.data(), &s));          // dict_fact.py:507
+        const int64_t bg = h_b_global ? h_b_global[t] : (int64_t)b;
+        if (bg < b) return MODL_EINVAL;
+        *n_iter += bg;                                                                      // :510
+        double w = 0;
+        MODL_TRY(modl_batch_weight(*n_iter, bg, learning_rate, 0.0, &w));                   // :515
+        MODL_TRY(modl_rk_permutation(order_rng, d.k, order.data()));                        // :672
+        modl_somf_batch bt;
+        std::memset(&bt, 0, sizeof(bt));
+        bt.d_X = X + (size_t)r0 * (size_t)ldx * pl->tsz;
+        bt.ldx = ldx;
+        bt.b = b;
+        bt.h_sample_idx = h_sample_idx ? h_sample_idx + r0 : nullptr;
+        std::vector<int64_t> idx_local;
+        if (!h_sample_idx) {                       // rows r0 .. r0 + b - 1 of code_ (a later chunk of the same call)
+            idx_local.resize((size_t)b);
+            for (int32_t i = 0; i < b; ++i) idx_local[(size_t)i] = r0 + i;
+            bt.h_sample_idx = idx_local.data();
+        }
+        if (s == d.p) { bt.s = (int32_t)d.p; bt.h_subset = nullptr; }   // every feature: no gather (any order is the same set)
+        else { bt.s = (int32_t)s; bt.h_subset = subset.data(); }
+        bt.h_order = order.data();
+        bt.w = w;
+        bt.reduction = reduction;
+        bt.b_global = bg;
+        MODL_TRY(comm ? modl_somf_step_dist(pl, st, &bt, comm, stream) : modl_somf_step(pl, st, &bt, stream));
+    }
+    return MODL_OK;
+}
+
 int modl_somf_full_gram(modl_somf_plan *pl, const void *d_Dt, void *d_G, void *stream) {
     if (!pl || !d_Dt || !d_G) return MODL_EINVAL;
     DeviceScope dev(pl);

@@ -134,7 +134,7 @@ class HipBackend:
     def release_all(self):
         self.release_plan()
         if getattr(self, '_pid', None) != os.getpid():
-            self.tplan = self.comm = None
+            self.tplan = self.comm = self._order_rk = None
             return
         if getattr(self, 'comm', None):
             lib.modl_comm_destroy(self.comm)
@@ -142,6 +142,9 @@ class HipBackend:
         if getattr(self, 'tplan', None):
             lib.modl_somf_plan_destroy(self.tplan)
             self.tplan = None
+        if getattr(self, '_order_rk', None):
+            lib.modl_rk_destroy(self._order_rk)
+            self._order_rk = None
 
     def __del__(self):
         try:
@@ -279,6 +282,36 @@ class HipBackend:
         bt, keep = self._batch(Xh, batch, idx, subset, order, w_sample, w, reduction, b_global)
         st = self._state()
         check(lib.modl_somf_step(self.plan, C.byref(st), C.byref(bt), stream_ptr(self.device)), 'modl_somf_step')
+
+    def fit_chunk(self, Xh, batch_size, sample_indices, sampler, np_random_state, n_iter, learning_rate, reduction,
+                  b_global=None, comm=None):
+        """A whole chunk of minibatches in ONE call (modl_somf_partial_fit_chunk): subset draws, minibatch weights and
+        atom orders are drawn inside the library - the atom order by a generator that is loaded with numpy's legacy
+        MT19937 state and handed back afterwards, so `np_random_state` continues exactly as if it had drawn them
+        (dict_fact.py:672).  Returns the new n_iter_."""
+        if getattr(self, '_order_rk', None) is None:
+            h = C.c_void_p()
+            check(lib.modl_rk_create(0, C.byref(h)), 'modl_rk_create')
+            self._order_rk = h
+        kind, key, pos, has_gauss, cached = np_random_state.get_state()
+        key = np.ascontiguousarray(key, dtype=np.uint32)
+        check(lib.modl_rk_set_mt_state(self._order_rk, key.ctypes.data_as(C.c_void_p), int(pos)), 'modl_rk_set_mt_state')
+        idx = None if sample_indices is None else np.ascontiguousarray(sample_indices, dtype=np.int64)
+        bg = None if b_global is None else np.ascontiguousarray(b_global, dtype=np.int64)
+        n = C.c_int64(int(n_iter))
+        st = self._state()
+        try:
+            check(lib.modl_somf_partial_fit_chunk(
+                self.plan, C.byref(st), ptr(Xh), Xh.stride(0), Xh.shape[0], int(batch_size),
+                None if idx is None else idx.ctypes.data_as(C.c_void_p), sampler._h, self._order_rk, C.byref(n),
+                float(learning_rate), float(reduction), None if bg is None else bg.ctypes.data_as(C.c_void_p), comm,
+                stream_ptr(self.device)), 'modl_somf_partial_fit_chunk')
+        finally:
+            out = np.empty(624, dtype=np.uint32)
+            p2 = C.c_int32()
+            check(lib.modl_rk_get_mt_state(self._order_rk, out.ctypes.data_as(C.c_void_p), C.byref(p2)))
+            np_random_state.set_state((kind, out, int(p2.value), has_gauss, cached))
+        return int(n.value)
 
     def native_comm(self, dist):
         """An RCCL communicator owned by the library (modl_comm_*): rank 0 draws the unique id, torch.distributed
@@ -711,10 +744,28 @@ class DictFact(CodingMixin, BaseEstimator):
         streamed = not isinstance(X, torch.Tensor) and hasattr(be, 'plan') and n > chunk_rows
         chunks = _HostChunks(be, X, chunk_rows) if streamed else [(0, be.stage_X(X))]
         # (a callback may change `reduction` between two minibatches: then every subset is drawn when it is needed)
-        ahead = len(batches) >= 4 and self.callback is None and not self.verbose
+        chunk_call = self._chunk_call_applies(be, sample_indices)
+        ahead = not chunk_call and len(batches) >= 4 and self.callback is None and not self.verbose
         self._subsets = _SubsetsAhead(self.feature_sampler_, self.reduction, len(batches)) if ahead else None
         t = 0
         try:
+            if chunk_call:
+                # the whole per-minibatch loop in ONE library call per chunk (same draws, same order, same bits)
+                world = self._world()
+                comm = None
+                if world > 1:
+                    import torch.distributed as dist
+                    comm = be.native_comm(dist)
+                for r0, Xh in chunks:
+                    nb = -(-Xh.shape[0] // self.batch_size)
+                    idx = get_sub_slice(sample_indices, slice(r0, r0 + Xh.shape[0]))
+                    self.n_iter_ = be.fit_chunk(Xh, self.batch_size, idx, self.feature_sampler_, self.random_state,
+                                                self.n_iter_, self.learning_rate, self.reduction,
+                                                None if b_global is None else b_global[t:t + nb], comm)
+                    for batch in gen_batches(Xh.shape[0], self.batch_size):      # dict_fact.py:511, per minibatch
+                        self.sample_n_iter_[idx[batch]] += 1
+                    t += nb
+                chunks = ()
             for r0, Xh in chunks:
                 for batch in gen_batches(Xh.shape[0], self.batch_size):
                     whole = slice(r0 + batch.start, r0 + batch.stop)
@@ -729,6 +780,27 @@ class DictFact(CodingMixin, BaseEstimator):
             be.synchronize()
         self.time_ += time.perf_counter() - t0 - self._cb_time
         return self
+
+    # the chunk call draws the subsets on the calling thread: beyond this many features the look-ahead thread of the
+    # Python loop is the better host (the bit-exact shuffle of p indices is ~5 ns per feature: 1 ms at p = 200 000)
+    CHUNK_CALL_MAX_FEATURES = 50000
+
+    def _chunk_call_applies(self, be, sample_indices):
+        """One library call per chunk instead of the Python loop over minibatches: the plain configuration only -
+        no callback / verbose output between minibatches, no per-sample averages (their weights come from
+        sample_n_iter_, which lives here), one rank or the library's own RCCL communicator, the numpy legacy
+        generator as random_state, and the library's sampler (tests wrap it to record the draws)."""
+        if not hasattr(be, 'fit_chunk') or getattr(self, '_python_loop', False):
+            return False
+        if self.callback is not None or self.verbose or getattr(self, '_two_phase', False):
+            return False
+        if self.G_agg == 'average' or self.Dx_agg == 'average' or be.p > self.CHUNK_CALL_MAX_FEATURES:
+            return False
+        if not isinstance(self.random_state, np.random.RandomState) or not isinstance(self.feature_sampler_, Sampler):
+            return False
+        if self._world() > 1 and not getattr(self, '_native_rccl', False):
+            return False
+        return True
 
     def set_params(self, **params):
         """dict_fact.py:339-357: only a switch of G_agg to 'full' is honoured for

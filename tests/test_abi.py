@@ -167,3 +167,31 @@ def test_new_entry_points_validate_arguments_without_gpu(lib):
     assert lib.modl_recsys_plan_create(7, 10, 4, 2, 8, C.byref(h)) == -1                    # bad dtype
     if lib.modl_device_count() == 0:
         assert lib.modl_recsys_plan_create(1, 10, 4, 2, 8, C.byref(h)) == -4                # MODL_ENOGPU
+
+
+def test_rk_continues_numpy_legacy_stream():
+    """modl_rk_set_mt_state / get_mt_state: a modl_rk loaded with numpy's legacy MT19937 state draws numpy's
+    RandomState.permutation(k) bit for bit (legacy shuffle == randomkit's masked-rejection shuffle) and hands back a
+    state from which numpy continues in step - how the atom order of dict_fact.py:672 is drawn behind the ABI."""
+    import ctypes as C
+    from modl_amd._lib import lib, check
+    rs, ref = np.random.RandomState(11), np.random.RandomState(11)
+    rs.randn(5), ref.randn(5)
+    h = C.c_void_p()
+    check(lib.modl_rk_create(0, C.byref(h)))
+    try:
+        for k in (256, 70, 1, 1000):
+            kind, key, pos, hg, cg = rs.get_state()
+            key = np.ascontiguousarray(key, dtype=np.uint32)
+            check(lib.modl_rk_set_mt_state(h, key.ctypes.data_as(C.c_void_p), int(pos)))
+            for _ in range(40):
+                o = np.empty(k, dtype=np.int64)
+                check(lib.modl_rk_permutation(h, k, o.ctypes.data_as(C.c_void_p)))
+                assert np.array_equal(o, ref.permutation(k))
+            k2, p2 = np.empty(624, dtype=np.uint32), C.c_int32()
+            check(lib.modl_rk_get_mt_state(h, k2.ctypes.data_as(C.c_void_p), C.byref(p2)))
+            rs.set_state((kind, k2, int(p2.value), hg, cg))
+            assert rs.randint(1 << 30) == ref.randint(1 << 30)
+        assert lib.modl_rk_set_mt_state(h, k2.ctypes.data_as(C.c_void_p), 625) != 0      # pos out of range
+    finally:
+        lib.modl_rk_destroy(h)

@@ -499,6 +499,33 @@ def test_transform_and_score_golden():
             assert abs(cd.score(X) - g['score_' + key]) < 1e-5 * abs(g['score_' + key])
 
 
+@pytest.mark.parametrize('case', ['masked_r10', 'full_r1', 'ragged'])
+def test_chunk_call_equals_python_loop(DictFact, case):
+    """modl_somf_partial_fit_chunk (the per-minibatch host loop behind the ABI: subset draw, _batch_weight, numpy's
+    legacy permutation(k) restated in the library) against the Python loop of _single_batch_fit: the same draws in the
+    same order, hence the same bits - dictionary, codes, statistics, n_iter_, and the numpy generator left in step."""
+    rs = np.random.RandomState(2)
+    p, k, b = 3000, 64, 48
+    n = 7 * b + (17 if case == 'ragged' else 0)
+    X = ((rs.randn(n, 20) * (rs.rand(n, 20) < 0.3)).dot(rs.randn(20, p)) + 0.1 * rs.randn(n, p)).astype(np.float32)
+    kw = dict(n_components=k, batch_size=b, reduction=10 if case != 'full_r1' else 1, code_alpha=0.5, learning_rate=0.92,
+              random_state=0)
+    if case == 'full_r1':
+        kw.update(G_agg='full', Dx_agg='full')
+    idx = rs.permutation(n + 9)[:n]
+    runs = []
+    for python_loop in (True, False):
+        est = DictFact(**kw)
+        est._python_loop = python_loop
+        est.prepare(n_samples=n + 9, X=X)
+        est.partial_fit(X, idx)
+        est.partial_fit(X[:3 * b])                                   # sample_indices = None: rows 0 .. of code_
+        runs.append((est.components_, est.code_, est.C_, est.B_, est.n_iter_, est.sample_n_iter_.copy(),
+                     est.random_state.randint(1 << 30), est.feature_sampler_.yield_subset(3.0)))
+    for a, c in zip(*runs):
+        assert_array_equal(a, c)
+
+
 def test_pickle_roundtrip(DictFact):
     import pickle
     X, _ = generate_synthetic(n_features=20, n_samples=100, dictionary_rank=4)
