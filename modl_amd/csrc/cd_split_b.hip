@@ -1,0 +1,7 @@
+// instantiations of the four-wavefront coordinate-descent solver (cd_split_impl.hpp; see cd_split.hip)
+#include "cd_split_impl.hpp"
+
+namespace modl {
+template void launch_split_nb<float, 8>(hipStream_t, const CdArgs<float> &);
+template void launch_split_nb<float, 16>(hipStream_t, const CdArgs<float> &);
+}  // namespace modl

@@ -1,0 +1,636 @@
+// Batched elastic-net code solver, shared Gram matrix, 64 < k <= 512: the cyclic coordinate descent of
+//   enet_coordinate_descent_gram (reference: modl/decomposition/dict_fact_fast.pyx:270-427)
+// with the Gauss-Seidel chain taken OFF the k-wide update and every load taken off both.
+//
+// cd_kernel (cd_solver.hip) runs a sample on one wavefront: every coordinate is 5 chain instructions, two
+// v_readlane, four v_pk_fma_f32 (the k-wide H <- H - w_old Q_i + w_new Q_i), a select and a 16-byte row load:
+// 14 instructions, ~110 cycles at one wavefront per SIMD, and the next coordinate cannot start before all of them
+// have issued - although it only needs ONE element of the k-wide update.  Here a sample is a WORKGROUP of four
+// wavefronts, one per SIMD of a compute unit:
+//   * the CHAIN wave owns the coordinates in blocks of 64 (lane l of block b <-> coordinate 64 b + l).  Inside a
+//     block it keeps only the block's 64 entries of H (one register) up to date - what it needs of the Gram matrix is
+//     the block's 64 x 64 diagonal tile, which it reads from LDS - and publishes (w_new, w_old) of the coordinates it
+//     has finished through LDS;
+//   * the UPDATE wave applies the published steps to all k entries of H, in coordinate order, with the SAME two
+//     fused multiply-adds per element as cd_kernel (H <- fma(w_new, Q_i, fma(-w_old, Q_i, H))), a few coordinates
+//     behind the chain, reading the Gram rows from an LDS ring, and hands the next block its 64 entries of H when the
+//     chain reaches a block boundary;
+//   * the ROW loader streams the Gram matrix - read in sweep order it is ONE cyclic, contiguous stream of memory -
+//     into that ring with direct-to-LDS loads (global_load_lds_dwordx4: a wave instruction moves 1 KiB, no VGPRs);
+//   * the TILE loader fetches the diagonal tile of the chain's next block the same way (two buffers).
+// Every entry of H sees the same operations in the same order as in cd_kernel: the iterates, the sweep counts and the
+// solutions are BIT-IDENTICAL to it (hence the reference's sweep order, skip rules and both stopping tests).  The gap
+// test reads w, q and H in cd_kernel's element order (lane l <-> elements KPL l ..) so that its five reductions round
+// identically too.
+//
+// Why four waves (measured with in-kernel stamps, scripts/diag_cd_split_stamps.py, k = 256, f32): a wave at one per
+// SIMD issues an instruction every ~4.5 cycles and a memory instruction costs it 18 (global_load) to 60+ cycles
+// (direct-to-LDS load); the chain wave alone with its own row loads ran at 86 cycles per coordinate (58 arithmetic,
+// 18 loads, 10 publishing), an update wave that also requested its rows at 110.  Counters in LDS are monotonic; data
+// is stored before its counter and the LDS executes a wavefront's operations in order; spins are bounded by the
+// workgroup's own progress (all four waves are resident together).  One sample per workgroup: a minibatch of 256
+// fills the chip's 256 compute units.
+#pragma once
+#include "kernels.hpp"
+#include "cd_common.hpp"
+#include <atomic>
+#include <type_traits>
+
+namespace modl {
+
+
+typedef __attribute__((address_space(3))) volatile int lds_vi32;
+typedef __attribute__((address_space(3))) volatile unsigned long long lds_vu64;
+
+constexpr int kStop = 0x7fffffff;
+extern std::atomic<unsigned long long *> g_cd_stamps;   // diagnostics, cd_split.hip
+extern std::atomic<int> g_cd_split_diag;
+
+template <typename T> struct SplitPair;
+template <> struct SplitPair<float> {
+    static constexpr int words = 1;   // 64-bit LDS words per (w_new, w_old) pair
+    __device__ static __forceinline__ void store(lds_vu64 *p, float wn, float wo) {
+        p[0] = ((unsigned long long)(unsigned int)__float_as_int(wo) << 32) | (unsigned int)__float_as_int(wn);
+    }
+    __device__ static __forceinline__ void load(lds_vu64 *p, float &wn, float &wo) {
+        const unsigned long long v = p[0];
+        wn = __int_as_float((int)(unsigned int)v);
+        wo = __int_as_float((int)(unsigned int)(v >> 32));
+    }
+};
+template <> struct SplitPair<double> {
+    static constexpr int words = 2;
+    __device__ static __forceinline__ void store(lds_vu64 *p, double wn, double wo) {
+        p[0] = (unsigned long long)__double_as_longlong(wn);
+        p[1] = (unsigned long long)__double_as_longlong(wo);
+    }
+    __device__ static __forceinline__ void load(lds_vu64 *p, double &wn, double &wo) {
+        const unsigned long long a = p[0], b = p[1];
+        wn = __longlong_as_double((long long)a);
+        wo = __longlong_as_double((long long)b);
+    }
+};
+
+// old with lane `lane` replaced by the wave-uniform value v (v_writelane_b32: no mask, no select)
+// (the lane is an immediate: one scalar register per VALU instruction on this part)
+template <int LANE> __device__ __forceinline__ int write_lane_b32(int old, int v_uniform) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(v_uniform), "n"(LANE));
+    return old;
+}
+template <int LANE> __device__ __forceinline__ float write_lane(float old, float v_uniform) {
+    return __int_as_float(write_lane_b32<LANE>(__float_as_int(old), __float_as_int(v_uniform)));
+}
+template <int LANE> __device__ __forceinline__ double write_lane(double old, double v_uniform) {
+    const long long vb = __double_as_longlong(v_uniform), ob = __double_as_longlong(old);
+    const int lo = write_lane_b32<LANE>((int)(ob & 0xffffffffll), (int)(vb & 0xffffffffll));
+    const int hi = write_lane_b32<LANE>((int)(ob >> 32), (int)(vb >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Spin until the LDS counter at `p` is >= need; returns the value read (or `cached` if that already suffices).  The
+// loop is ONE assembly block: the compiler sees straight-line code around it, so its s_waitcnt bookkeeping for the
+// row loads in flight stays exact (with a C loop here it waited for ALL outstanding rows at every join: measured).
+__device__ __forceinline__ int spin_until(int cached, const int *p_lds, int need) {
+    const unsigned int addr = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const int *)p_lds;
+    int v = cached, sv;
+    asm volatile(
+        "v_readfirstlane_b32 %1, %0\n\t"
+        "s_cmp_ge_i32 %1, %3\n\t"
+        "s_cbranch_scc1 modl_spin_done%=\n"
+        "modl_spin_loop%=:\n\t"
+        "ds_read_b32 %0, %2\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 %1, %0\n\t"
+        "s_cmp_lt_i32 %1, %3\n\t"
+        "s_cbranch_scc1 modl_spin_loop%=\n"
+        "modl_spin_done%=:"
+        : "+&v"(v), "=&s"(sv) : "v"(addr), "s"(need) : "memory", "scc");
+    return v;
+}
+
+// NB = row stride of the Gram matrix / 64 (the matrix is padded with dead coordinates up to it, cd_padded_ld)
+// FULL: k == 64 NB (every block has its 64 coordinates): the sweep is unrolled without a branch, see the update waves
+template <typename T, int NB, bool POSITIVE, bool FULL, int diag = 0>
+__global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned long long *stamps) {
+    constexpr int K = 64 * NB;                        // row stride of the Gram matrix
+    constexpr int KPL = NB;                           // cd_kernel's layout: element e <-> register e % KPL of lane e / KPL
+    constexpr int PW = SplitPair<T>::words;
+    constexpr unsigned int RBYTES = (unsigned int)(K * sizeof(T));   // bytes of a row: 512 ... 4096
+    constexpr unsigned int TRB = 64 * sizeof(T);      // bytes of a row of a diagonal tile
+    constexpr unsigned int TB = 64 * TRB;             // bytes of a tile: 16 / 32 KiB
+    constexpr int TP = (int)(TB / 1024);              // its pieces
+    __shared__ __attribute__((aligned(16))) unsigned char s_tile[2 * TB];
+    __shared__ unsigned long long s_pair[64 * PW];    // (w_new, w_old) of the chain wave's current block, by lane
+    __shared__ __attribute__((aligned(16))) T s_H[K]; // H after a whole block (cd_kernel's element order = plain order)
+    __shared__ T s_w[K];                              // the chain wave's coefficients, for the gap test
+    __shared__ int s_cnt[8];
+    typedef __attribute__((address_space(3))) volatile T lds_vT;
+    lds_vu64 *pairs = (lds_vu64 *)s_pair;
+    lds_vi32 *prog = (lds_vi32 *)&s_cnt[0];           // chain: 64 * (blocks finished) + coordinates published of the current one
+    lds_vi32 *ver = (lds_vi32 *)&s_cnt[1];            // update waves 0 / 1 (s_cnt[1], [2]): 1 + blocks applied completely
+                                                      // (their halves of the next block's H are in s_H)
+    lds_vi32 *tiles = (lds_vi32 *)&s_cnt[4];          // tile loader: tiles in LDS (tile t serves the chain's block t)
+    lds_vi32 *cblk = (lds_vi32 *)&s_cnt[5];           // chain: blocks finished (their tile buffers are free)
+    lds_vi32 *stopf = (lds_vi32 *)&s_cnt[6];          // chain: the solve is over
+
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;                 // 0 chain, 1 and 2 update (column halves), 3 tile loader
+    const int smp = blockIdx.x;
+    if (smp != 0) stamps = nullptr;
+    int nst = 0;
+#define MODL_STAMP(off) do { if (stamps && lane == 0 && nst < 250) stamps[(off) + nst++] = clock64(); } while (0)
+    const int k = a.k;
+    const int kc = FULL ? K : (k + 31) / 32 * 32;     // coordinates a sweep visits (the padding is dead: inv = 0)
+    const int nblk = FULL ? NB : (kc + 63) / 64;
+    const T *__restrict__ Q = a.G;
+    const int64_t row_out = a.idx ? a.idx[smp] : (int64_t)smp;
+    T *wptr = a.code + row_out * k;
+    const T *qptr = a.Dx + (int64_t)smp * k;
+    const T alpha = a.alpha, beta = a.beta;
+    if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+
+    if (wid == 3) {
+        // ------------------------------------------------------------------ tile loader
+        // tile t = rows and columns 64 b .. 64 b + 63 of the matrix (b = t mod nblk) -> buffer t % 2, row-major, as
+        // soon as the chain has finished block t - 2
+        const unsigned int lds_tile = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_tile;
+        constexpr int RPP = (int)(1024 / TRB);                   // tile rows per piece: 4 (f32), 2 (f64)
+        constexpr int LPR = 64 / RPP;                            // lanes per tile row
+        const unsigned int lane_off = (unsigned int)(lane / LPR) * RBYTES + (unsigned int)(lane % LPR) * 16u;
+        int fin = 0;
+        for (int t = 0;; ++t) {
+            if (t - __builtin_amdgcn_readfirstlane(fin) >= 2) {
+                int st = 0;
+                do {
+                    fin = *cblk;
+                    st = *stopf;
+                    __builtin_amdgcn_s_sleep(2);
+                } while (t - __builtin_amdgcn_readfirstlane(fin) >= 2 && __builtin_amdgcn_readfirstlane(st) == 0);
+                if (__builtin_amdgcn_readfirstlane(st) != 0) break;
+            }
+            const int b = t % nblk;
+            unsigned int voff = lane_off + (unsigned int)(64 * b) * RBYTES + (unsigned int)(64 * b * sizeof(T));
+            unsigned int m0v = lds_tile + (unsigned int)(t & 1) * TB;
+            for (int i = 0; i < TP; ++i) {
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(voff), "s"(Q) : "memory");
+                voff += RPP * RBYTES;
+                m0v += 1024u;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *tiles = t + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    if (wid == 1 || wid == 2) {
+        // ------------------------------------------------------------------ update waves: a column half each
+        constexpr int KU = KPL / 2;                              // elements per lane (NB >= 2)
+        constexpr int R = (KU * (int)sizeof(T) <= 16) ? 32 : 16; // Gram rows in flight (a row comes from L2 in ~600 ns)
+        const int uh = wid - 1;
+        const int e0 = uh * (K / 2) + lane * KU;                 // this lane's elements e0 .. e0 + KU - 1
+        T H[KU], w[KPL];
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {                          // (all of w: H0 = Q w broadcasts every coefficient)
+            const int e = lane * KPL + c;
+            const T wv = wptr[e < k ? e : 0];
+            w[c] = e < k ? wv : (T)0;
+        }
+#pragma unroll
+        for (int c = 0; c < KU; ++c) H[c] = 0;
+        constexpr int V = (KU * sizeof(T) >= 16) ? (int)(16 / sizeof(T)) : KU;   // elements per load
+        typedef T vec_t __attribute__((ext_vector_type(V)));
+        T ring[R][KU];
+        auto request = [&](T (&dst)[KU], const T *p) {
+            if constexpr (V == 1) {
+                dst[0] = *p;
+            } else {
+                const vec_t *rp = reinterpret_cast<const vec_t *>(p);
+#pragma unroll
+                for (int v = 0; v < KU / V; ++v) {
+                    const vec_t x = rp[v];
+#pragma unroll
+                    for (int c = 0; c < V; ++c) dst[v * V + c] = x[c];
+                }
+            }
+        };
+        const T *const mine0 = Q + e0;                // this lane's slice of row 0
+        const T *mine = mine0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) request(ring[j], mine + (int64_t)(j % kc) * K);
+        {
+            int64_t opaque = 0;
+            asm volatile("" : "+s"(opaque));
+            mine = mine0 + opaque;
+        }
+        int nrow = R % kc;                            // the row the next request fetches (rows cycle in sweep order)
+        if (a.H0) {
+            const T *hp = a.H0 + (int64_t)smp * k;
+#pragma unroll
+            for (int c = 0; c < KU; ++c) {
+                const T hv = hp[e0 + c < k ? e0 + c : 0];
+                H[c] = (e0 + c < k) ? hv : (T)0;
+            }
+        } else {
+            // H = Q w as a combination of rows, ascending (cd_kernel's order: same bits).  FULL: no loop - a back edge
+            // with row loads in flight makes the compiler wait for ALL of them (the values live in loop-carried
+            // registers it may have to copy): one full memory round trip per iteration, measured.
+            if constexpr (FULL) {
+                static_for<K>([&](auto JJ) {
+                    constexpr int jj = decltype(JJ)::value;
+                    constexpr int j = jj % R;
+                    const T wj = bcast_lane(w[jj % KPL], jj / KPL);
+#pragma unroll
+                    for (int c2 = 0; c2 < KU; ++c2) {
+                        H[c2] = fma(wj, ring[j][c2], H[c2]);
+                        asm volatile("" : "+v"(H[c2]));          // (pinned: see `step`)
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    request(ring[j], mine + (int64_t)((jj + R) % K) * K);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else {
+                for (int j0 = 0; j0 < kc; j0 += R) {
+                    const T *next = mine + (int64_t)nrow * K;
+                    static_for<R>([&](auto J) {
+                        constexpr int j = decltype(J)::value;
+                        const T wj = bcast_lane(w[j % KPL], (j0 / KPL + j / KPL) & 63);
+#pragma unroll
+                        for (int c2 = 0; c2 < KU; ++c2) H[c2] = fma(wj, ring[j][c2], H[c2]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        request(ring[j], next + (int64_t)j * K);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    nrow += R;
+                    if (nrow >= kc) nrow -= kc;
+                }
+            }
+        }
+        typedef T hvec_t __attribute__((ext_vector_type(KU)));
+        auto publish_H = [&](int version) {
+            if constexpr (KU == 1) {
+                s_H[e0] = H[0];
+            } else {
+                hvec_t hv;
+#pragma unroll
+                for (int c = 0; c < KU; ++c) hv[c] = H[c];
+                *reinterpret_cast<hvec_t *>(&s_H[e0]) = hv;
+            }
+            asm volatile("" ::: "memory");
+            ver[uh] = version;
+        };
+        publish_H(1);
+        if (uh == 0) MODL_STAMP(512);
+        if constexpr ((diag & 32) != 0) return;
+        int ready = 0;                                // cached value of the chain wave's counter
+        // one coordinate: H <- fma(w_new, Q_i, fma(-w_old, Q_i, H)) on this wave's entries, then the next request
+        auto step = [&](T (&row)[KU], T dn, T dold, const T *nextp) {
+            if constexpr ((diag & 16) == 0) {
+                // every result is pinned where it is computed: left alone, the compiler sinks the whole chain of
+                // updates to its first use (the block's end) and keeps every row and pair live until then: hundreds of
+                // spills.  f32 pairs go through v_pk_fma_f32 (half the issue slots of this wave's busiest loop).
+                if constexpr (sizeof(T) == 4 && KU % 2 == 0) {
+                    typedef float f2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int r = 0; r < KU; r += 2) {
+                        f2v h = {H[r], H[r + 1]};
+                        const f2v q2 = {row[r], row[r + 1]}, mo = {-dold, -dold}, pn2 = {dn, dn};
+                        h = __builtin_elementwise_fma(pn2, q2, __builtin_elementwise_fma(mo, q2, h));
+                        asm volatile("" : "+v"(h));
+                        H[r] = h[0];
+                        H[r + 1] = h[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < KU; ++r) {
+                        H[r] = fma(dn, row[r], fma(-dold, row[r], H[r]));
+                        asm volatile("" : "+v"(H[r]));
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            request(row, nextp);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // One chunk of 8 coordinates starting at coordinate c8 of the block (ring slots s0 ..): the chain wave publishes
+        // in eights, the last eight of a block as 4 + 4 (`halves`).  The waits are assembly blocks, the ring slots
+        // static: straight-line code.  (Publishing a block's last coordinates one by one was measured SLOWER: every
+        // single coordinate costs this wave two LDS round trips - counter, then pair - ~300 cycles against the 62 the
+        // chain needs for it; the block's H was out 1500 cycles after the chain's last coordinate instead of 1200.
+        // Also measured and NOT kept: a look-ahead - the update waves hand over H after a block's first 40 coordinates
+        // and the chain wave applies the last 24 steps to the next block's entries itself (a strip of rows fetched by
+        // the tile loader; same bits).  The wait only moved: the update waves run ~1100 cycles (18 coordinates) behind,
+        // so their snapshot "after 40" is not there when the chain reaches coordinate 40, and the 24 extra steps cost
+        // the chain as much as the wait they were meant to remove (block 5200 cycles against 4870).)
+        auto chunk = [&](auto S0, int cbase, int c8, int halves, auto &&next_of) {
+            constexpr int s0 = decltype(S0)::value;
+            T pn[8], po[8];
+            ready = spin_until(ready, s_cnt, cbase + c8 + (halves ? 4 : 8));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) SplitPair<T>::load(pairs + (c8 + i) * PW, pn[i], po[i]);
+            static_for<4>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                step(ring[s0 + i], pn[i], po[i], next_of(s0 + i));
+            });
+            ready = spin_until(ready, s_cnt, cbase + c8 + 8);
+#pragma unroll
+            for (int i = 4; i < 8; ++i) SplitPair<T>::load(pairs + (c8 + i) * PW, pn[i], po[i]);
+            static_for<4>([&](auto I) {
+                constexpr int i = 4 + decltype(I)::value;
+                step(ring[s0 + i], pn[i], po[i], next_of(s0 + i));
+            });
+        };
+        if constexpr (FULL) {
+            // the whole sweep unrolled (NB blocks of 8 chunks): the only back edge is the sweep's
+            for (int sw = 0;; ++sw) {
+                // (an opaque pointer per sweep: the matrix is read-only and every sweep reads the same addresses - left
+                // alone, the compiler hoists the loads out of the loop and keeps the whole slice in registers: spills)
+                {
+                    int64_t opaque = 0;                          // (an offset, not the pointer: that would turn the
+                    asm volatile("" : "+s"(opaque));             //  loads into flat ones, which also count as LDS traffic)
+                    mine = mine0 + opaque;
+                }
+                static_for<NB>([&](auto BB) {
+                    constexpr int bb = decltype(BB)::value;
+                    const int t = sw * NB + bb, base = 64 * t;
+                    // the first coordinates of a block that never comes: the chain wave has ended the solve.  (The
+                    // wave ends inside the assembly block: no join for the compiler; loads in flight die with it.)
+                    ready = spin_until(ready, s_cnt, base + 8);
+                    if (__builtin_amdgcn_readfirstlane(ready) == kStop) asm volatile("s_endpgm");
+                    if (uh == 0) MODL_STAMP(512);
+                    static_for<8>([&](auto CC) {
+                        constexpr int c8 = decltype(CC)::value * 8;
+                        constexpr int cs = bb * 64 + c8;                         // coordinate of the sweep
+                        if constexpr (c8 == 32) { if (uh == 0) MODL_STAMP(512); }
+                        // (the slot of coordinate c of the sweep is c % R; it is refilled with row (c + R) mod K)
+                        auto row_after = [&](int c) { return mine + (int64_t)((c + R) % K) * K; };
+                        if constexpr (c8 == 56) {                                // the block's last chunk comes as 4 + 4
+                            static_for<2>([&](auto HH) {
+                                constexpr int h4 = decltype(HH)::value * 4;
+                                T pn[4], po[4];
+                                ready = spin_until(ready, s_cnt, base + c8 + h4 + 4);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) SplitPair<T>::load(pairs + (c8 + h4 + i) * PW, pn[i], po[i]);
+                                static_for<4>([&](auto I) {
+                                    constexpr int i = decltype(I)::value;
+                                    step(ring[(cs + h4 + i) % R], pn[i], po[i], row_after(cs + h4 + i));
+                                });
+                            });
+                        } else {
+                            T pn[8], po[8];
+                            ready = spin_until(ready, s_cnt, base + c8 + 8);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) SplitPair<T>::load(pairs + (c8 + i) * PW, pn[i], po[i]);
+                            static_for<8>([&](auto I) {
+                                constexpr int i = decltype(I)::value;
+                                step(ring[(cs + i) % R], pn[i], po[i], row_after(cs + i));
+                            });
+                        }
+                    });
+                    publish_H(t + 2);
+                    if (uh == 0) MODL_STAMP(512);
+                });
+            }
+        } else {
+            for (int t = 0;; ++t) {                   // blocks, across sweeps
+                const int bsw = t % nblk;
+                const int len = (bsw == nblk - 1) ? kc - 64 * (nblk - 1) : 64;
+                const int base = 64 * t;
+                ready = spin_until(ready, s_cnt, base + 8);
+                if (__builtin_amdgcn_readfirstlane(ready) == kStop) asm volatile("s_endpgm");
+                for (int h = 0; h < len; h += 32) {
+                    if (uh == 0) MODL_STAMP(512);
+                    const int fine = (h + 32 >= len) ? 1 : 0;           // the block's last chunk comes as 4 + 4
+                    static_for<32 / R>([&](auto GG) {
+                        constexpr int gg = decltype(GG)::value;
+                        const T *next = mine + (int64_t)nrow * K;
+                        auto next_of = [&](int slot) { return next + (int64_t)slot * K; };
+                        static_for<R / 8>([&](auto CC) {
+                            constexpr int cc = decltype(CC)::value;
+                            chunk(std::integral_constant<int, cc * 8>{}, base, h + gg * R + cc * 8,
+                                  (gg * R + cc * 8 == 24) ? fine : 0, next_of);
+                        });
+                        nrow += R;
+                        if (nrow >= kc) nrow -= kc;
+                    });
+                }
+                publish_H(t + 2);
+                if (uh == 0) MODL_STAMP(512);
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------------- chain wave
+    // coordinate 64 b + lane in register b; the same vectors once more in cd_kernel's element order for the gap test
+    T w[NB], q[NB], inv[NB], wfix[NB];
+    T qe[KPL];
+#pragma unroll
+    for (int bI = 0; bI < NB; ++bI) {
+        const int e = 64 * bI + lane;
+        const bool in = e < k;
+        const int ec = in ? e : 0;
+        const T wv = wptr[ec], qv = qptr[ec], dv = Q[(int64_t)ec * K + ec];
+        q[bI] = in ? qv : (T)0;
+        const T dg = in ? dv : (T)0;
+        inv[bI] = (dg != (T)0) ? (T)1 / (dg + beta) : (T)0;   // reciprocal of the step denominator (:373); 0 = skipped (:357)
+        const bool lv = inv[bI] != (T)0;
+        const T w_in = in ? wv : (T)0;
+        wfix[bI] = lv ? (T)0 : w_in;                            // a skipped coordinate keeps its value here ...
+        w[bI] = lv ? w_in : (T)0;                               // ... and carries 0 in the sweeps
+    }
+#pragma unroll
+    for (int c = 0; c < KPL; ++c) {
+        const int e = lane * KPL + c;
+        const T qv = qptr[e < k ? e : 0];
+        qe[c] = e < k ? qv : (T)0;
+    }
+    const T y_norm2 = a.xnorm2[smp];
+    const T tol_abs = a.tol * y_norm2;             // :336
+    const T d_w_tol = a.tol;
+
+    int tblk = 0;                                   // blocks started, across sweeps
+    int n_iter = 0;
+    int have_tiles = 0;
+    T Hb;                                           // H of the current block's coordinates
+    {
+        // (counter, then data, in one round trip; the data is good if the counter it followed was)
+        lds_vT *sH = (lds_vT *)s_H;
+        int v0 = ver[0], v1 = ver[1];
+        Hb = sH[lane];
+        while (!(diag & 1) && (__builtin_amdgcn_readfirstlane(v0) < 1 || __builtin_amdgcn_readfirstlane(v1) < 1)) {
+            v0 = ver[0]; v1 = ver[1];
+            Hb = sH[lane];
+        }
+    }
+    bool done = false;
+    for (; n_iter < a.max_iter && !done; ++n_iter) {
+        T w0[NB];
+#pragma unroll
+        for (int bI = 0; bI < NB; ++bI) w0[bI] = w[bI];
+        static_for<NB>([&](auto BI) {
+            constexpr int bI = decltype(BI)::value;
+            if constexpr (!FULL) { if (bI >= nblk) return; }
+            const int len = FULL ? 64 : ((bI == nblk - 1) ? kc - 64 * bI : 64);
+            const T wob = w[bI];                    // the block's coefficients before the sweep touches them
+            if (__builtin_amdgcn_readfirstlane(have_tiles) <= tblk) {        // the block's diagonal tile is in LDS
+                do { have_tiles = *tiles; } while (__builtin_amdgcn_readfirstlane(have_tiles) <= tblk);   // (the tile loader never stops first)
+            }
+            MODL_STAMP(0);
+            const int base = 64 * tblk;
+            // row L of the tile, this lane's column: Q[64 b + L][64 b + lane]
+            lds_vT *tile = (lds_vT *)(s_tile + (unsigned int)(tblk & 1) * TB) + lane;
+            // groups of 8 coordinates, everything unrolled (the lane of a coordinate is an immediate); the slices of
+            // the tile and the broadcasts of w_old for the NEXT group are requested before the current one starts
+            T qd[8], qn[8], dolds[8], doldn[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                qd[i] = tile[i * 64];
+                dolds[i] = bcast_lane(wob, i);
+            }
+            static_for<8>([&](auto GG) {
+                constexpr int g = decltype(GG)::value;
+                if constexpr (!FULL) { if (g >= 4 && len == 32) return; }   // (a sweep of 64 m + 32 coordinates: short last block)
+                if constexpr (g < 7) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) qn[i] = tile[((g + 1) * 8 + i) * 64];
+                }
+                static_for<8>([&](auto II) {
+                    constexpr int i = decltype(II)::value;
+                    constexpr int L = g * 8 + i;                 // lane of the coordinate
+                    // t = fma(-w_old, Q_i, H) on the block's entries is at once the first half of their update
+                    // (:361-365) and, in lane L (whose slice element is the diagonal), the H[ii] of the formula
+                    const T tH = fma(-dolds[i], qd[i], Hb);
+                    const T tmp = q[bI] - tH;                                  // :367
+                    const T cl = POSITIVE ? (tmp < alpha ? tmp : alpha) : clamp3(tmp, -alpha, alpha);   // as cd_coordinate
+                    const T xv = (tmp - cl) * inv[bI];
+                    const T dn = bcast_lane(xv, L);
+                    Hb = fma(dn, qd[i], tH);                                   // :375-378
+                    w[bI] = write_lane<L>(w[bI], dn);
+                    if constexpr (g < 7) doldn[i] = bcast_lane(wob, (g + 1) * 8 + i);   // (off the chain: fills its gaps)
+                    // the block's last eight are published as 4 + 4: the update waves then have four coordinates left
+                    // when the chain needs the next block's H
+                    if constexpr ((g == 7 || (!FULL && g == 3)) && i == 3) {
+                        if (!(diag & 4) && (g == 7 || (!FULL && len == 32))) {
+                            SplitPair<T>::store(pairs + lane * PW, w[bI], wob);
+                            asm volatile("" ::: "memory");
+                            *prog = base + L + 1;
+                            asm volatile("" ::: "memory");
+                        }
+                    }
+                });
+                if (!(diag & 4)) {                               // publish: every 8 coordinates
+                    SplitPair<T>::store(pairs + lane * PW, w[bI], wob);
+                    asm volatile("" ::: "memory");
+                    *prog = base + g * 8 + 8;
+                    asm volatile("" ::: "memory");
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { qd[i] = qn[i]; dolds[i] = doldn[i]; }
+            });
+            ++tblk;
+            *cblk = tblk;
+            MODL_STAMP(0);
+            // the next block's entries of H (the first block's, after the sweep's last one), complete
+            const int nb_off = (bI + 1 < nblk) ? 64 * (bI + 1) : 0;
+            lds_vT *sH = (lds_vT *)s_H;
+            int v0 = ver[0], v1 = ver[1];
+            Hb = sH[nb_off + lane];
+            while (!(diag & 1) && (__builtin_amdgcn_readfirstlane(v0) < tblk + 1 || __builtin_amdgcn_readfirstlane(v1) < tblk + 1)) {
+                v0 = ver[0]; v1 = ver[1];
+                Hb = sH[nb_off + lane];
+            }
+            asm volatile("" ::: "memory");          // (the gap test below reads s_H with plain loads)
+        });
+        T dmx = 0, wmx = 0;                        // skipped coordinates do not count (:357): their w is 0 here
+#pragma unroll
+        for (int bI = 0; bI < NB; ++bI) {
+            const T d = fabs(w[bI] - w0[bI]), aw = fabs(w[bI]);
+            dmx = d > dmx ? d : dmx;
+            wmx = aw > wmx ? aw : wmx;
+        }
+        const T d_w_max = wave_max(dmx), w_max = wave_max(wmx);
+        if (w_max == (T)0 || d_w_max / w_max < d_w_tol || n_iter == a.max_iter - 1) {   // :388
+            // cd_kernel's element order (lane l <-> elements KPL l ..): the reductions round as they do there
+#pragma unroll
+            for (int bI = 0; bI < NB; ++bI) s_w[64 * bI + lane] = w[bI] + wfix[bI];     // one of the two is zero
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            T s_qw = 0, s_wH = 0, s_ww = 0, s_l1 = 0;
+            T xmax = POSITIVE ? -INFINITY : (T)0;
+            const int e0 = lane * KPL;
+#pragma unroll
+            for (int c = 0; c < KPL; ++c) {
+                const T wt = s_w[e0 + c], Hc = s_H[e0 + c];
+                s_qw += wt * qe[c];
+                s_wH += wt * Hc;
+                s_ww += wt * wt;
+                s_l1 += fabs(wt);
+                if (e0 + c < k) {
+                    const T x = (qe[c] - Hc) - beta * wt;                             // :397
+                    const T mx = POSITIVE ? x : fabs(x);
+                    xmax = mx > xmax ? mx : xmax;
+                }
+            }
+            const T q_dot_w = wave_sum(s_qw);
+            const T wH = wave_sum(s_wH);
+            const T w_norm2 = wave_sum(s_ww);
+            const T l1 = wave_sum(s_l1);
+            const T dual = wave_max(xmax);
+            const double R_norm2 = (double)(y_norm2 + wH) - 2.0 * (double)q_dot_w;      // :404
+            double cst;
+            T gap;
+            if (dual > alpha) {
+                cst = (double)(alpha / dual);
+                gap = (T)(0.5 * (R_norm2 + R_norm2 * cst * cst));
+            } else {
+                cst = 1.0;
+                gap = (T)R_norm2;
+            }
+            gap = (T)((double)gap + (((double)(alpha * l1) - cst * (double)y_norm2) + cst * (double)q_dot_w +
+                                     ((0.5 * (double)beta) * (1.0 + cst * cst)) * (double)w_norm2));   // :421-423
+            if (gap < tol_abs) done = true;                                           // :425
+        }
+    }
+    *stopf = 1;                                     // the loaders leave ...
+    asm volatile("" ::: "memory");
+    *prog = kStop;                                  // ... and the update wave
+    T *w2 = a.code2 ? a.code2 + (a.idx2 ? a.idx2[smp] : (int64_t)smp) * k : nullptr;
+#pragma unroll
+    for (int bI = 0; bI < NB; ++bI) {
+        const int e = 64 * bI + lane;
+        if (e < k) {
+            wptr[e] = w[bI] + wfix[bI];
+            if (w2) w2[e] = w[bI] + wfix[bI];
+        }
+    }
+    if (a.sweeps && lane == 0) a.sweeps[smp] = n_iter;
+}
+
+template <typename T, int NB>
+void launch_split_nb(hipStream_t stream, const CdArgs<T> &a) {
+    dim3 grid((unsigned)a.b), block(256);
+    unsigned long long *st = g_cd_stamps.load();
+    if constexpr (std::is_same<T, float>::value && NB == 4) {        // timing experiments (wrong results), f32 k = 256 only
+        switch (g_cd_split_diag.load()) {
+#define MODL_DIAG_CASE(D) case D: if (a.k == 64 * NB) { hipLaunchKernelGGL((cd_split_kernel<T, NB, false, true, D>), grid, block, 0, stream, a, st); return; } break;
+            MODL_DIAG_CASE(33) MODL_DIAG_CASE(37) MODL_DIAG_CASE(1) MODL_DIAG_CASE(17)
+#undef MODL_DIAG_CASE
+            default: break;
+        }
+    }
+    const bool full = a.k == 64 * NB;
+#define MODL_SPLIT_LAUNCH(POS, FULL) hipLaunchKernelGGL((cd_split_kernel<T, NB, POS, FULL>), grid, block, 0, stream, a, st)
+    if (full) { if (a.positive) MODL_SPLIT_LAUNCH(true, true); else MODL_SPLIT_LAUNCH(false, true); }
+    else { if (a.positive) MODL_SPLIT_LAUNCH(true, false); else MODL_SPLIT_LAUNCH(false, false); }
+#undef MODL_SPLIT_LAUNCH
+}
+
+
+// (the kernels are large - a whole sweep unrolled - and are instantiated in four translation units that compile side
+// by side: cd_split.hip f32 k <= 256, cd_split_b.hip f32 k <= 1024, cd_split_c.hip f64 k <= 512, cd_split_d.hip f64 k <= 1024)
+#define MODL_SPLIT_EXTERN(T, NB) extern template void launch_split_nb<T, NB>(hipStream_t, const CdArgs<T> &)
+MODL_SPLIT_EXTERN(float, 2); MODL_SPLIT_EXTERN(float, 4); MODL_SPLIT_EXTERN(float, 8); MODL_SPLIT_EXTERN(float, 16);
+MODL_SPLIT_EXTERN(double, 2); MODL_SPLIT_EXTERN(double, 4); MODL_SPLIT_EXTERN(double, 8); MODL_SPLIT_EXTERN(double, 16);
+#undef MODL_SPLIT_EXTERN
+
+}  // namespace modl

@@ -52,7 +52,7 @@ if __name__ == '__main__':
     for dt in (np.float32, np.float64):
         for (k, b, p, alpha) in ((256, 256, 1000, 0.3), (256, 64, 300, 0.3), (200, 33, 400, 0.2), (128, 40, 300, 0.3),
                                  (100, 17, 200, 0.3), (512, 24, 700, 0.3), (330, 9, 600, 0.3), (256, 40, 12, 0.05),
-                                 (250, 100, 64, 0.1)):
+                                 (250, 100, 64, 0.1), (1024, 12, 1200, 0.3), (600, 7, 900, 0.3)):
             ok &= case(dt, k, b, p, alpha)
             ok &= case(dt, k, b, p, alpha, pos=True, l1=0.7)
     print('ALL IDENTICAL' if ok else 'MISMATCH')

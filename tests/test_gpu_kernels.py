@@ -275,9 +275,10 @@ def test_ridge_wide_systems_vs_oracle(fast, oracle, dt, k):
 
 @pytest.mark.parametrize('dt', [np.float32, np.float64])
 @pytest.mark.parametrize('k,b,p,alpha', [(256, 48, 600, 0.3), (200, 33, 400, 0.2), (128, 40, 300, 0.3), (100, 17, 200, 0.3),
-                                         (512, 12, 700, 0.3), (330, 9, 600, 0.3), (256, 24, 12, 0.05), (250, 30, 64, 0.1)])
+                                         (512, 12, 700, 0.3), (330, 9, 600, 0.3), (256, 24, 12, 0.05), (250, 30, 64, 0.1),
+                                         (1024, 6, 1100, 0.3), (600, 5, 800, 0.3)])
 def test_cd_two_solvers_are_bit_identical(fast, dt, k, b, p, alpha):
-    """The four-wavefront solver (csrc/cd_split.hip: chain / update waves / tile loader, shared Gram, 64 < k <= 512)
+    """The four-wavefront solver (csrc/cd_split_impl.hpp: chain / update waves / tile loader, shared Gram, 64 < k <= 1024)
     performs, on every entry of H, the operations of the one-wavefront solver (csrc/cd_solver.hip) in the same order:
     codes and sweep counts must be IDENTICAL bit for bit - full and padded k, both stopping rules, positivity, a
     singular Gram matrix running into max_iter.  (modl_debug_set(MODL_DEBUG_CD_SPLIT, 0) forces the one-wavefront
