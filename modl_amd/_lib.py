@@ -15,6 +15,7 @@ MODL_F32, MODL_F64 = 0, 1
 FLAG_NO_RIDER, FLAG_GEMM_STAMPS = 1, 2          # modl_somf_desc.flags (diagnostics)
 DEBUG_CD_SPARSE_PCT = 1                         # modl_debug_set
 DEBUG_CD_SPLIT = 2
+DEBUG_BCD_ACC = 5
 AGG = {'masked': 0, 'full': 1, 'average': 2}
 OPT = {'variational': 0, 'sgd': 1}
 

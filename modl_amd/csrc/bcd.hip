@@ -36,6 +36,7 @@
 #include "gemm_dense.hpp"
 #include "gemm_wide.hpp"
 #include "kernels.hpp"
+#include <atomic>
 #include <utility>
 #include <type_traits>
 
@@ -45,6 +46,9 @@ namespace modl {
 #define MODL_RT1_MAX 2048
 #endif
 constexpr int kNB = 32;            // atoms per block of the blocked path
+// diagnostics (modl_debug_set(MODL_DEBUG_BCD_ACC, 0)): the per-workgroup Gram records instead of the atomic accumulator
+std::atomic<int> g_bcd_acc{1};
+constexpr int kAccWords = 3 * (2 * 136 + 256 + kNB);   // int64 words of one Gram accumulator (3 bins x packed record: kAccStride below)
 constexpr int kGramRows = 128;     // feature rows per Gram slab
 #ifndef MODL_KGROUP
 #define MODL_KGROUP 16
@@ -149,7 +153,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_t *order, int k, int kp, T *CPP, T *cdiag,
                                                         int32_t *frozen, double *coef_all, unsigned int *counter,
                                                         const T *comp_norm, T *norm_in, const T *Dt, const T *Bt,
-                                                        const int32_t *subset, int64_t s, T *DsP, T *BsP) {
+                                                        const int32_t *subset, int64_t s, T *DsP, T *BsP, long long *acc) {
     // kp = k rounded up to a multiple of 4: the packed arrays carry kp - k dead atoms (zero columns, frozen), so that the
     // 16-byte fragments of the block kernel exist for every number of atoms
     int id = (int)blockIdx.x;
@@ -157,6 +161,7 @@ __global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_
         const int m = id;
         if (m == 0) {
             if (threadIdx.x < kCounters) counter[threadIdx.x] = 0;
+            if (acc) for (int e = threadIdx.x; e < 3 * kAccWords; e += 256) acc[e] = 0;
             for (int j = threadIdx.x; j < kp; j += 256) {
                 const bool real = j < k;
                 const int oj = real ? order[j] : 0;
@@ -416,6 +421,35 @@ struct SinkGlobal {
     double *dst;
     __device__ __forceinline__ void operator()(int e, double v) const { dst[e] = v; }
 };
+
+// ---- the Gram accumulator: three signed fixed-point bins per entry, units 2^-70, 2^-30 and 2^10 (40 bits each: any
+// double of magnitude below 2^50 is represented to 2^-70 - the entries are Gram products of candidate atoms, O(1) -
+// and 2^22 contributions fit an int64 bin).  value = b2 2^10 + b1 2^-30 + b0 2^-70.
+constexpr int kAccBins = 3;
+constexpr int kAccStride = kAccBins * kPackStride;        // int64 words per accumulator
+static_assert(kAccStride == kAccWords, "accumulator size");
+__device__ __forceinline__ void acc_add(long long *acc, int idx, double v) {
+    const long long b2 = (long long)(v * 0x1p-10);                       // (truncation: the remainders are exact)
+    const double r1 = __builtin_fma(-(double)b2, 0x1p10, v);
+    const long long b1 = (long long)(r1 * 0x1p30);
+    const double r0 = __builtin_fma(-(double)b1, 0x1p-30, r1);
+    const long long b0 = __double2ll_rn(r0 * 0x1p70);
+    unsigned long long *a = reinterpret_cast<unsigned long long *>(acc);
+    if (b2) atomicAdd(a + 2 * kPackStride + idx, (unsigned long long)b2);   // (device scope, no return value)
+    if (b1) atomicAdd(a + 1 * kPackStride + idx, (unsigned long long)b1);
+    if (b0) atomicAdd(a + idx, (unsigned long long)b0);
+}
+// this thread's elements 2 e2, 2 e2 + 1 of the accumulated record -> sink
+template <typename Sink>
+__device__ __forceinline__ void acc_load(const long long *acc, int e2, bool valid, Sink sink) {
+    typedef long long l2v __attribute__((ext_vector_type(2)));
+    const l2v *base = reinterpret_cast<const l2v *>(acc) + (valid ? e2 : 0);
+    const l2v b0 = base[0], b1 = base[kPackStride / 2], b2 = base[kPackStride];   // (three 16-byte loads, one round trip)
+    if (valid) {
+        sink(2 * e2, ((double)b2.x * 0x1p10 + (double)b1.x * 0x1p-30) + (double)b0.x * 0x1p-70);
+        sink(2 * e2 + 1, ((double)b2.y * 0x1p10 + (double)b1.y * 0x1p-30) + (double)b0.y * 0x1p-70);
+    }
+}
 __device__ __forceinline__ void reduce_partials(const double *partial, int nslab, double (*M)[kNB + 1], double *D2) {
     reduce_records<kResStride>(partial, nslab, SinkLds{M, D2});
 }
@@ -827,6 +861,13 @@ struct BcdBlockArgs {
     float *a;                       // [s][NB] the a-tile: block b - 1's on entry, block b's on exit
     double *rec_out, *grec_out;     // Gram records / group sums written by this launch
     const double *rec_in, *grec_in; // ... written by the previous launch
+    // Accumulator mode (acc_in / acc_out non-null; replaces the records): every workgroup ADDS its Gram contribution to ONE
+    // record of fixed-point bins with integer atomics - integer addition is associative, so the sum does not depend on
+    // the order of arrival: deterministic, identical on every GPU - and the next launch reads 13 KB instead of one
+    // 4.5 KB record per workgroup (134 KB at the metric's shape).  Three buffers in rotation: read / add / being cleared.
+    long long *acc_out;
+    const long long *acc_in;
+    long long *acc_zero;
     const double *coef_all;
     const float *norm_in;           // norm budgets as they were before this dictionary update, in sweep order
     float *norm_out;                // comp_norm (written by workgroup 0 only)
@@ -902,6 +943,8 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
     const int nwg = rider.nslab, gsz = p.group, ngroups = (nwg + gsz - 1) / gsz;
     unsigned long long *st = (p.stamps && blockIdx.x == 0 && !fin) ? p.stamps : nullptr;
     if (st && tid == 0) st[0] = clock64();
+    if (p.acc_zero && blockIdx.x == 0)                    // the accumulator the NEXT launch adds to (idle during this one)
+        for (int e = tid; e < kAccStride; e += 384) p.acc_zero[e] = 0;
 
     // ---------------------------------------------------------------- (B) Gram of the previous block
     // First thing in the launch: the recursion is the critical path and only needs these records.
@@ -923,7 +966,8 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
                 const bool ok = p.j0_prev + e / kNB < k;
                 cf[q] = *reinterpret_cast<const d2v *>(p.coef_all + (ok ? (int64_t)p.j0_prev * kNB + e : 0));   // (zeroed below)
             }
-            reduce_records_v2<kPackStride>(recs, nrec, tid, true, rsink);
+            if (p.acc_in) acc_load(p.acc_in, tid, true, rsink);
+            else reduce_records_v2<kPackStride>(recs, nrec, tid, true, rsink);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int e = 2 * (tid + 256 * q);
@@ -941,7 +985,8 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
             const int res_jj_raw = p.order[p.j0_prev + ((x < p.nb_prev) ? x : 0)];   // (unconditional, clamped: no wait behind the load)
             res_jj = (x < p.nb_prev) ? res_jj_raw : 0;
             const float budget_raw = p.norm_in[(x < p.nb_prev) ? p.j0_prev + x : 0];
-            reduce_records_v2<kPackStride>(recs, nrec, 256 + lane, 256 + lane < kPackStride / 2, rsink);
+            if (p.acc_in) acc_load(p.acc_in, 256 + lane, 256 + lane < kPackStride / 2, rsink);
+            else reduce_records_v2<kPackStride>(recs, nrec, 256 + lane, 256 + lane < kPackStride / 2, rsink);
             res_budget = (x < p.nb_prev) ? (double)budget_raw : 0.0;
         } else {
 #pragma unroll
@@ -1274,13 +1319,19 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = (lane >> 4) + 4 * r, col = lane & 15;
-                if (it != jt) out[kTri + row * 16 + col] = g[r];                                   // tile (0,1): full
-                else if (row <= col) out[(it ? kTri + 256 : 0) + tri_index(row, col)] = g[r];        // diagonal tiles: triangle
+                if (p.acc_out) {
+                    if (it != jt) acc_add(p.acc_out, kTri + row * 16 + col, g[r]);
+                    else if (row <= col) acc_add(p.acc_out, (it ? kTri + 256 : 0) + tri_index(row, col), g[r]);
+                } else {
+                    if (it != jt) out[kTri + row * 16 + col] = g[r];                                   // tile (0,1): full
+                    else if (row <= col) out[(it ? kTri + 256 : 0) + tri_index(row, col)] = g[r];        // diagonal tiles: triangle
+                }
             }
         } else if (lane < kNB) {
             double t = 0;
             for (int gq = 0; gq < 8; ++gq) t += d2red[gq * kNB + lane];
-            out[2 * kTri + 256 + lane] = t;
+            if (p.acc_out) acc_add(p.acc_out, 2 * kTri + 256 + lane, t);
+            else out[2 * kTri + 256 + lane] = t;
         }
     }
     if (st && tid == 0) st[12] = clock64();
@@ -1799,6 +1850,9 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         const int GPW = (kp <= 256) ? 8 : 16;
         void (*blk)(BcdBlockArgs, BcdRiderArgs) = nullptr;
         T *DsP = reinterpret_cast<T *>(ws + L.off_Dnew), *BsP = reinterpret_cast<T *>(ws + L.off_BsP), *CPP = CP;
+        // the Gram accumulators of the fused path (three in rotation; in the space of the group sums, which they replace)
+        long long *fused_acc = (fused && g_bcd_acc.load(std::memory_order_relaxed)) ? reinterpret_cast<long long *>(ws + L.off_gpartial) : nullptr;
+        static_assert(sizeof(long long) * 3 * kAccWords <= sizeof(double) * 2 * (size_t)kCounters * (kNB * kNB + kNB), "accumulators fit");
         if (fused) {
             blk = (RT == 1) ? (GPW == 8 ? bcd_block_kernel<1, 8> : bcd_block_kernel<1, 16>)
                             : (RT == 2 ? bcd_block_kernel<2, 8> : bcd_block_kernel<3, 8>);
@@ -1806,7 +1860,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                                          160 * 1024));
             hipLaunchKernelGGL((bcd_setup_kernel<T>), dim3((unsigned)(kNB + kp + s)), dim3(256), 0, stream, a.C, a.order, k, kp, CPP,
                                cdiag, frozen, coef_all, counter, a.comp_norm, reinterpret_cast<T *>(ws + L.off_norm_in), a.Dt,
-                               a.Bt, a.subset, s, DsP, BsP);
+                               a.Bt, a.subset, s, DsP, BsP, fused_acc);
             MODL_LAUNCH_CHECK();
             ++nl;
         } else {
@@ -1819,6 +1873,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         const size_t rec_half = (size_t)L.nslab_max * kResStride, grec_half = (size_t)kCounters * kResStride;   // >= the packed sizes
         double *gpart = reinterpret_cast<double *>(ws + L.off_gpartial);
         BcdBlockArgs base;
+        base.acc_out = nullptr; base.acc_in = nullptr; base.acc_zero = nullptr;
         if (fused) {
             base.Dt = reinterpret_cast<float *>(DsP); base.Bt = reinterpret_cast<const float *>(BsP);
             base.CP = reinterpret_cast<const float *>(CPP); base.cdiag = reinterpret_cast<const float *>(cdiag);
@@ -1893,6 +1948,12 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                 ba.rec_out = partial + (size_t)(blk_i & 1) * rec_half; ba.rec_in = partial + (size_t)((blk_i + 1) & 1) * rec_half;
                 ba.grec_out = gpart + (size_t)(blk_i & 1) * grec_half; ba.grec_in = gpart + (size_t)((blk_i + 1) & 1) * grec_half;
                 ba.j0 = j0; ba.nb = nb; ba.j0_prev = j0_prev; ba.nb_prev = blk_i ? nb_prev : 0;
+                if (fused_acc) {
+                    ba.acc_out = fused_acc + (size_t)(blk_i % 3) * kAccWords;
+                    ba.acc_in = fused_acc + (size_t)((blk_i + 2) % 3) * kAccWords;
+                    ba.acc_zero = fused_acc + (size_t)((blk_i + 1) % 3) * kAccWords;
+                    ba.group = nslab;                                   // (no pre-summed groups: one accumulator)
+                }
                 BcdRiderArgs r = rid;
                 const int extra = blk_i ? ride(r) : 0;                 // (launch 0 is short: no resolver)
                 hipLaunchKernelGGL(blk, dim3(nslab + extra), dim3(384), lds_bytes(extra), stream, ba, r);
@@ -1927,6 +1988,11 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             ba.rec_out = nullptr; ba.grec_out = nullptr;
             ba.rec_in = partial + (size_t)((blk_i + 1) & 1) * rec_half; ba.grec_in = gpart + (size_t)((blk_i + 1) & 1) * grec_half;
             ba.j0 = 0; ba.nb = 0; ba.j0_prev = j0_prev; ba.nb_prev = nb_prev;
+            if (fused_acc) {
+                ba.acc_out = nullptr; ba.acc_zero = nullptr;
+                ba.acc_in = fused_acc + (size_t)((blk_i + 2) % 3) * kAccWords;     // (blk_i: the blocks launched so far)
+                ba.group = nslab;
+            }
             BcdRiderArgs r = rid;
             ride_per = ride_tiles - ride_next;                         // whatever is left
             const int extra = ride(r);

@@ -514,6 +514,7 @@ std::atomic<int> g_cd_sparse_pct{-1};
 std::atomic<int> g_cd_split{1};
 extern std::atomic<unsigned long long *> g_cd_stamps;   // cd_split.hip
 extern std::atomic<int> g_cd_split_diag;
+extern std::atomic<int> g_bcd_acc;                      // bcd.hip
 
 template <typename T>
 int launch_cd(hipStream_t stream, const CdArgs<T> &a0) {
@@ -614,6 +615,10 @@ extern "C" int modl_debug_set(int what, int64_t value) {
     }
     if (what == MODL_DEBUG_CD_STAMPS) {
         modl::g_cd_stamps.store(reinterpret_cast<unsigned long long *>((uintptr_t)value));
+        return MODL_OK;
+    }
+    if (what == MODL_DEBUG_BCD_ACC) {
+        modl::g_bcd_acc.store((int)value, std::memory_order_relaxed);
         return MODL_OK;
     }
     if (what == MODL_DEBUG_CD_SPLIT_DIAG) {
