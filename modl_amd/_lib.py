@@ -16,6 +16,7 @@ FLAG_NO_RIDER, FLAG_GEMM_STAMPS = 1, 2          # modl_somf_desc.flags (diagnost
 DEBUG_CD_SPARSE_PCT = 1                         # modl_debug_set
 DEBUG_CD_SPLIT = 2
 DEBUG_BCD_ACC = 5
+DEBUG_ATOM_STAMPS = 6
 AGG = {'masked': 0, 'full': 1, 'average': 2}
 OPT = {'variational': 0, 'sgd': 1}
 

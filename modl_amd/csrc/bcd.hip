@@ -48,6 +48,9 @@ namespace modl {
 constexpr int kNB = 32;            // atoms per block of the blocked path
 // diagnostics (modl_debug_set(MODL_DEBUG_BCD_ACC, 0)): the per-workgroup Gram records instead of the atomic accumulator
 std::atomic<int> g_bcd_acc{1};
+// diagnostics (modl_debug_set(MODL_DEBUG_ATOM_STAMPS, device pointer to 64 uint64)): cycle sums of the projecting
+// workgroup (atom_project_group_kernel), accumulated over the launches ([0] = launches; layout at the kernel)
+std::atomic<unsigned long long *> g_atom_stamps{nullptr};
 constexpr int kAccWords = 3 * (2 * 136 + 256 + kNB);   // int64 words of one Gram accumulator (3 bins x packed record: kAccStride below)
 constexpr int kGramRows = 128;     // feature rows per Gram slab
 #ifndef MODL_KGROUP
@@ -55,11 +58,16 @@ constexpr int kGramRows = 128;     // feature rows per Gram slab
 #endif
 constexpr int kGroup = MODL_KGROUP;         // minimum workgroups per group of the two-level partial reduction
 constexpr int kCounters = 64;      // arrival counters: [0] final, [1 + g] group g
+constexpr int kAtomGroupMax = 8;   // atoms per launch pair of the grouped atom update (l1 / elastic-net atoms)
 
 struct DuLayout {
     size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, off_BsP, off_gpartial, off_norm_in, total;
     int64_t nslab_max, nwg_grad;
 };
+
+// row stride of the scratch of the grouped atom update: what the projecting workgroup covers with 12 / 20 / 24 elements
+// per thread (s beyond that: the group path is not taken, the stride is never used)
+static int64_t atom_row_stride(int64_t s) { return s <= 12 * 256 ? 12 * 256 : (s <= 20 * 256 ? 20 * 256 : 24 * 256); }
 
 static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     DuLayout L;
@@ -77,7 +85,10 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     L.off_Tp = take(sizeof(double) * 2 * (kNB * kNB + kNB) + 256 + 512);  // two CA records (ping-pong) + arrival counters + debug stamps
     L.off_u = take(tsz * (size_t)s_max);
     L.off_pold = take(sizeof(double) * (size_t)L.nwg_grad);
-    L.off_Dnew = take(tsz * (size_t)(cdiv(s_max > 0 ? s_max : 1, 32) * 32) * k4);  // sgd / the packed dictionary (whole tiles of 32 rows)
+    // sgd / the packed dictionary (whole tiles of 32 rows) / the scratch of a group of kAtomGroupMax atoms of the grouped
+    // atom update (numerators f64, old values, two staged groups)
+    L.off_Dnew = take(std::max(tsz * (size_t)(cdiv(s_max > 0 ? s_max : 1, 32) * 32) * k4,
+                               (size_t)kAtomGroupMax * (size_t)atom_row_stride(s_max > 0 ? s_max : 1) * (sizeof(double) + 3 * tsz) + 64));
     L.off_colp = take(sizeof(double) * (size_t)L.nslab_max * k);
     L.off_BsP = take(tsz * (size_t)s_max * k4);                       // packed B rows (packed D shares off_Dnew)
     L.off_gpartial = take(sizeof(double) * 2 * (size_t)kCounters * (kNB * kNB + kNB));   // group sums (two-level reduction), ping-pong
@@ -1484,199 +1495,438 @@ __global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, cons
     if (dbg && threadIdx.x == 0) { dbg[0] = t0; dbg[1] = t1; dbg[2] = t2; dbg[3] = clock64(); }
 }
 
-// A GROUP of up to kAtomGroup (4) consecutive atoms of the sweep in ONE launch.  Of the 23 us an atom costs with one launch
-// each, the launch boundary, the gradient row and the hand-off to the projecting workgroup are 60 %; they are shared by
-// the group.  Every workgroup evaluates, for its features, the numerators of the candidates of ALL atoms of the group
-// against the dictionary as it is at the start of the launch (one read of the dictionary row serves the group); the
-// last workgroup to arrive then projects the atoms one after the other, the numerator of atom a corrected for what the
-// atoms before it in the group just changed:
-//     num_a[f] -= sum_{a' < a} C[j_a', j_a] (D_new[j_a'][f] - D_old[j_a'][f])
-// which is exactly the difference between the gradient row of the sequential sweep and the stale one (the own term
-// C_jj D_old[j][f] does not depend on the other atoms).  Same update as atom_step_kernel up to the rounding of that
-// double-precision correction.  Needs the vector in the registers of the projecting workgroup (s <= kProjEpt * 256).
-#ifndef MODL_ATOM_GROUP
-#define MODL_ATOM_GROUP 4          /* (tuning) even; 8 spills the f32 kernel (8 inlined projections): 56 us per atom */
-#endif
-constexpr int kAtomGroup = MODL_ATOM_GROUP;
 template <int... As, class F>
 __device__ __forceinline__ void for_each_int(std::integer_sequence<int, As...>, F &&f) {
     (f(std::integral_constant<int, As>{}), ...);
 }
-struct AtomGroup { int j[kAtomGroup]; int n; };
 
-// EPT: elements of the s-vector per thread of the projecting workgroup (s <= 256 EPT; the passes cost EPT selects each,
-// so the smallest that fits is used; elements beyond s are zeros: the sums and their order do not depend on EPT)
-template <typename T, int KPL, int EPT>
-__global__ __launch_bounds__(256) void atom_group_kernel(T *Dt, const T *Bt, const T *C, const int32_t *subset, int64_t s,
-                                                         int k, AtomGroup g, AtomGroup gp, const T *stage_in, T *stage_out,
-                                                         int pos, double rho, double *num, T *dold,
-                                                         double *partial_old, T *comp_norm, unsigned int *counter,
-                                                         double *level_hint) {
-    // The projected atoms leave the lone projecting workgroup as COMPACT rows (stage_out[a][feature], coalesced): written
-    // straight into the dictionary they were 20 scattered 4-byte stores per thread and atom, one cache line per lane -
-    // 10 of the 55 us of a group at the fMRI shape (measured).  The many workgroups of the NEXT launch put them where
-    // they belong while they read their dictionary rows anyway (gp, stage_in: the previous group of this sweep);
-    // atom_stage_flush_kernel does it for the last group.
-    __shared__ double red[32];
-    __shared__ int flag;
+// ---- The grouped atom update (l1 / elastic-net atoms, s <= 24 * 256 sampled features): a GROUP of up to eight consecutive
+// atoms of the sweep per pair of launches.  Of the 23 us an atom costs with one launch each (atom_step_kernel), the
+// launch boundary, the gradient row and the hand-off to the projecting workgroup are 60 %; they are shared by the group.
+// First launch: many small workgroups evaluate, for their features, the numerators of the candidates of ALL atoms of
+// the group against the dictionary as it is at the start of the launch (one read of the dictionary row serves the
+// group).  Second launch: ONE workgroup - a projection is a chain of block-wide reductions, which a single compute
+// unit does fastest - projects the atoms one after the other, the numerator of atom a corrected for what the atoms
+// before it in the group just changed:
+//     num_a[f] -= sum_{a' < a} C[j_a', j_a] (D_new[j_a'][f] - D_old[j_a'][f])
+// which is exactly the difference between the gradient row of the sequential sweep and the stale one (the own term
+// C_jj D_old[j][f] does not depend on the other atoms).  Same update as atom_step_kernel up to the rounding of that
+// double-precision correction.  It runs alone on the chip and may use the whole register file of its compute unit (256
+// VGPRs + 256 AGPRs per wavefront): the changes of the group's earlier atoms stay in registers.
+// Round 2 did this in ONE launch per group of four (the last workgroup to arrive projected): the launch boundary costs
+// what the release / ticket / acquire hand-off cost (1.5 against 1.7 us), but the single kernel had to keep the register
+// budget of its many gradient workgroups, so the changes travelled through memory (two dependent round trips per atom
+// for a lone workgroup: 18 k of its 108 k cycles on the fMRI shape) and eight atoms did not fit; fixed cost per group
+// (gradient phase, hand-off, prologue) 33 k cycles.  fMRI shape: 48.8 us per 4 atoms -> 43 us per 8.
+// The projected atoms leave the projecting workgroup as COMPACT rows (stage[a][feature], 16-byte stores): written
+// straight into the dictionary they would be scattered 4-byte stores, one cache line per lane.  The workgroups of the
+// NEXT gradient launch put them where they belong while they read their dictionary rows anyway (gp, stage_in: the
+// previous group of this sweep); atom_stage_flush_group_kernel does it for the last group.
+template <int G> struct AtomGroupN { int j[G]; int n; };
+
+// A wavefront takes kGradRows feature rows (grid = ceil(s / (4 kGradRows)) workgroups: s <= 24 * 256 fits 512) and requests
+// EVERYTHING it needs - the group's columns of C, its rows of the dictionary, the entries of B_, the staged atoms of
+// the previous group - before the first use: one memory round trip per launch instead of one for C and one per row.
+// After the wave-level sums every lane holds them: lane a writes atom a.
+constexpr int kGradRows = 3;
+template <typename T, int KPL, int G>
+__global__ __launch_bounds__(256) void atom_grad_group_kernel(T *Dt, const T *Bt, const T *C, const int32_t *subset, int64_t s,
+                                                              int k, AtomGroupN<G> g, AtomGroupN<G> gp, const T *stage_in,
+                                                              double rho, double *num, T *dold, double *partial_old,
+                                                              int64_t ldr) {
+    // ldr: stride of the rows of num / dold / stage (s rounded up to whole passes of the projecting workgroup, whose
+    // loads and stores are then unconditional)
+    static_assert(G <= 64, "one lane per atom of the group");
+    __shared__ double s_oldw[4][G];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int e0 = lane * KPL;
-    int ja[kAtomGroup];
-    T cc[kAtomGroup][KPL], Cjj[kAtomGroup];
+    int ja[G];
+    T cc[G][KPL], Cjj[G];
 #pragma unroll
-    for (int a = 0; a < kAtomGroup; ++a) {
+    for (int a = 0; a < G; ++a) {
         ja[a] = g.j[a < g.n ? a : 0];                                   // (a short last group repeats its first atom: not stored)
 #pragma unroll
-        for (int c = 0; c < KPL; ++c) {
-            const T cv = C[(int64_t)ja[a] * k + (e0 + c < k ? e0 + c : k - 1)];
-            cc[a][c] = (e0 + c < k) ? cv : (T)0;
-        }
+        for (int c = 0; c < KPL; ++c) cc[a][c] = C[(int64_t)ja[a] * k + (e0 + c < k ? e0 + c : k - 1)];
         Cjj[a] = C[(int64_t)ja[a] * k + ja[a]];
     }
-    double old[kAtomGroup];
+    const int64_t f0 = ((int64_t)blockIdx.x * 4 + wid) * kGradRows;
+    int64_t r[kGradRows];
+    T rv[kGradRows][KPL], dj[kGradRows][G], bj[kGradRows][G], pv[kGradRows][G];
 #pragma unroll
-    for (int a = 0; a < kAtomGroup; ++a) old[a] = 0;
-    const int nwv = (int)(blockDim.x >> 6);
-    for (int64_t f = (int64_t)blockIdx.x * nwv + wid; f < s; f += (int64_t)gridDim.x * nwv) {
-        const int64_t r = sub_row(subset, f) * k;
-        const T *row = Dt + r;
-        T rv[KPL], dj[kAtomGroup], bj[kAtomGroup], pv[kAtomGroup];
+    for (int q = 0; q < kGradRows; ++q) {
+        const int64_t f = f0 + q < s ? f0 + q : s - 1;                   // (clamped: no branch around a load)
+        r[q] = sub_row(subset, f) * k;
+    }
 #pragma unroll
-        for (int c = 0; c < KPL; ++c) rv[c] = row[e0 + c < k ? e0 + c : k - 1];
+    for (int q = 0; q < kGradRows; ++q) {
+        const int64_t f = f0 + q < s ? f0 + q : s - 1;
+        const T *row = Dt + r[q];
 #pragma unroll
-        for (int a = 0; a < kAtomGroup; ++a) { dj[a] = row[ja[a]]; bj[a] = Bt[r + ja[a]]; }
+        for (int c = 0; c < KPL; ++c) rv[q][c] = row[e0 + c < k ? e0 + c : k - 1];
 #pragma unroll
-        for (int a = 0; a < kAtomGroup; ++a) pv[a] = stage_in[(int64_t)(a < gp.n ? a : 0) * s + f];   // (unconditional)
+        for (int a = 0; a < G; ++a) { dj[q][a] = row[ja[a]]; bj[q][a] = Bt[r[q] + ja[a]]; }
 #pragma unroll
-        for (int a = 0; a < kAtomGroup; ++a) {
+        for (int a = 0; a < G; ++a) pv[q][a] = stage_in[(int64_t)(a < gp.n ? a : 0) * ldr + f];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < G; ++a)
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) cc[a][c] = (e0 + c < k) ? cc[a][c] : (T)0;
+    double old = 0;                                                      // lane a: atom a
+#pragma unroll
+    for (int q = 0; q < kGradRows; ++q) {
+        const bool live = f0 + q < s;                                    // wavefront-uniform
+        T pmine = 0;                                                     // lane a: the staged value of the previous group's atom a
+        int jmine = -1;
+#pragma unroll
+        for (int a = 0; a < G; ++a) {
             if (a < gp.n) {                                              // the previous group's atoms: into the row
 #pragma unroll
-                for (int c = 0; c < KPL; ++c) rv[c] = (e0 + c == gp.j[a]) ? pv[a] : rv[c];
-                if (lane == 0) Dt[r + gp.j[a]] = pv[a];
+                for (int c = 0; c < KPL; ++c) rv[q][c] = (e0 + c == gp.j[a]) ? pv[q][a] : rv[q][c];
+                if (lane == a) { pmine = pv[q][a]; jmine = gp.j[a]; }
             }
         }
+        if (live && jmine >= 0) Dt[r[q] + jmine] = pmine;
+        double nmine = 0;
+        T dmine = 0;
 #pragma unroll
-        for (int a = 0; a < kAtomGroup; ++a) {
+        for (int a = 0; a < G; ++a) {
             double dot = 0;
 #pragma unroll
-            for (int c = 0; c < KPL; ++c) dot += (double)rv[c] * (double)cc[a][c];
+            for (int c = 0; c < KPL; ++c) dot += (double)rv[q][c] * (double)cc[a][c];
             dot = wave_sum(dot);
-            if (lane == 0 && a < g.n) {
-                num[(int64_t)a * s + f] = ((double)bj[a] - dot) + (double)Cjj[a] * (double)dj[a];
-                dold[(int64_t)a * s + f] = dj[a];
-                const double ab = fabs((double)dj[a]);
-                old[a] += ab * (rho + (1.0 - rho) * ab);
-            }
+            const double nv = ((double)bj[q][a] - dot) + (double)Cjj[a] * (double)dj[q][a];
+            if (lane == a) { nmine = nv; dmine = dj[q][a]; }
+        }
+        if (live && lane < g.n) {
+            num[(int64_t)lane * ldr + f0 + q] = nmine;
+            dold[(int64_t)lane * ldr + f0 + q] = dmine;
+            const double ab = fabs((double)dmine);
+            old += ab * (rho + (1.0 - rho) * ab);
         }
     }
-#pragma unroll
-    for (int a = 0; a < kAtomGroup; ++a) {
-        const double o = block_sum(old[a], red);
-        if (threadIdx.x == 0) partial_old[(int64_t)a * gridDim.x + blockIdx.x] = o;
-    }
-    if (!arrive_last(counter, gridDim.x, &flag)) return;
+    if (lane < G) s_oldw[wid][lane] = old;
+    __syncthreads();
+    if (threadIdx.x < G)
+        partial_old[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] =
+            (s_oldw[0][threadIdx.x] + s_oldw[1][threadIdx.x]) + (s_oldw[2][threadIdx.x] + s_oldw[3][threadIdx.x]);
+}
 
-    // ---- the last workgroup: the atoms of the group, in sweep order.  A single workgroup pays a full memory round trip
-    // for every dependent load, so nothing is fetched when it is needed: the scalars of the whole group come first (one
-    // trip), the numerators of atom a + 1 are in registers before atom a is projected (ping-pong register sets, the
-    // steps are unrolled), and what atom a changed is applied from registers to the prefetched numerators of atom a + 1
-    // and, read-modify-write, to those of the atoms after it.
-    const int nparts = (int)gridDim.x;
-    __shared__ double s_coef[kAtomGroup][kAtomGroup], s_cjj[kAtomGroup], s_cn[kAtomGroup], s_old[kAtomGroup];
-    // EVERY load of the prologue is requested before the first barrier - the scatter offsets, the numerators of the
-    // first two atoms, the old-norm partials - so that the lone workgroup pays ONE memory round trip for them, not one
-    // per stage (7.4 us of a 54 us group before, measured with clock stamps)
-    int64_t dst[EPT];                                                    // (compact: feature i of the staged row)
+// two block-wide sums of a four-wavefront workgroup with ONE barrier: the exchange slots alternate (red4: 2 x 8 doubles;
+// a slot is rewritten two exchanges later, when every wavefront has passed the barrier behind its last read).  Same
+// association as block_sum2.
+__device__ __forceinline__ void block_sum2_pp(double &a, double &b, double *red4, int &par) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    a = wave_sum(a);
+    b = wave_sum(b);
+    double *r = red4 + 8 * par;
+    par ^= 1;
+    if (lane == 0) { r[2 * wid] = a; r[2 * wid + 1] = b; }
+    __syncthreads();
+    a = (r[0] + r[2]) + (r[4] + r[6]);
+    b = (r[1] + r[3]) + (r[5] + r[7]);
+}
+__device__ __forceinline__ void block_sum1_pp(double &a, double *red4, int &par) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    a = wave_sum(a);
+    double *r = red4 + 8 * par;
+    par ^= 1;
+    if (lane == 0) r[2 * wid] = a;
+    __syncthreads();
+    a = (r[0] + r[2]) + (r[4] + r[6]);
+}
+
+// Element e of a thread of the projecting workgroup is element atom_elem(e) of the row: chunks of four consecutive
+// elements per thread, so that numerators, old values and the output row move as 16-byte accesses - 20 memory
+// operations per atom instead of 80.  (With one operation per element the 40 prefetch loads of the next atom behind the
+// 20 output stores of the last one overflowed the 6-bit vmcnt counter, and the compiler drained the stores - a full
+// write round trip, exposed - before it could issue the loads.)
+__device__ __forceinline__ int atom_elem(int e) { return 4 * (int)threadIdx.x + (e & 3) + 1024 * (e >> 2); }
+template <int EPT>
+__device__ __forceinline__ void load_row4(const double *row, double (&v)[EPT]) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) dst[e] = threadIdx.x + (int64_t)e * 256;
-    double X[2][EPT];
-    T Dd[2][EPT];
-    auto load_atom = [&](int a, double (&xd)[EPT], T (&dd)[EPT]) {
-        const int ac = a < g.n ? a : g.n - 1;                            // always a valid slot: no branch around the loads
+    for (int q = 0; q < EPT / 4; ++q) {
+        const d2 *p = reinterpret_cast<const d2 *>(row + 4 * threadIdx.x + 1024 * q);
+        const d2 lo = p[0], hi = p[1];
+        v[4 * q] = lo[0]; v[4 * q + 1] = lo[1]; v[4 * q + 2] = hi[0]; v[4 * q + 3] = hi[1];
+    }
+}
+template <int EPT>
+__device__ __forceinline__ void load_row4(const float *row, float (&v)[EPT]) {
+#pragma unroll
+    for (int q = 0; q < EPT / 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4 *>(row + 4 * threadIdx.x + 1024 * q);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+}
+template <int EPT>
+__device__ __forceinline__ void store_row4(float *row, const float (&v)[EPT]) {
+#pragma unroll
+    for (int q = 0; q < EPT / 4; ++q)
+        *reinterpret_cast<float4 *>(row + 4 * threadIdx.x + 1024 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+template <int EPT>
+__device__ __forceinline__ void store_row4(double *row, const double (&v)[EPT]) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int q = 0; q < EPT / 4; ++q) {
+        d2 *p = reinterpret_cast<d2 *>(row + 4 * threadIdx.x + 1024 * q);
+        d2 lo, hi;
+        lo[0] = v[4 * q]; lo[1] = v[4 * q + 1]; hi[0] = v[4 * q + 2]; hi[1] = v[4 * q + 3];
+        p[0] = lo; p[1] = hi;
+    }
+}
+
+// block_enet_project_vals (enet_block.hpp) for the lone projecting workgroup of atom_project_group_kernel: the same
+// level equation and iteration, but |x| and its term are recomputed in every pass instead of kept (2 x EPT doubles of
+// registers that hold the group's changes instead), one barrier per exchange, ONE output code path (inside the ball is
+// level 0, radius 0 is a flag: every merge of two paths costs register copies in a kernel this large), the output
+// row written as 16-byte stores, and the warm start of l1 atoms (L1: l1_ratio == 1, gamma == 0) is the previous level
+// ITSELF: f(l) = sum_{|x| > l} (|x| - l) - R is convex and decreasing, so the Newton step that Michelot's update is
+// lands at or left of the root from EITHER side, and the iteration rises monotonically from there - no check, no safety
+// factor (4.4 -> 3.3 passes per atom on the fMRI shape).  A step that lands at or below zero proves nothing and falls
+// back to the cold start (which also settles "inside the ball").  The output row has room for EPT * 256 elements (x is
+// zero beyond n, and so is the output).  Leaves the result in x; returns its enet norm.
+// dbg[4] = passes | warm << 16, dbg[5] = clock when the level is known.
+template <typename T, int EPT, bool L1>
+__device__ __forceinline__ double enet_project_slim(double (&x)[EPT], T *out, double radius, double l1_ratio,
+                                                    double *red4, int &par, double l_prev, double *level_out,
+                                                    unsigned long long *dbg) {
+    if (!L1 && l1_ratio == 0.0 && radius > 0.0) {           // enet.pyx:62-70, radius in squared-norm units
+        double s2 = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) s2 += x[e] * x[e];
+        block_sum1_pp(s2, red4, par);
+        const T scale = (s2 <= radius) ? (T)1 : (T)sqrt(s2 / radius);
+        T o[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const int64_t i = threadIdx.x + (int64_t)e * 256;
-            const int64_t at = (int64_t)ac * s + (i < s ? i : s - 1);
-            xd[e] = num[at];
-            dd[e] = dold[at];
+            o[e] = (T)x[e] / scale;
+            x[e] = (double)o[e];
         }
+        store_row4<EPT>(out, o);
+        return (s2 <= radius) ? s2 : radius;
+    }
+    const bool zero = !(radius > 0.0);                       // enet.pyx:57-59 (radius == 0 -> zeros)
+    const double gamma = L1 ? 0.0 : 2.0 / l1_ratio - 2.0;
+    const double R = radius / l1_ratio;
+    const double hg = 0.5 * gamma;
+    auto term = [&](double ax) { return L1 ? ax : ax * (1.0 + hg * ax); };
+    auto pass = [&](double lv, double &S, double &cnt) {     // selects, no branches; two chains (block_enet_project_vals)
+        double S0 = 0, S1 = 0;
+        int c0 = 0, c1 = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; e += 2) {
+            const double a0 = fabs(x[e]), a1 = fabs(x[e + 1]);
+            const bool i0 = a0 > lv, i1 = a1 > lv;
+            S0 += i0 ? term(a0) : 0.0;
+            S1 += i1 ? term(a1) : 0.0;
+            c0 += i0 ? 1 : 0;
+            c1 += i1 ? 1 : 0;
+        }
+        S = S0 + S1;
+        cnt = (double)(c0 + c1);
+        block_sum2_pp(S, cnt, red4, par);
     };
-    load_atom(0, X[0], Dd[0]);
-    load_atom(1, X[1], Dd[1]);
-    {
-        double o[kAtomGroup];
-#pragma unroll
-        for (int a = 0; a < kAtomGroup; ++a) {
-            o[a] = 0;
-            for (int i = threadIdx.x; i < nparts; i += 256) o[a] += partial_old[(int64_t)a * nparts + i];
+    auto solve = [&](double S, double cnt) {
+        if (!L1) {                                           // enet.pyx:113-117
+            const double qa = gamma * gamma * R + gamma * cnt * 0.5;
+            const double qd = 2.0 * R * gamma + cnt;
+            const double qc = R - S;
+            return (-qd + sqrt(qd * qd - 4.0 * qa * qc)) / (2.0 * qa);
         }
-        // (the group's scalars last: these loads sit behind a per-thread branch, where the compiler waits for them)
-        if (threadIdx.x < kAtomGroup * kAtomGroup) {
-            const int b = threadIdx.x / kAtomGroup, a = threadIdx.x % kAtomGroup;
-            const int jb = g.j[b < g.n ? b : 0], jaa = g.j[a < g.n ? a : 0];   // (from the kernel arguments: a private array
-            s_coef[b][a] = (double)C[(int64_t)jb * k + jaa];                   //  indexed per thread would live in scratch)
-            if (b == 0) { s_cjj[a] = (double)C[(int64_t)jaa * k + jaa]; s_cn[a] = (double)comp_norm[jaa]; }
-        }
+        return (S - R) / cnt;                                // :119
+    };
+    double level = 0.0, prev_cnt = -1.0;
+    bool warm = false, search = !zero;
+    int npass = 0;
+    if (search && l_prev > 0.0 && l_prev < 1e300) {
+        const double l0 = L1 ? l_prev : 0.9 * l_prev;
+        double S, cnt;
+        if (L1) {
+            pass(l0, S, cnt);
+            ++npass;
+            const double l1 = (S - R) / cnt;
+            if (cnt != 0.0 && l1 > 0.0) { warm = true; prev_cnt = cnt; level = l1; }
+        } else {                                             // the verified guess of block_enet_project_vals
+            double P = 0;
 #pragma unroll
-        for (int a = 0; a < kAtomGroup; a += 2) block_sum2(o[a], o[a + 1], red, 256);
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int a = 0; a < kAtomGroup; ++a) s_old[a] = o[a];
+            for (int e = 0; e < EPT; ++e) P += (fabs(x[e]) > l0) ? fabs(x[e]) : 0.0;
+            pass(l0, S, cnt);
+            ++npass;
+            block_sum1_pp(P, red4, par);
+            const double d = 1.0 + l0 * gamma;
+            const double sum_u = (P - cnt * l0) / d;
+            const double sum_a2 = (S - P) / (0.5 * gamma);
+            const double sum_u2 = (sum_a2 - 2.0 * l0 * P + cnt * l0 * l0) / (d * d);
+            const double h0 = sum_u + 0.5 * gamma * sum_u2;
+            if (h0 >= R * (1.0 + 1e-9) && cnt != 0.0) { warm = true; prev_cnt = cnt; level = solve(S, cnt); }
         }
     }
-    __syncthreads();                                                     // s_coef / s_cjj / s_cn / s_old
+    if (search && !warm) {
+        double tot = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) tot += term(fabs(x[e]));
+        block_sum1_pp(tot, red4, par);
+        if (tot <= R) search = false;                        // inside the ball: level 0 is the identity
+    }
+    if (search) {
+        for (int p = 0; p < 256; ++p) {
+            double S, cnt;
+            pass(level, S, cnt);
+            ++npass;
+            if (cnt == prev_cnt || cnt == 0.0) break;
+            prev_cnt = cnt;
+            level = solve(S, cnt);
+        }
+    }
+    if (dbg && threadIdx.x == 0) { dbg[4] = (unsigned)npass | (warm ? 1u << 16 : 0u); dbg[5] = clock64(); }
+    if (level_out && threadIdx.x == 0 && search) *level_out = level;
+    const double lT = (double)(T)level;
+    const double inv_den = zero ? 0.0 : 1.0 / (1.0 + lT * gamma);   // one division (exactly 1 for l1 atoms), EPT products
+    double nrm = 0;
+    T o[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        double pos = fabs(x[e]) - lT;
+        pos = pos > 0 ? pos : 0;
+        o[e] = (T)(((x[e] >= 0) ? pos : -pos) * inv_den);   // enet.pyx:121, sign(0) = +1
+        o[e] = zero ? (T)0 : o[e];
+        x[e] = (double)o[e];
+        const double a = fabs(x[e]);
+        nrm += a * (l1_ratio + (1.0 - l1_ratio) * a);
+    }
+    store_row4<EPT>(out, o);
+    block_sum1_pp(nrm, red4, par);
+    return nrm;
+}
+
+// The projections of a group, in sweep order, by ONE workgroup of four wavefronts (one per SIMD).  Per atom: the
+// numerators (prefetched while the atom before was projected) minus what the group's earlier atoms changed, from
+// registers, in sweep order; the candidate; the projection; the output row; the change stays in registers for the atoms
+// behind.  Every scalar of the group (coefficients, budgets, old-norm sums, level hints) is fetched in the prologue, all
+// requests before the first wait: a lone workgroup pays a full memory round trip for every dependent load.
+// dbg: [0] launches, [3] prologue, [4 + 4a] atom a (corrections + projection), [5 + 4a] its passes, [7 + 4a] warm
+// starts taken (a < 4: the first four atoms of the group), [20] whole kernel, over all atoms: [24] corrections and
+// candidate, [25] level search, [26] output row and norm, [28] atoms; [32..39] scratch.  (The stamps cost a memory
+// round trip per atom on wavefront 0: they inflate what follows them.)
+template <typename T, int EPT, int G, bool L1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void atom_project_group_kernel(const T *C, int64_t s, int k, AtomGroupN<G> g, T *stage_out, int pos, double rho,
+                               const double *num, const T *dold, const double *partial_old, int nparts, T *comp_norm,
+                               double *level_hint, unsigned long long *dbg) {
+    static_assert(EPT % 4 == 0 && G % 4 == 0, "chunks of four elements, four wavefronts");
+    constexpr int64_t ldr = (int64_t)EPT * 256;                         // row stride of num / dold / stage_out
+    __shared__ double red4[16];
+    __shared__ double s_coef[G][G], s_cjj[G], s_cn[G], s_old[G], s_lvl[G];
+    const unsigned long long t0 = dbg ? clock64() : 0;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double X[2][EPT];
+    T Dd[2][EPT];
+    auto load_atom = [&](int a, double (&xd)[EPT], T (&dd)[EPT]) {      // (elements beyond s: whatever the scratch holds,
+        const int ac = a < g.n ? a : g.n - 1;                            //  masked where the candidate is formed)
+        load_row4<EPT>(num + (int64_t)ac * ldr, xd);
+        load_row4<EPT>(dold + (int64_t)ac * ldr, dd);
+    };
+    load_atom(0, X[0], Dd[0]);
+    {
+        // old-norm sums: wavefront w sums the partials of atoms w, w + 4, ... (no exchange between the wavefronts); up to
+        // 512 partials per atom, every load requested before the first sum (clamped, masked)
+        constexpr int NP = 8;
+        double pv[G / 4][NP];
+#pragma unroll
+        for (int h = 0; h < G / 4; ++h) {
+            const int a = 4 * h + wid;
+            const int ac = a < g.n ? a : 0;
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int i = lane + 64 * u;
+                pv[h][u] = partial_old[(int64_t)ac * nparts + (i < nparts ? i : nparts - 1)];
+            }
+        }
+        const int t = threadIdx.x;                                        // (G * G <= 64 < 256: one element per thread)
+        const int b = (t / G) % G, a = t % G;
+        const int jb = g.j[b < g.n ? b : 0], jaa = g.j[a < g.n ? a : 0];   // (from the kernel arguments)
+        const double cba = (double)C[(int64_t)jb * k + jaa], caa = (double)C[(int64_t)jaa * k + jaa];
+        const double cn = (double)comp_norm[jaa], lv = level_hint ? level_hint[jaa] : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+        if (t < G * G) {
+            s_coef[b][a] = cba;
+            if (b == 0) { s_cjj[a] = caa; s_cn[a] = cn; s_lvl[a] = lv; }
+        }
+#pragma unroll
+        for (int h = 0; h < G / 4; ++h) {
+            double o = 0;
+#pragma unroll
+            for (int u = 0; u < NP; ++u) o += (lane + 64 * u < nparts) ? pv[h][u] : 0.0;
+            o = wave_sum(o);
+            if (lane == 0) s_old[4 * h + wid] = o;
+        }
+    }
+    __syncthreads();
+    if (dbg && threadIdx.x == 0) { dbg[0] += 1; dbg[3] += clock64() - t0; }
+    int par = 0;
+    double dl[G > 1 ? G - 1 : 1][EPT];                                  // what the atoms of the group changed
     auto step = [&](auto A_) {
         constexpr int a = decltype(A_)::value;
         if (a >= g.n) return;                                            // workgroup-uniform
+        const unsigned long long ta = dbg ? clock64() : 0;
+        if (dbg && threadIdx.x == 0) dbg[36] = 0;
         double (&x)[EPT] = X[a & 1];
         T (&dd)[EPT] = Dd[a & 1];
+        if (a + 1 < G) load_atom(a + 1, X[(a + 1) & 1], Dd[(a + 1) & 1]);   // lands while this atom is projected
+#pragma unroll
+        for (int b = 0; b < a; ++b) {
+            const double c = s_coef[b][a];
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) x[e] -= c * dl[b][e];
+        }
         const int j = g.j[a];
         const double radius = (double)(T)(s_cn[a] + s_old[a]);          // comp_norm_[k] += subset_norm (:676-678)
         const double cjj = s_cjj[a];
         const bool frozen = !((T)cjj > (T)1e-20);
-        // one reciprocal, then products: a double-precision division is a dozen instructions (v_div_scale, v_rcp_f64,
-        // Newton steps, v_div_fmas, v_div_fixup), 24 of them per thread and atom were ~1.5 us of a 14 us atom step
-        const double icjj = 1.0 / cjj;
+        const double icjj = 1.0 / cjj;                                   // one reciprocal, then products
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const int64_t i = threadIdx.x + (int64_t)e * 256;
             T val = dd[e];
             if (!frozen) val = (T)(x[e] * icjj);
             if (pos && val < (T)0) val = 0;                              // dict_fact.py:684-685
-            x[e] = (i < s) ? (double)val : 0.0;
+            x[e] = (atom_elem(e) < s) ? (double)val : 0.0;
         }
-        const double nrm = block_enet_project_vals<T, EPT>(x, dst, stage_out + (int64_t)a * s, s, radius, rho, red, 256,
-                                                           nullptr, level_hint ? level_hint + j : nullptr);
+        const unsigned long long tb = dbg ? clock64() : 0;
+        const double nrm = enet_project_slim<T, EPT, L1>(x, stage_out + (int64_t)a * ldr, radius, rho, red4, par, s_lvl[a],
+                                                         level_hint ? level_hint + j : nullptr, dbg ? dbg + 32 : nullptr);
         if (threadIdx.x == 0) comp_norm[j] = (T)(radius - nrm);         // :690-692
-        if (a + 1 < g.n) {
-            double (&xn)[EPT] = X[(a + 1) & 1];
-            const double c1 = s_coef[a][(a + 1) % kAtomGroup];
+        if (a + 1 < G) {
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                x[e] -= (double)dd[e];                                   // what this atom changed (0 beyond s)
-                xn[e] -= c1 * x[e];
+            for (int e = 0; e < EPT; ++e) dl[a < G - 1 ? a : 0][e] = (atom_elem(e) < s) ? x[e] - (double)dd[e] : 0.0;
+        }
+        if (dbg && threadIdx.x == 0) {
+            const unsigned long long tc = clock64();
+            if (a < 4) {
+                dbg[4 + 4 * a] += tc - ta;
+                dbg[5 + 4 * a] += dbg[36] & 0xffff;
+                dbg[7 + 4 * a] += dbg[36] >> 16;
             }
-#pragma unroll
-            for (int a2 = a + 2; a2 < kAtomGroup; ++a2) {                // the atoms after the next: read-modify-write
-                if (a2 < g.n) {
-                    const double c2 = s_coef[a][a2];
-                    double t[EPT];
-#pragma unroll
-                    for (int e = 0; e < EPT; ++e) {
-                        const int64_t i = threadIdx.x + (int64_t)e * 256;
-                        t[e] = num[(int64_t)a2 * s + (i < s ? i : s - 1)];
-                    }
-#pragma unroll
-                    for (int e = 0; e < EPT; ++e) {
-                        const int64_t i = threadIdx.x + (int64_t)e * 256;
-                        if (i < s) num[(int64_t)a2 * s + i] = t[e] - c2 * x[e];   // read back by this same thread
-                    }
-                }
-            }
-            if (a + 2 < kAtomGroup) load_atom(a + 2, X[a & 1], Dd[a & 1]);   // lands while atom a + 1 is projected
+            dbg[24] += tb - ta; dbg[25] += dbg[37] - tb; dbg[26] += tc - dbg[37]; dbg[28] += 1;
         }
     };
-    for_each_int(std::make_integer_sequence<int, kAtomGroup>{}, step);
+    for_each_int(std::make_integer_sequence<int, G>{}, step);
+    if (dbg && threadIdx.x == 0) dbg[20] += clock64() - t0;
+}
+
+// the last group's staged atoms -> dictionary
+template <typename T, int G>
+__global__ __launch_bounds__(256) void atom_stage_flush_group_kernel(T *Dt, const int32_t *subset, int64_t s, int k,
+                                                                     AtomGroupN<G> g, const T *stage, int64_t ldr) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= s) return;
+    const int64_t r = sub_row(subset, f) * k;
+#pragma unroll
+    for (int a = 0; a < G; ++a)
+        if (a < g.n) Dt[r + g.j[a]] = stage[(int64_t)a * ldr + f];
 }
 
 // The whole sweep in ONE launch, by one workgroup, for TINY problems (u = the s-vector of the atom in flight
@@ -1685,18 +1935,6 @@ __global__ __launch_bounds__(256) void atom_group_kernel(T *Dt, const T *Bt, con
 // launches.  Its thread-per-row reads are uncoalesced, so anything larger uses one multi-workgroup launch
 // per atom (atom_step_kernel).  Same arithmetic as atom_grad_kernel + atom_project_kernel (the dot product is accumulated
 // in double, sequentially over the atoms instead of lane-wise).
-// the last group's staged atoms -> dictionary
-template <typename T>
-__global__ __launch_bounds__(256) void atom_stage_flush_kernel(T *Dt, const int32_t *subset, int64_t s, int k, AtomGroup g,
-                                                               const T *stage) {
-    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (f >= s) return;
-    const int64_t r = sub_row(subset, f) * k;
-#pragma unroll
-    for (int a = 0; a < kAtomGroup; ++a)
-        if (a < g.n) Dt[r + g.j[a]] = stage[(int64_t)a * s + f];
-}
-
 template <typename T>
 __global__ __launch_bounds__(1024) void atom_sweep_kernel(T *Dt, const T *Bt, const T *C, const int32_t *subset,
                                                           const int32_t *order, int64_t s, int k, int pos, double rho,
@@ -2045,52 +2283,61 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
     unsigned int *counter = reinterpret_cast<unsigned int *>(reinterpret_cast<double *>(ws + L.off_Tp) + 2 * kResStride);
     MODL_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned int), stream));   // the last arriver re-arms it after each atom
     const size_t u_lds = (sizeof(T) * (size_t)s <= 60 * 1024) ? sizeof(T) * (size_t)s : 0;
-    // groups of atoms per launch while the vector fits the registers of the projecting workgroup and the group's
-    // scratch (numerators, old values, changes) fits the region of the sgd candidate matrix
-    const size_t group_bytes = (size_t)kAtomGroup * (size_t)s * (sizeof(double) + 3 * sizeof(T));   // + two staged groups
-    if (s <= (int64_t)kProjEpt * 256 && group_bytes + 64 <= sizeof(T) * (size_t)s * k && k <= 512 &&
-        (int64_t)kAtomGroup * nwg <= L.nwg_grad) {
+    // groups of atoms per launch pair while the vector fits the registers of the projecting workgroup
+    if (s <= (int64_t)kProjEpt * 256 && k <= 512) {
+        const bool l1 = a.comp_l1_ratio == 1.0;
+        const int G = (s <= 20 * 256) ? 8 : 4;                           // (24 elements per thread: the changes of 3 atoms fit, not of 7)
+        nwg = (int)cdiv(s, 4 * kGradRows);                               // kGradRows rows per wavefront (<= 512: s <= 24 * 256)
+        const int64_t ldr = atom_row_stride(s);       // rows of the group's scratch: whole passes of the projecting workgroup
         char *gb = ws + L.off_Dnew;
         double *num = reinterpret_cast<double *>(gb);
-        T *dold = reinterpret_cast<T *>(num + (size_t)kAtomGroup * s);
-        T *stage[2] = {dold + (size_t)kAtomGroup * s, dold + (size_t)2 * kAtomGroup * s};
-        AtomGroup gp;                                 // the group whose projected atoms are staged (none yet)
-        gp.n = 0;
-        for (int a = 0; a < kAtomGroup; ++a) gp.j[a] = 0;
-        int gi = 0;
-        for (int t = 0; t < k; t += kAtomGroup, ++gi) {
-            AtomGroup g;
-            g.n = (k - t < kAtomGroup) ? k - t : kAtomGroup;
-            for (int a = 0; a < kAtomGroup; ++a) {
-                const int64_t j = h_order[t + (a < g.n ? a : 0)];
-                if (j < 0 || j >= k) return MODL_EINVAL;
-                g.j[a] = (int)j;
+        T *dold = reinterpret_cast<T *>(num + (size_t)G * ldr);
+        T *stage[2] = {dold + (size_t)G * ldr, dold + (size_t)2 * G * ldr};
+        unsigned long long *dbg = g_atom_stamps.load(std::memory_order_relaxed);
+        auto run = [&](auto G_) -> int {
+            constexpr int GG = decltype(G_)::value;
+            AtomGroupN<GG> gp;                            // the group whose projected atoms are staged (none yet)
+            gp.n = 0;
+            for (int x = 0; x < GG; ++x) gp.j[x] = 0;
+            int gi = 0;
+            for (int t = 0; t < k; t += GG, ++gi) {
+                AtomGroupN<GG> g;
+                g.n = (k - t < GG) ? k - t : GG;
+                for (int x = 0; x < GG; ++x) {
+                    const int64_t j = h_order[t + (x < g.n ? x : 0)];
+                    if (j < 0 || j >= k) return MODL_EINVAL;
+                    g.j[x] = (int)j;
+                }
+#define MODL_GRAD(KPL)                                                                                                        \
+    hipLaunchKernelGGL((atom_grad_group_kernel<T, KPL, GG>), dim3(nwg), dim3(256), 0, stream, a.Dt, a.Bt, a.C, a.subset, s, k, g, \
+                       gp, stage[(gi + 1) & 1], a.comp_l1_ratio, num, dold, pold, ldr)
+                if (k <= 64) MODL_GRAD(1);
+                else if (k <= 128) MODL_GRAD(2);
+                else if (k <= 256) MODL_GRAD(4);
+                else MODL_GRAD(8);
+#undef MODL_GRAD
+                MODL_LAUNCH_CHECK();
+#define MODL_PROJ(EPT, L1)                                                                                                    \
+    hipLaunchKernelGGL((atom_project_group_kernel<T, EPT, GG, L1>), dim3(1), dim3(256), 0, stream, a.C, s, k, g, stage[gi & 1],   \
+                       a.comp_pos, a.comp_l1_ratio, num, dold, pold, nwg, a.comp_norm, a.level_hint, dbg)
+                if constexpr (GG == 8) {
+                    if (s <= 12 * 256) { if (l1) MODL_PROJ(12, true); else MODL_PROJ(12, false); }
+                    else { if (l1) MODL_PROJ(20, true); else MODL_PROJ(20, false); }
+                } else {
+                    if (l1) MODL_PROJ(kProjEpt, true); else MODL_PROJ(kProjEpt, false);
+                }
+#undef MODL_PROJ
+                MODL_LAUNCH_CHECK();
+                if (launches) *launches += 2;
+                gp = g;
             }
-#define MODL_GROUP_E(KPL, EPT)                                                                                    \
-    hipLaunchKernelGGL((atom_group_kernel<T, KPL, EPT>), dim3(nwg), dim3(256), 0, stream, a.Dt, a.Bt, a.C, a.subset, s, k, g, \
-                       gp, stage[(gi + 1) & 1], stage[gi & 1], a.comp_pos, a.comp_l1_ratio, num, dold, pold, a.comp_norm,  \
-                       counter, a.level_hint)
-#define MODL_GROUP(KPL)                                                                                           \
-    do {                                                                                                          \
-        if (s <= 12 * 256) MODL_GROUP_E(KPL, 12);                                                                 \
-        else if (s <= 20 * 256) MODL_GROUP_E(KPL, 20);                                                            \
-        else MODL_GROUP_E(KPL, kProjEpt);                                                                         \
-    } while (0)
-            if (k <= 64) MODL_GROUP(1);
-            else if (k <= 128) MODL_GROUP(2);
-            else if (k <= 256) MODL_GROUP(4);
-            else MODL_GROUP(8);
-#undef MODL_GROUP
-#undef MODL_GROUP_E
+            hipLaunchKernelGGL((atom_stage_flush_group_kernel<T, GG>), dim3((unsigned)cdiv(s, 256)), dim3(256), 0, stream, a.Dt,
+                               a.subset, s, k, gp, stage[(gi + 1) & 1], ldr);
             MODL_LAUNCH_CHECK();
             if (launches) *launches += 1;
-            gp = g;
-        }
-        hipLaunchKernelGGL((atom_stage_flush_kernel<T>), dim3((unsigned)cdiv(s, 256)), dim3(256), 0, stream, a.Dt, a.subset, s,
-                           k, gp, stage[(gi + 1) & 1]);
-        MODL_LAUNCH_CHECK();
-        if (launches) *launches += 1;
-        return MODL_OK;
+            return MODL_OK;
+        };
+        return G == 8 ? run(std::integral_constant<int, 8>{}) : run(std::integral_constant<int, 4>{});
     }
     for (int t = 0; t < k; ++t) {
         const int j = (int)h_order[t];

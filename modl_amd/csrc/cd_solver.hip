@@ -513,6 +513,7 @@ static void launch_cd_kpl(hipStream_t stream, const CdArgs<T> &a, dim3 grid, dim
 std::atomic<int> g_cd_sparse_pct{-1};
 std::atomic<int> g_cd_split{1};
 extern std::atomic<unsigned long long *> g_cd_stamps;   // cd_split.hip
+extern std::atomic<unsigned long long *> g_atom_stamps; // bcd.hip
 extern std::atomic<int> g_cd_split_diag;
 extern std::atomic<int> g_bcd_acc;                      // bcd.hip
 
@@ -615,6 +616,10 @@ extern "C" int modl_debug_set(int what, int64_t value) {
     }
     if (what == MODL_DEBUG_CD_STAMPS) {
         modl::g_cd_stamps.store(reinterpret_cast<unsigned long long *>((uintptr_t)value));
+        return MODL_OK;
+    }
+    if (what == MODL_DEBUG_ATOM_STAMPS) {
+        modl::g_atom_stamps.store(reinterpret_cast<unsigned long long *>((uintptr_t)value));
         return MODL_OK;
     }
     if (what == MODL_DEBUG_BCD_ACC) {

@@ -236,7 +236,7 @@ __device__ __forceinline__ double block_enet_project_vals(double (&x)[EPT], cons
             }
             if (h0 >= R * (1.0 + 1e-9) && cnt != 0.0) {      // (otherwise the guess overshoots, or cannot be told apart)
                 warm = true;
-                if (dbg && threadIdx.x == 0) { dbg[4] = 1; dbg[5] = (unsigned long long)cnt; }
+                if (dbg && threadIdx.x == 0) { dbg[4] = 1 | (1 << 16); dbg[5] = (unsigned long long)cnt; }
                 prev_cnt = cnt;
                 if (gamma != 0.0) {
                     const double qa = gamma * gamma * R + gamma * cnt * 0.5;
@@ -277,7 +277,7 @@ __device__ __forceinline__ double block_enet_project_vals(double (&x)[EPT], cons
         S += S1;
         double cnt = (double)(c0 + c1);
         block_sum2(S, cnt, red2, nthreads);
-        if (dbg && threadIdx.x == 0) { dbg[4] = pass + 1; dbg[5] = (unsigned long long)cnt; }
+        if (dbg && threadIdx.x == 0) { dbg[4] = (dbg[4] & (1 << 16)) | (unsigned)(pass + 1 + (warm ? 1 : 0)); dbg[5] = (unsigned long long)cnt; }
         if (cnt == prev_cnt || cnt == 0.0) break;
         prev_cnt = cnt;
         if (gamma != 0.0) {                                  // enet.pyx:113-117

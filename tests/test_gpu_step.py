@@ -230,12 +230,15 @@ def test_wide_ridge_estimator_vs_oracle(DictFact, oracle, agg):
 
 
 @pytest.mark.parametrize('variant', ['fmri', 'fmri_pos', 'enet', 'nmf_l1'])
-@pytest.mark.parametrize('shape', ['groups', 'groups_ragged', 'per_atom'])
+@pytest.mark.parametrize('shape', ['groups', 'groups_ragged', 'groups_20', 'groups_24', 'few_atoms', 'per_atom'])
 def test_generic_dictionary_update_multi_workgroup_vs_oracle(DictFact, oracle, variant, shape):
     """The l1 / elastic-net / positive-atom dictionary update beyond the tiny single-workgroup sweep (s k > 32 k):
-    `groups` = four atoms per launch (csrc/bcd.hip atom_group_kernel: shared gradient pass, corrections between the
-    atoms of a group, warm-started projections over several minibatches), `groups_ragged` = k not a multiple of 4 and a
-    ragged feature count, `per_atom` = more than 6144 sampled features (one launch per atom, atom_step_kernel)."""
+    `groups` = eight atoms per launch pair (csrc/bcd.hip atom_grad_group_kernel + atom_project_group_kernel: shared
+    gradient pass, corrections between the atoms of a group from registers, warm-started projections over several
+    minibatches; 12 elements per thread of the projecting workgroup), `groups_ragged` = k not a multiple of the group
+    and a ragged feature count, `groups_20` / `groups_24` = 4500 / 5750 sampled features (20 elements per thread; 24,
+    groups of four), `few_atoms` = fewer atoms than a group, `per_atom` = more than 6144 sampled features (one launch
+    per atom, atom_step_kernel)."""
     extra = {
         'fmri': dict(code_l1_ratio=0, comp_l1_ratio=1, code_alpha=1e-2),           # fmri.py:481-495
         'fmri_pos': dict(code_l1_ratio=0, comp_l1_ratio=1, code_alpha=1e-2, comp_pos=True),
@@ -243,18 +246,28 @@ def test_generic_dictionary_update_multi_workgroup_vs_oracle(DictFact, oracle, v
         'nmf_l1': dict(comp_pos=True, code_pos=True, comp_l1_ratio=0.7, code_alpha=0.1),
     }[variant]
     n, p, k, b, r = {'groups': (160, 3000, 72, 20, 2), 'groups_ragged': (160, 2501, 70, 20, 3),
-                     'per_atom': (100, 14000, 24, 20, 2)}[shape]
+                     'groups_20': (120, 9000, 36, 20, 2), 'groups_24': (120, 11500, 27, 20, 2),
+                     'few_atoms': (120, 6000, 6, 20, 2), 'per_atom': (100, 14000, 24, 20, 2)}[shape]
     est, st = _one_step_pair(DictFact, oracle, np.float64, n=n, p=p, k=k, b=b, r=r, steps=4, **extra)
     eD, eC = rel_fro(est.components_, st.D), rel_fro(est.code_[:80], st.code[:80])
     assert eD < 1e-9 and eC < 1e-9, (variant, shape, eD, eC)
     assert rel_fro(est.comp_norm_, st.comp_norm) < 1e-9 or np.allclose(est.comp_norm_, st.comp_norm, atol=1e-12)
 
 
-def test_generic_dictionary_update_f32_groups_vs_oracle(DictFact, oracle):
-    """f32, first minibatch from identical state, through the atom groups (k >= 20 needed for their scratch)"""
-    est, st = _one_step_pair(DictFact, oracle, np.float32, n=160, p=3000, k=72, b=20, r=2, steps=1,
-                             code_l1_ratio=0, comp_l1_ratio=1, code_alpha=1e-2)
-    assert rel_fro(est.components_, st.D) < 1e-5 and rel_fro(est.code_[:20], st.code[:20]) < 1e-5
+@pytest.mark.parametrize('p,k,l1', [(3000, 72, 1), (9000, 36, 1), (9000, 36, 0.5), (11500, 27, 1), (11500, 27, 0.5)])
+def test_generic_dictionary_update_f32_groups_vs_oracle(DictFact, oracle, p, k, l1):
+    """f32, first minibatch from identical state, through the atom groups (12 / 20 / 24 elements per thread of the
+    projecting workgroup; l1 and elastic-net atoms): within the oracle's own f32 noise of its f64 run."""
+    kw = dict(n=160, p=p, k=k, b=20, r=2, code_l1_ratio=0, comp_l1_ratio=l1, code_alpha=1e-2)
+    from .conftest import assert_within_f32_noise
+    est, pr, st32, X = _make_pair(DictFact, oracle, np.float32, **kw)
+    X64 = X.astype(np.float64)                                   # the same float32 records, in double precision
+    st64 = oracle.prepare(pr, n_samples=X.shape[0], X=X64)
+    est.partial_fit(X[:20])
+    oracle.partial_fit(st32, pr, X[:20])
+    oracle.partial_fit(st64, pr, X64[:20])
+    assert_within_f32_noise(est.components_, st32.D, st64.D, 'dictionary')
+    assert_within_f32_noise(est.code_[:20], st32.code[:20], st64.code[:20], 'codes')
 
 
 def test_full_size_step_properties(DictFact):
