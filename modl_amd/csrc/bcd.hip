@@ -1060,8 +1060,15 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
         constexpr int PW0 = (GPW == 8) ? (RT == 1 ? 2 : 1) : 0;      // first wave that takes part in the product
         constexpr int GW = (GPW == 8) ? (RT == 1 ? 16 : 11) : GPW;   // contraction groups (8 atoms) per product wave
         const bool pwave = __builtin_amdgcn_readfirstlane(wid) >= PW0;   // (wave-uniform for the compiler too)
-        float bfr[GW][4];
-        float4 av[GW][RT];
+        // 96 features per workgroup (RT == 3): the operands of the product are requested in NBATCH batches of GB
+        // contraction groups, a batch behind the matrix-core instructions of the one before (whole range at once: 176
+        // registers of operands, 107 of them spilled - requesting them took 24 k cycles and the workers, not the
+        // recursion, were the critical path of the launch: 75.7 k cycles at p = 200 000; the extra round trips sit in
+        // the recursion's shadow)
+        constexpr int NBATCH = (RT == 3) ? 3 : 1;
+        constexpr int GB = (GW + NBATCH - 1) / NBATCH;
+        float bfr[GB][4];
+        float4 av[GB][RT];
         float4 va[NA];
         if (!fin) {
             // (unconditional, clamped requests; every mask is applied behind the scheduler fence below: a select next to
@@ -1084,7 +1091,7 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
             // for its first 16 steps: ~530 cycles per atom instead of ~430)
             if (pwave)
 #pragma unroll
-            for (int g = 0; g < GW; ++g) {
+            for (int g = 0; g < GB; ++g) {
                 const int kb = ((wid - PW0) * GW + g) * 8 + 4 * h;  // this lane's 4 consecutive atoms
                 // 32-bit element offsets from one uniform base (k <= 512): two instructions of address arithmetic per
                 // request instead of eight with a 64-bit multiply (92 cycles per request, measured).  k % 4 == 0, so
@@ -1109,7 +1116,7 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
                 if (f >= p.s) f = p.s - 1;               // clamped: results of padded rows are discarded
                 const float *rowp = p.Dt + dfrag(f, 0, k);
 #pragma unroll
-                for (int g = 0; g < GW; ++g) {
+                for (int g = 0; g < GB; ++g) {
                     const int kb = ((wid - PW0) * GW + g) * 8 + 4 * h;
                     const bool ok = kb + 3 < k;
                     av[g][t] = *reinterpret_cast<const float4 *>(rowp + (ok ? kb : 0) * 32);   // (masked below)
@@ -1193,8 +1200,11 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
                 for (int r = 0; r < 16; ++r) accx[q][r] = 0.f;
             if (pwave)
 #pragma unroll
-            for (int g = 0; g < GW; ++g) {
-                const int kb = ((wid - PW0) * GW + g) * 8 + 4 * h;
+            for (int bt = 0; bt < NBATCH; ++bt) {
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+                if (bt * GB + g >= GW) continue;                     // (compile time: the last batch may be short)
+                const int kb = ((wid - PW0) * GW + bt * GB + g) * 8 + 4 * h;
                 const bool cok = (lane & 31) < p.nb;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) bfr[g][u] = (cok && kb + u < k) ? bfr[g][u] : 0.f;
@@ -1213,6 +1223,29 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].w, bfr[g][3], acc[t], 0, 0, 0);
                     }
                 }
+            }
+            if constexpr (NBATCH > 1) {
+                if (bt + 1 < NBATCH) {                               // the next batch of operands, into the same registers
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bool cok = (lane & 31) < p.nb;
+                    const float *cp0 = p.CP + dfrag(p.j0, 0, k);
+                    const unsigned lane_off = cok ? (unsigned)(lane & 31) : 0u;
+#pragma unroll
+                    for (int g = 0; g < GB; ++g) {
+                        if ((bt + 1) * GB + g >= GW) continue;
+                        const int kb = ((wid - PW0) * GW + (bt + 1) * GB + g) * 8 + 4 * h;
+                        const float4 b4 = *reinterpret_cast<const float4 *>(cp0 + dfrag(lane_off, kb < k ? kb : 0, k));
+                        bfr[g][0] = b4.x; bfr[g][1] = b4.y; bfr[g][2] = b4.z; bfr[g][3] = b4.w;
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) {
+                            int64_t f = f0 + t * 32 + (lane & 31);
+                            if (f >= p.s) f = p.s - 1;
+                            av[g][t] = *reinterpret_cast<const float4 *>(p.Dt + dfrag(f, 0, k) + (kb + 3 < k ? kb : 0) * 32);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             }
             if (kFourAcc && pwave) {
 #pragma unroll
