@@ -51,7 +51,7 @@ std::atomic<int> g_bcd_acc{1};
 // diagnostics (modl_debug_set(MODL_DEBUG_ATOM_STAMPS, device pointer to 64 uint64)): cycle sums of the projecting
 // workgroup (atom_project_group_kernel), accumulated over the launches ([0] = launches; layout at the kernel)
 std::atomic<unsigned long long *> g_atom_stamps{nullptr};
-constexpr int kAccWords = 3 * (2 * 136 + 256 + kNB);   // int64 words of one Gram accumulator (3 bins x packed record: kAccStride below)
+constexpr int kAccWords = 3 * (2 * 136 + 256 + kNB) + 2;   // int64 words of one Gram accumulator (3 bins x packed record + the out-of-range word: kAccStride below)
 constexpr int kGramRows = 128;     // feature rows per Gram slab
 #ifndef MODL_KGROUP
 #define MODL_KGROUP 16
@@ -434,12 +434,20 @@ struct SinkGlobal {
 };
 
 // ---- the Gram accumulator: three signed fixed-point bins per entry, units 2^-70, 2^-30 and 2^10 (40 bits each: any
-// double of magnitude below 2^50 is represented to 2^-70 - the entries are Gram products of candidate atoms, O(1) -
-// and 2^22 contributions fit an int64 bin).  value = b2 2^10 + b1 2^-30 + b0 2^-70.
+// double of magnitude below 2^50 is represented to 2^-70 - the entries are Gram products of candidate atoms, O(1) in
+// dictionary units whatever the scale of the data - and 2^22 contributions fit an int64 bin).
+// value = b2 2^10 + b1 2^-30 + b0 2^-70.  A contribution outside that range (|v| >= 2^50, or not a number) raises the
+// accumulator's out-of-range word instead, and the readers of that block then sum the per-workgroup records, which
+// every workgroup still writes (560 plain stores that nobody reads otherwise): slower, any magnitude, never a wrapped
+// integer.
 constexpr int kAccBins = 3;
-constexpr int kAccStride = kAccBins * kPackStride;        // int64 words per accumulator
-static_assert(kAccStride == kAccWords, "accumulator size");
+constexpr int kAccStride = kAccBins * kPackStride;        // int64 words of the bins; word kAccStride: out of range
+static_assert(kAccStride + 2 == kAccWords, "accumulator size");
 __device__ __forceinline__ void acc_add(long long *acc, int idx, double v) {
+    if (!(fabs(v) < 0x1p50)) {
+        atomicOr(reinterpret_cast<unsigned long long *>(acc) + kAccStride, 1ull);
+        return;
+    }
     const long long b2 = (long long)(v * 0x1p-10);                       // (truncation: the remainders are exact)
     const double r1 = __builtin_fma(-(double)b2, 0x1p10, v);
     const long long b1 = (long long)(r1 * 0x1p30);
@@ -450,16 +458,18 @@ __device__ __forceinline__ void acc_add(long long *acc, int idx, double v) {
     if (b1) atomicAdd(a + 1 * kPackStride + idx, (unsigned long long)b1);
     if (b0) atomicAdd(a + idx, (unsigned long long)b0);
 }
-// this thread's elements 2 e2, 2 e2 + 1 of the accumulated record -> sink
+// this thread's elements 2 e2, 2 e2 + 1 of the accumulated record -> sink; returns the out-of-range word (uniform)
 template <typename Sink>
-__device__ __forceinline__ void acc_load(const long long *acc, int e2, bool valid, Sink sink) {
+__device__ __forceinline__ bool acc_load(const long long *acc, int e2, bool valid, Sink sink) {
     typedef long long l2v __attribute__((ext_vector_type(2)));
     const l2v *base = reinterpret_cast<const l2v *>(acc) + (valid ? e2 : 0);
     const l2v b0 = base[0], b1 = base[kPackStride / 2], b2 = base[kPackStride];   // (three 16-byte loads, one round trip)
+    const long long bad = acc[kAccStride];                                         // (the same trip)
     if (valid) {
         sink(2 * e2, ((double)b2.x * 0x1p10 + (double)b1.x * 0x1p-30) + (double)b0.x * 0x1p-70);
         sink(2 * e2 + 1, ((double)b2.y * 0x1p10 + (double)b1.y * 0x1p-30) + (double)b0.y * 0x1p-70);
     }
+    return bad != 0;
 }
 __device__ __forceinline__ void reduce_partials(const double *partial, int nslab, double (*M)[kNB + 1], double *D2) {
     reduce_records<kResStride>(partial, nslab, SinkLds{M, D2});
@@ -955,7 +965,7 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
     unsigned long long *st = (p.stamps && blockIdx.x == 0 && !fin) ? p.stamps : nullptr;
     if (st && tid == 0) st[0] = clock64();
     if (p.acc_zero && blockIdx.x == 0)                    // the accumulator the NEXT launch adds to (idle during this one)
-        for (int e = tid; e < kAccStride; e += 384) p.acc_zero[e] = 0;
+        for (int e = tid; e < kAccWords; e += 384) p.acc_zero[e] = 0;
 
     // ---------------------------------------------------------------- (B) Gram of the previous block
     // First thing in the launch: the recursion is the critical path and only needs these records.
@@ -977,8 +987,8 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
                 const bool ok = p.j0_prev + e / kNB < k;
                 cf[q] = *reinterpret_cast<const d2v *>(p.coef_all + (ok ? (int64_t)p.j0_prev * kNB + e : 0));   // (zeroed below)
             }
-            if (p.acc_in) acc_load(p.acc_in, tid, true, rsink);
-            else reduce_records_v2<kPackStride>(recs, nrec, tid, true, rsink);
+            const bool use_rec = !p.acc_in || acc_load(p.acc_in, tid, true, rsink);   // (out of range: the records)
+            if (use_rec) reduce_records_v2<kPackStride>(recs, nrec, tid, true, rsink);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int e = 2 * (tid + 256 * q);
@@ -996,8 +1006,8 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
             const int res_jj_raw = p.order[p.j0_prev + ((x < p.nb_prev) ? x : 0)];   // (unconditional, clamped: no wait behind the load)
             res_jj = (x < p.nb_prev) ? res_jj_raw : 0;
             const float budget_raw = p.norm_in[(x < p.nb_prev) ? p.j0_prev + x : 0];
-            if (p.acc_in) acc_load(p.acc_in, 256 + lane, 256 + lane < kPackStride / 2, rsink);
-            else reduce_records_v2<kPackStride>(recs, nrec, 256 + lane, 256 + lane < kPackStride / 2, rsink);
+            const bool use_rec = !p.acc_in || acc_load(p.acc_in, 256 + lane, 256 + lane < kPackStride / 2, rsink);
+            if (use_rec) reduce_records_v2<kPackStride>(recs, nrec, 256 + lane, 256 + lane < kPackStride / 2, rsink);
             res_budget = (x < p.nb_prev) ? (double)budget_raw : 0.0;
         } else {
 #pragma unroll
@@ -1366,16 +1376,15 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
                 if (p.acc_out) {
                     if (it != jt) acc_add(p.acc_out, kTri + row * 16 + col, g[r]);
                     else if (row <= col) acc_add(p.acc_out, (it ? kTri + 256 : 0) + tri_index(row, col), g[r]);
-                } else {
-                    if (it != jt) out[kTri + row * 16 + col] = g[r];                                   // tile (0,1): full
-                    else if (row <= col) out[(it ? kTri + 256 : 0) + tri_index(row, col)] = g[r];        // diagonal tiles: triangle
                 }
+                if (it != jt) out[kTri + row * 16 + col] = g[r];                                   // tile (0,1): full
+                else if (row <= col) out[(it ? kTri + 256 : 0) + tri_index(row, col)] = g[r];        // diagonal tiles: triangle
             }
         } else if (lane < kNB) {
             double t = 0;
             for (int gq = 0; gq < 8; ++gq) t += d2red[gq * kNB + lane];
             if (p.acc_out) acc_add(p.acc_out, 2 * kTri + 256 + lane, t);
-            else out[2 * kTri + 256 + lane] = t;
+            out[2 * kTri + 256 + lane] = t;
         }
     }
     if (st && tid == 0) st[12] = clock64();

@@ -300,6 +300,34 @@ def test_full_size_step_properties(DictFact):
     assert_array_equal(runs[0][1], runs[1][1])
 
 
+def test_gram_accumulator_out_of_range_falls_back_to_records(DictFact):
+    """The blocked dictionary update sums its 32 x 32 Gram contributions in fixed point (csrc/bcd.hip: acc_add, range
+    |entry| < 2^50 in dictionary units).  Candidate atoms of norm ~1e12 - statistics scaled by hand, nothing a fit
+    produces - must not come back as a wrapped integer sum: the block is then summed from the per-workgroup records,
+    the same result as with the accumulator switched off."""
+    from modl_amd._lib import lib, check, DEBUG_BCD_ACC
+    rs = np.random.RandomState(0)
+    X = ((rs.randn(256, 32) * (rs.rand(256, 32) < 0.3)).dot(rs.randn(32, 1000)) / np.sqrt(0.3 * 32)
+         + 0.1 * rs.randn(256, 1000)).astype(np.float32)
+    out = {}
+    try:
+        for acc in (1, 0):
+            check(lib.modl_debug_set(DEBUG_BCD_ACC, acc))
+            est = DictFact(n_components=64, batch_size=64, reduction=2, code_alpha=0.1, learning_rate=0.92, random_state=0)
+            est.prepare(n_samples=256, X=X[:64])
+            est.partial_fit(X[:64])
+            assert np.count_nonzero(np.diag(est.C_) > 1e-6) > 32
+            est.B_ = est.B_ * np.float32(1e13)
+            est.partial_fit(X[64:128])
+            out[acc] = (est.components_, est.comp_norm_)
+    finally:
+        check(lib.modl_debug_set(DEBUG_BCD_ACC, 1))
+    D1, D0 = out[1][0], out[0][0]
+    assert np.all(np.isfinite(D1)) and np.all(np.isfinite(out[1][1]))
+    assert np.all(np.abs(np.sqrt(np.sum(D1.astype(np.float64) ** 2, axis=1)) - 1) < 1e-4)   # projected onto the ball
+    assert rel_fro(D1, D0) < 1e-6
+
+
 @pytest.mark.parametrize('k,p,b,red', [(320, 1200, 64, 2), (512, 700, 48, 1), (40, 333, 32, 3), (250, 1200, 64, 2), (70, 2001, 96, 3)])
 def test_wide_dictionaries_f32_vs_oracle(DictFact, oracle, k, p, b, red):
     """k > 256 (two registers of coefficients per lane in the solver, 16 contraction groups per wave in the
