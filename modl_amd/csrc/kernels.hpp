@@ -45,6 +45,12 @@ int launch_cholesky(hipStream_t stream, const T *G, int64_t g_stride, const int6
                     int nmat);
 // solve F[m] F[m]^T x = rhs for b right-hand sides (rows of rhs, in place);
 // f_stride == 0: one shared factor.  Results also scattered to code rows.
+// k <= 128: factor (G[m] + alpha I) and solve in one launch, the matrix in LDS (shared matrix: all b right-hand sides;
+// g_stride != 0: one matrix and one right-hand side per workgroup).  rhs solved in place, also written to the code rows.
+template <typename T> bool ridge_small_applies(int k);
+template <typename T>
+int launch_ridge_small(hipStream_t stream, const T *G, int64_t g_stride, const int64_t *g_idx, T *rhs, int b, int k, T alpha,
+                       T *code, const int64_t *idx);
 template <typename T>
 int launch_chol_solve(hipStream_t stream, const T *F, int64_t f_stride, T *rhs, int b, int k, T *code,
                       const int64_t *idx);

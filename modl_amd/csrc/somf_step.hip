@@ -455,9 +455,14 @@ int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride
     }
     if (d.code_l1_ratio == 0.0) {                                     // ridge: dict_fact_fast.pyx:82-94, 174-197
         const int nmat = g_stride ? b : 1;
-        MODL_TRY(launch_cholesky<T>(st, G, g_stride, g_idx, Fbuf, k, (T)d.code_alpha, nmat));
-        MODL_TRY(launch_chol_solve<T>(st, Fbuf, g_stride ? (int64_t)k * k : 0, Dx, b, k, code, d_idx));
-        *nl += 2;
+        if (ridge_small_applies<T>(k)) {                              // factor + substitutions in one launch, in LDS
+            MODL_TRY(launch_ridge_small<T>(st, G, g_stride, g_idx, Dx, b, k, (T)d.code_alpha, code, d_idx));
+            *nl += 1;
+        } else {
+            MODL_TRY(launch_cholesky<T>(st, G, g_stride, g_idx, Fbuf, k, (T)d.code_alpha, nmat));
+            MODL_TRY(launch_chol_solve<T>(st, Fbuf, g_stride ? (int64_t)k * k : 0, Dx, b, k, code, d_idx));
+            *nl += 2;
+        }
         if (scatter_dst) {
             hipLaunchKernelGGL((scatter_rows_T_kernel<T, int64_t>), dim3((unsigned)b), dim3(256), 0, st, scatter_dst,
                                (int64_t)k, scatter_idx, (int64_t)b, (int64_t)k, code, (int64_t)k);
@@ -873,6 +878,8 @@ int enet_regression_abi(const T *G, int64_t g_stride, T *Dx, const T *X, int64_t
     }
     if (l1_ratio == 0) {
         const int nmat = g_stride ? (int)b : 1;
+        if (ridge_small_applies<T>((int)k))
+            return launch_ridge_small<T>(st, G, g_stride, nullptr, Dx, (int)b, (int)k, alpha, code, d_indices);
         MODL_TRY(launch_cholesky<T>(st, G, g_stride, nullptr, F, (int)k, alpha, nmat));
         return launch_chol_solve<T>(st, F, g_stride ? k * k : 0, Dx, (int)b, (int)k, code, d_indices);
     }

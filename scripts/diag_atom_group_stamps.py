@@ -38,3 +38,5 @@ for a in range(4):
 na = max(o[28], 1)
 print('   per atom: corrections + candidate %.0f, level search %.0f, output row + norm + change %.0f' %
       (o[24] / na, o[25] / na, o[26] / na))
+if o[40]:
+    print('ridge_small_kernel (thread 0): load %.0f, factor %.0f, substitutions + stores %.0f cycles' % (o[41] / o[40], o[42] / o[40], o[43] / o[40]))
