@@ -14,12 +14,14 @@ std::atomic<int> g_cd_split_diag{0};
 template void launch_split_nb<float, 2>(hipStream_t, const CdArgs<float> &);
 template void launch_split_nb<float, 4>(hipStream_t, const CdArgs<float> &);
 
-// the split solver takes a shared Gram matrix whose row stride is 128 / 256 / 512 (any k up to it: the padding is
-// dead coordinates) with kSplitRing readable rows... none needed: its prefetch wraps around inside the sweep
+// the split solver takes a Gram matrix whose row stride is 128 / 256 / 512 / 1024 (any k up to it: the padding is dead
+// coordinates), shared or one per sample; no readable rows behind it are needed (its prefetch wraps around inside the sweep)
 template <typename T>
 bool cd_split_applies(const CdArgs<T> &a) {
     const int kq = a.ldg ? a.ldg : a.k;
-    if (a.g_stride != 0 || a.g_idx != nullptr) return false;
+    // a matrix per sample (G_agg = 'average'): as they are stored, i.e. k itself one of the strides and every matrix
+    // 16-byte aligned; other k keep cd_kernel (a padded copy per sample would be b k^2 elements)
+    if (a.g_stride != 0 && (a.ldg != 0 || (a.g_stride * (int64_t)sizeof(T)) % 16 != 0)) return false;
     if (kq != 128 && kq != 256 && kq != 512 && kq != 1024) return false;
     if (a.k <= kq / 2 && kq > 128) return false;                  // (a smaller stride serves it)
     if (a.k < 32) return false;

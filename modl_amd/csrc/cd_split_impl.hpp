@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
     const int k = a.k;
     const int kc = FULL ? K : (k + 31) / 32 * 32;     // coordinates a sweep visits (the padding is dead: inv = 0)
     const int nblk = FULL ? NB : (kc + 63) / 64;
-    const T *__restrict__ Q = a.G;
+    // (a Gram matrix per sample, G_agg = 'average': the workgroup's own matrix; the index load is scalar, Q stays uniform)
+    const T *__restrict__ Q = a.G + (a.g_stride ? (a.g_idx ? a.g_idx[smp] : (int64_t)smp) * a.g_stride : 0);
     const int64_t row_out = a.idx ? a.idx[smp] : (int64_t)smp;
     T *wptr = a.code + row_out * k;
     const T *qptr = a.Dx + (int64_t)smp * k;

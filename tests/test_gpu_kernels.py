@@ -306,3 +306,37 @@ def test_cd_two_solvers_are_bit_identical(fast, dt, k, b, p, alpha):
         np.testing.assert_array_equal(out[0][1], out[1][1])
         np.testing.assert_array_equal(out[0][0], out[1][0])
         assert out[0][1].max() > 1
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+@pytest.mark.parametrize('k,b', [(128, 9), (256, 5)])
+def test_cd_two_solvers_are_bit_identical_per_sample_gram(fast, dt, k, b):
+    """A Gram matrix per sample (G_agg = 'average', dict_fact_fast.pyx:33-113) with k one of the strides of the
+    four-wavefront solver: solved from where the matrices are stored, bit for bit what the one-wavefront kernel gives."""
+    from modl_amd._lib import lib, check, DEBUG_CD_SPLIT
+    rs = np.random.RandomState(k + b)
+    p = 2 * k
+    Gm = np.empty((b, k, k), dtype=dt)
+    Dx = np.empty((b, k), dtype=dt)
+    X = np.empty((b, p), dtype=dt)
+    for i in range(b):
+        D = rs.randn(k, p).astype(dt)
+        D /= np.sqrt((D ** 2).sum(1))[:, None]
+        X[i] = ((rs.randn(k) * (rs.rand(k) < 0.1)).dot(D) + 0.1 * rs.randn(p)).astype(dt)
+        G = D.dot(D.T).astype(dt)
+        Gm[i] = (G + G.T) / 2
+        Dx[i] = X[i].dot(D.T)
+    idx = np.arange(b, dtype=np.int64)
+    out = {}
+    try:
+        for split in (0, 1):
+            check(lib.modl_debug_set(DEBUG_CD_SPLIT, split))
+            code = np.ones((b, k), dtype=dt)
+            sw = np.zeros(b, dtype=np.int32)
+            fast._enet_regression_multi_gram(Gm.copy(), Dx.copy(), X, code, idx, 0.9, 0.3, False, 1e-2, 100, sweeps=sw)
+            out[split] = (code, sw)
+    finally:
+        check(lib.modl_debug_set(DEBUG_CD_SPLIT, 1))
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    assert out[0][1].max() > 1

@@ -218,6 +218,27 @@ def test_midsize_variants_vs_oracle(DictFact, oracle, variant):
         assert rel_fro(est.G_, st.G) < 1e-9
 
 
+@pytest.mark.parametrize('dt,tol', [(np.float64, 1e-9), (np.float32, None)])
+def test_per_sample_gram_on_the_four_wavefront_solver(DictFact, oracle, dt, tol):
+    """G_agg = Dx_agg = 'average' with l1 codes at k = 128: one Gram matrix per sample (rows of G_average_), solved by
+    the four-wavefront coordinate-descent kernel straight from where they are stored (other k: cd_kernel)."""
+    kw = dict(n=160, p=400, k=128, b=16, r=2, G_agg='average', Dx_agg='average', code_alpha=0.3)
+    if tol is not None:
+        est, st = _one_step_pair(DictFact, oracle, dt, steps=3, **kw)
+        eD, eC = rel_fro(est.components_, st.D), rel_fro(est.code_[:48], st.code[:48])
+        assert eD < tol and eC < tol, (eD, eC)
+        return
+    from .conftest import assert_within_f32_noise
+    est, pr, st32, X = _make_pair(DictFact, oracle, dt, **kw)
+    X64 = X.astype(np.float64)
+    st64 = oracle.prepare(pr, n_samples=X.shape[0], X=X64)
+    est.partial_fit(X[:16])
+    oracle.partial_fit(st32, pr, X[:16])
+    oracle.partial_fit(st64, pr, X64[:16])
+    assert_within_f32_noise(est.components_, st32.D, st64.D, 'dictionary')
+    assert_within_f32_noise(est.code_[:16], st32.code[:16], st64.code[:16], 'codes')
+
+
 @pytest.mark.parametrize('agg', ['masked', 'average'])
 def test_wide_ridge_estimator_vs_oracle(DictFact, oracle, agg):
     """fMRIDictFact's configuration (ridge codes, l1 atoms) at n_components = 600 > 512 through the estimator:
