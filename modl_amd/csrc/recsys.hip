@@ -15,26 +15,30 @@
 // kernels of the dense path (csrc/bcd.hip blocked path is exactly that update).
 #include "gemm.hpp"
 #include "kernels.hpp"
+#include "chol_small.hpp"
 #include <algorithm>
 #include <cstring>
 #include <vector>
 
 namespace modl {
 
-template <typename T>
+// RPL: rows of the system per lane of the factorising wavefront (1: k <= 64, 2: k <= 128; chol_small.hpp), 0: any k that
+// fits LDS, two workgroup barriers per column
+template <typename T, int RPL>
 __global__ __launch_bounds__(256) void recsys_code_kernel(const T *Dt, int64_t p, int k, const int32_t *indptr,
                                                           const int32_t *indices, const T *data, const int64_t *row_ids,
                                                           const int64_t *code_rows, double alpha, T *code) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T *G = reinterpret_cast<T *>(smem_raw);                 // [k][k]
-    T *rhs = G + (size_t)k * k;                             // [k]
+    const int ld = RPL ? (k | 1) : k;                       // (odd row stride: a column of the factor is conflict-free)
+    T *G = reinterpret_cast<T *>(smem_raw);                 // [k][ld]
+    T *rhs = G + (size_t)k * ld;                            // [k]
     T *rows = rhs + k;                                      // [32][k] staged dictionary rows
     T *xv = rows + 32 * (size_t)k;                          // [32]
     const int64_t r = row_ids ? row_ids[blockIdx.x] : (int64_t)blockIdx.x;
     const int32_t beg = indptr[r], end = indptr[r + 1];
     const int nnz = end - beg;
     if (nnz == 0) return;                                   // recsys.py:170: rows without ratings keep their code
-    for (int e = threadIdx.x; e < k * k + k; e += 256) G[e] = 0;   // G and rhs are contiguous
+    for (int e = threadIdx.x; e < k * ld + k; e += 256) G[e] = 0;  // G and rhs are contiguous
     int *ids = reinterpret_cast<int *>(xv + 32);              // [32] item ids of the chunk
     for (int c0 = 0; c0 < nnz; c0 += 32) {
         const int nc = (nnz - c0 < 32) ? nnz - c0 : 32;
@@ -63,9 +67,9 @@ __global__ __launch_bounds__(256) void recsys_code_kernel(const T *Dt, int64_t p
         __syncthreads();
         for (int e = threadIdx.x; e < k * k; e += 256) {
             const int a = e / k, c = e % k;
-            T acc = G[e];
+            T acc = G[a * ld + c];
             for (int j = 0; j < nc; ++j) acc = fma(rows[j * k + a], rows[j * k + c], acc);
-            G[e] = acc;
+            G[a * ld + c] = acc;
         }
         for (int a = threadIdx.x; a < k; a += 256) {
             T acc = rhs[a];
@@ -75,7 +79,26 @@ __global__ __launch_bounds__(256) void recsys_code_kernel(const T *Dt, int64_t p
     }
     __syncthreads();
     const T ridge = (T)(alpha * (double)nnz / (double)p);   // alpha / reduction, reduction = p / |S_i| (:175,179)
-    for (int a = threadIdx.x; a < k; a += 256) G[a * k + a] += ridge;
+    for (int a = threadIdx.x; a < k; a += 256) G[a * ld + a] += ridge;
+    if constexpr (RPL > 0) {
+        // factor and substitutions of chol_small.hpp (four columns per pass, two barriers per pass; one wavefront solves)
+        T *dinv = reinterpret_cast<T *>(ids + 32);            // [k rounded up to 4]
+        T *part = dinv + ((k + 3) & ~3);                     // [3][RPL * 4][64]
+        __syncthreads();
+        chol_block_lds<T, RPL>(G, k, ld, dinv, part);
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            T y[RPL][1];
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) y[q][0] = (lane + 64 * q < k) ? rhs[lane + 64 * q] : (T)0;
+            chol_solve_wave_lds<T, RPL, 1>(G, dinv, k, ld, y);
+            T *out = code + (code_rows ? code_rows[blockIdx.x] : r) * k;
+#pragma unroll
+            for (int q = 0; q < RPL; ++q)
+                if (lane + 64 * q < k) out[lane + 64 * q] = y[q][0];
+        }
+        return;
+    }
     // Cholesky G = L L^T in place (symmetric storage; the diagonal of L goes to dg so that nobody overwrites an entry
     // others still read: two barriers per column instead of three), then L y = rhs, L^T x = y with ONE barrier per
     // step (every thread forms the pivot value itself; results go to their own arrays).  Same operations in the same
@@ -163,12 +186,26 @@ template <typename T>
 int recsys_codes(const T *Dt, int64_t p, int k, const int32_t *indptr, const int32_t *indices, const T *data,
                  const int64_t *row_ids, const int64_t *code_rows, int64_t b, double alpha, T *code, hipStream_t st) {
     if (b <= 0) return MODL_OK;
-    const size_t lds = sizeof(T) * ((size_t)k * k + k + 32 * (size_t)k + 32) + 32 * sizeof(int) + 16;
+    const int rpl = k <= 64 ? 1 : (k <= 128 ? 2 : 0);
+    const size_t extra = rpl ? (size_t)((k + 3) & ~3) + 3 * (size_t)rpl * 4 * 64 : 0;     // reciprocal pivots + partial sums
+    size_t lds = sizeof(T) * ((size_t)k * (rpl ? (k | 1) : k) + k + 32 * (size_t)k + 32 + extra) + 32 * sizeof(int) + 16;
+    int use = rpl;
+    if (lds > 160 * 1024 && rpl) {                           // (k near 128 in f64: the padded matrix no longer fits)
+        use = 0;
+        lds = sizeof(T) * ((size_t)k * k + k + 32 * (size_t)k + 32) + 32 * sizeof(int) + 16;
+    }
     if (lds > 160 * 1024) return MODL_EINVAL;
-    MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&recsys_code_kernel<T>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL((recsys_code_kernel<T>), dim3((unsigned)b), dim3(256), lds, st, Dt, p, k, indptr, indices, data,
-                       row_ids, code_rows, alpha, code);
+#define MODL_RECSYS_CODE(RPL)                                                                                              \
+    do {                                                                                                                   \
+        MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&recsys_code_kernel<T, RPL>),                           \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                             \
+        hipLaunchKernelGGL((recsys_code_kernel<T, RPL>), dim3((unsigned)b), dim3(256), lds, st, Dt, p, k, indptr, indices,  \
+                           data, row_ids, code_rows, alpha, code);                                                         \
+    } while (0)
+    if (use == 1) MODL_RECSYS_CODE(1);
+    else if (use == 2) MODL_RECSYS_CODE(2);
+    else MODL_RECSYS_CODE(0);
+#undef MODL_RECSYS_CODE
     MODL_LAUNCH_CHECK();
     return MODL_OK;
 }
