@@ -51,6 +51,8 @@ std::atomic<int> g_bcd_acc{1};
 // diagnostics (modl_debug_set(MODL_DEBUG_ATOM_STAMPS, device pointer to 64 uint64)): cycle sums of the projecting
 // workgroup (atom_project_group_kernel), accumulated over the launches ([0] = launches; layout at the kernel)
 std::atomic<unsigned long long *> g_atom_stamps{nullptr};
+// diagnostics (modl_debug_set(MODL_DEBUG_BCD_TINY, 0)): the separate launches of the blocked update also for small sampled sets
+std::atomic<int> g_bcd_tiny{1};
 constexpr int kAccWords = 3 * (2 * 136 + 256 + kNB) + 2;   // int64 words of one Gram accumulator (3 bins x packed record + the out-of-range word: kAccStride below)
 constexpr int kGramRows = 128;     // feature rows per Gram slab
 #ifndef MODL_KGROUP
@@ -842,6 +844,140 @@ __global__ __launch_bounds__(256) void bcd_apply_kernel(const T *a, const double
     const int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x / 4;       // 4 threads per feature
     if (f >= s) return;
     apply_row<T, 4>(a + f * kNB, CAs, Dt + sub_row(subset, f) * k, order, j0, nb, threadIdx.x % 4);
+}
+
+// ---- the blocked update of a SMALL sampled set in ONE launch ------------------------------------------------------
+// The separate-launch form of the blocked update (f64) costs five launches per block of 32 atoms - gather-GEMM, Gram,
+// recursion, apply - each of them a single small workgroup's worth of work when only a handful of features are sampled:
+// ImageDictFact's 8 x 8 patches at reduction 10 sample SIX features (k = 256: 8 blocks, 33 launches, 0.40 ms of a 1.6 ms
+// minibatch).  Here one workgroup runs the whole sweep: per block the candidates a = (B - D CP) / diag on the f64 matrix
+// cores into LDS, their Gram matrix and the old norms, the recursion on one wavefront (resolve_wave), the apply - the
+// dictionary rows it changes are the ones the next block reads, in order, inside one compute unit: 0.40 -> 0.13 ms at that
+// shape.  It costs ~10 us + 0.13 us per sampled feature per block against ~47 us for the separate launches, which spread
+// the features over several workgroups: taken up to kTinyRows sampled features (a masked minibatch of RecsysDictFact
+// touches 300-450 items and keeps the separate launches: 135 against 94 us, measured).
+constexpr int kTinyRows = 192;
+template <typename T>
+__global__ __launch_bounds__(256) void bcd_tiny_kernel(T *Dt, const T *Bt, const T *CP, const T *cdiag, const int32_t *frozen,
+                                                       const double *coef_all, const int32_t *subset, const int32_t *order,
+                                                       int s, int k, T *comp_norm) {
+    extern __shared__ __attribute__((aligned(16))) char tiny_smem[];
+    double (*M)[kNB + 1] = reinterpret_cast<double (*)[kNB + 1]>(tiny_smem);             // [NB][NB + 1]
+    double *D2 = reinterpret_cast<double *>(tiny_smem) + kNB * (kNB + 1);                // [NB]
+    double *Cs = D2 + kNB;                                                               // [NB * NB]
+    double *scr = Cs + kNB * kNB;                                                        // [4 NB]
+    double *CAs = scr + 4 * kNB;                                                         // [kResStride]
+    double *d2red = CAs + kResStride;                                                    // [8][NB]
+    T *As = reinterpret_cast<T *>(d2red + 8 * kNB);                                      // [s][NB + 1]
+    const int tid = threadIdx.x;
+    for (int j0 = 0; j0 < k; j0 += kNB) {
+        const int nb = (k - j0 < kNB) ? k - j0 : kNB;
+        stage_coef(coef_all, k, j0, Cs);
+        // (1) candidates on the f64 matrix cores: tiles of 16 features x 16 atoms, a wavefront per tile, the contraction
+        // over the k atoms in chunks of 64 whose operands - dictionary rows and coefficient columns straight from L2 -
+        // are all requested before the first product (a thread-per-element loop of dependent loads took 100 us per
+        // block at s = 300, k = 50)
+        {
+            typedef double d4v __attribute__((ext_vector_type(4)));
+            const int lane = tid & 63, wid = tid >> 6;
+            const int ntile = ((s + 15) / 16) * 2;
+            for (int t = wid; t < ntile; t += 4) {
+                const int ft = t >> 1, ct = t & 1;
+                const int f = ft * 16 + (lane & 15);
+                const int64_t rowoff = sub_row(subset, f < s ? f : s - 1) * k;
+                const int jj = ct * 16 + (lane & 15);
+                const int jc = (jj < nb) ? jj : 0;
+                d4v acc = {0.0, 0.0, 0.0, 0.0};
+                // the epilogue's operands with the first chunk (element (row (lane >> 4) + 4 r, column lane & 15) of the tile)
+                const int64_t ocolv = order[j0 + jc];
+                const T cd = cdiag[j0 + jc];
+                const int fz = frozen[j0 + jc];
+                T eB[4], eD[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int fr = ft * 16 + (lane >> 4) + 4 * r;
+                    const int64_t el = sub_row(subset, fr < s ? fr : s - 1) * k + ocolv;
+                    eB[r] = Bt[el];
+                    eD[r] = Dt[el];
+                }
+                constexpr int CH = 16;                                   // products per chunk (64 atoms)
+                for (int m0 = 0; m0 < k; m0 += 4 * CH) {
+                    double av[CH], bv[CH];
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int m = m0 + 4 * c + (lane >> 4);
+                        const int mc = (m < k) ? m : k - 1;
+                        av[c] = (double)Dt[rowoff + mc];
+                        bv[c] = (double)CP[(int64_t)mc * k + j0 + jc];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int m = m0 + 4 * c + (lane >> 4);
+                        const double a = (m < k) ? av[c] : 0.0, b = (m < k) ? bv[c] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int fr = ft * 16 + (lane >> 4) + 4 * r;
+                    const T av2 = fz ? eD[r] : (T)(((double)eB[r] - acc[r]) / (double)cd);
+                    if (fr < s) As[fr * (kNB + 1) + jj] = (jj < nb) ? av2 : (T)0;
+                }
+            }
+        }
+        __syncthreads();
+        // (2) Gram matrix of the candidates (thread: row i, four columns) and the old squared norms
+        {
+            const int i = tid / 8, jb = (tid % 8) * 4;
+            double acc[4] = {0, 0, 0, 0};
+            for (int f = 0; f < s; ++f) {
+                const double ai = (double)As[f * (kNB + 1) + i];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += ai * (double)As[f * (kNB + 1) + jb + q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) M[i][jb + q] = acc[q];
+            const int col = tid % kNB, rg = tid / kNB;
+            const int ocol = order[j0 + (col < nb ? col : 0)];
+            double d2 = 0;
+            for (int f = rg; f < s; f += 8) {
+                const double x = (double)Dt[sub_row(subset, f) * k + ocol];
+                d2 += x * x;
+            }
+            d2red[rg * kNB + col] = (col < nb) ? d2 : 0.0;
+        }
+        __syncthreads();
+        if (tid < kNB) {
+            double t = 0;
+            for (int g = 0; g < 8; ++g) t += d2red[g * kNB + tid];
+            D2[tid] = t;
+        }
+        __syncthreads();
+        // (3) the recursion of the block, one wavefront
+        if (tid < 64) {
+            const int x = tid & 31;
+            const int jj_x = (x < nb) ? order[j0 + x] : 0;
+            const double budget_x = (x < nb) ? (double)comp_norm[jj_x] : 0.0;
+            resolve_wave<T>(M, D2, Cs, jj_x, budget_x, nb, comp_norm, CAs, kNB, scr);
+        }
+        __syncthreads();
+        // (4) apply: four threads per feature
+        for (int f0 = 0; f0 < s; f0 += 64) {
+            const int f = f0 + tid / 4;
+            if (f < s) {
+                T ar[kNB];
+#pragma unroll
+                for (int m = 0; m < kNB; ++m) ar[m] = As[f * (kNB + 1) + m];
+                apply_row<T, 4>(ar, CAs, Dt + sub_row(subset, f) * k, order, j0, nb, tid % 4);
+            }
+        }
+        __syncthreads();                                   // (the rows are written: the next block reads them)
+    }
+}
+static size_t bcd_tiny_lds(size_t tsz, int64_t s) {
+    return sizeof(double) * (size_t)(kNB * (kNB + 1) + kNB + kNB * kNB + 4 * kNB + kResStride + 8 * kNB) +
+           tsz * (size_t)s * (kNB + 1) + 16;
 }
 
 // ---- fused block kernel (f32) -------------------------------------------------------------------
@@ -2149,6 +2285,16 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                                reinterpret_cast<T *>(ws + L.off_norm_in));
             MODL_LAUNCH_CHECK();
             ++nl;
+            if (std::is_same<T, double>::value && s <= kTinyRows && g_bcd_tiny.load(std::memory_order_relaxed)) {   // the whole sweep by one workgroup
+                MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bcd_tiny_kernel<T>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                hipLaunchKernelGGL((bcd_tiny_kernel<T>), dim3(1), dim3(256), bcd_tiny_lds(sizeof(T), s), stream, a.Dt, a.Bt, CP,
+                                   cdiag, frozen, coef_all, a.subset, a.order, (int)s, k, a.comp_norm);
+                MODL_LAUNCH_CHECK();
+                ++nl;
+                if (launches) *launches += nl;
+                return MODL_OK;
+            }
         }
         const size_t rec_half = (size_t)L.nslab_max * kResStride, grec_half = (size_t)kCounters * kResStride;   // >= the packed sizes
         double *gpart = reinterpret_cast<double *>(ws + L.off_gpartial);
