@@ -1048,12 +1048,17 @@ struct BcdRiderArgs {
     int t0 = 0, t1 = 0;             // tiles [t0, t1) ride with this launch
     int nslab = 0;                  // workgroups of the block step proper
     unsigned long long *dbg = nullptr;   // diagnostics: stamps of the first riding tile of a launch
+    StageRide stage;                // src != null: the workgroup behind the riding tiles copies the next minibatch's parameters
 };
 
 __device__ __forceinline__ void bcd_rider_tile(const BcdRiderArgs &r, char *smem) {
-    if (threadIdx.x >= 256) return;                  // the product uses four waves
     const int id = (int)blockIdx.x - r.nslab + r.t0;
-    if (id >= r.t1) return;
+    if (id >= r.t1) {
+        if (id == r.t1 && r.stage.src)               // (one workgroup: the next minibatch's parameter block, kernels.hpp)
+            stage_copy(r.stage.src, r.stage.dst, r.stage.off16, r.stage.n16, r.stage.ack, r.stage.use, (int)threadIdx.x, 384);
+        return;
+    }
+    if (threadIdx.x >= 256) return;                  // the product uses four waves
     if (r.wide == 32) gemm_wide_tile<32, EpiStatsSkip<float>, 128>(r.W, id, smem, (id == r.t0 && r.dbg) ? r.dbg : nullptr);
     else gemm_stats_tile<EpiStatsSkip<float>>(r.P, id, smem);     // the very tile of gemm_stats_pair_kernel: same bits
 }
@@ -2421,7 +2426,12 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             }
             BcdRiderArgs r = rid;
             ride_per = ride_tiles - ride_next;                         // whatever is left
-            const int extra = ride(r);
+            int extra = ride(r);
+            if (a.stage && a.stage->src) {                             // + one workgroup: the next minibatch's parameters
+                r.stage = *a.stage;
+                a.stage->consumed = 1;
+                hipLaunchKernelGGL(blk, dim3(nslab + extra + 1), dim3(384), lds_bytes(extra), stream, ba, r);
+            } else
             hipLaunchKernelGGL(blk, dim3(nslab + extra), dim3(384), lds_bytes(extra), stream, ba, r);
             MODL_LAUNCH_CHECK();
             nl += 1;

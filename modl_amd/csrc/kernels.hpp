@@ -97,6 +97,43 @@ struct StatsRider {
     int consumed;
 };
 
+// The parameter block of the NEXT minibatch (sample indices, subset, order, sample weights: a few KB of a pinned host
+// slot) copied to HBM by one extra workgroup of the dictionary update's last launch instead of a launch of its own at
+// the head of the next step (4.4 us of PCIe round trip on an otherwise idle chip, every step).  off16 / n16: up to four
+// ranges of 16-byte words; the acknowledgement word tells the host the slot may be refilled.
+struct StageRide {
+    const uint4 *src = nullptr;
+    uint4 *dst = nullptr;
+    unsigned int off16[4] = {0, 0, 0, 0}, n16[4] = {0, 0, 0, 0};
+    unsigned long long *ack = nullptr;
+    unsigned long long use = 0;
+    int consumed = 0;
+};
+// the copy itself, by `nthr` threads of ONE workgroup (every load of a round requested before the first store: the
+// reads cross the host link)
+__device__ __forceinline__ void stage_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, const unsigned int (&off16)[4],
+                                           const unsigned int (&n16)[4], unsigned long long *ack, unsigned long long use,
+                                           int tid, int nthr) {
+    constexpr int kMax = 4;
+    const size_t c1 = n16[0], c2 = c1 + n16[1], c3 = c2 + n16[2], total = c3 + n16[3];
+    for (size_t base = 0; base < total; base += (size_t)kMax * nthr) {
+        uint4 v[kMax];
+        size_t at[kMax];
+#pragma unroll
+        for (int u = 0; u < kMax; ++u) {
+            size_t e = base + tid + (size_t)u * nthr;
+            e = e < total ? e : total - 1;                        // (clamped, no branch around the load)
+            at[u] = e < c1 ? off16[0] + e : (e < c2 ? off16[1] + (e - c1) : (e < c3 ? off16[2] + (e - c2) : off16[3] + (e - c3)));
+            v[u] = src[at[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < kMax; ++u)
+            if (base + tid + (size_t)u * nthr < total) dst[at[u]] = v[u];
+    }
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(ack, use, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <typename T>
 struct DictUpdateArgs {
     T *Dt;                    // [p][k] dictionary, feature-major, updated in place on the subset rows
@@ -113,6 +150,7 @@ struct DictUpdateArgs {
     void *ws;                 // scratch, dict_update_workspace() bytes
     size_t ws_bytes;
     StatsRider *rider = nullptr;   // optional (f32 fused path only)
+    StageRide *stage = nullptr;    // optional (f32 fused path only): rides the last launch; `consumed` says whether it did
     double *level_hint = nullptr;  // optional [k], PERSISTENT across calls (zero-initialised): the soft-threshold level
                                    // each atom's l1 / elastic-net projection ended with, warm start of the next one
 };

@@ -213,6 +213,8 @@ struct modl_somf_plan {
     char *dws = nullptr;
     size_t dws_bytes = 0;
     size_t off_Gpad = 0; int ld_gpad = 0;   // zero-padded copy of a shared Gram whose size the vectorised solver does not take as is
+    size_t off_params2[2];             // two device parameter blocks: the next minibatch's may be staged while this one's is read
+    int cur_par = 0;                   // the block of the minibatch in flight
     size_t off_params, off_xnorm, off_Dx, off_H0, off_G, off_F, off_Linv, off_split, off_du, off_sweeps, off_Ds, off_Xs, off_codeb, off_level;
     int last_b = 0;
     int64_t last_s = 0;
@@ -232,6 +234,10 @@ struct modl_somf_plan {
     bool staged = false;
     bool has_idx = false, has_subset = false;
     std::vector<int64_t> h_order_copy;
+    // the NEXT minibatch, staged ahead by the previous step (modl_somf_partial_fit_chunk): its block is off_params2[cur_par ^ 1]
+    bool ahead = false;
+    bool ahead_has_idx = false, ahead_has_subset = false;
+    std::vector<int64_t> ahead_order;
     // profiling
     bool prof = false;
     bool head_pending = false;         // the last phase 1 was the two-phase one: phase 2 reads C and the sampled rows
@@ -317,43 +323,36 @@ int prof_flush(modl_somf_plan *pl) {
 // ONE workgroup copies the USED ranges of the slot (sample indices, subset, order, sample weights: a few KB of the
 // p-sized block); when all its loads have landed the slot may be overwritten by the host, which thread 0 tells it
 // by writing the slot's use count into the acknowledgement word of the slot itself (host memory, system scope).
-struct StageRanges { unsigned int off16[4], n16[4]; };
-__global__ __launch_bounds__(1024) void stage_params_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, StageRanges rg,
-                                                            unsigned long long *ack, unsigned long long use) {
-    // the ranges as ONE index space, every load of a round requested before the first store: the reads cross the
-    // host link (a few microseconds each way), so a round of loads per range would be four round trips instead of one
-    constexpr int kMax = 4;                                      // 4 x 1024 x 16 B = 64 KB per round of loads
-    const size_t c1 = rg.n16[0], c2 = c1 + rg.n16[1], c3 = c2 + rg.n16[2], total = c3 + rg.n16[3];
-    for (size_t base = 0; base < total; base += (size_t)kMax * 1024) {
-        uint4 v[kMax];
-        size_t at[kMax];
-#pragma unroll
-        for (int u = 0; u < kMax; ++u) {
-            size_t e = base + threadIdx.x + (size_t)u * 1024;
-            e = e < total ? e : total - 1;                        // (clamped, no branch around the load)
-            at[u] = e < c1 ? rg.off16[0] + e : (e < c2 ? rg.off16[1] + (e - c1) : (e < c3 ? rg.off16[2] + (e - c2) : rg.off16[3] + (e - c3)));
-            v[u] = src[at[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < kMax; ++u)
-            if (base + threadIdx.x + (size_t)u * 1024 < total) dst[at[u]] = v[u];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(ack, use, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+__global__ __launch_bounds__(1024) void stage_params_kernel(StageRide r) {
+    stage_copy(r.src, r.dst, r.off16, r.n16, r.ack, r.use, (int)threadIdx.x, 1024);
 }
 
-// copy the per-batch host arrays into the device parameter block through a pinned slot
+// The host half of staging a minibatch: validate, fill a pinned slot, describe the copy (into device block `par`).
+// has_idx / has_subset / order: what the step needs to know about the staged arrays.
+struct StageJob { StageRide ride; bool has_idx = false, has_subset = false; std::vector<int64_t> order; };
 template <typename T>
-int stage_batch(modl_somf_plan *pl, const modl_somf_batch *bt, hipStream_t st) {
+int stage_fill(modl_somf_plan *pl, const modl_somf_batch *bt, hipStream_t st, int par, StageJob &job) {
     const modl_somf_desc &d = pl->d;
     if (bt->b <= 0 || bt->b > d.max_batch || !bt->d_X || bt->ldx < d.p) return MODL_EINVAL;
     if (bt->s < 0 || bt->s > d.p || !bt->h_order) return MODL_EINVAL;
     if (!bt->h_subset && bt->s != d.p) return MODL_EINVAL;
     if ((d.G_agg == MODL_AGG_AVERAGE || d.Dx_agg == MODL_AGG_AVERAGE) && !bt->h_w_sample) return MODL_EINVAL;
+    // (everything is validated BEFORE a slot is taken: a rejected minibatch leaves the ring as it was)
+    if (bt->h_sample_idx) {
+        for (int i = 0; i < bt->b; ++i)
+            if (bt->h_sample_idx[i] < 0 || bt->h_sample_idx[i] >= d.n_samples) return MODL_EINVAL;
+    } else if (bt->b > d.n_samples) {
+        return MODL_EINVAL;
+    }
+    if (bt->h_subset)
+        for (int i = 0; i < bt->s; ++i)
+            if (bt->h_subset[i] < 0 || bt->h_subset[i] >= d.p) return MODL_EINVAL;
+    for (int i = 0; i < d.k; ++i)
+        if (bt->h_order[i] < 0 || bt->h_order[i] >= d.k) return MODL_EINVAL;
     const int slot = pl->slot;
     pl->slot = (slot + 1) % kStageSlots;
     char *h = pl->hstage[slot];
-    {   // the previous use of this slot (kStageSlots minibatches ago) must have been read by its staging kernel
+    {   // the previous use of this slot (kStageSlots minibatches ago) must have been read by its staging copy
         volatile unsigned long long *ack = reinterpret_cast<volatile unsigned long long *>(h + align_up(pl->params_bytes, 16));
         if (*ack < pl->slot_uses[slot]) {                      // the host is kStageSlots minibatches ahead of the device
             const auto t0 = std::chrono::steady_clock::now();
@@ -370,50 +369,68 @@ int stage_batch(modl_somf_plan *pl, const modl_somf_batch *bt, hipStream_t st) {
             pl->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
     }
-    pl->has_idx = bt->h_sample_idx != nullptr;
-    if (pl->has_idx) {
-        for (int i = 0; i < bt->b; ++i)
-            if (bt->h_sample_idx[i] < 0 || bt->h_sample_idx[i] >= d.n_samples) return MODL_EINVAL;
-        std::memcpy(h + pl->po_idx, bt->h_sample_idx, sizeof(int64_t) * (size_t)bt->b);
-    } else if (bt->b > d.n_samples) {
-        return MODL_EINVAL;
-    }
-    pl->has_subset = bt->h_subset != nullptr;
-    if (pl->has_subset) {
+    job.has_idx = bt->h_sample_idx != nullptr;
+    if (job.has_idx) std::memcpy(h + pl->po_idx, bt->h_sample_idx, sizeof(int64_t) * (size_t)bt->b);
+    job.has_subset = bt->h_subset != nullptr;
+    if (job.has_subset) {
         int32_t *dst = reinterpret_cast<int32_t *>(h + pl->po_subset);
-        for (int i = 0; i < bt->s; ++i) {
-            const int64_t f = bt->h_subset[i];
-            if (f < 0 || f >= d.p) return MODL_EINVAL;
-            dst[i] = (int32_t)f;
-        }
+        for (int i = 0; i < bt->s; ++i) dst[i] = (int32_t)bt->h_subset[i];
     }
     {
         int32_t *dst = reinterpret_cast<int32_t *>(h + pl->po_order);
-        pl->h_order_copy.assign(bt->h_order, bt->h_order + d.k);
-        for (int i = 0; i < d.k; ++i) {
-            if (bt->h_order[i] < 0 || bt->h_order[i] >= d.k) return MODL_EINVAL;
-            dst[i] = (int32_t)bt->h_order[i];
-        }
+        job.order.assign(bt->h_order, bt->h_order + d.k);
+        for (int i = 0; i < d.k; ++i) dst[i] = (int32_t)bt->h_order[i];
     }
     if (bt->h_w_sample) std::memcpy(h + pl->po_wsample, bt->h_w_sample, pl->tsz * (size_t)bt->b);
-    {
-        // the sections of the block start on 64-byte boundaries (params_layout): whole 16-byte words of each
-        StageRanges rg;
-        auto range = [&](int i, size_t off, size_t bytes) {
-            rg.off16[i] = (unsigned int)(off / 16);
-            rg.n16[i] = (unsigned int)((bytes + 15) / 16);
-        };
-        range(0, pl->po_idx, pl->has_idx ? sizeof(int64_t) * (size_t)bt->b : 0);
-        range(1, pl->po_subset, pl->has_subset ? sizeof(int32_t) * (size_t)bt->s : 0);
-        range(2, pl->po_order, sizeof(int32_t) * (size_t)d.k);
-        range(3, pl->po_wsample, bt->h_w_sample ? pl->tsz * (size_t)bt->b : 0);
-        const unsigned long long use = ++pl->slot_uses[slot];
-        pl->slot_stream[slot] = st;
-        hipLaunchKernelGGL(stage_params_kernel, dim3(1), dim3(1024), 0, st, reinterpret_cast<const uint4 *>(pl->hstage_dev[slot]),
-                           reinterpret_cast<uint4 *>(pl->dws + pl->off_params), rg,
-                           reinterpret_cast<unsigned long long *>(pl->hstage_dev[slot] + align_up(pl->params_bytes, 16)), use);
-        MODL_LAUNCH_CHECK();
+    // the sections of the block start on 64-byte boundaries (params_layout): whole 16-byte words of each
+    StageRide &rg = job.ride;
+    auto range = [&](int i, size_t off, size_t bytes) {
+        rg.off16[i] = (unsigned int)(off / 16);
+        rg.n16[i] = (unsigned int)((bytes + 15) / 16);
+    };
+    range(0, pl->po_idx, job.has_idx ? sizeof(int64_t) * (size_t)bt->b : 0);
+    range(1, pl->po_subset, job.has_subset ? sizeof(int32_t) * (size_t)bt->s : 0);
+    range(2, pl->po_order, sizeof(int32_t) * (size_t)d.k);
+    range(3, pl->po_wsample, bt->h_w_sample ? pl->tsz * (size_t)bt->b : 0);
+    rg.src = reinterpret_cast<const uint4 *>(pl->hstage_dev[slot]);
+    rg.dst = reinterpret_cast<uint4 *>(pl->dws + pl->off_params2[par]);
+    rg.ack = reinterpret_cast<unsigned long long *>(pl->hstage_dev[slot] + align_up(pl->params_bytes, 16));
+    rg.use = ++pl->slot_uses[slot];
+    rg.consumed = 0;
+    pl->slot_stream[slot] = st;
+    return MODL_OK;
+}
+// Parameter block: pinned host slot -> HBM by a kernel that reads the (device-mapped) pinned memory over
+// the host link.  A hipMemcpyAsync here would hop to the copy engine and back between two kernels of the
+// same stream, which costs several times the kernel floor.  ONE workgroup copies the USED ranges of the slot; when
+// all its loads have landed the slot may be overwritten by the host, which thread 0 tells it by writing the slot's use
+// count into the acknowledgement word of the slot itself (host memory, system scope).
+static int stage_launch(const StageRide &r, hipStream_t st) {
+    hipLaunchKernelGGL(stage_params_kernel, dim3(1), dim3(1024), 0, st, r);
+    MODL_LAUNCH_CHECK();
+    return MODL_OK;
+}
+
+// copy the per-batch host arrays into the device parameter block through a pinned slot - unless the previous step of
+// the chunk loop staged this minibatch ahead (its copy rode on that step's last launch)
+template <typename T>
+int stage_batch(modl_somf_plan *pl, const modl_somf_batch *bt, hipStream_t st) {
+    if (pl->ahead) {
+        pl->ahead = false;
+        pl->cur_par ^= 1;
+        pl->has_idx = pl->ahead_has_idx;
+        pl->has_subset = pl->ahead_has_subset;
+        pl->h_order_copy.swap(pl->ahead_order);
+    } else {
+        StageJob job;
+        MODL_TRY(stage_fill<T>(pl, bt, st, pl->cur_par ^ 1, job));
+        MODL_TRY(stage_launch(job.ride, st));
+        pl->cur_par ^= 1;
+        pl->has_idx = job.has_idx;
+        pl->has_subset = job.has_subset;
+        pl->h_order_copy.swap(job.order);
     }
+    pl->off_params = pl->off_params2[pl->cur_par];
     pl->staged = true;
     return MODL_OK;
 }
@@ -755,7 +772,8 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
 // the ranks: C is read from it, the rows of B_ are scattered into a plan-owned [p][k] array (the rank's own B_ keeps
 // its partial sums) - without a subset array the head IS that array.
 template <typename T>
-int phase2(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch *bt, const T *head, hipStream_t st) {
+int phase2(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch *bt, const T *head, hipStream_t st,
+           const modl_somf_batch *next = nullptr) {
     const modl_somf_desc &d = pl->d;
     const int k = d.k;
     const int64_t p = d.p, s = bt->s;
@@ -799,7 +817,21 @@ int phase2(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         a.ws = pl->dws + pl->off_du; a.ws_bytes = pl->du_bytes;
         a.rider = pl->ride_pending ? &pl->rider : nullptr;
         a.level_hint = reinterpret_cast<double *>(pl->dws + pl->off_level);
-        MODL_TRY(dict_update<T>(st, a, &ps.launches));
+        // the next minibatch of the chunk loop: its pinned slot is filled now and the copy into the OTHER device block
+        // rides on the update's last launch (or follows it as a launch of its own when that path has no riders); a
+        // next minibatch that does not validate is simply staged - and reported - by its own step
+        StageJob njob;
+        const bool have_next = next && stage_fill<T>(pl, next, st, pl->cur_par ^ 1, njob) == MODL_OK;
+        a.stage = have_next ? &njob.ride : nullptr;
+        const int rc_du = dict_update<T>(st, a, &ps.launches);
+        if (have_next) {
+            if (!njob.ride.consumed) (void)stage_launch(njob.ride, st);     // (the slot is taken: its copy must run)
+            pl->ahead = true;
+            pl->ahead_has_idx = njob.has_idx;
+            pl->ahead_has_subset = njob.has_subset;
+            pl->ahead_order.swap(njob.order);
+        }
+        MODL_TRY(rc_du);
         if (pl->ride_pending && !pl->rider.consumed) {                 // this dictionary update has no fused path
             const StatsRider &R = pl->rider;
             DenseOperand Xo, Cd;
@@ -977,7 +1009,9 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     pl->params_bytes = params_layout(pl);
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
-    pl->off_params = take(pl->params_bytes);
+    pl->off_params2[0] = take(pl->params_bytes);
+    pl->off_params2[1] = take(pl->params_bytes);
+    pl->off_params = pl->off_params2[0];
     pl->off_xnorm = take(t * b);
     pl->off_sweeps = take(sizeof(int32_t) * b);
     pl->off_Dx = take(t * b * k);
@@ -1063,6 +1097,7 @@ int modl_somf_code_and_partials(modl_somf_plan *pl, const modl_somf_state *st, c
                                 void *stream) {
     if (!pl || !bt) return MODL_EINVAL;
     DeviceScope dev(pl);
+    pl->ahead = false;
     return DISPATCH(pl, phase1<float>(pl, st, bt, static_cast<float *>(d_head), (hipStream_t)stream, true),
                     phase1<double>(pl, st, bt, static_cast<double *>(d_head), (hipStream_t)stream, true));
 }
@@ -1082,13 +1117,20 @@ int modl_somf_apply_and_update_dict(modl_somf_plan *pl, const modl_somf_state *s
                     phase2<double>(pl, st, bt, static_cast<const double *>(d_head), (hipStream_t)stream));
 }
 
-int modl_somf_step(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt, void *stream) {
-    // one GPU: both phases back to back, nothing travels through a head buffer
-    if (!pl || !bt) return MODL_EINVAL;
+// one GPU: both phases back to back, nothing travels through a head buffer; `next` (chunk loop only): staged ahead
+static int somf_step_next(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt,
+                          const modl_somf_batch *next, void *stream) {
     DeviceScope dev(pl);
     MODL_TRY(DISPATCH(pl, phase1<float>(pl, st, bt, nullptr, (hipStream_t)stream, false),
                       phase1<double>(pl, st, bt, nullptr, (hipStream_t)stream, false)));
-    return modl_somf_apply_and_update_dict(pl, st, bt, nullptr, stream);
+    return DISPATCH(pl, phase2<float>(pl, st, bt, nullptr, (hipStream_t)stream, next),
+                    phase2<double>(pl, st, bt, nullptr, (hipStream_t)stream, next));
+}
+
+int modl_somf_step(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt, void *stream) {
+    if (!pl || !bt) return MODL_EINVAL;
+    pl->ahead = false;                              // (a minibatch staged ahead belongs to an abandoned chunk loop)
+    return somf_step_next(pl, st, bt, nullptr, stream);
 }
 
 }  // extern "C"
@@ -1170,6 +1212,7 @@ int modl_somf_step_dist(modl_somf_plan *pl, const modl_somf_state *st, const mod
     // place, phase 2 (dictionary update from the summed head) - no cross-stream event anywhere
     if (!pl || !bt || !comm) return MODL_EINVAL;
     DeviceScope dev(pl);
+    pl->ahead = false;
     if (!pl->own_head) {
         const size_t n = (size_t)pl->d.k * pl->d.k + (size_t)pl->d.p * pl->d.k;
         MODL_HIP(hipMalloc(&pl->own_head, pl->tsz * n));
@@ -1189,39 +1232,59 @@ int modl_somf_partial_fit_chunk(modl_somf_plan *pl, const modl_somf_state *st, c
     const modl_somf_desc &d = pl->d;
     if (batch_size > d.max_batch || ldx < d.p || !(reduction >= 1.0)) return MODL_EINVAL;
     if (d.G_agg == MODL_AGG_AVERAGE || d.Dx_agg == MODL_AGG_AVERAGE) return MODL_EINVAL;   // (needs the caller's w_sample)
-    std::vector<int64_t> subset((size_t)std::max<int64_t>(d.p, 1)), order((size_t)d.k);
+    // One minibatch of look-ahead: the arrays of minibatch t + 1 are drawn (same generators, same order of draws) before
+    // step t is enqueued, so that step t can stage them - their copy to HBM rides on its last launch.
+    struct Prepared {
+        std::vector<int64_t> subset, order, idx_local;
+        modl_somf_batch bt;
+    };
+    Prepared prep[2];
+    for (auto &q : prep) { q.subset.resize((size_t)std::max<int64_t>(d.p, 1)); q.order.resize((size_t)d.k); }
     const char *X = static_cast<const char *>(d_X);
-    int64_t t = 0;
-    for (int64_t r0 = 0; r0 < n_rows; r0 += batch_size, ++t) {
+    auto prepare = [&](int64_t t, int64_t r0, Prepared &q) -> int {
         const int32_t b = (int32_t)std::min<int64_t>(batch_size, n_rows - r0);
         int64_t s = 0;
-        MODL_TRY(modl_sampler_yield_subset(sampler, reduction, subset.data(), &s));          // dict_fact.py:507
+        MODL_TRY(modl_sampler_yield_subset(sampler, reduction, q.subset.data(), &s));        // dict_fact.py:507
         const int64_t bg = h_b_global ? h_b_global[t] : (int64_t)b;
         if (bg < b) return MODL_EINVAL;
         *n_iter += bg;                                                                      // :510
         double w = 0;
         MODL_TRY(modl_batch_weight(*n_iter, bg, learning_rate, 0.0, &w));                   // :515
-        MODL_TRY(modl_rk_permutation(order_rng, d.k, order.data()));                        // :672
-        modl_somf_batch bt;
+        MODL_TRY(modl_rk_permutation(order_rng, d.k, q.order.data()));                      // :672
+        modl_somf_batch &bt = q.bt;
         std::memset(&bt, 0, sizeof(bt));
         bt.d_X = X + (size_t)r0 * (size_t)ldx * pl->tsz;
         bt.ldx = ldx;
         bt.b = b;
         bt.h_sample_idx = h_sample_idx ? h_sample_idx + r0 : nullptr;
-        std::vector<int64_t> idx_local;
         if (!h_sample_idx) {                       // rows r0 .. r0 + b - 1 of code_ (a later chunk of the same call)
-            idx_local.resize((size_t)b);
-            for (int32_t i = 0; i < b; ++i) idx_local[(size_t)i] = r0 + i;
-            bt.h_sample_idx = idx_local.data();
+            q.idx_local.resize((size_t)b);
+            for (int32_t i = 0; i < b; ++i) q.idx_local[(size_t)i] = r0 + i;
+            bt.h_sample_idx = q.idx_local.data();
         }
         if (s == d.p) { bt.s = (int32_t)d.p; bt.h_subset = nullptr; }   // every feature: no gather (any order is the same set)
-        else { bt.s = (int32_t)s; bt.h_subset = subset.data(); }
-        bt.h_order = order.data();
+        else { bt.s = (int32_t)s; bt.h_subset = q.subset.data(); }
+        bt.h_order = q.order.data();
         bt.w = w;
         bt.reduction = reduction;
         bt.b_global = bg;
-        MODL_TRY(comm ? modl_somf_step_dist(pl, st, &bt, comm, stream) : modl_somf_step(pl, st, &bt, stream));
+        return MODL_OK;
+    };
+    pl->ahead = false;
+    if (n_rows <= 0) return MODL_OK;
+    MODL_TRY(prepare(0, 0, prep[0]));
+    int64_t t = 0;
+    for (int64_t r0 = 0; r0 < n_rows; r0 += batch_size, ++t) {
+        Prepared &cur = prep[t & 1];
+        const bool more = r0 + batch_size < n_rows;
+        int rc_next = MODL_OK;
+        if (more) rc_next = prepare(t + 1, r0 + batch_size, prep[(t + 1) & 1]);
+        const modl_somf_batch *next = (more && rc_next == MODL_OK && !comm) ? &prep[(t + 1) & 1].bt : nullptr;
+        const int rc = comm ? modl_somf_step_dist(pl, st, &cur.bt, comm, stream) : somf_step_next(pl, st, &cur.bt, next, stream);
+        if (rc != MODL_OK) { pl->ahead = false; return rc; }
+        if (rc_next != MODL_OK) { pl->ahead = false; return rc_next; }
     }
+    pl->ahead = false;
     return MODL_OK;
 }
 
