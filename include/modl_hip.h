@@ -73,6 +73,7 @@ const char *modl_error_string(int code);
 #define MODL_DEBUG_BCD_ACC 5          /* 1 (default): the blocked dictionary update sums its Gram contributions with integer atomics into one fixed-point record; 0: one record per workgroup, summed by every workgroup of the next launch */
 #define MODL_DEBUG_ATOM_STAMPS 6      /* value = device pointer to 64 uint64, zeroed by the caller (0: off): cycle sums of the projecting workgroup of the grouped atom update (bcd.hip: atom_project_group_kernel) */
 #define MODL_DEBUG_BCD_TINY 7         /* 1 (default): the f64 blocked dictionary update of at most 192 sampled features runs as ONE one-workgroup launch; 0: five launches per block of 32 atoms */
+#define MODL_DEBUG_STAGE_AHEAD 8      /* 1 (default): inside modl_somf_partial_fit_chunk the next minibatch's parameters are copied to HBM by a workgroup of the dictionary update's last launch; 0: a staging launch at the head of every step */
 #define MODL_DEBUG_CD_STAMPS 3   /* value = device pointer to 1024 uint64 (0: off): shader-clock stamps of sample 0 of the two-wavefront solver */
 int modl_debug_set(int what, int64_t value);
 

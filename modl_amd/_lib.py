@@ -18,6 +18,7 @@ DEBUG_CD_SPLIT = 2
 DEBUG_BCD_ACC = 5
 DEBUG_ATOM_STAMPS = 6
 DEBUG_BCD_TINY = 7
+DEBUG_STAGE_AHEAD = 8
 AGG = {'masked': 0, 'full': 1, 'average': 2}
 OPT = {'variational': 0, 'sgd': 1}
 

@@ -517,6 +517,7 @@ extern std::atomic<unsigned long long *> g_atom_stamps; // bcd.hip
 extern std::atomic<int> g_cd_split_diag;
 extern std::atomic<int> g_bcd_acc;                      // bcd.hip
 extern std::atomic<int> g_bcd_tiny;                     // bcd.hip
+extern std::atomic<int> g_stage_ahead;                  // somf_step.hip
 
 template <typename T>
 int launch_cd(hipStream_t stream, const CdArgs<T> &a0) {
@@ -621,6 +622,10 @@ extern "C" int modl_debug_set(int what, int64_t value) {
     }
     if (what == MODL_DEBUG_ATOM_STAMPS) {
         modl::g_atom_stamps.store(reinterpret_cast<unsigned long long *>((uintptr_t)value));
+        return MODL_OK;
+    }
+    if (what == MODL_DEBUG_STAGE_AHEAD) {
+        modl::g_stage_ahead.store((int)value, std::memory_order_relaxed);
         return MODL_OK;
     }
     if (what == MODL_DEBUG_BCD_TINY) {

@@ -18,6 +18,7 @@
 // features]; the caller sums the head over the ranks (RCCL) and phase 2 runs the identical
 // dictionary update on every rank from the summed head.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -203,6 +204,10 @@ __global__ __launch_bounds__(256) void fill_kernel(T *dst, int64_t n, T v) {
 
 }  // namespace modl
 
+namespace modl {
+// diagnostics (modl_debug_set(MODL_DEBUG_STAGE_AHEAD, 0)): every minibatch of a chunk stages its own parameters
+std::atomic<int> g_stage_ahead{1};
+}
 using namespace modl;
 
 struct modl_somf_plan {
@@ -400,11 +405,7 @@ int stage_fill(modl_somf_plan *pl, const modl_somf_batch *bt, hipStream_t st, in
     pl->slot_stream[slot] = st;
     return MODL_OK;
 }
-// Parameter block: pinned host slot -> HBM by a kernel that reads the (device-mapped) pinned memory over
-// the host link.  A hipMemcpyAsync here would hop to the copy engine and back between two kernels of the
-// same stream, which costs several times the kernel floor.  ONE workgroup copies the USED ranges of the slot; when
-// all its loads have landed the slot may be overwritten by the host, which thread 0 tells it by writing the slot's use
-// count into the acknowledgement word of the slot itself (host memory, system scope).
+// the copy as a launch of its own (the first minibatch of a call, the Python loop, paths without riders)
 static int stage_launch(const StageRide &r, hipStream_t st) {
     hipLaunchKernelGGL(stage_params_kernel, dim3(1), dim3(1024), 0, st, r);
     MODL_LAUNCH_CHECK();
@@ -1279,7 +1280,8 @@ int modl_somf_partial_fit_chunk(modl_somf_plan *pl, const modl_somf_state *st, c
         const bool more = r0 + batch_size < n_rows;
         int rc_next = MODL_OK;
         if (more) rc_next = prepare(t + 1, r0 + batch_size, prep[(t + 1) & 1]);
-        const modl_somf_batch *next = (more && rc_next == MODL_OK && !comm) ? &prep[(t + 1) & 1].bt : nullptr;
+        const modl_somf_batch *next = (more && rc_next == MODL_OK && !comm && modl::g_stage_ahead.load(std::memory_order_relaxed))
+                                          ? &prep[(t + 1) & 1].bt : nullptr;
         const int rc = comm ? modl_somf_step_dist(pl, st, &cur.bt, comm, stream) : somf_step_next(pl, st, &cur.bt, next, stream);
         if (rc != MODL_OK) { pl->ahead = false; return rc; }
         if (rc_next != MODL_OK) { pl->ahead = false; return rc_next; }
