@@ -34,6 +34,7 @@
 // workgroup.
 #include "kernels.hpp"
 #include "cd_common.hpp"
+#include <algorithm>
 #include <atomic>
 #ifndef MODL_CD_SPARSE_RING
 #define MODL_CD_SPARSE_RING 4          /* (tuning) ring depth of the sparse sweep for k <= 256 */
@@ -561,6 +562,59 @@ int launch_cd_pad_gram(hipStream_t stream, const T *G, int k, T *Gp, int ldg) {
 }
 template int launch_cd_pad_gram<float>(hipStream_t, const float *, int, float *, int);
 template int launch_cd_pad_gram<double>(hipStream_t, const double *, int, double *, int);
+
+// ---- a Gram matrix per sample (G_agg = 'average') whose size is not one of the solver's strides --------------------
+// The general one-wavefront kernel loads such rows element by element (4.6x slower at k = 200, 40x at k = 320, and
+// its 16-coefficients-per-lane variants spill).  Instead the matrices of a SLICE of the minibatch are copied into
+// zero-padded slots of stride kq (the padding is dead coordinates, as for a shared matrix) and the slice goes to the
+// four-wavefront solver; slices of at most kCdSliceBytes, two launches each.  The slots must be zero outside the k x k
+// corners (the caller zero-fills the scratch once per k).  Bit-identical to cd_kernel.
+constexpr size_t kCdSliceBytes = (size_t)64 << 20;
+bool cd_split_enabled() { return g_cd_split.load(std::memory_order_relaxed) != 0; }   // (diagnostics switch MODL_DEBUG_CD_SPLIT)
+int cd_per_sample_ld(int k) { const int kq = cd_padded_ld(k); return kq < 128 ? 128 : kq; }
+size_t cd_per_sample_scratch_bytes(size_t tsz, int64_t b, int k) {
+    const size_t per = (size_t)cd_per_sample_ld(k) * cd_per_sample_ld(k) * tsz;
+    size_t n = kCdSliceBytes / per;
+    if (n < 1) n = 1;
+    if ((int64_t)n > b) n = (size_t)(b > 0 ? b : 1);
+    return n * per;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void cd_pad_gram_batch_kernel(const T *G, int64_t g_stride, const int64_t *g_idx, int first,
+                                                                int k, T *Gp, int kq) {
+    const int r = blockIdx.x, i = blockIdx.y;                        // row, sample of the slice
+    const T *g = G + (g_idx ? g_idx[first + i] : (int64_t)(first + i)) * g_stride + (int64_t)r * k;
+    T *d = Gp + ((int64_t)i * kq + r) * kq;
+    for (int c = threadIdx.x; c < k; c += 256) d[c] = g[c];
+}
+template <typename T>
+int launch_cd_per_sample(hipStream_t stream, const CdArgs<T> &a, T *slots, size_t slot_bytes) {
+    if (!a.g_stride || !slots) return MODL_EINVAL;
+    const int k = a.k, kq = cd_per_sample_ld(k);
+    const size_t per = (size_t)kq * kq * sizeof(T);
+    const int ns_max = (int)std::min<size_t>(slot_bytes / per, (size_t)a.b);
+    if (ns_max < 1) return MODL_ENOMEM;
+    for (int s0 = 0; s0 < a.b; s0 += ns_max) {
+        const int ns = a.b - s0 < ns_max ? a.b - s0 : ns_max;
+        hipLaunchKernelGGL((cd_pad_gram_batch_kernel<T>), dim3((unsigned)k, (unsigned)ns), dim3(256), 0, stream, a.G, a.g_stride,
+                           a.g_idx, s0, k, slots, kq);
+        MODL_LAUNCH_CHECK();
+        CdArgs<T> a2 = a;
+        a2.G = slots; a2.g_stride = (int64_t)kq * kq; a2.g_idx = nullptr; a2.ldg = kq; a2.g_pad_rows = 0;
+        a2.b = ns;
+        a2.Dx = a.Dx + (int64_t)s0 * k;
+        a2.xnorm2 = a.xnorm2 + s0;
+        if (a.H0) a2.H0 = a.H0 + (int64_t)s0 * k;
+        if (a.idx) a2.idx = a.idx + s0; else a2.code = a.code + (int64_t)s0 * k;
+        if (a.code2) { if (a.idx2) a2.idx2 = a.idx2 + s0; else a2.code2 = a.code2 + (int64_t)s0 * k; }
+        if (a.sweeps) a2.sweeps = a.sweeps + s0;
+        if (!cd_split_applies<T>(a2)) return MODL_EINVAL;
+        MODL_TRY(launch_cd_split<T>(stream, a2));
+    }
+    return MODL_OK;
+}
+template int launch_cd_per_sample<float>(hipStream_t, const CdArgs<float> &, float *, size_t);
+template int launch_cd_per_sample<double>(hipStream_t, const CdArgs<double> &, double *, size_t);
 
 // squared row norms: out[i] = sum_f X[i][f]^2   (dict_fact_fast.pyx:334 uses dot(y, y))
 template <typename T>

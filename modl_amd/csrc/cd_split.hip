@@ -19,9 +19,9 @@ template void launch_split_nb<float, 4>(hipStream_t, const CdArgs<float> &);
 template <typename T>
 bool cd_split_applies(const CdArgs<T> &a) {
     const int kq = a.ldg ? a.ldg : a.k;
-    // a matrix per sample (G_agg = 'average'): as they are stored, i.e. k itself one of the strides and every matrix
-    // 16-byte aligned; other k keep cd_kernel (a padded copy per sample would be b k^2 elements)
-    if (a.g_stride != 0 && (a.ldg != 0 || (a.g_stride * (int64_t)sizeof(T)) % 16 != 0)) return false;
+    // a matrix per sample (G_agg = 'average'): every matrix 16-byte aligned; k itself one of the strides (solved where
+    // the matrices are stored) or zero-padded copies of a slice of the minibatch (launch_cd_per_sample, cd_solver.hip)
+    if (a.g_stride != 0 && (a.g_stride * (int64_t)sizeof(T)) % 16 != 0) return false;
     if (kq != 128 && kq != 256 && kq != 512 && kq != 1024) return false;
     if (a.k <= kq / 2 && kq > 128) return false;                  // (a smaller stride serves it)
     if (a.k < 32) return false;

@@ -32,6 +32,12 @@ template <typename T> int launch_cd(hipStream_t stream, const CdArgs<T> &a);
 // cd_split.hip: the same solver with the chain and the k-wide update on two wavefronts (shared Gram, 64 < k <= 512)
 template <typename T> bool cd_split_applies(const CdArgs<T> &a);
 template <typename T> int launch_cd_split(hipStream_t stream, const CdArgs<T> &a);
+// a Gram matrix PER SAMPLE whose size is not one of the solver's strides: slices of the minibatch through zero-padded
+// copies (slots: scratch of cd_per_sample_scratch_bytes, zero outside the k x k corners - zero-filled once per k)
+bool cd_split_enabled();
+int cd_per_sample_ld(int k);
+size_t cd_per_sample_scratch_bytes(size_t tsz, int64_t b, int k);
+template <typename T> int launch_cd_per_sample(hipStream_t stream, const CdArgs<T> &a, T *slots, size_t slot_bytes);
 int cd_padded_ld(int k);   // the row stride the vectorised solver wants for k coefficients (k itself when it fits already)
 // Gp[ldg + 16][ldg] (zero-filled once by the caller) <- G[k][k]
 template <typename T> int launch_cd_pad_gram(hipStream_t stream, const T *G, int k, T *Gp, int ldg);

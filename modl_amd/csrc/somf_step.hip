@@ -249,6 +249,8 @@ struct modl_somf_plan {
                                        // of B from the (summed) head instead of the rank's partial statistics
     int64_t head_elems = 0;            // k*k + (rows of B in the head) * k
     void *Bsum = nullptr;              // [p][k] (lazily allocated): the summed rows of B_, scattered for the dictionary update
+    void *Gslots = nullptr;            // zero-padded copies of per-sample Gram matrices (lazily allocated, launch_cd_per_sample)
+    size_t Gslots_bytes = 0;
     void *own_head = nullptr;          // [k*k + p*k] (lazily allocated): the head buffer of modl_somf_step_dist
     bool ride_pending = false;         // single-GPU step: the B_ update of the rows that were not sampled rides along
     StatsRider rider{};                // the dictionary update (see StatsRider)
@@ -508,6 +510,18 @@ int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride
     a.alpha = (T)((T)d.code_alpha * (T)d.code_l1_ratio);
     a.beta = (T)((double)(T)d.code_alpha * (1.0 - (double)(T)d.code_l1_ratio));
     a.tol = (T)d.tol; a.max_iter = d.max_iter; a.positive = d.code_pos;
+    if (g_stride && k >= 32 && cd_split_enabled() && !cd_split_applies<T>(a)) {
+        // a Gram matrix per sample of a size the four-wavefront solver does not take as stored: zero-padded copies,
+        // a slice of the minibatch at a time (cd_solver.hip: launch_cd_per_sample)
+        if (!pl->Gslots) {
+            pl->Gslots_bytes = cd_per_sample_scratch_bytes(sizeof(T), d.max_batch, k);
+            MODL_HIP(hipMalloc(&pl->Gslots, pl->Gslots_bytes));
+            MODL_HIP(hipMemsetAsync(pl->Gslots, 0, pl->Gslots_bytes, st));
+        }
+        MODL_TRY(launch_cd_per_sample<T>(st, a, static_cast<T *>(pl->Gslots), pl->Gslots_bytes));
+        *nl += 2;
+        return MODL_OK;
+    }
     MODL_TRY(launch_cd<T>(st, a));
     ++*nl;
     return MODL_OK;
@@ -942,6 +956,12 @@ int enet_regression_abi(const T *G, int64_t g_stride, T *Dx, const T *X, int64_t
     a.alpha = alpha * l1_ratio;
     a.beta = (T)((double)alpha * (1.0 - (double)l1_ratio));
     a.tol = tol; a.max_iter = max_iter; a.positive = positive;
+    if (g_stride && k >= 32 && k <= 1024 && cd_split_enabled() && !cd_split_applies<T>(a)) {  // one Gram matrix per sample, any k: zero-padded slots
+        const size_t slot_bytes = cd_per_sample_scratch_bytes(sizeof(T), b, (int)k);   // (at the end of the workspace)
+        T *slots = reinterpret_cast<T *>(w + need - align_up(slot_bytes, 256));
+        MODL_HIP(hipMemsetAsync(slots, 0, slot_bytes, st));
+        return launch_cd_per_sample<T>(st, a, slots, slot_bytes);
+    }
     return launch_cd<T>(st, a);
 }
 
@@ -959,9 +979,10 @@ size_t modl_enet_regression_workspace(int dtype, int64_t b, int64_t k, int multi
     const size_t t = dtype == MODL_F32 ? 4 : 8;
     if (b < 0 || k < 0) return 0;
     const size_t kq = (!multi_gram && k > 0 && k <= 1024) ? (size_t)modl::cd_padded_ld((int)k) : 0;   // padded shared Gram (cd_padded_ld)
+    const size_t slots = (multi_gram && k >= 32 && k <= 1024) ? align_up(modl::cd_per_sample_scratch_bytes(t, b, (int)k), 256) : 0;
     return align_up(t * (size_t)b, 256) + align_up(t * (size_t)b * k, 256) +
            align_up(t * ((size_t)k * k * ((multi_gram && k <= 512) ? (size_t)b : 1) + modl::chol_wide_scratch_elems((int)k)), 256) +
-           ((kq && kq != (size_t)k) ? align_up(t * (kq + 16) * kq, 256) : 0);
+           ((kq && kq != (size_t)k) ? align_up(t * (kq + 16) * kq, 256) : 0) + slots;
 }
 
 #define ABI_REG(SFX, T)                                                                                            \
@@ -1061,6 +1082,7 @@ void modl_somf_plan_destroy(modl_somf_plan *pl) {
     if (!pl) return;
     if (pl->dws) (void)hipFree(pl->dws);
     if (pl->Bsum) (void)hipFree(pl->Bsum);
+    if (pl->Gslots) (void)hipFree(pl->Gslots);
     if (pl->own_head) (void)hipFree(pl->own_head);
     for (int i = 0; i < kStageSlots; ++i) {
         if (pl->hstage[i]) (void)hipHostFree(pl->hstage[i]);

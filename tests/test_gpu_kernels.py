@@ -309,10 +309,11 @@ def test_cd_two_solvers_are_bit_identical(fast, dt, k, b, p, alpha):
 
 
 @pytest.mark.parametrize('dt', [np.float32, np.float64])
-@pytest.mark.parametrize('k,b', [(128, 9), (256, 5)])
+@pytest.mark.parametrize('k,b', [(128, 9), (256, 5), (70, 9), (200, 7), (600, 3)])
 def test_cd_two_solvers_are_bit_identical_per_sample_gram(fast, dt, k, b):
-    """A Gram matrix per sample (G_agg = 'average', dict_fact_fast.pyx:33-113) with k one of the strides of the
-    four-wavefront solver: solved from where the matrices are stored, bit for bit what the one-wavefront kernel gives."""
+    """A Gram matrix per sample (G_agg = 'average', dict_fact_fast.pyx:33-113) on the four-wavefront solver - k one of
+    its strides: solved from where the matrices are stored; any other k: through zero-padded copies of a slice of the
+    minibatch (launch_cd_per_sample) - bit for bit what the one-wavefront kernel gives."""
     from modl_amd._lib import lib, check, DEBUG_CD_SPLIT
     rs = np.random.RandomState(k + b)
     p = 2 * k
