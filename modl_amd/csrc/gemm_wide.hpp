@@ -58,8 +58,13 @@ WideProblem<Epi> plan_wide(const DenseOperand &A, const DenseOperand &B, int64_t
 // one tile (256 threads: callers with larger workgroups retire the other threads first)
 // BN atoms per tile (256: every atom of the metric's shape, X fetched once; 128: twice, half the tile time): each of
 // the 4 wavefronts takes BN / 4 atoms
-template <int BM, class Epi, int BN = 256, int BK = kWideBK, int PAD = kWidePad>
+// SWZ: no padding; column c of row kk lives at c ^ ((kk & 1) << 4) instead - odd rows swap the two 16-float halves of
+// every 32-float group, so the four rows of a fragment read fall on the two bank halves alternately exactly as with a
+// row stride of 16 (mod 32), and a float4 stays a float4.  (PAD = 4 - what fits two workgroups per compute unit at
+// BN = 256 - is the 4-way conflict of the note above.)
+template <int BM, class Epi, int BN = 256, int BK = kWideBK, int PAD = kWidePad, bool SWZ = false>
 __device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int tile, char *smem, unsigned long long *dbg = nullptr) {
+    auto sw = [](int kk, int c) { return SWZ ? (c ^ ((kk & 1) << 4)) : c; };
     if (dbg && threadIdx.x == 0) dbg[0] = clock64();   // diagnostics (scripts/diag_stamps.py): phases of one tile
     constexpr int TI = BM / 16, WN = BN / 4, TJ = WN / 16;
     constexpr int NA = kWideKmax * BM / 4 / 256;           // float4 of the X tile per thread
@@ -90,7 +95,7 @@ __device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int ti
         for (int q = 0; q < NA; ++q) {
             const int e = tid + 256 * q, kk = e / (BM / 4), fv = (e % (BM / 4)) * 4;
             const bool in = kk < K && m0 + fv < M;
-            if (kk < kpad) *reinterpret_cast<f4v *>(&As[kk][fv]) = in ? a[q] : zero4;
+            if (kk < kpad) *reinterpret_cast<f4v *>(&As[kk][sw(kk, fv)]) = in ? a[q] : zero4;
         }
     }
     f4v bq[NB];
@@ -107,7 +112,7 @@ __device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int ti
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const int e = tid + 256 * q, kl = e / (BN / 4), jv = (e % (BN / 4)) * 4;
-            *reinterpret_cast<f4v *>(&Bs[buf][kl][jv]) = (n0 + jv < N) ? bq[q] : zero4;   // (rows >= K meet zero rows of X)
+            *reinterpret_cast<f4v *>(&Bs[buf][kl][sw(kl, jv)]) = (n0 + jv < N) ? bq[q] : zero4;   // (rows >= K meet zero rows of X)
         }
     };
     request_b(0);
@@ -148,9 +153,9 @@ __device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int ti
             const int kr = ks * 4 + (lane >> 4);
             float af[TI], bf[TJ];
 #pragma unroll
-            for (int ti = 0; ti < TI; ++ti) af[ti] = As[kt * BK + kr][16 * ti + (lane & 15)];
+            for (int ti = 0; ti < TI; ++ti) af[ti] = As[kt * BK + kr][sw(kt * BK + kr, 16 * ti + (lane & 15))];
 #pragma unroll
-            for (int tj = 0; tj < TJ; ++tj) bf[tj] = Bs[buf][kr][WN * wid + 16 * tj + (lane & 15)];
+            for (int tj = 0; tj < TJ; ++tj) bf[tj] = Bs[buf][kr][sw(kr, WN * wid + 16 * tj + (lane & 15))];
 #pragma unroll
             for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -179,7 +184,7 @@ __device__ __forceinline__ void gemm_wide_tile(const WideProblem<Epi> &P, int ti
 }
 
 // the small problem (code^T code -> C_, 32 x 32 tiles of gemm_stats_tile) and the wide one in ONE launch
-template <int BM, class Epi0, class Epi1, int BN = 256, int BK = kWideBK, int PAD = kWidePad>
+template <int BM, class Epi0, class Epi1, int BN = 256, int BK = kWideBK, int PAD = kWidePad, bool SWZ = false>
 __global__ __launch_bounds__(256) void gemm_stats_wide_pair_kernel(DenseProblem<float, Epi0> P0, WideProblem<Epi1> P1) {
     extern __shared__ __attribute__((aligned(16))) char wide_smem[];
     int id = (int)blockIdx.x;
@@ -190,16 +195,16 @@ __global__ __launch_bounds__(256) void gemm_stats_wide_pair_kernel(DenseProblem<
     }
     id -= t0;
     if (id >= P1.tm * P1.tn) return;
-    gemm_wide_tile<BM, Epi1, BN, BK, PAD>(P1, id, wide_smem);
+    gemm_wide_tile<BM, Epi1, BN, BK, PAD, SWZ>(P1, id, wide_smem);
 }
 
-template <int BM, class Epi0, class Epi1, int BN = 256, int BK = kWideBK, int PAD = kWidePad>
+template <int BM, class Epi0, class Epi1, int BN = 256, int BK = kWideBK, int PAD = kWidePad, bool SWZ = false>
 int launch_gemm_stats_wide_pair(hipStream_t stream, const DenseProblem<float, Epi0> &P0, const WideProblem<Epi1> &P1,
                                 int *launches = nullptr) {
     const int total = P0.tn * P0.tm + P1.tm * P1.tn;
     if (total <= 0) return MODL_OK;
     constexpr size_t lds = wide_lds_bytes<BM, BN, BK, PAD>() > kStatsLds ? wide_lds_bytes<BM, BN, BK, PAD>() : kStatsLds;
-    auto kern = gemm_stats_wide_pair_kernel<BM, Epi0, Epi1, BN, BK, PAD>;
+    auto kern = gemm_stats_wide_pair_kernel<BM, Epi0, Epi1, BN, BK, PAD, SWZ>;
     MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, stream, P0, P1);
     MODL_LAUNCH_CHECK();

@@ -539,13 +539,15 @@ int stats_pair(hipStream_t st, const DenseOperand &A0, const DenseOperand &B0, i
     if constexpr (std::is_same<T, float>::value) {
         auto P0 = plan_stats<Epi0>(A0, B0, M0, N0, K, e0);
         // a VERY tall second problem (the whole p x k product at p >= 65 536): k-wide tiles, X read once (gemm_wide.hpp),
-        // 32 features x 256 atoms with a 16-sample code tile: 70 KB of LDS, TWO workgroups per compute unit, so one
-        // stages its X tile / runs its epilogue while the other is on the matrix cores (67 TFLOP/s at p = 200 000;
-        // 64 features, one workgroup per compute unit: 56); at p = 10 000 the 32 x 32 tiles are faster (27 us against
-        // 37 us: ten times the workgroups to hide latency)
+        // 32 features x 256 atoms.  The tile is latency-bound (its code tiles come from L2 once per 32 features, its old
+        // values and its X tile from HBM), so what counts is how many workgroups share a compute unit: an 8-sample code
+        // tile and swizzled, unpadded LDS rows make it 48 KB - THREE per compute unit: 0.351 ms at p = 200 000 (75 TFLOP/s,
+        // 48 % of the f32 matrix peak); 16 samples, padded rows, two per unit: 0.385-0.397; 32 samples, one per unit:
+        // 0.489; 4 samples, four per unit: 0.387 (a barrier every 256 matrix-core cycles); 64 features, one per unit:
+        // 0.46.  At p = 10 000 the 32 x 32 tiles are faster (27 us against 37 us: ten times the workgroups to hide latency)
         if (P0.ok && cdiv(M1, 64) >= 1024 && !dbg) {
             auto W = plan_wide<32, Epi1>(A1, B1, M1, N1, K, e1);
-            if (W.ok) return launch_gemm_stats_wide_pair<32, Epi0, Epi1, 256, 16, 4>(st, P0, W, launches);
+            if (W.ok) return launch_gemm_stats_wide_pair<32, Epi0, Epi1, 256, 8, 0, true>(st, P0, W, launches);
         }   // (32 x 128 wide tiles as their own launch at p = 10 000: 40 us against 28 us for the 32 x 32 tiles, measured)
         auto P1 = plan_stats<Epi1>(A1, B1, M1, N1, K, e1);
         if (P0.ok && P1.ok) {
