@@ -195,3 +195,22 @@ def test_rk_continues_numpy_legacy_stream():
         assert lib.modl_rk_set_mt_state(h, k2.ctypes.data_as(C.c_void_p), 625) != 0      # pos out of range
     finally:
         lib.modl_rk_destroy(h)
+
+
+def test_debug_switch_numbers_match_the_header(lib):
+    """The diagnostics switches of modl_debug_set: the numbers the Python side uses are the header's, they are distinct,
+    and the library accepts each of them (restoring the default) and rejects an unknown one - no GPU involved."""
+    import re
+    from modl_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(__file__), '..', 'include', 'modl_hip.h')).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r'#define\s+MODL_(DEBUG_\w+)\s+(\d+)', hdr)}
+    assert len(set(defs.values())) == len(defs)
+    for name, value in defs.items():
+        if hasattr(_lib, name):
+            assert getattr(_lib, name) == value, name
+    defaults = {'DEBUG_CD_SPARSE_PCT': -1, 'DEBUG_CD_SPLIT': 1, 'DEBUG_BCD_ACC': 1, 'DEBUG_BCD_TINY': 1, 'DEBUG_STAGE_AHEAD': 1,
+                'DEBUG_CD_STAMPS': 0, 'DEBUG_ATOM_STAMPS': 0, 'DEBUG_CD_SPLIT_DIAG': 0}
+    assert set(defaults) == set(defs)
+    for name, dflt in defaults.items():
+        assert lib.modl_debug_set(defs[name], dflt) == 0, name
+    assert lib.modl_debug_set(max(defs.values()) + 1, 0) != 0
