@@ -1871,7 +1871,8 @@ __device__ __forceinline__ void store_row4(double *row, const double (&v)[EPT]) 
 // lands at or left of the root from EITHER side, and the iteration rises monotonically from there - no check, no safety
 // factor (4.4 -> 3.3 passes per atom on the fMRI shape).  A step that lands at or below zero proves nothing and falls
 // back to the cold start (which also settles "inside the ball").  The output row has room for EPT * 256 elements (x is
-// zero beyond n, and so is the output).  Leaves the result in x; returns its enet norm.
+// zero beyond n, and so is the output).  Leaves the result in x; returns THIS THREAD'S share of its enet norm (the
+// block-wide sum is off the chain of the projections: the caller forms it for all atoms of a group in one exchange).
 // dbg[4] = passes | warm << 16, dbg[5] = clock when the level is known.
 template <typename T, int EPT, bool L1>
 __device__ __forceinline__ double enet_project_slim(double (&x)[EPT], T *out, double radius, double l1_ratio,
@@ -1890,7 +1891,7 @@ __device__ __forceinline__ double enet_project_slim(double (&x)[EPT], T *out, do
             x[e] = (double)o[e];
         }
         store_row4<EPT>(out, o);
-        return (s2 <= radius) ? s2 : radius;
+        return threadIdx.x == 0 ? ((s2 <= radius) ? s2 : radius) : 0.0;   // (as a partial sum: thread 0 carries the value)
     }
     const bool zero = !(radius > 0.0);                       // enet.pyx:57-59 (radius == 0 -> zeros)
     const double gamma = L1 ? 0.0 : 2.0 / l1_ratio - 2.0;
@@ -1982,8 +1983,7 @@ __device__ __forceinline__ double enet_project_slim(double (&x)[EPT], T *out, do
         nrm += a * (l1_ratio + (1.0 - l1_ratio) * a);
     }
     store_row4<EPT>(out, o);
-    block_sum1_pp(nrm, red4, par);
-    return nrm;
+    return nrm;                                              // this thread's share: the caller sums a whole group's at once
 }
 
 // The projections of a group, in sweep order, by ONE workgroup of four wavefronts (one per SIMD).  Per atom: the
@@ -2004,6 +2004,7 @@ void atom_project_group_kernel(const T *C, int64_t s, int k, AtomGroupN<G> g, T 
     constexpr int64_t ldr = (int64_t)EPT * 256;                         // row stride of num / dold / stage_out
     __shared__ double red4[16];
     __shared__ double s_coef[G][G], s_cjj[G], s_cn[G], s_old[G], s_lvl[G];
+    __shared__ double s_nrm[G][256];                                    // the threads' shares of the atoms' norms
     const unsigned long long t0 = dbg ? clock64() : 0;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     double X[2][EPT];
@@ -2079,9 +2080,8 @@ void atom_project_group_kernel(const T *C, int64_t s, int k, AtomGroupN<G> g, T 
             x[e] = (atom_elem(e) < s) ? (double)val : 0.0;
         }
         const unsigned long long tb = dbg ? clock64() : 0;
-        const double nrm = enet_project_slim<T, EPT, L1>(x, stage_out + (int64_t)a * ldr, radius, rho, red4, par, s_lvl[a],
-                                                         level_hint ? level_hint + j : nullptr, dbg ? dbg + 32 : nullptr);
-        if (threadIdx.x == 0) comp_norm[j] = (T)(radius - nrm);         // :690-692
+        s_nrm[a][threadIdx.x] = enet_project_slim<T, EPT, L1>(x, stage_out + (int64_t)a * ldr, radius, rho, red4, par, s_lvl[a],
+                                                              level_hint ? level_hint + j : nullptr, dbg ? dbg + 32 : nullptr);
         if (a + 1 < G) {
 #pragma unroll
             for (int e = 0; e < EPT; ++e) dl[a < G - 1 ? a : 0][e] = (atom_elem(e) < s) ? x[e] - (double)dd[e] : 0.0;
@@ -2097,6 +2097,19 @@ void atom_project_group_kernel(const T *C, int64_t s, int k, AtomGroupN<G> g, T 
         }
     };
     for_each_int(std::make_integer_sequence<int, G>{}, step);
+    // the norms of the projected atoms, all at once (one barrier and two wave sums per wavefront instead of a block
+    // exchange per atom on the chain of the projections): wavefront w takes atoms w, w + 4, ...
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < G / 4; ++h) {
+        const int a = 4 * h + __builtin_amdgcn_readfirstlane(wid);
+        if (a < g.n) {                                                   // (wavefront-uniform)
+            double v = (s_nrm[a][lane] + s_nrm[a][lane + 64]) + (s_nrm[a][lane + 128] + s_nrm[a][lane + 192]);
+            v = wave_sum(v);
+            const double radius = (double)(T)(s_cn[a] + s_old[a]);
+            if (lane == 0) comp_norm[g.j[a]] = (T)(radius - v);          // :690-692
+        }
+    }
     if (dbg && threadIdx.x == 0) dbg[20] += clock64() - t0;
 }
 
