@@ -304,15 +304,21 @@ int launch_ridge_small(hipStream_t stream, const T *G, int64_t g_stride, const i
     // right-hand sides per wavefront: the whole minibatch in one pass of the four wavefronts while it fits 6 each (the
     // chains of a batch interleave; beyond that a step is bound by its instruction count and further passes follow)
     const int per_wave = g_stride ? 1 : (int)cdiv(b, 4);
+    // (a step of the substitutions costs its instruction count, i.e. grows with the batch: the smallest batch that covers
+    // the minibatch in one pass - 20 records: 5 per wavefront, not 6 + 6 + 6 + 2)
     if (k <= 64) {
         if (per_wave <= 1) MODL_RIDGE_SMALL(1, 1);
         else if (per_wave <= 2) MODL_RIDGE_SMALL(1, 2);
+        else if (per_wave <= 3) MODL_RIDGE_SMALL(1, 3);
         else if (per_wave <= 4) MODL_RIDGE_SMALL(1, 4);
+        else if (per_wave <= 5) MODL_RIDGE_SMALL(1, 5);
         else MODL_RIDGE_SMALL(1, 6);
     } else {
         if (per_wave <= 1) MODL_RIDGE_SMALL(2, 1);
         else if (per_wave <= 2) MODL_RIDGE_SMALL(2, 2);
+        else if (per_wave <= 3) MODL_RIDGE_SMALL(2, 3);
         else if (per_wave <= 4) MODL_RIDGE_SMALL(2, 4);
+        else if (per_wave <= 5) MODL_RIDGE_SMALL(2, 5);
         else MODL_RIDGE_SMALL(2, 6);
     }
 #undef MODL_RIDGE_SMALL
