@@ -212,10 +212,14 @@ class Run:
                             comp_l1_ratio=0, learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0)
         first = self.stream.chunk(0, prefetch_next=self.total_rows > CHUNK)
         self.est.prepare(n_samples=CHUNK, X=first[:K_COMP] if X0 is None else X0)
+        # N > 1: the head is summed by the library's own RCCL communicator, one library call per chunk of minibatches
+        # (default whenever the process group runs RCCL); --torch-collective: dist.all_reduce between two calls per
+        # minibatch (also what a gloo group - ranks sharing a GPU in the tests - uses)
+        torch_route = bool(getattr(args, 'torch_collective', False)) or getattr(args, 'backend', 'nccl') != 'nccl'
+        self.est._native_rccl = not torch_route
         if getattr(args, 'force_reduce', False):                 # testing only: the N > 1 step with one rank
-            self.est._two_phase = True
             self.est._force_reduce = True
-        self.est._native_rccl = bool(getattr(args, 'native_rccl', False))
+            self.est._two_phase = torch_route
         self.be = self.est._backend
         self.row = 0                                              # next unseen row of the stream
         self.enqueue_s = 0.0
@@ -314,7 +318,20 @@ def run_gpu(args, reduction, steps, warmup, rank, world, device, breakdown=True)
         res['replicas_identical'] = bool(torch.equal(lo, hi))
     res['rows_generated'] = run.stream.generated_rows
     res['rows_fitted'] = run.row
+    res['collective'] = collective_route(run, world, args)
     return res
+
+
+def collective_route(run, world, args):
+    """which of the two exchange routes of DESIGN §7 actually ran (None with one rank and no forced reduction)"""
+    if world == 1 and not getattr(args, 'force_reduce', False):
+        return None
+    if getattr(run.be, 'comm', None):
+        return 'native RCCL: modl_somf_partial_fit_chunk + the library\'s own communicator (one call per chunk of minibatches)'
+    why = ''
+    if getattr(run.be, '_comm_failed', False):
+        why = ' (FALLBACK: the library\'s communicator could not be created)'
+    return 'torch.distributed all_reduce (%s) between the two phases, two library calls per minibatch%s' % (args.backend, why)
 
 
 def steady_state(args, reduction, rank, world, device, steps, burn_in):
@@ -356,6 +373,7 @@ def cpu_baseline(X, reduction, budget_s=20.0, threads=None):
                         comp_l1_ratio=0, learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0)
     with limiter:
         st = orc.prepare(pr, n_samples=n_rows, X=X[:K_COMP])
+        st.sweeps = []                                  # (one int32 per sample and minibatch: for the parity block)
         done, t0 = 0, time.perf_counter()
         for r0 in range(0, n_rows, BATCH):
             orc.partial_fit(st, pr, X[r0:r0 + BATCH], np.arange(r0, r0 + BATCH))
@@ -372,7 +390,35 @@ def cpu_baseline(X, reduction, budget_s=20.0, threads=None):
         out['calibration'] = cal.get('summary', cal)
     except (OSError, ValueError):
         out['calibration'] = None
-    return out
+    return out, st, done
+
+
+def parity_block(X, done, st, reduction, device):
+    """The timed code path against the CPU oracle, outside the timed region: ONE `partial_fit` call on the rows the
+    cpu_baseline leg has just fitted with the oracle (same estimator parameters and seeds), i.e. one
+    modl_somf_partial_fit_chunk call of `done / 256` minibatches - staging ring wrap-around, both device parameter
+    blocks, the staging copy and the statistics product riding on the dictionary update's launches.  f32 against the
+    oracle's f32 run: relative Frobenius distances; `sweeps_agree` = share of the last minibatch's samples that did
+    the oracle's number of coordinate-descent sweeps."""
+    import torch
+    from modl_amd import DictFact
+    est = DictFact(n_components=K_COMP, batch_size=BATCH, reduction=reduction, code_alpha=1.0, code_l1_ratio=1,
+                   comp_l1_ratio=0, learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0)
+    est.prepare(n_samples=X.shape[0], X=X[:K_COMP])
+    Xd = torch.from_numpy(X[:done]).to(device)
+    t0 = time.perf_counter()
+    est.partial_fit(Xd, np.arange(done))
+    dt = time.perf_counter() - t0
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) /
+                             max(np.linalg.norm(np.asarray(b, np.float64)), 1e-300))
+    sw_gpu = est._backend.last_sweeps()
+    sw_ref = np.asarray(st.sweeps[-1]) if st.sweeps else None
+    return dict(steps=done // BATCH, rows=done, path='DictFact.partial_fit -> modl_somf_partial_fit_chunk (one call)',
+                rel_fro_D=rel(est.components_, st.D), rel_fro_C=rel(est.C_, st.C),
+                rel_fro_code=rel(est.code_[:done], st.code[:done]),
+                sweeps_agree=None if sw_ref is None or len(sw_ref) != len(sw_gpu) else float(np.mean(sw_gpu == sw_ref)),
+                n_iter_equal=bool(est.n_iter_ == st.n_iter), gpu_ms_per_step=dt / max(done // BATCH, 1) * 1e3,
+                reference='oracle/somf_oracle.py (f32), the run of the cpu_baseline leg')
 
 
 def survey_flops_per_sample(k, p, b, s, sweeps):
@@ -481,8 +527,11 @@ def main():
     ap.add_argument('--force-reduce', action='store_true',
                     help='testing only: run the multi-GPU step (two phases + RCCL all-reduces) even with one rank')
     ap.add_argument('--native-rccl', action='store_true',
-                    help='N > 1: the all-reduce issued by the library itself (modl_somf_step_dist, RCCL on the compute stream) '
-                         'instead of torch.distributed')
+                    help='(the default with --backend nccl; kept for older command lines) N > 1: the all-reduce issued by '
+                         'the library itself (RCCL on the compute stream, one library call per chunk of minibatches)')
+    ap.add_argument('--torch-collective', action='store_true',
+                    help='N > 1: dist.all_reduce of the head between two library calls per minibatch instead of the '
+                         'library\'s own RCCL communicator')
     ap.add_argument('--share-gpu', action='store_true', help='testing only: every rank uses cuda:0 (needs --backend gloo)')
     args = ap.parse_args()
 
@@ -520,7 +569,7 @@ def main():
         dt, sweeps, dom, prof = res['dt'], res['sweeps'], res['dom'], res['prof']
         samples = args.steps * BATCH * world
         s_mean = P_FEAT / args.reduction
-        ride = world == 1 and args.reduction > 1 and not args.force_reduce
+        ride = args.reduction > 1          # (the riding statistics product is active in the two-phase step too)
         fl = step_flops(K_COMP, P_FEAT, BATCH, s_mean, sweeps, ride=ride)
         by = step_bytes(K_COMP, P_FEAT, BATCH, s_mean, ride=ride)
         sections = {}
@@ -555,7 +604,8 @@ def main():
                                reduction=args.reduction, global_batch=BATCH * world,
                                parallelism='dp%d (row-sharded minibatch; all-reduce of the C increment and of the sampled rows '
                                            'of the B increment before each dictionary update; every rank keeps its own partial '
-                                           'B_ for the rows that were not sampled)' % world),
+                                           'B_ for the rows that were not sampled)' % world,
+                               collective=res['collective']),
                    roofline=roof, sections=sections, cd_sweeps_mean=sweeps, cd_sweeps_max=res['sweeps_max'],
                    step_tflops=total_fl / (dt / args.steps) / 1e12, finite=res['finite'],
                    replicas_identical=res['replicas_identical'],
@@ -564,9 +614,11 @@ def main():
                    steady_state=steady)
         if world == 1 and not args.no_cpu_baseline:
             Xh = M1Stream(P_FEAT, 1234, device, rank=0).rows(0, 40 * BATCH).cpu().numpy()
-            out['cpu_baseline'] = cpu_baseline(Xh, args.reduction)
+            out['cpu_baseline'], st_ref, done = cpu_baseline(Xh, args.reduction)
+            out['parity'] = parity_block(Xh, done, st_ref, args.reduction, device)
         else:
             out['cpu_baseline'] = None
+            out['parity'] = None
     if world > 1 or args.force_reduce:
         dist.barrier()
         dist.destroy_process_group()

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MODL_ABI_VERSION 2
+#define MODL_ABI_VERSION 3
 
 #define MODL_OK 0
 #define MODL_EINVAL (-1)   /* bad argument */
@@ -327,12 +327,17 @@ int modl_somf_step(modl_somf_plan *plan, const modl_somf_state *st, const modl_s
  * - the same draws in the same order as the Python loop, so the same bits.  h_sample_idx: n_rows rows of code_ or
  * NULL (0 .. n_rows-1); h_b_global: rows of each GLOBAL minibatch (several ranks) or NULL (== this rank's).
  * Plans with *_agg == average need the per-sample weights the caller keeps (sample_n_iter_): MODL_EINVAL - use the
- * per-minibatch calls.  Asynchronous on `stream` (blocks only on the 8-deep staging ring). */
+ * per-minibatch calls.  Asynchronous on `stream` (blocks only on the 8-deep staging ring).
+ * With a communicator the staging copy of minibatch t + 1 rides on the last launch of step t's dictionary update
+ * exactly as on one GPU (ABI 3; before, a multi-GPU step spent a launch on it).
+ * Errors (ABI 3): *n_done (may be NULL) receives the number of minibatches that were enqueued completely; when a
+ * minibatch fails, *n_iter, `sampler` and `order_rng` are left where the LAST ENQUEUED minibatch left them (the draws
+ * of the look-ahead are rewound), so that the caller can correct the input and continue the reference's streams. */
 struct modl_comm;
 int modl_somf_partial_fit_chunk(modl_somf_plan *plan, const modl_somf_state *st, const void *d_X, int64_t ldx,
                                 int64_t n_rows, int32_t batch_size, const int64_t *h_sample_idx, modl_sampler *sampler,
                                 modl_rk *order_rng, int64_t *n_iter, double learning_rate, double reduction,
-                                const int64_t *h_b_global, struct modl_comm *comm, void *stream);
+                                const int64_t *h_b_global, struct modl_comm *comm, int64_t *n_done, void *stream);
 
 /* Several GPUs (one process per GPU, the rows of a global minibatch of b_global rows split over the ranks; every
  * rank passes the same subset / order / w).  The recursions C_ <- (1 - w) C_ + (w / b_global) code^T code and

@@ -140,7 +140,7 @@ _sig('modl_somf_code_and_partials', C.c_int, _vp, _P(SomfState), _P(SomfBatch), 
 _sig('modl_somf_apply_and_update_dict', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
 _sig('modl_somf_step', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp)
 _sig('modl_somf_partial_fit_chunk', C.c_int, _vp, _P(SomfState), _vp, _i64, _i64, C.c_int32, _vp, _vp, _vp, _P(_i64), _f64,
-     _f64, _vp, _vp, _vp)
+     _f64, _vp, _vp, _P(_i64), _vp)
 _sig('modl_somf_head_elems', C.c_int, _vp, _P(_i64))
 _sig('modl_comm_unique_id', C.c_int, _vp)
 _sig('modl_comm_create', C.c_int, _vp, C.c_int, C.c_int, _P(_vp))
@@ -160,6 +160,10 @@ _sig('modl_somf_prof_reset', C.c_int, _vp)
 
 # every symbol declared in include/modl_hip.h (checked by tests/test_abi.py)
 DECLARED = [n for n in dir(lib) if n.startswith('modl_')]
+
+
+def error_string(rc):
+    return lib.modl_error_string(rc).decode()
 
 
 def check(rc, what=''):

@@ -1231,13 +1231,12 @@ int modl_comm_all_reduce_sum(modl_comm *c, void *d_buf, int64_t n, int dtype, vo
                             (hipStream_t)stream) == 0 ? MODL_OK : MODL_ERCCL;
 }
 
-int modl_somf_step_dist(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt, modl_comm *comm,
-                        void *stream) {
-    // several GPUs, everything on ONE stream: phase 1 (partial statistics + head), ncclAllReduce of the head in
-    // place, phase 2 (dictionary update from the summed head) - no cross-stream event anywhere
-    if (!pl || !bt || !comm) return MODL_EINVAL;
+// several GPUs, everything on ONE stream: phase 1 (partial statistics + head), ncclAllReduce of the head in place,
+// phase 2 (dictionary update from the summed head) - no cross-stream event anywhere; `next` (chunk loop only): the
+// following minibatch, staged ahead by phase 2's last launch exactly as in the one-GPU step
+static int somf_step_dist_next(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt,
+                               const modl_somf_batch *next, modl_comm *comm, void *stream) {
     DeviceScope dev(pl);
-    pl->ahead = false;
     if (!pl->own_head) {
         const size_t n = (size_t)pl->d.k * pl->d.k + (size_t)pl->d.p * pl->d.k;
         MODL_HIP(hipMalloc(&pl->own_head, pl->tsz * n));
@@ -1245,14 +1244,22 @@ int modl_somf_step_dist(modl_somf_plan *pl, const modl_somf_state *st, const mod
     MODL_TRY(DISPATCH(pl, phase1<float>(pl, st, bt, static_cast<float *>(pl->own_head), (hipStream_t)stream, true),
                       phase1<double>(pl, st, bt, static_cast<double *>(pl->own_head), (hipStream_t)stream, true)));
     MODL_TRY(modl_comm_all_reduce_sum(comm, pl->own_head, pl->head_elems, pl->d.dtype, stream));
-    return DISPATCH(pl, phase2<float>(pl, st, bt, static_cast<const float *>(pl->own_head), (hipStream_t)stream),
-                    phase2<double>(pl, st, bt, static_cast<const double *>(pl->own_head), (hipStream_t)stream));
+    return DISPATCH(pl, phase2<float>(pl, st, bt, static_cast<const float *>(pl->own_head), (hipStream_t)stream, next),
+                    phase2<double>(pl, st, bt, static_cast<const double *>(pl->own_head), (hipStream_t)stream, next));
+}
+
+int modl_somf_step_dist(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt, modl_comm *comm,
+                        void *stream) {
+    if (!pl || !bt || !comm) return MODL_EINVAL;
+    pl->ahead = false;                              // (a minibatch staged ahead belongs to an abandoned chunk loop)
+    return somf_step_dist_next(pl, st, bt, nullptr, comm, stream);
 }
 
 int modl_somf_partial_fit_chunk(modl_somf_plan *pl, const modl_somf_state *st, const void *d_X, int64_t ldx, int64_t n_rows,
                                 int32_t batch_size, const int64_t *h_sample_idx, modl_sampler *sampler, modl_rk *order_rng,
                                 int64_t *n_iter, double learning_rate, double reduction, const int64_t *h_b_global,
-                                modl_comm *comm, void *stream) {
+                                modl_comm *comm, int64_t *n_done, void *stream) {
+    if (n_done) *n_done = 0;
     if (!pl || !st || !d_X || !sampler || !order_rng || !n_iter || n_rows < 0 || batch_size <= 0) return MODL_EINVAL;
     const modl_somf_desc &d = pl->d;
     if (batch_size > d.max_batch || ldx < d.p || !(reduction >= 1.0)) return MODL_EINVAL;
@@ -1266,11 +1273,39 @@ int modl_somf_partial_fit_chunk(modl_somf_plan *pl, const modl_somf_state *st, c
     Prepared prep[2];
     for (auto &q : prep) { q.subset.resize((size_t)std::max<int64_t>(d.p, 1)); q.order.resize((size_t)d.k); }
     const char *X = static_cast<const char *>(d_X);
+    // what a failed minibatch is rewound to: the state of both generators and of the counter at the start of the call
+    // (the look-ahead has drawn for minibatch t + 1 when step t fails; a retry must continue the reference's streams
+    // where the last FITTED minibatch left them, dict_fact.py:507,672)
+    const int64_t n_iter0 = *n_iter;
+    std::vector<char> sampler0(modl_sampler_state_bytes(sampler));
+    MODL_TRY(modl_sampler_get_state(sampler, sampler0.data(), sampler0.size()));
+    uint32_t order_key0[624];
+    int32_t order_pos0 = 0;
+    MODL_TRY(modl_rk_get_mt_state(order_rng, order_key0, &order_pos0));
+    auto global_rows = [&](int64_t t, int64_t r0) -> int64_t {
+        return h_b_global ? h_b_global[t] : std::min<int64_t>(batch_size, n_rows - r0);
+    };
+    auto fail = [&](int64_t done, int rc) -> int {
+        pl->ahead = false;
+        if (n_done) *n_done = done;
+        // replay exactly the draws of the `done` fitted minibatches (the two generators are independent streams)
+        int64_t s = 0;
+        if (modl_sampler_set_state(sampler, sampler0.data(), sampler0.size()) != MODL_OK ||
+            modl_rk_set_mt_state(order_rng, order_key0, order_pos0) != MODL_OK) return rc;
+        int64_t it = n_iter0;
+        for (int64_t t = 0; t < done; ++t) {
+            (void)modl_sampler_yield_subset(sampler, reduction, prep[0].subset.data(), &s);
+            (void)modl_rk_permutation(order_rng, d.k, prep[0].order.data());
+            it += global_rows(t, t * (int64_t)batch_size);
+        }
+        *n_iter = it;
+        return rc;
+    };
     auto prepare = [&](int64_t t, int64_t r0, Prepared &q) -> int {
         const int32_t b = (int32_t)std::min<int64_t>(batch_size, n_rows - r0);
         int64_t s = 0;
         MODL_TRY(modl_sampler_yield_subset(sampler, reduction, q.subset.data(), &s));        // dict_fact.py:507
-        const int64_t bg = h_b_global ? h_b_global[t] : (int64_t)b;
+        const int64_t bg = global_rows(t, r0);
         if (bg < b) return MODL_EINVAL;
         *n_iter += bg;                                                                      // :510
         double w = 0;
@@ -1297,20 +1332,22 @@ int modl_somf_partial_fit_chunk(modl_somf_plan *pl, const modl_somf_state *st, c
     };
     pl->ahead = false;
     if (n_rows <= 0) return MODL_OK;
-    MODL_TRY(prepare(0, 0, prep[0]));
+    { const int rc0 = prepare(0, 0, prep[0]); if (rc0 != MODL_OK) return fail(0, rc0); }
     int64_t t = 0;
     for (int64_t r0 = 0; r0 < n_rows; r0 += batch_size, ++t) {
         Prepared &cur = prep[t & 1];
         const bool more = r0 + batch_size < n_rows;
         int rc_next = MODL_OK;
         if (more) rc_next = prepare(t + 1, r0 + batch_size, prep[(t + 1) & 1]);
-        const modl_somf_batch *next = (more && rc_next == MODL_OK && !comm && modl::g_stage_ahead.load(std::memory_order_relaxed))
+        const modl_somf_batch *next = (more && rc_next == MODL_OK && modl::g_stage_ahead.load(std::memory_order_relaxed))
                                           ? &prep[(t + 1) & 1].bt : nullptr;
-        const int rc = comm ? modl_somf_step_dist(pl, st, &cur.bt, comm, stream) : somf_step_next(pl, st, &cur.bt, next, stream);
-        if (rc != MODL_OK) { pl->ahead = false; return rc; }
-        if (rc_next != MODL_OK) { pl->ahead = false; return rc_next; }
+        const int rc = comm ? somf_step_dist_next(pl, st, &cur.bt, next, comm, stream)
+                            : somf_step_next(pl, st, &cur.bt, next, stream);
+        if (rc != MODL_OK) return fail(t, rc);
+        if (rc_next != MODL_OK) return fail(t + 1, rc_next);
     }
     pl->ahead = false;
+    if (n_done) *n_done = t;
     return MODL_OK;
 }
 

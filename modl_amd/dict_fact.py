@@ -145,6 +145,7 @@ class HipBackend:
         if getattr(self, '_order_rk', None):
             lib.modl_rk_destroy(self._order_rk)
             self._order_rk = None
+        self._host_chunk_buffers = None               # 2 x 256 MB pinned + 2 x 256 MB of HBM (_HostChunks)
 
     def __del__(self):
         try:
@@ -288,7 +289,9 @@ class HipBackend:
         """A whole chunk of minibatches in ONE call (modl_somf_partial_fit_chunk): subset draws, minibatch weights and
         atom orders are drawn inside the library - the atom order by a generator that is loaded with numpy's legacy
         MT19937 state and handed back afterwards, so `np_random_state` continues exactly as if it had drawn them
-        (dict_fact.py:672).  Returns the new n_iter_."""
+        (dict_fact.py:672).  Returns (new n_iter_, minibatches enqueued); an error raised here carries both as
+        `e.n_iter` / `e.n_done` - n_iter_, the sampler and `np_random_state` are then where the last enqueued minibatch
+        left them."""
         if getattr(self, '_order_rk', None) is None:
             h = C.c_void_p()
             check(lib.modl_rk_create(0, C.byref(h)), 'modl_rk_create')
@@ -299,36 +302,65 @@ class HipBackend:
         idx = None if sample_indices is None else np.ascontiguousarray(sample_indices, dtype=np.int64)
         bg = None if b_global is None else np.ascontiguousarray(b_global, dtype=np.int64)
         n = C.c_int64(int(n_iter))
+        done = C.c_int64(0)
         st = self._state()
         try:
-            check(lib.modl_somf_partial_fit_chunk(
+            rc = lib.modl_somf_partial_fit_chunk(
                 self.plan, C.byref(st), ptr(Xh), Xh.stride(0), Xh.shape[0], int(batch_size),
                 None if idx is None else idx.ctypes.data_as(C.c_void_p), sampler._h, self._order_rk, C.byref(n),
                 float(learning_rate), float(reduction), None if bg is None else bg.ctypes.data_as(C.c_void_p), comm,
-                stream_ptr(self.device)), 'modl_somf_partial_fit_chunk')
+                C.byref(done), stream_ptr(self.device))
         finally:
             out = np.empty(624, dtype=np.uint32)
             p2 = C.c_int32()
             check(lib.modl_rk_get_mt_state(self._order_rk, out.ctypes.data_as(C.c_void_p), C.byref(p2)))
             np_random_state.set_state((kind, out, int(p2.value), has_gauss, cached))
-        return int(n.value)
+        if rc != 0:
+            # the library has rewound both generators and n_iter to the last minibatch it enqueued completely: the caller
+            # books those minibatches before it raises (ChunkError carries the counts)
+            try:
+                check(rc, 'modl_somf_partial_fit_chunk')
+            except Exception as e:
+                e.n_iter, e.n_done = int(n.value), int(done.value)
+                raise
+        return int(n.value), int(done.value)
 
     def native_comm(self, dist):
         """An RCCL communicator owned by the library (modl_comm_*): rank 0 draws the unique id, torch.distributed
-        only ships its 128 bytes."""
-        if getattr(self, 'comm', None) is None:
+        only ships its 128 bytes (dist=None: one rank, nothing is shipped).  Returns None - on EVERY rank - when the
+        communicator cannot be created on some rank (no librccl, RCCL error): the caller then uses torch's collective."""
+        if getattr(self, 'comm', None) is None and not getattr(self, '_comm_failed', False):
+            rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
             ident = (C.c_char * 128)()
-            if dist.get_rank() == 0:
-                check(lib.modl_comm_unique_id(ident), 'modl_comm_unique_id')
-            box = [bytes(ident.raw)]
-            if dist.get_world_size() > 1:
+            rc = lib.modl_comm_unique_id(ident) if rank == 0 else 0
+            box = [bytes(ident.raw), rc]
+            if world > 1:
                 dist.broadcast_object_list(box, src=0)
-            ident = C.create_string_buffer(box[0], 128)
             h = C.c_void_p()
-            with torch.cuda.device(self.device):
-                check(lib.modl_comm_create(ident, dist.get_rank(), dist.get_world_size(), C.byref(h)), 'modl_comm_create')
-            self.comm = h
-        return self.comm
+            if box[1] == 0:
+                ident = C.create_string_buffer(box[0], 128)
+                with torch.cuda.device(self.device):
+                    rc = lib.modl_comm_create(ident, rank, world, C.byref(h))
+            else:
+                rc = box[1]
+            if world > 1:                                   # the same decision on every rank
+                flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32,
+                                    device=self.device if dist.get_backend() == 'nccl' else 'cpu')
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = bool(flag.item())
+            else:
+                ok = rc == 0
+            if ok:
+                self.comm = h
+            else:
+                if rc == 0:
+                    lib.modl_comm_destroy(h)
+                self._comm_failed = True
+                import warnings
+                warnings.warn('modl_amd: the library\'s own RCCL communicator could not be created (%s); the all-reduce '
+                              'of the statistics head goes through torch.distributed instead'
+                              % _lib.error_string(rc if rc != 0 else -6))
+        return getattr(self, 'comm', None)
 
     def step_dist(self, comm, Xh, batch, idx, subset, order, w_sample, w, reduction, b_global):
         """Several GPUs, ONE call: phase 1, ncclAllReduce of the head, phase 2 - all on the current stream."""
@@ -435,11 +467,14 @@ class _HostChunks:
         if cache is None or cache[0] != (rows, X.shape[1], td):
             cache = ((rows, X.shape[1], td),
                      [torch.empty((rows, X.shape[1]), dtype=td, pin_memory=True) for _ in range(2)],
-                     [torch.empty((rows, X.shape[1]), dtype=td, device=self.device) for _ in range(2)])
+                     [torch.empty((rows, X.shape[1]), dtype=td, device=self.device) for _ in range(2)],
+                     [None, None], [None, None])
             be._host_chunk_buffers = cache
+        self.cache = cache
         self.pinned, self.dev = cache[1], cache[2]
-        self.copied = [None, None]        # event: the upload out of pinned[i] / into dev[i] has finished
-        self.consumed = [None, None]      # event: the fit has finished reading dev[i]
+        # events carried over from the last call on these buffers (it returns without synchronising):
+        self.consumed = list(cache[3])    # the fit has finished reading dev[i]
+        self.copied = list(cache[4])      # the upload out of pinned[i] / into dev[i] has finished
         self.stream = torch.cuda.Stream(self.device)
         self.pool = ThreadPoolExecutor(1)
 
@@ -460,6 +495,7 @@ class _HostChunks:
         return r0, r1
 
     def __iter__(self):
+        finished = False
         try:
             pending = self.pool.submit(self._stage, 0)
             for c in range(self.n_chunks):
@@ -472,13 +508,21 @@ class _HostChunks:
                 ev = torch.cuda.Event()
                 ev.record(main)
                 self.consumed[c % 2] = ev
+            finished = True
         finally:
-            # also on an error in a minibatch (or a generator that is dropped half way): no worker thread, no upload
-            # out of the pinned buffers and no fit reading the device buffers may outlive the call - the buffers are
-            # reused by the next one
             self.pool.shutdown(wait=True)
-            self.stream.synchronize()
-            torch.cuda.current_stream(self.device).synchronize()
+            if finished:
+                # every upload has been waited for by the fit (main.wait_event above); the device buffers are still
+                # being read by the enqueued minibatches: the NEXT call waits for these events before it reuses them
+                self.cache[3][:] = self.consumed
+                self.cache[4][:] = self.copied
+            else:
+                # an error in a minibatch (or a generator that is dropped half way): no upload out of the pinned
+                # buffers and no fit reading the device buffers may outlive the call - the buffers are reused
+                self.stream.synchronize()
+                torch.cuda.current_stream(self.device).synchronize()
+                self.cache[3][:] = [None, None]
+                self.cache[4][:] = [None, None]
 
 
 class _SubsetsAhead:
@@ -651,7 +695,8 @@ def _state_property(name, getter=None, setter=None, summed=False, local=False):
         if be is None:
             raise AttributeError('%s can only be set after prepare()' % name)
         if summed:
-            value = _rank0_share(value)
+            if not local:                                 # (the local twin sets THIS rank's share as given)
+                value = _rank0_share(value)
             self.__dict__['_stats_on_rank0'] = False      # (true again after the next consolidate_statistics())
         (setter(be, value) if setter else be.set(name, value))
     return property(fget, fset)
@@ -692,7 +737,8 @@ class DictFact(CodingMixin, BaseEstimator):
     components_ = _state_property('components_', lambda be: be.get_dictionary(), lambda be, v: be.set_dictionary(v))
     # Several ranks: C_ and B_ live as per-rank partial sums.  `B_` / `C_` are the sums over the ranks -
     # a COLLECTIVE read, every rank must perform it; `local_B_` / `local_C_` are this rank's share, no communication
-    # (after consolidate_statistics() rank 0's share is the whole statistic).  Setting one puts the value on rank 0.
+    # (after consolidate_statistics() rank 0's share is the whole statistic).  Setting `B_` / `C_` puts the value on
+    # rank 0 (zeros elsewhere: the sum is the value); setting a `local_` twin sets this rank's share as given.
     B_ = _state_property('B_', lambda be: be.get_B(), lambda be, v: be.set_B(v), summed=True)
     C_ = _state_property('C', summed=True)
     local_B_ = _state_property('B_', lambda be: be.get_B(), lambda be, v: be.set_B(v), summed=True, local=True)
@@ -737,6 +783,10 @@ class DictFact(CodingMixin, BaseEstimator):
         n = X.shape[0]
         batches = list(gen_batches(n, self.batch_size))
         b_global = self._global_batch_sizes(n, len(batches))
+        if b_global is not None and len(batches):
+            # several ranks: whatever route the minibatches take (Python loop, one call per chunk), C_ / B_ are per-rank
+            # partial sums again afterwards - a pickle written now must say so (consolidate_statistics() resets this)
+            self._stats_on_rank0 = False
         # host input that does not fit a chunk is streamed: pinned, double-buffered chunks of whole minibatches
         chunk_rows = getattr(self, '_host_chunk_rows', None) or \
             max(1, HOST_CHUNK_BYTES // max(1, X.shape[1] * be.dtype.itemsize))
@@ -751,19 +801,26 @@ class DictFact(CodingMixin, BaseEstimator):
         try:
             if chunk_call:
                 # the whole per-minibatch loop in ONE library call per chunk (same draws, same order, same bits)
-                world = self._world()
-                comm = None
-                if world > 1:
-                    import torch.distributed as dist
-                    comm = be.native_comm(dist)
+                comm = self._native_comm(be)
                 for r0, Xh in chunks:
                     nb = -(-Xh.shape[0] // self.batch_size)
                     idx = get_sub_slice(sample_indices, slice(r0, r0 + Xh.shape[0]))
-                    self.n_iter_ = be.fit_chunk(Xh, self.batch_size, idx, self.feature_sampler_, self.random_state,
-                                                self.n_iter_, self.learning_rate, self.reduction,
-                                                None if b_global is None else b_global[t:t + nb], comm)
-                    for batch in gen_batches(Xh.shape[0], self.batch_size):      # dict_fact.py:511, per minibatch
+                    err = None
+                    try:
+                        self.n_iter_, done = be.fit_chunk(Xh, self.batch_size, idx, self.feature_sampler_,
+                                                          self.random_state, self.n_iter_, self.learning_rate,
+                                                          self.reduction,
+                                                          None if b_global is None else b_global[t:t + nb], comm)
+                    except Exception as e:
+                        # the library left n_iter, the sampler and the order generator where the last minibatch it
+                        # enqueued left them: book exactly those minibatches, then report
+                        if not hasattr(e, 'n_done'):
+                            raise
+                        self.n_iter_, done, err = e.n_iter, e.n_done, e
+                    for batch in list(gen_batches(Xh.shape[0], self.batch_size))[:done]:   # dict_fact.py:511
                         self.sample_n_iter_[idx[batch]] += 1
+                    if err is not None:
+                        raise err
                     t += nb
                 chunks = ()
             for r0, Xh in chunks:
@@ -798,9 +855,32 @@ class DictFact(CodingMixin, BaseEstimator):
             return False
         if not isinstance(self.random_state, np.random.RandomState) or not isinstance(self.feature_sampler_, Sampler):
             return False
-        if self._world() > 1 and not getattr(self, '_native_rccl', False):
+        if (self._world() > 1 or getattr(self, '_force_reduce', False)) and not self._wants_native_rccl(be):
             return False
         return True
+
+    def _wants_native_rccl(self, be):
+        """Several ranks: is the head summed by the library's own RCCL communicator (one call per chunk of minibatches,
+        the all-reduce on the compute stream) or by torch.distributed between two calls per minibatch?  `_native_rccl`
+        = True / False decides; unset, the library's communicator is used whenever the process group runs RCCL
+        (backend 'nccl') - gloo groups (tests, ranks sharing a GPU) keep torch's collective.  A communicator that
+        cannot be created falls back to torch's, on every rank (HipBackend.native_comm)."""
+        if not hasattr(be, 'native_comm') or getattr(be, '_comm_failed', False):
+            return False
+        flag = getattr(self, '_native_rccl', None)
+        if flag is not None:
+            return bool(flag)
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl'
+
+    def _native_comm(self, be):
+        """the library's communicator for this call, or None (one rank without a forced reduction / torch's route)"""
+        world = self._world()
+        if world == 1 and not getattr(self, '_force_reduce', False):
+            return None
+        if not self._wants_native_rccl(be):
+            return None
+        return be.native_comm(_dist())
 
     def set_params(self, **params):
         """dict_fact.py:339-357: only a switch of G_agg to 'full' is honoured for
@@ -968,11 +1048,10 @@ class DictFact(CodingMixin, BaseEstimator):
         # only what the dictionary update reads - C_ and the sampled rows of B_ - is summed over the ranks.
         if world > 1:
             self._stats_on_rank0 = False
-        if getattr(self, '_native_rccl', False) and hasattr(be, 'step_dist'):
+        comm = self._native_comm(be) if hasattr(be, 'step_dist') else None
+        if comm is not None:
             # the exchange inside the library (modl_somf_step_dist): RCCL called directly, on the compute stream
-            import torch.distributed as dist
-            be.step_dist(be.native_comm(dist), Xh, batch, sample_indices, subset, order, w_sample, w, self.reduction,
-                         b_global)
+            be.step_dist(comm, Xh, batch, sample_indices, subset, order, w_sample, w, self.reduction, b_global)
             return
         head = be.phase1(Xh, batch, sample_indices, subset, order, w_sample, w, self.reduction, b_global)
         if world > 1 or getattr(self, '_force_reduce', False):       # (the latter: single-rank RCCL test of this path)

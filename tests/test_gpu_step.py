@@ -588,6 +588,120 @@ def test_chunk_call_equals_python_loop(DictFact, case):
         assert_array_equal(a, c)
 
 
+@pytest.mark.parametrize('r', [10, 1])
+def test_timed_path_long_horizon_vs_oracle(DictFact, oracle, r):
+    """The code path bench.py times, over a long horizon: ONE partial_fit call = ONE modl_somf_partial_fit_chunk call of
+    up to 48 minibatches at the metric's full shape (k = 256, p = 10 000, b = 256) - the 8-deep pinned staging ring
+    wraps five times, both device parameter blocks alternate, the staging copy of minibatch t + 1 and the statistics
+    product of the rows that were not sampled ride on the dictionary update's launches, warm starts are chunk-local -
+    against the CPU oracle fitted on the same rows.  Calls of 8, 16, 32 and 48 minibatches (each from a fresh
+    estimator) are compared with the oracle's state after as many: f64 <= 1e-8 on D, C and B[:, :64]; f32 within the
+    reference algorithm's own f32 noise (2 noise + 1e-5); n_iter_ and both generators left in step with the oracle's
+    (all 48 subset draws: a subset that differed would move D by O(1))."""
+    from .conftest import m1_rows, HEADLINE_KW, assert_within_f32_noise
+    import torch
+    p, b, marks = 10000, 256, (8, 16, 32, 48)
+    n = marks[-1] * b
+    X32 = m1_rows(n, p, seed=77)
+    kw = dict(HEADLINE_KW, reduction=r)
+    snaps = {}
+    for dt in (np.float64, np.float32):
+        X = X32.astype(dt)
+        pr = oracle.SomfParams(**kw)
+        st = oracle.prepare(pr, n_samples=n, X=X)
+        st.sweeps = []
+        for t in range(marks[-1]):
+            oracle.partial_fit(st, pr, X[t * b:(t + 1) * b], np.arange(t * b, (t + 1) * b))
+            if t + 1 in marks:
+                snaps[(dt, t + 1)] = dict(D=st.D.copy(), C=st.C.copy(), B=st.B[:, :64].copy(), code=st.code[t * b:(t + 1) * b].copy(),
+                                          sweeps=st.sweeps[-1].copy(), n_iter=st.n_iter)
+        snaps[(dt, 'next_subset')] = st.sampler.yield_subset(r) if hasattr(st, 'sampler') else None
+    report = []
+    for dt in (np.float64, np.float32):
+        Xd = torch.from_numpy(X32.astype(dt)).cuda()
+        for m in marks:
+            est = DictFact(**kw)
+            est.prepare(n_samples=n, X=X32[:256].astype(dt))
+            assert est._chunk_call_applies(est._backend, np.arange(m * b))          # the one-call-per-chunk route
+            est.partial_fit(Xd[:m * b], np.arange(m * b))
+            ref64, ref32 = snaps[(np.float64, m)], snaps[(np.float32, m)]
+            got = dict(D=est.components_, C=est.C_, B=est.B_[:, :64], code=est.code_[(m - 1) * b:m * b])
+            agree = float(np.mean(est._backend.last_sweeps() == snaps[(dt, m)]['sweeps']))
+            assert est.n_iter_ == ref64['n_iter'] == m * b
+            for key in ('D', 'C', 'B', 'code'):
+                if dt == np.float64:
+                    e = rel_fro(got[key], ref64[key])
+                    assert e < 1e-8, (r, m, key, e)
+                else:
+                    e, noise = assert_within_f32_noise(got[key], ref32[key], ref64[key], (r, m, key))
+                report.append((np.dtype(dt).name, m, key, float(e)))
+            report.append((np.dtype(dt).name, m, 'sweeps_agree', agree))
+            assert agree >= (1.0 if dt == np.float64 else 0.97), (r, m, agree)
+            if m == marks[-1] and snaps[(dt, 'next_subset')] is not None:
+                assert_array_equal(est.feature_sampler_.yield_subset(r), snaps[(dt, 'next_subset')])
+    print('long horizon r=%d: %s' % (r, report))
+
+
+def test_chunk_call_error_is_consistent(DictFact):
+    """modl_somf_partial_fit_chunk, a minibatch that does not validate (a sample index outside code_) in the middle of
+    a call: the call reports it, and n_iter_, sample_n_iter_, the feature sampler and the numpy generator are left
+    exactly where the last ENQUEUED minibatch left them (the draws of the look-ahead rewound) - after the index is
+    corrected, fitting the remaining rows gives the bits of an uninterrupted run."""
+    from modl_amd._lib import ModlError
+    rs = np.random.RandomState(3)
+    p, k, b, nb = 1500, 32, 24, 9
+    n = nb * b
+    X = ((rs.randn(n, 12) * (rs.rand(n, 12) < 0.4)).dot(rs.randn(12, p)) + 0.1 * rs.randn(n, p)).astype(np.float32)
+    kw = dict(n_components=k, batch_size=b, reduction=5, code_alpha=0.3, learning_rate=0.92, random_state=0)
+    idx = rs.permutation(n)
+    clean = DictFact(**kw)
+    clean.prepare(n_samples=n, X=X)
+    clean.partial_fit(X, idx)
+    est = DictFact(**kw)
+    est.prepare(n_samples=n, X=X)
+    bad = idx.copy()
+    bad[4 * b + 5] = n + 3                                     # minibatch 4 is rejected before anything is enqueued for it
+    with pytest.raises(ModlError):
+        est.partial_fit(X, bad)
+    assert est.n_iter_ == 4 * b
+    want = np.zeros(n, dtype=int)
+    want[idx[:4 * b]] = 1
+    assert_array_equal(est.sample_n_iter_, want)
+    est.partial_fit(X[4 * b:], idx[4 * b:])                    # the corrected rest
+    for a, c in ((est.components_, clean.components_), (est.code_, clean.code_), (est.C_, clean.C_), (est.B_, clean.B_)):
+        assert_array_equal(a, c)
+    assert est.n_iter_ == clean.n_iter_
+    assert_array_equal(est.sample_n_iter_, clean.sample_n_iter_)
+    assert est.random_state.randint(1 << 30) == clean.random_state.randint(1 << 30)
+    assert_array_equal(est.feature_sampler_.yield_subset(3.0), clean.feature_sampler_.yield_subset(3.0))
+
+
+@pytest.mark.parametrize('dt', [np.float64, np.float32])
+def test_wide_l2_estimator_vs_oracle(DictFact, oracle, dt):
+    """512 < n_components <= 1024 with l1 codes and l2 atoms (the reference's HCP runs use 1024 maps,
+    exps/hcp/decompose_hcp.py:50-60): the blocked dictionary update as separate launches (gather-GEMM + Gram + resolve +
+    apply: the branch the fused block kernel does not cover) and the four-wavefront solver at k = 640, through the
+    estimator, two minibatches."""
+    from .conftest import assert_within_f32_noise
+    kw = dict(n=700, p=1500, k=640, b=32, r=3, code_alpha=0.5)
+    est, pr, st, X = _make_pair(DictFact, oracle, dt, **kw)
+    X64 = X.astype(np.float64)
+    st64 = oracle.prepare(pr, n_samples=X.shape[0], X=X64) if dt == np.float32 else None
+    for t in range(2):
+        rows = slice(t * 32, (t + 1) * 32)
+        est.partial_fit(X[rows], np.arange(rows.start, rows.stop))
+        oracle.partial_fit(st, pr, X[rows], np.arange(rows.start, rows.stop))
+        if st64 is not None:
+            oracle.partial_fit(st64, pr, X64[rows], np.arange(rows.start, rows.stop))
+    if dt == np.float64:
+        errs = (rel_fro(est.components_, st.D), rel_fro(est.code_[:64], st.code[:64]), rel_fro(est.C_, st.C), rel_fro(est.B_, st.B))
+        assert max(errs) < 1e-9, errs
+    else:
+        assert_within_f32_noise(est.components_, st.D, st64.D, 'dictionary')
+        assert_within_f32_noise(est.code_[:64], st.code[:64], st64.code[:64], 'codes')
+        assert_within_f32_noise(est.C_, st.C, st64.C, 'C')
+
+
 def test_pickle_roundtrip(DictFact):
     import pickle
     X, _ = generate_synthetic(n_features=20, n_samples=100, dictionary_rank=4)
@@ -883,12 +997,12 @@ def _rccl_rank_main(rank, port, kw, X, out):
     try:
         from modl_amd import DictFact as DF
         res = {}
-        for name in ('fused', 'rccl', 'native'):
+        for name in ('fused', 'rccl', 'native', 'native_chunk'):
             est = DF(**kw)
             if name != 'fused':
-                est._two_phase = True
+                est._two_phase = name != 'native_chunk'          # the Python loop over minibatches / ONE call per chunk
                 est._force_reduce = True                         # the head really goes through an RCCL all-reduce
-                est._native_rccl = name == 'native'              # ... issued by torch.distributed / by the library itself
+                est._native_rccl = name != 'rccl'                # ... issued by torch.distributed / by the library itself
             est.prepare(n_samples=X.shape[0], X=X)
             est.partial_fit(X)
             res[name] = dict(D=est.components_, C=est.C_, B=est.B_, code=est.code_)
@@ -919,6 +1033,9 @@ def test_rccl_single_rank_two_phase_equals_fused(red):
     for name in ('D', 'C', 'B', 'code'):
         assert_array_equal(out['fused'][name], out['rccl'][name], err_msg=name)
         assert_array_equal(out['fused'][name], out['native'][name], err_msg='native ' + name)   # modl_somf_step_dist
+        # modl_somf_partial_fit_chunk with the library's communicator: the staging copy of minibatch t + 1 rides on
+        # the last launch of step t's dictionary update, the all-reduce sits between the two phases on the same stream
+        assert_array_equal(out['fused'][name], out['native_chunk'][name], err_msg='native_chunk ' + name)
 
 
 @pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-12), (np.float32, 1e-5)])
@@ -949,3 +1066,28 @@ def test_objective_on_device_chunked(dtype, tol):
     assert np.array_equal(outs[1], outs[2])
     ws = torch.empty(64, dtype=torch.uint8, device=dev)
     assert f(ptr(dX), p + 3, n, p, ptr(dDt), k, ptr(dcode), ptr(ws), 64, ptr(out), stream_ptr(dev)) == -2      # MODL_ENOMEM
+
+
+def test_bench_forced_reduce_native_rccl():
+    """`bench.py --gpus 1 --force-reduce --native-rccl`: the multi-GPU step as the driver's N > 1 runs execute it - one
+    modl_somf_partial_fit_chunk call per chunk with the library's own RCCL communicator (world = 1: the all-reduce is the
+    identity, its launch and stream ordering are real), the staging copy riding on phase 2's last launch."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import socket
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    env['MASTER_PORT'] = str(sock.getsockname()[1])
+    sock.close()
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-reduce', '--native-rccl',
+           '--steps', '12', '--warmup', '4', '--steady-steps', '0', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec['n_gpus'] == 1 and rec['finite'] is True and rec['value'] > 0
+    assert rec['config']['collective'].startswith('native RCCL'), rec['config']['collective']

@@ -206,6 +206,13 @@ def _rank_main_pickle(rank, world, port, kw, X_parts, out):
                 res['pickle'] = pickle.dumps(est)
         est.partial_fit(X[:kw['batch_size']], np.arange(kw['batch_size']))     # the run goes on from the consolidated state
         res['D_next'], res['B_next'] = est.components_, est.B_
+        if rank == 0:
+            # ... and its statistics are per-rank partial sums again, whatever route the minibatches took (the Python
+            # loop here, one library call per chunk on the GPU): a pickle written now must say so
+            with warnings.catch_warnings(record=True) as wlist:
+                warnings.simplefilter('always')
+                res['pickle_after_fit'] = pickle.dumps(est)
+            res['warned_after_fit'] = any('partial' in str(w_.message) for w_ in wlist)
         out[rank] = res
     finally:
         dist.destroy_process_group()
@@ -234,6 +241,9 @@ def test_two_rank_pickle_consolidated_loads_on_one_rank(oracle):
     assert r0['warned']
     with pytest.raises(ValueError, match='rank 0 of 2'):
         pickle.loads(r0['partial_pickle'])
+    assert r0['warned_after_fit']                                        # consolidate -> partial_fit -> pickle: partial again
+    with pytest.raises(ValueError, match='rank 0 of 2'):
+        pickle.loads(r0['pickle_after_fit'])
     # the one-rank reference run: batch 2b on [rank0 batch t ; rank1 batch t], then the next rows
     Xc = np.concatenate([np.concatenate([X0[t * b:(t + 1) * b], X1[t * b:(t + 1) * b]]) for t in range(steps)])
     ref = _host_estimator()(**dict(kw, batch_size=2 * b))
@@ -267,7 +277,11 @@ def _rank_main_setters(rank, world, port, kw, X0, out):
         v = np.arange(kw['n_components'] * X0.shape[1], dtype=np.float64).reshape(kw['n_components'], -1)
         est.B_ = v
         est.C_ = np.eye(kw['n_components'])
-        out[rank] = dict(B=est.B_, C=est.C_, v=v)
+        res = dict(B=est.B_, C=est.C_, v=v)
+        est.local_B_ = (rank + 1) * v                                    # the local twin sets THIS rank's share as given
+        res['local_B'] = est.local_B_
+        res['B_from_local'] = est.B_                                     # (collective) = 1 v + 2 v
+        out[rank] = res
     finally:
         dist.destroy_process_group()
 
@@ -282,6 +296,8 @@ def test_two_rank_setters_set_the_sum():
     for r in (0, 1):
         assert_array_equal(out[r]['B'], out[r]['v'])
         assert_array_equal(out[r]['C'], np.eye(3))
+        assert_array_equal(out[r]['local_B'], (r + 1) * out[r]['v'])
+        assert_array_equal(out[r]['B_from_local'], 3 * out[r]['v'])
 
 
 def test_failed_minibatch_rewinds_the_subset_lookahead():
@@ -313,3 +329,52 @@ def test_failed_minibatch_rewinds_the_subset_lookahead():
         est.partial_fit(X, np.arange(96))                      # 12 minibatches, the 4th fails before it draws
     # three subsets were consumed: the next draw is the fourth of the stream, whatever the worker had drawn ahead
     assert_array_equal(est.feature_sampler_.yield_subset(2), seen[3])
+
+
+def test_chunk_call_error_books_the_enqueued_minibatches():
+    """The one-call-per-chunk route (modl_somf_partial_fit_chunk) reports how many minibatches it enqueued when one
+    fails and leaves n_iter / the generators behind the last of them (GPU side: test_chunk_call_error_is_consistent).
+    The Python side must book exactly those minibatches - n_iter_, sample_n_iter_ - before it raises, so that a
+    retry weighs the next minibatch as the reference would (dict_fact.py:510-515)."""
+    from modl_amd._lib import ModlError
+    rs = np.random.RandomState(8)
+    X = rs.randn(96, 20)
+    b = 8
+    est = HostDictFact(n_components=4, batch_size=b, reduction=2, random_state=0, code_alpha=0.1)
+    est.prepare(n_samples=200, X=X)
+    be = est._backend
+    calls = []
+
+    def fit_chunk(Xh, batch_size, idx, sampler, np_rs, n_iter, lr, red, b_global=None, comm=None):
+        calls.append((Xh.shape[0], n_iter))
+        if len(calls) == 2:                                   # the second chunk fails in its 4th minibatch
+            e = ModlError('modl_somf_partial_fit_chunk failed: bad argument (code -1)')
+            e.n_iter, e.n_done = n_iter + 3 * batch_size, 3
+            raise e
+        return n_iter + Xh.shape[0], -(-Xh.shape[0] // batch_size)
+    be.fit_chunk = fit_chunk
+    est._chunk_call_applies = lambda be_, idx_: True
+    est._native_comm = lambda be_: None
+    est._host_chunk_rows = 5 * b                              # chunks of 5 minibatches: 40 + 40 + 16 rows
+    idx = np.arange(100, 196)
+
+    class Chunks:                                             # (stands in for the pinned host stream of the GPU backend)
+        def __init__(self, be_, X_, rows):
+            self.X, self.rows = X_, rows
+
+        def __iter__(self):
+            for r0 in range(0, self.X.shape[0], self.rows):
+                yield r0, self.X[r0:r0 + self.rows]
+    import modl_amd.dict_fact as mod
+    orig, be.plan = mod._HostChunks, object()
+    mod._HostChunks = Chunks
+    try:
+        with pytest.raises(ModlError):
+            est.partial_fit(X, idx)
+    finally:
+        mod._HostChunks = orig
+    assert calls == [(40, 0), (40, 40)]
+    assert est.n_iter_ == 40 + 3 * b                          # the first chunk and three minibatches of the second
+    want = np.zeros(200, dtype=int)
+    want[100:100 + 40 + 3 * b] = 1
+    assert_array_equal(est.sample_n_iter_, want)
