@@ -62,20 +62,27 @@ int modl_abi_version(void);
 /* number of visible HIP devices (0 without a GPU); never fails */
 int modl_device_count(void);
 const char *modl_error_string(int code);
-/* process-wide diagnostics switches (the test-suite forces code paths with them; nothing reads the environment).
- * MODL_DEBUG_CD_SPARSE_PCT: value >= 0 = share of active coordinates (percent) below which a coordinate-descent
- * sweep runs as an active-set sweep (0: always dense, 100: always sparse), -1 = the default rule.
- * MODL_DEBUG_CD_SPLIT: 1 (default) = shared-Gram solves with 64 < k <= 512 run the two-wavefront solver
- * (cd_split.hip), 0 = the one-wavefront solver everywhere (the two are bit-identical; the tests compare them). */
+/* process-wide diagnostics switches (the test-suite forces code paths with them; nothing reads the environment; every
+ * switch of the product library selects between CORRECT code paths).
+ * MODL_DEBUG_CD_SPARSE_PCT: value >= 0 = share of active coordinates (percent) below which a sweep of the one-wavefront
+ * coordinate-descent kernel runs as an active-set sweep (0: always dense, 100: always sparse), -1 = the default rule.
+ * MODL_DEBUG_CD_SPLIT: 1 (default) = shared-Gram solves with 32 <= k <= 1024 run the four-wavefront solver
+ * (cd_split_impl.hpp), 0 = the one-wavefront solver (cd_solver.hip: the reference's operation order; the two agree to
+ * rounding, the tests compare them).  Its variants for k > 256 spill registers and are only built into the
+ * diagnostics library (libmodl_hip_diag.so, -DMODL_DIAG): the product library keeps the four-wavefront solver there.
+ * MODL_DEBUG_CD_STAMPS / MODL_DEBUG_ATOM_STAMPS (shader-clock stamps written to a caller-supplied device buffer) exist
+ * in the diagnostics library only: the product library answers MODL_EINVAL. */
 #define MODL_DEBUG_CD_SPARSE_PCT 1
 #define MODL_DEBUG_CD_SPLIT 2
-#define MODL_DEBUG_CD_SPLIT_DIAG 4   /* timing experiments on the two-wavefront solver (WRONG results; cd_split.hip) */
+#define MODL_DEBUG_CD_STAMPS 3        /* (diagnostics library) value = device pointer to 1024 uint64 (0: off): shader-clock stamps of sample 0 of the four-wavefront solver */
 #define MODL_DEBUG_BCD_ACC 5          /* 1 (default): the blocked dictionary update sums its Gram contributions with integer atomics into one fixed-point record; 0: one record per workgroup, summed by every workgroup of the next launch */
-#define MODL_DEBUG_ATOM_STAMPS 6      /* value = device pointer to 64 uint64, zeroed by the caller (0: off): cycle sums of the projecting workgroup of the grouped atom update (bcd.hip: atom_project_group_kernel) */
+#define MODL_DEBUG_ATOM_STAMPS 6      /* (diagnostics library) value = device pointer to 64 uint64, zeroed by the caller (0: off): cycle sums of the projecting workgroup of the grouped atom update (bcd.hip: atom_project_group_kernel) */
 #define MODL_DEBUG_BCD_TINY 7         /* 1 (default): the f64 blocked dictionary update of at most 192 sampled features runs as ONE one-workgroup launch; 0: five launches per block of 32 atoms */
 #define MODL_DEBUG_STAGE_AHEAD 8      /* 1 (default): inside modl_somf_partial_fit_chunk the next minibatch's parameters are copied to HBM by a workgroup of the dictionary update's last launch; 0: a staging launch at the head of every step */
-#define MODL_DEBUG_CD_STAMPS 3   /* value = device pointer to 1024 uint64 (0: off): shader-clock stamps of sample 0 of the two-wavefront solver */
 int modl_debug_set(int what, int64_t value);
+/* 1 in libmodl_hip_diag.so (built with -DMODL_DIAG: the same sources plus the A/B-only kernel variants and the stamp
+ * switches), 0 in the product library */
+int modl_is_diag_build(void);
 
 /* ------------------------------------------------------------------------- *
  * Host-side RNG — replaces modl/utils/randomkit/random_fast.pyx (RandomState,

@@ -63,100 +63,116 @@ def _load():
         raise ImportError('modl_amd: cannot load %s: %s' % (LIB_PATH, e))
 
 
-lib = _load()
-
 _vp, _i32, _i64, _u64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double, C.c_size_t
 _P = C.POINTER
 
 
-def _sig(name, restype, *argtypes):
-    f = getattr(lib, name)
-    f.restype = restype
-    f.argtypes = list(argtypes)
-    return f
+def bind(lib):
+    """declares the argument / result types of every entry point on a loaded library (the product library, or the
+    diagnostics build of the same sources, load_diag())"""
+    def _sig(name, restype, *argtypes):
+        f = getattr(lib, name)
+        f.restype = restype
+        f.argtypes = list(argtypes)
+        return f
+
+    _sig('modl_abi_version', C.c_int)
+    _sig('modl_device_count', C.c_int)
+    _sig('modl_error_string', C.c_char_p, C.c_int)
+    _sig('modl_debug_set', C.c_int, C.c_int, _i64)
+    _sig('modl_is_diag_build', C.c_int)
+    _sig('modl_rk_create', C.c_int, _u64, _P(_vp))
+    _sig('modl_rk_destroy', None, _vp)
+    _sig('modl_rk_seed', C.c_int, _vp, _u64)
+    _sig('modl_rk_random', C.c_int, _vp, _P(C.c_uint32))
+    _sig('modl_rk_randint', C.c_int, _vp, _u64, _P(_i64))
+    _sig('modl_rk_double', C.c_int, _vp, _P(_f64))
+    _sig('modl_rk_binomial', C.c_int, _vp, _i64, _f64, _P(_i64))
+    _sig('modl_rk_permutation', C.c_int, _vp, _i64, _vp)
+    _sig('modl_rk_get_mt_state', C.c_int, _vp, _vp, _P(C.c_int32))
+    _sig('modl_rk_set_mt_state', C.c_int, _vp, _vp, C.c_int32)
+    _sig('modl_rk_shuffle_i64', C.c_int, _vp, _vp, _i64)
+    _sig('modl_rk_shuffle_trace', C.c_int, _vp, _i64, _vp, _vp)
+    _sig('modl_apply_swaps_rows', C.c_int, _vp, _i64, _sz, _vp)
+    _sig('modl_apply_swaps_rows_device', C.c_int, _vp, _i64, _sz, _vp, _vp)
+    _sig('modl_sampler_create', C.c_int, _i64, C.c_int, C.c_int, _u64, _P(_vp))
+    _sig('modl_sampler_destroy', None, _vp)
+    _sig('modl_sampler_yield_subset', C.c_int, _vp, _f64, _vp, _P(_i64))
+    _sig('modl_sampler_get', C.c_int, _vp, _P(_i64), _P(_i64), _P(_i64), _vp)
+    _sig('modl_sampler_state_bytes', _sz, _vp)
+    _sig('modl_sampler_get_state', C.c_int, _vp, _vp, _sz)
+    _sig('modl_sampler_set_state', C.c_int, _vp, _vp, _sz)
+    _sig('modl_batch_weight', C.c_int, _i64, _i64, _f64, _f64, _P(_f64))
+    _sig('modl_enet_regression_workspace', _sz, C.c_int, _i64, _i64, C.c_int)
+    for _sfx, _ct in (('f32', C.c_float), ('f64', C.c_double)):
+        for _kind in ('single', 'multi'):
+            _sig('modl_enet_regression_%s_gram_%s' % (_kind, _sfx), C.c_int, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64,
+                 _i64, _ct, _ct, C.c_int, _ct, C.c_int, _vp, _vp, _sz, _vp)
+        _sig('modl_update_G_average_' + _sfx, C.c_int, _vp, _vp, _vp, _i64, _i64, _vp)
+        _sig('modl_enet_norm_' + _sfx, C.c_int, _vp, _i64, _i64, _i64, _i64, _ct, _vp, _vp)
+        _sig('modl_enet_projection_' + _sfx, C.c_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _ct, _vp)
+        _sig('modl_enet_scale_' + _sfx, C.c_int, _vp, _i64, _i64, _i64, _i64, _ct, _ct, _vp)
+        _sig('modl_transpose_' + _sfx, C.c_int, _vp, _vp, _i64, _i64, _vp)
+        _sig('modl_gather_rows_' + _sfx, C.c_int, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp)
+    for _sfx, _ct in (('f32', C.c_float), ('f64', C.c_double)):
+        _sig('modl_recsys_codes_' + _sfx, C.c_int, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp)
+        _sig('modl_recsys_update_B_' + _sfx, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _i64, _vp)
+        _sig('modl_recsys_minibatch_' + _sfx, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _f64, _f64, _f64,
+             _vp, _vp, _vp, _vp, _vp, _vp, _vp)
+        _sig('modl_recsys_predict_' + _sfx, C.c_int, _vp, _vp, _vp, _vp, _i64, C.c_int, _vp, _vp)
+        _sig('modl_gram_axpby_' + _sfx, C.c_int, _vp, _i64, C.c_int, _vp, _ct, _ct, _vp)
+        _sig('modl_dict_update_' + _sfx, C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, C.c_int, C.c_int, C.c_int, _f64,
+             _f64, _f64, _vp, _sz, _vp)
+        _sig('modl_image_clean_mask_' + _sfx, C.c_int, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _P(_i64))
+        _sig('modl_image_patches_' + _sfx, C.c_int, _vp, _i64, _i64, _i64, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int,
+             C.c_int, _vp, _i64, _vp)
+        _sig('modl_objective_' + _sfx, C.c_int, _vp, _i64, _i64, _i64, _vp, C.c_int, _vp, _vp, _sz, _vp, _vp)
+    _sig('modl_image_fill', C.c_int, _i64, _i64, _i64, _vp)
+    _sig('modl_objective_workspace', _sz, C.c_int, _i64, _i64)
+    _sig('modl_dict_update_workspace', _sz, C.c_int, _i64, C.c_int)
+    _sig('modl_recsys_plan_create', C.c_int, C.c_int, _i64, C.c_int, _i64, _i64, _P(_vp))
+    _sig('modl_recsys_plan_destroy', None, _vp)
+    _sig('modl_predict_csr', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp)
+    _sig('modl_somf_plan_create', C.c_int, _P(SomfDesc), _P(_vp))
+    _sig('modl_somf_plan_destroy', None, _vp)
+    _sig('modl_somf_plan_update', C.c_int, _vp, _P(SomfDesc))
+    _sig('modl_somf_delta_elems', _i64, _P(SomfDesc))
+    _sig('modl_somf_code_and_partials', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
+    _sig('modl_somf_apply_and_update_dict', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
+    _sig('modl_somf_step', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp)
+    _sig('modl_somf_partial_fit_chunk', C.c_int, _vp, _P(SomfState), _vp, _i64, _i64, C.c_int32, _vp, _vp, _vp, _P(_i64), _f64,
+         _f64, _vp, _vp, _P(_i64), _vp)
+    _sig('modl_somf_head_elems', C.c_int, _vp, _P(_i64))
+    _sig('modl_comm_unique_id', C.c_int, _vp)
+    _sig('modl_comm_create', C.c_int, _vp, C.c_int, C.c_int, _P(_vp))
+    _sig('modl_comm_destroy', None, _vp)
+    _sig('modl_comm_all_reduce_sum', C.c_int, _vp, _vp, _i64, C.c_int, _vp)
+    _sig('modl_somf_step_dist', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
+    _sig('modl_somf_full_gram', C.c_int, _vp, _vp, _vp, _vp)
+    _sig('modl_somf_transform', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp)
+    _sig('modl_somf_debug_stamps', C.c_int, _vp, _vp)
+    _sig('modl_somf_debug_gemm_stamps', C.c_int, _vp, _vp)
+    _sig('modl_somf_last_sweeps', C.c_int, _vp, _vp, C.c_int, _P(C.c_int), _vp)
+    _sig('modl_somf_prof_enable', C.c_int, _vp, C.c_int)
+    _sig('modl_somf_prof_stride', C.c_int, _vp, C.c_int)
+    _sig('modl_somf_host_wait_ms', C.c_int, _vp, _P(_f64), C.c_int)
+    _sig('modl_somf_prof_get', C.c_int, _vp, _P(ProfEntry), C.c_int, _P(C.c_int))
+    _sig('modl_somf_prof_reset', C.c_int, _vp)
+
+    return lib
 
 
-_sig('modl_abi_version', C.c_int)
-_sig('modl_device_count', C.c_int)
-_sig('modl_error_string', C.c_char_p, C.c_int)
-_sig('modl_debug_set', C.c_int, C.c_int, _i64)
-_sig('modl_rk_create', C.c_int, _u64, _P(_vp))
-_sig('modl_rk_destroy', None, _vp)
-_sig('modl_rk_seed', C.c_int, _vp, _u64)
-_sig('modl_rk_random', C.c_int, _vp, _P(C.c_uint32))
-_sig('modl_rk_randint', C.c_int, _vp, _u64, _P(_i64))
-_sig('modl_rk_double', C.c_int, _vp, _P(_f64))
-_sig('modl_rk_binomial', C.c_int, _vp, _i64, _f64, _P(_i64))
-_sig('modl_rk_permutation', C.c_int, _vp, _i64, _vp)
-_sig('modl_rk_get_mt_state', C.c_int, _vp, _vp, _P(C.c_int32))
-_sig('modl_rk_set_mt_state', C.c_int, _vp, _vp, C.c_int32)
-_sig('modl_rk_shuffle_i64', C.c_int, _vp, _vp, _i64)
-_sig('modl_rk_shuffle_trace', C.c_int, _vp, _i64, _vp, _vp)
-_sig('modl_apply_swaps_rows', C.c_int, _vp, _i64, _sz, _vp)
-_sig('modl_apply_swaps_rows_device', C.c_int, _vp, _i64, _sz, _vp, _vp)
-_sig('modl_sampler_create', C.c_int, _i64, C.c_int, C.c_int, _u64, _P(_vp))
-_sig('modl_sampler_destroy', None, _vp)
-_sig('modl_sampler_yield_subset', C.c_int, _vp, _f64, _vp, _P(_i64))
-_sig('modl_sampler_get', C.c_int, _vp, _P(_i64), _P(_i64), _P(_i64), _vp)
-_sig('modl_sampler_state_bytes', _sz, _vp)
-_sig('modl_sampler_get_state', C.c_int, _vp, _vp, _sz)
-_sig('modl_sampler_set_state', C.c_int, _vp, _vp, _sz)
-_sig('modl_batch_weight', C.c_int, _i64, _i64, _f64, _f64, _P(_f64))
-_sig('modl_enet_regression_workspace', _sz, C.c_int, _i64, _i64, C.c_int)
-for _sfx, _ct in (('f32', C.c_float), ('f64', C.c_double)):
-    for _kind in ('single', 'multi'):
-        _sig('modl_enet_regression_%s_gram_%s' % (_kind, _sfx), C.c_int, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64,
-             _i64, _ct, _ct, C.c_int, _ct, C.c_int, _vp, _vp, _sz, _vp)
-    _sig('modl_update_G_average_' + _sfx, C.c_int, _vp, _vp, _vp, _i64, _i64, _vp)
-    _sig('modl_enet_norm_' + _sfx, C.c_int, _vp, _i64, _i64, _i64, _i64, _ct, _vp, _vp)
-    _sig('modl_enet_projection_' + _sfx, C.c_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _ct, _vp)
-    _sig('modl_enet_scale_' + _sfx, C.c_int, _vp, _i64, _i64, _i64, _i64, _ct, _ct, _vp)
-    _sig('modl_transpose_' + _sfx, C.c_int, _vp, _vp, _i64, _i64, _vp)
-    _sig('modl_gather_rows_' + _sfx, C.c_int, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp)
-for _sfx, _ct in (('f32', C.c_float), ('f64', C.c_double)):
-    _sig('modl_recsys_codes_' + _sfx, C.c_int, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp)
-    _sig('modl_recsys_update_B_' + _sfx, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _i64, _vp)
-    _sig('modl_recsys_minibatch_' + _sfx, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _f64, _f64, _f64,
-         _vp, _vp, _vp, _vp, _vp, _vp, _vp)
-    _sig('modl_recsys_predict_' + _sfx, C.c_int, _vp, _vp, _vp, _vp, _i64, C.c_int, _vp, _vp)
-    _sig('modl_gram_axpby_' + _sfx, C.c_int, _vp, _i64, C.c_int, _vp, _ct, _ct, _vp)
-    _sig('modl_dict_update_' + _sfx, C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, C.c_int, C.c_int, C.c_int, _f64,
-         _f64, _f64, _vp, _sz, _vp)
-    _sig('modl_image_clean_mask_' + _sfx, C.c_int, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _P(_i64))
-    _sig('modl_image_patches_' + _sfx, C.c_int, _vp, _i64, _i64, _i64, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int,
-         C.c_int, _vp, _i64, _vp)
-    _sig('modl_objective_' + _sfx, C.c_int, _vp, _i64, _i64, _i64, _vp, C.c_int, _vp, _vp, _sz, _vp, _vp)
-_sig('modl_image_fill', C.c_int, _i64, _i64, _i64, _vp)
-_sig('modl_objective_workspace', _sz, C.c_int, _i64, _i64)
-_sig('modl_dict_update_workspace', _sz, C.c_int, _i64, C.c_int)
-_sig('modl_recsys_plan_create', C.c_int, C.c_int, _i64, C.c_int, _i64, _i64, _P(_vp))
-_sig('modl_recsys_plan_destroy', None, _vp)
-_sig('modl_predict_csr', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp)
-_sig('modl_somf_plan_create', C.c_int, _P(SomfDesc), _P(_vp))
-_sig('modl_somf_plan_destroy', None, _vp)
-_sig('modl_somf_plan_update', C.c_int, _vp, _P(SomfDesc))
-_sig('modl_somf_delta_elems', _i64, _P(SomfDesc))
-_sig('modl_somf_code_and_partials', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
-_sig('modl_somf_apply_and_update_dict', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
-_sig('modl_somf_step', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp)
-_sig('modl_somf_partial_fit_chunk', C.c_int, _vp, _P(SomfState), _vp, _i64, _i64, C.c_int32, _vp, _vp, _vp, _P(_i64), _f64,
-     _f64, _vp, _vp, _P(_i64), _vp)
-_sig('modl_somf_head_elems', C.c_int, _vp, _P(_i64))
-_sig('modl_comm_unique_id', C.c_int, _vp)
-_sig('modl_comm_create', C.c_int, _vp, C.c_int, C.c_int, _P(_vp))
-_sig('modl_comm_destroy', None, _vp)
-_sig('modl_comm_all_reduce_sum', C.c_int, _vp, _vp, _i64, C.c_int, _vp)
-_sig('modl_somf_step_dist', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
-_sig('modl_somf_full_gram', C.c_int, _vp, _vp, _vp, _vp)
-_sig('modl_somf_transform', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp)
-_sig('modl_somf_debug_stamps', C.c_int, _vp, _vp)
-_sig('modl_somf_debug_gemm_stamps', C.c_int, _vp, _vp)
-_sig('modl_somf_last_sweeps', C.c_int, _vp, _vp, C.c_int, _P(C.c_int), _vp)
-_sig('modl_somf_prof_enable', C.c_int, _vp, C.c_int)
-_sig('modl_somf_prof_stride', C.c_int, _vp, C.c_int)
-_sig('modl_somf_host_wait_ms', C.c_int, _vp, _P(_f64), C.c_int)
-_sig('modl_somf_prof_get', C.c_int, _vp, _P(ProfEntry), C.c_int, _P(C.c_int))
-_sig('modl_somf_prof_reset', C.c_int, _vp)
+lib = bind(_load())
+
+
+def load_diag():
+    """libmodl_hip_diag.so: the product's sources built with -DMODL_DIAG - adds the kernel variants that only exist to be
+    compared with (the one-wavefront coordinate-descent kernel for k > 256, which spills) and the shader-clock stamp
+    switches.  Tests and scripts/ load it next to the product library; nothing in modl_amd uses it."""
+    path = os.path.join(_HERE, 'libmodl_hip_diag.so')
+    if not os.path.exists(path):
+        raise ImportError('modl_amd: %s is missing (make -C modl_amd/csrc)' % path)
+    return bind(C.CDLL(path))
 
 # every symbol declared in include/modl_hip.h (checked by tests/test_abi.py)
 DECLARED = [n for n in dir(lib) if n.startswith('modl_')]

@@ -515,7 +515,6 @@ std::atomic<int> g_cd_sparse_pct{-1};
 std::atomic<int> g_cd_split{1};
 extern std::atomic<unsigned long long *> g_cd_stamps;   // cd_split.hip
 extern std::atomic<unsigned long long *> g_atom_stamps; // bcd.hip
-extern std::atomic<int> g_cd_split_diag;
 extern std::atomic<int> g_bcd_acc;                      // bcd.hip
 extern std::atomic<int> g_bcd_tiny;                     // bcd.hip
 extern std::atomic<int> g_stage_ahead;                  // somf_step.hip
@@ -527,16 +526,28 @@ int launch_cd(hipStream_t stream, const CdArgs<T> &a0) {
     CdArgs<T> a = a0;
     const int sparse_pct = g_cd_sparse_pct.load(std::memory_order_relaxed);   // diagnostics: modl_debug_set
     if (sparse_pct >= 0) a.sparse_pct = sparse_pct;
-    // a shared Gram matrix with k > 64: a workgroup per sample, the chain on one wavefront and the k-wide update on
-    // another (cd_split.hip); bit-identical to cd_kernel, which keeps the per-sample Gram matrices, k <= 64 and
-    // k > 512 (diagnostics: modl_debug_set(MODL_DEBUG_CD_SPLIT, 0) forces cd_kernel)
-    if (g_cd_split.load(std::memory_order_relaxed) && cd_split_applies<T>(a)) return launch_cd_split<T>(stream, a);
+    // a shared Gram matrix with k >= 32: a workgroup per sample, the chain on one wavefront and the k-wide update on
+    // two others (cd_split_impl.hpp); cd_kernel keeps k < 32 and is the reference-order implementation the tests compare
+    // the four-wavefront solver with (diagnostics: modl_debug_set(MODL_DEBUG_CD_SPLIT, 0) forces it - for k > 256 only in
+    // the diagnostics library: its 8 / 16-coefficients-per-lane variants spill hundreds of registers and are not built
+    // into the product)
+#ifdef MODL_DIAG
+    const bool want_split = g_cd_split.load(std::memory_order_relaxed) != 0;
+#else
+    const bool want_split = g_cd_split.load(std::memory_order_relaxed) != 0 || a.k > 256;
+#endif
+    if (want_split && cd_split_applies<T>(a)) return launch_cd_split<T>(stream, a);
     dim3 grid((unsigned)cdiv(a.b, 4)), block(256);
     if (a.k <= 64) launch_cd_kpl<T, 1>(stream, a, grid, block);
     else if (a.k <= 128) launch_cd_kpl<T, 2>(stream, a, grid, block);
     else if (a.k <= 256) launch_cd_kpl<T, 4>(stream, a, grid, block);
+#ifdef MODL_DIAG
     else if (a.k <= 512) launch_cd_kpl<T, 8>(stream, a, grid, block);
     else launch_cd_kpl<T, 16>(stream, a, grid, block);
+#else
+    else return MODL_EINVAL;     // (k > 256 needs a Gram matrix the four-wavefront solver takes: 16-byte aligned, row
+                                 //  stride 512 / 1024 - every caller in this library pads and aligns it)
+#endif
     MODL_LAUNCH_CHECK();
     return MODL_OK;
 }
@@ -665,11 +676,20 @@ template int launch_row_norm2<double>(hipStream_t, const double *, int64_t, int6
 
 }  // namespace modl
 
+extern "C" int modl_is_diag_build(void) {
+#ifdef MODL_DIAG
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int modl_debug_set(int what, int64_t value) {
     if (what == MODL_DEBUG_CD_SPARSE_PCT) {
         modl::g_cd_sparse_pct.store((int)value, std::memory_order_relaxed);
         return MODL_OK;
     }
+#ifdef MODL_DIAG     // shader-clock stamps into a caller-supplied buffer: the diagnostics library only
     if (what == MODL_DEBUG_CD_STAMPS) {
         modl::g_cd_stamps.store(reinterpret_cast<unsigned long long *>((uintptr_t)value));
         return MODL_OK;
@@ -678,6 +698,7 @@ extern "C" int modl_debug_set(int what, int64_t value) {
         modl::g_atom_stamps.store(reinterpret_cast<unsigned long long *>((uintptr_t)value));
         return MODL_OK;
     }
+#endif
     if (what == MODL_DEBUG_STAGE_AHEAD) {
         modl::g_stage_ahead.store((int)value, std::memory_order_relaxed);
         return MODL_OK;
@@ -688,10 +709,6 @@ extern "C" int modl_debug_set(int what, int64_t value) {
     }
     if (what == MODL_DEBUG_BCD_ACC) {
         modl::g_bcd_acc.store((int)value, std::memory_order_relaxed);
-        return MODL_OK;
-    }
-    if (what == MODL_DEBUG_CD_SPLIT_DIAG) {
-        modl::g_cd_split_diag.store((int)value);
         return MODL_OK;
     }
     if (what == MODL_DEBUG_CD_SPLIT) {

@@ -6,10 +6,7 @@ namespace modl {
 
 // diagnostics (modl_debug_set(MODL_DEBUG_CD_STAMPS, device pointer to 1024 uint64)): shader-clock stamps of sample 0
 std::atomic<unsigned long long *> g_cd_stamps{nullptr};
-// diagnostics (MODL_DEBUG_CD_SPLIT_DIAG; WRONG RESULTS, timing experiments only): 1 = the chain wave never waits for the
-// update wave, 4 = the chain wave publishes nothing, 16 = the update wave skips its arithmetic, 32 = the update wave
-// leaves at once
-std::atomic<int> g_cd_split_diag{0};
+
 
 template void launch_split_nb<float, 2>(hipStream_t, const CdArgs<float> &);
 template void launch_split_nb<float, 4>(hipStream_t, const CdArgs<float> &);

@@ -1,4 +1,4 @@
-// Batched elastic-net code solver, shared Gram matrix, 64 < k <= 512: the cyclic coordinate descent of
+// Batched elastic-net code solver, shared Gram matrix, 32 <= k <= 1024: the cyclic coordinate descent of
 //   enet_coordinate_descent_gram (reference: modl/decomposition/dict_fact_fast.pyx:270-427)
 // with the Gauss-Seidel chain taken OFF the k-wide update and every load taken off both.
 //
@@ -8,28 +8,34 @@
 // have issued - although it only needs ONE element of the k-wide update.  Here a sample is a WORKGROUP of four
 // wavefronts, one per SIMD of a compute unit:
 //   * the CHAIN wave owns the coordinates in blocks of 64 (lane l of block b <-> coordinate 64 b + l).  Inside a
-//     block it keeps only the block's 64 entries of H (one register) up to date - what it needs of the Gram matrix is
-//     the block's 64 x 64 diagonal tile, which it reads from LDS - and publishes (w_new, w_old) of the coordinates it
-//     has finished through LDS;
-//   * the UPDATE wave applies the published steps to all k entries of H, in coordinate order, with the SAME two
-//     fused multiply-adds per element as cd_kernel (H <- fma(w_new, Q_i, fma(-w_old, Q_i, H))), a few coordinates
-//     behind the chain, reading the Gram rows from an LDS ring, and hands the next block its 64 entries of H when the
-//     chain reaches a block boundary;
-//   * the ROW loader streams the Gram matrix - read in sweep order it is ONE cyclic, contiguous stream of memory -
-//     into that ring with direct-to-LDS loads (global_load_lds_dwordx4: a wave instruction moves 1 KiB, no VGPRs);
-//   * the TILE loader fetches the diagonal tile of the chain's next block the same way (two buffers).
-// Every entry of H sees the same operations in the same order as in cd_kernel: the iterates, the sweep counts and the
-// solutions are BIT-IDENTICAL to it (hence the reference's sweep order, skip rules and both stopping tests).  The gap
-// test reads w, q and H in cd_kernel's element order (lane l <-> elements KPL l ..) so that its five reductions round
-// identically too.
+//     block it keeps ONE register: Z[m] = q[m] - (H[m] - Q[m][m] w_old[m]) - sum over the block's coordinates j < m
+//     already visited of Q[j][m] (w_new[j] - w_old[j]), i.e. the `tmp` of dict_fact_fast.pyx:367 of every coordinate
+//     of the block AS IT WILL BE at that coordinate's turn once the steps before it have been applied.  What it needs
+//     of the Gram matrix is the STRICTLY UPPER triangle of the block's 64 x 64 diagonal tile (LDS): a step only moves
+//     the Z of the coordinates AFTER it, so the Z of a visited coordinate is frozen at the value its step used, and
+//     re-evaluating the step formula on all 64 lanes (which every step does) reproduces the visited coordinates'
+//     results bit for bit - no per-coordinate write-back (v_writelane) of the result, no separate w_old pass.  Per
+//     coordinate: v_med3, v_sub, v_fma (delta = w_new - w_old), v_readlane, v_fma (Z), ds_read: SIX instructions
+//     (round 3: ten).  Every 8 coordinates it publishes the block's deltas and a monotonic counter to LDS;
+//   * two UPDATE waves (a column half each) apply the published steps to all k entries of H = Q w, in coordinate
+//     order, as ONE fused multiply-add per element (H <- H + delta_j Q_j; round 3: two, H - w_old Q_j + w_new Q_j, the
+//     reference's operation order), a chunk of 8 behind the chain, from a register ring of Gram rows requested a ring
+//     ahead, and hand the next block its 64 entries of H through LDS when the chain reaches a block boundary;
+//   * the TILE loader brings the diagonal tile of the chain's next block (plain 16-byte loads), clears its lower
+//     triangle and diagonal in registers and stores it to one of two LDS buffers.
+// Same sweep order, skip rule, step formula and both stopping tests as the reference; what differs from its
+// operation order is the ROUNDING of the k-wide update (one fma with the rounded difference instead of two), so the
+// iterates agree with cd_kernel / the oracle to rounding noise, not bit for bit (tests/test_gpu_kernels.py:
+// test_cd_two_solvers_agree: f64 <= 1e-12 with identical sweep counts, f32 within the f32 noise rule).  The gap test
+// reads w, q and H in cd_kernel's element order (lane l <-> elements KPL l ..).
 //
 // Why four waves (measured with in-kernel stamps, scripts/diag_cd_split_stamps.py, k = 256, f32): a wave at one per
-// SIMD issues an instruction every ~4.5 cycles and a memory instruction costs it 18 (global_load) to 60+ cycles
-// (direct-to-LDS load); the chain wave alone with its own row loads ran at 86 cycles per coordinate (58 arithmetic,
-// 18 loads, 10 publishing), an update wave that also requested its rows at 110.  Counters in LDS are monotonic; data
-// is stored before its counter and the LDS executes a wavefront's operations in order; spins are bounded by the
-// workgroup's own progress (all four waves are resident together).  One sample per workgroup: a minibatch of 256
-// fills the chip's 256 compute units.
+// SIMD issues an instruction every ~4.5-6 cycles whether or not it depends on the one before (a dependent fma chain
+// runs at 4.2-5.8 cycles per link, scripts/micro/launch_gap.hip), so what a coordinate costs the chain wave is its
+// INSTRUCTION COUNT; a memory instruction costs the issuing wave 18 (global_load) to 60+ cycles (direct-to-LDS load).
+// Counters in LDS are monotonic; data is stored before its counter and the LDS executes a wavefront's operations in
+// order; spins are bounded by the workgroup's own progress (all four waves are resident together).  One sample per
+// workgroup: a minibatch of 256 fills the chip's 256 compute units.
 #pragma once
 #include "kernels.hpp"
 #include "cd_common.hpp"
@@ -44,48 +50,6 @@ typedef __attribute__((address_space(3))) volatile unsigned long long lds_vu64;
 
 constexpr int kStop = 0x7fffffff;
 extern std::atomic<unsigned long long *> g_cd_stamps;   // diagnostics, cd_split.hip
-extern std::atomic<int> g_cd_split_diag;
-
-template <typename T> struct SplitPair;
-template <> struct SplitPair<float> {
-    static constexpr int words = 1;   // 64-bit LDS words per (w_new, w_old) pair
-    __device__ static __forceinline__ void store(lds_vu64 *p, float wn, float wo) {
-        p[0] = ((unsigned long long)(unsigned int)__float_as_int(wo) << 32) | (unsigned int)__float_as_int(wn);
-    }
-    __device__ static __forceinline__ void load(lds_vu64 *p, float &wn, float &wo) {
-        const unsigned long long v = p[0];
-        wn = __int_as_float((int)(unsigned int)v);
-        wo = __int_as_float((int)(unsigned int)(v >> 32));
-    }
-};
-template <> struct SplitPair<double> {
-    static constexpr int words = 2;
-    __device__ static __forceinline__ void store(lds_vu64 *p, double wn, double wo) {
-        p[0] = (unsigned long long)__double_as_longlong(wn);
-        p[1] = (unsigned long long)__double_as_longlong(wo);
-    }
-    __device__ static __forceinline__ void load(lds_vu64 *p, double &wn, double &wo) {
-        const unsigned long long a = p[0], b = p[1];
-        wn = __longlong_as_double((long long)a);
-        wo = __longlong_as_double((long long)b);
-    }
-};
-
-// old with lane `lane` replaced by the wave-uniform value v (v_writelane_b32: no mask, no select)
-// (the lane is an immediate: one scalar register per VALU instruction on this part)
-template <int LANE> __device__ __forceinline__ int write_lane_b32(int old, int v_uniform) {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(v_uniform), "n"(LANE));
-    return old;
-}
-template <int LANE> __device__ __forceinline__ float write_lane(float old, float v_uniform) {
-    return __int_as_float(write_lane_b32<LANE>(__float_as_int(old), __float_as_int(v_uniform)));
-}
-template <int LANE> __device__ __forceinline__ double write_lane(double old, double v_uniform) {
-    const long long vb = __double_as_longlong(v_uniform), ob = __double_as_longlong(old);
-    const int lo = write_lane_b32<LANE>((int)(ob & 0xffffffffll), (int)(vb & 0xffffffffll));
-    const int hi = write_lane_b32<LANE>((int)(ob >> 32), (int)(vb >> 32));
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
 
 // Spin until the LDS counter at `p` is >= need; returns the value read (or `cached` if that already suffices).  The
 // loop is ONE assembly block: the compiler sees straight-line code around it, so its s_waitcnt bookkeeping for the
@@ -110,22 +74,19 @@ __device__ __forceinline__ int spin_until(int cached, const int *p_lds, int need
 
 // NB = row stride of the Gram matrix / 64 (the matrix is padded with dead coordinates up to it, cd_padded_ld)
 // FULL: k == 64 NB (every block has its 64 coordinates): the sweep is unrolled without a branch, see the update waves
-template <typename T, int NB, bool POSITIVE, bool FULL, int diag = 0>
+template <typename T, int NB, bool POSITIVE, bool FULL>
 __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned long long *stamps) {
     constexpr int K = 64 * NB;                        // row stride of the Gram matrix
     constexpr int KPL = NB;                           // cd_kernel's layout: element e <-> register e % KPL of lane e / KPL
-    constexpr int PW = SplitPair<T>::words;
-    constexpr unsigned int RBYTES = (unsigned int)(K * sizeof(T));   // bytes of a row: 512 ... 4096
     constexpr unsigned int TRB = 64 * sizeof(T);      // bytes of a row of a diagonal tile
     constexpr unsigned int TB = 64 * TRB;             // bytes of a tile: 16 / 32 KiB
-    constexpr int TP = (int)(TB / 1024);              // its pieces
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[2 * TB];
-    __shared__ unsigned long long s_pair[64 * PW];    // (w_new, w_old) of the chain wave's current block, by lane
+    __shared__ T s_delta[64];                         // w_new - w_old of the chain wave's current block, by lane
     __shared__ __attribute__((aligned(16))) T s_H[K]; // H after a whole block (cd_kernel's element order = plain order)
     __shared__ T s_w[K];                              // the chain wave's coefficients, for the gap test
     __shared__ int s_cnt[8];
     typedef __attribute__((address_space(3))) volatile T lds_vT;
-    lds_vu64 *pairs = (lds_vu64 *)s_pair;
+    lds_vT *deltas = (lds_vT *)s_delta;
     lds_vi32 *prog = (lds_vi32 *)&s_cnt[0];           // chain: 64 * (blocks finished) + coordinates published of the current one
     lds_vi32 *ver = (lds_vi32 *)&s_cnt[1];            // update waves 0 / 1 (s_cnt[1], [2]): 1 + blocks applied completely
                                                       // (their halves of the next block's H are in s_H)
@@ -154,11 +115,14 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
     if (wid == 3) {
         // ------------------------------------------------------------------ tile loader
         // tile t = rows and columns 64 b .. 64 b + 63 of the matrix (b = t mod nblk) -> buffer t % 2, row-major, as
-        // soon as the chain has finished block t - 2
-        const unsigned int lds_tile = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_tile;
-        constexpr int RPP = (int)(1024 / TRB);                   // tile rows per piece: 4 (f32), 2 (f64)
-        constexpr int LPR = 64 / RPP;                            // lanes per tile row
-        const unsigned int lane_off = (unsigned int)(lane / LPR) * RBYTES + (unsigned int)(lane % LPR) * 16u;
+        // soon as the chain has finished block t - 2.  Only its STRICTLY UPPER triangle is kept (the rest is zero): a
+        // step of the chain wave moves the coordinates after it and leaves the visited ones exactly as they were.
+        constexpr int VE = (int)(16 / sizeof(T));                // elements per 16-byte unit: 4 (f32), 2 (f64)
+        constexpr int UPR = 64 / VE;                             // units per tile row
+        constexpr int RPP = 64 / UPR;                            // tile rows per piece of 64 units: 4 (f32), 2 (f64)
+        constexpr int TP = 64 / RPP;                             // pieces per tile
+        typedef T tvec_t __attribute__((ext_vector_type(VE)));
+        const int r_l = lane / UPR, c_l = (lane % UPR) * VE;     // this lane's row within a piece, first column
         int fin = 0;
         for (int t = 0;; ++t) {
             if (t - __builtin_amdgcn_readfirstlane(fin) >= 2) {
@@ -171,17 +135,22 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                 if (__builtin_amdgcn_readfirstlane(st) != 0) break;
             }
             const int b = t % nblk;
-            unsigned int voff = lane_off + (unsigned int)(64 * b) * RBYTES + (unsigned int)(64 * b * sizeof(T));
-            unsigned int m0v = lds_tile + (unsigned int)(t & 1) * TB;
+            const T *src = Q + (int64_t)(64 * b + r_l) * K + 64 * b + c_l;
+            tvec_t pc[TP];
+#pragma unroll
+            for (int i = 0; i < TP; ++i) pc[i] = *reinterpret_cast<const tvec_t *>(src + (int64_t)(i * RPP) * K);
+            T *dst = reinterpret_cast<T *>(s_tile + (unsigned int)(t & 1) * TB) + r_l * 64 + c_l;
+#pragma unroll
             for (int i = 0; i < TP; ++i) {
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(voff), "s"(Q) : "memory");
-                voff += RPP * RBYTES;
-                m0v += 1024u;
+                const int row = i * RPP + r_l;
+                tvec_t v = pc[i];
+#pragma unroll
+                for (int e = 0; e < VE; ++e) v[e] = (c_l + e > row) ? v[e] : (T)0;
+                *reinterpret_cast<tvec_t *>(dst + i * RPP * 64) = v;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             *tiles = t + 1;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
     if (wid == 1 || wid == 2) {
@@ -282,31 +251,29 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
         };
         publish_H(1);
         if (uh == 0) MODL_STAMP(512);
-        if constexpr ((diag & 32) != 0) return;
         int ready = 0;                                // cached value of the chain wave's counter
-        // one coordinate: H <- fma(w_new, Q_i, fma(-w_old, Q_i, H)) on this wave's entries, then the next request
-        auto step = [&](T (&row)[KU], T dn, T dold, const T *nextp) {
-            if constexpr ((diag & 16) == 0) {
-                // every result is pinned where it is computed: left alone, the compiler sinks the whole chain of
-                // updates to its first use (the block's end) and keeps every row and pair live until then: hundreds of
-                // spills.  f32 pairs go through v_pk_fma_f32 (half the issue slots of this wave's busiest loop).
-                if constexpr (sizeof(T) == 4 && KU % 2 == 0) {
-                    typedef float f2v __attribute__((ext_vector_type(2)));
+        // one coordinate: H <- H + (w_new - w_old) Q_i on this wave's entries (dict_fact_fast.pyx:361-365 and :375-378
+        // as ONE fused multiply-add with the rounded difference), then the next request
+        auto step = [&](T (&row)[KU], T dd, const T *nextp) {
+            // every result is pinned where it is computed: left alone, the compiler sinks the whole chain of
+            // updates to its first use (the block's end) and keeps every row and delta live until then: hundreds of
+            // spills.  f32 pairs go through v_pk_fma_f32 (half the issue slots of this wave's busiest loop).
+            if constexpr (sizeof(T) == 4 && KU % 2 == 0) {
+                typedef float f2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-                    for (int r = 0; r < KU; r += 2) {
-                        f2v h = {H[r], H[r + 1]};
-                        const f2v q2 = {row[r], row[r + 1]}, mo = {-dold, -dold}, pn2 = {dn, dn};
-                        h = __builtin_elementwise_fma(pn2, q2, __builtin_elementwise_fma(mo, q2, h));
-                        asm volatile("" : "+v"(h));
-                        H[r] = h[0];
-                        H[r + 1] = h[1];
-                    }
-                } else {
+                for (int r = 0; r < KU; r += 2) {
+                    f2v h = {H[r], H[r + 1]};
+                    const f2v q2 = {row[r], row[r + 1]}, d2 = {dd, dd};
+                    h = __builtin_elementwise_fma(d2, q2, h);
+                    asm volatile("" : "+v"(h));
+                    H[r] = h[0];
+                    H[r + 1] = h[1];
+                }
+            } else {
 #pragma unroll
-                    for (int r = 0; r < KU; ++r) {
-                        H[r] = fma(dn, row[r], fma(-dold, row[r], H[r]));
-                        asm volatile("" : "+v"(H[r]));
-                    }
+                for (int r = 0; r < KU; ++r) {
+                    H[r] = fma(dd, row[r], H[r]);
+                    asm volatile("" : "+v"(H[r]));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -325,20 +292,20 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
         // the chain as much as the wait they were meant to remove (block 5200 cycles against 4870).)
         auto chunk = [&](auto S0, int cbase, int c8, int halves, auto &&next_of) {
             constexpr int s0 = decltype(S0)::value;
-            T pn[8], po[8];
+            T pd[8];
             ready = spin_until(ready, s_cnt, cbase + c8 + (halves ? 4 : 8));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) SplitPair<T>::load(pairs + (c8 + i) * PW, pn[i], po[i]);
+            for (int i = 0; i < 4; ++i) pd[i] = deltas[c8 + i];
             static_for<4>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                step(ring[s0 + i], pn[i], po[i], next_of(s0 + i));
+                step(ring[s0 + i], pd[i], next_of(s0 + i));
             });
             ready = spin_until(ready, s_cnt, cbase + c8 + 8);
 #pragma unroll
-            for (int i = 4; i < 8; ++i) SplitPair<T>::load(pairs + (c8 + i) * PW, pn[i], po[i]);
+            for (int i = 4; i < 8; ++i) pd[i] = deltas[c8 + i];
             static_for<4>([&](auto I) {
                 constexpr int i = 4 + decltype(I)::value;
-                step(ring[s0 + i], pn[i], po[i], next_of(s0 + i));
+                step(ring[s0 + i], pd[i], next_of(s0 + i));
             });
         };
         if constexpr (FULL) {
@@ -368,23 +335,23 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                         if constexpr (c8 == 56) {                                // the block's last chunk comes as 4 + 4
                             static_for<2>([&](auto HH) {
                                 constexpr int h4 = decltype(HH)::value * 4;
-                                T pn[4], po[4];
+                                T pd[4];
                                 ready = spin_until(ready, s_cnt, base + c8 + h4 + 4);
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) SplitPair<T>::load(pairs + (c8 + h4 + i) * PW, pn[i], po[i]);
+                                for (int i = 0; i < 4; ++i) pd[i] = deltas[c8 + h4 + i];
                                 static_for<4>([&](auto I) {
                                     constexpr int i = decltype(I)::value;
-                                    step(ring[(cs + h4 + i) % R], pn[i], po[i], row_after(cs + h4 + i));
+                                    step(ring[(cs + h4 + i) % R], pd[i], row_after(cs + h4 + i));
                                 });
                             });
                         } else {
-                            T pn[8], po[8];
+                            T pd[8];
                             ready = spin_until(ready, s_cnt, base + c8 + 8);
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) SplitPair<T>::load(pairs + (c8 + i) * PW, pn[i], po[i]);
+                            for (int i = 0; i < 8; ++i) pd[i] = deltas[c8 + i];
                             static_for<8>([&](auto I) {
                                 constexpr int i = decltype(I)::value;
-                                step(ring[(cs + i) % R], pn[i], po[i], row_after(cs + i));
+                                step(ring[(cs + i) % R], pd[i], row_after(cs + i));
                             });
                         }
                     });
@@ -423,7 +390,7 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
 
     // ---------------------------------------------------------------------- chain wave
     // coordinate 64 b + lane in register b; the same vectors once more in cd_kernel's element order for the gap test
-    T w[NB], q[NB], inv[NB], wfix[NB];
+    T w[NB], q[NB], inv[NB], wfix[NB], qdg[NB];
     T qe[KPL];
 #pragma unroll
     for (int bI = 0; bI < NB; ++bI) {
@@ -433,6 +400,7 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
         const T wv = wptr[ec], qv = qptr[ec], dv = Q[(int64_t)ec * K + ec];
         q[bI] = in ? qv : (T)0;
         const T dg = in ? dv : (T)0;
+        qdg[bI] = dg;
         inv[bI] = (dg != (T)0) ? (T)1 / (dg + beta) : (T)0;   // reciprocal of the step denominator (:373); 0 = skipped (:357)
         const bool lv = inv[bI] != (T)0;
         const T w_in = in ? wv : (T)0;
@@ -458,11 +426,16 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
         lds_vT *sH = (lds_vT *)s_H;
         int v0 = ver[0], v1 = ver[1];
         Hb = sH[lane];
-        while (!(diag & 1) && (__builtin_amdgcn_readfirstlane(v0) < 1 || __builtin_amdgcn_readfirstlane(v1) < 1)) {
+        while (__builtin_amdgcn_readfirstlane(v0) < 1 || __builtin_amdgcn_readfirstlane(v1) < 1) {
             v0 = ver[0]; v1 = ver[1];
             Hb = sH[lane];
         }
     }
+    // the step formula on the block's 64 lanes at once (:367-373 with tmp = z): returns w_new - w_old
+    auto delta_of = [&](T z, T ri, T wold) -> T {
+        const T cl = POSITIVE ? (z < alpha ? z : alpha) : clamp3(z, -alpha, alpha);   // as cd_coordinate
+        return fma(z - cl, ri, -wold);
+    };
     bool done = false;
     for (; n_iter < a.max_iter && !done; ++n_iter) {
         T w0[NB];
@@ -473,21 +446,23 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
             if constexpr (!FULL) { if (bI >= nblk) return; }
             const int len = FULL ? 64 : ((bI == nblk - 1) ? kc - 64 * bI : 64);
             const T wob = w[bI];                    // the block's coefficients before the sweep touches them
+            const T rib = inv[bI];
             if (__builtin_amdgcn_readfirstlane(have_tiles) <= tblk) {        // the block's diagonal tile is in LDS
                 do { have_tiles = *tiles; } while (__builtin_amdgcn_readfirstlane(have_tiles) <= tblk);   // (the tile loader never stops first)
             }
             MODL_STAMP(0);
             const int base = 64 * tblk;
-            // row L of the tile, this lane's column: Q[64 b + L][64 b + lane]
+            // Z[m] = q[m] - (H[m] - Q[m][m] w_old[m]): the tmp of :367 of every coordinate of the block, before the
+            // steps of the block's own coordinates (H = Q w with the coefficients as they are at the block's start)
+            T Z = fma(qdg[bI], wob, q[bI]) - Hb;
+            // row L of the tile, this lane's column: Q[64 b + L][64 b + lane] for lane > L, else 0
             lds_vT *tile = (lds_vT *)(s_tile + (unsigned int)(tblk & 1) * TB) + lane;
             // groups of 8 coordinates, everything unrolled (the lane of a coordinate is an immediate); the slices of
-            // the tile and the broadcasts of w_old for the NEXT group are requested before the current one starts
-            T qd[8], qn[8], dolds[8], doldn[8];
+            // the tile for the NEXT group are requested before the current one starts
+            T qd[8], qn[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                qd[i] = tile[i * 64];
-                dolds[i] = bcast_lane(wob, i);
-            }
+            for (int i = 0; i < 8; ++i) qd[i] = tile[i * 64];
+            T dl = 0;
             static_for<8>([&](auto GG) {
                 constexpr int g = decltype(GG)::value;
                 if constexpr (!FULL) { if (g >= 4 && len == 32) return; }   // (a sweep of 64 m + 32 coordinates: short last block)
@@ -498,36 +473,34 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                 static_for<8>([&](auto II) {
                     constexpr int i = decltype(II)::value;
                     constexpr int L = g * 8 + i;                 // lane of the coordinate
-                    // t = fma(-w_old, Q_i, H) on the block's entries is at once the first half of their update
-                    // (:361-365) and, in lane L (whose slice element is the diagonal), the H[ii] of the formula
-                    const T tH = fma(-dolds[i], qd[i], Hb);
-                    const T tmp = q[bI] - tH;                                  // :367
-                    const T cl = POSITIVE ? (tmp < alpha ? tmp : alpha) : clamp3(tmp, -alpha, alpha);   // as cd_coordinate
-                    const T xv = (tmp - cl) * inv[bI];
-                    const T dn = bcast_lane(xv, L);
-                    Hb = fma(dn, qd[i], tH);                                   // :375-378
-                    w[bI] = write_lane<L>(w[bI], dn);
-                    if constexpr (g < 7) doldn[i] = bcast_lane(wob, (g + 1) * 8 + i);   // (off the chain: fills its gaps)
+                    // every lane evaluates the step on its own Z: lane L's is this coordinate's (:367-373), the lanes
+                    // before it reproduce what their own steps found (their Z has not moved since), the lanes after it
+                    // are not there yet
+                    dl = delta_of(Z, rib, wob);
+                    const T dn = bcast_lane(dl, L);
+                    Z = fma(-dn, qd[i], Z);                                    // :361-365, :375-378 on the coordinates after L
                     // the block's last eight are published as 4 + 4: the update waves then have four coordinates left
                     // when the chain needs the next block's H
                     if constexpr ((g == 7 || (!FULL && g == 3)) && i == 3) {
-                        if (!(diag & 4) && (g == 7 || (!FULL && len == 32))) {
-                            SplitPair<T>::store(pairs + lane * PW, w[bI], wob);
+                        if (g == 7 || (!FULL && len == 32)) {
+                            deltas[lane] = dl;
                             asm volatile("" ::: "memory");
                             *prog = base + L + 1;
                             asm volatile("" ::: "memory");
                         }
                     }
                 });
-                if (!(diag & 4)) {                               // publish: every 8 coordinates
-                    SplitPair<T>::store(pairs + lane * PW, w[bI], wob);
-                    asm volatile("" ::: "memory");
-                    *prog = base + g * 8 + 8;
-                    asm volatile("" ::: "memory");
-                }
+                deltas[lane] = dl;                               // publish: every 8 coordinates (lanes <= 8 g + 7 are final)
+                asm volatile("" ::: "memory");
+                *prog = base + g * 8 + 8;
+                asm volatile("" ::: "memory");
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { qd[i] = qn[i]; dolds[i] = doldn[i]; }
+                for (int i = 0; i < 8; ++i) qd[i] = qn[i];
             });
+            {   // the block's new coefficients, from the frozen Z of every coordinate (the product the step rounded)
+                const T cl = POSITIVE ? (Z < alpha ? Z : alpha) : clamp3(Z, -alpha, alpha);
+                w[bI] = (Z - cl) * rib;
+            }
             ++tblk;
             *cblk = tblk;
             MODL_STAMP(0);
@@ -536,7 +509,7 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
             lds_vT *sH = (lds_vT *)s_H;
             int v0 = ver[0], v1 = ver[1];
             Hb = sH[nb_off + lane];
-            while (!(diag & 1) && (__builtin_amdgcn_readfirstlane(v0) < tblk + 1 || __builtin_amdgcn_readfirstlane(v1) < tblk + 1)) {
+            while (__builtin_amdgcn_readfirstlane(v0) < tblk + 1 || __builtin_amdgcn_readfirstlane(v1) < tblk + 1) {
                 v0 = ver[0]; v1 = ver[1];
                 Hb = sH[nb_off + lane];
             }
@@ -611,14 +584,6 @@ template <typename T, int NB>
 void launch_split_nb(hipStream_t stream, const CdArgs<T> &a) {
     dim3 grid((unsigned)a.b), block(256);
     unsigned long long *st = g_cd_stamps.load();
-    if constexpr (std::is_same<T, float>::value && NB == 4) {        // timing experiments (wrong results), f32 k = 256 only
-        switch (g_cd_split_diag.load()) {
-#define MODL_DIAG_CASE(D) case D: if (a.k == 64 * NB) { hipLaunchKernelGGL((cd_split_kernel<T, NB, false, true, D>), grid, block, 0, stream, a, st); return; } break;
-            MODL_DIAG_CASE(33) MODL_DIAG_CASE(37) MODL_DIAG_CASE(1) MODL_DIAG_CASE(17)
-#undef MODL_DIAG_CASE
-            default: break;
-        }
-    }
     const bool full = a.k == 64 * NB;
 #define MODL_SPLIT_LAUNCH(POS, FULL) hipLaunchKernelGGL((cd_split_kernel<T, NB, POS, FULL>), grid, block, 0, stream, a, st)
     if (full) { if (a.positive) MODL_SPLIT_LAUNCH(true, true); else MODL_SPLIT_LAUNCH(false, true); }

@@ -12,7 +12,8 @@ from .device import default_device, dtype_id, sfx, ptr, stream_ptr, to_device
 from .randomkit import batch_weight as _batch_weight  # noqa: F401  (dict_fact_fast.pyx:115)
 
 
-def _regression(kind, G, Dx, X, code, indices, l1_ratio, alpha, positive, tol, max_iter, sweeps=None):
+def _regression(kind, G, Dx, X, code, indices, l1_ratio, alpha, positive, tol, max_iter, sweeps=None, _lib=None):
+    lib = _lib if _lib is not None else globals()['lib']        # (tests: the diagnostics build, _lib.load_diag())
     dev = default_device()
     np_in = isinstance(code, np.ndarray)
     dt = code.dtype if np_in else (np.float32 if code.dtype == torch.float32 else np.float64)
@@ -42,14 +43,14 @@ def _regression(kind, G, Dx, X, code, indices, l1_ratio, alpha, positive, tol, m
     return dcode
 
 
-def _enet_regression_single_gram(G, Dx, X, code, indices, l1_ratio, alpha, positive, tol, max_iter, sweeps=None):
+def _enet_regression_single_gram(G, Dx, X, code, indices, l1_ratio, alpha, positive, tol, max_iter, sweeps=None, _lib=None):
     """dict_fact_fast.pyx:125-215"""
-    return _regression('single', G, Dx, X, code, indices, l1_ratio, alpha, positive, tol, max_iter, sweeps)
+    return _regression('single', G, Dx, X, code, indices, l1_ratio, alpha, positive, tol, max_iter, sweeps, _lib)
 
 
-def _enet_regression_multi_gram(G, Dx, X, code, indices, l1_ratio, alpha, positive, tol, max_iter, sweeps=None):
+def _enet_regression_multi_gram(G, Dx, X, code, indices, l1_ratio, alpha, positive, tol, max_iter, sweeps=None, _lib=None):
     """dict_fact_fast.pyx:33-113"""
-    return _regression('multi', G, Dx, X, code, indices, l1_ratio, alpha, positive, tol, max_iter, sweeps)
+    return _regression('multi', G, Dx, X, code, indices, l1_ratio, alpha, positive, tol, max_iter, sweeps, _lib)
 
 
 def _update_G_average(G_average, G, w_sample):

@@ -209,8 +209,33 @@ def test_debug_switch_numbers_match_the_header(lib):
         if hasattr(_lib, name):
             assert getattr(_lib, name) == value, name
     defaults = {'DEBUG_CD_SPARSE_PCT': -1, 'DEBUG_CD_SPLIT': 1, 'DEBUG_BCD_ACC': 1, 'DEBUG_BCD_TINY': 1, 'DEBUG_STAGE_AHEAD': 1,
-                'DEBUG_CD_STAMPS': 0, 'DEBUG_ATOM_STAMPS': 0, 'DEBUG_CD_SPLIT_DIAG': 0}
+                'DEBUG_CD_STAMPS': 0, 'DEBUG_ATOM_STAMPS': 0}
     assert set(defaults) == set(defs)
+    # the product library only has switches between CORRECT code paths: the stamp switches (they write to a
+    # caller-supplied device buffer) and round 3's timing-experiment switch (4: wrong results) are rejected
+    diag_only = {'DEBUG_CD_STAMPS', 'DEBUG_ATOM_STAMPS'}
+    assert lib.modl_is_diag_build() == 0
     for name, dflt in defaults.items():
-        assert lib.modl_debug_set(defs[name], dflt) == 0, name
+        assert (lib.modl_debug_set(defs[name], dflt) == 0) == (name not in diag_only), name
+    assert lib.modl_debug_set(4, 1) != 0
+    dlib = _lib.load_diag()
+    assert dlib.modl_is_diag_build() == 1
+    for name, dflt in defaults.items():
+        assert dlib.modl_debug_set(defs[name], dflt) == 0, name
+    assert dlib.modl_debug_set(4, 1) != 0
     assert lib.modl_debug_set(max(defs.values()) + 1, 0) != 0
+
+
+def test_product_library_has_no_register_spills():
+    """Every kernel of the product library fits its registers: no scratch instruction in any gfx950 code object (the
+    variants that spill - kept only to be compared with - live in libmodl_hip_diag.so)."""
+    import importlib.util
+    import shutil
+    root = os.path.join(os.path.dirname(__file__), '..')
+    spec = importlib.util.spec_from_file_location('count_scratch', os.path.join(root, 'scripts', 'count_scratch.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.OBJDUMP) or shutil.which('objcopy') is None:
+        pytest.skip('llvm-objdump / objcopy not available')
+    nco, scratch = mod.count(os.path.join(root, 'modl_amd', 'libmodl_hip.so'))
+    assert nco >= 8 and scratch == 0, (nco, scratch)

@@ -273,17 +273,34 @@ def test_ridge_wide_systems_vs_oracle(fast, oracle, dt, k):
         assert_within_f32_noise(c1, c2, c3, k)
 
 
+def _assert_solvers_agree(dt, got, ref, what):
+    """Two roundings of the same sweep (the four-wavefront solver applies w_new - w_old with ONE fused multiply-add where
+    the one-wavefront kernel - the reference's operation order - uses two): f64 to 1e-10 with identical sweep counts;
+    f32 identical sweep counts on >= 95 % of the samples and 2e-5 on those."""
+    (code_a, sw_a), (code_b, sw_b) = got, ref
+    if dt == np.float64:
+        np.testing.assert_array_equal(sw_a, sw_b)
+        err = np.linalg.norm(code_a - code_b) / np.linalg.norm(code_b)
+        assert err < 1e-10, (what, err)
+    else:
+        same = sw_a == sw_b
+        assert same.mean() >= 0.95, (what, same.mean())
+        return same
+
+
 @pytest.mark.parametrize('dt', [np.float32, np.float64])
 @pytest.mark.parametrize('k,b,p,alpha', [(256, 48, 600, 0.3), (200, 33, 400, 0.2), (128, 40, 300, 0.3), (100, 17, 200, 0.3),
                                          (512, 12, 700, 0.3), (330, 9, 600, 0.3), (256, 24, 12, 0.05), (250, 30, 64, 0.1),
                                          (1024, 6, 1100, 0.3), (600, 5, 800, 0.3)])
-def test_cd_two_solvers_are_bit_identical(fast, dt, k, b, p, alpha):
-    """The four-wavefront solver (csrc/cd_split_impl.hpp: chain / update waves / tile loader, shared Gram, 64 < k <= 1024)
-    performs, on every entry of H, the operations of the one-wavefront solver (csrc/cd_solver.hip) in the same order:
-    codes and sweep counts must be IDENTICAL bit for bit - full and padded k, both stopping rules, positivity, a
-    singular Gram matrix running into max_iter.  (modl_debug_set(MODL_DEBUG_CD_SPLIT, 0) forces the one-wavefront
-    solver; every other test of this file runs whichever the library picks, i.e. the new one where it applies.)"""
-    from modl_amd._lib import lib, check, DEBUG_CD_SPLIT
+def test_cd_two_solvers_agree(fast, dt, k, b, p, alpha):
+    """The four-wavefront solver (csrc/cd_split_impl.hpp: chain / update waves / tile loader, shared Gram, 32 <= k <= 1024)
+    against the one-wavefront solver (csrc/cd_solver.hip, the reference's operation order; modl_debug_set(
+    MODL_DEBUG_CD_SPLIT, 0) forces it): same sweep order, skip rule, step formula and stopping tests, the k-wide update
+    rounded once instead of twice - full and padded k, both stopping rules, positivity, a singular Gram matrix running
+    into max_iter.  (Every other test of this file runs whichever the library picks, i.e. the four-wavefront one where
+    it applies, against the oracle.)"""
+    from modl_amd._lib import check, DEBUG_CD_SPLIT, load_diag
+    lib = load_diag()          # (the one-wavefront kernel for k > 256 only exists in the diagnostics build)
     rs = np.random.RandomState(k + b)
     D = rs.randn(k, p).astype(dt)
     D /= np.sqrt((D ** 2).sum(1))[:, None]
@@ -299,22 +316,29 @@ def test_cd_two_solvers_are_bit_identical(fast, dt, k, b, p, alpha):
                 check(lib.modl_debug_set(DEBUG_CD_SPLIT, split))
                 code = np.ones((b + 5, k), dtype=dt)
                 sw = np.zeros(b, dtype=np.int32)
-                fast._enet_regression_single_gram(G, Dx.copy(), X, code, idx, l1, alpha, pos, 1e-2, mi, sweeps=sw)
-                out[split] = (code, sw)
+                fast._enet_regression_single_gram(G, Dx.copy(), X, code, idx, l1, alpha, pos, 1e-2, mi, sweeps=sw, _lib=lib)
+                out[split] = (code[idx], sw)
         finally:
             check(lib.modl_debug_set(DEBUG_CD_SPLIT, 1))
-        np.testing.assert_array_equal(out[0][1], out[1][1])
-        np.testing.assert_array_equal(out[0][0], out[1][0])
+        same = _assert_solvers_agree(dt, out[1], out[0], (k, l1))
+        if dt == np.float32:
+            a_, b_ = out[1][0][same].astype(np.float64), out[0][0][same].astype(np.float64)
+            # (a rank-deficient Gram matrix - p < k - has no unique minimiser: codes then agree through the fit D^T w)
+            if p < k:
+                a_, b_ = a_.dot(D.astype(np.float64)), b_.dot(D.astype(np.float64))
+            err = np.linalg.norm(a_ - b_) / max(np.linalg.norm(b_), 1e-30)
+            assert err < 2e-5, (k, l1, err)
         assert out[0][1].max() > 1
 
 
 @pytest.mark.parametrize('dt', [np.float32, np.float64])
 @pytest.mark.parametrize('k,b', [(128, 9), (256, 5), (70, 9), (200, 7), (600, 3)])
-def test_cd_two_solvers_are_bit_identical_per_sample_gram(fast, dt, k, b):
+def test_cd_two_solvers_agree_per_sample_gram(fast, dt, k, b):
     """A Gram matrix per sample (G_agg = 'average', dict_fact_fast.pyx:33-113) on the four-wavefront solver - k one of
     its strides: solved from where the matrices are stored; any other k: through zero-padded copies of a slice of the
-    minibatch (launch_cd_per_sample) - bit for bit what the one-wavefront kernel gives."""
-    from modl_amd._lib import lib, check, DEBUG_CD_SPLIT
+    minibatch (launch_cd_per_sample) - against the one-wavefront kernel."""
+    from modl_amd._lib import check, DEBUG_CD_SPLIT, load_diag
+    lib = load_diag()
     rs = np.random.RandomState(k + b)
     p = 2 * k
     Gm = np.empty((b, k, k), dtype=dt)
@@ -334,10 +358,12 @@ def test_cd_two_solvers_are_bit_identical_per_sample_gram(fast, dt, k, b):
             check(lib.modl_debug_set(DEBUG_CD_SPLIT, split))
             code = np.ones((b, k), dtype=dt)
             sw = np.zeros(b, dtype=np.int32)
-            fast._enet_regression_multi_gram(Gm.copy(), Dx.copy(), X, code, idx, 0.9, 0.3, False, 1e-2, 100, sweeps=sw)
+            fast._enet_regression_multi_gram(Gm.copy(), Dx.copy(), X, code, idx, 0.9, 0.3, False, 1e-2, 100, sweeps=sw, _lib=lib)
             out[split] = (code, sw)
     finally:
         check(lib.modl_debug_set(DEBUG_CD_SPLIT, 1))
-    np.testing.assert_array_equal(out[0][1], out[1][1])
-    np.testing.assert_array_equal(out[0][0], out[1][0])
+    same = _assert_solvers_agree(dt, out[1], out[0], k)
+    if dt == np.float32:
+        err = np.linalg.norm(out[1][0][same] - out[0][0][same]) / np.linalg.norm(out[0][0][same])
+        assert err < 2e-5, (k, err)
     assert out[0][1].max() > 1

@@ -616,7 +616,7 @@ def test_timed_path_long_horizon_vs_oracle(DictFact, oracle, r):
                 snaps[(dt, t + 1)] = dict(D=st.D.copy(), C=st.C.copy(), B=st.B[:, :64].copy(), code=st.code[t * b:(t + 1) * b].copy(),
                                           sweeps=st.sweeps[-1].copy(), n_iter=st.n_iter)
         snaps[(dt, 'next_subset')] = st.sampler.yield_subset(r) if hasattr(st, 'sampler') else None
-    report = []
+    report, failures = [], []
     for dt in (np.float64, np.float32):
         Xd = torch.from_numpy(X32.astype(dt)).cuda()
         for m in marks:
@@ -629,17 +629,23 @@ def test_timed_path_long_horizon_vs_oracle(DictFact, oracle, r):
             agree = float(np.mean(est._backend.last_sweeps() == snaps[(dt, m)]['sweeps']))
             assert est.n_iter_ == ref64['n_iter'] == m * b
             for key in ('D', 'C', 'B', 'code'):
+                e = rel_fro(got[key], ref64[key])
                 if dt == np.float64:
-                    e = rel_fro(got[key], ref64[key])
-                    assert e < 1e-8, (r, m, key, e)
+                    if not e < 1e-8:
+                        failures.append((r, m, key, e))
+                    report.append(('float64', m, key, float(e)))
                 else:
-                    e, noise = assert_within_f32_noise(got[key], ref32[key], ref64[key], (r, m, key))
-                report.append((np.dtype(dt).name, m, key, float(e)))
+                    noise = rel_fro(ref32[key], ref64[key])
+                    if not e <= 2 * noise + 1e-5:
+                        failures.append((r, m, key, e, noise))
+                    report.append(('float32', m, key, float(e), 'oracle f32 noise %.2e' % noise))
             report.append((np.dtype(dt).name, m, 'sweeps_agree', agree))
-            assert agree >= (1.0 if dt == np.float64 else 0.97), (r, m, agree)
+            if agree < (1.0 if dt == np.float64 else 0.97):
+                failures.append((r, m, 'sweeps_agree', agree))
             if m == marks[-1] and snaps[(dt, 'next_subset')] is not None:
                 assert_array_equal(est.feature_sampler_.yield_subset(r), snaps[(dt, 'next_subset')])
-    print('long horizon r=%d: %s' % (r, report))
+    print('long horizon r=%d:\n%s' % (r, '\n'.join(str(x) for x in report)))
+    assert not failures, failures
 
 
 def test_chunk_call_error_is_consistent(DictFact):
