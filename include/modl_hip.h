@@ -399,6 +399,11 @@ int modl_somf_transform(modl_somf_plan *plan, const void *d_Dt, const void *d_G,
 /* diagnostics: coordinate-descent sweeps per sample of the last phase-1 call of this plan
  * (0 for the ridge branch).  Synchronises `stream`. */
 int modl_somf_last_sweeps(modl_somf_plan *plan, int32_t *h_out, int cap, int *n_out, void *stream);
+/* diagnostics: from now on minibatch number t (counted from this call) of this plan leaves its sweep counts in
+ * d_buf[(t % cap_minibatches) * max_batch ...] (int32, device memory owned by the caller, cap_minibatches * max_batch
+ * entries) - a tolerance-stopped solver may legitimately do a sweep more or less on a sample when its inputs differ in
+ * the last bits, and a long-horizon parity test has to know where that happened.  d_buf == NULL: off. */
+int modl_somf_sweeps_history(modl_somf_plan *plan, int32_t *d_buf, int64_t cap_minibatches);
 
 /* diagnostics: 48 shader-clock stamps of the last fused dictionary-update block launch (40 ..: the first riding tile),
  * h_out[48] (synchronises the device) */

@@ -153,6 +153,7 @@ def bind(lib):
     _sig('modl_somf_debug_stamps', C.c_int, _vp, _vp)
     _sig('modl_somf_debug_gemm_stamps', C.c_int, _vp, _vp)
     _sig('modl_somf_last_sweeps', C.c_int, _vp, _vp, C.c_int, _P(C.c_int), _vp)
+    _sig('modl_somf_sweeps_history', C.c_int, _vp, _vp, _i64)
     _sig('modl_somf_prof_enable', C.c_int, _vp, C.c_int)
     _sig('modl_somf_prof_stride', C.c_int, _vp, C.c_int)
     _sig('modl_somf_host_wait_ms', C.c_int, _vp, _P(_f64), C.c_int)

@@ -80,13 +80,22 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
     constexpr int KPL = NB;                           // cd_kernel's layout: element e <-> register e % KPL of lane e / KPL
     constexpr unsigned int TRB = 64 * sizeof(T);      // bytes of a row of a diagonal tile
     constexpr unsigned int TB = 64 * TRB;             // bytes of a tile: 16 / 32 KiB
+    // LA: look-ahead.  The chain wave applies the block's LAST LA coordinates to the NEXT block's entries itself (one
+    // extra fma per coordinate, with the delta it has just broadcast, on a strip of rows the tile loader brings), so
+    // what it needs from the update waves at a block boundary is H as it was LA coordinates before the block's end:
+    // they run ~1200 cycles (two LDS round trips and a chunk) behind, which the chain used to wait for, four times a sweep.
+    constexpr int LA = FULL ? 32 : 0;
+    constexpr bool NEAR = sizeof(T) == 4;             // the step of coordinate L reaches coordinate L + 1 through DPP (f32)
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[2 * TB];
-    __shared__ T s_delta[64];                         // w_new - w_old of the chain wave's current block, by lane
+    __shared__ __attribute__((aligned(16))) T s_strip[LA > 0 ? 2 * LA * 64 : 4];   // rows 64 b + 64 - LA .. of the columns of block b + 1
+    __shared__ T s_delta[2 * 64];                     // w_new - w_old of the chain wave's current block, by lane (blocks alternate)
     __shared__ __attribute__((aligned(16))) T s_H[K]; // H after a whole block (cd_kernel's element order = plain order)
+    __shared__ __attribute__((aligned(16))) T s_Hs[K];// H after the first 64 - LA coordinates of a block (look-ahead hand-off)
     __shared__ T s_w[K];                              // the chain wave's coefficients, for the gap test
-    __shared__ int s_cnt[8];
+    __shared__ int s_cnt[12];
     typedef __attribute__((address_space(3))) volatile T lds_vT;
     lds_vT *deltas = (lds_vT *)s_delta;
+    lds_vi32 *sver = (lds_vi32 *)&s_cnt[8];           // update waves 0 / 1 (s_cnt[8], [9]): 2 + the block whose snapshot is in s_Hs
     lds_vi32 *prog = (lds_vi32 *)&s_cnt[0];           // chain: 64 * (blocks finished) + coordinates published of the current one
     lds_vi32 *ver = (lds_vi32 *)&s_cnt[1];            // update waves 0 / 1 (s_cnt[1], [2]): 1 + blocks applied completely
                                                       // (their halves of the next block's H are in s_H)
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
     T *wptr = a.code + row_out * k;
     const T *qptr = a.Dx + (int64_t)smp * k;
     const T alpha = a.alpha, beta = a.beta;
-    if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 12) s_cnt[threadIdx.x] = 0;
     __syncthreads();
 
     if (wid == 3) {
@@ -147,6 +156,19 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
 #pragma unroll
                 for (int e = 0; e < VE; ++e) v[e] = (c_l + e > row) ? v[e] : (T)0;
                 *reinterpret_cast<tvec_t *>(dst + i * RPP * 64) = v;
+            }
+            if constexpr (LA > 0) {
+                // the strip of the transition b -> b + 1 (the sweep's last block -> block 0): the block's last LA rows,
+                // the NEXT block's columns, as they are
+                constexpr int SP = LA / RPP;
+                const int nb2 = (b + 1 == nblk) ? 0 : b + 1;
+                const T *ssrc = Q + (int64_t)(64 * b + 64 - LA + r_l) * K + 64 * nb2 + c_l;
+                tvec_t sp[SP];
+#pragma unroll
+                for (int i = 0; i < SP; ++i) sp[i] = *reinterpret_cast<const tvec_t *>(ssrc + (int64_t)(i * RPP) * K);
+                T *sdst = s_strip + (t & 1) * (LA * 64) + r_l * 64 + c_l;
+#pragma unroll
+                for (int i = 0; i < SP; ++i) *reinterpret_cast<tvec_t *>(sdst + i * RPP * 64) = sp[i];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             *tiles = t + 1;
@@ -249,6 +271,18 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
             asm volatile("" ::: "memory");
             ver[uh] = version;
         };
+        auto publish_snap = [&](int version) {        // (look-ahead hand-off: H after the first 64 - LA coordinates of a block)
+            if constexpr (KU == 1) {
+                s_Hs[e0] = H[0];
+            } else {
+                hvec_t hv;
+#pragma unroll
+                for (int c = 0; c < KU; ++c) hv[c] = H[c];
+                *reinterpret_cast<hvec_t *>(&s_Hs[e0]) = hv;
+            }
+            asm volatile("" ::: "memory");
+            sver[uh] = version;
+        };
         publish_H(1);
         if (uh == 0) MODL_STAMP(512);
         int ready = 0;                                // cached value of the chain wave's counter
@@ -293,16 +327,17 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
         auto chunk = [&](auto S0, int cbase, int c8, int halves, auto &&next_of) {
             constexpr int s0 = decltype(S0)::value;
             T pd[8];
+            const int dbo = (cbase >> 6 & 1) * 64;    // (the deltas of consecutive blocks alternate between two buffers)
             ready = spin_until(ready, s_cnt, cbase + c8 + (halves ? 4 : 8));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pd[i] = deltas[c8 + i];
+            for (int i = 0; i < 4; ++i) pd[i] = deltas[dbo + c8 + i];
             static_for<4>([&](auto I) {
                 constexpr int i = decltype(I)::value;
                 step(ring[s0 + i], pd[i], next_of(s0 + i));
             });
             ready = spin_until(ready, s_cnt, cbase + c8 + 8);
 #pragma unroll
-            for (int i = 4; i < 8; ++i) pd[i] = deltas[c8 + i];
+            for (int i = 4; i < 8; ++i) pd[i] = deltas[dbo + c8 + i];
             static_for<4>([&](auto I) {
                 constexpr int i = 4 + decltype(I)::value;
                 step(ring[s0 + i], pd[i], next_of(s0 + i));
@@ -321,6 +356,7 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                 static_for<NB>([&](auto BB) {
                     constexpr int bb = decltype(BB)::value;
                     const int t = sw * NB + bb, base = 64 * t;
+                    const int dbo = (t & 1) * 64;
                     // the first coordinates of a block that never comes: the chain wave has ended the solve.  (The
                     // wave ends inside the assembly block: no join for the compiler; loads in flight die with it.)
                     ready = spin_until(ready, s_cnt, base + 8);
@@ -332,28 +368,17 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                         if constexpr (c8 == 32) { if (uh == 0) MODL_STAMP(512); }
                         // (the slot of coordinate c of the sweep is c % R; it is refilled with row (c + R) mod K)
                         auto row_after = [&](int c) { return mine + (int64_t)((c + R) % K) * K; };
-                        if constexpr (c8 == 56) {                                // the block's last chunk comes as 4 + 4
-                            static_for<2>([&](auto HH) {
-                                constexpr int h4 = decltype(HH)::value * 4;
-                                T pd[4];
-                                ready = spin_until(ready, s_cnt, base + c8 + h4 + 4);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) pd[i] = deltas[c8 + h4 + i];
-                                static_for<4>([&](auto I) {
-                                    constexpr int i = decltype(I)::value;
-                                    step(ring[(cs + h4 + i) % R], pd[i], row_after(cs + h4 + i));
-                                });
-                            });
-                        } else {
+                        {
                             T pd[8];
                             ready = spin_until(ready, s_cnt, base + c8 + 8);
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) pd[i] = deltas[c8 + i];
+                            for (int i = 0; i < 8; ++i) pd[i] = deltas[dbo + c8 + i];
                             static_for<8>([&](auto I) {
                                 constexpr int i = decltype(I)::value;
                                 step(ring[(cs + i) % R], pd[i], row_after(cs + i));
                             });
                         }
+                        if constexpr (LA > 0 && c8 + 8 == 64 - LA) publish_snap(t + 2);
                     });
                     publish_H(t + 2);
                     if (uh == 0) MODL_STAMP(512);
@@ -436,6 +461,7 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
         const T cl = POSITIVE ? (z < alpha ? z : alpha) : clamp3(z, -alpha, alpha);   // as cd_coordinate
         return fma(z - cl, ri, -wold);
     };
+    T Zcarry = 0;                                   // look-ahead: what the previous block's last LA steps did to this block
     bool done = false;
     for (; n_iter < a.max_iter && !done; ++n_iter) {
         T w0[NB];
@@ -452,65 +478,111 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
             }
             MODL_STAMP(0);
             const int base = 64 * tblk;
+            const int dbo = (tblk & 1) * 64;
             // Z[m] = q[m] - (H[m] - Q[m][m] w_old[m]): the tmp of :367 of every coordinate of the block, before the
             // steps of the block's own coordinates (H = Q w with the coefficients as they are at the block's start)
-            T Z = fma(qdg[bI], wob, q[bI]) - Hb;
+            T Z = (fma(qdg[bI], wob, q[bI]) - Hb) + Zcarry;
+            T Zla = 0;                              // look-ahead: this block's last LA steps on the NEXT block's entries
             // row L of the tile, this lane's column: Q[64 b + L][64 b + lane] for lane > L, else 0
             lds_vT *tile = (lds_vT *)(s_tile + (unsigned int)(tblk & 1) * TB) + lane;
+            lds_vT *strip = (lds_vT *)(s_strip + (LA > 0 ? (tblk & 1) * (LA * 64) : 0)) + lane;
             // groups of 8 coordinates, everything unrolled (the lane of a coordinate is an immediate); the slices of
-            // the tile for the NEXT group are requested before the current one starts
-            T qd[8], qn[8];
+            // the tile (and of the strip) for the NEXT group are requested before the current one starts
+            T qd[8], qn[8], sd[8], sn[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) qd[i] = tile[i * 64];
-            T dl = 0;
+            for (int i = 0; i < 8; ++i) { qd[i] = tile[i * 64]; sd[i] = 0; sn[i] = 0; }
+            // NEAR: minus the tile's first superdiagonal, Q[64 b + lane - 1][64 b + lane] (what coordinate L does to L + 1)
+            T ngs = 0;
+            if constexpr (NEAR) ngs = -tile[(lane > 0 ? lane - 1 : 0) * 64];
+            T dl = 0, qlast = 0, slast = 0;
+            // what the step of coordinate LP (delta in lane LP of dlv) does to the coordinates after it in the block (:361-365
+            // and :375-378 as one fused multiply-add with the rounded difference) and, look-ahead, to the next block
+            auto apply = [&](auto LP_, T dlv, T rowv, T spv) {
+                constexpr int LP = decltype(LP_)::value;
+                const T dn = bcast_lane(dlv, LP);
+                Z = fma(-dn, rowv, Z);
+                if constexpr (LA > 0 && LP >= 64 - LA) Zla = fma(-dn, spv, Zla);
+            };
             static_for<8>([&](auto GG) {
                 constexpr int g = decltype(GG)::value;
                 if constexpr (!FULL) { if (g >= 4 && len == 32) return; }   // (a sweep of 64 m + 32 coordinates: short last block)
                 if constexpr (g < 7) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) qn[i] = tile[((g + 1) * 8 + i) * 64];
+                    if constexpr (LA > 0 && (g + 1) * 8 >= 64 - LA) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) sn[i] = strip[((g + 1) * 8 + i - (64 - LA)) * 64];
+                    }
                 }
                 static_for<8>([&](auto II) {
                     constexpr int i = decltype(II)::value;
                     constexpr int L = g * 8 + i;                 // lane of the coordinate
-                    // every lane evaluates the step on its own Z: lane L's is this coordinate's (:367-373), the lanes
-                    // before it reproduce what their own steps found (their Z has not moved since), the lanes after it
-                    // are not there yet
-                    dl = delta_of(Z, rib, wob);
-                    const T dn = bcast_lane(dl, L);
-                    Z = fma(-dn, qd[i], Z);                                    // :361-365, :375-378 on the coordinates after L
-                    // the block's last eight are published as 4 + 4: the update waves then have four coordinates left
-                    // when the chain needs the next block's H
-                    if constexpr ((g == 7 || (!FULL && g == 3)) && i == 3) {
-                        if (g == 7 || (!FULL && len == 32)) {
-                            deltas[lane] = dl;
+                    if constexpr (NEAR) {
+                        // The k-wide effect of coordinate L - 1 is applied one step LATE (its broadcast, v_readlane ->
+                        // scalar register -> v_fma, is the long hop of the chain); coordinate L gets it from its
+                        // neighbour lane through DPP meanwhile: tmp = Z[L] - Q[L-1][L] delta[L-1], the very fused
+                        // multiply-add the late update then performs on Z[L] - which is therefore frozen at the value
+                        // this step used, as without the detour.
+                        T tmp = Z;
+                        if constexpr (L > 0)
+                            asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf"
+                                         : "+v"(tmp) : "v"(dl), "v"(ngs));
+                        const T dlp = dl;
+                        dl = delta_of(tmp, rib, wob);
+                        if constexpr (L > 0) {
+                            if constexpr (i > 0) apply(std::integral_constant<int, (L > 0 ? L - 1 : 0)>{}, dlp, qd[i > 0 ? i - 1 : 0], sd[i > 0 ? i - 1 : 0]);
+                            else apply(std::integral_constant<int, (L > 0 ? L - 1 : 0)>{}, dlp, qlast, slast);
+                        }
+                    } else {
+                        // every lane evaluates the step on its own Z: lane L's is this coordinate's (:367-373), the lanes
+                        // before it reproduce what their own steps found (their Z has not moved since), the lanes after it
+                        // are not there yet
+                        dl = delta_of(Z, rib, wob);
+                        apply(std::integral_constant<int, L>{}, dl, qd[i], sd[i]);
+                    }
+                    // (!FULL) the block's last eight are published as 4 + 4: the update waves then have four coordinates
+                    // left when the chain needs the next block's H
+                    if constexpr (!FULL && (g == 7 || g == 3) && i == 3) {
+                        if (g == 7 || len == 32) {
+                            deltas[dbo + lane] = NEAR ? delta_of(Z, rib, wob) : dl;
                             asm volatile("" ::: "memory");
                             *prog = base + L + 1;
                             asm volatile("" ::: "memory");
                         }
                     }
                 });
-                deltas[lane] = dl;                               // publish: every 8 coordinates (lanes <= 8 g + 7 are final)
+                // publish: every 8 coordinates.  The lanes <= 8 g + 7 are final: re-evaluated from their frozen Z (NEAR:
+                // lane 8 g + 7's Z has received coordinate 8 g + 6 in the step just done)
+                deltas[dbo + lane] = NEAR ? delta_of(Z, rib, wob) : dl;
                 asm volatile("" ::: "memory");
                 *prog = base + g * 8 + 8;
                 asm volatile("" ::: "memory");
+                qlast = qd[7];
+                slast = sd[7];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) qd[i] = qn[i];
+                for (int i = 0; i < 8; ++i) { qd[i] = qn[i]; sd[i] = sn[i]; }
             });
             {   // the block's new coefficients, from the frozen Z of every coordinate (the product the step rounded)
                 const T cl = POSITIVE ? (Z < alpha ? Z : alpha) : clamp3(Z, -alpha, alpha);
                 w[bI] = (Z - cl) * rib;
             }
+            if constexpr (NEAR && LA > 0) {         // the last coordinate's step still has to reach the next block
+                const T dn = bcast_lane(dl, 63);
+                Zla = fma(-dn, slast, Zla);
+            }
+            Zcarry = Zla;
             ++tblk;
             *cblk = tblk;
             MODL_STAMP(0);
-            // the next block's entries of H (the first block's, after the sweep's last one), complete
+            // the next block's entries of H (the first block's, after the sweep's last one): complete, or (look-ahead)
+            // as they were LA coordinates before the end of the block just finished
             const int nb_off = (bI + 1 < nblk) ? 64 * (bI + 1) : 0;
-            lds_vT *sH = (lds_vT *)s_H;
-            int v0 = ver[0], v1 = ver[1];
+            lds_vT *sH = (lds_vT *)(LA > 0 ? s_Hs : s_H);
+            lds_vi32 *vv = LA > 0 ? sver : ver;
+            int v0 = vv[0], v1 = vv[1];
             Hb = sH[nb_off + lane];
             while (__builtin_amdgcn_readfirstlane(v0) < tblk + 1 || __builtin_amdgcn_readfirstlane(v1) < tblk + 1) {
-                v0 = ver[0]; v1 = ver[1];
+                v0 = vv[0]; v1 = vv[1];
                 Hb = sH[nb_off + lane];
             }
             asm volatile("" ::: "memory");          // (the gap test below reads s_H with plain loads)
@@ -524,6 +596,13 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
         }
         const T d_w_max = wave_max(dmx), w_max = wave_max(wmx);
         if (w_max == (T)0 || d_w_max / w_max < d_w_tol || n_iter == a.max_iter - 1) {   // :388
+            if constexpr (LA > 0) {                 // (look-ahead: nobody has waited for the sweep's complete H yet)
+                int v0 = ver[0], v1 = ver[1];
+                while (__builtin_amdgcn_readfirstlane(v0) < tblk + 1 || __builtin_amdgcn_readfirstlane(v1) < tblk + 1) {
+                    v0 = ver[0]; v1 = ver[1];
+                }
+                asm volatile("" ::: "memory");
+            }
             // cd_kernel's element order (lane l <-> elements KPL l ..): the reductions round as they do there
 #pragma unroll
             for (int bI = 0; bI < NB; ++bI) s_w[64 * bI + lane] = w[bI] + wfix[bI];     // one of the two is zero

@@ -255,6 +255,10 @@ struct modl_somf_plan {
     bool ride_pending = false;         // single-GPU step: the B_ update of the rows that were not sampled rides along
     StatsRider rider{};                // the dictionary update (see StatsRider)
     int32_t step_id = 0;
+    // diagnostics (modl_somf_sweeps_history): the sweep counts of EVERY minibatch, a ring of hist_cap slots of max_batch
+    int32_t *hist = nullptr;
+    int64_t hist_cap = 0, hist_n = 0;
+    const int32_t *last_sweeps_ptr = nullptr;
     size_t off_stamp = 0, off_pos = 0, off_gstamps = 0;
     unsigned prof_mask = ~0u;          // sections that record events
     int prof_stride = 1;               // ... on every prof_stride-th minibatch only (an event pair costs ~9 us of bubble)
@@ -599,6 +603,8 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
     T *Fbuf = reinterpret_cast<T *>(pl->dws + pl->off_F);
     SplitWs sws{pl->dws + pl->off_split, pl->split_bytes};
     int32_t *d_sweeps = reinterpret_cast<int32_t *>(pl->dws + pl->off_sweeps);
+    if (pl->hist) d_sweeps = pl->hist + (pl->hist_n++ % pl->hist_cap) * (int64_t)d.max_batch;
+    pl->last_sweeps_ptr = d_sweeps;
     pl->last_b = b;
     const T red = (T)bt->reduction;
 
@@ -1418,9 +1424,19 @@ int modl_somf_last_sweeps(modl_somf_plan *pl, int32_t *h_out, int cap, int *n_ou
     const int n = pl->last_b < cap ? pl->last_b : cap;
     *n_out = n;
     if (n <= 0) return MODL_OK;
-    MODL_HIP(hipMemcpyAsync(h_out, pl->dws + pl->off_sweeps, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost,
+    const void *src = pl->last_sweeps_ptr ? (const void *)pl->last_sweeps_ptr : (const void *)(pl->dws + pl->off_sweeps);
+    MODL_HIP(hipMemcpyAsync(h_out, src, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost,
                             (hipStream_t)stream));
     MODL_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return MODL_OK;
+}
+
+int modl_somf_sweeps_history(modl_somf_plan *pl, int32_t *d_buf, int64_t cap_minibatches) {
+    if (!pl || (d_buf && cap_minibatches <= 0)) return MODL_EINVAL;
+    pl->hist = d_buf;
+    pl->hist_cap = d_buf ? cap_minibatches : 0;
+    pl->hist_n = 0;
+    pl->last_sweeps_ptr = nullptr;
     return MODL_OK;
 }
 

@@ -414,6 +414,18 @@ class HipBackend:
                                         stream_ptr(self.device)))
         return out[:n.value]
 
+    def sweeps_history(self, n_minibatches):
+        """diagnostics: keep the sweep counts of the next `n_minibatches` minibatches (a ring); returns a function that
+        reads them back as an (n, max_batch) array, oldest first (None: off)"""
+        if not n_minibatches:
+            check(lib.modl_somf_sweeps_history(self.plan, None, 0))
+            self._sweep_hist = None
+            return None
+        mb = self._desc_kw['max_batch']
+        self._sweep_hist = torch.zeros((int(n_minibatches), mb), dtype=torch.int32, device=self.device)
+        check(lib.modl_somf_sweeps_history(self.plan, ptr(self._sweep_hist), int(n_minibatches)))
+        return lambda: self._sweep_hist.cpu().numpy()
+
     # -- profiling ------------------------------------------------------------
     PROF_SECTIONS = ('code_gemm', 'code_solve', 'stats_gemm', 'stats_apply', 'dict_update')
 

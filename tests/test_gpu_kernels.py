@@ -327,7 +327,7 @@ def test_cd_two_solvers_agree(fast, dt, k, b, p, alpha):
             if p < k:
                 a_, b_ = a_.dot(D.astype(np.float64)), b_.dot(D.astype(np.float64))
             err = np.linalg.norm(a_ - b_) / max(np.linalg.norm(b_), 1e-30)
-            assert err < 2e-5, (k, l1, err)
+            assert err < (1e-4 if p < k else 2e-5), (k, l1, err)
         assert out[0][1].max() > 1
 
 

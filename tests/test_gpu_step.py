@@ -595,16 +595,20 @@ def test_timed_path_long_horizon_vs_oracle(DictFact, oracle, r):
     wraps five times, both device parameter blocks alternate, the staging copy of minibatch t + 1 and the statistics
     product of the rows that were not sampled ride on the dictionary update's launches, warm starts are chunk-local -
     against the CPU oracle fitted on the same rows.  Calls of 8, 16, 32 and 48 minibatches (each from a fresh
-    estimator) are compared with the oracle's state after as many: f64 <= 1e-8 on D, C and B[:, :64]; f32 within the
-    reference algorithm's own f32 noise (2 noise + 1e-5); n_iter_ and both generators left in step with the oracle's
-    (all 48 subset draws: a subset that differed would move D by O(1))."""
-    from .conftest import m1_rows, HEADLINE_KW, assert_within_f32_noise
+    estimator) are compared with the oracle's state after as many: f64 <= 1e-8 on D, C, B[:, :64] and the last
+    minibatch's codes with the oracle's sweep count on EVERY sample of EVERY minibatch (modl_somf_sweeps_history);
+    f32 within the reference algorithm's own f32 noise (2 noise + 1e-5) as long as every sample so far did the f64
+    oracle's number of sweeps - a tolerance-stopped solver may legitimately do a sweep more or less on a sample whose
+    duality gap sits on the threshold when its inputs differ in the last bits (the oracle's own f32 run does it too);
+    such flips must stay under 0.1 % of the samples and the distance under 2 noise + 6e-5 after one.  n_iter_ and both
+    generators are left in step with the oracle's (all 48 subset draws: a subset that differed would move D by O(1))."""
+    from .conftest import m1_rows, HEADLINE_KW
     import torch
     p, b, marks = 10000, 256, (8, 16, 32, 48)
     n = marks[-1] * b
     X32 = m1_rows(n, p, seed=77)
     kw = dict(HEADLINE_KW, reduction=r)
-    snaps = {}
+    snaps, sweeps = {}, {}
     for dt in (np.float64, np.float32):
         X = X32.astype(dt)
         pr = oracle.SomfParams(**kw)
@@ -614,19 +618,23 @@ def test_timed_path_long_horizon_vs_oracle(DictFact, oracle, r):
             oracle.partial_fit(st, pr, X[t * b:(t + 1) * b], np.arange(t * b, (t + 1) * b))
             if t + 1 in marks:
                 snaps[(dt, t + 1)] = dict(D=st.D.copy(), C=st.C.copy(), B=st.B[:, :64].copy(), code=st.code[t * b:(t + 1) * b].copy(),
-                                          sweeps=st.sweeps[-1].copy(), n_iter=st.n_iter)
-        snaps[(dt, 'next_subset')] = st.sampler.yield_subset(r) if hasattr(st, 'sampler') else None
-    report, failures = [], []
+                                          n_iter=st.n_iter)
+        sweeps[dt] = np.stack(st.sweeps)
+        snaps[(dt, 'next_subset')] = st.sampler.yield_subset(r)
+    flips_ref = int((sweeps[np.float32] != sweeps[np.float64]).sum())
+    report, failures = ['oracle f32 vs oracle f64: %d samples with another sweep count' % flips_ref], []
     for dt in (np.float64, np.float32):
         Xd = torch.from_numpy(X32.astype(dt)).cuda()
         for m in marks:
             est = DictFact(**kw)
             est.prepare(n_samples=n, X=X32[:256].astype(dt))
             assert est._chunk_call_applies(est._backend, np.arange(m * b))          # the one-call-per-chunk route
+            hist = est._backend.sweeps_history(m)
             est.partial_fit(Xd[:m * b], np.arange(m * b))
+            sw = hist()
             ref64, ref32 = snaps[(np.float64, m)], snaps[(np.float32, m)]
             got = dict(D=est.components_, C=est.C_, B=est.B_[:, :64], code=est.code_[(m - 1) * b:m * b])
-            agree = float(np.mean(est._backend.last_sweeps() == snaps[(dt, m)]['sweeps']))
+            flips = int((sw != sweeps[np.float64][:m]).sum())
             assert est.n_iter_ == ref64['n_iter'] == m * b
             for key in ('D', 'C', 'B', 'code'):
                 e = rel_fro(got[key], ref64[key])
@@ -636,13 +644,13 @@ def test_timed_path_long_horizon_vs_oracle(DictFact, oracle, r):
                     report.append(('float64', m, key, float(e)))
                 else:
                     noise = rel_fro(ref32[key], ref64[key])
-                    if not e <= 2 * noise + 1e-5:
-                        failures.append((r, m, key, e, noise))
+                    if not e <= 2 * noise + 1e-5 + (6e-5 if flips else 0.0):
+                        failures.append((r, m, key, e, noise, flips))
                     report.append(('float32', m, key, float(e), 'oracle f32 noise %.2e' % noise))
-            report.append((np.dtype(dt).name, m, 'sweeps_agree', agree))
-            if agree < (1.0 if dt == np.float64 else 0.97):
-                failures.append((r, m, 'sweeps_agree', agree))
-            if m == marks[-1] and snaps[(dt, 'next_subset')] is not None:
+            report.append((np.dtype(dt).name, m, 'samples with another sweep count than the f64 oracle', flips))
+            if flips > (0 if dt == np.float64 else 1e-3 * m * b):
+                failures.append((r, m, 'sweep flips', flips))
+            if m == marks[-1]:
                 assert_array_equal(est.feature_sampler_.yield_subset(r), snaps[(dt, 'next_subset')])
     print('long horizon r=%d:\n%s' % (r, '\n'.join(str(x) for x in report)))
     assert not failures, failures
