@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 K_COMP, P_FEAT, BATCH, CHUNK, BLOCK = 256, 10000, 256, 65536, 8192
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = 'r03_pmc_hbm_traffic.json'
+PMC_FILES = ('r04_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic.json')     # the newest committed PMC passes
 DOM_KERNEL = {'dict_update': 'modl::bcd_block_kernel', 'code_solve': 'modl::cd_split_kernel', 'stats_gemm': 'modl::gemm_stats_pair_kernel',
               'code_gemm': 'modl::gemm_dense_pair_kernel<float, false', 'stats_apply': 'modl::stats_apply2_kernel'}
 # the calibration of the CPU port against the real reference, measured in the build container
@@ -490,6 +490,7 @@ def roofline_of(dom, prof_dom, fl, by, reduction):
     # HBM traffic per launch of the section's main kernel: from the committed rocprofv3 --pmc passes of this round
     # (FETCH_SIZE and WRITE_SIZE need separate profiler passes and cannot be collected from inside this process)
     try:
+        PMC_FILE = [f for f in PMC_FILES if os.path.exists(os.path.join(ROOT, 'profiles', f))][0]
         pmc = json.load(open(os.path.join(ROOT, 'profiles', PMC_FILE)))
         kern = [k_ for k_ in pmc if k_.startswith(DOM_KERNEL.get(dom, '?'))]
         if kern and abs(reduction - 10.0) < 1e-9:
@@ -497,7 +498,7 @@ def roofline_of(dom, prof_dom, fl, by, reduction):
             roof['traffic'] = e.get('fetch_bytes_corrected', 0.0) + e.get('write_bytes', 0.0)
             roof['traffic_source'] = ('OFFLINE: profiles/%s (rocprofv3 --pmc passes of bench.py at reduction=10): %s, '
                                       'FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per launch' % (PMC_FILE, kern[0]))
-    except (OSError, ValueError):
+    except (OSError, ValueError, IndexError):
         pass
     return roof
 

@@ -16,16 +16,21 @@
 //     re-evaluating the step formula on all 64 lanes (which every step does) reproduces the visited coordinates'
 //     results bit for bit - no per-coordinate write-back (v_writelane) of the result, no separate w_old pass.  Per
 //     coordinate: v_med3, v_sub, v_fma (delta = w_new - w_old), v_readlane, v_fma (Z), ds_read: SIX instructions
-//     (round 3: ten).  Every 8 coordinates it publishes the block's deltas and a monotonic counter to LDS;
+//     (round 3: ten).  Every 8 coordinates it publishes the block's new coefficients and a monotonic counter to LDS;
 //   * two UPDATE waves (a column half each) apply the published steps to all k entries of H = Q w, in coordinate
-//     order, as ONE fused multiply-add per element (H <- H + delta_j Q_j; round 3: two, H - w_old Q_j + w_new Q_j, the
-//     reference's operation order), a chunk of 8 behind the chain, from a register ring of Gram rows requested a ring
-//     ahead, and hand the next block its 64 entries of H through LDS when the chain reaches a block boundary;
+//     order, with the reference's two fused multiply-adds per element (H <- fma(w_new, Q_j, fma(-w_old, Q_j, H)): a single
+//     fma with the rounded difference is MORE accurate per operation and was measured 1.7 x NOISIER on the codes), a chunk
+//     of 8 behind the chain, from a register ring of Gram rows requested a ring ahead; the counter and the chunk's pairs
+//     come in ONE LDS round trip.  They hand the next block its 64 entries of H through LDS: a snapshot taken 32
+//     coordinates before the block's end - the chain wave applies those last 32 steps to the next block itself (LOOK-AHEAD:
+//     one more fma per coordinate with the delta it has just broadcast, on a strip of rows the tile loader brings), so it
+//     no longer waits ~1200 cycles at every block boundary for the update waves to catch up;
 //   * the TILE loader brings the diagonal tile of the chain's next block (plain 16-byte loads), clears its lower
 //     triangle and diagonal in registers and stores it to one of two LDS buffers.
-// Same sweep order, skip rule, step formula and both stopping tests as the reference; what differs from its
-// operation order is the ROUNDING of the k-wide update (one fma with the rounded difference instead of two), so the
-// iterates agree with cd_kernel / the oracle to rounding noise, not bit for bit (tests/test_gpu_kernels.py:
+// Same sweep order, skip rule, step formula and both stopping tests as the reference, the same two roundings per element
+// on H; what differs from its operation order is the rounding INSIDE a block of 64 coordinates (the chain wave's private
+// Z takes one fma with the rounded difference per earlier coordinate of the block), so the iterates agree with
+// cd_kernel / the oracle to rounding noise, not bit for bit (tests/test_gpu_kernels.py:
 // test_cd_two_solvers_agree: f64 <= 1e-12 with identical sweep counts, f32 within the f32 noise rule).  The gap test
 // reads w, q and H in cd_kernel's element order (lane l <-> elements KPL l ..).
 //
@@ -85,16 +90,17 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
     // what it needs from the update waves at a block boundary is H as it was LA coordinates before the block's end:
     // they run ~1200 cycles (two LDS round trips and a chunk) behind, which the chain used to wait for, four times a sweep.
     constexpr int LA = FULL ? 32 : 0;
-    constexpr bool NEAR = sizeof(T) == 4;             // the step of coordinate L reaches coordinate L + 1 through DPP (f32)
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[2 * TB];
     __shared__ __attribute__((aligned(16))) T s_strip[LA > 0 ? 2 * LA * 64 : 4];   // rows 64 b + 64 - LA .. of the columns of block b + 1
-    __shared__ T s_delta[2 * 64];                     // w_new - w_old of the chain wave's current block, by lane (blocks alternate)
+    __shared__ __attribute__((aligned(16))) T s_wn[2 * 64];   // the chain wave's current block: new coefficients, by lane (blocks alternate) ...
+    __shared__ __attribute__((aligned(16))) T s_wo[2 * 64];   // ... and the coefficients the block had before the sweep touched it
     __shared__ __attribute__((aligned(16))) T s_H[K]; // H after a whole block (cd_kernel's element order = plain order)
     __shared__ __attribute__((aligned(16))) T s_Hs[K];// H after the first 64 - LA coordinates of a block (look-ahead hand-off)
     __shared__ T s_w[K];                              // the chain wave's coefficients, for the gap test
     __shared__ int s_cnt[12];
     typedef __attribute__((address_space(3))) volatile T lds_vT;
-    lds_vT *deltas = (lds_vT *)s_delta;
+    lds_vT *wns = (lds_vT *)s_wn;
+    lds_vT *wos = (lds_vT *)s_wo;
     lds_vi32 *sver = (lds_vi32 *)&s_cnt[8];           // update waves 0 / 1 (s_cnt[8], [9]): 2 + the block whose snapshot is in s_Hs
     lds_vi32 *prog = (lds_vi32 *)&s_cnt[0];           // chain: 64 * (blocks finished) + coordinates published of the current one
     lds_vi32 *ver = (lds_vi32 *)&s_cnt[1];            // update waves 0 / 1 (s_cnt[1], [2]): 1 + blocks applied completely
@@ -286,19 +292,21 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
         publish_H(1);
         if (uh == 0) MODL_STAMP(512);
         int ready = 0;                                // cached value of the chain wave's counter
-        // one coordinate: H <- H + (w_new - w_old) Q_i on this wave's entries (dict_fact_fast.pyx:361-365 and :375-378
-        // as ONE fused multiply-add with the rounded difference), then the next request
-        auto step = [&](T (&row)[KU], T dd, const T *nextp) {
+        // one coordinate: H <- fma(w_new, Q_i, fma(-w_old, Q_i, H)) on this wave's entries (dict_fact_fast.pyx:361-365 and
+        // :375-378: the reference's two roundings.  ONE fma with the rounded difference w_new - w_old was measured NOISIER -
+        // 1.35 x the reference algorithm's own f32 noise on the codes against 0.8 x, scripts/diag_f32_noise.py - although
+        // each single operation is more accurate: DESIGN 3.2), then the next request
+        auto step = [&](T (&row)[KU], T dn, T dold, const T *nextp) {
             // every result is pinned where it is computed: left alone, the compiler sinks the whole chain of
-            // updates to its first use (the block's end) and keeps every row and delta live until then: hundreds of
+            // updates to its first use (the block's end) and keeps every row and pair live until then: hundreds of
             // spills.  f32 pairs go through v_pk_fma_f32 (half the issue slots of this wave's busiest loop).
             if constexpr (sizeof(T) == 4 && KU % 2 == 0) {
                 typedef float f2v __attribute__((ext_vector_type(2)));
 #pragma unroll
                 for (int r = 0; r < KU; r += 2) {
                     f2v h = {H[r], H[r + 1]};
-                    const f2v q2 = {row[r], row[r + 1]}, d2 = {dd, dd};
-                    h = __builtin_elementwise_fma(d2, q2, h);
+                    const f2v q2 = {row[r], row[r + 1]}, mo = {-dold, -dold}, pn2 = {dn, dn};
+                    h = __builtin_elementwise_fma(pn2, q2, __builtin_elementwise_fma(mo, q2, h));
                     asm volatile("" : "+v"(h));
                     H[r] = h[0];
                     H[r + 1] = h[1];
@@ -306,13 +314,103 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
             } else {
 #pragma unroll
                 for (int r = 0; r < KU; ++r) {
-                    H[r] = fma(dd, row[r], H[r]);
+                    H[r] = fma(dn, row[r], fma(-dold, row[r], H[r]));
                     asm volatile("" : "+v"(H[r]));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             request(row, nextp);
             __builtin_amdgcn_sched_barrier(0);
+        };
+        // The chain wave's counter and N published (w_new, w_old) pairs starting at coordinate c of the block, in ONE LDS
+        // round trip: the counter is requested first, the LDS executes a wavefront's operations in order and the chain
+        // wave stores data before counter, so the pairs are good if the counter that came with them was; repeated until
+        // it is.  (Round 3 spun on the counter and only then asked for the pairs: two round trips, ~130 cycles each, in
+        // front of every chunk of 8 - the update waves never made up the lag they start a block with.)  One assembly block:
+        // the compiler sees straight-line code around it, so its s_waitcnt bookkeeping for the row loads in flight
+        // stays exact.
+        auto fetch = [&](auto N_, int need, int dbo, int c, T (&pn)[8], T (&po)[8]) {
+            constexpr int N = decltype(N_)::value;                // 4 or 8
+            const unsigned int a_cnt = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const int *)s_cnt;
+            const unsigned int a_n = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const T *)(s_wn + dbo + c);
+            const unsigned int a_o = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const T *)(s_wo + dbo + c);
+            int v, sv;
+            if constexpr (sizeof(T) == 4) {
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                f4v n0, n1, o0, o1;
+                if constexpr (N == 8) {
+                    asm volatile(
+                        "modl_fetch%=:\n\t"
+                        "ds_read_b32 %0, %6\n\t"
+                        "ds_read_b128 %2, %7\n\t"
+                        "ds_read_b128 %3, %7 offset:16\n\t"
+                        "ds_read_b128 %4, %8\n\t"
+                        "ds_read_b128 %5, %8 offset:16\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        "v_readfirstlane_b32 %1, %0\n\t"
+                        "s_cmp_lt_i32 %1, %9\n\t"
+                        "s_cbranch_scc1 modl_fetch%="
+                        : "=&v"(v), "=&s"(sv), "=&v"(n0), "=&v"(n1), "=&v"(o0), "=&v"(o1)
+                        : "v"(a_cnt), "v"(a_n), "v"(a_o), "s"(need) : "memory", "scc");
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { pn[i] = n0[i]; pn[4 + i] = n1[i]; po[i] = o0[i]; po[4 + i] = o1[i]; }
+                } else {
+                    asm volatile(
+                        "modl_fetch%=:\n\t"
+                        "ds_read_b32 %0, %4\n\t"
+                        "ds_read_b128 %2, %5\n\t"
+                        "ds_read_b128 %3, %6\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        "v_readfirstlane_b32 %1, %0\n\t"
+                        "s_cmp_lt_i32 %1, %7\n\t"
+                        "s_cbranch_scc1 modl_fetch%="
+                        : "=&v"(v), "=&s"(sv), "=&v"(n0), "=&v"(o0)
+                        : "v"(a_cnt), "v"(a_n), "v"(a_o), "s"(need) : "memory", "scc");
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { pn[i] = n0[i]; po[i] = o0[i]; }
+                }
+            } else {
+                typedef double d2v __attribute__((ext_vector_type(2)));
+                d2v n0, n1, n2, n3, o0, o1, o2, o3;
+                if constexpr (N == 8) {
+                    asm volatile(
+                        "modl_fetch%=:\n\t"
+                        "ds_read_b32 %0, %10\n\t"
+                        "ds_read_b128 %2, %11\n\t"
+                        "ds_read_b128 %3, %11 offset:16\n\t"
+                        "ds_read_b128 %4, %11 offset:32\n\t"
+                        "ds_read_b128 %5, %11 offset:48\n\t"
+                        "ds_read_b128 %6, %12\n\t"
+                        "ds_read_b128 %7, %12 offset:16\n\t"
+                        "ds_read_b128 %8, %12 offset:32\n\t"
+                        "ds_read_b128 %9, %12 offset:48\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        "v_readfirstlane_b32 %1, %0\n\t"
+                        "s_cmp_lt_i32 %1, %13\n\t"
+                        "s_cbranch_scc1 modl_fetch%="
+                        : "=&v"(v), "=&s"(sv), "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3), "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+                        : "v"(a_cnt), "v"(a_n), "v"(a_o), "s"(need) : "memory", "scc");
+                    pn[0] = n0[0]; pn[1] = n0[1]; pn[2] = n1[0]; pn[3] = n1[1]; pn[4] = n2[0]; pn[5] = n2[1]; pn[6] = n3[0]; pn[7] = n3[1];
+                    po[0] = o0[0]; po[1] = o0[1]; po[2] = o1[0]; po[3] = o1[1]; po[4] = o2[0]; po[5] = o2[1]; po[6] = o3[0]; po[7] = o3[1];
+                } else {
+                    asm volatile(
+                        "modl_fetch%=:\n\t"
+                        "ds_read_b32 %0, %6\n\t"
+                        "ds_read_b128 %2, %7\n\t"
+                        "ds_read_b128 %3, %7 offset:16\n\t"
+                        "ds_read_b128 %4, %8\n\t"
+                        "ds_read_b128 %5, %8 offset:16\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        "v_readfirstlane_b32 %1, %0\n\t"
+                        "s_cmp_lt_i32 %1, %9\n\t"
+                        "s_cbranch_scc1 modl_fetch%="
+                        : "=&v"(v), "=&s"(sv), "=&v"(n0), "=&v"(n1), "=&v"(o0), "=&v"(o1)
+                        : "v"(a_cnt), "v"(a_n), "v"(a_o), "s"(need) : "memory", "scc");
+                    pn[0] = n0[0]; pn[1] = n0[1]; pn[2] = n1[0]; pn[3] = n1[1];
+                    po[0] = o0[0]; po[1] = o0[1]; po[2] = o1[0]; po[3] = o1[1];
+                }
+            }
+            return v;
         };
         // One chunk of 8 coordinates starting at coordinate c8 of the block (ring slots s0 ..): the chain wave publishes
         // in eights, the last eight of a block as 4 + 4 (`halves`).  The waits are assembly blocks, the ring slots
@@ -326,22 +424,27 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
         // the chain as much as the wait they were meant to remove (block 5200 cycles against 4870).)
         auto chunk = [&](auto S0, int cbase, int c8, int halves, auto &&next_of) {
             constexpr int s0 = decltype(S0)::value;
-            T pd[8];
-            const int dbo = (cbase >> 6 & 1) * 64;    // (the deltas of consecutive blocks alternate between two buffers)
-            ready = spin_until(ready, s_cnt, cbase + c8 + (halves ? 4 : 8));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pd[i] = deltas[dbo + c8 + i];
-            static_for<4>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                step(ring[s0 + i], pd[i], next_of(s0 + i));
-            });
-            ready = spin_until(ready, s_cnt, cbase + c8 + 8);
-#pragma unroll
-            for (int i = 4; i < 8; ++i) pd[i] = deltas[dbo + c8 + i];
-            static_for<4>([&](auto I) {
-                constexpr int i = 4 + decltype(I)::value;
-                step(ring[s0 + i], pd[i], next_of(s0 + i));
-            });
+            T pn[8], po[8];
+            const int dbo = (cbase >> 6 & 1) * 64;    // (the pairs of consecutive blocks alternate between two buffers)
+            if (halves) {
+                ready = fetch(std::integral_constant<int, 4>{}, cbase + c8 + 4, dbo, c8, pn, po);
+                static_for<4>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    step(ring[s0 + i], pn[i], po[i], next_of(s0 + i));
+                });
+                T qn4[8], qo4[8];
+                ready = fetch(std::integral_constant<int, 4>{}, cbase + c8 + 8, dbo, c8 + 4, qn4, qo4);
+                static_for<4>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    step(ring[s0 + 4 + i], qn4[i], qo4[i], next_of(s0 + 4 + i));
+                });
+            } else {
+                ready = fetch(std::integral_constant<int, 8>{}, cbase + c8 + 8, dbo, c8, pn, po);
+                static_for<8>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    step(ring[s0 + i], pn[i], po[i], next_of(s0 + i));
+                });
+            }
         };
         if constexpr (FULL) {
             // the whole sweep unrolled (NB blocks of 8 chunks): the only back edge is the sweep's
@@ -357,10 +460,6 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                     constexpr int bb = decltype(BB)::value;
                     const int t = sw * NB + bb, base = 64 * t;
                     const int dbo = (t & 1) * 64;
-                    // the first coordinates of a block that never comes: the chain wave has ended the solve.  (The
-                    // wave ends inside the assembly block: no join for the compiler; loads in flight die with it.)
-                    ready = spin_until(ready, s_cnt, base + 8);
-                    if (__builtin_amdgcn_readfirstlane(ready) == kStop) asm volatile("s_endpgm");
                     if (uh == 0) MODL_STAMP(512);
                     static_for<8>([&](auto CC) {
                         constexpr int c8 = decltype(CC)::value * 8;
@@ -369,13 +468,14 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                         // (the slot of coordinate c of the sweep is c % R; it is refilled with row (c + R) mod K)
                         auto row_after = [&](int c) { return mine + (int64_t)((c + R) % K) * K; };
                         {
-                            T pd[8];
-                            ready = spin_until(ready, s_cnt, base + c8 + 8);
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) pd[i] = deltas[dbo + c8 + i];
+                            T pn[8], po[8];
+                            ready = fetch(std::integral_constant<int, 8>{}, base + c8 + 8, dbo, c8, pn, po);
+                            // the first coordinates of a block that never comes: the chain wave has ended the solve.  (The
+                            // wave ends inside the assembly block: no join for the compiler; loads in flight die with it.)
+                            if constexpr (c8 == 0) { if (__builtin_amdgcn_readfirstlane(ready) == kStop) asm volatile("s_endpgm"); }
                             static_for<8>([&](auto I) {
                                 constexpr int i = decltype(I)::value;
-                                step(ring[(cs + i) % R], pd[i], row_after(cs + i));
+                                step(ring[(cs + i) % R], pn[i], po[i], row_after(cs + i));
                             });
                         }
                         if constexpr (LA > 0 && c8 + 8 == 64 - LA) publish_snap(t + 2);
@@ -461,6 +561,10 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
         const T cl = POSITIVE ? (z < alpha ? z : alpha) : clamp3(z, -alpha, alpha);   // as cd_coordinate
         return fma(z - cl, ri, -wold);
     };
+    auto wnew_of = [&](T z, T ri) -> T {            // the new coefficient itself (:372-373), the product rounded once
+        const T cl = POSITIVE ? (z < alpha ? z : alpha) : clamp3(z, -alpha, alpha);
+        return (z - cl) * ri;
+    };
     T Zcarry = 0;                                   // look-ahead: what the previous block's last LA steps did to this block
     bool done = false;
     for (; n_iter < a.max_iter && !done; ++n_iter) {
@@ -491,10 +595,8 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
             T qd[8], qn[8], sd[8], sn[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) { qd[i] = tile[i * 64]; sd[i] = 0; sn[i] = 0; }
-            // NEAR: minus the tile's first superdiagonal, Q[64 b + lane - 1][64 b + lane] (what coordinate L does to L + 1)
-            T ngs = 0;
-            if constexpr (NEAR) ngs = -tile[(lane > 0 ? lane - 1 : 0) * 64];
-            T dl = 0, qlast = 0, slast = 0;
+            T dl = 0;
+            wos[dbo + lane] = wob;                  // (read by the update waves behind the first counter of the block)
             // what the step of coordinate LP (delta in lane LP of dlv) does to the coordinates after it in the block (:361-365
             // and :375-378 as one fused multiply-add with the rounded difference) and, look-ahead, to the next block
             auto apply = [&](auto LP_, T dlv, T rowv, T spv) {
@@ -517,59 +619,32 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                 static_for<8>([&](auto II) {
                     constexpr int i = decltype(II)::value;
                     constexpr int L = g * 8 + i;                 // lane of the coordinate
-                    if constexpr (NEAR) {
-                        // The k-wide effect of coordinate L - 1 is applied one step LATE (its broadcast, v_readlane ->
-                        // scalar register -> v_fma, is the long hop of the chain); coordinate L gets it from its
-                        // neighbour lane through DPP meanwhile: tmp = Z[L] - Q[L-1][L] delta[L-1], the very fused
-                        // multiply-add the late update then performs on Z[L] - which is therefore frozen at the value
-                        // this step used, as without the detour.
-                        T tmp = Z;
-                        if constexpr (L > 0)
-                            asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf"
-                                         : "+v"(tmp) : "v"(dl), "v"(ngs));
-                        const T dlp = dl;
-                        dl = delta_of(tmp, rib, wob);
-                        if constexpr (L > 0) {
-                            if constexpr (i > 0) apply(std::integral_constant<int, (L > 0 ? L - 1 : 0)>{}, dlp, qd[i > 0 ? i - 1 : 0], sd[i > 0 ? i - 1 : 0]);
-                            else apply(std::integral_constant<int, (L > 0 ? L - 1 : 0)>{}, dlp, qlast, slast);
-                        }
-                    } else {
-                        // every lane evaluates the step on its own Z: lane L's is this coordinate's (:367-373), the lanes
-                        // before it reproduce what their own steps found (their Z has not moved since), the lanes after it
-                        // are not there yet
-                        dl = delta_of(Z, rib, wob);
-                        apply(std::integral_constant<int, L>{}, dl, qd[i], sd[i]);
-                    }
+                    // every lane evaluates the step on its own Z: lane L's is this coordinate's (:367-373), the lanes
+                    // before it reproduce what their own steps found (their Z has not moved since), the lanes after it
+                    // are not there yet
+                    dl = delta_of(Z, rib, wob);
+                    apply(std::integral_constant<int, L>{}, dl, qd[i], sd[i]);
                     // (!FULL) the block's last eight are published as 4 + 4: the update waves then have four coordinates
                     // left when the chain needs the next block's H
                     if constexpr (!FULL && (g == 7 || g == 3) && i == 3) {
                         if (g == 7 || len == 32) {
-                            deltas[dbo + lane] = NEAR ? delta_of(Z, rib, wob) : dl;
+                            wns[dbo + lane] = wnew_of(Z, rib);
                             asm volatile("" ::: "memory");
                             *prog = base + L + 1;
                             asm volatile("" ::: "memory");
                         }
                     }
                 });
-                // publish: every 8 coordinates.  The lanes <= 8 g + 7 are final: re-evaluated from their frozen Z (NEAR:
-                // lane 8 g + 7's Z has received coordinate 8 g + 6 in the step just done)
-                deltas[dbo + lane] = NEAR ? delta_of(Z, rib, wob) : dl;
+                // publish: every 8 coordinates.  The lanes <= 8 g + 7 are final: their frozen Z reproduces their step, and
+                // their new coefficients are re-evaluated from it (what the block's end stores in w)
+                wns[dbo + lane] = wnew_of(Z, rib);
                 asm volatile("" ::: "memory");
                 *prog = base + g * 8 + 8;
                 asm volatile("" ::: "memory");
-                qlast = qd[7];
-                slast = sd[7];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { qd[i] = qn[i]; sd[i] = sn[i]; }
             });
-            {   // the block's new coefficients, from the frozen Z of every coordinate (the product the step rounded)
-                const T cl = POSITIVE ? (Z < alpha ? Z : alpha) : clamp3(Z, -alpha, alpha);
-                w[bI] = (Z - cl) * rib;
-            }
-            if constexpr (NEAR && LA > 0) {         // the last coordinate's step still has to reach the next block
-                const T dn = bcast_lane(dl, 63);
-                Zla = fma(-dn, slast, Zla);
-            }
+            w[bI] = wnew_of(Z, rib);               // the block's new coefficients, from the frozen Z of every coordinate
             Zcarry = Zla;
             ++tblk;
             *cblk = tblk;

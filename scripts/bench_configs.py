@@ -118,16 +118,69 @@ def c4(args):
     return out
 
 
+HCP_KW = dict(n_components=1024, batch_size=200, reduction=20, learning_rate=0.92, code_alpha=1e-4, code_l1_ratio=0,
+              comp_l1_ratio=1, comp_pos=True, G_agg='masked', Dx_agg='masked', random_state=0)
+
+
+def hcp_rows(n, p, seed, device=None, k0=64):
+    """rest-fMRI-like rows (n, p) float32: a few dozen smooth positive maps mixed by random loadings + noise, rows
+    standardised as fmri.py does; produced on the device when one is given (the same rows on the host otherwise)"""
+    import torch
+    dev = device if device is not None else torch.device('cpu')
+    g = torch.Generator(device=dev).manual_seed(seed)
+    maps = torch.relu(torch.randn(k0, p, device=dev, generator=g) - 1.0)
+    L = torch.randn(n, k0, device=dev, generator=g)
+    X = L @ maps + 0.5 * torch.randn(n, p, device=dev, generator=g)
+    X -= X.mean(dim=1, keepdim=True)
+    X /= X.std(dim=1, keepdim=True)
+    return X.float().contiguous()
+
+
+def c6(args):
+    """The reference's own largest published run (exps/hcp/decompose_hcp.py:50-60): 1024 maps, minibatches of 200
+    records, reduction 20, ridge codes, positive l1 atoms - at p = 200 000 voxels, DictFact on device-resident rows."""
+    import torch
+    from modl_amd import DictFact
+    dev = torch.device('cuda')
+    p, nb = 200000, args.c6_batches
+    kw = dict(HCP_KW)
+    b, k = kw['batch_size'], kw['n_components']
+    X = hcp_rows(max(nb * b, k), p, 0, dev)
+    est = DictFact(**kw)
+    est.prepare(n_samples=X.shape[0], X=X[:k])
+    est.partial_fit(X[:2 * b], np.arange(2 * b))             # warm-up (allocations, first launches)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    est.partial_fit(X[2 * b:nb * b], np.arange(2 * b, nb * b))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = (nb - 2) * b
+    be = est._backend
+    be.prof_enable(True)
+    be.prof_reset()
+    est.partial_fit(X[:2 * b], np.arange(2 * b))
+    torch.cuda.synchronize()
+    prof = {name: v['ms'] / v['calls'] for name, v in be.prof_get().items() if v['calls']}
+    be.prof_enable(False)
+    D = est._backend.Dt
+    return dict(config='C6 the reference\'s HCP run (exps/hcp/decompose_hcp.py:50-60): k=1024, b=200, r=20, ridge codes, '
+                       'positive l1 atoms, p=%d f32, %d minibatches timed' % (p, nb - 2),
+                samples=int(n), seconds=dt, samples_per_s=n / dt, ms_per_minibatch=dt / (nb - 2) * 1e3,
+                sections_ms=prof, finite=bool(torch.isfinite(D).all().item()),
+                nonneg=bool((D >= 0).all().item()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='c2,c3,c4')
+    ap.add_argument('--c6-batches', type=int, default=8)
     ap.add_argument('--c2-patches', type=int, default=None)
     ap.add_argument('--c3-records', type=int, default=40)
     ap.add_argument('--c4-batches', type=int, default=7000)
     ap.add_argument('--c4-nnz', type=int, default=10_000_000)
     args = ap.parse_args()
     for name in args.only.split(','):
-        out = dict(c2=c2, c3=c3, c4=c4)[name](args)
+        out = dict(c2=c2, c3=c3, c4=c4, c6=c6)[name](args)
         print(json.dumps(out), flush=True)
 
 

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Regenerates the round's profile artifacts on the GPU box (run through gpurun from the repo root):
-#   bash scripts/make_profiles.sh r03
+#   bash scripts/make_profiles.sh r04
 # writes gpurun_out/<tag>_*; copy what is to be judged into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 mkdir -p $OUT /tmp/w
@@ -33,6 +33,27 @@ python3 $R/scripts/diag_hcp_shape.py > $OUT/${TAG}_c5_shape_sections.txt 2>&1
 rm -rf /tmp/w/c5; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/w/c5 -o t -- python3 $R/scripts/diag_hcp_shape.py > /tmp/w/c5.log 2>&1
 { tail -8 /tmp/w/c5.log; python3 $R/scripts/prof_summary.py $(find /tmp/w/c5 -name "*.db" | head -1) 0.3; } > $OUT/${TAG}_c5_shape_kernel_trace.txt 2>&1
 ls -la $OUT | grep $TAG
-# BASELINE configs 2-4: GPU throughput, the CPU oracle on a bounded prefix, the dominant section's roofline fraction
-timeout 900 python3 $R/tests/diag/bench_configs_full.py > $OUT/${TAG}_bench_configs.jsonl 2> $OUT/${TAG}_bench_configs.err
+# the multi-GPU (two-phase) step's cost on ONE GPU: the fused step against the forced reduction (world = 1: the all-reduce
+# is the identity, its launch and stream ordering are real) on the library's own RCCL communicator (one call per chunk,
+# the default of `bench.py --gpus N`) and on torch.distributed (two calls + a collective per minibatch)
+for v in fused native torch; do
+  case $v in
+    fused) F="" ;;
+    native) F="--force-reduce --native-rccl" ;;
+    torch) F="--force-reduce --torch-collective" ;;
+  esac
+  export MASTER_PORT=$((20000 + RANDOM % 20000))
+  python3 $R/bench.py --steps 600 --warmup 400 --no-cpu-baseline --steady-steps 0 --no-breakdown $F > $OUT/${TAG}_two_phase_$v.json 2> /tmp/w/tp_$v.err
+  rm -rf /tmp/w/tp_$v
+  export MASTER_PORT=$((20000 + RANDOM % 20000))
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/w/tp_$v -o t -- python3 $R/bench.py --steps 600 --warmup 400 --no-cpu-baseline --steady-steps 0 --no-breakdown $F > /tmp/w/tp_$v.log 2>&1
+  DB=$(find /tmp/w/tp_$v -name "*.db" | head -1)
+  { echo "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 600 --warmup 400 --no-cpu-baseline --steady-steps 0 --no-breakdown $F   (second half of the trace)"; python3 $R/scripts/prof_summary.py $DB 0.5; } > $OUT/${TAG}_two_phase_${v}_kernel_trace.txt 2>&1
+  python3 $R/scripts/step_timeline.py $DB 1 > $OUT/${TAG}_two_phase_${v}_timeline.txt 2>&1
+done
+# BASELINE configs 2-4 and the reference's HCP run (C6): GPU throughput, the CPU oracle on a bounded prefix, the dominant
+# section's roofline fraction
+timeout 1500 python3 $R/tests/diag/bench_configs_full.py --only c2,c3,c4,c6 > $OUT/${TAG}_bench_configs.jsonl 2> $OUT/${TAG}_bench_configs.err
+rm -rf /tmp/w/c6; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/w/c6 -o t -- python3 $R/scripts/bench_configs.py --only c6 --c6-batches 5 > /tmp/w/c6.log 2>&1
+{ tail -3 /tmp/w/c6.log; python3 $R/scripts/prof_summary.py $(find /tmp/w/c6 -name "*.db" | head -1) 0.3; } > $OUT/${TAG}_cfg_c6_kernel_trace.txt 2>&1
 ls -la $OUT | grep $TAG

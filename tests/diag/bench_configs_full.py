@@ -57,7 +57,7 @@ def main():
     import torch
     from types import SimpleNamespace
     for name in a.only.split(','):
-        args = SimpleNamespace(c2_patches=None, c3_records=40, c4_batches=7000, c4_nnz=10_000_000)
+        args = SimpleNamespace(c2_patches=None, c3_records=40, c4_batches=7000, c4_nnz=10_000_000, c6_batches=8)
         rec = dict(gpu=getattr(gpu, name)(args))
         # the section split of a second, shorter run (HIP events on the stream slow it down: not the timed one)
         if name == 'c2':
@@ -87,6 +87,21 @@ def main():
             torch.cuda.synchronize()
             rec['roofline'] = section_roofline(be, 70, 60000, 20, 60000 / 12.0, 4, 'f32')
             be.prof_enable(False)
+        elif name == 'c6':
+            g = rec['gpu']
+            sec = g['sections_ms']
+            dom = max(sec, key=sec.get)
+            kw = gpu.HCP_KW
+            k, b, p, e = kw['n_components'], kw['batch_size'], 200000, 4
+            s_ = p / kw['reduction']
+            # the l1 projection of 1024 atoms is a chain of per-atom passes over the s sampled features: algorithmic bytes
+            # of the dictionary update = read + write the sampled columns of D and read those of B_ once, plus C_
+            by = e * (k * k + 3 * s_ * k)
+            rec['roofline'] = dict(section=dom, share_of_gpu_time=sec[dom] / sum(sec.values()), ms_per_minibatch=sec[dom],
+                                   bound='hbm', achieved=by / sec[dom] / 1e6, peak=PEAK['hbm'], unit='GB/s',
+                                   frac=by / sec[dom] / 1e6 / PEAK['hbm'],
+                                   note='dictionary update with l1 atoms and more than 6144 sampled features: one launch per '
+                                        'atom (atom_step_kernel), 1024 dependent launches per minibatch')
         else:
             # the masked path has its own plan (no section events): algorithmic HBM bytes per rating - its code row,
             # the item's dictionary column and the read-modify-write of its B_ column: (3 k + k) e bytes, f64

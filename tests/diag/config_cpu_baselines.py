@@ -64,12 +64,28 @@ def c4(budget):
     return dict(config='C4', samples_per_s=X.shape[0] / (time.perf_counter() - t0), sample='%d rows' % X.shape[0])
 
 
+def c6(budget):
+    """one minibatch (two if the budget allows) of the HCP configuration on the oracle"""
+    kw = dict(bc.HCP_KW)
+    b, k, p = kw['batch_size'], kw['n_components'], 200000
+    X = bc.hcp_rows(max(2 * b, k), p, 0).numpy()
+    pr = orc.SomfParams(**kw)
+    st = orc.prepare(pr, n_samples=X.shape[0], X=X[:k])
+    t0, done = time.perf_counter(), 0
+    for r0 in range(0, 2 * b, b):
+        orc.partial_fit(st, pr, X[r0:r0 + b], np.arange(r0, r0 + b))
+        done += b
+        if time.perf_counter() - t0 > budget:
+            break
+    return dict(config='C6', samples_per_s=done / (time.perf_counter() - t0), sample='%d records' % done)
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='c2,c3,c4')
     ap.add_argument('--budget', type=float, default=15.0)
     a = ap.parse_args()
     for name in a.only.split(','):
-        out = dict(c2=c2, c3=c3, c4=c4)[name](a.budget)
+        out = dict(c2=c2, c3=c3, c4=c4, c6=c6)[name](a.budget)
         out['cores'] = os.cpu_count()
         print(json.dumps(out), flush=True)
