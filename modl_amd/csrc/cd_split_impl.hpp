@@ -114,7 +114,12 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
     const int smp = blockIdx.x;
     if (smp != 0) stamps = nullptr;
     int nst = 0;
+    (void)nst;
+#ifdef MODL_DIAG     // shader-clock stamps of sample 0: the diagnostics build only (the product kernels carry no stamp code)
 #define MODL_STAMP(off) do { if (stamps && lane == 0 && nst < 250) stamps[(off) + nst++] = clock64(); } while (0)
+#else
+#define MODL_STAMP(off) do { } while (0)
+#endif
     const int k = a.k;
     const int kc = FULL ? K : (k + 31) / 32 * 32;     // coordinates a sweep visits (the padding is dead: inv = 0)
     const int nblk = FULL ? NB : (kc + 63) / 64;
@@ -447,6 +452,27 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
             }
         };
         if constexpr (FULL) {
+            // The chunk AFTER the one being applied is requested (counter first, then its pairs: plain LDS reads, the
+            // compiler places the wait) before the current chunk's steps start, so the LDS round trip runs under them;
+            // only if the counter that came with the pairs falls short - the chain wave has not published that chunk yet -
+            // does the wave fall back to the blocking `fetch`.  (Round 4 stamps: with the round trip in front of every
+            // chunk the update waves needed 57 cycles per coordinate against the chain wave's 48 - the chain waited.)
+            constexpr int VN = (int)(16 / sizeof(T));                 // coefficients per 16-byte LDS read: 4 / 2
+            typedef T cvec_t __attribute__((ext_vector_type(VN)));
+            typedef __attribute__((address_space(3))) volatile cvec_t lds_cvec;
+            struct Pref { T pn[8], po[8]; int cnt; };
+            auto prefetch = [&](int dbo_, int c, Pref &P) {
+                P.cnt = *prog;
+                lds_cvec *pn_ = (lds_cvec *)(s_wn + dbo_ + c), *po_ = (lds_cvec *)(s_wo + dbo_ + c);
+#pragma unroll
+                for (int v = 0; v < 8 / VN; ++v) {
+                    const cvec_t a_ = pn_[v], b_ = po_[v];
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) { P.pn[v * VN + e] = a_[e]; P.po[v * VN + e] = b_[e]; }
+                }
+            };
+            Pref cur;
+            prefetch(0, 0, cur);
             // the whole sweep unrolled (NB blocks of 8 chunks): the only back edge is the sweep's
             for (int sw = 0;; ++sw) {
                 // (an opaque pointer per sweep: the matrix is read-only and every sweep reads the same addresses - left
@@ -467,17 +493,20 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                         if constexpr (c8 == 32) { if (uh == 0) MODL_STAMP(512); }
                         // (the slot of coordinate c of the sweep is c % R; it is refilled with row (c + R) mod K)
                         auto row_after = [&](int c) { return mine + (int64_t)((c + R) % K) * K; };
-                        {
-                            T pn[8], po[8];
-                            ready = fetch(std::integral_constant<int, 8>{}, base + c8 + 8, dbo, c8, pn, po);
-                            // the first coordinates of a block that never comes: the chain wave has ended the solve.  (The
-                            // wave ends inside the assembly block: no join for the compiler; loads in flight die with it.)
-                            if constexpr (c8 == 0) { if (__builtin_amdgcn_readfirstlane(ready) == kStop) asm volatile("s_endpgm"); }
-                            static_for<8>([&](auto I) {
-                                constexpr int i = decltype(I)::value;
-                                step(ring[(cs + i) % R], pn[i], po[i], row_after(cs + i));
-                            });
-                        }
+                        Pref nxt;
+                        if constexpr (c8 < 56) prefetch(dbo, c8 + 8, nxt);
+                        else prefetch(dbo ^ 64, 0, nxt);                         // (the next block's first chunk)
+                        ready = cur.cnt;
+                        if (__builtin_amdgcn_readfirstlane(ready) < base + c8 + 8)
+                            ready = fetch(std::integral_constant<int, 8>{}, base + c8 + 8, dbo, c8, cur.pn, cur.po);
+                        // the first coordinates of a block that never comes: the chain wave has ended the solve.  (The
+                        // wave ends inside the assembly block: no join for the compiler; loads in flight die with it.)
+                        if constexpr (c8 == 0) { if (__builtin_amdgcn_readfirstlane(ready) == kStop) asm volatile("s_endpgm"); }
+                        static_for<8>([&](auto I) {
+                            constexpr int i = decltype(I)::value;
+                            step(ring[(cs + i) % R], cur.pn[i], cur.po[i], row_after(cs + i));
+                        });
+                        cur = nxt;
                         if constexpr (LA > 0 && c8 + 8 == 64 - LA) publish_snap(t + 2);
                     });
                     publish_H(t + 2);
