@@ -566,6 +566,8 @@ def main():
                     help='N > 1: dist.all_reduce of the head between two library calls per minibatch instead of the '
                          'library\'s own RCCL communicator')
     ap.add_argument('--share-gpu', action='store_true', help='testing only: every rank uses cuda:0 (needs --backend gloo)')
+    ap.add_argument('--debug-set', action='append', default=[], metavar='WHAT=VALUE',
+                    help='diagnostics: modl_debug_set(WHAT, VALUE) before anything runs (A/B runs of scripts/; see include/modl_hip.h)')
     args = ap.parse_args()
 
     if args.gpus > 1 and ('WORLD_SIZE' not in os.environ or (
@@ -592,6 +594,10 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    for item in args.debug_set:
+        from modl_amd._lib import lib as _l, check as _c
+        what, value = item.split('=')
+        _c(_l.modl_debug_set(int(what), int(value)), 'modl_debug_set')
     res = run_gpu(args, args.reduction, args.steps, args.warmup, rank, world, device, breakdown=not args.no_breakdown)
     steady = []
     if args.steady_steps > 0:

@@ -441,12 +441,15 @@ struct SinkGlobal {
 // value = b2 2^10 + b1 2^-30 + b0 2^-70.  A contribution outside that range (|v| >= 2^50, or not a number) raises the
 // accumulator's out-of-range word instead, and the readers of that block then sum the per-workgroup records, which
 // every workgroup still writes (560 plain stores that nobody reads otherwise): slower, any magnitude, never a wrapped
-// integer.
+// integer.  The bins are ABSOLUTE (2^-71): what the recursion needs is precision relative to the squared norms on the
+// Gram diagonal, so a NORM entry (`norm_entry`: a diagonal element, an old squared norm) that is positive but below
+// 2^-40 - a user-set dictionary of tiny atoms, a tiny norm budget - raises the same word: relative to any norm the
+// accumulator accepts its quantisation is then below 2^-31, under the f32 data's own rounding.
 constexpr int kAccBins = 3;
 constexpr int kAccStride = kAccBins * kPackStride;        // int64 words of the bins; word kAccStride: out of range
 static_assert(kAccStride + 2 == kAccWords, "accumulator size");
-__device__ __forceinline__ void acc_add(long long *acc, int idx, double v) {
-    if (!(fabs(v) < 0x1p50)) {
+__device__ __forceinline__ void acc_add(long long *acc, int idx, double v, bool norm_entry = false) {
+    if (!(fabs(v) < 0x1p50) || (norm_entry && v != 0.0 && fabs(v) < 0x1p-40)) {
         atomicOr(reinterpret_cast<unsigned long long *>(acc) + kAccStride, 1ull);
         return;
     }
@@ -1516,7 +1519,7 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
                 const int row = (lane >> 4) + 4 * r, col = lane & 15;
                 if (p.acc_out) {
                     if (it != jt) acc_add(p.acc_out, kTri + row * 16 + col, g[r]);
-                    else if (row <= col) acc_add(p.acc_out, (it ? kTri + 256 : 0) + tri_index(row, col), g[r]);
+                    else if (row <= col) acc_add(p.acc_out, (it ? kTri + 256 : 0) + tri_index(row, col), g[r], row == col);
                 }
                 if (it != jt) out[kTri + row * 16 + col] = g[r];                                   // tile (0,1): full
                 else if (row <= col) out[(it ? kTri + 256 : 0) + tri_index(row, col)] = g[r];        // diagonal tiles: triangle
@@ -1524,7 +1527,7 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
         } else if (lane < kNB) {
             double t = 0;
             for (int gq = 0; gq < 8; ++gq) t += d2red[gq * kNB + lane];
-            if (p.acc_out) acc_add(p.acc_out, 2 * kTri + 256 + lane, t);
+            if (p.acc_out) acc_add(p.acc_out, 2 * kTri + 256 + lane, t, true);
             out[2 * kTri + 256 + lane] = t;
         }
     }

@@ -90,6 +90,14 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
     // what it needs from the update waves at a block boundary is H as it was LA coordinates before the block's end:
     // they run ~1200 cycles (two LDS round trips and a chunk) behind, which the chain used to wait for, four times a sweep.
     constexpr int LA = FULL ? 32 : 0;
+    // MR: f32 with k <= 256 - a column half of a row is 256 / 512 bytes, i.e. 4 / 8 bytes per lane of an update wave: such
+    // accesses run at 0.5-0.7 of the 16-byte rate and every memory instruction costs the compute unit's address pipe 16
+    // cycles whatever its width - the update waves, not the chain, bounded the sweep (57 cycles per coordinate against
+    // 48, stamps).  There ONE 16-byte-per-lane request fetches RPI consecutive rows (a group of 64 / RPI lanes per row, 4
+    // columns per lane) and every group of lanes accumulates the rows of its residue class: RPI partial sums per entry of
+    // H, added (in a fixed order) when H is handed over.
+    constexpr bool MR = FULL && sizeof(T) == 4 && NB <= 4;
+    constexpr int RPI = MR ? 8 / NB : 1;              // rows per request: 4 (k = 128), 2 (k = 256)
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[2 * TB];
     __shared__ __attribute__((aligned(16))) T s_strip[LA > 0 ? 2 * LA * 64 : 4];   // rows 64 b + 64 - LA .. of the columns of block b + 1
     __shared__ __attribute__((aligned(16))) T s_wn[2 * 64];   // the chain wave's current block: new coefficients, by lane (blocks alternate) ...
@@ -188,6 +196,143 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
     }
     if (wid == 1 || wid == 2) {
         // ------------------------------------------------------------------ update waves: a column half each
+        if constexpr (MR) {
+            constexpr int LPR = 64 / RPI;                        // lanes per row: 16 (k = 128), 32 (k = 256)
+            constexpr int NI = K / RPI;                          // requests per sweep
+            constexpr int RR = 32 / RPI;                         // requests in flight (32 rows, as in the generic path)
+            constexpr int CQ = 8 / RPI;                          // requests per chunk of 8 coordinates
+            const int uh = wid - 1;
+            const int rsub = lane / LPR;                         // this lane's row inside a request
+            const int cb = uh * (K / 2) + (lane % LPR) * 4;      // its four columns
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            const float *const mine0 = Q + (int64_t)rsub * K + cb;   // this lane's slice of request 0
+            const float *mine = mine0;
+            f4v ring[RR];
+#pragma unroll
+            for (int j = 0; j < RR; ++j) ring[j] = *reinterpret_cast<const f4v *>(mine + (int64_t)(j * RPI) * K);
+            {
+                int64_t opaque = 0;
+                asm volatile("" : "+s"(opaque));
+                mine = mine0 + opaque;
+            }
+            f2v H01 = {0.f, 0.f}, H23 = {0.f, 0.f};              // partial sums of this lane's four entries of H
+            if (a.H0) {
+                if (rsub == 0) {                                 // (the first group of lanes carries H0, the others zero)
+                    const f4v h = *reinterpret_cast<const f4v *>(a.H0 + (int64_t)smp * k + cb);
+                    H01 = {h[0], h[1]};
+                    H23 = {h[2], h[3]};
+                }
+            } else {
+                // H0 = Q w: the coefficient of a lane's row comes from LDS (the chain wave stores its w there first)
+                lds_vi32 *wflag = (lds_vi32 *)&s_cnt[10];
+                int wf = *wflag;
+                while (__builtin_amdgcn_readfirstlane(wf) == 0) wf = *wflag;
+                asm volatile("" ::: "memory");
+                lds_vT *sw = (lds_vT *)s_w + rsub;
+                float wq[8], wqn[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) wq[q] = sw[q * RPI];
+                static_for<NI / 8>([&](auto GG) {
+                    constexpr int g8 = decltype(GG)::value * 8;
+                    if constexpr (g8 + 8 < NI) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) wqn[q] = sw[(g8 + 8 + q) * RPI];
+                    }
+                    static_for<8>([&](auto QQ) {
+                        constexpr int jj = g8 + decltype(QQ)::value;
+                        constexpr int j = jj % RR;
+                        const f2v w2 = {wq[jj - g8], wq[jj - g8]};
+                        const f2v r01 = {ring[j][0], ring[j][1]}, r23 = {ring[j][2], ring[j][3]};
+                        H01 = __builtin_elementwise_fma(w2, r01, H01);
+                        H23 = __builtin_elementwise_fma(w2, r23, H23);
+                        asm volatile("" : "+v"(H01), "+v"(H23));
+                        __builtin_amdgcn_sched_barrier(0);
+                        ring[j] = *reinterpret_cast<const f4v *>(mine + (int64_t)(((jj + RR) % NI) * RPI) * K);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) wq[q] = wqn[q];
+                });
+            }
+            // this lane's four entries of H: the sum of the RPI partial sums, in a fixed order (every group gets it)
+            auto total = [&](f2v x) -> f2v {
+                f2v r;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float v = x[e], lo, hi;
+                    if constexpr (RPI == 4) { lane_swap<true>(v, lo, hi); v = lo + hi; }
+                    lane_swap<false>(v, lo, hi);
+                    r[e] = lo + hi;
+                }
+                return r;
+            };
+            auto publish_to = [&](float *dst, lds_vi32 *cnt, int version) {
+                const f2v t01 = total(H01), t23 = total(H23);
+                if (rsub == 0) *reinterpret_cast<f4v *>(dst + cb) = f4v{t01[0], t01[1], t23[0], t23[1]};
+                asm volatile("" ::: "memory");
+                cnt[uh] = version;
+            };
+            publish_to(s_H, ver, 1);
+            if (uh == 0) MODL_STAMP(512);
+            int ready = 0;
+            // the pairs of this lane's rows of a chunk of 8 coordinates (the chunk after the one being applied is requested
+            // before its steps start; the counter first: the pairs are good if the counter that came with them was)
+            struct Pref { float pn[CQ], po[CQ]; int cnt; };
+            auto prefetch = [&](int dbo_, int c, Pref &P) {
+                P.cnt = *prog;
+                lds_vT *pn_ = wns + dbo_ + c + rsub, *po_ = wos + dbo_ + c + rsub;
+#pragma unroll
+                for (int q = 0; q < CQ; ++q) { P.pn[q] = pn_[q * RPI]; P.po[q] = po_[q * RPI]; }
+            };
+            Pref cur;
+            prefetch(0, 0, cur);
+            for (int sw = 0;; ++sw) {
+                {
+                    int64_t opaque = 0;                          // (see the generic path: keeps the row loads inside the sweep)
+                    asm volatile("" : "+s"(opaque));
+                    mine = mine0 + opaque;
+                }
+                static_for<NB>([&](auto BB) {
+                    constexpr int bb = decltype(BB)::value;
+                    const int t = sw * NB + bb, base = 64 * t;
+                    const int dbo = (t & 1) * 64;
+                    if (uh == 0) MODL_STAMP(512);
+                    static_for<8>([&](auto CC) {
+                        constexpr int c8 = decltype(CC)::value * 8;
+                        constexpr int js = (bb * 64 + c8) / RPI;                 // first request of the chunk, in the sweep
+                        if constexpr (c8 == 32) { if (uh == 0) MODL_STAMP(512); }
+                        Pref nxt;
+                        if constexpr (c8 < 56) prefetch(dbo, c8 + 8, nxt);
+                        else prefetch(dbo ^ 64, 0, nxt);
+                        ready = cur.cnt;
+                        if (__builtin_amdgcn_readfirstlane(ready) < base + c8 + 8) {
+                            ready = spin_until(ready, s_cnt, base + c8 + 8);
+                            prefetch(dbo, c8, cur);
+                        }
+                        if constexpr (c8 == 0) { if (__builtin_amdgcn_readfirstlane(ready) == kStop) asm volatile("s_endpgm"); }
+                        static_for<CQ>([&](auto QQ) {
+                            constexpr int q = decltype(QQ)::value;
+                            constexpr int j = (js + q) % RR;
+                            // H <- fma(w_new, Q_i, fma(-w_old, Q_i, H)) on this lane's row (dict_fact_fast.pyx:361-365, :375-378)
+                            const f2v mo = {-cur.po[q], -cur.po[q]}, pn2 = {cur.pn[q], cur.pn[q]};
+                            const f2v r01 = {ring[j][0], ring[j][1]}, r23 = {ring[j][2], ring[j][3]};
+                            H01 = __builtin_elementwise_fma(pn2, r01, __builtin_elementwise_fma(mo, r01, H01));
+                            H23 = __builtin_elementwise_fma(pn2, r23, __builtin_elementwise_fma(mo, r23, H23));
+                            asm volatile("" : "+v"(H01), "+v"(H23));
+                            __builtin_amdgcn_sched_barrier(0);
+                            ring[j] = *reinterpret_cast<const f4v *>(mine + (int64_t)(((js + q + RR) % NI) * RPI) * K);
+                            __builtin_amdgcn_sched_barrier(0);
+                        });
+                        cur = nxt;
+                        if constexpr (c8 + 8 == 64 - LA) publish_to(s_Hs, sver, t + 2);
+                    });
+                    publish_to(s_H, ver, t + 2);
+                    if (uh == 0) MODL_STAMP(512);
+                });
+            }
+        }
+        if constexpr (!MR) {
         constexpr int KU = KPL / 2;                              // elements per lane (NB >= 2)
         constexpr int R = (KU * (int)sizeof(T) <= 16) ? 32 : 16; // Gram rows in flight (a row comes from L2 in ~600 ns)
         const int uh = wid - 1;
@@ -540,6 +685,7 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                 if (uh == 0) MODL_STAMP(512);
             }
         }
+        }   // !MR
     }
 
     // ---------------------------------------------------------------------- chain wave
@@ -566,6 +712,14 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
         const int e = lane * KPL + c;
         const T qv = qptr[e < k ? e : 0];
         qe[c] = e < k ? qv : (T)0;
+    }
+    if constexpr (MR) {                            // (the update waves form H0 = Q w with a coefficient per LANE: from LDS)
+        if (!a.H0) {
+#pragma unroll
+            for (int bI = 0; bI < NB; ++bI) s_w[64 * bI + lane] = w[bI];
+            asm volatile("" ::: "memory");
+            s_cnt[10] = 1;
+        }
     }
     const T y_norm2 = a.xnorm2[smp];
     const T tol_abs = a.tol * y_norm2;             // :336

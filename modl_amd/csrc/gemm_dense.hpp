@@ -420,13 +420,18 @@ template <typename T, class Epi> struct DenseProblem {
     T *partial = nullptr;
     Epi epi;
     int tn = 0, tm = 0, splits = 1;
+    int sym = 0;                                      // 1: out = A A^T (same operand twice, square tiles) with split-K - only the
+                                                      // tiles on and above the diagonal are computed, the split-K sum mirrors them
+                                                      // (bitwise symmetric, as the full product was: same k-ordered fma chain)
+    __host__ __device__ int tiles() const { return sym ? tm * (tm + 1) / 2 : tn * tm; }
     bool ok = false;                                  // aligned: eligible for the dense kernels
     unsigned long long *dbg = nullptr;                // diagnostics: shader-clock stamps of the FIRST tile (resident-K variant)
 };
 
 template <typename T, class Epi>
 DenseProblem<T, Epi> plan_dense(const DenseOperand &A, const DenseOperand &B, int64_t M, int64_t N, int64_t K, const Epi &epi,
-                                T *ws, size_t ws_elems, int target_wgs = 512, int max_splits = 64, int bm = 64, int bn = 64) {
+                                T *ws, size_t ws_elems, int target_wgs = 512, int max_splits = 64, int bm = 64, int bn = 64,
+                                bool symmetric = false) {
     DenseProblem<T, Epi> P;
     P.A = A; P.B = B; P.M = M; P.N = N; P.K = K; P.epi = epi;
     constexpr int VN = Vec4<T>::N;
@@ -444,9 +449,11 @@ DenseProblem<T, Epi> plan_dense(const DenseOperand &A, const DenseOperand &B, in
     if ((P.A.unal || P.B.unal) && M * N * K < (int64_t)1 << 22) { P.ok = false; return P; }
     constexpr int BK = (sizeof(T) == 4) ? 32 : 16;
     const int64_t tm = cdiv(M, bm), tn = cdiv(N, bn);
+    const bool sym = symmetric && M == N && bm == bn && A.ptr == B.ptr && A.si == B.si && A.sk == B.sk;
+    const int64_t ntile = sym ? tm * (tm + 1) / 2 : tm * tn;
     int64_t splits = 1;
-    if (tm * tn < target_wgs && max_splits > 1 && ws) {
-        splits = target_wgs / (tm * tn);
+    if (ntile < target_wgs && max_splits > 1 && ws) {
+        splits = target_wgs / ntile;
         const int64_t max_by_k = K / (4 * BK) > 0 ? K / (4 * BK) : 1;       // >= 4 k-tiles per split
         if (splits > max_by_k) splits = max_by_k;
         if (splits > max_splits) splits = max_splits;
@@ -458,6 +465,7 @@ DenseProblem<T, Epi> plan_dense(const DenseOperand &A, const DenseOperand &B, in
     P.splits = (int)cdiv(K, P.kps);
     P.tn = (int)tn; P.tm = (int)tm;
     P.partial = ws;
+    P.sym = (sym && P.splits > 1) ? 1 : 0;              // (a direct store would need the mirrored epilogue: split-K only)
     return P;
 }
 
@@ -466,24 +474,41 @@ __global__ __launch_bounds__(256) void gemm_dense_pair_kernel(DenseProblem<T, Ep
     constexpr int BM = 64, BN = 64, BK = (sizeof(T) == 4) ? 32 : 16;
     extern __shared__ __attribute__((aligned(16))) char gd_smem[];   // sized for the larger of the two tilings
     int id = (int)blockIdx.x;
-    const int t0 = P0.tn * P0.tm * P0.splits;
+    // tile number -> (column tile, row tile, split); a symmetric problem only has the tiles with bx >= by
+    auto tile_of = [](int tid_, int tn_, int tm_, int sym_, int &bx_, int &by_, int &bz_) {
+        if (sym_) {
+            const int ut = tm_ * (tm_ + 1) / 2;
+            bz_ = tid_ / ut;
+            int rem = tid_ % ut, r = 0;
+            while (rem >= tn_ - r) { rem -= tn_ - r; ++r; }
+            by_ = r;
+            bx_ = r + rem;
+        } else {
+            bx_ = tid_ % tn_;
+            by_ = (tid_ / tn_) % tm_;
+            bz_ = tid_ / (tn_ * tm_);
+        }
+    };
+    const int t0 = P0.tiles() * P0.splits;
     if (id < t0) {
         T (*As)[BK][BM + 4] = reinterpret_cast<T (*)[BK][BM + 4]>(gd_smem);
         T (*Bs)[BK][BN + 4] = reinterpret_cast<T (*)[BK][BN + 4]>(gd_smem + sizeof(T) * 2 * BK * (BM + 4));
-        const int bx = id % P0.tn, by = (id / P0.tn) % P0.tm, bz = id / (P0.tn * P0.tm);
+        int bx, by, bz;
+        tile_of(id, P0.tn, P0.tm, P0.sym, bx, by, bz);
         gemm_dense_tile_auto<T, AI0, BI0, Epi0, BM, BN, BK>(P0.A, P0.B, P0.M, P0.N, P0.K, P0.kps, P0.partial, P0.epi, bx, by,
                                                             bz, P0.splits, As, Bs);
     } else {
         id -= t0;
         // XCD-aware order for the large problem: workgroups are dealt round-robin to the 8 XCDs (each with its
         // own L2), so the tiles that share an A row-tile are renumbered to land on ONE XCD and fetch it once
-        const int t1 = P1.tn * P1.tm * P1.splits, chunk = (t1 + 7) / 8;
+        const int t1 = P1.tiles() * P1.splits, chunk = (t1 + 7) / 8;
         id = (id % 8) * chunk + id / 8;
         if (id >= t1) return;
         constexpr int BKB = BK1 > 0 ? BK1 : BK;
         T (*As)[BKB][BM1 + 4] = reinterpret_cast<T (*)[BKB][BM1 + 4]>(gd_smem);
         T (*Bs)[BKB][BN1 + 4] = reinterpret_cast<T (*)[BKB][BN1 + 4]>(gd_smem + sizeof(T) * 2 * BKB * (BM1 + 4));
-        const int bx = id % P1.tn, by = (id / P1.tn) % P1.tm, bz = id / (P1.tn * P1.tm);
+        int bx, by, bz;
+        tile_of(id, P1.tn, P1.tm, P1.sym, bx, by, bz);
         gemm_dense_tile_auto<T, AI1, BI1, Epi1, BM1, BN1, BKB>(P1.A, P1.B, P1.M, P1.N, P1.K, P1.kps, P1.partial, P1.epi, bx,
                                                                by, bz, P1.splits, As, Bs, id == 0 ? P1.dbg : nullptr);
     }
@@ -492,19 +517,25 @@ __global__ __launch_bounds__(256) void gemm_dense_pair_kernel(DenseProblem<T, Ep
 template <typename T, class Epi0, class Epi1>
 __global__ __launch_bounds__(256) void gemm_reduce_pair_kernel(const T *partial0, int splits0, int64_t M0, int64_t N0, Epi0 epi0,
                                                                int nblk0, const T *partial1, int splits1, int64_t M1,
-                                                               int64_t N1, Epi1 epi1) {
+                                                               int64_t N1, Epi1 epi1, int sym0, int sym1) {
+    // (a symmetric problem has partial sums only in its tiles on and above the diagonal, 64 x 64: an element below
+    //  them is the sum of its mirror image - the same numbers in the same order, so the result is bitwise symmetric)
     if ((int)blockIdx.x < nblk0) {
         const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
         if (e >= M0 * N0) return;
+        const int64_t m = e / N0, n = e % N0;
+        const int64_t src = (sym0 && (m >> 6) > (n >> 6)) ? n * N0 + m : e;
         T v = 0;
-        for (int z = 0; z < splits0; ++z) v += partial0[(int64_t)z * M0 * N0 + e];
-        epi0(e / N0, e % N0, v);
+        for (int z = 0; z < splits0; ++z) v += partial0[(int64_t)z * M0 * N0 + src];
+        epi0(m, n, v);
     } else {
         const int64_t e = (int64_t)((int)blockIdx.x - nblk0) * 256 + threadIdx.x;
         if (e >= M1 * N1) return;
+        const int64_t m = e / N1, n = e % N1;
+        const int64_t src = (sym1 && (m >> 6) > (n >> 6)) ? n * N1 + m : e;
         T v = 0;
-        for (int z = 0; z < splits1; ++z) v += partial1[(int64_t)z * M1 * N1 + e];
-        epi1(e / N1, e % N1, v);
+        for (int z = 0; z < splits1; ++z) v += partial1[(int64_t)z * M1 * N1 + src];
+        epi1(m, n, v);
     }
 }
 
@@ -517,7 +548,7 @@ int launch_gemm_dense_pair(hipStream_t stream, const DenseProblem<T, Epi0> &P0, 
     constexpr int BKB = BK1 > 0 ? BK1 : BK;
     constexpr size_t lds0 = sizeof(T) * 2 * BK * ((64 + 4) + (64 + 4)), lds1 = sizeof(T) * 2 * BKB * ((BM1 + 4) + (BN1 + 4));
     constexpr size_t lds = lds0 > lds1 ? lds0 : lds1;
-    const int total = P0.tn * P0.tm * P0.splits + 8 * ((P1.tn * P1.tm * P1.splits + 7) / 8);   // second problem padded to 8 XCD chunks
+    const int total = P0.tiles() * P0.splits + 8 * ((P1.tiles() * P1.splits + 7) / 8);   // second problem padded to 8 XCD chunks
     auto kern = gemm_dense_pair_kernel<T, AI0, BI0, Epi0, AI1, BI1, Epi1, BM1, BN1, BK1>;
     if (lds > 64 * 1024)
         MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -527,7 +558,7 @@ int launch_gemm_dense_pair(hipStream_t stream, const DenseProblem<T, Epi0> &P0, 
     const int nb0 = P0.splits > 1 ? (int)cdiv(P0.M * P0.N, 256) : 0, nb1 = P1.splits > 1 ? (int)cdiv(P1.M * P1.N, 256) : 0;
     if (nb0 + nb1 > 0) {
         hipLaunchKernelGGL((gemm_reduce_pair_kernel<T, Epi0, Epi1>), dim3((unsigned)(nb0 + nb1)), dim3(256), 0, stream,
-                           P0.partial, P0.splits, P0.M, P0.N, P0.epi, nb0, P1.partial, P1.splits, P1.M, P1.N, P1.epi);
+                           P0.partial, P0.splits, P0.M, P0.N, P0.epi, nb0, P1.partial, P1.splits, P1.M, P1.N, P1.epi, P0.sym, P1.sym);
         MODL_LAUNCH_CHECK();
         if (launches) ++*launches;
     }

@@ -687,7 +687,8 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
             // split-K partials double and the minibatch at reduction 1 takes 0.352 instead of 0.344 ms (same box),
             // with 192 or 384 each 0.354 / 0.358 ms
             constexpr int kPairTarget = 256;
-            auto PG = plan_dense<T, EpiStore<T>>(Dg, Dg, k, k, s, epiG, ws_split + half, ws_elems - half, kPairTarget);
+            // (the Gram matrix is symmetric: only its tiles on and above the diagonal are computed, plan_dense `symmetric`)
+            auto PG = plan_dense<T, EpiStore<T>>(Dg, Dg, k, k, s, epiG, ws_split + half, ws_elems - half, kPairTarget, 64, 64, 64, true);
             if (d.Dx_agg == MODL_AGG_AVERAGE) {
                 EpiDxAverage<T> epi{Dx, static_cast<T *>(stt->d_Dx_average), d_idx, d_wsample, k, scale};
                 auto PD = plan_dense<T, EpiDxAverage<T>>(A, B, b, k, Kdim, epi, ws_split, half, kPairTarget);

@@ -321,11 +321,13 @@ def test_full_size_step_properties(DictFact):
     assert_array_equal(runs[0][1], runs[1][1])
 
 
-def test_gram_accumulator_out_of_range_falls_back_to_records(DictFact):
+@pytest.mark.parametrize('scale', [1e13, 1e-9])
+def test_gram_accumulator_out_of_range_falls_back_to_records(DictFact, scale):
     """The blocked dictionary update sums its 32 x 32 Gram contributions in fixed point (csrc/bcd.hip: acc_add, range
-    |entry| < 2^50 in dictionary units).  Candidate atoms of norm ~1e12 - statistics scaled by hand, nothing a fit
-    produces - must not come back as a wrapped integer sum: the block is then summed from the per-workgroup records,
-    the same result as with the accumulator switched off."""
+    |entry| < 2^50 in dictionary units, absolute resolution 2^-71).  Candidate atoms of norm ~1e12 - statistics scaled by
+    hand, nothing a fit produces - must not come back as a wrapped integer sum, and candidate atoms of norm ~1e-10 (squared
+    norms under 2^-40) must not lose their relative precision to the absolute bins: in both cases the block is summed
+    from the per-workgroup records, the same result as with the accumulator switched off."""
     from modl_amd._lib import lib, check, DEBUG_BCD_ACC
     rs = np.random.RandomState(0)
     X = ((rs.randn(256, 32) * (rs.rand(256, 32) < 0.3)).dot(rs.randn(32, 1000)) / np.sqrt(0.3 * 32)
@@ -338,14 +340,18 @@ def test_gram_accumulator_out_of_range_falls_back_to_records(DictFact):
             est.prepare(n_samples=256, X=X[:64])
             est.partial_fit(X[:64])
             assert np.count_nonzero(np.diag(est.C_) > 1e-6) > 32
-            est.B_ = est.B_ * np.float32(1e13)
+            est.B_ = est.B_ * np.float32(scale)
+            if scale < 1:                                  # tiny candidates: tiny norm budgets too, else they are kept whole
+                est.components_ = est.components_ * np.float32(scale)
+                est.comp_norm_ = est.comp_norm_ * np.float32(scale ** 2)
             est.partial_fit(X[64:128])
             out[acc] = (est.components_, est.comp_norm_)
     finally:
         check(lib.modl_debug_set(DEBUG_BCD_ACC, 1))
     D1, D0 = out[1][0], out[0][0]
     assert np.all(np.isfinite(D1)) and np.all(np.isfinite(out[1][1]))
-    assert np.all(np.abs(np.sqrt(np.sum(D1.astype(np.float64) ** 2, axis=1)) - 1) < 1e-4)   # projected onto the ball
+    if scale > 1:
+        assert np.all(np.abs(np.sqrt(np.sum(D1.astype(np.float64) ** 2, axis=1)) - 1) < 1e-4)   # projected onto the ball
     assert rel_fro(D1, D0) < 1e-6
 
 
