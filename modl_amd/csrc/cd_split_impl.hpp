@@ -151,6 +151,27 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
         constexpr int TP = 64 / RPP;                             // pieces per tile
         typedef T tvec_t __attribute__((ext_vector_type(VE)));
         const int r_l = lane / UPR, c_l = (lane % UPR) * VE;     // this lane's row within a piece, first column
+        constexpr int SP = LA > 0 ? LA / RPP : 1;
+        tvec_t pc[TP], sp[SP];
+        // the loads of a tile (and of its strip) into registers: requested for tile t + 1 as soon as tile t is in LDS, i.e.
+        // a whole block of the chain wave before its buffer is free - when the chain finishes a block only the masking and
+        // the LDS stores remain (round 4 stamps: with the loads requested AFTER the buffer had become free the chain wave
+        // waited ~490 cycles for its tile at every block boundary)
+        auto request_tile = [&](int t) {
+            const int b = t % nblk;
+            const T *src = Q + (int64_t)(64 * b + r_l) * K + 64 * b + c_l;
+#pragma unroll
+            for (int i = 0; i < TP; ++i) pc[i] = *reinterpret_cast<const tvec_t *>(src + (int64_t)(i * RPP) * K);
+            if constexpr (LA > 0) {
+                // the strip of the transition b -> b + 1 (the sweep's last block -> block 0): the block's last LA rows,
+                // the NEXT block's columns, as they are
+                const int nb2 = (b + 1 == nblk) ? 0 : b + 1;
+                const T *ssrc = Q + (int64_t)(64 * b + 64 - LA + r_l) * K + 64 * nb2 + c_l;
+#pragma unroll
+                for (int i = 0; i < SP; ++i) sp[i] = *reinterpret_cast<const tvec_t *>(ssrc + (int64_t)(i * RPP) * K);
+            }
+        };
+        request_tile(0);
         int fin = 0;
         for (int t = 0;; ++t) {
             if (t - __builtin_amdgcn_readfirstlane(fin) >= 2) {
@@ -162,11 +183,6 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                 } while (t - __builtin_amdgcn_readfirstlane(fin) >= 2 && __builtin_amdgcn_readfirstlane(st) == 0);
                 if (__builtin_amdgcn_readfirstlane(st) != 0) break;
             }
-            const int b = t % nblk;
-            const T *src = Q + (int64_t)(64 * b + r_l) * K + 64 * b + c_l;
-            tvec_t pc[TP];
-#pragma unroll
-            for (int i = 0; i < TP; ++i) pc[i] = *reinterpret_cast<const tvec_t *>(src + (int64_t)(i * RPP) * K);
             T *dst = reinterpret_cast<T *>(s_tile + (unsigned int)(t & 1) * TB) + r_l * 64 + c_l;
 #pragma unroll
             for (int i = 0; i < TP; ++i) {
@@ -177,21 +193,15 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                 *reinterpret_cast<tvec_t *>(dst + i * RPP * 64) = v;
             }
             if constexpr (LA > 0) {
-                // the strip of the transition b -> b + 1 (the sweep's last block -> block 0): the block's last LA rows,
-                // the NEXT block's columns, as they are
-                constexpr int SP = LA / RPP;
-                const int nb2 = (b + 1 == nblk) ? 0 : b + 1;
-                const T *ssrc = Q + (int64_t)(64 * b + 64 - LA + r_l) * K + 64 * nb2 + c_l;
-                tvec_t sp[SP];
-#pragma unroll
-                for (int i = 0; i < SP; ++i) sp[i] = *reinterpret_cast<const tvec_t *>(ssrc + (int64_t)(i * RPP) * K);
                 T *sdst = s_strip + (t & 1) * (LA * 64) + r_l * 64 + c_l;
 #pragma unroll
                 for (int i = 0; i < SP; ++i) *reinterpret_cast<tvec_t *>(sdst + i * RPP * 64) = sp[i];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             *tiles = t + 1;
+            request_tile(t + 1);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
     if (wid == 1 || wid == 2) {
