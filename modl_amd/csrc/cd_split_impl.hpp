@@ -89,7 +89,10 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
     // extra fma per coordinate, with the delta it has just broadcast, on a strip of rows the tile loader brings), so
     // what it needs from the update waves at a block boundary is H as it was LA coordinates before the block's end:
     // they run ~1200 cycles (two LDS round trips and a chunk) behind, which the chain used to wait for, four times a sweep.
-    constexpr int LA = FULL ? 32 : 0;
+#ifndef MODL_CD_LA
+#define MODL_CD_LA 32
+#endif
+    constexpr int LA = FULL ? MODL_CD_LA : 0;         // (a multiple of 8, < 64; A/B builds override it: scripts/build_variant.sh)
     // MR: f32 with k <= 256 - a column half of a row is 256 / 512 bytes, i.e. 4 / 8 bytes per lane of an update wave: such
     // accesses run at 0.5-0.7 of the 16-byte rate and every memory instruction costs the compute unit's address pipe 16
     // cycles whatever its width - the update waves, not the chain, bounded the sweep (57 cycles per coordinate against
@@ -759,6 +762,13 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
         return (z - cl) * ri;
     };
     T Zcarry = 0;                                   // look-ahead: what the previous block's last LA steps did to this block
+    // (look-ahead) requested under a block's last eight coordinates, for the NEXT block: the first eight rows of its tile
+    // (good if the tile loader's counter, requested first, already covered it) - the block boundary then costs one check
+    // instead of three dependent LDS round trips (versions + H, tile counter, first rows: ~480 cycles per block, stamps)
+    T qpre[8];
+    bool pre_ok = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qpre[i] = 0;
     bool done = false;
     for (; n_iter < a.max_iter && !done; ++n_iter) {
         T w0[NB];
@@ -786,9 +796,18 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
             // groups of 8 coordinates, everything unrolled (the lane of a coordinate is an immediate); the slices of
             // the tile (and of the strip) for the NEXT group are requested before the current one starts
             T qd[8], qn[8], sd[8], sn[8];
+            if (pre_ok) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { qd[i] = tile[i * 64]; sd[i] = 0; sn[i] = 0; }
+                for (int i = 0; i < 8; ++i) { qd[i] = qpre[i]; sd[i] = 0; sn[i] = 0; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { qd[i] = tile[i * 64]; sd[i] = 0; sn[i] = 0; }
+            }
             T dl = 0;
+            // (look-ahead) the hand-off of the next block, requested under this block's last group
+            const int nb_off = (bI + 1 < nblk) ? 64 * (bI + 1) : 0;
+            int spec_t = 0, sv0 = 0, sv1 = 0;
+            T Hspec = 0;
             wos[dbo + lane] = wob;                  // (read by the update waves behind the first counter of the block)
             // what the step of coordinate LP (delta in lane LP of dlv) does to the coordinates after it in the block (:361-365
             // and :375-378 as one fused multiply-add with the rounded difference) and, look-ahead, to the next block
@@ -808,6 +827,14 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
 #pragma unroll
                         for (int i = 0; i < 8; ++i) sn[i] = strip[((g + 1) * 8 + i - (64 - LA)) * 64];
                     }
+                } else if constexpr (LA > 0) {
+                    // counters first, then what they guard (the LDS executes a wavefront's operations in order)
+                    spec_t = *tiles;
+                    lds_vT *ntile = (lds_vT *)(s_tile + (unsigned int)((tblk + 1) & 1) * TB) + lane;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) qpre[i] = ntile[i * 64];
+                    sv0 = sver[0]; sv1 = sver[1];
+                    Hspec = ((lds_vT *)s_Hs)[nb_off + lane];
                 }
                 static_for<8>([&](auto II) {
                     constexpr int i = decltype(II)::value;
@@ -844,14 +871,27 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
             MODL_STAMP(0);
             // the next block's entries of H (the first block's, after the sweep's last one): complete, or (look-ahead)
             // as they were LA coordinates before the end of the block just finished
-            const int nb_off = (bI + 1 < nblk) ? 64 * (bI + 1) : 0;
             lds_vT *sH = (lds_vT *)(LA > 0 ? s_Hs : s_H);
             lds_vi32 *vv = LA > 0 ? sver : ver;
-            int v0 = vv[0], v1 = vv[1];
-            Hb = sH[nb_off + lane];
-            while (__builtin_amdgcn_readfirstlane(v0) < tblk + 1 || __builtin_amdgcn_readfirstlane(v1) < tblk + 1) {
-                v0 = vv[0]; v1 = vv[1];
+            if constexpr (LA > 0) {
+                Hb = Hspec;
+                if (__builtin_amdgcn_readfirstlane(sv0) < tblk + 1 || __builtin_amdgcn_readfirstlane(sv1) < tblk + 1) {
+                    int v0 = vv[0], v1 = vv[1];
+                    Hb = sH[nb_off + lane];
+                    while (__builtin_amdgcn_readfirstlane(v0) < tblk + 1 || __builtin_amdgcn_readfirstlane(v1) < tblk + 1) {
+                        v0 = vv[0]; v1 = vv[1];
+                        Hb = sH[nb_off + lane];
+                    }
+                }
+                pre_ok = __builtin_amdgcn_readfirstlane(spec_t) > tblk;      // the next block's tile was in LDS when its rows were read
+                if (pre_ok) have_tiles = spec_t;
+            } else {
+                int v0 = vv[0], v1 = vv[1];
                 Hb = sH[nb_off + lane];
+                while (__builtin_amdgcn_readfirstlane(v0) < tblk + 1 || __builtin_amdgcn_readfirstlane(v1) < tblk + 1) {
+                    v0 = vv[0]; v1 = vv[1];
+                    Hb = sH[nb_off + lane];
+                }
             }
             asm volatile("" ::: "memory");          // (the gap test below reads s_H with plain loads)
         });
@@ -862,7 +902,7 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
             dmx = d > dmx ? d : dmx;
             wmx = aw > wmx ? aw : wmx;
         }
-        const T d_w_max = wave_max(dmx), w_max = wave_max(wmx);
+        const T d_w_max = wave_max_nn(dmx), w_max = wave_max_nn(wmx);
         if (w_max == (T)0 || d_w_max / w_max < d_w_tol || n_iter == a.max_iter - 1) {   // :388
             if constexpr (LA > 0) {                 // (look-ahead: nobody has waited for the sweep's complete H yet)
                 int v0 = ver[0], v1 = ver[1];

@@ -90,6 +90,31 @@ __device__ __forceinline__ T wave_max(T v) {
     return (a > b) ? a : b;
 }
 
+// the same for values that are >= 0 and not NaN (|differences|, |coefficients|): v_max with a DPP operand, one
+// instruction per stage instead of move + compare + select
+__device__ __forceinline__ float wave_max_nn(float v) {
+    v = fmaxf(v, dpp_perm<0xB1>(v));
+    v = fmaxf(v, dpp_perm<0x4E>(v));
+    v = fmaxf(v, dpp_perm<0x141>(v));
+    v = fmaxf(v, dpp_perm<0x140>(v));
+    float a, b;
+    lane_swap<true>(v, a, b);
+    v = fmaxf(a, b);
+    lane_swap<false>(v, a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ double wave_max_nn(double v) {
+    v = fmax(v, dpp_perm<0xB1>(v));
+    v = fmax(v, dpp_perm<0x4E>(v));
+    v = fmax(v, dpp_perm<0x141>(v));
+    v = fmax(v, dpp_perm<0x140>(v));
+    double a, b;
+    lane_swap<true>(v, a, b);
+    v = fmax(a, b);
+    lane_swap<false>(v, a, b);
+    return fmax(a, b);
+}
+
 // block-wide sum of doubles; `red` = LDS scratch of >= blockDim/64 doubles.
 // Every thread gets the result.  Deterministic.
 __device__ __forceinline__ double block_sum(double v, double *red) {

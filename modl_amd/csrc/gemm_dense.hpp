@@ -518,24 +518,26 @@ template <typename T, class Epi0, class Epi1>
 __global__ __launch_bounds__(256) void gemm_reduce_pair_kernel(const T *partial0, int splits0, int64_t M0, int64_t N0, Epi0 epi0,
                                                                int nblk0, const T *partial1, int splits1, int64_t M1,
                                                                int64_t N1, Epi1 epi1, int sym0, int sym1) {
-    // (a symmetric problem has partial sums only in its tiles on and above the diagonal, 64 x 64: an element below
-    //  them is the sum of its mirror image - the same numbers in the same order, so the result is bitwise symmetric)
+    // (a symmetric problem has partial sums only in its tiles on and above the diagonal, 64 x 64: the element of a tile
+    //  above the diagonal is summed once, with coalesced reads, and stored to both sides - bitwise symmetric)
     if ((int)blockIdx.x < nblk0) {
         const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
         if (e >= M0 * N0) return;
         const int64_t m = e / N0, n = e % N0;
-        const int64_t src = (sym0 && (m >> 6) > (n >> 6)) ? n * N0 + m : e;
+        if (sym0 && (m >> 6) > (n >> 6)) return;
         T v = 0;
-        for (int z = 0; z < splits0; ++z) v += partial0[(int64_t)z * M0 * N0 + src];
+        for (int z = 0; z < splits0; ++z) v += partial0[(int64_t)z * M0 * N0 + e];
         epi0(m, n, v);
+        if (sym0 && (m >> 6) < (n >> 6)) epi0(n, m, v);
     } else {
         const int64_t e = (int64_t)((int)blockIdx.x - nblk0) * 256 + threadIdx.x;
         if (e >= M1 * N1) return;
         const int64_t m = e / N1, n = e % N1;
-        const int64_t src = (sym1 && (m >> 6) > (n >> 6)) ? n * N1 + m : e;
+        if (sym1 && (m >> 6) > (n >> 6)) return;
         T v = 0;
-        for (int z = 0; z < splits1; ++z) v += partial1[(int64_t)z * M1 * N1 + src];
+        for (int z = 0; z < splits1; ++z) v += partial1[(int64_t)z * M1 * N1 + e];
         epi1(m, n, v);
+        if (sym1 && (m >> 6) < (n >> 6)) epi1(n, m, v);
     }
 }
 
