@@ -815,7 +815,13 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                 constexpr int LP = decltype(LP_)::value;
                 const T dn = bcast_lane(dlv, LP);
                 Z = fma(-dn, rowv, Z);
-                if constexpr (LA > 0 && LP >= 64 - LA) Zla = fma(-dn, spv, Zla);
+                if constexpr (LA > 0 && LP >= 64 - LA) {
+                    Zla = fma(-dn, spv, Zla);
+                    // (pinned to its step: left alone, the compiler sinks the whole chain of LA fused multiply-adds to its
+                    //  first use - the block's end - and keeps the LA broadcast deltas and strip rows live until then: 64
+                    //  instructions in a row at every block boundary, the ~460 cycles the stamps showed there)
+                    asm volatile("" : "+v"(Zla));
+                }
             };
             static_for<8>([&](auto GG) {
                 constexpr int g = decltype(GG)::value;
