@@ -53,6 +53,13 @@ class ProfEntry(C.Structure):
 
 
 def _load():
+    # MODL_AMD_DIAG=1 (scripts/diag_*.py that read in-kernel stamps of a whole estimator run): the diagnostics build of the
+    # same sources takes the product library's place for this process
+    if os.environ.get('MODL_AMD_DIAG') == '1':
+        path = os.path.join(_HERE, 'libmodl_hip_diag.so')
+        if not os.path.exists(path):
+            raise ImportError('modl_amd: MODL_AMD_DIAG=1 but %s is missing (make -C modl_amd/csrc)' % path)
+        return C.CDLL(path)
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             'modl_amd: %s is missing. Build it with `python -c "import __graft_entry__ as g; g.build()"` '

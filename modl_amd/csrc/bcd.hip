@@ -1106,7 +1106,13 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
     if (tid == 0) { *mail.pcount = 0; *mail.zcount = 0; }
     const int64_t f0 = (int64_t)blockIdx.x * RB;
     const int nwg = rider.nslab, gsz = p.group, ngroups = (nwg + gsz - 1) / gsz;
+#ifdef MODL_DIAG     // phase stamps of workgroup 0 (modl_somf_debug_stamps): the diagnostics build only - every stamp is an
+                     // s_memtime behind an s_waitcnt lgkmcnt(0), i.e. it drains the LDS requests the recursion keeps in flight,
+                     // and the launch lasts as long as its slowest workgroup
     unsigned long long *st = (p.stamps && blockIdx.x == 0 && !fin) ? p.stamps : nullptr;
+#else
+    unsigned long long *const st = nullptr;
+#endif
     if (st && tid == 0) st[0] = clock64();
     if (p.acc_zero && blockIdx.x == 0)                    // the accumulator the NEXT launch adds to (idle during this one)
         for (int e = tid; e < kAccWords; e += 384) p.acc_zero[e] = 0;

@@ -791,8 +791,14 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
             T Z = (fma(qdg[bI], wob, q[bI]) - Hb) + Zcarry;
             T Zla = 0;                              // look-ahead: this block's last LA steps on the NEXT block's entries
             // row L of the tile, this lane's column: Q[64 b + L][64 b + lane] for lane > L, else 0
-            lds_vT *tile = (lds_vT *)(s_tile + (unsigned int)(tblk & 1) * TB) + lane;
-            lds_vT *strip = (lds_vT *)(s_strip + (LA > 0 ? (tblk & 1) * (LA * 64) : 0)) + lane;
+            // (plain, not volatile, LDS pointers: rows L and L + n of a lane's column are 256 n bytes apart - what
+            //  ds_read2st64_b32 fetches in ONE instruction, and an LDS instruction costs the chain wave an issue slot
+            //  like any other; the compiler barrier keeps the reads behind the wait for the tile, and after it the
+            //  buffer is not written until the chain wave itself releases it)
+            typedef __attribute__((address_space(3))) const T lds_cT;
+            asm volatile("" ::: "memory");
+            lds_cT *tile = (lds_cT *)(s_tile + (unsigned int)(tblk & 1) * TB) + lane;
+            lds_cT *strip = (lds_cT *)(s_strip + (LA > 0 ? (tblk & 1) * (LA * 64) : 0)) + lane;
             // groups of 8 coordinates, everything unrolled (the lane of a coordinate is an immediate); the slices of
             // the tile (and of the strip) for the NEXT group are requested before the current one starts
             T qd[8], qn[8], sd[8], sn[8];
@@ -836,9 +842,11 @@ __global__ __launch_bounds__(256) void cd_split_kernel(CdArgs<T> a, unsigned lon
                 } else if constexpr (LA > 0) {
                     // counters first, then what they guard (the LDS executes a wavefront's operations in order)
                     spec_t = *tiles;
-                    lds_vT *ntile = (lds_vT *)(s_tile + (unsigned int)((tblk + 1) & 1) * TB) + lane;
+                    asm volatile("" ::: "memory");               // (the rows stay behind their counter)
+                    lds_cT *ntile = (lds_cT *)(s_tile + (unsigned int)((tblk + 1) & 1) * TB) + lane;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) qpre[i] = ntile[i * 64];
+                    asm volatile("" ::: "memory");
                     sv0 = sver[0]; sv1 = sver[1];
                     Hspec = ((lds_vT *)s_Hs)[nb_off + lane];
                 }

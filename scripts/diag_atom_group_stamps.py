@@ -1,6 +1,8 @@
 """Cycle breakdown of the grouped atom update (bcd.hip: atom_grad_group_kernel + atom_project_group_kernel) on the fMRI
 shape (config 3: k = 70 l1 atoms, p = 60 000, reduction 12): time per minibatch, then the sums over the launches of the
 projecting workgroup's stamps (MODL_DEBUG_ATOM_STAMPS; the stamps themselves cost a memory round trip per atom)."""
+import os as _os
+_os.environ.setdefault('MODL_AMD_DIAG', '1')     # the stamps only exist in the diagnostics build (libmodl_hip_diag.so)
 import sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

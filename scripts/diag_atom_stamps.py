@@ -1,3 +1,5 @@
+import os as _os
+_os.environ.setdefault('MODL_AMD_DIAG', '1')     # the stamps only exist in the diagnostics build (libmodl_hip_diag.so)
 import sys, os, ctypes as C
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch

@@ -1,5 +1,7 @@
 """Diagnostic: where one tile of the head statistics product (K = b = 256) spends its time.
 Run with MODL_GEMM_STAMPS=1."""
+import os as _os
+_os.environ.setdefault('MODL_AMD_DIAG', '1')     # the stamps only exist in the diagnostics build (libmodl_hip_diag.so)
 import ctypes as C
 import os
 import sys

@@ -1,5 +1,7 @@
 """In-kernel stamps of the blocked dictionary update at the C5 shape (p = 200 000, k = 256, reduction 12: 96 features per
 workgroup, bcd_block_kernel<3, 8>), workgroup 0 of the last full block launch."""
+import os as _os
+_os.environ.setdefault('MODL_AMD_DIAG', '1')     # the stamps only exist in the diagnostics build (libmodl_hip_diag.so)
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
