@@ -2343,7 +2343,9 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         // deferred statistics product riding along (launches 1 .. nblk carry cdiv(tiles, nblk) tiles each)
         BcdRiderArgs rid;
         rid.nslab = nslab;
-        if (fused) rid.dbg = reinterpret_cast<unsigned long long *>(counter + kCounters) + 40;
+#ifdef MODL_DIAG
+        if (fused) rid.dbg = reinterpret_cast<unsigned long long *>(counter + kCounters) + 40;     // (stamps of the first riding tile)
+#endif
         int ride_tiles = 0, ride_per = 0, ride_next = 0;
         if (fused && a.rider) {
             const StatsRider &R = *a.rider;
