@@ -12,6 +12,11 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # A/B runs of the whole suite under another mode of the blocked dictionary update (include/modl_hip.h, MODL_DEBUG_BCD_ACC)
+    mode = os.environ.get('MODL_TEST_BCD_ACC')
+    if mode is not None:
+        from modl_amd._lib import lib, check, DEBUG_BCD_ACC
+        check(lib.modl_debug_set(DEBUG_BCD_ACC, int(mode)))
 
 
 def load_golden(name):
