@@ -54,8 +54,6 @@ std::atomic<unsigned long long *> g_atom_stamps{nullptr};
 // diagnostics (modl_debug_set(MODL_DEBUG_BCD_TINY, 0)): the separate launches of the blocked update also for small sampled sets
 std::atomic<int> g_bcd_tiny{1};
 constexpr int kAccWords = 3 * (2 * 136 + 256 + kNB) + 2;   // int64 words of one Gram accumulator (3 bins x packed record + the out-of-range word: kAccStride below)
-constexpr int kAheadEntries = kNB * kNB + (2 * 136 + 256) + (2 * 136 + 256 + kNB);   // look-ahead mode: the cross products X (32 x 32) and the packed Gram matrix of the previous block's candidates in front of the packed record
-constexpr int kAheadWords = 3 * kAheadEntries + 2;         // ... and its accumulator
 constexpr int kGramRows = 128;     // feature rows per Gram slab
 #ifndef MODL_KGROUP
 #define MODL_KGROUP 16
@@ -65,7 +63,7 @@ constexpr int kCounters = 64;      // arrival counters: [0] final, [1 + g] group
 constexpr int kAtomGroupMax = 8;   // atoms per launch pair of the grouped atom update (l1 / elastic-net atoms)
 
 struct DuLayout {
-    size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, off_BsP, off_gpartial, off_norm_in, off_qcoef, off_save, total;
+    size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, off_BsP, off_gpartial, off_norm_in, total;
     int64_t nslab_max, nwg_grad;
 };
 
@@ -85,7 +83,7 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     L.off_frozen = take(sizeof(int32_t) * k4);
     L.off_coef = take(sizeof(double) * (size_t)kNB * k4);
     L.off_a = take(tsz * (size_t)s_max * kNB);
-    L.off_partial = take(sizeof(double) * 2 * (size_t)L.nslab_max * kAheadEntries);       // two record buffers (ping-pong; look-ahead mode: cross products + packed record)
+    L.off_partial = take(sizeof(double) * 2 * (size_t)L.nslab_max * (kNB * kNB + kNB));   // two record buffers (ping-pong)
     L.off_Tp = take(sizeof(double) * 2 * (kNB * kNB + kNB) + 256 + 512);  // two CA records (ping-pong) + arrival counters + debug stamps
     L.off_u = take(tsz * (size_t)s_max);
     L.off_pold = take(sizeof(double) * (size_t)L.nwg_grad);
@@ -97,8 +95,6 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     L.off_BsP = take(tsz * (size_t)s_max * k4);                       // packed B rows (packed D shares off_Dnew)
     L.off_gpartial = take(sizeof(double) * 2 * (size_t)kCounters * (kNB * kNB + kNB));   // group sums (two-level reduction), ping-pong
     L.off_norm_in = take(tsz * k4);
-    L.off_qcoef = take(sizeof(double) * (size_t)kNB * k4);           // look-ahead mode: Q of every block against its predecessor
-    L.off_save = take(sizeof(double) * 2 * kNB * kNB);               // ... S of the block before (ping-pong)
     L.total = o;
     return L;
 }
@@ -170,8 +166,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_t *order, int k, int kp, T *CPP, T *cdiag,
                                                         int32_t *frozen, double *coef_all, unsigned int *counter,
                                                         const T *comp_norm, T *norm_in, const T *Dt, const T *Bt,
-                                                        const int32_t *subset, int64_t s, T *DsP, T *BsP, long long *acc,
-                                                        int acc_words, double *qcoef) {
+                                                        const int32_t *subset, int64_t s, T *DsP, T *BsP, long long *acc) {
     // kp = k rounded up to a multiple of 4: the packed arrays carry kp - k dead atoms (zero columns, frozen), so that the
     // 16-byte fragments of the block kernel exist for every number of atoms
     int id = (int)blockIdx.x;
@@ -179,7 +174,7 @@ __global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_
         const int m = id;
         if (m == 0) {
             if (threadIdx.x < kCounters) counter[threadIdx.x] = 0;
-            if (acc) for (int e = threadIdx.x; e < 3 * acc_words; e += 256) acc[e] = 0;
+            if (acc) for (int e = threadIdx.x; e < 3 * kAccWords; e += 256) acc[e] = 0;
             for (int j = threadIdx.x; j < kp; j += 256) {
                 const bool real = j < k;
                 const int oj = real ? order[j] : 0;
@@ -198,15 +193,6 @@ __global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_
                 if (d > (T)1e-20) c = (double)C[(int64_t)oi * k + oj] / (double)d;
             }
             coef_all[(int64_t)jj * kNB + m] = c;          // [sweep position][atom of its block]: one contiguous row per step
-            if (qcoef) {                                  // look-ahead mode: against atom m of the block BEFORE (gram_ahead)
-                double q = 0;
-                if (jj < k && jb0 >= kNB) {
-                    const int oi = order[jb0 - kNB + m], oj = order[jj];
-                    const T d = C[(int64_t)oj * k + oj];
-                    if (d > (T)1e-20) q = (double)C[(int64_t)oi * k + oj] / (double)d;
-                }
-                qcoef[(int64_t)jj * kNB + m] = q;
-            }
         }
         return;
     }
@@ -444,30 +430,6 @@ struct SinkBasePacked {
         Base[i * 64 + 32 + j] = v;
     }
 };
-constexpr int kTS = kNB + 2;            // LDS row stride (doubles) of the 32 x 32 matrices of the Gram-domain step (gram_ahead)
-// look-ahead record: the cross products X[m][c] (entries 0 .. 1023), the packed Gram matrix of the previous block's
-// candidates (528 entries) and the packed record of this block
-constexpr int kAheadMp = kNB * kNB, kAheadG0 = kNB * kNB + 2 * kTri + 256;
-struct SinkAhead {
-    double *Xs, *Mp; SinkBasePacked g;
-    __device__ __forceinline__ void operator()(int e, double v) const {
-        if (e < kAheadMp) Xs[(e >> 5) * kTS + (e & 31)] = v;
-        else if (e < kAheadG0) {
-            int i, j;
-            const int q = e - kAheadMp;
-            if (q < kTri) {
-                SinkLdsPacked::untri(q, i, j);
-            } else if (q < kTri + 256) {
-                i = (q - kTri) >> 4; j = 16 + ((q - kTri) & 15);
-            } else {
-                SinkLdsPacked::untri(q - kTri - 256, i, j);
-                i += 16; j += 16;
-            }
-            Mp[i * kTS + j] = v;
-            Mp[j * kTS + i] = v;
-        } else g(e - kAheadG0, v);
-    }
-};
 struct SinkGlobal {
     double *dst;
     __device__ __forceinline__ void operator()(int e, double v) const { dst[e] = v; }
@@ -486,62 +448,45 @@ struct SinkGlobal {
 constexpr int kAccBins = 3;
 constexpr int kAccStride = kAccBins * kPackStride;        // int64 words of the bins; word kAccStride: out of range
 static_assert(kAccStride + 2 == kAccWords, "accumulator size");
-// The split: adding 1.5 * 2^(52 + e) to a value below 2^(51 + e) leaves round(v / 2^e) in the low bits of the sum's
-// mantissa (the exponent field is that of the constant), and subtracting the constant again gives the rounded value, so
-// that the remainder v - round(v / 2^e) 2^e is exact: five additions and three integer subtractions per entry (the
-// conversions double -> int64 are software on this part: ~45 instructions per entry before, on wavefronts that issue
-// one instruction every 6-7 cycles - 2 k cycles of every block launch).
-template <int ENTRIES = kPackStride>
-__device__ __forceinline__ void acc_add(long long *acc, int idx, double v, bool norm_entry = false) {
-    if (!(fabs(v) < 0x1p50) || (norm_entry && v != 0.0 && fabs(v) < 0x1p-40)) {
-        atomicOr(reinterpret_cast<unsigned long long *>(acc) + kAccBins * ENTRIES, 1ull);
-        return;
-    }
+// The split without a conversion: adding 1.5 * 2^(52 + e) to a value below 2^(51 + e) leaves round(v / 2^e) in the low bits
+// of the sum's mantissa (the exponent field is the constant's), and subtracting the constant again gives the rounded value,
+// so that the remainder v - round(v / 2^e) 2^e is exact: five additions and three integer subtractions per entry, no
+// branch but the one around the top bin (a double -> int64 conversion is software on this part: ~45 instructions and four
+// branches per entry before - 600 to 1000 cycles of a wavefront that issues an instruction every 6-7 cycles, four entries
+// per lane at the end of every block launch: profiles/r04_ab_look_ahead_stamps.txt, "G detail").  `bad` collects the
+// out-of-range lanes (their contribution is dropped: the readers take the records then); acc_flag raises the word once.
+__device__ __forceinline__ void acc_add(long long *acc, int idx, double v, bool norm_entry, bool &bad) {
+    const bool out = !(fabs(v) < 0x1p50) || (norm_entry && v != 0.0 && fabs(v) < 0x1p-40);
+    bad = bad || out;
+    const double w = out ? 0.0 : v;
     const double m2 = 0x1.8p62, m1 = 0x1.8p22, m0 = 0x1.8p-18;          // units 2^10, 2^-30, 2^-70
-    const double x2 = v + m2;
+    const double x2 = w + m2;
     const long long b2 = __double_as_longlong(x2) - __double_as_longlong(m2);
-    const double r1 = v - (x2 - m2);                                      // |r1| <= 2^9, exact
+    const double r1 = w - (x2 - m2);                                      // |r1| <= 2^9, exact
     const double x1 = r1 + m1;
     const long long b1 = __double_as_longlong(x1) - __double_as_longlong(m1);
     const double r0 = r1 - (x1 - m1);                                     // |r0| <= 2^-31, exact
     const double x0 = r0 + m0;
     const long long b0 = __double_as_longlong(x0) - __double_as_longlong(m0);   // (to nearest)
     unsigned long long *a = reinterpret_cast<unsigned long long *>(acc);
-    if (b2) atomicAdd(a + 2 * ENTRIES + idx, (unsigned long long)b2);   // (device scope, no return value)
-    if (b1) atomicAdd(a + 1 * ENTRIES + idx, (unsigned long long)b1);
-    if (b0) atomicAdd(a + idx, (unsigned long long)b0);
+    if (__builtin_expect(b2 != 0, 0)) atomicAdd(a + 2 * kPackStride + idx, (unsigned long long)b2);   // (|v| >= 2^9 only)
+    atomicAdd(a + 1 * kPackStride + idx, (unsigned long long)b1);        // (device scope, no return value)
+    atomicAdd(a + idx, (unsigned long long)b0);
+}
+__device__ __forceinline__ void acc_flag(long long *acc, bool bad) {
+    if (bad) atomicOr(reinterpret_cast<unsigned long long *>(acc) + kAccStride, 1ull);
 }
 // this thread's elements 2 e2, 2 e2 + 1 of the accumulated record -> sink; returns the out-of-range word (uniform)
-template <int ENTRIES = kPackStride, typename Sink>
+template <typename Sink>
 __device__ __forceinline__ bool acc_load(const long long *acc, int e2, bool valid, Sink sink) {
     typedef long long l2v __attribute__((ext_vector_type(2)));
     const l2v *base = reinterpret_cast<const l2v *>(acc) + (valid ? e2 : 0);
-    const l2v b0 = base[0], b1 = base[ENTRIES / 2], b2 = base[ENTRIES];   // (three 16-byte loads, one round trip)
-    const long long bad = acc[kAccBins * ENTRIES];                         // (the same trip)
+    const l2v b0 = base[0], b1 = base[kPackStride / 2], b2 = base[kPackStride];   // (three 16-byte loads, one round trip)
+    const long long bad = acc[kAccStride];                                         // (the same trip)
     if (valid) {
         sink(2 * e2, ((double)b2.x * 0x1p10 + (double)b1.x * 0x1p-30) + (double)b0.x * 0x1p-70);
         sink(2 * e2 + 1, ((double)b2.y * 0x1p10 + (double)b1.y * 0x1p-30) + (double)b0.y * 0x1p-70);
     }
-    return bad != 0;
-}
-// N pairs of one accumulator in ONE round trip (every request before the first conversion)
-template <int ENTRIES, int N, typename Sink>
-__device__ __forceinline__ bool acc_load_n(const long long *acc, const int (&e2)[N], const bool (&valid)[N], Sink sink) {
-    typedef long long l2v __attribute__((ext_vector_type(2)));
-    l2v b[N][3];
-#pragma unroll
-    for (int q = 0; q < N; ++q) {
-        const l2v *base = reinterpret_cast<const l2v *>(acc) + (valid[q] ? e2[q] : 0);
-        b[q][0] = base[0]; b[q][1] = base[ENTRIES / 2]; b[q][2] = base[ENTRIES];
-    }
-    const long long bad = acc[kAccBins * ENTRIES];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < N; ++q)
-        if (valid[q]) {
-            sink(2 * e2[q], ((double)b[q][2].x * 0x1p10 + (double)b[q][1].x * 0x1p-30) + (double)b[q][0].x * 0x1p-70);
-            sink(2 * e2[q] + 1, ((double)b[q][2].y * 0x1p10 + (double)b[q][1].y * 0x1p-30) + (double)b[q][0].y * 0x1p-70);
-        }
     return bad != 0;
 }
 __device__ __forceinline__ void reduce_partials(const double *partial, int nslab, double (*M)[kNB + 1], double *D2) {
@@ -1081,55 +1026,6 @@ __device__ __forceinline__ void lds_barrier() {
 
 constexpr int kCaStride = kNB + 2;      // LDS row stride (doubles) of the S matrix: 2-way instead of 16-way conflicts
 constexpr int kApStride = kNB + 4;      // LDS row stride (floats) of the staged a-tile
-static_assert(kCaStride == kTS, "the S matrix of the previous block is an operand of the Gram-domain step");
-
-// ---- Look-ahead mode: the Gram matrix of a block WITHOUT a reduction over the features behind its predecessor's recursion.
-// Block b's candidates are a_c = N'_c - sum_i Dnew_i Q[i][c] (N': the candidates with block b - 1 left out of the
-// product; Dnew_i = sum_m S[i][m] a'_m the atoms block b - 1 ends up with, a' its candidates; Q[i][c] = C[o_i,o_c] / C[o_c,o_c]),
-// so with P = Q^T S (32 x 32)
-//     <a_c, a_c'> = <N'_c, N'_c'> - sum_m P[c][m] X[m][c'] - sum_m P[c'][m] X[m][c] + (P M' P^T)[c][c'],
-// where X[m][c] = <a'_m, N'_c> and M' is the Gram matrix of block b - 1's candidates.  <N', N'> and X do not depend on the
-// recursion of block b - 1: every workgroup adds its share to the accumulator while that recursion runs, the atomics
-// retire in its shadow (scripts/micro/atomic_drain.hip), and the next launch turns them into the Gram matrix of block b
-// with four 32 x 32 x 32 products on the f64 matrix cores.  All matrices in LDS, row stride kTS.
-typedef double d4v_t __attribute__((ext_vector_type(4)));
-template <bool BT>   // C tile (t1, t2) of A B (BT: of A B^T), 16 x 16, contraction over 32
-__device__ __forceinline__ d4v_t tile32(const double *Am, const double *Bm, int t1, int t2, int lane) {
-    d4v_t c = {0.0, 0.0, 0.0, 0.0};
-    const double *ap = Am + (t1 * 16 + (lane & 15)) * kTS + (lane >> 4);
-    const double *bp = BT ? Bm + (t2 * 16 + (lane & 15)) * kTS + (lane >> 4) : Bm + (lane >> 4) * kTS + t2 * 16 + (lane & 15);
-#pragma unroll
-    for (int kk = 0; kk < kNB / 4; ++kk)
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kk], BT ? bp[4 * kk] : bp[4 * kk * kTS], c, 0, 0, 0);
-    return c;
-}
-__device__ __forceinline__ void tile32_store(double *Cm, const d4v_t &c, int t1, int t2, int lane) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Cm[(t1 * 16 + (lane >> 4) + 4 * r) * kTS + t2 * 16 + (lane & 15)] = c[r];
-}
-// Called by all six wavefronts (the four workers compute, one tile each).  On entry: Base holds <N', N'> (SinkBasePacked),
-// Qt[c][i] = Q[i][c], Ss = S, Mp = M', Xs = X; on exit Base holds the block's Gram matrix (Qt and Ss are overwritten).
-__device__ __forceinline__ void gram_ahead(double *Qt, double *Ss, const double *Mp, const double *Xs, double *Ps, double *Base,
-                                           int wid, int lane) {
-    const int t1 = wid >> 1, t2 = wid & 1;
-    if (wid < 4) tile32_store(Ps, tile32<false>(Qt, Ss, t1, t2, lane), t1, t2, lane);            // P = Q^T S
-    lds_barrier();
-    if (wid < 4) {
-        const d4v_t R = tile32<false>(Ps, Xs, t1, t2, lane);                                       // R = P X
-        const d4v_t Z = tile32<true>(Mp, Ps, t1, t2, lane);                                        // Z = M' P^T
-        tile32_store(Qt, R, t1, t2, lane);
-        tile32_store(Ss, Z, t1, t2, lane);
-    }
-    lds_barrier();
-    if (wid < 4) {
-        const d4v_t V = tile32<false>(Ps, Ss, t1, t2, lane);                                       // V = P Z
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = t1 * 16 + (lane >> 4) + 4 * r, c2 = t2 * 16 + (lane & 15);
-            Base[c2 * 64 + 32 + c] += (V[r] - Qt[c * kTS + c2]) - Qt[c2 * kTS + c];
-        }
-    }
-}
 
 struct BcdBlockArgs {
     float *Dt;                      // PACKED dictionary [s][k]: row = sampled feature, column = sweep position
@@ -1155,11 +1051,6 @@ struct BcdBlockArgs {
     int64_t s;
     int k, j0, nb, j0_prev, nb_prev, group;   // k: atoms of the PACKED arrays (a multiple of 4, dead atoms behind the real ones)
     int kout;                                 // row stride of Dt_out: the real number of atoms
-    // look-ahead mode (gram_ahead): Q[i][c] of every block against its predecessor, [sweep position c][32] doubles;
-    // save_in: S of block b - 2 (left by workgroup 0 of the previous launch), save_out: that of b - 1
-    const double *qcoef, *save_in;
-    double *save_out;
-    int has_pp;                               // block b - 2 exists
 };
 
 // Riding along (see StatsRider in kernels.hpp): the workgroups behind the first `nslab` ones each take one 32 x 32
@@ -1236,8 +1127,6 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
     unsigned long long *const st = nullptr;
 #endif
     if (st && tid == 0) st[0] = clock64();
-    if (p.acc_zero && blockIdx.x == 0)                    // the accumulator the NEXT launch adds to (idle during this one)
-        for (int e = tid; e < kAccWords; e += 384) p.acc_zero[e] = 0;
 
     // ---------------------------------------------------------------- (B) Gram of the previous block
     // First thing in the launch: the recursion is the critical path and only needs these records.
@@ -1462,6 +1351,11 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
                 }
             }
         }
+        // the accumulator the NEXT launch adds to (idle during this one): cleared by a wavefront that has a SIMD to itself
+        // and nothing to do until its operands arrive (at the head of the launch it sat in front of workgroup 0's record
+        // loads; on wavefront 0 or 1 it takes issue slots from the recursion: 13.6 k cycles instead of 12.9 k)
+        if (p.acc_zero && blockIdx.x == 0 && wid == 3)
+            for (int e = lane; e < kAccWords; e += 64) p.acc_zero[e] = 0;
         if (st && tid == 0) st[13] = clock64();
         if (st && tid == 64) st[20] = clock64();
         if (st && tid == 128) st[21] = clock64();            // product wave 2: operands requested
@@ -1562,12 +1456,19 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
 #pragma unroll
         for (int u = 0; u < RT; ++u) {
             const int t = wid * RT + u, ft = t >> 1, jt = t & 1;
-            d4v dn = {0.0, 0.0, 0.0, 0.0};
+            d4v dn = {0.0, 0.0, 0.0, 0.0}, dn1 = {0.0, 0.0, 0.0, 0.0};
             const float *ap = Ap + (ft * 16 + (lane & 15)) * kApStride + (lane >> 4);
             const double *sp = CAs + (jt * 16 + (lane & 15)) * kCaStride + (lane >> 4);
+            float fa[kNB / 4];                          // (every LDS operand requested before the first product; two accumulators)
+            double fs[kNB / 4];
 #pragma unroll
-            for (int kk = 0; kk < kNB / 4; ++kk)
-                dn = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ap[4 * kk], sp[4 * kk], dn, 0, 0, 0);
+            for (int kk = 0; kk < kNB / 4; ++kk) { fa[kk] = ap[4 * kk]; fs[kk] = sp[4 * kk]; }
+#pragma unroll
+            for (int kk = 0; kk < kNB / 4; kk += 2) {
+                dn = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[kk], fs[kk], dn, 0, 0, 0);
+                dn1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[kk + 1], fs[kk + 1], dn1, 0, 0, 0);
+            }
+            dn += dn1;
             const int cj = jt * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1632,34 +1533,65 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
     if (st && tid == 0) st[7] = clock64();
     // ---------------------------------------------------------------- (G) Gram record of this workgroup
     if (worker) {
-        // tiles (0,0) (0,1) (1,1) of 16 x 16 on waves 0, 1, 3 (tile (1,0) is the transpose of (0,1))
-        const int it = wid >> 1, jt = wid & 1;
-        d4v g = {0.0, 0.0, 0.0, 0.0};
+        // tiles (0,0) (0,1) (1,1) of 16 x 16 (tile (1,0) is the transpose of (0,1)) on waves 0, 1 + 2, 3: both wave 1 and
+        // wave 2 form tile (0,1), the only one without idle lanes, and add two of its four rows of entries each.  Every LDS
+        // operand is requested before the first product and the contraction runs on two accumulators (as one dependent chain
+        // of load - convert - product rounds the tile took 1.2 k cycles of the 4.7 k of this section).  What is left is the
+        // compute unit's rate of 8-byte atomics and stores, ~1.3 cycles per lane: handing the 560 entries through LDS to all
+        // 256 threads, two or three contiguous ones each, made the section LONGER (3.9 k against 3.2 k cycles).
+        const int it = (wid == 3) ? 1 : 0, jt = (wid == 0) ? 0 : 1;
         const float *ai = As + (lane >> 4) * (kNB + 1) + it * 16 + (lane & 15);
         const float *aj = As + (lane >> 4) * (kNB + 1) + jt * 16 + (lane & 15);
         double *out = p.rec_out + (int64_t)blockIdx.x * kPackStride;
-        if (wid != 2) {
+        float fa[RB / 4], fb[RB / 4];
 #pragma unroll
-            for (int kk = 0; kk < RB / 4; ++kk)
-                g = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ai[4 * kk * (kNB + 1)], (double)aj[4 * kk * (kNB + 1)], g, 0, 0, 0);
+        for (int kk = 0; kk < RB / 4; ++kk) {
+            fa[kk] = ai[4 * kk * (kNB + 1)];
+            fb[kk] = aj[4 * kk * (kNB + 1)];
+        }
+        double t = 0;
+        if (wid == 2 && lane < kNB)
+            for (int gq = 0; gq < 8; ++gq) t += d2red[gq * kNB + lane];
+        d4v g = {0.0, 0.0, 0.0, 0.0}, g1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < RB / 4; kk += 2) {
+            g = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[kk], (double)fb[kk], g, 0, 0, 0);
+            g1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[kk + 1], (double)fb[kk + 1], g1, 0, 0, 0);
+        }
+        g += g1;
+        if (st && tid == 0) st[30] = clock64() + (unsigned long long)(g[0] * 0.0);
+        bool bad = false;
+        const int c15 = lane & 15;
+        if (it != jt) {                                              // tile (0,1): full; wave 1 rows r = 0, 1, wave 2 rows 2, 3
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = (wid == 2) ? 2 + rr : rr;
+                const int e = kTri + ((lane >> 4) + 4 * r) * 16 + c15;
+                const double v = (wid == 2) ? (rr ? g[3] : g[2]) : (rr ? g[1] : g[0]);
+                if (p.acc_out) acc_add(p.acc_out, e, v, false, bad);
+                out[e] = v;
+            }
+            if (wid == 2 && lane < kNB) {                            // + the old squared norms
+                if (p.acc_out) acc_add(p.acc_out, 2 * kTri + 256 + lane, t, true, bad);
+                out[2 * kTri + 256 + lane] = t;
+            }
+        } else {                                                     // diagonal tiles: triangle
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = (lane >> 4) + 4 * r, col = lane & 15;
-                if (p.acc_out) {
-                    if (it != jt) acc_add(p.acc_out, kTri + row * 16 + col, g[r]);
-                    else if (row <= col) acc_add(p.acc_out, (it ? kTri + 256 : 0) + tri_index(row, col), g[r], row == col);
+                const int row = (lane >> 4) + 4 * r;
+                if (row <= c15) {
+                    const int e = (it ? kTri + 256 : 0) + tri_index(row, c15);
+                    if (p.acc_out) acc_add(p.acc_out, e, g[r], row == c15, bad);
+                    out[e] = g[r];
                 }
-                if (it != jt) out[kTri + row * 16 + col] = g[r];                                   // tile (0,1): full
-                else if (row <= col) out[(it ? kTri + 256 : 0) + tri_index(row, col)] = g[r];        // diagonal tiles: triangle
             }
-        } else if (lane < kNB) {
-            double t = 0;
-            for (int gq = 0; gq < 8; ++gq) t += d2red[gq * kNB + lane];
-            if (p.acc_out) acc_add(p.acc_out, 2 * kTri + 256 + lane, t, true);
-            out[2 * kTri + 256 + lane] = t;
         }
+        if (p.acc_out) acc_flag(p.acc_out, bad);
     }
     if (st && tid == 0) st[12] = clock64();
+    if (st && tid == 64) st[33] = clock64();
+    if (st && tid == 128) st[35] = clock64();
+    if (st && tid == 192) st[34] = clock64();
     if (ngroups > 1) {   // pre-sum this group's records: the last workgroup of the group to arrive does it
         const int g = (int)blockIdx.x / gsz;
         const int gsize = (nwg - g * gsz < gsz) ? nwg - g * gsz : gsz;
@@ -1670,630 +1602,10 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
     }
 }
 
-// ---- fused block kernel, look-ahead mode (modl_debug_set(MODL_DEBUG_BCD_ACC, 2)) ---------------------------------------
-// The block kernel above with the feature-domain reduction taken off the critical path (gram_ahead).  Launch b
-//   head (wavefronts 0, 1, 4, 5): the accumulated pieces of block b - 1 + S of block b - 2 -> the Gram matrix of block b - 1's
-//       candidates, four 32 x 32 x 32 products on the f64 matrix cores;  wavefronts 2, 3 meanwhile request the operands of
-//       the product (they take ~3.5 k cycles to issue and ~8 k to arrive: requested behind the head, the product would end
-//       with the recursion and everything behind it would lengthen the launch);
-//   recursion of block b - 1 on wavefronts 4, 5, and in its shadow on wavefronts 2, 3 (SIMDs of their own: wavefronts 0, 1
-//       share theirs with the recursion and stay idle): N' = this block's candidates with block b - 1 left out of the
-//       product, its Gram matrix, the cross products with block b - 1's candidates, their Gram matrix and the old norms
-//       -> accumulator (integer atomics that retire before the recursion ends);
-//   tail (all four workers): apply block b - 1, a = N' - (Dnew C) / diag.
-// No Gram record at the end of the launch, no atomics in flight when it ends.
-__device__ __forceinline__ void untri_fast(int e, int &row, int &col) {   // (exhaustively checked for e < 136)
-    const float d = __builtin_sqrtf((float)(1089 - 8 * e));
-    row = (int)((33.0f - d) * 0.5f + 1e-3f);
-    col = row + (e - (row * 16 - row * (row - 1) / 2));
-}
-struct SinkAheadFast {
-    double *Xs, *Mp, *Base, *D2;
-    __device__ __forceinline__ void packed(int q, int &i, int &j) const {
-        if (q < kTri) {
-            untri_fast(q, i, j);
-        } else if (q < kTri + 256) {
-            i = (q - kTri) >> 4; j = 16 + ((q - kTri) & 15);
-        } else {
-            untri_fast(q - kTri - 256, i, j);
-            i += 16; j += 16;
-        }
-    }
-    __device__ __forceinline__ void operator()(int e, double v) const {
-        int i, j;
-        if (e < kAheadMp) Xs[(e >> 5) * kTS + (e & 31)] = v;
-        else if (e < kAheadG0) {
-            packed(e - kAheadMp, i, j);
-            Mp[i * kTS + j] = v;
-            Mp[j * kTS + i] = v;
-        } else if (e < kAheadG0 + 2 * kTri + 256) {
-            packed(e - kAheadG0, i, j);
-            Base[j * 64 + 32 + i] = v;
-            Base[i * 64 + 32 + j] = v;
-        } else D2[e - kAheadG0 - 2 * kTri - 256] = v;
-    }
-};
-// N pairs of the look-ahead accumulator in one round trip; the top bins (units 2^10) only when a contribution has set the
-// accumulator's second flag word (values below 2^9 never touch them)
-template <int N, typename Sink>
-__device__ __forceinline__ bool acc_load_ahead(const long long *acc, const int (&e2)[N], const bool (&valid)[N], Sink sink) {
-    typedef long long l2v __attribute__((ext_vector_type(2)));
-    constexpr int E = kAheadEntries;
-    l2v b[N][2];
-#pragma unroll
-    for (int q = 0; q < N; ++q) {
-        const l2v *base = reinterpret_cast<const l2v *>(acc) + (valid[q] ? e2[q] : 0);
-        b[q][0] = base[0]; b[q][1] = base[E / 2];
-    }
-    const long long bad = acc[kAccBins * E], top = acc[kAccBins * E + 1];
-    __builtin_amdgcn_sched_barrier(0);
-    if (__builtin_expect(top != 0, 0)) {
-#pragma unroll
-        for (int q = 0; q < N; ++q) {
-            const l2v b2 = (reinterpret_cast<const l2v *>(acc) + (valid[q] ? e2[q] : 0))[E];
-            if (valid[q]) {
-                sink(2 * e2[q], ((double)b2.x * 0x1p10 + (double)b[q][1].x * 0x1p-30) + (double)b[q][0].x * 0x1p-70);
-                sink(2 * e2[q] + 1, ((double)b2.y * 0x1p10 + (double)b[q][1].y * 0x1p-30) + (double)b[q][0].y * 0x1p-70);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < N; ++q)
-            if (valid[q]) {
-                sink(2 * e2[q], (double)b[q][1].x * 0x1p-30 + (double)b[q][0].x * 0x1p-70);
-                sink(2 * e2[q] + 1, (double)b[q][1].y * 0x1p-30 + (double)b[q][0].y * 0x1p-70);
-            }
-    }
-    return bad != 0;
-}
-__device__ __forceinline__ void acc_add_ahead(long long *acc, int idx, double v, bool norm_entry = false) {
-    constexpr int E = kAheadEntries;
-    if (!(fabs(v) < 0x1p50) || (norm_entry && v != 0.0 && fabs(v) < 0x1p-40)) {
-        atomicOr(reinterpret_cast<unsigned long long *>(acc) + kAccBins * E, 1ull);
-        return;
-    }
-    const double m2 = 0x1.8p62, m1 = 0x1.8p22, m0 = 0x1.8p-18;          // (acc_add)
-    const double x2 = v + m2;
-    const long long b2 = __double_as_longlong(x2) - __double_as_longlong(m2);
-    const double r1 = v - (x2 - m2);
-    const double x1 = r1 + m1;
-    const long long b1 = __double_as_longlong(x1) - __double_as_longlong(m1);
-    const double r0 = r1 - (x1 - m1);
-    const double x0 = r0 + m0;
-    const long long b0 = __double_as_longlong(x0) - __double_as_longlong(m0);
-    unsigned long long *a = reinterpret_cast<unsigned long long *>(acc);
-    if (b2) {
-        atomicAdd(a + 2 * E + idx, (unsigned long long)b2);
-        atomicOr(a + kAccBins * E + 1, 1ull);
-    }
-    if (b1) atomicAdd(a + 1 * E + idx, (unsigned long long)b1);
-    if (b0) atomicAdd(a + idx, (unsigned long long)b0);
-}
-// arrival at / wait for an LDS counter (the shadow workers' rendezvous: the wavefronts of the recursion run on)
-__device__ __forceinline__ void lds_arrive(int *cnt, int lane) {
-    asm volatile("" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_wait(int *cnt, int target) {
-    typedef __attribute__((address_space(3))) volatile int lds_vint;
-    while (__builtin_amdgcn_readfirstlane(*(lds_vint *)cnt) < target) __builtin_amdgcn_s_sleep(1);
-    asm volatile("" ::: "memory");
-}
-
-template <int RT, int GPW>
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void bcd_ahead_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
-    constexpr int RB = 32 * RT;
-    constexpr int EPT = RB / 8;                      // epilogue elements per thread (256 threads)
-    constexpr int EP2 = RB / 4;                      // ... of the shadow epilogue (128 threads)
-    constexpr int DLS = kNB + 4;                     // row stride of the Dnew tile (16-byte aligned rows)
-    typedef float f16v __attribute__((ext_vector_type(16)));
-    typedef double d4v __attribute__((ext_vector_type(4)));
-    typedef double d2v __attribute__((ext_vector_type(2)));
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int k = p.k;
-    double *Ms = reinterpret_cast<double *>(smem_raw);                        // [NB][64] Base rows
-    double *D2s = Ms + kNB * 64;                                               // [NB]
-    double *Cs = D2s + kNB;                                                    // [NB][NB] recursion coefficients
-    double *CAs = Cs + kNB * kNB;                                              // [NB][kCaStride] S of block b - 2, then of b - 1
-    double *scr = CAs + kNB * kCaStride;                                       // [8][NB] the chain wave's scratch
-    float *red = reinterpret_cast<float *>(scr + 8 * kNB);                     // [4][RB][NB + 1]
-    float *As = red + 4 * RB * (kNB + 1);                                      // [RB][NB + 1] N'
-    float *Dl = As + RB * (kNB + 1) + ((4 - (RB * (kNB + 1)) % 4) % 4);        // [RB][DLS] Dnew of the previous block; before: the old norms' partial sums
-    float *Ap = Dl + RB * DLS;                                                 // [RB][kApStride] a-tile of the previous block
-    // the matrices of gram_ahead lie over the float tiles, which nobody touches before barrier 1
-    constexpr int FLOATS = 4 * RB * (kNB + 1) + RB * (kNB + 1) + ((4 - (RB * (kNB + 1)) % 4) % 4) + RB * DLS + RB * kApStride;
-    constexpr int REGION = (FLOATS * 4 < 4 * kNB * kTS * 8) ? 4 * kNB * kTS * 8 : FLOATS * 4;   // bytes
-    static_assert(REGION % 16 == 0, "aligned pieces");
-    int *flag = reinterpret_cast<int *>(reinterpret_cast<char *>(red) + REGION);
-    double *CsT = reinterpret_cast<double *>(flag + 4);                        // [NB][NB] Cs transposed (resolve_helper)
-    double *Qt = reinterpret_cast<double *>(red), *Mp = Qt + kNB * kTS, *Xs = Mp + kNB * kTS, *Ps = Xs + kNB * kTS;
-    ResolveMail mail;
-    mail.Pm = CsT + kNB * kNB;
-    mail.Zm = mail.Pm + kMbox * 64;
-    mail.pcount = flag + 1;
-    mail.zcount = flag + 2;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if ((int)blockIdx.x >= rider.nslab) {
-        bcd_rider_tile(rider, smem_raw);
-        return;
-    }
-    const int wu = __builtin_amdgcn_readfirstlane(wid);           // (wave-uniform for the compiler too)
-    const bool shadow = wu == 2 || wu == 3;          // the workers with a SIMD of their own; wave 4: the chain of the recursion, wave 5: its helper
-    const bool has_prev = p.nb_prev > 0, fin = p.nb == 0;
-    if (tid == 0) { *mail.pcount = 0; *mail.zcount = 0; flag[0] = 0; flag[3] = 0; }
-    const int64_t f0 = (int64_t)blockIdx.x * RB;
-    const int nwg = rider.nslab;
-#ifdef MODL_DIAG
-    unsigned long long *st = (p.stamps && blockIdx.x == 0 && !fin) ? p.stamps : nullptr;
-#else
-    unsigned long long *const st = nullptr;
-#endif
-    if (st && tid == 0) st[0] = clock64();
-
-    // ---------------------------------------------------------------- operands of the workers (requested: see below)
-    const int col = tid % kNB, rg = (tid / kNB) % 8;             // tail epilogue: column, row group (256 threads)
-    const int rg2 = (tid / kNB) % 4;                             // shadow epilogue: row group (waves 2, 3)
-    const bool col_ok = col < p.nb;
-    float cdg = 1.f, eB[EP2], eD[EP2];
-    int fz = 0;
-    const int h = lane >> 5;
-    constexpr int NA = RB * (kNB / 4) / 256;
-    int ocr[RT], subr[RT][4];
-    float bq[4] = {0.f, 0.f, 0.f, 0.f};
-    f16v acc[RT];
-    constexpr int PW0 = (GPW == 8) ? (RT == 1 ? 2 : 1) : 0;      // first wave that takes part in the product
-    constexpr int GW = (GPW == 8) ? (RT == 1 ? 16 : 11) : GPW;   // contraction groups (8 atoms) per product wave
-    const bool pwave = __builtin_amdgcn_readfirstlane(wid) >= PW0;
-    constexpr int NBATCH = (RT == 3) ? 3 : 1;
-    constexpr int GB = (GW + NBATCH - 1) / NBATCH;
-    float bfr[GB][4];
-    float4 av[GB][RT];
-    float4 va[NA];
-    // (requests and their masks apart: a mask next to its load makes the wavefront wait for the round trip on the spot, and
-    //  the shadow workers request theirs in front of the head, whose barriers they must reach at once)
-    auto request = [&]() {
-        if (!fin) {
-            cdg = p.cdiag[p.j0 + (col_ok ? col : 0)];
-            fz = p.frozen[p.j0 + (col_ok ? col : 0)];
-            if (shadow) {
-#pragma unroll
-                for (int q = 0; q < EP2; ++q) {
-                    const int64_t f = f0 + rg2 + 4 * q;
-                    const bool ok = col_ok && f < p.s;
-                    const int64_t el = ok ? f * k + p.j0 + col : 0;
-                    eB[q] = p.Bt[el];
-                    eD[q] = p.Dt[ok ? dfrag(f, p.j0 + col, k) : 0];
-                }
-            }
-            const bool cok = (lane & 31) < p.nb;
-            const float *cp0 = p.CP + dfrag(p.j0, 0, k);
-            const unsigned lane_off = cok ? (unsigned)(lane & 31) : 0u;
-            if (pwave)
-#pragma unroll
-            for (int g = 0; g < GB; ++g) {
-                const int kb = ((wid - PW0) * GW + g) * 8 + 4 * h;
-                const float4 b4 = *reinterpret_cast<const float4 *>(cp0 + dfrag(lane_off, kb < k ? kb : 0, k));
-                bfr[g][0] = b4.x; bfr[g][1] = b4.y; bfr[g][2] = b4.z; bfr[g][3] = b4.w;
-            }
-            if (has_prev) {   // correction with the new atoms of the previous block: wave w contracts its atoms 8w .. 8w+7
-                const int jb = wid * 8 + 4 * h;
-                const float4 q4 = *reinterpret_cast<const float4 *>(cp0 + dfrag(lane_off, jb < p.nb_prev ? p.j0_prev + jb : 0, k));
-                bq[0] = q4.x; bq[1] = q4.y; bq[2] = q4.z; bq[3] = q4.w;
-            }
-            if (pwave)
-#pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                int64_t f = f0 + t * 32 + (lane & 31);
-                if (f >= p.s) f = p.s - 1;
-                const float *rowp = p.Dt + dfrag(f, 0, k);
-#pragma unroll
-                for (int g = 0; g < GB; ++g) {
-                    const int kb = ((wid - PW0) * GW + g) * 8 + 4 * h;
-                    const bool ok = kb + 3 < k;
-                    av[g][t] = *reinterpret_cast<const float4 *>(rowp + (ok ? kb : 0) * 32);
-                }
-            }
-        }
-        if (has_prev) {
-#pragma unroll
-            for (int u = 0; u < RT; ++u) {
-                const int t = wid * RT + u, ft = t >> 1, jt = t & 1;
-                const int cj = jt * 16 + (lane & 15);
-                const int32_t *sub_src = p.subset ? p.subset : p.order;
-                ocr[u] = p.order[p.j0_prev + ((cj < p.nb_prev) ? cj : 0)];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t f = f0 + ft * 16 + (lane >> 4) + 4 * r;
-                    const bool live = f < p.s && cj < p.nb_prev;
-                    subr[u][r] = sub_src[(p.subset && live) ? f : 0];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < NA; ++q) {
-                const int e = tid + 256 * q;
-                const int r = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
-                const int64_t fr = (f0 + r < p.s) ? f0 + r : p.s - 1;
-                va[q] = *reinterpret_cast<const float4 *>(p.a + fr * kNB + c4);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto request_masks = [&]() {
-        if (!fin) {
-            cdg = col_ok ? cdg : 1.f;
-            fz = col_ok ? fz : 0;
-            if (shadow) {
-#pragma unroll
-                for (int q = 0; q < EP2; ++q) {
-                    const bool ok = col_ok && f0 + rg2 + 4 * q < p.s;
-                    eB[q] = ok ? eB[q] : 0.f;
-                    eD[q] = ok ? eD[q] : 0.f;
-                }
-            }
-            if (has_prev) {
-                const bool cok = (lane & 31) < p.nb;
-                const int jb = wid * 8 + 4 * h;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) bq[u] = (cok && jb + u < p.nb_prev) ? bq[u] : 0.f;
-            }
-        }
-    };
-    // ---------------------------------------------------------------- head: Gram matrix of the previous block
-    // (thread hid of 256 over wavefronts 0, 1, 4, 5; tile: this wavefront's tile of the products of gram_ahead)
-    int res_jj = 0;
-    double res_budget = 0.0;
-    auto head = [&](int hid, int tile) {
-        const SinkAheadFast asink{Xs, Mp, Ms, D2s};
-        if (st && tid == 0) st[16] = clock64();
-        d2v cf[2], qv[2], sv[2];
-        const bool pp = p.has_pp != 0;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e = 2 * (hid + 256 * q);
-            const bool ok = p.j0_prev + e / kNB < k;
-            cf[q] = *reinterpret_cast<const d2v *>(p.coef_all + (ok ? (int64_t)p.j0_prev * kNB + e : 0));
-            qv[q] = *reinterpret_cast<const d2v *>(p.qcoef + ((pp && ok) ? (int64_t)p.j0_prev * kNB + e : 0));
-            sv[q] = *reinterpret_cast<const d2v *>(p.save_in + (pp ? e : 0));
-        }
-        int x_raw = 0;
-        float budget_raw = 0.f;
-        if (wu == 4) {                               // the chain wave's own inputs
-            const int x = lane & 31;
-            x_raw = p.order[p.j0_prev + ((x < p.nb_prev) ? x : 0)];
-            budget_raw = p.norm_in[(x < p.nb_prev) ? p.j0_prev + x : 0];
-        }
-        const int e2[5] = {hid, hid + 256, hid + 512, hid + 768, 1024 + (hid & 31)};
-        const bool valid[5] = {true, true, true, true, hid < 32};
-        const bool use_rec = acc_load_ahead<5>(p.acc_in, e2, valid, asink);     // (out of range: the records)
-        if (use_rec) {
-#pragma unroll
-            for (int q = 0; q < 5; ++q) reduce_records_v2<kAheadEntries>(p.rec_in, nwg, e2[q], valid[q], asink);
-        }
-        if (wu == 4) {
-            const int x = lane & 31;
-            res_jj = (x < p.nb_prev) ? x_raw : 0;
-            res_budget = (x < p.nb_prev) ? (double)budget_raw : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e = 2 * (hid + 256 * q), row = e / kNB, c0 = e % kNB;
-            const bool ok = p.j0_prev + row < k;
-            Cs[e] = ok ? cf[q].x : 0.0;
-            Cs[e + 1] = ok ? cf[q].y : 0.0;
-            CsT[c0 * kNB + row] = ok ? cf[q].x : 0.0;
-            CsT[(c0 + 1) * kNB + row] = ok ? cf[q].y : 0.0;
-            if (pp) {
-                Qt[row * kTS + c0] = ok ? qv[q].x : 0.0;           // (rows of Qt: atoms of the previous block)
-                Qt[row * kTS + c0 + 1] = ok ? qv[q].y : 0.0;
-                CAs[row * kCaStride + c0] = sv[q].x;
-                CAs[row * kCaStride + c0 + 1] = sv[q].y;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {                // the identity half of the Base rows
-            const int e = hid + 256 * q, m = e >> 5, xx = e & 31;
-            Ms[m * 64 + xx] = (m == xx) ? 1.0 : 0.0;
-        }
-        if (st && tid == 0) st[17] = clock64();
-        if (pp) {                                    // (uniform) the pieces -> the Gram matrix of the previous block
-            lds_barrier();
-            gram_ahead(Qt, CAs, Mp, Xs, Ps, Ms, tile, lane);
-        }
-    };
-    // Three roles, three paths (nothing of one role's registers is live across another's code: a common path made the
-    // register allocator carry the shadow workers' operands through the head and the recursion - 436 spilled registers).
-    if (wu >= 4) {
-        if (has_prev) head(tid - 128, wu - 2);
-        lds_barrier();                               // ---- barrier 1 (LDS only)
-        __builtin_amdgcn_s_setprio(3);
-        if (wu == 4) {
-            if (has_prev)
-                resolve_chain<float>(D2s, Cs, res_jj, res_budget, p.nb_prev, blockIdx.x == 0 ? p.norm_out : nullptr, scr, mail, st);
-            if (st && lane == 0) st[2] = clock64();
-        } else if (has_prev) {
-            resolve_helper(Ms, CsT, CAs, kCaStride, mail);
-            if (st && lane == 0) st[14] = clock64();
-        }
-        lds_barrier();                                                                // ---- barrier 2
-        if (fin || !has_prev) return;
-        if (blockIdx.x == 0)                         // S of this block for the next launch's gram_ahead
-            for (int e = (wid - 4) * 64 + lane; e < kNB * kNB; e += 128) p.save_out[e] = CAs[(e / kNB) * kCaStride + e % kNB];
-        lds_barrier();                                                                // ---- barrier 3
-        lds_barrier();                                                                // ---- barrier 4
-        return;
-    }
-    if (shadow) {
-        request();                                   // ~100 requests, in flight through the head
-        if (st && tid == 128) st[21] = clock64();
-        if (has_prev && p.has_pp) { lds_barrier(); lds_barrier(); lds_barrier(); }    // (the barriers of gram_ahead)
-        lds_barrier();                               // ---- barrier 1 (LDS only: the requests stay in flight)
-    } else {
-        if (has_prev) head(tid, wu);
-        lds_barrier();                               // ---- barrier 1
-        if (st && tid == 0) st[1] = clock64();
-        request();
-        if (p.acc_zero && blockIdx.x == 0)           // the accumulator the NEXT launch adds to (idle during this one)
-            for (int e = tid; e < kAheadWords; e += 128) p.acc_zero[e] = 0;
-    }
-    request_masks();
-    if (!fin) {
-        // ------------------------------------------------------------ main product (the previous block left out)
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        constexpr bool kFourAcc = (RT == 1);
-        f16v accx[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accx[q][r] = 0.f;
-        if (pwave)
-#pragma unroll
-        for (int bt = 0; bt < NBATCH; ++bt) {
-#pragma unroll
-        for (int g = 0; g < GB; ++g) {
-            if (bt * GB + g >= GW) continue;
-            const int kb = ((wid - PW0) * GW + bt * GB + g) * 8 + 4 * h;
-            const bool cok = (lane & 31) < p.nb && !(has_prev && (kb >> 5) == (p.j0_prev >> 5));
-#pragma unroll
-            for (int u = 0; u < 4; ++u) bfr[g][u] = (cok && kb + u < k) ? bfr[g][u] : 0.f;
-#pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                if (!(kb + 3 < k)) av[g][t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kFourAcc) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].x, bfr[g][0], acc[t], 0, 0, 0);
-                    accx[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].y, bfr[g][1], accx[0], 0, 0, 0);
-                    accx[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].z, bfr[g][2], accx[1], 0, 0, 0);
-                    accx[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].w, bfr[g][3], accx[2], 0, 0, 0);
-                } else {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].x, bfr[g][0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].y, bfr[g][1], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].z, bfr[g][2], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][t].w, bfr[g][3], acc[t], 0, 0, 0);
-                }
-            }
-        }
-        if constexpr (NBATCH > 1) {
-            if (bt + 1 < NBATCH) {
-                __builtin_amdgcn_sched_barrier(0);
-                const bool cok = (lane & 31) < p.nb;
-                const float *cp0 = p.CP + dfrag(p.j0, 0, k);
-                const unsigned lane_off = cok ? (unsigned)(lane & 31) : 0u;
-#pragma unroll
-                for (int g = 0; g < GB; ++g) {
-                    if ((bt + 1) * GB + g >= GW) continue;
-                    const int kb = ((wid - PW0) * GW + (bt + 1) * GB + g) * 8 + 4 * h;
-                    const float4 b4 = *reinterpret_cast<const float4 *>(cp0 + dfrag(lane_off, kb < k ? kb : 0, k));
-                    bfr[g][0] = b4.x; bfr[g][1] = b4.y; bfr[g][2] = b4.z; bfr[g][3] = b4.w;
-#pragma unroll
-                    for (int t = 0; t < RT; ++t) {
-                        int64_t f = f0 + t * 32 + (lane & 31);
-                        if (f >= p.s) f = p.s - 1;
-                        av[g][t] = *reinterpret_cast<const float4 *>(p.Dt + dfrag(f, 0, k) + (kb + 3 < k ? kb : 0) * 32);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        }
-        if (kFourAcc && pwave) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] = (acc[0][r] + accx[0][r]) + (accx[1][r] + accx[2][r]);
-        }
-        if (st && tid == 128) st[22] = clock64();
-        if (pwave) {                                 // partial products -> LDS
-#pragma unroll
-            for (int t = 0; t < RT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, c = lane & 31;
-                    red[(wid * RB + row) * (kNB + 1) + c] = acc[t][r];
-                }
-        }
-    }
-    if (has_prev) {                                  // a-tile of the previous block -> LDS
-#pragma unroll
-        for (int q = 0; q < NA; ++q) {
-            const int e = tid + 256 * q;
-            const int r = e / (kNB / 4), c4 = (e % (kNB / 4)) * 4;
-            float4 v = va[q];                        // columns >= nb_prev were never written
-            const bool rok = f0 + r < p.s;           // (rows beyond the sampled set: clamped copies of the last one)
-            v.x = (rok && c4 + 0 < p.nb_prev) ? v.x : 0.f;
-            v.y = (rok && c4 + 1 < p.nb_prev) ? v.y : 0.f;
-            v.z = (rok && c4 + 2 < p.nb_prev) ? v.z : 0.f;
-            v.w = (rok && c4 + 3 < p.nb_prev) ? v.w : 0.f;
-            *reinterpret_cast<float4 *>(Ap + r * kApStride + c4) = v;
-        }
-    }
-    if (!fin) {
-        lds_arrive(flag + 3, lane);                  // partial products and a-tile rows of this wave are in LDS
-        if (shadow) {
-            // ---- in the recursion's shadow (wavefronts 2, 3): N', its Gram matrix, the cross products with the previous
-            // block's candidates, their Gram matrix and the old norms -> accumulator
-            double *d2w = reinterpret_cast<double *>(Dl);     // (the Dnew tile's place is free until barrier 2)
-            static_assert(RB * DLS * 4 >= 4 * kNB * 8, "the partial sums fit");
-            lds_wait(flag + 3, 4);
-            {
-                double d2 = 0;
-#pragma unroll
-                for (int q = 0; q < EP2; ++q) {
-                    const int row = rg2 + 4 * q;
-                    const int64_t f = f0 + row;
-                    float val = 0.f;
-                    if (f < p.s && col_ok) {
-                        float v = red[(PW0 * RB + row) * (kNB + 1) + col];
-#pragma unroll
-                        for (int w = PW0 + 1; w < 4; ++w) v += red[(w * RB + row) * (kNB + 1) + col];
-                        val = fz ? eD[q] : (eB[q] - v) / cdg;
-                        if (!has_prev) p.a[f * kNB + col] = val;       // (the first block: nothing to correct)
-                        d2 += (double)eD[q] * (double)eD[q];
-                    }
-                    As[row * (kNB + 1) + col] = val;
-                }
-                d2w[rg2 * kNB + col] = d2;
-            }
-            lds_arrive(flag, lane);
-            lds_wait(flag, 2);
-            if (st && tid == 128) st[23] = clock64();
-            {
-                double *out = p.rec_out + (int64_t)blockIdx.x * kAheadEntries;
-                // one 16 x 16 tile of A^T B over this workgroup's features (A, B: LDS tiles [RB][lda / ldb] of floats)
-                auto tile = [&](const float *A, int lda, int ta, const float *B, int ldb, int tb) {
-                    d4v g = {0.0, 0.0, 0.0, 0.0};
-                    const float *ai = A + (lane >> 4) * lda + ta * 16 + (lane & 15);
-                    const float *bj = B + (lane >> 4) * ldb + tb * 16 + (lane & 15);
-#pragma unroll
-                    for (int kk = 0; kk < RB / 4; ++kk)
-                        g = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ai[4 * kk * lda], (double)bj[4 * kk * ldb], g, 0, 0, 0);
-                    return g;
-                };
-                auto add_packed = [&](const d4v &g, int base, int it, int jt, bool norms) {   // tile (it, jt), it <= jt, of a symmetric matrix
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = (lane >> 4) + 4 * r, c = lane & 15;
-                        if (it != jt) {
-                            acc_add_ahead(p.acc_out, base + kTri + row * 16 + c, g[r]);
-                            out[base + kTri + row * 16 + c] = g[r];
-                        } else if (row <= c) {
-                            acc_add_ahead(p.acc_out, base + (it ? kTri + 256 : 0) + tri_index(row, c), g[r], norms && row == c);
-                            out[base + (it ? kTri + 256 : 0) + tri_index(row, c)] = g[r];
-                        }
-                    }
-                };
-                auto add_full = [&](const d4v &g, int it, int jt) {                          // tile (it, jt) of X
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = it * 16 + (lane >> 4) + 4 * r, c = jt * 16 + (lane & 15);
-                        acc_add_ahead(p.acc_out, m * kNB + c, g[r]);
-                        out[m * kNB + c] = g[r];
-                    }
-                };
-                if (wid == 2) {
-                    add_packed(tile(As, kNB + 1, 0, As, kNB + 1, 0), kAheadG0, 0, 0, true);
-                    add_packed(tile(As, kNB + 1, 0, As, kNB + 1, 1), kAheadG0, 0, 1, true);
-                    if (has_prev) {
-                        add_full(tile(Ap, kApStride, 0, As, kNB + 1, 0), 0, 0);
-                        add_full(tile(Ap, kApStride, 0, As, kNB + 1, 1), 0, 1);
-                        add_packed(tile(Ap, kApStride, 0, Ap, kApStride, 0), kAheadMp, 0, 0, false);
-                    }
-                    if (lane < kNB) {
-                        const double t = (d2w[lane] + d2w[kNB + lane]) + (d2w[2 * kNB + lane] + d2w[3 * kNB + lane]);
-                        acc_add_ahead(p.acc_out, kAheadG0 + 2 * kTri + 256 + lane, t, true);
-                        out[kAheadG0 + 2 * kTri + 256 + lane] = t;
-                    }
-                } else {
-                    add_packed(tile(As, kNB + 1, 1, As, kNB + 1, 1), kAheadG0, 1, 1, true);
-                    if (has_prev) {
-                        add_full(tile(Ap, kApStride, 1, As, kNB + 1, 0), 1, 0);
-                        add_full(tile(Ap, kApStride, 1, As, kNB + 1, 1), 1, 1);
-                        add_packed(tile(Ap, kApStride, 0, Ap, kApStride, 1), kAheadMp, 0, 1, false);
-                        add_packed(tile(Ap, kApStride, 1, Ap, kApStride, 1), kAheadMp, 1, 1, false);
-                    }
-                }
-            }
-            if (st && tid == 128) st[12] = clock64();
-        }
-    }
-    if (st && tid == 0) st[3] = clock64();
-    lds_barrier();                                                                    // ---- barrier 2
-    if (st && tid == 0) st[4] = clock64();
-    // ---------------------------------------------------------------- apply the previous block
-    if (has_prev) {
-#pragma unroll
-        for (int u = 0; u < RT; ++u) {
-            const int t = wid * RT + u, ft = t >> 1, jt = t & 1;
-            d4v dn = {0.0, 0.0, 0.0, 0.0};
-            const float *ap = Ap + (ft * 16 + (lane & 15)) * kApStride + (lane >> 4);
-            const double *sp = CAs + (jt * 16 + (lane & 15)) * kCaStride + (lane >> 4);
-#pragma unroll
-            for (int kk = 0; kk < kNB / 4; ++kk)
-                dn = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ap[4 * kk], sp[4 * kk], dn, 0, 0, 0);
-            const int cj = jt * 16 + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int frow = ft * 16 + (lane >> 4) + 4 * r;
-                const int64_t f = f0 + frow;
-                const bool live = f < p.s && cj < p.nb_prev;
-                const float dnew = (float)dn[r];
-                if (live) {
-                    p.Dt[dfrag(f, p.j0_prev + cj, k)] = dnew;
-                    p.Dt_out[(p.subset ? (int64_t)subr[u][r] : f) * p.kout + ocr[u]] = dnew;
-                }
-                Dl[frow * DLS + cj] = live ? dnew : 0.f;
-            }
-        }
-    }
-    if (fin || !has_prev) return;
-    lds_barrier();                                                                    // ---- barrier 3
-    if (st && tid == 0) st[5] = clock64();
-    // ---------------------------------------------------------------- correction with the new atoms, cross-wave sum
-    {
-        const int jb = wid * 8 + 4 * h;
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-            const float4 dv = *reinterpret_cast<const float4 *>(Dl + (t * 32 + (lane & 31)) * DLS + jb);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv.x, bq[0], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv.y, bq[1], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv.z, bq[2], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv.w, bq[3], acc[t], 0, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, c = lane & 31;
-                red[(wid * RB + row) * (kNB + 1) + c] = acc[t][r];
-            }
-    }
-    lds_barrier();                                                                    // ---- barrier 4
-    if (st && tid == 0) st[6] = clock64();
-    // ---------------------------------------------------------------- a = N' - (Dnew C) / diag
-#pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int row = rg + 8 * q;
-        const int64_t f = f0 + row;
-        if (f < p.s && col_ok) {
-            const float v = ((red[(0 * RB + row) * (kNB + 1) + col] + red[(1 * RB + row) * (kNB + 1) + col]) +
-                             red[(2 * RB + row) * (kNB + 1) + col]) + red[(3 * RB + row) * (kNB + 1) + col];
-            const float np = As[row * (kNB + 1) + col];
-            p.a[f * kNB + col] = fz ? np : np - v / cdg;
-        }
-    }
-    if (st && tid == 0) st[7] = clock64();
-}
-
-static size_t bcd_block_lds(int gpw, int RT, bool la) {
+static size_t bcd_block_lds(int gpw, int RT) {
     const int kpad = gpw * 32, RB = 32 * RT;
     const size_t dbl = (size_t)kNB * 64 + kNB + kNB * kNB + (size_t)kNB * kCaStride + 8 * kNB;
-    size_t fl = 4 * (size_t)RB * (kNB + 1) + RB * (kNB + 1) + 4 + RB * (kNB + 4) + 4;
-    if (la) {                                                   // + the a-tile's own place; at least the matrices of gram_ahead
-        fl += (size_t)RB * kApStride;
-        if (fl * 4 < (size_t)4 * kNB * kTS * 8) fl = (size_t)kNB * kTS * 8;
-    }
+    const size_t fl = 4 * (size_t)RB * (kNB + 1) + RB * (kNB + 1) + 4 + RB * (kNB + 4) + 4;
     const size_t mail = (size_t)kNB * kNB + 2 * kMbox * 64;     // Cs transposed + the two mailboxes of the recursion
     (void)kpad;
     return dbl * 8 + fl * 4 + 16 + mail * 8 + 16;
@@ -3030,30 +2342,25 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                 return 256;
             }();
             if (RT == 2 && cdiv(s, 64) > ncu_blk && cdiv(s, 96) <= ncu_blk) RT = 3;
+#ifdef MODL_RT3_MIN
+            if (RT == 2 && s >= MODL_RT3_MIN) RT = 3;              // (A/B builds, scripts/build_variant.sh)
+#endif
         }
         const int nslab = fused ? (int)cdiv(s, 32 * RT) : (int)cdiv(s, kGramRows);
         const int GPW = (kp <= 256) ? 8 : 16;
         void (*blk)(BcdBlockArgs, BcdRiderArgs) = nullptr;
         T *DsP = reinterpret_cast<T *>(ws + L.off_Dnew), *BsP = reinterpret_cast<T *>(ws + L.off_BsP), *CPP = CP;
         // the Gram accumulators of the fused path (three in rotation; in the space of the group sums, which they replace)
-        const int acc_mode = g_bcd_acc.load(std::memory_order_relaxed);
-        long long *fused_acc = (fused && acc_mode) ? reinterpret_cast<long long *>(ws + L.off_gpartial) : nullptr;
-        const bool ahead = fused && acc_mode == 2;        // look-ahead mode (gram_ahead)
-        static_assert(sizeof(long long) * 3 * kAheadWords <= sizeof(double) * 2 * (size_t)kCounters * (kNB * kNB + kNB), "accumulators fit");
-        const int acc_words = ahead ? kAheadWords : kAccWords;
-        double *qcoef = reinterpret_cast<double *>(ws + L.off_qcoef), *save = reinterpret_cast<double *>(ws + L.off_save);
+        long long *fused_acc = (fused && g_bcd_acc.load(std::memory_order_relaxed)) ? reinterpret_cast<long long *>(ws + L.off_gpartial) : nullptr;
+        static_assert(sizeof(long long) * 3 * kAccWords <= sizeof(double) * 2 * (size_t)kCounters * (kNB * kNB + kNB), "accumulators fit");
         if (fused) {
-            if (ahead)
-                blk = (RT == 1) ? (GPW == 8 ? bcd_ahead_kernel<1, 8> : bcd_ahead_kernel<1, 16>)
-                                : (RT == 2 ? bcd_ahead_kernel<2, 8> : bcd_ahead_kernel<3, 8>);
-            else
             blk = (RT == 1) ? (GPW == 8 ? bcd_block_kernel<1, 8> : bcd_block_kernel<1, 16>)
                             : (RT == 2 ? bcd_block_kernel<2, 8> : bcd_block_kernel<3, 8>);
             MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(blk), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024));
             hipLaunchKernelGGL((bcd_setup_kernel<T>), dim3((unsigned)(kNB + kp + s)), dim3(256), 0, stream, a.C, a.order, k, kp, CPP,
                                cdiag, frozen, coef_all, counter, a.comp_norm, reinterpret_cast<T *>(ws + L.off_norm_in), a.Dt,
-                               a.Bt, a.subset, s, DsP, BsP, fused_acc, acc_words, ahead ? qcoef : nullptr);
+                               a.Bt, a.subset, s, DsP, BsP, fused_acc);
             MODL_LAUNCH_CHECK();
             ++nl;
         } else {
@@ -3073,7 +2380,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                 return MODL_OK;
             }
         }
-        const size_t rec_half = (size_t)L.nslab_max * kAheadEntries, grec_half = (size_t)kCounters * kResStride;   // >= the packed sizes
+        const size_t rec_half = (size_t)L.nslab_max * kResStride, grec_half = (size_t)kCounters * kResStride;   // >= the packed sizes
         double *gpart = reinterpret_cast<double *>(ws + L.off_gpartial);
         BcdBlockArgs base;
         base.acc_out = nullptr; base.acc_in = nullptr; base.acc_zero = nullptr;
@@ -3089,7 +2396,6 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             // round of record loads it saves (measured at 32 workgroups: 17.7 -> 15.9 us per launch); beyond, groups
             base.group = nslab <= kCounters ? nslab : ((nslab + 31) / 32 > kGroup ? (nslab + 31) / 32 : kGroup);
             base.Dt_out = reinterpret_cast<float *>(a.Dt); base.subset = a.subset;
-            base.qcoef = qcoef; base.save_in = save; base.save_out = save; base.has_pp = 0;
         }
         // deferred statistics product riding along (launches 1 .. nblk carry cdiv(tiles, nblk) tiles each)
         BcdRiderArgs rid;
@@ -3134,7 +2440,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         }
         // a launch that carries k-wide tiles needs their LDS (one workgroup per compute unit then)
         auto lds_bytes = [&](int extra) {
-            size_t n = bcd_block_lds(GPW, RT, ahead);
+            size_t n = bcd_block_lds(GPW, RT);
             if (extra > 0 && rid.wide) n = std::max(n, wide_lds_bytes<32, 128>());
             return n;
         };
@@ -3155,13 +2461,11 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                 ba.grec_out = gpart + (size_t)(blk_i & 1) * grec_half; ba.grec_in = gpart + (size_t)((blk_i + 1) & 1) * grec_half;
                 ba.j0 = j0; ba.nb = nb; ba.j0_prev = j0_prev; ba.nb_prev = blk_i ? nb_prev : 0;
                 if (fused_acc) {
-                    ba.acc_out = fused_acc + (size_t)(blk_i % 3) * acc_words;
-                    ba.acc_in = fused_acc + (size_t)((blk_i + 2) % 3) * acc_words;
-                    ba.acc_zero = fused_acc + (size_t)((blk_i + 1) % 3) * acc_words;
+                    ba.acc_out = fused_acc + (size_t)(blk_i % 3) * kAccWords;
+                    ba.acc_in = fused_acc + (size_t)((blk_i + 2) % 3) * kAccWords;
+                    ba.acc_zero = fused_acc + (size_t)((blk_i + 1) % 3) * kAccWords;
                     ba.group = nslab;                                   // (no pre-summed groups: one accumulator)
                 }
-                ba.save_out = save + (size_t)(blk_i & 1) * kNB * kNB; ba.save_in = save + (size_t)((blk_i + 1) & 1) * kNB * kNB;
-                ba.has_pp = blk_i >= 2;
                 BcdRiderArgs r = rid;
                 const int extra = blk_i ? ride(r) : 0;                 // (launch 0 is short: no resolver)
                 hipLaunchKernelGGL(blk, dim3(nslab + extra), dim3(384), lds_bytes(extra), stream, ba, r);
@@ -3198,11 +2502,9 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             ba.j0 = 0; ba.nb = 0; ba.j0_prev = j0_prev; ba.nb_prev = nb_prev;
             if (fused_acc) {
                 ba.acc_out = nullptr; ba.acc_zero = nullptr;
-                ba.acc_in = fused_acc + (size_t)((blk_i + 2) % 3) * acc_words;     // (blk_i: the blocks launched so far)
+                ba.acc_in = fused_acc + (size_t)((blk_i + 2) % 3) * kAccWords;     // (blk_i: the blocks launched so far)
                 ba.group = nslab;
             }
-            ba.save_out = save + (size_t)(blk_i & 1) * kNB * kNB; ba.save_in = save + (size_t)((blk_i + 1) & 1) * kNB * kNB;
-            ba.has_pp = blk_i >= 2;
             BcdRiderArgs r = rid;
             ride_per = ride_tiles - ride_next;                         // whatever is left
             int extra = ride(r);

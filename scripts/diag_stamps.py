@@ -27,6 +27,8 @@ for r in (10, 1):
             ('G Gram record', o[12] - o[7])]
     for n, v in rows:
         print('   %-56s %8d' % (n, v))
+    print('   G detail (cycles after barrier 5): wave 0 tile formed %d, its entries added %d; wave 1 done %d, wave 2 %d, wave 3 %d' % (
+        o[30] - o[7], o[12] - o[7], o[33] - o[7], o[35] - o[7], o[34] - o[7]))
     print('   helper wave done %d, product wave 1 loads requested %d, done %d, wave 2 done %d, wave 3 done %d (after barrier 1)' % (o[14] - o[1], o[20] - o[1], o[15] - o[1], o[18] - o[1], o[19] - o[1]))
     print('   first steps (cycles after barrier 1):', [int(o[24 + u] - o[1]) for u in range(8)])
     print('   product wave 2: operands requested %d, product issued %d (after barrier 1)' % (o[21] - o[1], o[22] - o[1]))
