@@ -45,6 +45,9 @@ namespace modl {
 #ifndef MODL_RT1_MAX
 #define MODL_RT1_MAX 2048
 #endif
+#ifndef MODL_ACC_SHARD_MIN
+#define MODL_ACC_SHARD_MIN 64      // workgroups of the block step above which the Gram accumulator is sharded (acc_load_sharded)
+#endif
 constexpr int kNB = 32;            // atoms per block of the blocked path
 // diagnostics (modl_debug_set(MODL_DEBUG_BCD_ACC, 0)): the per-workgroup Gram records instead of the atomic accumulator
 std::atomic<int> g_bcd_acc{1};
@@ -54,6 +57,7 @@ std::atomic<unsigned long long *> g_atom_stamps{nullptr};
 // diagnostics (modl_debug_set(MODL_DEBUG_BCD_TINY, 0)): the separate launches of the blocked update also for small sampled sets
 std::atomic<int> g_bcd_tiny{1};
 constexpr int kAccWords = 3 * (2 * 136 + 256 + kNB) + 2;   // int64 words of one Gram accumulator (3 bins x packed record + the out-of-range word: kAccStride below)
+constexpr int kAccShards = 4;      // accumulators side by side for large grids (acc_load_sharded)
 constexpr int kGramRows = 128;     // feature rows per Gram slab
 #ifndef MODL_KGROUP
 #define MODL_KGROUP 16
@@ -172,9 +176,12 @@ __global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_
     int id = (int)blockIdx.x;
     if (id < kNB) {
         const int m = id;
+        if (acc) {                                    // the accumulators, a slice per workgroup of this group
+            constexpr int W = 3 * kAccShards * kAccWords, SL = (W + kNB - 1) / kNB;
+            for (int e = m * SL + threadIdx.x; e < (m + 1) * SL && e < W; e += 256) acc[e] = 0;
+        }
         if (m == 0) {
             if (threadIdx.x < kCounters) counter[threadIdx.x] = 0;
-            if (acc) for (int e = threadIdx.x; e < 3 * kAccWords; e += 256) acc[e] = 0;
             for (int j = threadIdx.x; j < kp; j += 256) {
                 const bool real = j < k;
                 const int oj = real ? order[j] : 0;
@@ -484,6 +491,30 @@ __device__ __forceinline__ bool acc_load(const long long *acc, int e2, bool vali
     const l2v b0 = base[0], b1 = base[kPackStride / 2], b2 = base[kPackStride];   // (three 16-byte loads, one round trip)
     const long long bad = acc[kAccStride];                                         // (the same trip)
     if (valid) {
+        sink(2 * e2, ((double)b2.x * 0x1p10 + (double)b1.x * 0x1p-30) + (double)b0.x * 0x1p-70);
+        sink(2 * e2 + 1, ((double)b2.y * 0x1p10 + (double)b1.y * 0x1p-30) + (double)b0.y * 0x1p-70);
+    }
+    return bad != 0;
+}
+// The same over kAccShards accumulators (large grids: workgroup b adds to accumulator b % kAccShards - the atomics on one
+// address are served one after the other, ~25 ns each, and a launch cannot end before the last one: 157 workgroups on one
+// accumulator cost 4 us at the end of every launch, scripts/micro/atomic_drain.hip).  The bins are integers: their sums do
+// not depend on the order, the result is the same as with one accumulator.  One round trip.
+template <typename Sink>
+__device__ __forceinline__ bool acc_load_sharded(const long long *acc, int e2, bool valid, Sink sink) {
+    typedef long long l2v __attribute__((ext_vector_type(2)));
+    l2v b[kAccShards][3];
+    long long bad = 0;
+#pragma unroll
+    for (int z = 0; z < kAccShards; ++z) {
+        const l2v *base = reinterpret_cast<const l2v *>(acc + (size_t)z * kAccWords) + (valid ? e2 : 0);
+        b[z][0] = base[0]; b[z][1] = base[kPackStride / 2]; b[z][2] = base[kPackStride];
+        bad |= acc[(size_t)z * kAccWords + kAccStride];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (valid) {
+        const l2v b0 = (b[0][0] + b[1][0]) + (b[2][0] + b[3][0]), b1 = (b[0][1] + b[1][1]) + (b[2][1] + b[3][1]),
+                  b2 = (b[0][2] + b[1][2]) + (b[2][2] + b[3][2]);
         sink(2 * e2, ((double)b2.x * 0x1p10 + (double)b1.x * 0x1p-30) + (double)b0.x * 0x1p-70);
         sink(2 * e2 + 1, ((double)b2.y * 0x1p10 + (double)b1.y * 0x1p-30) + (double)b0.y * 0x1p-70);
     }
@@ -1051,6 +1082,7 @@ struct BcdBlockArgs {
     int64_t s;
     int k, j0, nb, j0_prev, nb_prev, group;   // k: atoms of the PACKED arrays (a multiple of 4, dead atoms behind the real ones)
     int kout;                                 // row stride of Dt_out: the real number of atoms
+    int shards;                               // 1, or kAccShards accumulators side by side (acc_load_sharded)
 };
 
 // Riding along (see StatsRider in kernels.hpp): the workgroups behind the first `nslab` ones each take one 32 x 32
@@ -1148,7 +1180,8 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
                 const bool ok = p.j0_prev + e / kNB < k;
                 cf[q] = *reinterpret_cast<const d2v *>(p.coef_all + (ok ? (int64_t)p.j0_prev * kNB + e : 0));   // (zeroed below)
             }
-            const bool use_rec = !p.acc_in || acc_load(p.acc_in, tid, true, rsink);   // (out of range: the records)
+            const bool use_rec = !p.acc_in || (p.shards > 1 ? acc_load_sharded(p.acc_in, tid, true, rsink)
+                                                           : acc_load(p.acc_in, tid, true, rsink));   // (out of range: the records)
             if (use_rec) reduce_records_v2<kPackStride>(recs, nrec, tid, true, rsink);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -1167,7 +1200,8 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
             const int res_jj_raw = p.order[p.j0_prev + ((x < p.nb_prev) ? x : 0)];   // (unconditional, clamped: no wait behind the load)
             res_jj = (x < p.nb_prev) ? res_jj_raw : 0;
             const float budget_raw = p.norm_in[(x < p.nb_prev) ? p.j0_prev + x : 0];
-            const bool use_rec = !p.acc_in || acc_load(p.acc_in, 256 + lane, 256 + lane < kPackStride / 2, rsink);
+            const bool use_rec = !p.acc_in || (p.shards > 1 ? acc_load_sharded(p.acc_in, 256 + lane, 256 + lane < kPackStride / 2, rsink)
+                                                           : acc_load(p.acc_in, 256 + lane, 256 + lane < kPackStride / 2, rsink));
             if (use_rec) reduce_records_v2<kPackStride>(recs, nrec, 256 + lane, 256 + lane < kPackStride / 2, rsink);
             res_budget = (x < p.nb_prev) ? (double)budget_raw : 0.0;
         } else {
@@ -1354,8 +1388,8 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
         // the accumulator the NEXT launch adds to (idle during this one): cleared by a wavefront that has a SIMD to itself
         // and nothing to do until its operands arrive (at the head of the launch it sat in front of workgroup 0's record
         // loads; on wavefront 0 or 1 it takes issue slots from the recursion: 13.6 k cycles instead of 12.9 k)
-        if (p.acc_zero && blockIdx.x == 0 && wid == 3)
-            for (int e = lane; e < kAccWords; e += 64) p.acc_zero[e] = 0;
+        if (p.acc_zero && (int)blockIdx.x < p.shards && wid == 3)
+            for (int e = lane; e < kAccWords; e += 64) p.acc_zero[(size_t)blockIdx.x * kAccWords + e] = 0;
         if (st && tid == 0) st[13] = clock64();
         if (st && tid == 64) st[20] = clock64();
         if (st && tid == 128) st[21] = clock64();            // product wave 2: operands requested
@@ -1543,6 +1577,7 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
         const float *ai = As + (lane >> 4) * (kNB + 1) + it * 16 + (lane & 15);
         const float *aj = As + (lane >> 4) * (kNB + 1) + jt * 16 + (lane & 15);
         double *out = p.rec_out + (int64_t)blockIdx.x * kPackStride;
+        long long *acc_out = p.acc_out ? p.acc_out + (size_t)((int)blockIdx.x & (p.shards - 1)) * kAccWords : nullptr;   // (1 or kAccShards = 4)
         float fa[RB / 4], fb[RB / 4];
 #pragma unroll
         for (int kk = 0; kk < RB / 4; ++kk) {
@@ -1568,11 +1603,11 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
                 const int r = (wid == 2) ? 2 + rr : rr;
                 const int e = kTri + ((lane >> 4) + 4 * r) * 16 + c15;
                 const double v = (wid == 2) ? (rr ? g[3] : g[2]) : (rr ? g[1] : g[0]);
-                if (p.acc_out) acc_add(p.acc_out, e, v, false, bad);
+                if (acc_out) acc_add(acc_out, e, v, false, bad);
                 out[e] = v;
             }
             if (wid == 2 && lane < kNB) {                            // + the old squared norms
-                if (p.acc_out) acc_add(p.acc_out, 2 * kTri + 256 + lane, t, true, bad);
+                if (acc_out) acc_add(acc_out, 2 * kTri + 256 + lane, t, true, bad);
                 out[2 * kTri + 256 + lane] = t;
             }
         } else {                                                     // diagonal tiles: triangle
@@ -1581,12 +1616,12 @@ void bcd_block_kernel(BcdBlockArgs p, BcdRiderArgs rider) {
                 const int row = (lane >> 4) + 4 * r;
                 if (row <= c15) {
                     const int e = (it ? kTri + 256 : 0) + tri_index(row, c15);
-                    if (p.acc_out) acc_add(p.acc_out, e, g[r], row == c15, bad);
+                    if (acc_out) acc_add(acc_out, e, g[r], row == c15, bad);
                     out[e] = g[r];
                 }
             }
         }
-        if (p.acc_out) acc_flag(p.acc_out, bad);
+        if (acc_out) acc_flag(acc_out, bad);
     }
     if (st && tid == 0) st[12] = clock64();
     if (st && tid == 64) st[33] = clock64();
@@ -2342,9 +2377,6 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                 return 256;
             }();
             if (RT == 2 && cdiv(s, 64) > ncu_blk && cdiv(s, 96) <= ncu_blk) RT = 3;
-#ifdef MODL_RT3_MIN
-            if (RT == 2 && s >= MODL_RT3_MIN) RT = 3;              // (A/B builds, scripts/build_variant.sh)
-#endif
         }
         const int nslab = fused ? (int)cdiv(s, 32 * RT) : (int)cdiv(s, kGramRows);
         const int GPW = (kp <= 256) ? 8 : 16;
@@ -2352,7 +2384,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         T *DsP = reinterpret_cast<T *>(ws + L.off_Dnew), *BsP = reinterpret_cast<T *>(ws + L.off_BsP), *CPP = CP;
         // the Gram accumulators of the fused path (three in rotation; in the space of the group sums, which they replace)
         long long *fused_acc = (fused && g_bcd_acc.load(std::memory_order_relaxed)) ? reinterpret_cast<long long *>(ws + L.off_gpartial) : nullptr;
-        static_assert(sizeof(long long) * 3 * kAccWords <= sizeof(double) * 2 * (size_t)kCounters * (kNB * kNB + kNB), "accumulators fit");
+        static_assert(sizeof(long long) * 3 * kAccShards * kAccWords <= sizeof(double) * 2 * (size_t)kCounters * (kNB * kNB + kNB), "accumulators fit");
         if (fused) {
             blk = (RT == 1) ? (GPW == 8 ? bcd_block_kernel<1, 8> : bcd_block_kernel<1, 16>)
                             : (RT == 2 ? bcd_block_kernel<2, 8> : bcd_block_kernel<3, 8>);
@@ -2383,7 +2415,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         const size_t rec_half = (size_t)L.nslab_max * kResStride, grec_half = (size_t)kCounters * kResStride;   // >= the packed sizes
         double *gpart = reinterpret_cast<double *>(ws + L.off_gpartial);
         BcdBlockArgs base;
-        base.acc_out = nullptr; base.acc_in = nullptr; base.acc_zero = nullptr;
+        base.acc_out = nullptr; base.acc_in = nullptr; base.acc_zero = nullptr; base.shards = 1;
         if (fused) {
             base.Dt = reinterpret_cast<float *>(DsP); base.Bt = reinterpret_cast<const float *>(BsP);
             base.CP = reinterpret_cast<const float *>(CPP); base.cdiag = reinterpret_cast<const float *>(cdiag);
@@ -2396,6 +2428,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             // round of record loads it saves (measured at 32 workgroups: 17.7 -> 15.9 us per launch); beyond, groups
             base.group = nslab <= kCounters ? nslab : ((nslab + 31) / 32 > kGroup ? (nslab + 31) / 32 : kGroup);
             base.Dt_out = reinterpret_cast<float *>(a.Dt); base.subset = a.subset;
+            base.shards = nslab > MODL_ACC_SHARD_MIN ? kAccShards : 1;       // (one accumulator: 30 workgroups at the metric's shape)
         }
         // deferred statistics product riding along (launches 1 .. nblk carry cdiv(tiles, nblk) tiles each)
         BcdRiderArgs rid;
@@ -2461,9 +2494,9 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                 ba.grec_out = gpart + (size_t)(blk_i & 1) * grec_half; ba.grec_in = gpart + (size_t)((blk_i + 1) & 1) * grec_half;
                 ba.j0 = j0; ba.nb = nb; ba.j0_prev = j0_prev; ba.nb_prev = blk_i ? nb_prev : 0;
                 if (fused_acc) {
-                    ba.acc_out = fused_acc + (size_t)(blk_i % 3) * kAccWords;
-                    ba.acc_in = fused_acc + (size_t)((blk_i + 2) % 3) * kAccWords;
-                    ba.acc_zero = fused_acc + (size_t)((blk_i + 1) % 3) * kAccWords;
+                    ba.acc_out = fused_acc + (size_t)(blk_i % 3) * kAccShards * kAccWords;
+                    ba.acc_in = fused_acc + (size_t)((blk_i + 2) % 3) * kAccShards * kAccWords;
+                    ba.acc_zero = fused_acc + (size_t)((blk_i + 1) % 3) * kAccShards * kAccWords;
                     ba.group = nslab;                                   // (no pre-summed groups: one accumulator)
                 }
                 BcdRiderArgs r = rid;
@@ -2502,7 +2535,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             ba.j0 = 0; ba.nb = 0; ba.j0_prev = j0_prev; ba.nb_prev = nb_prev;
             if (fused_acc) {
                 ba.acc_out = nullptr; ba.acc_zero = nullptr;
-                ba.acc_in = fused_acc + (size_t)((blk_i + 2) % 3) * kAccWords;     // (blk_i: the blocks launched so far)
+                ba.acc_in = fused_acc + (size_t)((blk_i + 2) % 3) * kAccShards * kAccWords;     // (blk_i: the blocks launched so far)
                 ba.group = nslab;
             }
             BcdRiderArgs r = rid;
