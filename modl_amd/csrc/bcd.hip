@@ -57,7 +57,7 @@ std::atomic<unsigned long long *> g_atom_stamps{nullptr};
 // diagnostics (modl_debug_set(MODL_DEBUG_BCD_TINY, 0)): the separate launches of the blocked update also for small sampled sets
 std::atomic<int> g_bcd_tiny{1};
 constexpr int kAccWords = 3 * (2 * 136 + 256 + kNB) + 2;   // int64 words of one Gram accumulator (3 bins x packed record + the out-of-range word: kAccStride below)
-constexpr int kAccShards = 4;      // accumulators side by side for large grids (acc_load_sharded)
+constexpr int kAccShards = 4;      // accumulators side by side for large grids (acc_load_sharded; a power of two)
 constexpr int kGramRows = 128;     // feature rows per Gram slab
 #ifndef MODL_KGROUP
 #define MODL_KGROUP 16
@@ -513,8 +513,9 @@ __device__ __forceinline__ bool acc_load_sharded(const long long *acc, int e2, b
     }
     __builtin_amdgcn_sched_barrier(0);
     if (valid) {
-        const l2v b0 = (b[0][0] + b[1][0]) + (b[2][0] + b[3][0]), b1 = (b[0][1] + b[1][1]) + (b[2][1] + b[3][1]),
-                  b2 = (b[0][2] + b[1][2]) + (b[2][2] + b[3][2]);
+        l2v b0 = b[0][0], b1 = b[0][1], b2 = b[0][2];
+#pragma unroll
+        for (int z = 1; z < kAccShards; ++z) { b0 += b[z][0]; b1 += b[z][1]; b2 += b[z][2]; }
         sink(2 * e2, ((double)b2.x * 0x1p10 + (double)b1.x * 0x1p-30) + (double)b0.x * 0x1p-70);
         sink(2 * e2 + 1, ((double)b2.y * 0x1p10 + (double)b1.y * 0x1p-30) + (double)b0.y * 0x1p-70);
     }

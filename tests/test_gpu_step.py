@@ -321,26 +321,29 @@ def test_full_size_step_properties(DictFact):
     assert_array_equal(runs[0][1], runs[1][1])
 
 
-@pytest.mark.parametrize('scale', [1e13, 1e-9])
-def test_gram_accumulator_out_of_range_falls_back_to_records(DictFact, scale):
-    """The blocked dictionary update sums its 32 x 32 Gram contributions in fixed point (csrc/bcd.hip: acc_add, range
+@pytest.mark.parametrize('p,red', [(1000, 2), (6000, 1)])       # 16 workgroups on one accumulator; 94 on four (acc_load_sharded)
+@pytest.mark.parametrize('scale', [1e13, 1e-9, 1.0])
+def test_gram_accumulator_out_of_range_falls_back_to_records(DictFact, scale, p, red):
+    """(scale 1: the accumulator itself against the records, in range.)
+    The blocked dictionary update sums its 32 x 32 Gram contributions in fixed point (csrc/bcd.hip: acc_add, range
     |entry| < 2^50 in dictionary units, absolute resolution 2^-71).  Candidate atoms of norm ~1e12 - statistics scaled by
     hand, nothing a fit produces - must not come back as a wrapped integer sum, and candidate atoms of norm ~1e-10 (squared
     norms under 2^-40) must not lose their relative precision to the absolute bins: in both cases the block is summed
     from the per-workgroup records, the same result as with the accumulator switched off."""
     from modl_amd._lib import lib, check, DEBUG_BCD_ACC
     rs = np.random.RandomState(0)
-    X = ((rs.randn(256, 32) * (rs.rand(256, 32) < 0.3)).dot(rs.randn(32, 1000)) / np.sqrt(0.3 * 32)
-         + 0.1 * rs.randn(256, 1000)).astype(np.float32)
+    X = ((rs.randn(256, 32) * (rs.rand(256, 32) < 0.3)).dot(rs.randn(32, p)) / np.sqrt(0.3 * 32)
+         + 0.1 * rs.randn(256, p)).astype(np.float32)
     out = {}
     try:
         for acc in (1, 0):
             check(lib.modl_debug_set(DEBUG_BCD_ACC, acc))
-            est = DictFact(n_components=64, batch_size=64, reduction=2, code_alpha=0.1, learning_rate=0.92, random_state=0)
+            est = DictFact(n_components=64, batch_size=64, reduction=red, code_alpha=0.1, learning_rate=0.92, random_state=0)
             est.prepare(n_samples=256, X=X[:64])
             est.partial_fit(X[:64])
             assert np.count_nonzero(np.diag(est.C_) > 1e-6) > 32
-            est.B_ = est.B_ * np.float32(scale)
+            if scale != 1.0:
+                est.B_ = est.B_ * np.float32(scale)
             if scale < 1:                                  # tiny candidates: tiny norm budgets too, else they are kept whole
                 est.components_ = est.components_ * np.float32(scale)
                 est.comp_norm_ = est.comp_norm_ * np.float32(scale ** 2)
