@@ -57,6 +57,7 @@ std::atomic<unsigned long long *> g_atom_stamps{nullptr};
 // diagnostics (modl_debug_set(MODL_DEBUG_BCD_TINY, 0)): the separate launches of the blocked update also for small sampled sets
 std::atomic<int> g_bcd_tiny{1};
 constexpr int kAccWords = 3 * (2 * 136 + 256 + kNB) + 2;   // int64 words of one Gram accumulator (3 bins x packed record + the out-of-range word: kAccStride below)
+constexpr int kSetupRows = 8;      // rows per workgroup of bcd_setup_kernel's gathers
 constexpr int kAccShards = 4;      // accumulators side by side for large grids (acc_load_sharded; a power of two)
 constexpr int kGramRows = 128;     // feature rows per Gram slab
 #ifndef MODL_KGROUP
@@ -162,9 +163,9 @@ __global__ __launch_bounds__(256) void bcd_prepare_kernel(const T *C, const int3
 }
 
 // Fused path: everything the block launches need, in ONE launch.  Blocks [0, NB): recursion coefficients
-// (block 0 also: arrival counters, snapshot of the norm budgets, diagonal and frozen flags); blocks
-// [NB, NB + k): C in sweep coordinates, CPP[m'][jj] = C[o_m'][o_jj] with the block-lower-triangular mask;
-// blocks [NB + k, NB + k + s): the sampled rows gathered in sweep order, DsP[f][jj] = Dt[subset[f]][order[jj]]
+// (block 0 also: arrival counters, snapshot of the norm budgets, diagonal and frozen flags; all: a slice of the Gram
+// accumulators to clear); then groups of kSetupRows rows per block: C in sweep coordinates, CPP[m'][jj] = C[o_m'][o_jj]
+// with the block-lower-triangular mask; then the sampled rows gathered in sweep order, DsP[f][jj] = Dt[subset[f]][order[jj]]
 // and BsP likewise — every later access of the block kernels is a plain contiguous row.
 template <typename T>
 __global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_t *order, int k, int kp, T *CPP, T *cdiag,
@@ -203,24 +204,53 @@ __global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_
         }
         return;
     }
+    // kSetupRows rows per workgroup (one row each: k + s workgroups of one element per thread, a launch that lasted as long as
+    // its grid took to start - 5.7 us at the metric's shape, 13.6 at reduction 1); a row's loads are all requested before
+    // the first store, and the gathered column index serves the rows of the group
     id -= kNB;
-    if (id < kp) {
-        const int mp = id, om = mp < k ? order[mp] : 0;
+    const int ncp = (kp + kSetupRows - 1) / kSetupRows;
+    if (id < ncp) {
+        int om[kSetupRows];
+#pragma unroll
+        for (int r = 0; r < kSetupRows; ++r) {
+            const int mp = id * kSetupRows + r;
+            om[r] = mp < k ? order[mp] : 0;
+        }
         for (int jj = threadIdx.x; jj < kp; jj += 256) {
-            T v = (mp < k && jj < k) ? C[(int64_t)om * k + order[jj]] : (T)0;
-            if (mp / kNB == jj / kNB && mp <= jj) v = 0;
-            CPP[dfrag(jj, mp, kp)] = v;                  // fragment order: (target position, 4 consecutive source atoms)
+            const int oj = jj < k ? order[jj] : 0;
+            T v[kSetupRows];
+#pragma unroll
+            for (int r = 0; r < kSetupRows; ++r) v[r] = C[(int64_t)om[r] * k + oj];
+#pragma unroll
+            for (int r = 0; r < kSetupRows; ++r) {
+                const int mp = id * kSetupRows + r;
+                if (mp >= kp) break;
+                T x = (mp < k && jj < k) ? v[r] : (T)0;
+                if (mp / kNB == jj / kNB && mp <= jj) x = 0;
+                CPP[dfrag(jj, mp, kp)] = x;              // fragment order: (target position, 4 consecutive source atoms)
+            }
         }
         return;
     }
-    id -= kp;
-    if (id < s) {
-        const int64_t f = id, src = sub_row(subset, f) * k;
+    id -= ncp;
+    const int64_t fb = (int64_t)id * kSetupRows;
+    if (fb < s) {
+        int64_t src[kSetupRows];
+#pragma unroll
+        for (int r = 0; r < kSetupRows; ++r) src[r] = sub_row(subset, fb + r < s ? fb + r : s - 1) * k;
         for (int jj = threadIdx.x; jj < kp; jj += 256) {
             const bool real = jj < k;
             const int o = real ? order[jj] : 0;
-            DsP[dfrag(f, jj, kp)] = real ? Dt[src + o] : (T)0;
-            BsP[f * kp + jj] = real ? Bt[src + o] : (T)0;
+            T dv[kSetupRows], bv[kSetupRows];
+#pragma unroll
+            for (int r = 0; r < kSetupRows; ++r) { dv[r] = Dt[src[r] + o]; bv[r] = Bt[src[r] + o]; }
+#pragma unroll
+            for (int r = 0; r < kSetupRows; ++r) {
+                const int64_t f = fb + r;
+                if (f >= s) break;
+                DsP[dfrag(f, jj, kp)] = real ? dv[r] : (T)0;
+                BsP[f * kp + jj] = real ? bv[r] : (T)0;
+            }
         }
     }
 }
@@ -2391,7 +2421,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                             : (RT == 2 ? bcd_block_kernel<2, 8> : bcd_block_kernel<3, 8>);
             MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(blk), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024));
-            hipLaunchKernelGGL((bcd_setup_kernel<T>), dim3((unsigned)(kNB + kp + s)), dim3(256), 0, stream, a.C, a.order, k, kp, CPP,
+            hipLaunchKernelGGL((bcd_setup_kernel<T>), dim3((unsigned)(kNB + cdiv(kp, kSetupRows) + cdiv(s, kSetupRows))), dim3(256), 0, stream, a.C, a.order, k, kp, CPP,
                                cdiag, frozen, coef_all, counter, a.comp_norm, reinterpret_cast<T *>(ws + L.off_norm_in), a.Dt,
                                a.Bt, a.subset, s, DsP, BsP, fused_acc);
             MODL_LAUNCH_CHECK();

@@ -90,12 +90,13 @@ template <typename T> struct EpiStatsRows {
 // dictionary rows Ds = Dt[subset], the sampled minibatch columns Xs = X[:, subset], the minibatch's code rows.
 template <typename T> struct PrepArgs {
     const T *X; int64_t ldx, p; int b; T *xnorm; int n_norm;                 // n_norm = b or 0
-    const T *Dt; const int32_t *subset; int64_t s; int k; T *Ds; int n_rows;  // n_rows = s or 0
+    const T *Dt; const int32_t *subset; int64_t s; int k; T *Ds; int n_rows;  // n_rows = cdiv(s, kPrepRows) workgroups or 0
     int64_t s_pad; T *Xs; int gx; int n_cols;                                 // n_cols = gx * b or 0
-    const T *code; const int64_t *idx; T *codeb; int n_code;                  // n_code = b or 0
+    const T *code; const int64_t *idx; T *codeb; int n_code;                  // n_code = cdiv(b, kPrepRows) workgroups or 0
     int32_t *stamp, *pos; int32_t step;                                       // stamp[subset[i]] = step, pos[subset[i]] = i
     int fuse_cols;        // the row-norm workgroups also gather the sampled columns of their row (n_cols == 0 then)
 };
+constexpr int kPrepRows = 8;      // rows per workgroup of prep_kernel's row gathers
 template <typename T>
 __global__ __launch_bounds__(256) void prep_kernel(PrepArgs<T> a) {
     __shared__ double red[4];
@@ -170,11 +171,24 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs<T> a) {
         return;
     }
     id -= a.n_norm;
-    if (id < a.n_rows) {
-        if (a.stamp && threadIdx.x == 0) { a.stamp[a.subset[id]] = a.step; a.pos[a.subset[id]] = id; }
-        const T *src = a.Dt + (int64_t)a.subset[id] * a.k;
-        T *dst = a.Ds + (int64_t)id * a.k;
-        for (int c = threadIdx.x; c < a.k; c += 256) dst[c] = src[c];
+    if (id < a.n_rows) {                                 // kPrepRows sampled rows per workgroup, their loads requested together
+        // (a row each: s workgroups of one element per thread - the launch lasted as long as its 1500 workgroups took to start)
+        const int64_t r0 = (int64_t)id * kPrepRows;
+        int64_t sub[kPrepRows];
+#pragma unroll
+        for (int r = 0; r < kPrepRows; ++r) sub[r] = a.subset[r0 + r < a.s ? r0 + r : a.s - 1];
+        if (a.stamp && threadIdx.x < kPrepRows && r0 + threadIdx.x < a.s) {
+            const int32_t f = a.subset[r0 + threadIdx.x];
+            a.stamp[f] = a.step; a.pos[f] = (int32_t)(r0 + threadIdx.x);
+        }
+        for (int c = threadIdx.x; c < a.k; c += 256) {
+            T v[kPrepRows];
+#pragma unroll
+            for (int r = 0; r < kPrepRows; ++r) v[r] = a.Dt[sub[r] * a.k + c];
+#pragma unroll
+            for (int r = 0; r < kPrepRows; ++r)
+                if (r0 + r < a.s) a.Ds[(r0 + r) * a.k + c] = v[r];
+        }
         return;
     }
     id -= a.n_rows;
@@ -189,10 +203,19 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs<T> a) {
         return;
     }
     id -= a.n_cols;
-    if (id < a.n_code) {
-        const T *src = a.code + a.idx[id] * a.k;
-        T *dst = a.codeb + (int64_t)id * a.k;
-        for (int c = threadIdx.x; c < a.k; c += 256) dst[c] = src[c];
+    if (id < a.n_code) {                                 // kPrepRows code rows per workgroup
+        const int r0 = id * kPrepRows;
+        int64_t src[kPrepRows];
+#pragma unroll
+        for (int r = 0; r < kPrepRows; ++r) src[r] = a.idx[r0 + r < a.b ? r0 + r : a.b - 1] * a.k;
+        for (int c = threadIdx.x; c < a.k; c += 256) {
+            T v[kPrepRows];
+#pragma unroll
+            for (int r = 0; r < kPrepRows; ++r) v[r] = a.code[src[r] + c];
+#pragma unroll
+            for (int r = 0; r < kPrepRows; ++r)
+                if (r0 + r < a.b) a.codeb[(int64_t)(r0 + r) * a.k + c] = v[r];
+        }
     }
 }
 
@@ -632,7 +655,7 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         const bool need_sub = d_subset && (d.Dx_agg != MODL_AGG_FULL || d.G_agg != MODL_AGG_FULL);
         PrepArgs<T> pa;
         pa.X = X; pa.ldx = bt->ldx; pa.p = p; pa.b = b; pa.xnorm = xnorm; pa.n_norm = (d.code_l1_ratio != 0.0) ? b : 0;
-        pa.Dt = Dt; pa.subset = d_subset; pa.s = s; pa.k = k; pa.Ds = Dsb; pa.n_rows = need_sub ? (int)s : 0;
+        pa.Dt = Dt; pa.subset = d_subset; pa.s = s; pa.k = k; pa.Ds = Dsb; pa.n_rows = need_sub ? (int)cdiv(s, kPrepRows) : 0;
         pa.s_pad = s_pad; pa.Xs = Xsb; pa.gx = (int)std::min<int64_t>(cdiv(s_pad, 256), 64);
         pa.n_cols = (need_sub && d.Dx_agg != MODL_AGG_FULL) ? pa.gx * b : 0;
         // the column gather rides with the row norms when a row fits in LDS next to nothing else (<= 64 KB) and the
@@ -641,7 +664,7 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         pa.fuse_cols = (pa.n_cols > 0 && pa.n_norm == b && row_bytes <= 64 * 1024 &&
                         reinterpret_cast<uintptr_t>(X) % 16 == 0 && (bt->ldx * sizeof(T)) % 16 == 0) ? 1 : 0;
         if (pa.fuse_cols) pa.n_cols = 0;
-        pa.code = code; pa.idx = d_idx; pa.codeb = codeb; pa.n_code = (cd_on_compact && d_idx) ? b : 0;
+        pa.code = code; pa.idx = d_idx; pa.codeb = codeb; pa.n_code = (cd_on_compact && d_idx) ? (int)cdiv(b, kPrepRows) : 0;
         const bool proper = need_sub && s > 0 && s < p;               // a proper subset, gathered
         // only the sampled rows of B_ are needed by the dictionary update -> the rest of the B_ update is deferred
         // and rides along its launches; the sampled features are stamped so that the rider leaves them alone
