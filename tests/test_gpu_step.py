@@ -291,7 +291,8 @@ def test_generic_dictionary_update_f32_groups_vs_oracle(DictFact, oracle, p, k, 
     assert_within_f32_noise(est.code_[:20], st32.code[:20], st64.code[:20], 'codes')
 
 
-def test_full_size_step_properties(DictFact):
+@pytest.mark.parametrize('reduction', [10, 1])       # 32 workgroups on one Gram accumulator; 157 on four (acc_load_sharded)
+def test_full_size_step_properties(DictFact, reduction):
     """Size-independent properties at the metric's full shape (k = 256, p = 10000, b = 256, f32)."""
     import torch
     k, p, b, n = 256, 10000, 256, 1024
@@ -302,7 +303,7 @@ def test_full_size_step_properties(DictFact):
     X = X.float().contiguous()
     runs = []
     for rep in range(2):
-        est = DictFact(n_components=k, batch_size=b, reduction=10, code_alpha=1.0, learning_rate=0.92, random_state=0)
+        est = DictFact(n_components=k, batch_size=b, reduction=reduction, code_alpha=1.0, learning_rate=0.92, random_state=0)
         est.prepare(n_samples=n, X=X[:k])
         D0 = est.components_
         rec = Recorder(est)
@@ -312,6 +313,7 @@ def test_full_size_step_properties(DictFact):
         touched = np.unique(np.concatenate(rec.subsets))
         untouched = np.setdiff1d(np.arange(p), touched)
         assert_array_equal(D1[:, untouched], D0[:, untouched])            # only sampled columns move
+        assert reduction > 1 or untouched.size == 0
         assert np.any(D1[:, touched] != D0[:, touched])
         assert np.all(np.sum(D1.astype(np.float64) ** 2, axis=1) <= 1 + 1e-4)    # atoms stay in the l2 ball
         Cm = runs[-1][2]
