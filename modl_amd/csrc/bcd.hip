@@ -1729,8 +1729,22 @@ __device__ __forceinline__ void atom_project(T *u, T *ul, const double *partial_
     double old = 0, dummy = 0;
     for (int i = threadIdx.x; i < nparts; i += nthr) old += partial_old[i];
     T *w = u;
-    if (!in_regs && ul) {
-        for (int64_t f = threadIdx.x; f < s; f += nthr) ul[f] = u[f];
+    constexpr int NQ = 8;                                            // elements per thread in flight (a dependent load - store loop
+    if (!in_regs && ul) {                                            //  took one round trip per element: 40 of them at 10 000 features)
+        for (int64_t f0 = 0; f0 < s; f0 += (int64_t)NQ * nthr) {
+            T v[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int64_t f = f0 + threadIdx.x + (int64_t)q * nthr;
+                v[q] = u[f < s ? f : s - 1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int64_t f = f0 + threadIdx.x + (int64_t)q * nthr;
+                if (f < s) ul[f] = v[q];
+            }
+        }
         w = ul;
     }
     block_sum2(old, dummy, red, nthr);                               // (also orders the LDS copy)
@@ -1741,9 +1755,23 @@ __device__ __forceinline__ void atom_project(T *u, T *ul, const double *partial_
         nrm = block_enet_project_reg<T, kProjEpt>(u, Dt + j, subset, (int64_t)k, s, radius, rho, red, nthr, dbg,
                                                   level_hint ? level_hint + j : nullptr);
     } else {
-        nrm = block_enet_project<T>(w, 1, w, 1, s, radius, rho, red);
+        nrm = block_enet_project<T>(w, 1, w, 1, s, radius, rho, red, dbg);
         __syncthreads();
-        for (int64_t f = threadIdx.x; f < s; f += nthr) Dt[sub_row(subset, f) * k + j] = w[f];
+        if (dbg && threadIdx.x == 0) dbg[5] = clock64();
+        for (int64_t f0 = 0; f0 < s; f0 += (int64_t)NQ * nthr) {      // (the row indices of a batch in one round trip)
+            int64_t row[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int64_t f = f0 + threadIdx.x + (int64_t)q * nthr;
+                row[q] = sub_row(subset, f < s ? f : s - 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int64_t f = f0 + threadIdx.x + (int64_t)q * nthr;
+                if (f < s) Dt[row[q] * k + j] = w[f];
+            }
+        }
     }
     if (threadIdx.x == 0) comp_norm[j] = (T)(radius - nrm);          // :690-692
 }
@@ -1768,33 +1796,60 @@ __global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, cons
     __shared__ int flag;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const unsigned long long t0 = clock64();
-    const int e0 = lane * KPL;
+    // lane l takes elements l, l + 64, ...: a wavefront's load is 256 contiguous bytes (with KPL consecutive elements per
+    // lane the KPL loads of a row walked the same cache lines KPL times and counted on the L1 to keep them: four rows of
+    // eight wavefronts in flight evicted each other - the batched rows below were SLOWER that way, 89 k against 69 k cycles)
     T cc[KPL];
 #pragma unroll
     for (int c = 0; c < KPL; ++c) {                                     // row j == column j (unconditional, clamped loads)
-        const T cv = C[(int64_t)j * k + (e0 + c < k ? e0 + c : k - 1)];
-        cc[c] = (e0 + c < k) ? cv : (T)0;
+        const int e = lane + 64 * c;
+        const T cv = C[(int64_t)j * k + (e < k ? e : k - 1)];
+        cc[c] = (e < k) ? cv : (T)0;
     }
     const T Cjj = C[(int64_t)j * k + j];
     const bool frozen = !(Cjj > (T)1e-20);
     double old = 0;
     const int nwv = (int)(blockDim.x >> 6);
-    for (int64_t f = (int64_t)blockIdx.x * nwv + wid; f < s; f += (int64_t)gridDim.x * nwv) {
-        const int64_t r = sub_row(subset, f) * k;
-        const T *row = Dt + r;
-        // every load of the row's step is requested before the reduction (one memory round trip per row)
-        const T dj = row[j], bj = Bt[r + j];
-        double dot = 0;
+    // A wavefront's rows in batches of kStepRows: the batch's row indices in one round trip, every load of its rows in a
+    // second one, then the reductions (a row at a time - index, then row, then the next index - a wavefront had ONE 4 KB row
+    // in flight and ten dependent round trips at config 6's shape, 10 000 rows of 1024 atoms over 2048 wavefronts: 29 us of
+    // the 86 an atom costs there, 1.4 TB/s).  Same sums in the same order.
+    constexpr int kStepRows = 3;                                         // (3 x (KPL + 2) loads in flight: under the 6-bit counter at KPL = 16)
+    const int64_t fstride = (int64_t)gridDim.x * nwv;
+    for (int64_t fb = (int64_t)blockIdx.x * nwv + wid; fb < s; fb += fstride * kStepRows) {
+        int64_t r[kStepRows];
 #pragma unroll
-        for (int c = 0; c < KPL; ++c) dot += (double)row[e0 + c < k ? e0 + c : k - 1] * (double)cc[c];   // cc = 0 beyond k
-        dot = wave_sum(dot);
-        if (lane == 0) {
-            T val = dj;
-            if (!frozen) val = (T)((((double)bj - dot) + (double)Cjj * (double)dj) / (double)Cjj);
-            if (pos && val < (T)0) val = 0;            // dict_fact.py:684-685
-            u[f] = val;
-            const double a = fabs((double)dj);
-            old += a * (rho + (1.0 - rho) * a);
+        for (int q = 0; q < kStepRows; ++q) {
+            const int64_t f = fb + q * fstride;
+            r[q] = sub_row(subset, f < s ? f : fb) * k;                  // (clamped to the batch's first row: no branch around a load)
+        }
+        T rv[kStepRows][KPL], djv[kStepRows], bjv[kStepRows];
+#pragma unroll
+        for (int q = 0; q < kStepRows; ++q) {
+            const T *row = Dt + r[q];
+            djv[q] = row[j];
+            bjv[q] = Bt[r[q] + j];
+#pragma unroll
+            for (int c = 0; c < KPL; ++c) rv[q][c] = row[lane + 64 * c < k ? lane + 64 * c : k - 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < kStepRows; ++q) {
+            const int64_t f = fb + q * fstride;
+            if (f >= s) break;                                           // (wavefront-uniform)
+            double dot = 0;
+#pragma unroll
+            for (int c = 0; c < KPL; ++c) dot += (double)rv[q][c] * (double)cc[c];   // cc = 0 beyond k
+            dot = wave_sum(dot);
+            if (lane == 0) {
+                const T dj = djv[q], bj = bjv[q];
+                T val = dj;
+                if (!frozen) val = (T)((((double)bj - dot) + (double)Cjj * (double)dj) / (double)Cjj);
+                if (pos && val < (T)0) val = 0;            // dict_fact.py:684-685
+                u[f] = val;
+                const double a = fabs((double)dj);
+                old += a * (rho + (1.0 - rho) * a);
+            }
         }
     }
     old = block_sum(old, red);

@@ -31,7 +31,7 @@ __device__ __forceinline__ double block_enet_norm(const T *v, int64_t inc, int64
 // v -> out (may alias).  Returns the enet norm of the result (every thread).
 template <typename T>
 __device__ double block_enet_project(const T *v, int64_t inc_v, T *out, int64_t inc_o, int64_t n, double radius,
-                                     double l1_ratio, double *red) {
+                                     double l1_ratio, double *red, unsigned long long *dbg = nullptr) {
     if (!(radius > 0.0)) {                                   // enet.pyx:57-59 (radius == 0 -> zeros)
         for (int64_t i = threadIdx.x; i < n; i += blockDim.x) out[i * inc_o] = 0;
         return 0.0;
@@ -60,7 +60,8 @@ __device__ double block_enet_project(const T *v, int64_t inc_v, T *out, int64_t 
         return tot * l1_ratio;
     }
     double level = 0.0, prev_cnt = -1.0;
-    for (int pass = 0; pass < MODL_MAX_PASS; ++pass) {
+    int pass = 0;
+    for (; pass < MODL_MAX_PASS; ++pass) {
         double S = 0, cnt = 0;
         for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
             const double a = fabs((double)v[i * inc_v]);
@@ -79,6 +80,7 @@ __device__ double block_enet_project(const T *v, int64_t inc_v, T *out, int64_t 
             level = (S - R) / cnt;
         }
     }
+    if (dbg && threadIdx.x == 0) { dbg[4] = (unsigned long long)pass; dbg[6] = clock64(); }
     const double lT = (double)(T)level;
     const double den = 1.0 + lT * gamma;
     double nrm = 0;
