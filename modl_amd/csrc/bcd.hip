@@ -1722,7 +1722,8 @@ constexpr int kProjEpt = 24;
 template <typename T>
 __device__ __forceinline__ void atom_project(T *u, T *ul, const double *partial_old, int nparts, T *Dt,
                                              const int32_t *subset, int64_t s, int k, int j, double rho, T *comp_norm,
-                                             double *red, unsigned long long *dbg = nullptr, double *level_hint = nullptr) {
+                                             double *red, unsigned long long *dbg = nullptr, double *level_hint = nullptr,
+                                             T *stage_out = nullptr) {
     const bool in_regs = s <= (int64_t)kProjEpt * 256 && blockDim.x >= 256;
     const int nthr = in_regs ? 256 : (int)blockDim.x;
     if ((int)threadIdx.x >= nthr) return;
@@ -1755,9 +1756,19 @@ __device__ __forceinline__ void atom_project(T *u, T *ul, const double *partial_
         nrm = block_enet_project_reg<T, kProjEpt>(u, Dt + j, subset, (int64_t)k, s, radius, rho, red, nthr, dbg,
                                                   level_hint ? level_hint + j : nullptr);
     } else {
-        nrm = block_enet_project<T>(w, 1, w, 1, s, radius, rho, red, dbg);
+        if (ul && rho == 1.0)                                        // (l1 ball, vector in LDS: fused sums, warm start - same bits)
+            nrm = block_l1_project_inplace<T>(ul, s, radius, red, nthr, level_hint ? level_hint + j : nullptr, dbg);
+        else
+            nrm = block_enet_project<T>(w, 1, w, 1, s, radius, rho, red, dbg);
         __syncthreads();
         if (dbg && threadIdx.x == 0) dbg[5] = clock64();
+        if (stage_out && ul) {
+            // the projected atom leaves as a COMPACT row: the workgroups of the NEXT atom's launch put its values where they
+            // belong while they read their dictionary rows anyway (atom_step_kernel: stage_in) - written from here they are
+            // 10 000 scattered 4-byte stores by one workgroup, 42 k of the 160 k cycles an atom costs at config 6's shape
+            typedef __attribute__((address_space(3))) T lds_T;
+            for (int64_t f = threadIdx.x; f < s; f += nthr) stage_out[f] = ((lds_T *)ul)[f];
+        } else
         for (int64_t f0 = 0; f0 < s; f0 += (int64_t)NQ * nthr) {      // (the row indices of a batch in one round trip)
             int64_t row[NQ];
 #pragma unroll
@@ -1766,10 +1777,11 @@ __device__ __forceinline__ void atom_project(T *u, T *ul, const double *partial_
                 row[q] = sub_row(subset, f < s ? f : s - 1);
             }
             __builtin_amdgcn_sched_barrier(0);
+            typedef __attribute__((address_space(3))) T lds_T;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int64_t f = f0 + threadIdx.x + (int64_t)q * nthr;
-                if (f < s) Dt[row[q] * k + j] = w[f];
+                if (f < s) Dt[row[q] * k + j] = ul ? (T)((lds_T *)ul)[f] : w[f];
             }
         }
     }
@@ -1790,7 +1802,10 @@ template <typename T, int KPL>
 __global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, const T *C, const int32_t *subset, int64_t s,
                                                         int k, int j, int pos, double rho, T *u, double *partial_old,
                                                         T *comp_norm, unsigned int *counter, int u_in_lds,
-                                                        unsigned long long *dbg, double *level_hint) {
+                                                        unsigned long long *dbg, double *level_hint,
+                                                        const T *stage_in, int j_prev, T *stage_out) {
+    // stage_in / j_prev: the compact row of the atom projected by the launch before (j_prev < 0: none) - this launch writes
+    // its values into the dictionary and uses them; stage_out: where this launch's projecting workgroup leaves its atom
     extern __shared__ __attribute__((aligned(16))) char step_smem[];   // the s-vector for the projection, if it fits
     __shared__ double red[32];
     __shared__ int flag;
@@ -1823,10 +1838,12 @@ __global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, cons
             const int64_t f = fb + q * fstride;
             r[q] = sub_row(subset, f < s ? f : fb) * k;                  // (clamped to the batch's first row: no branch around a load)
         }
-        T rv[kStepRows][KPL], djv[kStepRows], bjv[kStepRows];
+        T rv[kStepRows][KPL], djv[kStepRows], bjv[kStepRows], sv[kStepRows];
 #pragma unroll
         for (int q = 0; q < kStepRows; ++q) {
             const T *row = Dt + r[q];
+            const int64_t f = fb + q * fstride;
+            sv[q] = stage_in[(j_prev >= 0 && f < s) ? f : 0];
             djv[q] = row[j];
             bjv[q] = Bt[r[q] + j];
 #pragma unroll
@@ -1837,6 +1854,11 @@ __global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, cons
         for (int q = 0; q < kStepRows; ++q) {
             const int64_t f = fb + q * fstride;
             if (f >= s) break;                                           // (wavefront-uniform)
+            if (j_prev >= 0) {                                           // the previous atom's new value: into the row, and home
+#pragma unroll
+                for (int c = 0; c < KPL; ++c) rv[q][c] = (lane + 64 * c == j_prev) ? sv[q] : rv[q][c];
+                if (lane == 0) Dt[r[q] + j_prev] = sv[q];
+            }
             double dot = 0;
 #pragma unroll
             for (int c = 0; c < KPL; ++c) dot += (double)rv[q][c] * (double)cc[c];   // cc = 0 beyond k
@@ -1858,7 +1880,7 @@ __global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, cons
     if (!arrive_last(counter, gridDim.x, &flag)) return;
     const unsigned long long t2 = clock64();
     atom_project<T>(u, u_in_lds ? reinterpret_cast<T *>(step_smem) : nullptr, partial_old, (int)gridDim.x, Dt, subset, s, k, j,
-                    rho, comp_norm, red, dbg, level_hint);
+                    rho, comp_norm, red, dbg, level_hint, stage_out);
     if (dbg && threadIdx.x == 0) { dbg[0] = t0; dbg[1] = t1; dbg[2] = t2; dbg[3] = clock64(); }
 }
 
@@ -2648,6 +2670,14 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
     return MODL_OK;
 }
 
+// the last atom of a sweep of atom_step_kernel launches with staged rows: its values into the dictionary
+template <typename T>
+__global__ __launch_bounds__(256) void atom_stage_flush_kernel(T *Dt, const int32_t *subset, int64_t s, int k, int j,
+                                                               const T *stage) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f < s) Dt[sub_row(subset, f) * k + j] = stage[f];
+}
+
 // generic path: the sweep order is needed on the host (one launch pair per atom)
 template <typename T>
 int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
@@ -2737,13 +2767,19 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
         };
         return G == 8 ? run(std::integral_constant<int, 8>{}) : run(std::integral_constant<int, 4>{});
     }
+    // beyond the register-resident projection (24 elements per thread) the projected atom travels as a compact row to the
+    // next launch (atom_project: stage_out); two rows in rotation, in the a-tile's space (unused on this path)
+    const bool staged = u_lds != 0 && s > (int64_t)kProjEpt * 256;
+    T *stage2[2] = {reinterpret_cast<T *>(ws + L.off_a), reinterpret_cast<T *>(ws + L.off_a) + s};
+    int j_prev = -1;
     for (int t = 0; t < k; ++t) {
         const int j = (int)h_order[t];
         if (j < 0 || j >= k) return MODL_EINVAL;
 #define MODL_STEP(KPL)                                                                                            \
     hipLaunchKernelGGL((atom_step_kernel<T, KPL>), dim3(nwg), dim3(256), u_lds, stream, a.Dt, a.Bt, a.C, a.subset, s, k, j, \
                        a.comp_pos, a.comp_l1_ratio, u, pold, a.comp_norm, counter, u_lds ? 1 : 0, \
-                       reinterpret_cast<unsigned long long *>(counter + kCounters), a.level_hint)
+                       reinterpret_cast<unsigned long long *>(counter + kCounters), a.level_hint,                  \
+                       (const T *)stage2[(t + 1) & 1], staged ? j_prev : -1, staged ? stage2[t & 1] : (T *)nullptr)
         if (k <= 64) MODL_STEP(1);
         else if (k <= 128) MODL_STEP(2);
         else if (k <= 256) MODL_STEP(4);
@@ -2751,6 +2787,13 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
         else MODL_STEP(16);
 #undef MODL_STEP
         MODL_LAUNCH_CHECK();
+        j_prev = j;
+    }
+    if (staged && j_prev >= 0) {
+        hipLaunchKernelGGL((atom_stage_flush_kernel<T>), dim3((unsigned)cdiv(s, 256)), dim3(256), 0, stream, a.Dt, a.subset, s, k,
+                           j_prev, (const T *)stage2[(k - 1) & 1]);
+        MODL_LAUNCH_CHECK();
+        if (launches) *launches += 1;
     }
     if (launches) *launches += k;
     return MODL_OK;

@@ -311,6 +311,106 @@ __device__ __forceinline__ double block_enet_project_vals(double (&x)[EPT], cons
     return nrm;
 }
 
+// block_enet_project for an l1 ball (l1_ratio == 1), in place on a unit-stride vector too long for the registers of
+// nthreads threads (the s-vector of an atom beyond 24 elements per thread, kept in LDS by the caller): the same level
+// equation on the same supports - hence the same sums in the same order and the same bits - with
+//   * both sums of a pass in ONE exchange (block_sum2: same association as two block_sum calls),
+//   * the cold start's first pass doubling as the inside-the-ball test (level 0: S is the vector's l1 norm),
+//   * the warm start of block_enet_project_vals (level_io: the level this atom ended with at its previous projection).
+// 9 scans of 7.4 k cycles each at 10 000 elements before (profiles/r04_atom_step_c6_stamps.txt).  red2: >= 2 * nthreads / 64.
+// w_generic MUST point into LDS: it is read and written through an LDS-typed pointer (through the generic pointer the
+// caller has - a select of the global and the LDS copy - every access was a flat load: 4.4 k cycles per scan).
+template <typename T>
+__device__ double block_l1_project_inplace(T *w_generic, int64_t n, double radius, double *red2, int nthreads, double *level_io,
+                                           unsigned long long *dbg = nullptr) {
+    typedef __attribute__((address_space(3))) T lds_T;
+    lds_T *w = (lds_T *)w_generic;
+    if (!(radius > 0.0)) {                                   // enet.pyx:57-59 (radius == 0 -> zeros)
+        for (int64_t i = threadIdx.x; i < n; i += nthreads) w[i] = 0;
+        return 0.0;
+    }
+    const double R = radius;
+    // (eight elements per thread requested before the first is used: two at a time, each iteration waited for its own LDS
+    //  round trip - 5.2 k cycles per scan of 40 elements per thread)
+    constexpr int NQ = 8;
+    auto scan = [&](double level, double &S, double &cnt) {
+        double S0 = 0;
+        int c0 = 0;
+        for (int64_t i0 = threadIdx.x; i0 < n; i0 += (int64_t)NQ * nthreads) {
+            T v[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int64_t i = i0 + (int64_t)q * nthreads;
+                v[q] = w[i < n ? i : i0];
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {                   // (in the order of the plain loop: same sums)
+                const int64_t i = i0 + (int64_t)q * nthreads;
+                const double a = (i < n) ? fabs((double)v[q]) : 0.0;
+                const bool in = a > level;                   // (level >= 0: the padding never counts)
+                S0 += in ? a : 0.0;
+                c0 += in ? 1 : 0;
+            }
+        }
+        S = S0;
+        cnt = (double)c0;
+        block_sum2(S, cnt, red2, nthreads);
+    };
+    double level = 0.0, prev_cnt = -1.0, S, cnt;
+    bool warm = false;
+    int pass = 0;
+    if (level_io) {
+        const double l0 = 0.9 * *level_io;
+        if (l0 > 0.0 && l0 < 1e300) {
+            scan(l0, S, cnt);
+            ++pass;
+            if (S - cnt * l0 >= R * (1.0 + 1e-9) && cnt != 0.0) {   // the guess lies at or below the level: Michelot continues from it
+                warm = true;
+                prev_cnt = cnt;
+                level = (S - R) / cnt;
+            }
+        }
+    }
+    if (!warm) {
+        scan(0.0, S, cnt);                                   // S = the l1 norm (zeros add nothing), cnt = the non-zeros
+        ++pass;
+        if (S <= R) return S;                                // inside the ball: nothing moves
+        if (cnt != 0.0) { prev_cnt = cnt; level = (S - R) / cnt; }
+    }
+    for (; pass < MODL_MAX_PASS && cnt != 0.0; ++pass) {
+        scan(level, S, cnt);
+        if (cnt == prev_cnt || cnt == 0.0) break;
+        prev_cnt = cnt;
+        level = (S - R) / cnt;                               // enet.pyx:119
+    }
+    if (dbg && threadIdx.x == 0) { dbg[4] = (unsigned long long)pass | (warm ? 1u << 16 : 0u); dbg[6] = clock64(); }
+    if (level_io && threadIdx.x == 0) *level_io = level;
+    const double lT = (double)(T)level;
+    double nrm = 0;
+    for (int64_t i0 = threadIdx.x; i0 < n; i0 += (int64_t)NQ * nthreads) {
+        T v[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int64_t i = i0 + (int64_t)q * nthreads;
+            v[q] = w[i < n ? i : i0];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int64_t i = i0 + (int64_t)q * nthreads;
+            const double x = (double)v[q];
+            double pos = fabs(x) - lT;
+            pos = pos > 0 ? pos : 0;
+            const T o = (T)((x >= 0) ? pos : -pos);          // enet.pyx:121, sign(0) = +1 (denominator 1 for an l1 ball)
+            if (i < n) {
+                w[i] = o;
+                nrm += fabs((double)o);
+            }
+        }
+    }
+    block_sum1(nrm, red2, nthreads);
+    return nrm;
+}
+
 template <typename T, int EPT>
 __device__ double block_enet_project_reg(const T *v, T *out, const int32_t *rows, int64_t row_stride, int64_t n,
                                          double radius, double l1_ratio, double *red2, int nthreads,

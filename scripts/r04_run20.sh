@@ -1,5 +1,4 @@
 #!/bin/bash
-# config 6 (one launch per atom): batched, coalesced loads in atom_step_kernel / atom_project
 cd /root/repo
 export TMPDIR=/tmp
 timeout 500 python scripts/diag_atom_stamps_c6.py 2>&1 | grep -v amdgpu.ids | tail -3
