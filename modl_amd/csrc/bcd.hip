@@ -1719,12 +1719,12 @@ __global__ __launch_bounds__(256) void atom_grad_kernel(const T *Dt, const T *Bt
 // retires the other threads first: see block_enet_project_reg); beyond that every thread takes part and the
 // passes scan the vector (from its LDS copy `ul` when given, else from L2).  red: >= 32 doubles.
 constexpr int kProjEpt = 24;
-template <typename T>
+template <typename T, bool REGS = true>   // REGS = false: no register-resident projection (callers beyond its reach: 1024-thread workgroups)
 __device__ __forceinline__ void atom_project(T *u, T *ul, const double *partial_old, int nparts, T *Dt,
                                              const int32_t *subset, int64_t s, int k, int j, double rho, T *comp_norm,
                                              double *red, unsigned long long *dbg = nullptr, double *level_hint = nullptr,
                                              T *stage_out = nullptr) {
-    const bool in_regs = s <= (int64_t)kProjEpt * 256 && blockDim.x >= 256;
+    const bool in_regs = REGS && s <= (int64_t)kProjEpt * 256 && blockDim.x >= 256;
     const int nthr = in_regs ? 256 : (int)blockDim.x;
     if ((int)threadIdx.x >= nthr) return;
     double old = 0, dummy = 0;
@@ -1752,7 +1752,7 @@ __device__ __forceinline__ void atom_project(T *u, T *ul, const double *partial_
     const double radius = (double)(T)((double)comp_norm[j] + old);   // comp_norm_[k] += subset_norm (:676-678)
     if (dbg && threadIdx.x == 0) dbg[7] = clock64();
     double nrm;
-    if (in_regs) {                                                   // projected values go straight to the dictionary
+    if (REGS && in_regs) {                                           // projected values go straight to the dictionary
         nrm = block_enet_project_reg<T, kProjEpt>(u, Dt + j, subset, (int64_t)k, s, radius, rho, red, nthr, dbg,
                                                   level_hint ? level_hint + j : nullptr);
     } else {
@@ -1764,7 +1764,7 @@ __device__ __forceinline__ void atom_project(T *u, T *ul, const double *partial_
         if (dbg && threadIdx.x == 0) dbg[5] = clock64();
         if (stage_out && ul) {
             // the projected atom leaves as a COMPACT row: the workgroups of the NEXT atom's launch put its values where they
-            // belong while they read their dictionary rows anyway (atom_step_kernel: stage_in) - written from here they are
+            // belong while they read their dictionary rows anyway (atom_grad4_kernel: stage_prev) - written from here they are
             // 10 000 scattered 4-byte stores by one workgroup, 42 k of the 160 k cycles an atom costs at config 6's shape
             typedef __attribute__((address_space(3))) T lds_T;
             for (int64_t f = threadIdx.x; f < s; f += nthr) stage_out[f] = ((lds_T *)ul)[f];
@@ -1802,10 +1802,7 @@ template <typename T, int KPL>
 __global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, const T *C, const int32_t *subset, int64_t s,
                                                         int k, int j, int pos, double rho, T *u, double *partial_old,
                                                         T *comp_norm, unsigned int *counter, int u_in_lds,
-                                                        unsigned long long *dbg, double *level_hint,
-                                                        const T *stage_in, int j_prev, T *stage_out) {
-    // stage_in / j_prev: the compact row of the atom projected by the launch before (j_prev < 0: none) - this launch writes
-    // its values into the dictionary and uses them; stage_out: where this launch's projecting workgroup leaves its atom
+                                                        unsigned long long *dbg, double *level_hint) {
     extern __shared__ __attribute__((aligned(16))) char step_smem[];   // the s-vector for the projection, if it fits
     __shared__ double red[32];
     __shared__ int flag;
@@ -1838,12 +1835,10 @@ __global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, cons
             const int64_t f = fb + q * fstride;
             r[q] = sub_row(subset, f < s ? f : fb) * k;                  // (clamped to the batch's first row: no branch around a load)
         }
-        T rv[kStepRows][KPL], djv[kStepRows], bjv[kStepRows], sv[kStepRows];
+        T rv[kStepRows][KPL], djv[kStepRows], bjv[kStepRows];
 #pragma unroll
         for (int q = 0; q < kStepRows; ++q) {
             const T *row = Dt + r[q];
-            const int64_t f = fb + q * fstride;
-            sv[q] = stage_in[(j_prev >= 0 && f < s) ? f : 0];
             djv[q] = row[j];
             bjv[q] = Bt[r[q] + j];
 #pragma unroll
@@ -1854,11 +1849,6 @@ __global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, cons
         for (int q = 0; q < kStepRows; ++q) {
             const int64_t f = fb + q * fstride;
             if (f >= s) break;                                           // (wavefront-uniform)
-            if (j_prev >= 0) {                                           // the previous atom's new value: into the row, and home
-#pragma unroll
-                for (int c = 0; c < KPL; ++c) rv[q][c] = (lane + 64 * c == j_prev) ? sv[q] : rv[q][c];
-                if (lane == 0) Dt[r[q] + j_prev] = sv[q];
-            }
             double dot = 0;
 #pragma unroll
             for (int c = 0; c < KPL; ++c) dot += (double)rv[q][c] * (double)cc[c];   // cc = 0 beyond k
@@ -1880,7 +1870,159 @@ __global__ __launch_bounds__(256) void atom_step_kernel(T *Dt, const T *Bt, cons
     if (!arrive_last(counter, gridDim.x, &flag)) return;
     const unsigned long long t2 = clock64();
     atom_project<T>(u, u_in_lds ? reinterpret_cast<T *>(step_smem) : nullptr, partial_old, (int)gridDim.x, Dt, subset, s, k, j,
-                    rho, comp_norm, red, dbg, level_hint, stage_out);
+                    rho, comp_norm, red, dbg, level_hint);
+    if (dbg && threadIdx.x == 0) { dbg[0] = t0; dbg[1] = t1; dbg[2] = t2; dbg[3] = clock64(); }
+}
+
+template <int G> struct AtomGroupN { int j[G]; int n; };
+
+// ---- The one-launch-per-atom path for GROUPS of kStepGroup consecutive atoms of the sweep, sampled sets beyond the register-resident
+// projection (more than 6144 features: the reference's HCP run samples 10 000 of 200 000 for 1024 atoms).  The gradient row
+// is what an atom costs there - 41 MB of dictionary per atom - so the launch of a group's FIRST atom evaluates the
+// numerators of all its atoms against the dictionary as it is then (one read serves the group; they are kept in double
+// with the old values), and the launches of the other atoms only correct theirs for what the atoms before them in the
+// group changed, from compact rows:
+//     num_a[f] -= sum_{a' < a} C[j_a', j_a] (D_new[j_a'][f] - D_old[j_a'][f])
+// (the difference between the sequential sweep's gradient row and the stale one - the grouped atom update's identity, below).
+// Every atom's launch ends like atom_step_kernel: the last workgroup to arrive projects from LDS - and leaves a compact
+// row; the gradient launch of the NEXT group puts the group's rows where they belong while it reads the dictionary.
+constexpr int kStepGroup = 4;
+// (1) the group's gradient rows: numerators and old values of all its atoms, the old-norm partial sums, and the rows of
+// the group BEFORE put where they belong
+template <typename T, int KPL>
+__global__ __launch_bounds__(256) void atom_grad4_kernel(T *Dt, const T *Bt, const T *C, const int32_t *subset, int64_t s, int k,
+                                                         AtomGroupN<kStepGroup> g, AtomGroupN<kStepGroup> gp, const T *stage_prev,
+                                                         double rho, double *num, T *dold, int64_t ldr, double *partial_old,
+                                                         int part_stride) {
+    constexpr int G = kStepGroup;
+    __shared__ double s_oldw[4][G];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int ja[G];
+    T cc[G][KPL], Cjj[G];
+#pragma unroll
+    for (int b = 0; b < G; ++b) {
+        ja[b] = g.j[b < g.n ? b : 0];                               // (a short last group repeats its first atom: not stored)
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+            const int e = lane + 64 * c;
+            const T cv = C[(int64_t)ja[b] * k + (e < k ? e : k - 1)];
+            cc[b][c] = (e < k) ? cv : (T)0;
+        }
+        Cjj[b] = C[(int64_t)ja[b] * k + ja[b]];
+    }
+    double old = 0;                                                 // lane b: atom b
+    const int nwv = (int)(blockDim.x >> 6);
+    constexpr int kRows = 2;                                        // (2 x (KPL + 3 G) loads in flight at KPL = 16)
+    const int64_t fstride = (int64_t)gridDim.x * nwv;
+    for (int64_t fb = (int64_t)blockIdx.x * nwv + wid; fb < s; fb += fstride * kRows) {
+        int64_t r[kRows];
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) {
+            const int64_t f = fb + q * fstride;
+            r[q] = sub_row(subset, f < s ? f : fb) * k;
+        }
+        T rv[kRows][KPL], dj[kRows][G], bj[kRows][G], pv[kRows][G];
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) {
+            const T *row = Dt + r[q];
+            const int64_t f = fb + q * fstride;
+#pragma unroll
+            for (int c = 0; c < KPL; ++c) rv[q][c] = row[lane + 64 * c < k ? lane + 64 * c : k - 1];
+#pragma unroll
+            for (int b = 0; b < G; ++b) {
+                dj[q][b] = row[ja[b]];
+                bj[q][b] = Bt[r[q] + ja[b]];
+                pv[q][b] = stage_prev[(int64_t)(b < gp.n ? b : 0) * ldr + (f < s ? f : 0)];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) {
+            const int64_t f = fb + q * fstride;
+            if (f >= s) break;                                       // (wavefront-uniform)
+            T pmine = 0;                                             // lane b: the staged value of the previous group's atom b
+            int jmine = -1;
+#pragma unroll
+            for (int b = 0; b < G; ++b) {
+                if (b < gp.n) {                                      // the previous group's atoms: into the row, and home
+#pragma unroll
+                    for (int c = 0; c < KPL; ++c) rv[q][c] = (lane + 64 * c == gp.j[b]) ? pv[q][b] : rv[q][c];
+                    if (lane == b) { pmine = pv[q][b]; jmine = gp.j[b]; }
+                }
+            }
+            if (jmine >= 0) Dt[r[q] + jmine] = pmine;
+            double nmine = 0;
+            T dmine = 0;
+#pragma unroll
+            for (int b = 0; b < G; ++b) {
+                double dot = 0;
+#pragma unroll
+                for (int c = 0; c < KPL; ++c) dot += (double)rv[q][c] * (double)cc[b][c];   // cc = 0 beyond k
+                dot = wave_sum(dot);
+                const double nv = ((double)bj[q][b] - dot) + (double)Cjj[b] * (double)dj[q][b];
+                if (lane == b) { nmine = nv; dmine = dj[q][b]; }
+            }
+            if (lane < g.n) {
+                num[(int64_t)lane * ldr + f] = nmine;
+                dold[(int64_t)lane * ldr + f] = dmine;
+                const double ab = fabs((double)dmine);
+                old += ab * (rho + (1.0 - rho) * ab);
+            }
+        }
+    }
+    if (lane < G) s_oldw[wid][lane] = old;
+    __syncthreads();
+    if (threadIdx.x < G)
+        partial_old[(int64_t)threadIdx.x * part_stride + blockIdx.x] =
+            (s_oldw[0][threadIdx.x] + s_oldw[1][threadIdx.x]) + (s_oldw[2][threadIdx.x] + s_oldw[3][threadIdx.x]);
+}
+
+// (2) one atom of the group: its candidate from the stored numerator minus what the atoms before it in the group changed (a
+// thread per feature), then the last workgroup to arrive projects from LDS (atom_project) and leaves the compact row.
+// (256 threads: the projection is 22 of the 24 us of such a launch, scans of the 10 000-element vector and block-wide
+// sums - and with 1024 threads, sixteen wavefronts, it took 29: the sums and their barriers grow faster than the scans
+// shrink.)
+template <typename T>
+__global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *C, const int32_t *subset, int64_t s, int k,
+                                                                AtomGroupN<kStepGroup> g, int a, int pos, double rho, T *u,
+                                                                const double *num, const T *dold, T *stage_cur, int64_t ldr,
+                                                                const double *partial_old, int part_stride, T *comp_norm,
+                                                                unsigned int *counter, unsigned long long *dbg, double *level_hint) {
+    constexpr int G = kStepGroup;
+    extern __shared__ __attribute__((aligned(16))) char step_smem[];   // the s-vector for the projection
+    __shared__ double red[32];
+    __shared__ int flag;
+    const unsigned long long t0 = clock64();
+    const int j = g.j[a];
+    // the numerators of the group's launch, minus what the atoms before this one changed
+    const double cjj = (double)C[(int64_t)j * k + j];
+    const bool frozen = !((T)cjj > (T)1e-20);
+    double cb[G];
+#pragma unroll
+    for (int b = 0; b < G; ++b) cb[b] = (b < a) ? (double)C[(int64_t)g.j[b] * k + j] : 0.0;
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < s; f += (int64_t)gridDim.x * blockDim.x) {
+        double x = num[(int64_t)a * ldr + f];
+        const T dj = dold[(int64_t)a * ldr + f];
+        T sn[G], so[G];
+#pragma unroll
+        for (int b = 0; b < G; ++b) {
+            const int bc = b < a ? b : 0;
+            sn[b] = stage_cur[(int64_t)bc * ldr + f];
+            so[b] = dold[(int64_t)bc * ldr + f];
+        }
+#pragma unroll
+        for (int b = 0; b < G; ++b)
+            if (b < a) x -= cb[b] * ((double)sn[b] - (double)so[b]);
+        T val = dj;
+        if (!frozen) val = (T)(x / cjj);
+        if (pos && val < (T)0) val = 0;                              // dict_fact.py:684-685
+        u[f] = val;
+    }
+    const unsigned long long t1 = clock64();
+    if (!arrive_last(counter, gridDim.x, &flag)) return;
+    const unsigned long long t2 = clock64();
+    atom_project<T, false>(u, reinterpret_cast<T *>(step_smem), partial_old + (int64_t)a * part_stride, part_stride, Dt, subset, s, k, j,
+                           rho, comp_norm, red, dbg, level_hint, stage_cur + (int64_t)a * ldr);
     if (dbg && threadIdx.x == 0) { dbg[0] = t0; dbg[1] = t1; dbg[2] = t2; dbg[3] = clock64(); }
 }
 
@@ -1911,7 +2053,6 @@ __device__ __forceinline__ void for_each_int(std::integer_sequence<int, As...>, 
 // straight into the dictionary they would be scattered 4-byte stores, one cache line per lane.  The workgroups of the
 // NEXT gradient launch put them where they belong while they read their dictionary rows anyway (gp, stage_in: the
 // previous group of this sweep); atom_stage_flush_group_kernel does it for the last group.
-template <int G> struct AtomGroupN { int j[G]; int n; };
 
 // A wavefront takes kGradRows feature rows (grid = ceil(s / (4 kGradRows)) workgroups: s <= 24 * 256 fits 512) and requests
 // EVERYTHING it needs - the group's columns of C, its rows of the dictionary, the entries of B_, the staged atoms of
@@ -2767,19 +2908,64 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
         };
         return G == 8 ? run(std::integral_constant<int, 8>{}) : run(std::integral_constant<int, 4>{});
     }
-    // beyond the register-resident projection (24 elements per thread) the projected atom travels as a compact row to the
-    // next launch (atom_project: stage_out); two rows in rotation, in the a-tile's space (unused on this path)
+    // beyond the register-resident projection (24 elements per thread): groups of atoms, compact rows (atom_grad4_kernel)
     const bool staged = u_lds != 0 && s > (int64_t)kProjEpt * 256;
-    T *stage2[2] = {reinterpret_cast<T *>(ws + L.off_a), reinterpret_cast<T *>(ws + L.off_a) + s};
-    int j_prev = -1;
+    if (staged) {
+        // groups of kStepGroup atoms (atom_step_group_kernel): one read of the dictionary per group; scratch in the a-tile's space
+        constexpr int G = kStepGroup;
+        static_assert(sizeof(T) * 3 * G + sizeof(double) * G <= sizeof(T) * kNB, "the group's rows fit the a-tile's space");
+        const int64_t ldr = s;
+        T *base = reinterpret_cast<T *>(ws + L.off_a);
+        T *stage[2] = {base, base + (size_t)G * ldr};
+        T *dold = base + (size_t)2 * G * ldr;
+        double *num = reinterpret_cast<double *>(ws + L.off_a + align_up(sizeof(T) * (size_t)3 * G * ldr, 16));
+        if (align_up(sizeof(T) * (size_t)3 * G * ldr, 16) + sizeof(double) * (size_t)G * ldr > sizeof(T) * (size_t)s * kNB) return MODL_ENOMEM;
+        if ((int64_t)G * nwg > L.nwg_grad) return MODL_ENOMEM;
+        const int nwg_corr = (int)cdiv(s, 256);                           // a thread per feature
+        AtomGroupN<G> g, gp;
+        gp.n = 0;
+        for (int b = 0; b < G; ++b) gp.j[b] = 0;
+        int gi = 0;
+        for (int t0 = 0; t0 < k; t0 += G, ++gi) {
+            g.n = (k - t0 < G) ? k - t0 : G;
+            for (int b = 0; b < G; ++b) {
+                g.j[b] = (int)h_order[t0 + (b < g.n ? b : 0)];
+                if (g.j[b] < 0 || g.j[b] >= k) return MODL_EINVAL;
+            }
+#define MODL_GRAD4(KPL)                                                                                               \
+    hipLaunchKernelGGL((atom_grad4_kernel<T, KPL>), dim3(nwg), dim3(256), 0, stream, a.Dt, a.Bt, a.C, a.subset, s, k, g, gp,          \
+                       (const T *)stage[(gi + 1) & 1], a.comp_l1_ratio, num, dold, ldr, pold, nwg)
+            if (k <= 64) MODL_GRAD4(1);
+            else if (k <= 128) MODL_GRAD4(2);
+            else if (k <= 256) MODL_GRAD4(4);
+            else if (k <= 512) MODL_GRAD4(8);
+            else MODL_GRAD4(16);
+#undef MODL_GRAD4
+            MODL_LAUNCH_CHECK();
+            for (int ai = 0; ai < g.n; ++ai) {
+                hipLaunchKernelGGL((atom_corr_project_kernel<T>), dim3(nwg_corr), dim3(256), u_lds, stream, a.Dt, a.C, a.subset, s, k,
+                                   g, ai, a.comp_pos, a.comp_l1_ratio, u, (const double *)num, (const T *)dold, stage[gi & 1], ldr,
+                                   (const double *)pold, nwg, a.comp_norm, counter,
+                                   reinterpret_cast<unsigned long long *>(counter + kCounters), a.level_hint);
+                MODL_LAUNCH_CHECK();
+            }
+            gp = g;
+        }
+        for (int b = 0; b < gp.n; ++b) {                                 // the last group's rows
+            hipLaunchKernelGGL((atom_stage_flush_kernel<T>), dim3((unsigned)cdiv(s, 256)), dim3(256), 0, stream, a.Dt, a.subset, s, k,
+                               gp.j[b], (const T *)(stage[(gi + 1) & 1] + (size_t)b * ldr));
+            MODL_LAUNCH_CHECK();
+        }
+        if (launches) *launches += k + gi + gp.n;
+        return MODL_OK;
+    }
     for (int t = 0; t < k; ++t) {
         const int j = (int)h_order[t];
         if (j < 0 || j >= k) return MODL_EINVAL;
 #define MODL_STEP(KPL)                                                                                            \
     hipLaunchKernelGGL((atom_step_kernel<T, KPL>), dim3(nwg), dim3(256), u_lds, stream, a.Dt, a.Bt, a.C, a.subset, s, k, j, \
                        a.comp_pos, a.comp_l1_ratio, u, pold, a.comp_norm, counter, u_lds ? 1 : 0, \
-                       reinterpret_cast<unsigned long long *>(counter + kCounters), a.level_hint,                  \
-                       (const T *)stage2[(t + 1) & 1], staged ? j_prev : -1, staged ? stage2[t & 1] : (T *)nullptr)
+                       reinterpret_cast<unsigned long long *>(counter + kCounters), a.level_hint)
         if (k <= 64) MODL_STEP(1);
         else if (k <= 128) MODL_STEP(2);
         else if (k <= 256) MODL_STEP(4);
@@ -2787,13 +2973,6 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
         else MODL_STEP(16);
 #undef MODL_STEP
         MODL_LAUNCH_CHECK();
-        j_prev = j;
-    }
-    if (staged && j_prev >= 0) {
-        hipLaunchKernelGGL((atom_stage_flush_kernel<T>), dim3((unsigned)cdiv(s, 256)), dim3(256), 0, stream, a.Dt, a.subset, s, k,
-                           j_prev, (const T *)stage2[(k - 1) & 1]);
-        MODL_LAUNCH_CHECK();
-        if (launches) *launches += 1;
     }
     if (launches) *launches += k;
     return MODL_OK;
