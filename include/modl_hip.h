@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MODL_ABI_VERSION 3
+#define MODL_ABI_VERSION 4
 
 #define MODL_OK 0
 #define MODL_EINVAL (-1)   /* bad argument */
@@ -378,6 +378,15 @@ int modl_comm_create(const modl_comm_id *id, int rank, int world, modl_comm **ou
 void modl_comm_destroy(modl_comm *comm);
 /* in-place sum over the ranks of n elements (dtype MODL_F32 / MODL_F64) of a device buffer, on `stream` */
 int modl_comm_all_reduce_sum(modl_comm *comm, void *d_buf, int64_t n, int dtype, void *stream);
+/* ABI 4 - the abort path.  A rank that dies leaves the others inside ncclAllReduce in the middle of a chunk call; a plain
+ * stream synchronisation would then wait for ever.  modl_comm_wait waits for `stream` to drain WHILE watching the
+ * communicator (ncclCommGetAsyncError) and the clock: an asynchronous RCCL error, or more than timeout_s seconds
+ * (<= 0: no limit) without the stream draining, aborts the communicator (ncclCommAbort: the kernels of this rank that wait
+ * inside a collective are released) and returns MODL_ERCCL; MODL_OK when the stream is idle.  After an abort every call
+ * on the communicator returns MODL_ERCCL; modl_comm_destroy still frees the handle.  modl_comm_abort: the same, at once
+ * (a launcher that has seen another rank exit).  The reference has no counterpart (it is a single-process estimator). */
+int modl_comm_wait(modl_comm *comm, void *stream, double timeout_s);
+int modl_comm_abort(modl_comm *comm);
 int modl_somf_step_dist(modl_somf_plan *plan, const modl_somf_state *st, const modl_somf_batch *bt, modl_comm *comm,
                         void *stream);
 

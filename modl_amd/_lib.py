@@ -154,6 +154,8 @@ def bind(lib):
     _sig('modl_comm_create', C.c_int, _vp, C.c_int, C.c_int, _P(_vp))
     _sig('modl_comm_destroy', None, _vp)
     _sig('modl_comm_all_reduce_sum', C.c_int, _vp, _vp, _i64, C.c_int, _vp)
+    _sig('modl_comm_wait', C.c_int, _vp, _vp, C.c_double)
+    _sig('modl_comm_abort', C.c_int, _vp)
     _sig('modl_somf_step_dist', C.c_int, _vp, _P(SomfState), _P(SomfBatch), _vp, _vp)
     _sig('modl_somf_full_gram', C.c_int, _vp, _vp, _vp, _vp)
     _sig('modl_somf_transform', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp)

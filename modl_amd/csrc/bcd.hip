@@ -2833,11 +2833,14 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
     char *ws = static_cast<char *>(a.ws);
     T *u = reinterpret_cast<T *>(ws + L.off_u);
     double *pold = reinterpret_cast<double *>(ws + L.off_pold);
+    // the whole sweep order is checked BEFORE the first launch: an index out of range in a later group would otherwise
+    // come back as MODL_EINVAL with earlier groups' norm budgets already updated and their projected atoms still in the
+    // staging rows
+    for (int t = 0; t < k; ++t)
+        if (h_order[t] < 0 || h_order[t] >= k) return MODL_EINVAL;
     // small problems: the whole sweep in one launch (u in LDS, see atom_sweep_kernel)
     const size_t lds = sizeof(double) * (16 + (size_t)k) + sizeof(T) * (size_t)s + 16;
     if (a.order && lds <= 64 * 1024 && (double)s * k <= 32e3) {     // thread-per-row reads: only worth it when tiny
-        for (int t = 0; t < k; ++t)
-            if (h_order[t] < 0 || h_order[t] >= k) return MODL_EINVAL;
         auto kern = atom_sweep_kernel<T>;
         hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, stream, a.Dt, a.Bt, a.C, a.subset, a.order, s, k, a.comp_pos,
                            a.comp_l1_ratio, a.comp_norm);

@@ -582,6 +582,15 @@ template int launch_cd_pad_gram<double>(hipStream_t, const double *, int, double
 // corners (the caller zero-fills the scratch once per k).  Bit-identical to cd_kernel.
 constexpr size_t kCdSliceBytes = (size_t)64 << 20;
 bool cd_split_enabled() { return g_cd_split.load(std::memory_order_relaxed) != 0; }   // (diagnostics switch MODL_DEBUG_CD_SPLIT)
+// does the one-wavefront kernel exist for k coefficients?  (beyond 256 only in the diagnostics library: with MODL_DEBUG_CD_SPLIT
+// = 0 the product library still solves such systems on the four-wavefront solver - every switch selects between correct paths)
+bool cd_one_wave_covers(int k) {
+#ifdef MODL_DIAG
+    (void)k; return true;
+#else
+    return k <= 256;
+#endif
+}
 int cd_per_sample_ld(int k) { const int kq = cd_padded_ld(k); return kq < 128 ? 128 : kq; }
 size_t cd_per_sample_scratch_bytes(size_t tsz, int64_t b, int k) {
     const size_t per = (size_t)cd_per_sample_ld(k) * cd_per_sample_ld(k) * tsz;

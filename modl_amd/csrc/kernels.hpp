@@ -38,6 +38,7 @@ bool cd_split_enabled();
 int cd_per_sample_ld(int k);
 size_t cd_per_sample_scratch_bytes(size_t tsz, int64_t b, int k);
 template <typename T> int launch_cd_per_sample(hipStream_t stream, const CdArgs<T> &a, T *slots, size_t slot_bytes);
+bool cd_one_wave_covers(int k);   // the one-wavefront kernel exists for k coefficients (k <= 256; any k in the diagnostics library)
 int cd_padded_ld(int k);   // the row stride the vectorised solver wants for k coefficients (k itself when it fits already)
 // Gp[ldg + 16][ldg] (zero-filled once by the caller) <- G[k][k]
 template <typename T> int launch_cd_pad_gram(hipStream_t stream, const T *G, int k, T *Gp, int ldg);

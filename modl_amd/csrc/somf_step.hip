@@ -20,6 +20,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
@@ -537,7 +540,7 @@ int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride
     a.alpha = (T)((T)d.code_alpha * (T)d.code_l1_ratio);
     a.beta = (T)((double)(T)d.code_alpha * (1.0 - (double)(T)d.code_l1_ratio));
     a.tol = (T)d.tol; a.max_iter = d.max_iter; a.positive = d.code_pos;
-    if (g_stride && k >= 32 && cd_split_enabled() && !cd_split_applies<T>(a)) {
+    if (g_stride && k >= 32 && (cd_split_enabled() || !cd_one_wave_covers(k)) && !cd_split_applies<T>(a)) {
         // a Gram matrix per sample of a size the four-wavefront solver does not take as stored: zero-padded copies,
         // a slice of the minibatch at a time (cd_solver.hip: launch_cd_per_sample)
         if (!pl->Gslots) {
@@ -977,8 +980,12 @@ int enet_regression_abi(const T *G, int64_t g_stride, T *Dx, const T *X, int64_t
     a.G = G; a.g_stride = g_stride; a.g_idx = nullptr; a.Dx = Dx; a.xnorm2 = xnorm; a.H0 = H0p; a.code = code;
     a.idx = d_indices;
     a.sweeps = d_sweeps; a.b = (int)b; a.k = (int)k;
-    if (!g_stride && k <= 1024 && cd_padded_ld((int)k) != (int)k) {     // any k on the vectorised kernel: padded copy at the
-        const int kq = cd_padded_ld((int)k);                            // end of the caller's workspace
+    // any k on the vectorised kernel: padded copy at the end of the caller's workspace.  Also for k = 512 / 1024 when the
+    // caller's matrix is not 16-byte aligned: beyond 256 coefficients only the four-wavefront solver exists in the product
+    // build, and it wants aligned rows (such a call used to end in MODL_EINVAL)
+    const bool g_misaligned = reinterpret_cast<uintptr_t>(G) % 16 != 0;
+    if (!g_stride && k <= 1024 && (cd_padded_ld((int)k) != (int)k || (k > 256 && g_misaligned))) {
+        const int kq = cd_padded_ld((int)k);
         const size_t gp_bytes = align_up(sizeof(T) * ((size_t)kq + 16) * kq, 256);
         T *Gp = reinterpret_cast<T *>(w + need - gp_bytes);
         MODL_HIP(hipMemsetAsync(Gp, 0, gp_bytes, st));
@@ -988,7 +995,7 @@ int enet_regression_abi(const T *G, int64_t g_stride, T *Dx, const T *X, int64_t
     a.alpha = alpha * l1_ratio;
     a.beta = (T)((double)alpha * (1.0 - (double)l1_ratio));
     a.tol = tol; a.max_iter = max_iter; a.positive = positive;
-    if (g_stride && k >= 32 && k <= 1024 && cd_split_enabled() && !cd_split_applies<T>(a)) {  // one Gram matrix per sample, any k: zero-padded slots
+    if (g_stride && k >= 32 && k <= 1024 && (cd_split_enabled() || !cd_one_wave_covers((int)k)) && !cd_split_applies<T>(a)) {  // one Gram matrix per sample, any k: zero-padded slots
         const size_t slot_bytes = cd_per_sample_scratch_bytes(sizeof(T), b, (int)k);   // (at the end of the workspace)
         T *slots = reinterpret_cast<T *>(w + need - align_up(slot_bytes, 256));
         MODL_HIP(hipMemsetAsync(slots, 0, slot_bytes, st));
@@ -1014,7 +1021,7 @@ size_t modl_enet_regression_workspace(int dtype, int64_t b, int64_t k, int multi
     const size_t slots = (multi_gram && k >= 32 && k <= 1024) ? align_up(modl::cd_per_sample_scratch_bytes(t, b, (int)k), 256) : 0;
     return align_up(t * (size_t)b, 256) + align_up(t * (size_t)b * k, 256) +
            align_up(t * ((size_t)k * k * ((multi_gram && k <= 512) ? (size_t)b : 1) + modl::chol_wide_scratch_elems((int)k)), 256) +
-           ((kq && kq != (size_t)k) ? align_up(t * (kq + 16) * kq, 256) : 0) + slots;
+           ((kq && (kq != (size_t)k || k > 256)) ? align_up(t * (kq + 16) * kq, 256) : 0) + slots;   // (k > 256: a misaligned matrix is copied too)
 }
 
 #define ABI_REG(SFX, T)                                                                                            \
@@ -1200,6 +1207,8 @@ struct RcclApi {
     int (*CommInitRank)(void **, int, modl_comm_id, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommAbort)(void *) = nullptr;                  // optional (the abort path: modl_comm_abort / modl_comm_wait)
+    int (*CommGetAsyncError)(void *, int *) = nullptr;   // optional
     bool ok = false;
 };
 RcclApi &rccl() {
@@ -1215,12 +1224,15 @@ RcclApi &rccl() {
         a.CommDestroy = reinterpret_cast<int (*)(void *)>(dlsym(a.handle, "ncclCommDestroy"));
         a.AllReduce = reinterpret_cast<int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)>(
             dlsym(a.handle, "ncclAllReduce"));
+        a.CommAbort = reinterpret_cast<int (*)(void *)>(dlsym(a.handle, "ncclCommAbort"));
+        a.CommGetAsyncError = reinterpret_cast<int (*)(void *, int *)>(dlsym(a.handle, "ncclCommGetAsyncError"));
         a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce;
         return a;
     }();
     return api;
 }
 constexpr int kNcclSum = 0, kNcclFloat32 = 7, kNcclFloat64 = 8;      // rccl.h: ncclRedOp_t / ncclDataType_t
+constexpr int kNcclSuccess = 0, kNcclInProgress = 7;                 // rccl.h: ncclResult_t
 }  // namespace
 
 extern "C" {
@@ -1228,7 +1240,20 @@ extern "C" {
 struct modl_comm {
     void *nccl = nullptr;
     int rank = 0, world = 1;
+    bool dead = false;                 // aborted (an RCCL error, a peer that never arrived): every later call is MODL_ERCCL
 };
+
+// an asynchronous RCCL error on this communicator (a peer died, a link failed)?  Aborts it then: the kernels of this
+// rank that wait inside a collective are released, the stream drains, and the caller sees MODL_ERCCL instead of a hang.
+static int comm_poll(modl_comm *c) {
+    if (c->dead) return MODL_ERCCL;
+    int err = kNcclSuccess;
+    if (rccl().CommGetAsyncError && rccl().CommGetAsyncError(c->nccl, &err) == 0 && err != kNcclSuccess && err != kNcclInProgress) {
+        (void)modl_comm_abort(c);
+        return MODL_ERCCL;
+    }
+    return MODL_OK;
+}
 
 int modl_comm_unique_id(modl_comm_id *out) {
     if (!out) return MODL_EINVAL;
@@ -1250,15 +1275,49 @@ int modl_comm_create(const modl_comm_id *id, int rank, int world, modl_comm **ou
 
 void modl_comm_destroy(modl_comm *c) {
     if (!c) return;
-    if (c->nccl && rccl().ok) (void)rccl().CommDestroy(c->nccl);
+    if (c->nccl && rccl().ok && !c->dead) (void)rccl().CommDestroy(c->nccl);      // (an aborted communicator is gone already)
     delete c;
 }
 
+int modl_comm_abort(modl_comm *c) {
+    if (!c) return MODL_EINVAL;
+    if (!c->dead) {
+        c->dead = true;
+        if (c->nccl && rccl().CommAbort) (void)rccl().CommAbort(c->nccl);          // frees the communicator
+        c->nccl = nullptr;
+    }
+    return MODL_OK;
+}
+
+int modl_comm_wait(modl_comm *c, void *stream, double timeout_s) {
+    if (!c) return MODL_EINVAL;
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    for (;;) {
+        const hipError_t q = hipStreamQuery((hipStream_t)stream);
+        if (q == hipSuccess) return c->dead ? MODL_ERCCL : MODL_OK;
+        if (q != hipErrorNotReady) { (void)hipGetLastError(); (void)modl_comm_abort(c); return (int)q; }   // (a HIP error code, as everywhere)
+        if (comm_poll(c) != MODL_OK) return MODL_ERCCL;
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (timeout_s > 0 && waited > timeout_s) {     // a rank that never arrives: do not wait for it for ever
+            (void)modl_comm_abort(c);
+            return MODL_ERCCL;
+        }
+        if (++spins < 2000) sched_yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(waited < 0.05 ? 20 : 500));
+    }
+}
+
 int modl_comm_all_reduce_sum(modl_comm *c, void *d_buf, int64_t n, int dtype, void *stream) {
-    if (!c || !c->nccl || !d_buf || n < 0 || (dtype != MODL_F32 && dtype != MODL_F64)) return MODL_EINVAL;
+    if (!c || !d_buf || n < 0 || (dtype != MODL_F32 && dtype != MODL_F64)) return MODL_EINVAL;
+    if (c->dead || !c->nccl) return c->dead ? MODL_ERCCL : MODL_EINVAL;
     if (n == 0) return MODL_OK;
-    return rccl().AllReduce(d_buf, d_buf, (size_t)n, dtype == MODL_F32 ? kNcclFloat32 : kNcclFloat64, kNcclSum, c->nccl,
-                            (hipStream_t)stream) == 0 ? MODL_OK : MODL_ERCCL;
+    if (rccl().AllReduce(d_buf, d_buf, (size_t)n, dtype == MODL_F32 ? kNcclFloat32 : kNcclFloat64, kNcclSum, c->nccl,
+                         (hipStream_t)stream) != 0) {
+        (void)modl_comm_abort(c);              // whatever this rank has enqueued on the communicator is released
+        return MODL_ERCCL;
+    }
+    return MODL_OK;
 }
 
 // several GPUs, everything on ONE stream: phase 1 (partial statistics + head), ncclAllReduce of the head in place,
@@ -1285,6 +1344,70 @@ int modl_somf_step_dist(modl_somf_plan *pl, const modl_somf_state *st, const mod
     return somf_step_dist_next(pl, st, bt, nullptr, comm, stream);
 }
 
+// The feature subsets of a chunk call drawn AHEAD on a worker thread (same sampler, same order of draws: the same
+// streams bit for bit).  The bit-exact shuffle of p indices costs ~5 ns per feature - 1 ms at p = 200 000, as long as
+// the device step there - so beyond kDrawAheadFeatures features the chunk call would be host-bound with the draw on the
+// calling thread (round 4 sent such shapes back to the Python loop and its look-ahead thread: one library call per
+// minibatch, and with several ranks one modl_somf_step_dist call each).  A ring of NQ buffers; minibatch u is drawn
+// once minibatch u - NQ has been enqueued.  Only this thread touches the sampler while it runs; stop() joins it before
+// anybody else does (the rewind of a failed call).
+namespace {
+constexpr int64_t kDrawAheadFeatures = 32768;
+struct DrawAhead {
+    static constexpr int NQ = 4;
+    modl_sampler *sampler = nullptr;
+    double reduction = 1.0;
+    int64_t nb = 0;
+    std::vector<int64_t> buf[NQ];
+    int64_t len[NQ] = {0, 0, 0, 0};
+    int rcs[NQ] = {0, 0, 0, 0};
+    std::mutex m;
+    std::condition_variable cv;
+    int64_t drawn = 0, released = 0;
+    bool quit = false;
+    std::thread th;
+    void start(modl_sampler *s, double red, int64_t p, int64_t n_batches) {
+        sampler = s; reduction = red; nb = n_batches;
+        for (auto &b : buf) b.resize((size_t)std::max<int64_t>(p, 1));
+        th = std::thread([this] { run(); });
+    }
+    void run() {
+        for (int64_t u = 0; u < nb; ++u) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return quit || u - NQ < released; });
+                if (quit) return;
+            }
+            int64_t s = 0;
+            const int rc = modl_sampler_yield_subset(sampler, reduction, buf[u % NQ].data(), &s);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                len[u % NQ] = s; rcs[u % NQ] = rc; drawn = u + 1;
+            }
+            cv.notify_all();
+            if (rc != MODL_OK) return;
+        }
+    }
+    int take(int64_t u, const int64_t **ptr, int64_t *s) {       // blocks until minibatch u's subset is drawn
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return drawn > u; });
+        *ptr = buf[u % NQ].data(); *s = len[u % NQ];
+        return rcs[u % NQ];
+    }
+    void release(int64_t upto) {                                  // the buffers of minibatches < upto may be reused
+        { std::lock_guard<std::mutex> lk(m); if (upto > released) released = upto; }
+        cv.notify_all();
+    }
+    void stop() {
+        if (!th.joinable()) return;
+        { std::lock_guard<std::mutex> lk(m); quit = true; }
+        cv.notify_all();
+        th.join();
+    }
+    ~DrawAhead() { stop(); }
+};
+}  // namespace
+
 int modl_somf_partial_fit_chunk(modl_somf_plan *pl, const modl_somf_state *st, const void *d_X, int64_t ldx, int64_t n_rows,
                                 int32_t batch_size, const int64_t *h_sample_idx, modl_sampler *sampler, modl_rk *order_rng,
                                 int64_t *n_iter, double learning_rate, double reduction, const int64_t *h_b_global,
@@ -1301,7 +1424,10 @@ int modl_somf_partial_fit_chunk(modl_somf_plan *pl, const modl_somf_state *st, c
         modl_somf_batch bt;
     };
     Prepared prep[2];
-    for (auto &q : prep) { q.subset.resize((size_t)std::max<int64_t>(d.p, 1)); q.order.resize((size_t)d.k); }
+    const int64_t n_batches = (n_rows + batch_size - 1) / batch_size;
+    const bool draw_ahead = d.p >= kDrawAheadFeatures && n_batches >= 4;
+    DrawAhead ahead;                               // (declared before anything that can return: its destructor joins)
+    for (auto &q : prep) { q.subset.resize((size_t)(draw_ahead ? 1 : std::max<int64_t>(d.p, 1))); q.order.resize((size_t)d.k); }
     const char *X = static_cast<const char *>(d_X);
     // what a failed minibatch is rewound to: the state of both generators and of the counter at the start of the call
     // (the look-ahead has drawn for minibatch t + 1 when step t fails; a retry must continue the reference's streams
@@ -1317,14 +1443,16 @@ int modl_somf_partial_fit_chunk(modl_somf_plan *pl, const modl_somf_state *st, c
     };
     auto fail = [&](int64_t done, int rc) -> int {
         pl->ahead = false;
+        ahead.stop();                              // (nobody else draws from the sampler while it is rewound)
         if (n_done) *n_done = done;
+        std::vector<int64_t> scratch((size_t)std::max<int64_t>(d.p, 1));
         // replay exactly the draws of the `done` fitted minibatches (the two generators are independent streams)
         int64_t s = 0;
         if (modl_sampler_set_state(sampler, sampler0.data(), sampler0.size()) != MODL_OK ||
             modl_rk_set_mt_state(order_rng, order_key0, order_pos0) != MODL_OK) return rc;
         int64_t it = n_iter0;
         for (int64_t t = 0; t < done; ++t) {
-            (void)modl_sampler_yield_subset(sampler, reduction, prep[0].subset.data(), &s);
+            (void)modl_sampler_yield_subset(sampler, reduction, scratch.data(), &s);
             (void)modl_rk_permutation(order_rng, d.k, prep[0].order.data());
             it += global_rows(t, t * (int64_t)batch_size);
         }
@@ -1334,7 +1462,9 @@ int modl_somf_partial_fit_chunk(modl_somf_plan *pl, const modl_somf_state *st, c
     auto prepare = [&](int64_t t, int64_t r0, Prepared &q) -> int {
         const int32_t b = (int32_t)std::min<int64_t>(batch_size, n_rows - r0);
         int64_t s = 0;
-        MODL_TRY(modl_sampler_yield_subset(sampler, reduction, q.subset.data(), &s));        // dict_fact.py:507
+        const int64_t *subset_ptr = q.subset.data();
+        if (draw_ahead) MODL_TRY(ahead.take(t, &subset_ptr, &s));                           // dict_fact.py:507, drawn ahead
+        else MODL_TRY(modl_sampler_yield_subset(sampler, reduction, q.subset.data(), &s));  // dict_fact.py:507
         const int64_t bg = global_rows(t, r0);
         if (bg < b) return MODL_EINVAL;
         *n_iter += bg;                                                                      // :510
@@ -1353,7 +1483,7 @@ int modl_somf_partial_fit_chunk(modl_somf_plan *pl, const modl_somf_state *st, c
             bt.h_sample_idx = q.idx_local.data();
         }
         if (s == d.p) { bt.s = (int32_t)d.p; bt.h_subset = nullptr; }   // every feature: no gather (any order is the same set)
-        else { bt.s = (int32_t)s; bt.h_subset = q.subset.data(); }
+        else { bt.s = (int32_t)s; bt.h_subset = subset_ptr; }
         bt.h_order = q.order.data();
         bt.w = w;
         bt.reduction = reduction;
@@ -1362,6 +1492,7 @@ int modl_somf_partial_fit_chunk(modl_somf_plan *pl, const modl_somf_state *st, c
     };
     pl->ahead = false;
     if (n_rows <= 0) return MODL_OK;
+    if (draw_ahead) ahead.start(sampler, reduction, d.p, n_batches);
     { const int rc0 = prepare(0, 0, prep[0]); if (rc0 != MODL_OK) return fail(0, rc0); }
     int64_t t = 0;
     for (int64_t r0 = 0; r0 < n_rows; r0 += batch_size, ++t) {
@@ -1375,7 +1506,9 @@ int modl_somf_partial_fit_chunk(modl_somf_plan *pl, const modl_somf_state *st, c
                             : somf_step_next(pl, st, &cur.bt, next, stream);
         if (rc != MODL_OK) return fail(t, rc);
         if (rc_next != MODL_OK) return fail(t + 1, rc_next);
+        if (draw_ahead) ahead.release(t + 1);      // (minibatch t's arrays were copied to the staging ring when it was enqueued)
     }
+    ahead.stop();
     pl->ahead = false;
     if (n_done) *n_done = t;
     return MODL_OK;

@@ -238,7 +238,16 @@ class HipBackend:
     def take_rows(self, Xh, perm):
         return gather_rows(Xh, perm)
 
+    # seconds a rank waits for its stream to drain while it holds the library's RCCL communicator before it aborts the
+    # communicator and raises (a peer that died leaves the others inside ncclAllReduce: modl_comm_wait); <= 0: no limit
+    COMM_TIMEOUT_S = float(os.environ.get('MODL_COMM_TIMEOUT_S', '1800'))
+
     def synchronize(self):
+        comm = getattr(self, 'comm', None)
+        if comm is not None and getattr(self, '_comm_world', 1) > 1:
+            # several ranks on the library's communicator: a bounded wait that watches RCCL's asynchronous errors - an
+            # RCCL failure surfaces as MODL_ERCCL here instead of a hang in hipStreamSynchronize
+            check(lib.modl_comm_wait(comm, stream_ptr(self.device), self.COMM_TIMEOUT_S), 'modl_comm_wait')
         torch.cuda.synchronize(self.device)
 
     # -- the step -------------------------------------------------------------
@@ -352,6 +361,7 @@ class HipBackend:
                 ok = rc == 0
             if ok:
                 self.comm = h
+                self._comm_world = world
             else:
                 if rc == 0:
                     lib.modl_comm_destroy(h)
@@ -807,13 +817,20 @@ class DictFact(CodingMixin, BaseEstimator):
         chunks = _HostChunks(be, X, chunk_rows) if streamed else [(0, be.stage_X(X))]
         # (a callback may change `reduction` between two minibatches: then every subset is drawn when it is needed)
         chunk_call = self._chunk_call_applies(be, sample_indices)
+        comm = None
+        if chunk_call and (self._world() > 1 or getattr(self, '_force_reduce', False)):
+            # the communicator is resolved BEFORE the route is chosen: when it cannot be created (no librccl, an RCCL
+            # error - decided on every rank together, HipBackend.native_comm) the chunk call must not run with comm = None,
+            # which is the single-GPU step without any reduction; the per-minibatch loop with torch's collective runs instead
+            comm = self._native_comm(be)
+            if comm is None:
+                chunk_call = False
         ahead = not chunk_call and len(batches) >= 4 and self.callback is None and not self.verbose
         self._subsets = _SubsetsAhead(self.feature_sampler_, self.reduction, len(batches)) if ahead else None
         t = 0
         try:
             if chunk_call:
                 # the whole per-minibatch loop in ONE library call per chunk (same draws, same order, same bits)
-                comm = self._native_comm(be)
                 for r0, Xh in chunks:
                     nb = -(-Xh.shape[0] // self.batch_size)
                     idx = get_sub_slice(sample_indices, slice(r0, r0 + Xh.shape[0]))
@@ -850,9 +867,10 @@ class DictFact(CodingMixin, BaseEstimator):
         self.time_ += time.perf_counter() - t0 - self._cb_time
         return self
 
-    # the chunk call draws the subsets on the calling thread: beyond this many features the look-ahead thread of the
-    # Python loop is the better host (the bit-exact shuffle of p indices is ~5 ns per feature: 1 ms at p = 200 000)
-    CHUNK_CALL_MAX_FEATURES = 50000
+    # round 5: no feature limit any more - the chunk call draws the subsets of wide problems ahead on a worker thread of
+    # its own (somf_step.hip: DrawAhead; the bit-exact shuffle of p indices is ~5 ns per feature: 1 ms at p = 200 000,
+    # as long as the device step), so that BASELINE config 5 with several ranks is ONE library call per chunk too
+    CHUNK_CALL_MAX_FEATURES = None
 
     def _chunk_call_applies(self, be, sample_indices):
         """One library call per chunk instead of the Python loop over minibatches: the plain configuration only -
@@ -863,7 +881,8 @@ class DictFact(CodingMixin, BaseEstimator):
             return False
         if self.callback is not None or self.verbose or getattr(self, '_two_phase', False):
             return False
-        if self.G_agg == 'average' or self.Dx_agg == 'average' or be.p > self.CHUNK_CALL_MAX_FEATURES:
+        if self.G_agg == 'average' or self.Dx_agg == 'average' or \
+                (self.CHUNK_CALL_MAX_FEATURES is not None and be.p > self.CHUNK_CALL_MAX_FEATURES):
             return False
         if not isinstance(self.random_state, np.random.RandomState) or not isinstance(self.feature_sampler_, Sampler):
             return False

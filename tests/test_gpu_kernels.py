@@ -299,8 +299,12 @@ def test_cd_two_solvers_agree(fast, dt, k, b, p, alpha):
     rounded once instead of twice - full and padded k, both stopping rules, positivity, a singular Gram matrix running
     into max_iter.  (Every other test of this file runs whichever the library picks, i.e. the four-wavefront one where
     it applies, against the oracle.)"""
+    from modl_amd import _lib as L
     from modl_amd._lib import check, DEBUG_CD_SPLIT, load_diag
-    lib = load_diag()          # (the one-wavefront kernel for k > 256 only exists in the diagnostics build)
+    # ADVICE round 4: the four-wavefront solver under test is the one that SHIPS (the product library, compiled without
+    # MODL_DIAG: other register allocation, no stamp code); the one-wavefront kernel comes from the product library where
+    # it exists there (k <= 256) and from the diagnostics build beyond
+    libs = {1: L.lib, 0: L.lib if k <= 256 else load_diag()}
     rs = np.random.RandomState(k + b)
     D = rs.randn(k, p).astype(dt)
     D /= np.sqrt((D ** 2).sum(1))[:, None]
@@ -313,13 +317,16 @@ def test_cd_two_solvers_agree(fast, dt, k, b, p, alpha):
         out = {}
         try:
             for split in (0, 1):
+                lib = libs[split]
                 check(lib.modl_debug_set(DEBUG_CD_SPLIT, split))
                 code = np.ones((b + 5, k), dtype=dt)
                 sw = np.zeros(b, dtype=np.int32)
                 fast._enet_regression_single_gram(G, Dx.copy(), X, code, idx, l1, alpha, pos, 1e-2, mi, sweeps=sw, _lib=lib)
+                check(lib.modl_debug_set(DEBUG_CD_SPLIT, 1))
                 out[split] = (code[idx], sw)
         finally:
-            check(lib.modl_debug_set(DEBUG_CD_SPLIT, 1))
+            for lib in libs.values():
+                check(lib.modl_debug_set(DEBUG_CD_SPLIT, 1))
         same = _assert_solvers_agree(dt, out[1], out[0], (k, l1))
         if dt == np.float32:
             a_, b_ = out[1][0][same].astype(np.float64), out[0][0][same].astype(np.float64)
@@ -331,14 +338,58 @@ def test_cd_two_solvers_agree(fast, dt, k, b, p, alpha):
         assert out[0][1].max() > 1
 
 
+@pytest.mark.parametrize('k', [512, 1024])
+def test_cd_wide_misaligned_gram_and_split_switch(fast, k):
+    """beyond 256 coefficients the product library only has the four-wavefront solver, which wants
+    16-byte aligned rows.  A caller's k = 512 / 1024 Gram matrix that is NOT aligned (a view one element into a buffer)
+    used to come back as MODL_EINVAL; it is copied into the aligned scratch now - same bits as the aligned call - and
+    modl_debug_set(MODL_DEBUG_CD_SPLIT, 0) still selects a correct path for k > 256 (shared and per-sample Gram)."""
+    import torch
+    from modl_amd import _lib as L
+    from modl_amd._lib import check, DEBUG_CD_SPLIT
+    rs = np.random.RandomState(k)
+    b, p = 5, k + 100
+    D = rs.randn(k, p).astype(np.float32)
+    D /= np.sqrt((D ** 2).sum(1))[:, None]
+    X = np.ascontiguousarray(((rs.randn(b, k) * (rs.rand(b, k) < 0.1)).dot(D) + 0.1 * rs.randn(b, p)).astype(np.float32))
+    G = D.dot(D.T).astype(np.float32)
+    G = np.ascontiguousarray((G + G.T) / 2)
+    Dx = np.ascontiguousarray(X.dot(D.T).astype(np.float32))
+    idx = np.arange(b, dtype=np.int64)
+    dev = torch.device('cuda', 0)
+
+    def solve(Gdev):
+        code = torch.ones((b, k), dtype=torch.float32, device=dev)
+        fast._enet_regression_single_gram(Gdev, torch.from_numpy(Dx).to(dev), torch.from_numpy(X).to(dev), code, idx,
+                                          1.0, 0.3, False, 1e-2, 100)
+        return code.cpu().numpy()
+    aligned = torch.from_numpy(G).to(dev)
+    buf = torch.empty(k * k + 1, dtype=torch.float32, device=dev)
+    shifted = buf[1:].view(k, k)
+    shifted.copy_(aligned)
+    assert aligned.data_ptr() % 16 == 0 and shifted.data_ptr() % 16 == 4
+    want = solve(aligned)
+    np.testing.assert_array_equal(solve(shifted), want)
+    try:                                                       # the diagnostics switch selects between correct paths
+        check(L.lib.modl_debug_set(DEBUG_CD_SPLIT, 0))
+        np.testing.assert_array_equal(solve(aligned), want)
+        Gm = np.ascontiguousarray(np.broadcast_to(G, (b, k, k)))
+        code = np.ones((b, k), dtype=np.float32)
+        fast._enet_regression_multi_gram(Gm, Dx.copy(), X, code, idx, 1.0, 0.3, False, 1e-2, 100)
+        assert rel_fro(code, want) < 2e-5            # (H0 = Qw formed in another order than the shared-matrix route)
+    finally:
+        check(L.lib.modl_debug_set(DEBUG_CD_SPLIT, 1))
+
+
 @pytest.mark.parametrize('dt', [np.float32, np.float64])
 @pytest.mark.parametrize('k,b', [(128, 9), (256, 5), (70, 9), (200, 7), (600, 3)])
 def test_cd_two_solvers_agree_per_sample_gram(fast, dt, k, b):
     """A Gram matrix per sample (G_agg = 'average', dict_fact_fast.pyx:33-113) on the four-wavefront solver - k one of
     its strides: solved from where the matrices are stored; any other k: through zero-padded copies of a slice of the
     minibatch (launch_cd_per_sample) - against the one-wavefront kernel."""
+    from modl_amd import _lib as L
     from modl_amd._lib import check, DEBUG_CD_SPLIT, load_diag
-    lib = load_diag()
+    libs = {1: L.lib, 0: L.lib if k <= 256 else load_diag()}       # (as in test_cd_two_solvers_agree)
     rs = np.random.RandomState(k + b)
     p = 2 * k
     Gm = np.empty((b, k, k), dtype=dt)
@@ -355,13 +406,16 @@ def test_cd_two_solvers_agree_per_sample_gram(fast, dt, k, b):
     out = {}
     try:
         for split in (0, 1):
+            lib = libs[split]
             check(lib.modl_debug_set(DEBUG_CD_SPLIT, split))
             code = np.ones((b, k), dtype=dt)
             sw = np.zeros(b, dtype=np.int32)
             fast._enet_regression_multi_gram(Gm.copy(), Dx.copy(), X, code, idx, 0.9, 0.3, False, 1e-2, 100, sweeps=sw, _lib=lib)
+            check(lib.modl_debug_set(DEBUG_CD_SPLIT, 1))
             out[split] = (code, sw)
     finally:
-        check(lib.modl_debug_set(DEBUG_CD_SPLIT, 1))
+        for lib in libs.values():
+            check(lib.modl_debug_set(DEBUG_CD_SPLIT, 1))
     same = _assert_solvers_agree(dt, out[1], out[0], k)
     if dt == np.float32:
         err = np.linalg.norm(out[1][0][same] - out[0][0][same]) / np.linalg.norm(out[0][0][same])

@@ -378,3 +378,45 @@ def test_chunk_call_error_books_the_enqueued_minibatches():
     want = np.zeros(200, dtype=int)
     want[100:100 + 40 + 3 * b] = 1
     assert_array_equal(est.sample_n_iter_, want)
+
+
+def test_failed_native_communicator_takes_the_torch_route():
+    """when the library's RCCL communicator cannot be created (native_comm() returns None on every
+    rank) the one-call-per-chunk route must NOT run with comm = None - that is the single-GPU step without any
+    reduction, and the replicas would diverge silently.  The per-minibatch phase1 / all-reduce / phase2 loop with
+    torch's collective runs instead, from the very first partial_fit on."""
+    rs = np.random.RandomState(11)
+    X = rs.randn(48, 20)
+    est = HostDictFact(n_components=4, batch_size=8, reduction=2, random_state=0, code_alpha=0.1)
+    est.prepare(n_samples=48, X=X)
+    be = est._backend
+    est._force_reduce = True                                  # (what world > 1 switches on; one process here)
+    est._native_rccl = True                                   # the library's communicator is wanted ...
+    trace = []
+
+    def native_comm(dist_):                                   # ... and cannot be created
+        trace.append('native_comm')
+        be._comm_failed = True
+        return None
+    be.native_comm = native_comm
+
+    def fit_chunk(*a, **kw):
+        raise AssertionError('the chunk call ran without a communicator: no reduction at all')
+    be.fit_chunk = fit_chunk
+    be.step_dist = lambda *a, **kw: (_ for _ in ()).throw(AssertionError('step_dist without a communicator'))
+    p1, p2 = be.phase1, be.phase2
+    be.phase1 = lambda *a, **kw: (trace.append('phase1'), p1(*a, **kw))[1]
+    be.phase2 = lambda *a, **kw: (trace.append('phase2'), p2(*a, **kw))[1]
+    est._all_reduce = lambda head: trace.append('all_reduce')
+    assert est._chunk_call_applies(be, None)                  # the route the first call would have taken
+    est.partial_fit(X)
+    assert trace[0] == 'native_comm'
+    assert trace[1:] == ['phase1', 'all_reduce', 'phase2'] * 6
+    # the same rows through the plain one-rank loop: the identity "reduction" changes nothing
+    ref = HostDictFact(n_components=4, batch_size=8, reduction=2, random_state=0, code_alpha=0.1)
+    ref.prepare(n_samples=48, X=X)
+    ref.partial_fit(X)
+    assert rel_fro(est.components_, ref.components_) < 1e-12
+    # a second call goes straight to torch's route (the failure is remembered)
+    est.partial_fit(X)
+    assert trace.count('native_comm') == 1
