@@ -60,6 +60,13 @@ def _load():
         if not os.path.exists(path):
             raise ImportError('modl_amd: MODL_AMD_DIAG=1 but %s is missing (make -C modl_amd/csrc)' % path)
         return C.CDLL(path)
+    # MODL_HIP_LIBRARY=<path>: an A/B build of the same sources (scripts/build_variant.sh -> build_ab/<name>/libmodl_hip.so)
+    # takes the product library's place for THIS process; the product library on disk is never overwritten
+    override = os.environ.get('MODL_HIP_LIBRARY')
+    if override:
+        if not os.path.exists(override):
+            raise ImportError('modl_amd: MODL_HIP_LIBRARY=%s does not exist' % override)
+        return C.CDLL(os.path.abspath(override))
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             'modl_amd: %s is missing. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
