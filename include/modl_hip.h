@@ -79,6 +79,7 @@ const char *modl_error_string(int code);
 #define MODL_DEBUG_ATOM_STAMPS 6      /* (diagnostics library) value = device pointer to 64 uint64, zeroed by the caller (0: off): cycle sums of the projecting workgroup of the grouped atom update (bcd.hip: atom_project_group_kernel) */
 #define MODL_DEBUG_BCD_TINY 7         /* 1 (default): the f64 blocked dictionary update of at most 192 sampled features runs as ONE one-workgroup launch; 0: five launches per block of 32 atoms */
 #define MODL_DEBUG_STAGE_AHEAD 8      /* 1 (default): inside modl_somf_partial_fit_chunk the next minibatch's parameters are copied to HBM by a workgroup of the dictionary update's last launch; 0: a staging launch at the head of every step */
+#define MODL_DEBUG_BCD_PERSIST 9      /* 1 (default): the f32 blocked dictionary update runs as ONE persistent launch (a resolver workgroup + one workgroup per 32 / 64 sampled rows resident in LDS, look-ahead Gram matrices: csrc/bcd_persist.hip) whenever its workgroups fit the chip; 0: one launch per block of 32 atoms */
 int modl_debug_set(int what, int64_t value);
 /* 1 in libmodl_hip_diag.so (built with -DMODL_DIAG: the same sources plus the A/B-only kernel variants and the stamp
  * switches), 0 in the product library */
@@ -417,6 +418,11 @@ int modl_somf_sweeps_history(modl_somf_plan *plan, int32_t *d_buf, int64_t cap_m
 /* diagnostics: 48 shader-clock stamps of the last fused dictionary-update block launch (40 ..: the first riding tile),
  * h_out[48] (synchronises the device) */
 int modl_somf_debug_stamps(modl_somf_plan *plan, unsigned long long *h_out);
+/* diagnostics: 192 shader-clock stamps of the last PERSISTENT dictionary-update launch (csrc/bcd_persist.hip; written by the
+ * diagnostics build only): [0] resolver start, [1 + 5 b ..] per block b: arrivals complete, pieces in LDS, Gram matrix
+ * formed, recursion done, S published; [96] row workgroup 0 start, [97] block 0 handed over, [98 + 4 b ..] per block b >= 1:
+ * S of block b - 2 fetched, applied + corrected, candidates formed, pieces handed over */
+int modl_somf_debug_persist_stamps(modl_somf_plan *plan, unsigned long long *h_out);
 
 /* diagnostics (env MODL_GEMM_STAMPS=1): h_out[8] = shader-clock stamps of one tile of the head statistics product:
  * [0] entry, [1] loads issued, [2] first K-tile in LDS, [3] K loop done, [4] epilogue done; [6], [7] = 100 MHz wall

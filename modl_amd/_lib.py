@@ -19,6 +19,7 @@ DEBUG_BCD_ACC = 5
 DEBUG_ATOM_STAMPS = 6
 DEBUG_BCD_TINY = 7
 DEBUG_STAGE_AHEAD = 8
+DEBUG_BCD_PERSIST = 9
 AGG = {'masked': 0, 'full': 1, 'average': 2}
 OPT = {'variational': 0, 'sgd': 1}
 
@@ -167,6 +168,7 @@ def bind(lib):
     _sig('modl_somf_full_gram', C.c_int, _vp, _vp, _vp, _vp)
     _sig('modl_somf_transform', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp)
     _sig('modl_somf_debug_stamps', C.c_int, _vp, _vp)
+    _sig('modl_somf_debug_persist_stamps', C.c_int, _vp, _vp)
     _sig('modl_somf_debug_gemm_stamps', C.c_int, _vp, _vp)
     _sig('modl_somf_last_sweeps', C.c_int, _vp, _vp, C.c_int, _P(C.c_int), _vp)
     _sig('modl_somf_sweeps_history', C.c_int, _vp, _vp, _i64)

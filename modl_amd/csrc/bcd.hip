@@ -38,9 +38,12 @@ namespace modl {
 std::atomic<int> g_bcd_acc{1};
 std::atomic<unsigned long long *> g_atom_stamps{nullptr};
 std::atomic<int> g_bcd_tiny{1};
+// diagnostics (modl_debug_set(MODL_DEBUG_BCD_PERSIST, 0)): one launch per block of 32 atoms (bcd_block_kernel) instead of the
+// persistent launch of bcd_persist.hip
+std::atomic<int> g_bcd_persist{1};
 
 struct DuLayout {
-    size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, off_BsP, off_gpartial, off_norm_in, total;
+    size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, off_BsP, off_gpartial, off_norm_in, off_pacc, off_prec, off_Sbuf, off_pflags, off_qcoef, off_pstamps, total;
     int64_t nslab_max, nwg_grad;
 };
 
@@ -72,12 +75,26 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     L.off_BsP = take(tsz * (size_t)s_max * k4);                       // packed B rows (packed D shares off_Dnew)
     L.off_gpartial = take(sizeof(double) * 2 * (size_t)kCounters * (kNB * kNB + kNB));   // group sums (two-level reduction), ping-pong
     L.off_norm_in = take(tsz * k4);
+    // the persistent launch (bcd_persist.hip; f32, <= 512 atoms): one accumulator (x kAccShards) of the look-ahead pieces,
+    // one S buffer and one pair of flags per block of 32 atoms, two sets of per-workgroup records, Q against the block before
+    const bool persist = tsz == 4 && k <= 32 * kPersistBlocksMax;
+    const size_t nblk = (size_t)cdiv(k, kNB);
+    L.off_pacc = take(persist ? sizeof(long long) * nblk * kAccShards * kPAccWords : 0);
+    L.off_prec = take(persist ? sizeof(double) * 2 * (size_t)std::min<int64_t>(L.nslab_max, kPersistRowsMax) * kPEntries : 0);
+    L.off_Sbuf = take(persist ? sizeof(double) * nblk * kNB * kNB : 0);
+    L.off_pflags = take(persist ? sizeof(unsigned int) * 64 : 0);      // arrive[16], sflag[16], err
+    L.off_qcoef = take(persist ? sizeof(double) * (size_t)kNB * k4 : 0);
+    L.off_pstamps = take(persist ? sizeof(unsigned long long) * kPersistStampWords : 0);
     L.total = o;
     return L;
 }
 
 size_t dict_update_stamps_offset(int dtype, int64_t s_max, int k) {
     return du_layout(dtype == MODL_F32 ? 4 : 8, s_max, k).off_Tp + sizeof(double) * 2 * (kNB * kNB + kNB) + 256;
+}
+
+size_t dict_update_persist_stamps_offset(int dtype, int64_t s_max, int k) {
+    return du_layout(dtype == MODL_F32 ? 4 : 8, s_max, k).off_pstamps;
 }
 
 size_t dict_update_workspace(int dtype, int64_t s_max, int k) {
@@ -135,10 +152,22 @@ template <typename T>
 __global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_t *order, int k, int kp, T *CPP, T *cdiag,
                                                         int32_t *frozen, double *coef_all, unsigned int *counter,
                                                         const T *comp_norm, T *norm_in, const T *Dt, const T *Bt,
-                                                        const int32_t *subset, int64_t s, T *DsP, T *BsP, long long *acc) {
+                                                        const int32_t *subset, int64_t s, T *DsP, T *BsP, long long *acc,
+                                                        long long *pacc, long long pacc_words, double *qcoef, unsigned int *pflags,
+                                                        long long *sbuf, long long sbuf_words) {
     // kp = k rounded up to a multiple of 4: the packed arrays carry kp - k dead atoms (zero columns, frozen), so that the
     // 16-byte fragments of the block kernel exist for every number of atoms
     int id = (int)blockIdx.x;
+    if (pacc) {                                       // the persistent launch's accumulators (a slice per workgroup) and flags
+        const long long sl = (pacc_words + gridDim.x - 1) / gridDim.x;
+        const long long e1 = ((long long)(id + 1) * sl < pacc_words) ? (long long)(id + 1) * sl : pacc_words;
+        for (long long e = (long long)id * sl + threadIdx.x; e < e1; e += 256) pacc[e] = 0;
+        if (id == 0 && threadIdx.x < 64) pflags[threadIdx.x] = 0;
+        // the S buffers: sentinels, which the resolver's 8-byte stores replace - the data is its own flag (bcd_persist.hip: fetch_S)
+        const long long ss = (sbuf_words + gridDim.x - 1) / gridDim.x;
+        const long long s1 = ((long long)(id + 1) * ss < sbuf_words) ? (long long)(id + 1) * ss : sbuf_words;
+        for (long long e = (long long)id * ss + threadIdx.x; e < s1; e += 256) sbuf[e] = kPersistSentinel;
+    }
     if (id < kNB) {
         const int m = id;
         if (acc) {                                    // the accumulators, a slice per workgroup of this group
@@ -165,6 +194,15 @@ __global__ __launch_bounds__(256) void bcd_setup_kernel(const T *C, const int32_
                 if (d > (T)1e-20) c = (double)C[(int64_t)oi * k + oj] / (double)d;
             }
             coef_all[(int64_t)jj * kNB + m] = c;          // [sweep position][atom of its block]: one contiguous row per step
+            if (qcoef) {                                  // ... and against atom m of the block BEFORE (look-ahead: gram_ahead)
+                double qv = 0;
+                if (jj < k && jb0 >= kNB) {
+                    const int oi = order[jb0 - kNB + m], oj = order[jj];
+                    const T d = C[(int64_t)oj * k + oj];
+                    if (d > (T)1e-20) qv = (double)C[(int64_t)oi * k + oj] / (double)d;
+                }
+                qcoef[(int64_t)jj * kNB + m] = qv;
+            }
         }
         return;
     }
@@ -1983,12 +2021,35 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             }();
             if (RT == 2 && cdiv(s, 64) > ncu_blk && cdiv(s, 96) <= ncu_blk) RT = 3;
         }
+        // ONE persistent launch per dictionary update (bcd_persist.hip) when its workgroups - one per 32 or 64 sampled rows
+        // plus the resolver - can all be resident at once; otherwise one launch per block of 32 atoms
+        int persist_rt = 0;
+        if (fused && g_bcd_persist.load(std::memory_order_relaxed) && g_bcd_acc.load(std::memory_order_relaxed) &&
+            cdiv(k, kNB) <= kPersistBlocksMax) {
+            static const int ncu_p = [] {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                    return prop.multiProcessorCount;
+                return 256;
+            }();
+            // (more than 64 row workgroups - reduction 1, config 5 - stay with one launch per block for now: their atomics on the
+            //  shared accumulators are what a phase lasts; modl_debug_set(MODL_DEBUG_BCD_PERSIST, 2) takes them anyway)
+            const int64_t rows_max = g_bcd_persist.load(std::memory_order_relaxed) >= 2 ? std::min<int64_t>(kPersistRowsMax, ncu_p - 1) : 64;
+            if (cdiv(s, 32) <= rows_max) persist_rt = 1;
+            else if (kp <= 256 && cdiv(s, 64) <= rows_max) persist_rt = 2;
+        }
+        if (persist_rt) RT = persist_rt;
         const int nslab = fused ? (int)cdiv(s, 32 * RT) : (int)cdiv(s, kGramRows);
         const int GPW = (kp <= 256) ? 8 : 16;
         void (*blk)(BcdBlockArgs, BcdRiderArgs) = nullptr;
         T *DsP = reinterpret_cast<T *>(ws + L.off_Dnew), *BsP = reinterpret_cast<T *>(ws + L.off_BsP), *CPP = CP;
         // the Gram accumulators of the fused path (three in rotation; in the space of the group sums, which they replace)
-        long long *fused_acc = (fused && g_bcd_acc.load(std::memory_order_relaxed)) ? reinterpret_cast<long long *>(ws + L.off_gpartial) : nullptr;
+        long long *fused_acc = (fused && !persist_rt && g_bcd_acc.load(std::memory_order_relaxed)) ? reinterpret_cast<long long *>(ws + L.off_gpartial) : nullptr;
+        const int pshards = nslab > MODL_ACC_SHARD_MIN ? kAccShards : 1;
+        long long *pacc = persist_rt ? reinterpret_cast<long long *>(ws + L.off_pacc) : nullptr;
+        unsigned int *pflags = reinterpret_cast<unsigned int *>(ws + L.off_pflags);
+        double *qcoef = persist_rt ? reinterpret_cast<double *>(ws + L.off_qcoef) : nullptr;
         static_assert(sizeof(long long) * 3 * kAccShards * kAccWords <= sizeof(double) * 2 * (size_t)kCounters * (kNB * kNB + kNB), "accumulators fit");
         if (fused) {
             blk = (RT == 1) ? (GPW == 8 ? bcd_block_kernel<1, 8> : bcd_block_kernel<1, 16>)
@@ -1997,7 +2058,9 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                                          160 * 1024));
             hipLaunchKernelGGL((bcd_setup_kernel<T>), dim3((unsigned)(kNB + cdiv(kp, kSetupRows) + cdiv(s, kSetupRows))), dim3(256), 0, stream, a.C, a.order, k, kp, CPP,
                                cdiag, frozen, coef_all, counter, a.comp_norm, reinterpret_cast<T *>(ws + L.off_norm_in), a.Dt,
-                               a.Bt, a.subset, s, DsP, BsP, fused_acc);
+                               a.Bt, a.subset, s, DsP, BsP, fused_acc, pacc,
+                               (long long)cdiv(k, kNB) * pshards * kPAccWords, qcoef, pflags,
+                               reinterpret_cast<long long *>(ws + L.off_Sbuf), persist_rt ? (long long)cdiv(k, kNB) * kNB * kNB : 0);
             MODL_LAUNCH_CHECK();
             ++nl;
         } else {
@@ -2037,7 +2100,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         }
         // deferred statistics product riding along (launches 1 .. nblk carry cdiv(tiles, nblk) tiles each)
         BcdRiderArgs rid;
-        rid.nslab = nslab;
+        rid.nslab = persist_rt ? nslab + 1 : nslab;                 // (the persistent launch: the resolver in front of the row workgroups)
 #ifdef MODL_DIAG
         if (fused) rid.dbg = reinterpret_cast<unsigned long long *>(counter + kCounters) + 40;     // (stamps of the first riding tile)
 #endif
@@ -2067,7 +2130,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                         return prop.multiProcessorCount;
                     return 256;
                 }();
-                const int free_cu = (ncu - nslab > 64) ? ncu - nslab : 64;
+                const int free_cu = (ncu - rid.nslab > 64) ? ncu - rid.nslab : 64;
                 const int nblk_all = (int)cdiv(k, kNB);
                 int carriers = (int)cdiv(ride_tiles, free_cu);
                 if (carriers > nblk_all) carriers = nblk_all;
@@ -2089,6 +2152,34 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             ride_next = r.t1;
             return r.t1 - r.t0;
         };
+        if (persist_rt) {
+            BcdPersistArgs pa;
+            pa.DsP = reinterpret_cast<const float *>(DsP); pa.BsP = reinterpret_cast<const float *>(BsP);
+            pa.CPP = reinterpret_cast<const float *>(CPP); pa.cdiag = reinterpret_cast<const float *>(cdiag);
+            pa.frozen = frozen; pa.order = a.order; pa.subset = a.subset;
+            pa.coef_all = coef_all; pa.qcoef = qcoef;
+            pa.norm_in = reinterpret_cast<const float *>(ws + L.off_norm_in);
+            pa.norm_out = reinterpret_cast<float *>(a.comp_norm);
+            pa.Dt_out = reinterpret_cast<float *>(a.Dt);
+            pa.acc = pacc;
+            pa.rec = reinterpret_cast<double *>(ws + L.off_prec);
+            pa.Sbuf = reinterpret_cast<double *>(ws + L.off_Sbuf);
+            pa.arrive = pflags; pa.sflag = pflags + kPersistBlocksMax; pa.err = pflags + 2 * kPersistBlocksMax;
+            pa.stamps = reinterpret_cast<unsigned long long *>(ws + L.off_pstamps);
+            pa.s = s; pa.k = kp; pa.kout = k; pa.nblk = (int)cdiv(k, kNB); pa.nrow = nslab; pa.shards = pshards;
+            BcdRiderArgs r = rid;                                       // every riding tile with the one launch
+            r.t0 = 0; r.t1 = ride_tiles;
+            int extra = ride_tiles;
+            if (a.stage && a.stage->src) {                              // + one workgroup: the next minibatch's parameters
+                r.stage = *a.stage;
+                a.stage->consumed = 1;
+                ++extra;
+            }
+            MODL_TRY(launch_bcd_persist(stream, pa, r, extra, (ride_tiles > 0 && rid.wide) ? wide_lds_bytes<32, 128>() : 0, persist_rt));
+            ++nl;
+            if (launches) *launches += nl;
+            return MODL_OK;
+        }
         int blk_i = 0, j0_prev = 0, nb_prev = 0;
         for (int j0 = 0; j0 < k; j0 += kNB, ++blk_i) {
             const int nb = (k - j0 < kNB) ? k - j0 : kNB;

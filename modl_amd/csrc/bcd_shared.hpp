@@ -28,6 +28,7 @@ extern std::atomic<int> g_bcd_acc;
 extern std::atomic<unsigned long long *> g_atom_stamps;
 // diagnostics (modl_debug_set(MODL_DEBUG_BCD_TINY, 0)): the separate launches of the blocked update also for small sampled sets
 extern std::atomic<int> g_bcd_tiny;
+extern std::atomic<int> g_bcd_persist;   // bcd.hip (modl_debug_set(MODL_DEBUG_BCD_PERSIST, ...))
 constexpr int kAccWords = 3 * (2 * 136 + 256 + kNB) + 2;   // int64 words of one Gram accumulator (3 bins x packed record + the out-of-range word: kAccStride below)
 constexpr int kSetupRows = 8;      // rows per workgroup of bcd_setup_kernel's gathers
 constexpr int kAccShards = 4;      // accumulators side by side for large grids (acc_load_sharded; a power of two)
@@ -533,8 +534,10 @@ __device__ __forceinline__ void resolve_chain(const double *D2, const double *Cs
 }
 
 // CsT[i][m] = Cs[m][i]: the coefficients that multiply S[i], contiguous in m
+// gS (optional): every row of S also goes to global memory as it is produced, write-through (the persistent launch: the row
+// workgroups read it; by the end of the recursion all rows but the last have long arrived)
 __device__ __forceinline__ void resolve_helper(const double *Base, const double *CsT, double *CAout,
-                                               int ca_stride, const ResolveMail &mb) {
+                                               int ca_stride, const ResolveMail &mb, double *gS = nullptr) {
     const int lane = threadIdx.x & 63, x = lane & 31;
     const bool lower = lane < 32;
     lds_vf64 *Pm = (lds_vf64 *)mb.Pm;
@@ -580,6 +583,9 @@ __device__ __forceinline__ void resolve_helper(const double *Base, const double 
             *pcount = (i + 3 == kNB - 1) ? kNB + 1 : i + 4;  // (+ the row the chain wave's last step asks for)
         }
         if (lower) CAout[i * ca_stride + x] = Zi;            // S[i] for the apply step
+        if (lower && gS)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(gS + i * kNB + x), (unsigned long long)__double_as_longlong(Zi),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (an sc1 store)
 #pragma unroll
         for (int m = i + 4; m < kNB; ++m) {
             P[m] = __builtin_fma(-cc[m / 2][m % 2], Zi, P[m]);
@@ -655,5 +661,42 @@ __device__ __forceinline__ void bcd_rider_tile(const BcdRiderArgs &r, char *smem
     if (r.wide == 32) gemm_wide_tile<32, EpiStatsSkip<float>, 128>(r.W, id, smem, (id == r.t0 && r.dbg) ? r.dbg : nullptr);
     else gemm_stats_tile<EpiStatsSkip<float>>(r.P, id, smem);     // the very tile of gemm_stats_pair_kernel: same bits
 }
+
+
+// ---- the persistent launch (bcd_persist.hip) ---------------------------------------------------------------------------
+// per-block accumulator of the look-ahead pieces: X = <a', N'> (32 x 32), the packed Gram matrix of the previous block's
+// candidates M' = <a', a'> (528), the packed <N', N'> (528), the old squared norms of the block's columns (32)
+constexpr int kPX = 0, kPMp = kNB * kNB, kPNN = kPMp + 2 * kTri + 256, kPD2 = kPNN + 2 * kTri + 256;
+constexpr int kPEntries = kPD2 + kNB;                       // 2112
+constexpr int kPAccWords = kAccBins * kPEntries + 2;        // three fixed-point bins per entry + the out-of-range word + the top-bins-used word
+constexpr int kPersistBlocksMax = 16;                       // 512 atoms
+constexpr int kPersistRowsMax = 255;                        // row workgroups (+ the resolver: co-resident on 256 compute units)
+constexpr int kPersistStampWords = 192;
+constexpr long long kPersistSentinel = 0x7ff8c0dec0dec0dell;   // fills the S buffers before a persistent launch: a NaN no recursion produces
+static_assert(kPEntries % 2 == 0 && (kPAccWords * 8) % 16 == 0, "16-byte pairs");
+struct BcdPersistArgs {
+    const float *DsP;               // packed sampled rows of the dictionary [s][k], fragment order (bcd_setup_kernel), read once
+    const float *BsP;               // [s][k] sampled rows of B_
+    const float *CPP;               // C in sweep coordinates, fragment order, the in-block part masked
+    const float *cdiag;
+    const int32_t *frozen, *order, *subset;
+    const double *coef_all;         // [k][32] recursion coefficients (against the atoms of the same block)
+    const double *qcoef;            // [k][32] Q against the atoms of the block BEFORE
+    const float *norm_in;           // budgets before this update, sweep order
+    float *norm_out;                // comp_norm
+    float *Dt_out;                  // the real dictionary [p][kout]
+    long long *acc;                 // [nblk][shards][kPAccWords], zero on entry
+    double *rec;                    // [2][nrow][kPEntries] per-workgroup records (the out-of-range fallback)
+    double *Sbuf;                   // [nblk][32 * 32]
+    unsigned int *arrive, *sflag;   // [nblk] each, zero on entry
+    unsigned int *err;              // raised by a wait that gave up (zero on entry)
+    unsigned long long *stamps;     // diagnostics build: [kPersistStampWords]
+    int64_t s;
+    int k, kout, nblk, nrow, shards;
+};
+size_t bcd_persist_lds(int kp, int RT);
+// grid: the resolver, nrow row workgroups of 32 RT rows, extra_wgs riding workgroups (rider.nslab must be nrow + 1)
+int launch_bcd_persist(hipStream_t stream, const BcdPersistArgs &p, const BcdRiderArgs &rider, int extra_wgs, size_t extra_lds,
+                       int RT);
 
 }  // namespace modl

@@ -517,6 +517,7 @@ extern std::atomic<unsigned long long *> g_cd_stamps;   // cd_split.hip
 extern std::atomic<unsigned long long *> g_atom_stamps; // bcd.hip
 extern std::atomic<int> g_bcd_acc;                      // bcd.hip
 extern std::atomic<int> g_bcd_tiny;                     // bcd.hip
+extern std::atomic<int> g_bcd_persist;                  // bcd.hip
 extern std::atomic<int> g_stage_ahead;                  // somf_step.hip
 
 template <typename T>
@@ -714,6 +715,10 @@ extern "C" int modl_debug_set(int what, int64_t value) {
     }
     if (what == MODL_DEBUG_BCD_TINY) {
         modl::g_bcd_tiny.store((int)value, std::memory_order_relaxed);
+        return MODL_OK;
+    }
+    if (what == MODL_DEBUG_BCD_PERSIST) {
+        modl::g_bcd_persist.store((int)value, std::memory_order_relaxed);
         return MODL_OK;
     }
     if (what == MODL_DEBUG_BCD_ACC) {

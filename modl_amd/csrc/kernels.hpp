@@ -163,6 +163,7 @@ struct DictUpdateArgs {
 };
 size_t dict_update_workspace(int dtype, int64_t s_max, int k);
 size_t dict_update_stamps_offset(int dtype, int64_t s_max, int k);
+size_t dict_update_persist_stamps_offset(int dtype, int64_t s_max, int k);
 template <typename T> int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches);
 
 }  // namespace modl

@@ -1568,6 +1568,16 @@ int modl_somf_debug_stamps(modl_somf_plan *pl, unsigned long long *h_out) {
     return MODL_OK;
 }
 
+int modl_somf_debug_persist_stamps(modl_somf_plan *pl, unsigned long long *h_out) {
+    // diagnostics only: the stamps the resolver ([0, 96)) and row workgroup 0 ([96, 192)) of the last persistent
+    // dictionary-update launch left (written by the diagnostics build only)
+    if (!pl || !h_out) return MODL_EINVAL;
+    MODL_HIP(hipDeviceSynchronize());
+    const size_t off = modl::dict_update_persist_stamps_offset(pl->d.dtype, pl->last_s, pl->d.k);
+    MODL_HIP(hipMemcpy(h_out, pl->dws + pl->off_du + off, 192 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return MODL_OK;
+}
+
 int modl_somf_debug_gemm_stamps(modl_somf_plan *pl, unsigned long long *h_out) {
     // diagnostics only (MODL_GEMM_STAMPS=1): stamps of the last tile of the head product of the single-GPU step
     if (!pl || !h_out) return MODL_EINVAL;

@@ -36,14 +36,19 @@ class Recorder:
 
 
 @pytest.mark.parametrize('name', _cases())
-def test_trajectory_small_golden(DictFact, name):
+def test_trajectory_small_golden(DictFact, oracle, name):
     """All aggregation modes / optimizers / atom constraints: the whole fit, against what the
-    reference produced (tests/golden/traj_small.npz)."""
+    reference produced (tests/golden/traj_small.npz).  f32 end states: within the reference's own f32 noise while every
+    sample did the f64 oracle's number of sweeps; a sample whose duality gap sits on the threshold may legitimately do one
+    sweep more or less when its inputs differ in the last bits (these small cases have samples at 80 - 90 of max_iter = 100
+    sweeps) - such flips are located with the sweep history, bounded, and allow 6e-5 more, as in the long-horizon test."""
     g = load_golden('traj_small')
     kw, X, dt = small_case_params(name)
     est = DictFact(**kw)
     est.prepare(n_samples=X.shape[0], X=X)
     rec = Recorder(est)
+    nmb = kw['n_epochs'] * -(-X.shape[0] // kw['batch_size'])
+    hist = est._backend.sweeps_history(nmb) if dt == np.float32 and hasattr(est._backend, 'sweeps_history') else None
     Xh = X
     first_codes = None
     for ep in range(kw['n_epochs']):
@@ -71,10 +76,16 @@ def test_trajectory_small_golden(DictFact, name):
         # f32 end state (two epochs): float summation order is unpinned, so the yardstick is the
         # reference's OWN f32 noise - its f32 run against its f64 run of the same case - not a flat tolerance
         ref64 = name[:-3] + 'f64'
+        flips = 0
+        if hist is not None and kw.get('code_l1_ratio', 1) != 0:
+            sw64 = oracle.fit(oracle.SomfParams(**kw), X.astype(np.float64), sweeps=True).sweeps
+            sw = hist()
+            flips = sum(int((sw[t, :len(a)] != a).sum()) for t, a in enumerate(sw64))
+            assert flips <= max(1, 5e-3 * sum(len(a) for a in sw64)), flips
         for key, val in (('D_final', est.components_), ('code_final', est.code_), ('C_final', est.C_)):
             noise = rel_fro(g[name + '/' + key], g[ref64 + '/' + key])
             err = rel_fro(val, g[ref64 + '/' + key])
-            assert err <= 2 * noise + 1e-5, (key, err, noise)
+            assert err <= 2 * noise + 1e-5 + (6e-5 if flips else 0.0), (key, err, noise, flips)
     assert est.n_iter_ == int(g[name + '/n_iter'])
 
 
@@ -334,14 +345,17 @@ def test_gram_accumulator_out_of_range_falls_back_to_records(DictFact, scale, p,
     hand, nothing a fit produces - must not come back as a wrapped integer sum, and candidate atoms of norm ~1e-10 (squared
     norms under 2^-40) must not lose their relative precision to the absolute bins: in both cases the block is summed
     from the per-workgroup records, the same result as with the accumulator switched off."""
-    from modl_amd._lib import lib, check, DEBUG_BCD_ACC
+    from modl_amd._lib import lib, check, DEBUG_BCD_ACC, DEBUG_BCD_PERSIST
     rs = np.random.RandomState(0)
     X = ((rs.randn(256, 32) * (rs.rand(256, 32) < 0.3)).dot(rs.randn(32, p)) / np.sqrt(0.3 * 32)
          + 0.1 * rs.randn(256, p)).astype(np.float32)
     out = {}
     try:
-        for acc in (1, 0):
-            check(lib.modl_debug_set(DEBUG_BCD_ACC, acc))
+        # 2: the persistent launch (csrc/bcd_persist.hip: look-ahead accumulators, the same fixed-point bins and the same
+        # fallback to per-workgroup records); 1: one launch per block with the accumulator; 0: ... with the records
+        for acc in (2, 1, 0):
+            check(lib.modl_debug_set(DEBUG_BCD_PERSIST, 1 if acc == 2 else 0))
+            check(lib.modl_debug_set(DEBUG_BCD_ACC, min(acc, 1)))
             est = DictFact(n_components=64, batch_size=64, reduction=red, code_alpha=0.1, learning_rate=0.92, random_state=0)
             est.prepare(n_samples=256, X=X[:64])
             est.partial_fit(X[:64])
@@ -355,11 +369,14 @@ def test_gram_accumulator_out_of_range_falls_back_to_records(DictFact, scale, p,
             out[acc] = (est.components_, est.comp_norm_)
     finally:
         check(lib.modl_debug_set(DEBUG_BCD_ACC, 1))
-    D1, D0 = out[1][0], out[0][0]
-    assert np.all(np.isfinite(D1)) and np.all(np.isfinite(out[1][1]))
-    if scale > 1:
-        assert np.all(np.abs(np.sqrt(np.sum(D1.astype(np.float64) ** 2, axis=1)) - 1) < 1e-4)   # projected onto the ball
-    assert rel_fro(D1, D0) < 1e-6
+        check(lib.modl_debug_set(DEBUG_BCD_PERSIST, 1))
+    D0 = out[0][0]
+    for acc, tol in ((1, 1e-6), (2, 1e-5)):    # (the persistent launch rounds its f32 candidates in another order: a - N' cancels)
+        D1 = out[acc][0]
+        assert np.all(np.isfinite(D1)) and np.all(np.isfinite(out[acc][1]))
+        if scale > 1:
+            assert np.all(np.abs(np.sqrt(np.sum(D1.astype(np.float64) ** 2, axis=1)) - 1) < 1e-4)   # projected onto the ball
+        assert rel_fro(D1, D0) < tol, (acc, rel_fro(D1, D0))
 
 
 @pytest.mark.parametrize('k,p,b,red', [(320, 1200, 64, 2), (512, 700, 48, 1), (40, 333, 32, 3), (250, 1200, 64, 2), (70, 2001, 96, 3)])
