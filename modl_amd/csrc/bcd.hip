@@ -2033,9 +2033,10 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
                     return prop.multiProcessorCount;
                 return 256;
             }();
-            // (more than 64 row workgroups - reduction 1, config 5 - stay with one launch per block for now: their atomics on the
-            //  shared accumulators are what a phase lasts; modl_debug_set(MODL_DEBUG_BCD_PERSIST, 2) takes them anyway)
-            const int64_t rows_max = g_bcd_persist.load(std::memory_order_relaxed) >= 2 ? std::min<int64_t>(kPersistRowsMax, ncu_p - 1) : 64;
+            // (every workgroup must be resident: the resolver + one per 32 or 64 sampled rows.  Reduction 1 at the metric's shape:
+            //  157 workgroups of 64 rows, 0.173 -> 0.138 ms per dictionary update against one launch per block; config 5's
+            //  16.7 k sampled rows do not fit and keep one launch per block)
+            const int64_t rows_max = std::min<int64_t>(kPersistRowsMax, ncu_p - 1);
             if (cdiv(s, 32) <= rows_max) persist_rt = 1;
             else if (kp <= 256 && cdiv(s, 64) <= rows_max) persist_rt = 2;
         }

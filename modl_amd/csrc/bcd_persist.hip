@@ -582,26 +582,49 @@ __device__ __forceinline__ void persist_rows(const BcdPersistArgs &p, char *smem
     };
     auto prod_mma = [&](int nb, int gb, int skip_lo, int skip_hi, const f4v (&bf)[16], f4v (&acc)[RT]) {
         const bool cok = col < nb;
+        // The row fragments of GH steps are read from LDS up front (one wait instead of one LDS round trip per step), and
+        // the four products of a step go to FOUR accumulators: as one chain on one accumulator the 64 products of a block
+        // each waited for their predecessor (40 cycles dependent against 32 issued) behind an LDS round trip per step -
+        // 4.6 k cycles for 2 k of matrix-core time (ISA).
+        constexpr int GH = RT == 1 ? 16 : 8;
+        f4v c4[RT][4];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            // (a skipped step contributes zeros instead of being branched around: straight-line code, every LDS read of the
-            //  batch in flight before the first product - with a branch per step each read was waited for on the spot)
-            const int gs = gb + g;
-            const int grp = 4 * gs + q;
-            const bool ok = cok && grp < KQ && !(gs >= skip_lo && gs < skip_hi);
-            f4v bb;
-            bb.x = ok ? bf[g].x : 0.f; bb.y = ok ? bf[g].y : 0.f; bb.z = ok ? bf[g].z : 0.f; bb.w = ok ? bf[g].w : 0.f;
-            const int gcl = grp < KQ ? grp : 0;
+        for (int u = 0; u < RT; ++u)
 #pragma unroll
-            for (int u = 0; u < RT; ++u) {
-                const int rt = rt0 + u;
-                const f4v a = *reinterpret_cast<const f4v *>(Dl + ((((rt >> 1) * KQ + gcl) << 5) + ((rt & 1) << 4) + m) * 4);
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bb.x, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb.y, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bb.z, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bb.w, acc[u], 0, 0, 0);
+            for (int x = 0; x < 4; ++x) c4[u][x] = (f4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g0 = 0; g0 < 16; g0 += GH) {
+            f4v af[GH][RT];
+#pragma unroll
+            for (int g = 0; g < GH; ++g) {
+                const int grp = 4 * (gb + g0 + g) + q;
+                const int gcl = grp < KQ ? grp : 0;
+#pragma unroll
+                for (int u = 0; u < RT; ++u) {
+                    const int rt = rt0 + u;
+                    af[g][u] = *reinterpret_cast<const f4v *>(Dl + ((((rt >> 1) * KQ + gcl) << 5) + ((rt & 1) << 4) + m) * 4);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < GH; ++g) {
+                // (a skipped step contributes zeros instead of being branched around: straight-line code)
+                const int gs = gb + g0 + g;
+                const int grp = 4 * gs + q;
+                const bool ok = cok && grp < KQ && !(gs >= skip_lo && gs < skip_hi);
+                f4v bb;
+                bb.x = ok ? bf[g0 + g].x : 0.f; bb.y = ok ? bf[g0 + g].y : 0.f; bb.z = ok ? bf[g0 + g].z : 0.f; bb.w = ok ? bf[g0 + g].w : 0.f;
+#pragma unroll
+                for (int u = 0; u < RT; ++u) {
+                    c4[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][u].x, bb.x, c4[u][0], 0, 0, 0);
+                    c4[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][u].y, bb.y, c4[u][1], 0, 0, 0);
+                    c4[u][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][u].z, bb.z, c4[u][2], 0, 0, 0);
+                    c4[u][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][u].w, bb.w, c4[u][3], 0, 0, 0);
+                }
             }
         }
+#pragma unroll
+        for (int u = 0; u < RT; ++u) acc[u] += (c4[u][0] + c4[u][1]) + (c4[u][2] + c4[u][3]);
     };
     // the whole product; bf: the fragments of the first 16 steps, already requested
     auto product = [&](int jb, int nb, int skip_lo, int skip_hi, f4v (&bf)[16], f4v (&acc)[RT]) {
@@ -678,6 +701,14 @@ __device__ __forceinline__ void persist_rows(const BcdPersistArgs &p, char *smem
     // acc += Dn . C[block js, target block] (rank 32; bf: the two coefficient fragments of corr_load, masked here)
     auto rank32 = [&](int nbt, int js, const f4v (&bf)[2], f4v (&acc)[RT]) {
         const bool cok = col < nbt;
+        f4v c1[RT];
+        f4v av[2][RT];
+#pragma unroll
+        for (int u = 0; u < RT; ++u) c1[u] = (f4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+            for (int u = 0; u < RT; ++u) av[g2][u] = *reinterpret_cast<const f4v *>(Dn + (16 * (rt0 + u) + m) * kTF + 16 * g2 + 4 * q);
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {
             const int grp = 4 * (2 * js + g2) + q;
@@ -686,13 +717,15 @@ __device__ __forceinline__ void persist_rows(const BcdPersistArgs &p, char *smem
             bb.x = ok ? bf[g2].x : 0.f; bb.y = ok ? bf[g2].y : 0.f; bb.z = ok ? bf[g2].z : 0.f; bb.w = ok ? bf[g2].w : 0.f;
 #pragma unroll
             for (int u = 0; u < RT; ++u) {
-                const f4v a = *reinterpret_cast<const f4v *>(Dn + (16 * (rt0 + u) + m) * kTF + 16 * g2 + 4 * q);
+                const f4v a = av[g2][u];                                         // (two chains: a dependent product waits 40 cycles)
                 acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bb.x, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb.y, acc[u], 0, 0, 0);
+                c1[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb.y, c1[u], 0, 0, 0);
                 acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bb.z, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bb.w, acc[u], 0, 0, 0);
+                c1[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bb.w, c1[u], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int u = 0; u < RT; ++u) acc[u] += c1[u];
     };
     // T[:, target block] -= (Dn . C[block js, target block]) / diag: its candidates with block js put back in
     auto correct = [&](int nbt, int js, float cd, int fz, float *Ttile, const f4v (&bf)[2]) {
@@ -811,22 +844,35 @@ __device__ __forceinline__ void persist_rows(const BcdPersistArgs &p, char *smem
     float Bv[RT][4], cd = 1.f, cd_prev = 1.f;
     int fz = 0, fz_prev = 0;
     f4v acc[RT], bf[16], cfr[2], cfr2[2];
-    for (int b = 0; b <= nblk + 1; ++b) {
-        refresh();
+    int oc = 0;
+    float cd_next = 1.f;
+    int fz_next = 0;
+    // everything phase b reads from memory: requested at the END of phase b - 1, in front of the wait for that phase's atomics
+    // (the requests then land while the atomics drain), phase 0's at the start
+    auto request = [&](int b) {
         const bool has_prod = b < nblk, has_apply = b >= 2, has_prev = has_apply && b - 1 < nblk;
-        const int nb = has_prod ? nb_of(b) : 0;
-        // everything this phase reads from memory is requested up front
         if (has_prod) {
-            load_epi(b, nb, Bv, cd, fz);
+            load_epi(b, nb_of(b), Bv, cd_next, fz_next);
             prod_load(b, 0, bf);
         }
-        int oc = 0;
         if (has_apply) {
             oc = p.order[(b - 2) * kNB + ((col < nb_of(b - 2)) ? col : 0)];
             if (has_prev) corr_load(b - 1, b - 2, cfr);
             if (has_prod) corr_load(b, b - 2, cfr2);
         }
         __builtin_amdgcn_sched_barrier(0);
+    };
+    // Requested at the top of its phase.  Measured and not kept (same box, dictionary update per minibatch): requested at the end
+    // of the phase before, behind the pieces (the drain in front of the arrival then waits for them too: 0.0976 -> 0.0996 ms) or in
+    // front of the pieces (their ~30 address computations sit on the chain S -> pieces -> arrival: 0.1024 ms).
+    constexpr bool kAhead = false;
+    if (kAhead) request(0);
+    for (int b = 0; b <= nblk + 1; ++b) {
+        refresh();
+        const bool has_prod = b < nblk, has_apply = b >= 2, has_prev = has_apply && b - 1 < nblk;
+        const int nb = has_prod ? nb_of(b) : 0;
+        if (!kAhead) request(b);
+        cd = cd_next; fz = fz_next;
         if (st && tid == 0 && b == 0) st[5] = clock64();
         if (b == 0) {
             // the rows -> LDS, once (rows beyond s: copies of the last one; whatever they produce is masked)
@@ -866,8 +912,11 @@ __device__ __forceinline__ void persist_rows(const BcdPersistArgs &p, char *smem
             if (!fetch_S(b - 2)) return;
             if (st && tid == 0 && b < 16) st[8 + 5 * (b - 1)] = clock64();
             apply(b - 2, nb_of(b - 2), tile(b - 2), oc);
+            if (st && tid == 0 && b == 3) st[90] = clock64();
             lds_barrier();                                                       // (LDS only: the dictionary stores stay in flight)
+            if (st && tid == 0 && b == 3) st[91] = clock64();
             if (has_prev) correct(nb_of(b - 1), b - 2, cd_prev, fz_prev, tile(b - 1), cfr);   // a_{b-1}: block b - 2 put back in
+            if (st && tid == 0 && b == 3) st[92] = clock64();
             if (has_prod) rank32(nb, b - 2, cfr2, acc);                                        // N'_b: block b - 2's new atoms
         }
         if (st && tid == 0 && b >= 1 && b < 16) st[9 + 5 * (b - 1)] = clock64();
@@ -875,11 +924,22 @@ __device__ __forceinline__ void persist_rows(const BcdPersistArgs &p, char *smem
             epilogue(b, nb, acc, Bv, cd, fz, tile(b));
             lds_barrier();
             if (st && tid == 0) st[b == 0 ? 2 : 10 + 5 * (b - 1)] = clock64();
+            cd_prev = cd; fz_prev = fz;
+            if (kAhead) {
+                // (in FRONT of the pieces: older than their atomics, the requests have landed long before the drain that
+                //  precedes the arrival ends - behind them they would lengthen it)
+                refresh();
+                request(b + 1);                                                  // (Bv, bf, cfr, cfr2, oc: all consumed by now)
+                refresh();
+            }
             pieces(b, tile(b), b > 0 ? tile(b - 1) : nullptr);
             if (st && tid == 0) st[b == 0 ? 3 : 11 + 5 * (b - 1)] = clock64();
             signal_word(p.arrive + b, true);
-            cd_prev = cd; fz_prev = fz;
+            if (st && tid == 0 && b == 3) st[93] = clock64();
             if (st && tid == 0 && b == 0) st[4] = clock64();
+        } else if (kAhead && b + 1 <= nblk + 1) {
+            refresh();
+            request(b + 1);
         }
     }
     if (st && tid == 0) st[89] = clock64();

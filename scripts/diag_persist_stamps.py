@@ -8,6 +8,12 @@ import numpy as np, torch
 import bench
 from modl_amd import DictFact
 from modl_amd._lib import lib, check
+if os.environ.get('MODL_DIAG_NO_RIDER') == '1':          # the statistics product of the rows that were not sampled as a launch of its own
+    class DictFact(DictFact):
+        def _make_backend(self):
+            be = super()._make_backend()
+            be.flags = 1                                # FLAG_NO_RIDER
+            return be
 dev = torch.device('cuda')
 X = bench.M1Stream(10000, 1234, dev).rows(0, 4096)
 for r in [float(a) for a in sys.argv[1:]] or (10.0, 1.0):
@@ -38,3 +44,4 @@ for r in [float(a) for a in sys.argv[1:]] or (10.0, 1.0):
         print('   block %d: stable product done %7d (%5d after the last pieces) | S fetched %7d (%5d) | applied + corrected %7d (%5d) | candidates %7d (%5d) | pieces issued %7d (%5d)' % (
             b, v[0], v[0] - prev, v[1] if b > 1 else -1, v[1] - v[0] if b > 1 else 0, v[2], v[2] - (v[1] if b > 1 else v[0]), v[3], v[3] - v[2], v[4], v[4] - v[3]))
     print('   end %d' % (q[89] - r0))
+    print('   phase 3 detail (cycles after S fetched): applied %d, barrier %d, corrected %d, + rank 32 %d; signalled %d after pieces issued' % (q[90] - q[8 + 5 * 2], q[91] - q[8 + 5 * 2], q[92] - q[8 + 5 * 2], q[9 + 5 * 2] - q[8 + 5 * 2], q[93] - q[11 + 5 * 2]))

@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r05_14; mkdir -p $O
+O=gpurun_out/r05_20; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
 tail -8 $O/pytest.log
 for v in 1 0; do
