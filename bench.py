@@ -40,8 +40,8 @@ sys.path.insert(0, ROOT)
 K_COMP, P_FEAT, BATCH, CHUNK, BLOCK = 256, 10000, 256, 65536, 8192
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
-PMC_FILES = ('r04_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic.json')     # the newest committed PMC passes
-DOM_KERNEL = {'dict_update': 'modl::bcd_block_kernel', 'code_solve': 'modl::cd_split_kernel', 'stats_gemm': 'modl::gemm_stats_pair_kernel',
+PMC_FILES = ('r05_pmc_hbm_traffic.json', 'r04_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic.json')     # the newest committed PMC passes
+DOM_KERNEL = {'dict_update': ('modl::bcd_persist_kernel', 'modl::bcd_block_kernel'), 'code_solve': 'modl::cd_split_kernel', 'stats_gemm': 'modl::gemm_stats_pair_kernel',
               'code_gemm': 'modl::gemm_dense_pair_kernel<float, false', 'stats_apply': 'modl::stats_apply2_kernel'}
 # the calibration of the CPU port against the real reference, measured in the build container
 # (scripts/calibrate_cpu_baseline.py -> profiles/r02_cpu_calibration.json)
@@ -500,7 +500,9 @@ def roofline_of(dom, prof_dom, fl, by, reduction):
     try:
         PMC_FILE = [f for f in PMC_FILES if os.path.exists(os.path.join(ROOT, 'profiles', f))][0]
         pmc = json.load(open(os.path.join(ROOT, 'profiles', PMC_FILE)))
-        kern = [k_ for k_ in pmc if k_.startswith(DOM_KERNEL.get(dom, '?'))]
+        names = DOM_KERNEL.get(dom, '?')
+        names = names if isinstance(names, tuple) else (names,)
+        kern = [k_ for n_ in names for k_ in pmc if k_.startswith(n_)]          # (the first name that the passes hold)
         if kern and abs(reduction - 10.0) < 1e-9:
             e = pmc[kern[0]]
             roof['traffic'] = e.get('fetch_bytes_corrected', 0.0) + e.get('write_bytes', 0.0)

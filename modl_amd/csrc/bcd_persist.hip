@@ -758,6 +758,9 @@ __device__ __forceinline__ void persist_rows(const BcdPersistArgs &p, char *smem
         }
         return g + g1;
     };
+    // (Measured and not kept: every workgroup walking its entries in an order of its own - rotated accumulator registers and
+    //  tile order, so that the same address is not hit by all 30 at once: the pieces took 4.5 k cycles instead of 3.85 k and the
+    //  drain in front of the arrival 5.8 k instead of 3.9 k.)
     auto emit_full = [&](long long *acc, double *rec, const d4v &g, int base, int ld, int it, int jt, bool &bad, bool &top) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Regenerates the round's profile artifacts on the GPU box (run through gpurun from the repo root):
-#   bash scripts/make_profiles.sh r04
+#   bash scripts/make_profiles.sh r05
 # writes gpurun_out/<tag>_*; copy what is to be judged into profiles/.
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 mkdir -p $OUT /tmp/w
@@ -56,4 +56,20 @@ done
 timeout 1500 python3 $R/tests/diag/bench_configs_full.py --only c2,c3,c4,c6 > $OUT/${TAG}_bench_configs.jsonl 2> $OUT/${TAG}_bench_configs.err
 rm -rf /tmp/w/c6; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/w/c6 -o t -- python3 $R/scripts/bench_configs.py --only c6 --c6-batches 5 > /tmp/w/c6.log 2>&1
 { tail -3 /tmp/w/c6.log; python3 $R/scripts/prof_summary.py $(find /tmp/w/c6 -name "*.db" | head -1) 0.3; } > $OUT/${TAG}_cfg_c6_kernel_trace.txt 2>&1
+ls -la $OUT | grep $TAG
+# BASELINE config 5 as a bench workload (p = 200 000, reduction 12): fused, and the two-phase step forced with one rank on
+# the library's RCCL communicator / on torch's collective - what the head mirror + scatter of 17 MB costs before a byte crosses xGMI
+for v in fused native torch; do
+  case $v in
+    fused) F="" ;;
+    native) F="--force-reduce" ;;
+    torch) F="--force-reduce --torch-collective" ;;
+  esac
+  export MASTER_PORT=$((20000 + RANDOM % 20000))
+  python3 $R/bench.py --features 200000 --reduction 12 --steps 200 --warmup 60 --no-cpu-baseline $F > $OUT/${TAG}_two_phase_c5_$v.json 2> /tmp/w/tpc5_$v.err
+done
+export MASTER_PORT=$((20000 + RANDOM % 20000))
+rm -rf /tmp/w/tpc5; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/w/tpc5 -o t -- python3 $R/bench.py --features 200000 --reduction 12 --steps 100 --warmup 40 --no-cpu-baseline --no-breakdown --force-reduce > /tmp/w/tpc5.log 2>&1
+{ echo "rocprofv3 --kernel-trace --stats -- python3 bench.py --features 200000 --reduction 12 --steps 100 --warmup 40 --no-cpu-baseline --no-breakdown --force-reduce (second half)"; python3 $R/scripts/prof_summary.py $(find /tmp/w/tpc5 -name "*.db" | head -1) 0.5; } > $OUT/${TAG}_two_phase_c5_native_kernel_trace.txt 2>&1
+python3 $R/scripts/diag_persist_stamps.py 10 1 > $OUT/${TAG}_persist_stamps.txt 2>&1
 ls -la $OUT | grep $TAG
