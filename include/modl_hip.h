@@ -43,6 +43,7 @@ extern "C" {
 #define MODL_ENOGPU (-4)   /* no HIP device available, or not a gfx950-class part (160 KiB of LDS per compute unit) */
 #define MODL_ENORCCL (-5)  /* librccl.so could not be loaded (modl_comm_*) */
 #define MODL_ERCCL (-6)    /* an RCCL call failed */
+#define MODL_ETIMEOUT (-7) /* a wait inside a persistent kernel gave up (its workgroups were not all resident): modl_somf_status */
 
 #define MODL_F32 0
 #define MODL_F64 1
@@ -79,7 +80,7 @@ const char *modl_error_string(int code);
 #define MODL_DEBUG_ATOM_STAMPS 6      /* (diagnostics library) value = device pointer to 64 uint64, zeroed by the caller (0: off): cycle sums of the projecting workgroup of the grouped atom update (bcd.hip: atom_project_group_kernel) */
 #define MODL_DEBUG_BCD_TINY 7         /* 1 (default): the f64 blocked dictionary update of at most 192 sampled features runs as ONE one-workgroup launch; 0: five launches per block of 32 atoms */
 #define MODL_DEBUG_STAGE_AHEAD 8      /* 1 (default): inside modl_somf_partial_fit_chunk the next minibatch's parameters are copied to HBM by a workgroup of the dictionary update's last launch; 0: a staging launch at the head of every step */
-#define MODL_DEBUG_BCD_PERSIST 9      /* 1 (default): the f32 blocked dictionary update runs as ONE persistent launch (a resolver workgroup + one workgroup per 32 / 64 sampled rows resident in LDS, look-ahead Gram matrices: csrc/bcd_persist.hip) whenever its workgroups fit the chip; 0: one launch per block of 32 atoms */
+#define MODL_DEBUG_BCD_PERSIST 9      /* 1 (default): the f32 blocked dictionary update runs as ONE persistent launch (a resolver workgroup + one workgroup per 32 / 64 sampled rows resident in LDS, look-ahead Gram matrices: csrc/bcd_persist.hip) whenever its workgroups fit the chip; 0: one launch per block of 32 atoms; 3 (tests): as 1, but the resolver waits for a workgroup that never comes - the bounded waits give up, modl_somf_status reports MODL_ETIMEOUT */
 int modl_debug_set(int what, int64_t value);
 /* 1 in libmodl_hip_diag.so (built with -DMODL_DIAG: the same sources plus the A/B-only kernel variants and the stamp
  * switches), 0 in the product library */
@@ -417,6 +418,12 @@ int modl_somf_sweeps_history(modl_somf_plan *plan, int32_t *d_buf, int64_t cap_m
 
 /* diagnostics: 48 shader-clock stamps of the last fused dictionary-update block launch (40 ..: the first riding tile),
  * h_out[48] (synchronises the device) */
+/* The persistent dictionary-update launch (csrc/bcd_persist.hip) needs all its workgroups resident at once; if they are not -
+ * another process holding compute units of the same GPU for seconds - its bounded waits give up, the launch ends and the
+ * dictionary is NOT updated correctly.  That raises a sticky word in the plan: modl_somf_status synchronises `stream`, returns
+ * MODL_ETIMEOUT if a launch of this plan gave up since the last call (and clears the word), MODL_OK otherwise.  The Python
+ * estimator checks it whenever it synchronises.  (The reference has no counterpart: it is CPU code.) */
+int modl_somf_status(modl_somf_plan *plan, void *stream);
 int modl_somf_debug_stamps(modl_somf_plan *plan, unsigned long long *h_out);
 /* diagnostics: 192 shader-clock stamps of the last PERSISTENT dictionary-update launch (csrc/bcd_persist.hip; written by the
  * diagnostics build only): [0] resolver start, [1 + 5 b ..] per block b: arrivals complete, pieces in LDS, Gram matrix

@@ -2166,6 +2166,8 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             pa.rec = reinterpret_cast<double *>(ws + L.off_prec);
             pa.Sbuf = reinterpret_cast<double *>(ws + L.off_Sbuf);
             pa.arrive = pflags; pa.sflag = pflags + kPersistBlocksMax; pa.err = pflags + 2 * kPersistBlocksMax;
+            pa.sticky = a.sticky_err;
+            pa.expect = nslab + (g_bcd_persist.load(std::memory_order_relaxed) == 3 ? 1 : 0);   // (3: the give-up path, tests)
             pa.stamps = reinterpret_cast<unsigned long long *>(ws + L.off_pstamps);
             pa.s = s; pa.k = kp; pa.kout = k; pa.nblk = (int)cdiv(k, kNB); pa.nrow = nslab; pa.shards = pshards;
             BcdRiderArgs r = rid;                                       // every riding tile with the one launch

@@ -105,12 +105,16 @@ __device__ __forceinline__ long long load_sc1(const long long *ptr) {
 
 // ---- bounded waits --------------------------------------------------------------------------------------------------
 // ONE lane polls ONE word (relaxed, agent scope); the payload behind it is read with sc1 loads (no acquire).
-__device__ __forceinline__ bool poll_word(unsigned int *word, unsigned int target, unsigned int *err) {
+__device__ __forceinline__ void give_up(unsigned int *err, unsigned int *sticky) {
+    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sticky) __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool poll_word(unsigned int *word, unsigned int target, unsigned int *err, unsigned int *sticky) {
     for (unsigned spins = 0;; ++spins) {
         const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v >= target) break;
         if (spins > kSpinLimit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            give_up(err, sticky);
             return false;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -425,7 +429,7 @@ __device__ __forceinline__ void persist_resolver(const BcdPersistArgs &p, char *
         int tv = tid;
         asm volatile("" : "+v"(tv));
         if (wid < 4) { coef_request(0, tv); block_inputs(0, tv); }
-        if (tid == 0) flag[0] = poll_word(p.arrive + 0, (unsigned)p.nrow, p.err) ? 1 : 0;
+        if (tid == 0) flag[0] = poll_word(p.arrive + 0, (unsigned)p.expect, p.err, p.sticky) ? 1 : 0;
         __syncthreads();
         if (!flag[0]) return;
         if (st && tid == 0) st[1] = clock64();
@@ -472,7 +476,7 @@ __device__ __forceinline__ void persist_resolver(const BcdPersistArgs &p, char *
                 coef_request(b + 1, tv - 128);
                 coef_request2(b + 1, tv - 128);
                 if (tv == 128) {                                                // one lane waits for the row workgroups
-                    const int ok = poll_word(p.arrive + b + 1, (unsigned)p.nrow, p.err) ? 1 : 2;
+                    const int ok = poll_word(p.arrive + b + 1, (unsigned)p.expect, p.err, p.sticky) ? 1 : 2;
                     if (st) st[5 + 4 * b] = clock64();
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     *(lds_vint *)(flag + 3) = ok + 4 * (b + 1);                  // (monotonic: verdict + 4 x block)
@@ -827,7 +831,7 @@ __device__ __forceinline__ void persist_rows(const BcdPersistArgs &p, char *smem
                               __double_as_longlong(s2) != kSentinel && __double_as_longlong(s3) != kSentinel;
             if (__all(have)) break;
             if (spins > kSpinLimit || ((spins & 63) == 63 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                give_up(p.err, p.sticky);
                 ok = false;
                 break;
             }

@@ -690,9 +690,11 @@ struct BcdPersistArgs {
     double *Sbuf;                   // [nblk][32 * 32]
     unsigned int *arrive, *sflag;   // [nblk] each, zero on entry
     unsigned int *err;              // raised by a wait that gave up (zero on entry)
+    unsigned int *sticky;           // optional: raised with it, never cleared by the kernels (modl_somf_status)
     unsigned long long *stamps;     // diagnostics build: [kPersistStampWords]
     int64_t s;
     int k, kout, nblk, nrow, shards;
+    int expect;                     // arrivals the resolver waits for per block: nrow (diagnostics: nrow + 1 - a workgroup that never comes)
 };
 size_t bcd_persist_lds(int kp, int RT);
 // grid: the resolver, nrow row workgroups of 32 RT rows, extra_wgs riding workgroups (rider.nslab must be nrow + 1)

@@ -158,6 +158,7 @@ struct DictUpdateArgs {
     size_t ws_bytes;
     StatsRider *rider = nullptr;   // optional (f32 fused path only)
     StageRide *stage = nullptr;    // optional (f32 fused path only): rides the last launch; `consumed` says whether it did
+    unsigned int *sticky_err = nullptr;   // optional, PERSISTENT across calls (zero-initialised): raised when a wait of the persistent launch gives up
     double *level_hint = nullptr;  // optional [k], PERSISTENT across calls (zero-initialised): the soft-threshold level
                                    // each atom's l1 / elastic-net projection ended with, warm start of the next one
 };

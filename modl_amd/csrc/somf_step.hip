@@ -867,6 +867,7 @@ int phase2(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         a.ws = pl->dws + pl->off_du; a.ws_bytes = pl->du_bytes;
         a.rider = pl->ride_pending ? &pl->rider : nullptr;
         a.level_hint = reinterpret_cast<double *>(pl->dws + pl->off_level);
+        a.sticky_err = reinterpret_cast<unsigned int *>(pl->dws + pl->off_level + sizeof(double) * (size_t)k);
         // the next minibatch of the chunk loop: its pinned slot is filled now and the copy into the OTHER device block
         // rides on the update's last launch (or follows it as a launch of its own when that path has no riders); a
         // next minibatch that does not validate is simply staged - and reported - by its own step
@@ -1099,12 +1100,12 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     pl->off_split = take(pl->split_bytes);
     pl->du_bytes = dict_update_workspace(desc->dtype, (int64_t)p, desc->k);
     pl->off_du = take(pl->du_bytes);
-    pl->off_level = take(sizeof(double) * k);   // per-atom projection levels (warm start of the next projection)
+    pl->off_level = take(sizeof(double) * k + 64);   // per-atom projection levels (warm start of the next projection) + the sticky error word
     pl->dws_bytes = o;
     hipError_t e = hipMalloc((void **)&pl->dws, pl->dws_bytes);
     if (e != hipSuccess) { delete pl; return (int)e; }
     e = hipMemset(pl->dws + pl->off_stamp, 0, sizeof(int32_t) * p);
-    if (e == hipSuccess) e = hipMemset(pl->dws + pl->off_level, 0, sizeof(double) * k);
+    if (e == hipSuccess) e = hipMemset(pl->dws + pl->off_level, 0, sizeof(double) * k + 64);
     if (e == hipSuccess && pl->ld_gpad) e = hipMemset(pl->dws + pl->off_Gpad, 0, t * ((size_t)pl->ld_gpad + 16) * pl->ld_gpad);
     if (e != hipSuccess) { modl_somf_plan_destroy(pl); return (int)e; }
     for (int i = 0; i < kStageSlots; ++i) {
@@ -1566,6 +1567,18 @@ int modl_somf_debug_stamps(modl_somf_plan *pl, unsigned long long *h_out) {
     const size_t off = modl::dict_update_stamps_offset(pl->d.dtype, pl->last_s, pl->d.k);
     MODL_HIP(hipMemcpy(h_out, pl->dws + pl->off_du + off, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return MODL_OK;
+}
+
+int modl_somf_status(modl_somf_plan *pl, void *stream) {
+    if (!pl) return MODL_EINVAL;
+    DeviceScope dev(pl);
+    unsigned int word = 0;
+    unsigned int *d_word = reinterpret_cast<unsigned int *>(pl->dws + pl->off_level + sizeof(double) * (size_t)pl->d.k);
+    MODL_HIP(hipMemcpyAsync(&word, d_word, sizeof(word), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    MODL_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (word == 0) return MODL_OK;
+    MODL_HIP(hipMemsetAsync(d_word, 0, sizeof(word), (hipStream_t)stream));
+    return MODL_ETIMEOUT;
 }
 
 int modl_somf_debug_persist_stamps(modl_somf_plan *pl, unsigned long long *h_out) {

@@ -248,6 +248,10 @@ class HipBackend:
             # several ranks on the library's communicator: a bounded wait that watches RCCL's asynchronous errors - an
             # RCCL failure surfaces as MODL_ERCCL here instead of a hang in hipStreamSynchronize
             check(lib.modl_comm_wait(comm, stream_ptr(self.device), self.COMM_TIMEOUT_S), 'modl_comm_wait')
+        if self.plan is not None:
+            # (also a synchronisation of the stream) a persistent dictionary-update launch whose workgroups were not all
+            # resident gives up instead of hanging: that must not pass for a fit
+            check(lib.modl_somf_status(self.plan, stream_ptr(self.device)), 'modl_somf_status')
         torch.cuda.synchronize(self.device)
 
     # -- the step -------------------------------------------------------------

@@ -1162,6 +1162,29 @@ def test_objective_on_device_chunked(dtype, tol):
     assert f(ptr(dX), p + 3, n, p, ptr(dDt), k, ptr(dcode), ptr(ws), 64, ptr(out), stream_ptr(dev)) == -2      # MODL_ENOMEM
 
 
+def test_persistent_launch_gives_up_loudly(DictFact):
+    """The persistent dictionary-update launch needs every workgroup resident; when one never arrives (another process holding
+    the compute units: here simulated, modl_debug_set(MODL_DEBUG_BCD_PERSIST, 3) makes the resolver wait for nrow + 1 arrivals)
+    its bounded waits give up, every workgroup leaves - no hang - and the next synchronisation raises (modl_somf_status:
+    MODL_ETIMEOUT) instead of passing a half-updated dictionary for a fit.  Afterwards the estimator works again."""
+    from modl_amd._lib import lib, check, ModlError, DEBUG_BCD_PERSIST
+    rs = np.random.RandomState(5)
+    n, p, k, b = 256, 600, 64, 64
+    X = (rs.randn(n, 24).dot(rs.randn(24, p)) + 0.3 * rs.randn(n, p)).astype(np.float32)
+    est = DictFact(n_components=k, batch_size=b, reduction=3, code_alpha=0.2, random_state=0)
+    est.prepare(n_samples=n, X=X)
+    est.partial_fit(X[:b], np.arange(b))
+    try:
+        check(lib.modl_debug_set(DEBUG_BCD_PERSIST, 3))
+        with pytest.raises(ModlError, match='wait gave up'):
+            est.partial_fit(X[b:2 * b], np.arange(b, 2 * b))
+    finally:
+        check(lib.modl_debug_set(DEBUG_BCD_PERSIST, 1))
+    est.prepare(n_samples=n, X=X)                                   # (the dictionary of the failed update is not to be trusted)
+    est.partial_fit(X, np.arange(n))
+    assert np.all(np.isfinite(est.components_))
+
+
 def test_bench_c5_shape_forced_reduce():
     """BASELINE config 5's per-GPU shape as a first-class bench workload: `bench.py --features 200000 --reduction 12
     --force-reduce` prints the same line (config.workload names C5), the two-phase step with the library's own RCCL
