@@ -514,6 +514,30 @@ __global__ __launch_bounds__(256) void gemm_dense_pair_kernel(DenseProblem<T, Ep
     }
 }
 
+// The sum of `splits` partial tiles at element e, in the order of the splits (the same bits as a plain loop), with the loads
+// of eight splits in flight at once: as `v += partial[z]` in a loop every load was waited for before the next was requested -
+// eight dependent round trips, the whole duration of the reduce launch of the code step (5 us for 2 x 256 x 256 outputs).
+template <typename T>
+__device__ __forceinline__ T sum_partials(const T *partial, int splits, int64_t stride, int64_t e) {
+    T v = 0;
+    int z = 0;
+    for (; z + 8 <= splits; z += 8) {
+        T x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = partial[(int64_t)(z + u) * stride + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += x[u];
+    }
+    if (z < splits) {
+        T x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = partial[(int64_t)((z + u < splits) ? z + u : splits - 1) * stride + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += (z + u < splits) ? x[u] : (T)0;
+    }
+    return v;
+}
+
 template <typename T, class Epi0, class Epi1>
 __global__ __launch_bounds__(256) void gemm_reduce_pair_kernel(const T *partial0, int splits0, int64_t M0, int64_t N0, Epi0 epi0,
                                                                int nblk0, const T *partial1, int splits1, int64_t M1,
@@ -525,8 +549,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_pair_kernel(const T *partial0
         if (e >= M0 * N0) return;
         const int64_t m = e / N0, n = e % N0;
         if (sym0 && (m >> 6) > (n >> 6)) return;
-        T v = 0;
-        for (int z = 0; z < splits0; ++z) v += partial0[(int64_t)z * M0 * N0 + e];
+        const T v = sum_partials(partial0, splits0, M0 * N0, e);
         epi0(m, n, v);
         if (sym0 && (m >> 6) < (n >> 6)) epi0(n, m, v);
     } else {
@@ -534,8 +557,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_pair_kernel(const T *partial0
         if (e >= M1 * N1) return;
         const int64_t m = e / N1, n = e % N1;
         if (sym1 && (m >> 6) > (n >> 6)) return;
-        T v = 0;
-        for (int z = 0; z < splits1; ++z) v += partial1[(int64_t)z * M1 * N1 + e];
+        const T v = sum_partials(partial1, splits1, M1 * N1, e);
         epi1(m, n, v);
         if (sym1 && (m >> 6) < (n >> 6)) epi1(n, m, v);
     }
