@@ -81,6 +81,7 @@ const char *modl_error_string(int code);
 #define MODL_DEBUG_BCD_TINY 7         /* 1 (default): the f64 blocked dictionary update of at most 192 sampled features runs as ONE one-workgroup launch; 0: five launches per block of 32 atoms */
 #define MODL_DEBUG_STAGE_AHEAD 8      /* 1 (default): inside modl_somf_partial_fit_chunk the next minibatch's parameters are copied to HBM by a workgroup of the dictionary update's last launch; 0: a staging launch at the head of every step */
 #define MODL_DEBUG_BCD_PERSIST 9      /* 1 (default): the f32 blocked dictionary update runs as ONE persistent launch (a resolver workgroup + one workgroup per 32 / 64 sampled rows resident in LDS, look-ahead Gram matrices: csrc/bcd_persist.hip) whenever its workgroups fit the chip; 0: one launch per block of 32 atoms; 3 (tests): as 1, but the resolver waits for a workgroup that never comes - the bounded waits give up, modl_somf_status reports MODL_ETIMEOUT */
+#define MODL_DEBUG_STATS_RESIDENT 10  /* 1 (default): the f32 statistics product X^T code over at least 4096 features and at most 256 atoms runs on persistent workgroups that keep the code matrix in registers (csrc/gemm_resident.hpp), tiles of 16 or 32 features by balance; 2 / 3: always 16 / 32; 0: the 32 x 32 tiles or the k-wide tiles of rounds 2-4 */
 int modl_debug_set(int what, int64_t value);
 /* 1 in libmodl_hip_diag.so (built with -DMODL_DIAG: the same sources plus the A/B-only kernel variants and the stamp
  * switches), 0 in the product library */

@@ -20,6 +20,7 @@ DEBUG_ATOM_STAMPS = 6
 DEBUG_BCD_TINY = 7
 DEBUG_STAGE_AHEAD = 8
 DEBUG_BCD_PERSIST = 9
+DEBUG_STATS_RESIDENT = 10
 AGG = {'masked': 0, 'full': 1, 'average': 2}
 OPT = {'variational': 0, 'sgd': 1}
 

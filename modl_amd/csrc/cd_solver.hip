@@ -518,6 +518,7 @@ extern std::atomic<unsigned long long *> g_atom_stamps; // bcd.hip
 extern std::atomic<int> g_bcd_acc;                      // bcd.hip
 extern std::atomic<int> g_bcd_tiny;                     // bcd.hip
 extern std::atomic<int> g_bcd_persist;                  // bcd.hip
+extern std::atomic<int> g_stats_resident;               // somf_step.hip
 extern std::atomic<int> g_stage_ahead;                  // somf_step.hip
 
 template <typename T>
@@ -719,6 +720,10 @@ extern "C" int modl_debug_set(int what, int64_t value) {
     }
     if (what == MODL_DEBUG_BCD_PERSIST) {
         modl::g_bcd_persist.store((int)value, std::memory_order_relaxed);
+        return MODL_OK;
+    }
+    if (what == MODL_DEBUG_STATS_RESIDENT) {
+        modl::g_stats_resident.store((int)value, std::memory_order_relaxed);
         return MODL_OK;
     }
     if (what == MODL_DEBUG_BCD_ACC) {

@@ -37,6 +37,8 @@ template <class Epi> struct WideProblem {
     int N = 0, K = 0;
     Epi epi;
     int tm = 0, tn = 0;                              // feature tiles, atom chunks of BN
+    bool vec4 = false;                               // (gemm_resident.hpp: the epilogue takes 16 bytes at a time)
+    unsigned long long *dbg = nullptr;               // (diagnostics, gemm_resident.hpp: shader-clock stamps of workgroup 0)
     bool ok = false;
 };
 

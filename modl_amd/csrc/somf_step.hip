@@ -32,9 +32,11 @@
 
 #include "gemm_dense.hpp"
 #include "gemm_wide.hpp"
+#include "gemm_resident.hpp"
 #include "kernels.hpp"
 
 namespace modl {
+std::atomic<int> g_stats_resident{1};      // modl_debug_set(MODL_DEBUG_STATS_RESIDENT, ...)
 
 enum Section { SEC_CODE_GEMM = 0, SEC_CODE_SOLVE, SEC_STATS_GEMM, SEC_STATS_APPLY, SEC_DICT, SEC_COUNT };
 static const char *kSectionNames[SEC_COUNT] = {"code_gemm", "code_solve", "stats_gemm", "stats_apply", "dict_update"};
@@ -64,16 +66,45 @@ template <typename T> struct EpiDxAverage {   // dict_fact.py:596-601
 
 // C <- (1 - w) C + (w / b) v ; the same for Bt (dict_fact.py:559-575) as a GEMM epilogue: the increments never
 // travel through HBM.  `mirror` (two-phase step): the updated value is also written to the head buffer.
+// (w v) / b: b is the global minibatch size, a power of two more often than not - then the product with its reciprocal is
+// the same number (both are the correctly rounded value of the same real; 2^-e is representable), three instructions
+// instead of the twelve of a division.  Uniform test, one reciprocal per thread.
+template <typename T> __device__ __forceinline__ bool stats_pow2(T b) {
+    if constexpr (sizeof(T) == 4) return (__float_as_uint(b) & 0x007fffffu) == 0 && b > (T)0 && b < (T)1e30;
+    else return (__double_as_longlong(b) & 0x000fffffffffffffll) == 0 && b > (T)0 && b < (T)1e300;
+}
+template <typename T> __device__ __forceinline__ T stats_value(T v, T old, T beta, T wt, T bdiv, int replace, bool p2, T rinv) {
+    const T x = replace ? v : wt * v;
+    const T q = p2 ? x * rinv : x / bdiv;
+    return replace ? q : old * beta + q;
+}
 template <typename T> struct EpiStats {
     static constexpr bool rmw = true;
+    typedef T vec4 __attribute__((ext_vector_type(4)));
     T *out; int64_t ld; T beta, wt, bdiv; int replace; T *mirror;
     __device__ __forceinline__ T load(int64_t m, int64_t n) const { return out[m * ld + n]; }   // unconditional
     __device__ __forceinline__ void store(int64_t m, int64_t n, T v, T old) const {
-        const T nv = replace ? v / bdiv : old * beta + (wt * v) / bdiv;
+        const bool p2 = stats_pow2(bdiv);
+        const T nv = stats_value(v, old, beta, wt, bdiv, replace, p2, (T)1 / bdiv);
         out[m * ld + n] = nv;
         if (mirror) mirror[m * ld + n] = nv;
     }
     __device__ __forceinline__ void operator()(int64_t m, int64_t n, T v) const { store(m, n, v, load(m, n)); }
+    // four consecutive n at once (gemm_resident.hpp: a lane of its transposed tile holds four consecutive atoms of a feature)
+    bool vec4_ok() const {
+        return ld % 4 == 0 && reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T)) == 0 &&
+               reinterpret_cast<uintptr_t>(mirror) % (4 * sizeof(T)) == 0;
+    }
+    __device__ __forceinline__ vec4 load4(int64_t m, int64_t n) const { return *reinterpret_cast<const vec4 *>(out + m * ld + n); }
+    __device__ __forceinline__ void store4(int64_t m, int64_t n, vec4 v, vec4 old) const {
+        const bool p2 = stats_pow2(bdiv);
+        const T rinv = (T)1 / bdiv;
+        vec4 nv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) nv[c] = stats_value(v[c], old[c], beta, wt, bdiv, replace, p2, rinv);
+        *reinterpret_cast<vec4 *>(out + m * ld + n) = nv;
+        if (mirror) *reinterpret_cast<vec4 *>(mirror + m * ld + n) = nv;
+    }
 };
 
 // ... for the sampled rows only: product row m is feature rows[m]; the mirror is compact (row m)
@@ -82,7 +113,7 @@ template <typename T> struct EpiStatsRows {
     T *out; int64_t ld; const int32_t *rows; T beta, wt, bdiv; int replace; T *mirror;
     __device__ __forceinline__ T load(int64_t m, int64_t n) const { return out[(int64_t)rows[m] * ld + n]; }
     __device__ __forceinline__ void store(int64_t m, int64_t n, T v, T old) const {
-        const T nv = replace ? v / bdiv : old * beta + (wt * v) / bdiv;
+        const T nv = stats_value(v, old, beta, wt, bdiv, replace, stats_pow2(bdiv), (T)1 / bdiv);
         out[(int64_t)rows[m] * ld + n] = nv;
         if (mirror) mirror[m * ld + n] = nv;
     }
@@ -557,6 +588,8 @@ int solve_codes(modl_somf_plan *pl, hipStream_t st, const T *G, int64_t g_stride
     return MODL_OK;
 }
 
+constexpr int64_t kResidentMinRows = 4096;
+
 // Two statistics products (contraction over the b samples of the minibatch, both operands contiguous along their
 // rows) in ONE launch; M0 == 0: only the second.  f32 with b <= 256 goes through the 32 x 32 / 16x16x4 tiling
 // (gemm_stats_pair_kernel), anything else through the generic pair kernel or, unaligned, the gather kernel.  Every
@@ -575,6 +608,22 @@ int stats_pair(hipStream_t st, const DenseOperand &A0, const DenseOperand &B0, i
         // 48 % of the f32 matrix peak); 16 samples, padded rows, two per unit: 0.385-0.397; 32 samples, one per unit:
         // 0.489; 4 samples, four per unit: 0.387 (a barrier every 256 matrix-core cycles); 64 features, one per unit:
         // 0.46.  At p = 10 000 the 32 x 32 tiles are faster (27 us against 37 us: ten times the workgroups to hide latency)
+        // a TALL second problem (the whole p x k product: reduction 1, or config 5's 200 000 features) with at most 256 atoms:
+        // persistent workgroups with the code matrix resident in registers (gemm_resident.hpp), tiles of 16 or 32 features -
+        // whichever leaves the slowest workgroup less to contract
+        if (P0.ok && M1 >= kResidentMinRows && N1 <= 256 && K % 4 == 0 && !dbg && g_stats_resident.load(std::memory_order_relaxed)) {
+            auto W = plan_wide<16, Epi1>(A1, B1, M1, N1, K, e1);
+            if (W.ok) {
+                static const int ncu = [] {
+                    int dev = 0;
+                    hipDeviceProp_t prop;
+                    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                        return prop.multiProcessorCount;
+                    return 256;
+                }();
+                return launch_gemm_stats_resident_pair<16, Epi0, Epi1>(st, P0, W, ncu, launches);
+            }
+        }
         if (P0.ok && cdiv(M1, 64) >= 1024 && !dbg) {
             auto W = plan_wide<32, Epi1>(A1, B1, M1, N1, K, e1);
             if (W.ok) return launch_gemm_stats_wide_pair<32, Epi0, Epi1, 256, 8, 0, true>(st, P0, W, launches);

@@ -466,6 +466,49 @@ def test_partial_fit_streams_host_input_in_chunks(DictFact, tmp_path, source):
         assert_array_equal(a, c)
 
 
+@pytest.mark.parametrize('p,k,b', [(10000, 256, 256), (4104, 100, 200), (8192, 256, 64), (4100, 36, 256)])
+def test_resident_statistics_product(DictFact, p, k, b):
+    """At least 4096 features, at most 256 atoms, a minibatch that is a multiple of four: the p x k statistics product runs
+    on persistent workgroups with the code matrix resident in registers (csrc/gemm_resident.hpp; reduction 1 at the
+    metric's shape, config 5's 200 000 features).  Ragged last tile (p not a multiple of 16), fewer atoms than a
+    workgroup's wavefronts cover, K < 256 (skipped k-steps).  After the FIRST minibatch (w = 1) B_ = code^T X / b exactly -
+    checked against that product of the GPU's own codes in f64, every row; the second minibatch (the read-modify-write)
+    likewise; then two minibatches against the run with MODL_DEBUG_STATS_RESIDENT = 0 (the 32 x 32 tiles)."""
+    from modl_amd._lib import lib, check, DEBUG_STATS_RESIDENT
+    rs = np.random.RandomState(p + k)
+    n = max(3 * b, k)
+    X = (rs.randn(n, 16) @ rs.randn(16, p) / 4 + 0.5 * rs.randn(n, p)).astype(np.float32)
+    kw = dict(n_components=k, batch_size=b, reduction=1, code_alpha=0.3, learning_rate=0.9, random_state=0)
+    est = DictFact(**kw)
+    est.prepare(n_samples=n, X=X)
+    est.partial_fit(X[:b], np.arange(b))
+    code = est.code_[:b].astype(np.float64)
+    assert rel_fro(est.B_, code.T @ X[:b].astype(np.float64) / b) < 2e-6
+    assert rel_fro(est.C_, code.T @ code / b) < 2e-6
+    # the read-modify-write part: the SECOND minibatch against (1 - w) B_1 + (w / b) code_2^T X_2 in f64, from the GPU's own
+    # B_1 and codes
+    from modl_amd.randomkit import batch_weight
+    B1, C1 = est.B_.astype(np.float64), est.C_.astype(np.float64)
+    est.partial_fit(X[b:2 * b], np.arange(b, 2 * b))
+    w = batch_weight(est.n_iter_, b, kw['learning_rate'], 0)
+    code = est.code_[b:2 * b].astype(np.float64)
+    assert rel_fro(est.B_, (1 - w) * B1 + w * (code.T @ X[b:2 * b].astype(np.float64) / b)) < 2e-6
+    assert rel_fro(est.C_, (1 - w) * C1 + w * (code.T @ code / b)) < 2e-6
+    # and against the run with the 32 x 32 tiles (a rounding difference in B_ moves the dictionary, hence the next codes)
+    res = []
+    try:
+        for sw in (0, 1):
+            check(lib.modl_debug_set(DEBUG_STATS_RESIDENT, sw))
+            e = DictFact(**kw)
+            e.prepare(n_samples=n, X=X)
+            e.partial_fit(X[:2 * b], np.arange(2 * b))
+            res.append((e.B_.copy(), e.C_.copy(), e.components_.copy()))
+    finally:
+        check(lib.modl_debug_set(DEBUG_STATS_RESIDENT, 1))
+    for a, c, name in zip(res[0], res[1], ('B', 'C', 'D')):
+        assert rel_fro(c, a) < 1e-4, (name, rel_fro(c, a))
+
+
 @pytest.mark.parametrize('k,b,red', [(32, 64, 4), (72, 50, 1)])
 def test_wide_statistics_tile(DictFact, oracle, k, b, red):
     """p >= 65 536 features: the p x k statistics product runs as its own k-wide launch (csrc/gemm_wide.hpp: 32 features
