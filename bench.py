@@ -559,8 +559,11 @@ def self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2000)
-    ap.add_argument('--warmup', type=int, default=500)
+    ap.add_argument('--steps', type=int, default=None,
+                    help='timed minibatches (default 2000 at the metric\'s shape; 300 at another --features: with the 100 warm-up and the 50 '
+                         'breakdown minibatches the stream of p = 200 000 stays resident in HBM, 92 GB - beyond 96 GB it becomes a '
+                         'two-chunk ring whose generator runs next to the timed steps)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed warm-up minibatches (default 500; 100 at another --features)')
     ap.add_argument('--reduction', type=float, default=10.0)
     ap.add_argument('--features', type=int, default=10000,
                     help='p of the synthetic stream (10000: the metric\'s workload M1; 200000 with --reduction 12: the per-GPU '
@@ -592,6 +595,10 @@ def main():
         BLOCK = CHUNK // 8
     if args.steady_steps is None:
         args.steady_steps = 2000 if P_FEAT == 10000 else 0
+    if args.steps is None:
+        args.steps = 2000 if P_FEAT == 10000 else 300
+    if args.warmup is None:
+        args.warmup = 500 if P_FEAT == 10000 else 100
 
     if args.gpus > 1 and ('WORLD_SIZE' not in os.environ or (
             os.environ['WORLD_SIZE'] == '1' and 'TORCHELASTIC_RUN_ID' not in os.environ and 'RANK' not in os.environ)):

@@ -72,4 +72,13 @@ export MASTER_PORT=$((20000 + RANDOM % 20000))
 rm -rf /tmp/w/tpc5; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/w/tpc5 -o t -- python3 $R/bench.py --features 200000 --reduction 12 --steps 100 --warmup 40 --no-cpu-baseline --no-breakdown --force-reduce > /tmp/w/tpc5.log 2>&1
 { echo "rocprofv3 --kernel-trace --stats -- python3 bench.py --features 200000 --reduction 12 --steps 100 --warmup 40 --no-cpu-baseline --no-breakdown --force-reduce (second half)"; python3 $R/scripts/prof_summary.py $(find /tmp/w/tpc5 -name "*.db" | head -1) 0.5; } > $OUT/${TAG}_two_phase_c5_native_kernel_trace.txt 2>&1
 python3 $R/scripts/diag_persist_stamps.py 10 1 > $OUT/${TAG}_persist_stamps.txt 2>&1
+# config 5 with the defaults of its workload (300 timed minibatches, the stream resident in HBM), the statistics product with
+# the code matrix in registers on its own (scripts/micro/res_gemm.hip), and the SQ counters of the reduction-1 and
+# config-5 steps (the three products of the round-4 review: MFMA-busy and LDS-wait shares per kernel)
+python3 $R/bench.py --features 200000 --reduction 12 --no-cpu-baseline > $OUT/${TAG}_bench_c5.json 2> $OUT/${TAG}_bench_c5.err
+{ for a in "10000" "200000" "4104 100 200"; do $R/scripts/micro/res_gemm $a; done; } > $OUT/${TAG}_stats_resident_micro.txt 2>&1
+rm -rf /tmp/w/sq1; timeout 600 rocprofv3 --kernel-trace --pmc $SQC -d /tmp/w/sq1 -o t -- python3 $R/bench.py --reduction 1 --steps 100 --warmup 40 --no-cpu-baseline --steady-steps 0 --no-breakdown > /tmp/w/sq1.log 2>&1
+{ echo "rocprofv3 --kernel-trace --pmc $SQC -- python3 bench.py --reduction 1 --steps 100 --warmup 40 ..."; echo "(SQ_* cycle counters are in quad-cycles; use the RATIOS)"; echo; python3 $R/scripts/pmc_summary.py $(find /tmp/w/sq1 -name '*.db' | head -1); } > $OUT/${TAG}_pmc_sq_counters_r1.txt 2>&1
+rm -rf /tmp/w/sq5; timeout 600 rocprofv3 --kernel-trace --pmc $SQC -d /tmp/w/sq5 -o t -- python3 $R/bench.py --features 200000 --reduction 12 --steps 40 --warmup 20 --no-cpu-baseline --no-breakdown > /tmp/w/sq5.log 2>&1
+{ echo "rocprofv3 --kernel-trace --pmc $SQC -- python3 bench.py --features 200000 --reduction 12 --steps 40 --warmup 20 ..."; echo "(SQ_* cycle counters are in quad-cycles; use the RATIOS)"; echo; python3 $R/scripts/pmc_summary.py $(find /tmp/w/sq5 -name '*.db' | head -1); } > $OUT/${TAG}_pmc_sq_counters_c5.txt 2>&1
 ls -la $OUT | grep $TAG

@@ -509,6 +509,25 @@ def test_resident_statistics_product(DictFact, p, k, b):
         assert rel_fro(c, a) < 1e-4, (name, rel_fro(c, a))
 
 
+@pytest.mark.parametrize('p,k,b,red', [(4104, 100, 200, 1), (16416, 64, 64, 3)])
+def test_resident_product_two_phase_equals_fused(DictFact, p, k, b, red):
+    """The register-resident statistics product with the head mirror of the two-phase (multi-GPU) step: reduction 1 (every
+    row of B_ through the 16-byte epilogue, mirrored) and a sampled set of 5472 rows (the row-indirected epilogue, element by
+    element, compact mirror) - the same bits as the fused step."""
+    rs = np.random.RandomState(p)
+    n = max(3 * b, k)
+    X = (rs.randn(n, 16) @ rs.randn(16, p) / 4 + 0.5 * rs.randn(n, p)).astype(np.float32)
+    out = []
+    for two_phase in (False, True):
+        est = DictFact(n_components=k, batch_size=b, reduction=red, code_alpha=0.3, learning_rate=0.9, random_state=0)
+        est._two_phase = two_phase
+        est.prepare(n_samples=n, X=X)
+        est.partial_fit(X[:3 * b], np.arange(3 * b))
+        out.append((est.components_, est.code_.copy(), est.C_, est.B_))
+    for a, c in zip(out[0], out[1]):
+        assert_array_equal(a, c)
+
+
 @pytest.mark.parametrize('k,b,red', [(32, 64, 4), (72, 50, 1)])
 def test_wide_statistics_tile(DictFact, oracle, k, b, red):
     """p >= 65 536 features: the p x k statistics product runs as its own k-wide launch (csrc/gemm_wide.hpp: 32 features
