@@ -242,6 +242,9 @@ class Run:
                 self.stream.release(c)
 
     def sync(self):
+        # the estimator's own wait first (DictFact.partial_fit's: it polls the stream and checks the status word of the
+        # persistent launches), then the device-wide synchronisation the timing contract asks for
+        self.be.synchronize()
         self.torch.cuda.synchronize(self.device)
 
 

@@ -22,10 +22,23 @@ from math import ceil
 import numpy as np
 import torch
 from sklearn.base import BaseEstimator, TransformerMixin
-from sklearn.utils import check_array, check_random_state, gen_batches
+from sklearn.utils import check_array, check_random_state
 from sklearn.utils.validation import check_is_fitted
 
 from . import _lib
+
+
+def gen_batches(n, batch_size):
+    """sklearn.utils.gen_batches (slices of batch_size rows, the last one shorter; dict_fact.py:510) without its parameter
+    validation - an inspect.signature() binding per call, 25 us in front of the first launch of every partial_fit."""
+    start = 0
+    for _ in range(int(n // batch_size)):
+        end = start + batch_size
+        yield slice(start, end)
+        start = end
+    if start < n:
+        yield slice(start, n)
+
 from ._lib import lib, check, SomfDesc, SomfState, SomfBatch, ProfEntry, AGG, OPT
 from .device import (default_device, dtype_id, sfx, torch_dtype, ptr, stream_ptr, to_device, transpose_to, gather_rows)
 from .randomkit import RandomState, Sampler, batch_weight
