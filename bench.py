@@ -435,8 +435,13 @@ def parity_block(X, done, st32, reduction, device):
     with limiter:
         st64 = orc.prepare(pr, n_samples=X.shape[0], X=X[:K_COMP].astype(np.float64))
         st64.sweeps = []
-        for r0 in range(0, done, BATCH):
+        t_flip, before = None, None                 # first minibatch in which a sample does another number of sweeps than on the GPU
+        for t, r0 in enumerate(range(0, done, BATCH)):
+            if t_flip is None:
+                prev = (st64.D.copy(), st64.C.copy())            # the f64 state after t minibatches
             orc.partial_fit(st64, pr, X64[r0:r0 + BATCH], np.arange(r0, r0 + BATCH))
+            if t_flip is None and (np.asarray(st64.sweeps[-1]) != sw_gpu[t, :BATCH]).any():
+                t_flip, before = t, prev
     rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) /
                              max(np.linalg.norm(np.asarray(b, np.float64)), 1e-300))
     sw64, sw32 = np.stack(st64.sweeps), np.stack(st32.sweeps)
@@ -445,7 +450,7 @@ def parity_block(X, done, st32, reduction, device):
     ref64 = dict(D=st64.D, C=st64.C, code=st64.code[:done])
     out = dict(steps=nb, rows=done, path='DictFact.partial_fit -> modl_somf_partial_fit_chunk (one call)',
                reference='oracle/somf_oracle.py in f64 on the same float32 rows; the f32 noise is the cpu_baseline leg\'s run against it')
-    ok = flat = True
+    ok = flat = behind = True
     for key in ('D', 'C', 'code'):
         e, noise = rel(got[key], ref64[key]), rel(ref32[key], ref64[key])
         out['rel_fro_' + key] = e
@@ -453,11 +458,27 @@ def parity_block(X, done, st32, reduction, device):
         out['gpu_vs_oracle_f32_' + key] = rel(got[key], ref32[key])
         ok = ok and e <= 2 * noise + 1e-5
         flat = flat and e <= 1e-5
+        behind = behind and e <= 2 * noise + 1e-5 + 6e-5
     # `within_1e5`: the north star's bound, flat, on dictionary / C / codes (what the GPU tests assert while no sample has
     # flipped its sweep count); the noise-relative flag is the rule behind a flip
     flips = int((sw_gpu[:, :BATCH] != sw64).sum())
-    out.update(within_1e5=bool(flat) if flips == 0 else None,      # (None: a sample flipped its sweep count - the noise rule applies)
-               within_2x_reference_f32_noise_plus_1e5=bool(ok), sweep_flips=flips,
+    # `within_tolerance`: the gate of tests/test_gpu_step.py::test_timed_path_long_horizon_vs_oracle - 1e-5 flat while no sample has
+    # flipped; behind a flip (a tolerance-stopped solver doing one sweep more or less on a sample whose duality gap sits on the
+    # threshold - the oracle's own f32 run does it too, `oracle_f32_sweep_flips`; at most 0.1 % of the samples) 2 x the
+    # oracle's f32 noise + 1e-5 + 6e-5
+    if t_flip is not None and t_flip > 0:
+        # the flat bound where it applies: the state after the last minibatch BEFORE the first flip (a fresh estimator fitted on
+        # those minibatches - the same draws, the same bits as the first t_flip steps of the call above)
+        e2 = DictFact(**kw)
+        e2.prepare(n_samples=X.shape[0], X=X[:K_COMP])
+        e2.partial_fit(Xd[:t_flip * BATCH], np.arange(t_flip * BATCH))
+        bf = dict(steps=t_flip, rel_fro_D=rel(e2.components_, before[0]), rel_fro_C=rel(e2.C_, before[1]),
+                  rel_fro_code=rel(e2.code_[:t_flip * BATCH], st64.code[:t_flip * BATCH]))
+        bf['within_1e5'] = bool(max(bf['rel_fro_D'], bf['rel_fro_C'], bf['rel_fro_code']) <= 1e-5)
+        out['before_first_flip'] = bf
+    out.update(within_1e5=bool(flat) if flips == 0 else None,      # (None: a sample flipped its sweep count - the rule behind a flip applies)
+               within_2x_reference_f32_noise_plus_1e5=bool(ok),
+               within_tolerance=bool(flat) if flips == 0 else bool(behind and flips <= 1e-3 * sw64.size), sweep_flips=flips,
                oracle_f32_sweep_flips=int((sw32 != sw64).sum()), samples=int(sw64.size),
                sweeps_agree=float(np.mean(sw_gpu[:, :BATCH] == sw64)), n_iter_equal=bool(est.n_iter_ == st64.n_iter),
                gpu_ms_per_step=dt / max(nb, 1) * 1e3)
