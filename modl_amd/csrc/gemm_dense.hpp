@@ -390,7 +390,7 @@ __device__ __forceinline__ void gemm_dense_tile_auto(const DenseOperand &A, cons
                                                      int nsplit, T (*As)[BK][BM + 4], T (*Bs)[BK][BN + 4],
                                                      unsigned long long *dbg = nullptr) {
     constexpr int NKT = 8;
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 4 && BM <= 64 && BN <= 64) {      // (128 x 128 tiles: 256 registers of operands - the pipelined tile only)
         const int64_t k_begin = (int64_t)bz * kps, k_end = (k_begin + kps < K) ? k_begin + kps : K;
         if (k_end - k_begin <= (int64_t)NKT * BK) {
             gemm_dense_tile_rk<T, AI, BI, Epi, BM, BN, BK, NKT>(A, B, M, N, k_begin, k_end, partial, epi, bx, by, bz, nsplit,
@@ -469,9 +469,10 @@ DenseProblem<T, Epi> plan_dense(const DenseOperand &A, const DenseOperand &B, in
     return P;
 }
 
-template <typename T, bool AI0, bool BI0, class Epi0, bool AI1, bool BI1, class Epi1, int BM1 = 64, int BN1 = 64, int BK1 = 0>
+template <typename T, bool AI0, bool BI0, class Epi0, bool AI1, bool BI1, class Epi1, int BM1 = 64, int BN1 = 64, int BK1 = 0, int BM0 = 64,
+          int BN0 = 64>
 __global__ __launch_bounds__(256) void gemm_dense_pair_kernel(DenseProblem<T, Epi0> P0, DenseProblem<T, Epi1> P1) {
-    constexpr int BM = 64, BN = 64, BK = (sizeof(T) == 4) ? 32 : 16;
+    constexpr int BM = BM0, BN = BN0, BK = (sizeof(T) == 4) ? 32 : 16;
     extern __shared__ __attribute__((aligned(16))) char gd_smem[];   // sized for the larger of the two tilings
     int id = (int)blockIdx.x;
     // tile number -> (column tile, row tile, split); a symmetric problem only has the tiles with bx >= by
@@ -541,39 +542,41 @@ __device__ __forceinline__ T sum_partials(const T *partial, int splits, int64_t 
 template <typename T, class Epi0, class Epi1>
 __global__ __launch_bounds__(256) void gemm_reduce_pair_kernel(const T *partial0, int splits0, int64_t M0, int64_t N0, Epi0 epi0,
                                                                int nblk0, const T *partial1, int splits1, int64_t M1,
-                                                               int64_t N1, Epi1 epi1, int sym0, int sym1) {
-    // (a symmetric problem has partial sums only in its tiles on and above the diagonal, 64 x 64: the element of a tile
+                                                               int64_t N1, Epi1 epi1, int sym0, int sym1, int sh0 = 6,
+                                                               int sh1 = 6) {
+    // (a symmetric problem has partial sums only in its tiles on and above the diagonal, 2^sh x 2^sh: the element of a tile
     //  above the diagonal is summed once, with coalesced reads, and stored to both sides - bitwise symmetric)
     if ((int)blockIdx.x < nblk0) {
         const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
         if (e >= M0 * N0) return;
         const int64_t m = e / N0, n = e % N0;
-        if (sym0 && (m >> 6) > (n >> 6)) return;
+        if (sym0 && (m >> sh0) > (n >> sh0)) return;
         const T v = sum_partials(partial0, splits0, M0 * N0, e);
         epi0(m, n, v);
-        if (sym0 && (m >> 6) < (n >> 6)) epi0(n, m, v);
+        if (sym0 && (m >> sh0) < (n >> sh0)) epi0(n, m, v);
     } else {
         const int64_t e = (int64_t)((int)blockIdx.x - nblk0) * 256 + threadIdx.x;
         if (e >= M1 * N1) return;
         const int64_t m = e / N1, n = e % N1;
-        if (sym1 && (m >> 6) > (n >> 6)) return;
+        if (sym1 && (m >> sh1) > (n >> sh1)) return;
         const T v = sum_partials(partial1, splits1, M1 * N1, e);
         epi1(m, n, v);
-        if (sym1 && (m >> 6) < (n >> 6)) epi1(n, m, v);
+        if (sym1 && (m >> sh1) < (n >> sh1)) epi1(n, m, v);
     }
 }
 
 // Both problems must be `ok` (see plan_dense) and their operand orientations known statically; the second
 // problem may use a larger block tile (BM1 x BN1, planned with the same values).
-template <typename T, bool AI0, bool BI0, class Epi0, bool AI1, bool BI1, class Epi1, int BM1 = 64, int BN1 = 64, int BK1 = 0>
+template <typename T, bool AI0, bool BI0, class Epi0, bool AI1, bool BI1, class Epi1, int BM1 = 64, int BN1 = 64, int BK1 = 0, int BM0 = 64,
+          int BN0 = 64>
 int launch_gemm_dense_pair(hipStream_t stream, const DenseProblem<T, Epi0> &P0, const DenseProblem<T, Epi1> &P1,
                            int *launches = nullptr) {
     constexpr int BK = (sizeof(T) == 4) ? 32 : 16;
     constexpr int BKB = BK1 > 0 ? BK1 : BK;
-    constexpr size_t lds0 = sizeof(T) * 2 * BK * ((64 + 4) + (64 + 4)), lds1 = sizeof(T) * 2 * BKB * ((BM1 + 4) + (BN1 + 4));
+    constexpr size_t lds0 = sizeof(T) * 2 * BK * ((BM0 + 4) + (BN0 + 4)), lds1 = sizeof(T) * 2 * BKB * ((BM1 + 4) + (BN1 + 4));
     constexpr size_t lds = lds0 > lds1 ? lds0 : lds1;
     const int total = P0.tiles() * P0.splits + 8 * ((P1.tiles() * P1.splits + 7) / 8);   // second problem padded to 8 XCD chunks
-    auto kern = gemm_dense_pair_kernel<T, AI0, BI0, Epi0, AI1, BI1, Epi1, BM1, BN1, BK1>;
+    auto kern = gemm_dense_pair_kernel<T, AI0, BI0, Epi0, AI1, BI1, Epi1, BM1, BN1, BK1, BM0, BN0>;
     if (lds > 64 * 1024)
         MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, stream, P0, P1);
@@ -582,7 +585,8 @@ int launch_gemm_dense_pair(hipStream_t stream, const DenseProblem<T, Epi0> &P0, 
     const int nb0 = P0.splits > 1 ? (int)cdiv(P0.M * P0.N, 256) : 0, nb1 = P1.splits > 1 ? (int)cdiv(P1.M * P1.N, 256) : 0;
     if (nb0 + nb1 > 0) {
         hipLaunchKernelGGL((gemm_reduce_pair_kernel<T, Epi0, Epi1>), dim3((unsigned)(nb0 + nb1)), dim3(256), 0, stream,
-                           P0.partial, P0.splits, P0.M, P0.N, P0.epi, nb0, P1.partial, P1.splits, P1.M, P1.N, P1.epi, P0.sym, P1.sym);
+                           P0.partial, P0.splits, P0.M, P0.N, P0.epi, nb0, P1.partial, P1.splits, P1.M, P1.N, P1.epi, P0.sym, P1.sym,
+                           BM0 == 128 ? 7 : 6, BM1 == 128 ? 7 : 6);
         MODL_LAUNCH_CHECK();
         if (launches) ++*launches;
     }
