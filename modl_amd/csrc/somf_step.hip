@@ -227,7 +227,19 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs<T> a) {
     }
     id -= a.n_rows;
     if (id < a.n_cols) {
-        const int i = id / a.gx, bx = id % a.gx;
+        // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: the gx workgroups of a row - a random gather over
+        // the whole row, which only pays one memory fetch per line if the row sits in ONE L2 while they work on it - are numbered
+        // so that they all land on the XCD (row % 8), the one the row's norm workgroup ran on.  (With row = id / gx every XCD
+        // fetched every row: at p = 200 000 the launch took 111 us for 205 MB of X, 81 us this way.  Measured and not kept: the
+        // row norms as partial sums of the same workgroups, a contiguous 1 / gx of the row each, summed by the last to arrive -
+        // one pass over X instead of two, and 102 us: 16 384 workgroups with a block reduction, a ticket and 12 KB of
+        // contiguous reads each; with agent-scope fences around the ticket 706 us - a release writes back the XCD's whole L2.)
+        int i = id / a.gx, bx = id % a.gx;
+        if (a.b % 8 == 0) {
+            const int xcd = (int)(blockIdx.x % 8), slot = id / 8;
+            i = xcd + 8 * (slot / a.gx);
+            bx = slot % a.gx;
+        }
         const T *row = a.X + (int64_t)i * a.ldx;
         for (int64_t f = (int64_t)bx * 256 + threadIdx.x; f < a.s_pad; f += (int64_t)a.gx * 256)
         {
