@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r05_43; mkdir -p $O /tmp/w; R=$PWD
+O=gpurun_out/r05_45; mkdir -p $O /tmp/w; R=$PWD
 python bench.py --features 200000 --reduction 12 --no-cpu-baseline > $O/bench_c5.json 2>/dev/null; python -c "
 import json;d=json.loads(open('$O/bench_c5.json').read().strip().splitlines()[-1]);print('c5', round(d['value']), d['ms_per_step'], {k:round(v['ms_per_step'],4) for k,v in d['sections'].items()})"
 cd /tmp && export TMPDIR=/tmp
