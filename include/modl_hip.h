@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MODL_ABI_VERSION 4
+#define MODL_ABI_VERSION 5
 
 #define MODL_OK 0
 #define MODL_EINVAL (-1)   /* bad argument */
@@ -43,7 +43,7 @@ extern "C" {
 #define MODL_ENOGPU (-4)   /* no HIP device available, or not a gfx950-class part (160 KiB of LDS per compute unit) */
 #define MODL_ENORCCL (-5)  /* librccl.so could not be loaded (modl_comm_*) */
 #define MODL_ERCCL (-6)    /* an RCCL call failed */
-#define MODL_ETIMEOUT (-7) /* a wait inside a persistent kernel gave up (its workgroups were not all resident): modl_somf_status */
+#define MODL_ETIMEOUT (-7) /* a persistent dictionary-update launch gave up half-way (the update is incomplete): modl_somf_status */
 
 #define MODL_F32 0
 #define MODL_F64 1
@@ -80,8 +80,8 @@ const char *modl_error_string(int code);
 #define MODL_DEBUG_ATOM_STAMPS 6      /* (diagnostics library) value = device pointer to 64 uint64, zeroed by the caller (0: off): cycle sums of the projecting workgroup of the grouped atom update (bcd.hip: atom_project_group_kernel) */
 #define MODL_DEBUG_BCD_TINY 7         /* 1 (default): the f64 blocked dictionary update of at most 192 sampled features runs as ONE one-workgroup launch; 0: five launches per block of 32 atoms */
 #define MODL_DEBUG_STAGE_AHEAD 8      /* 1 (default): inside modl_somf_partial_fit_chunk the next minibatch's parameters are copied to HBM by a workgroup of the dictionary update's last launch; 0: a staging launch at the head of every step */
-#define MODL_DEBUG_BCD_PERSIST 9      /* 1 (default): the f32 blocked dictionary update runs as ONE persistent launch (a resolver workgroup + one workgroup per 32 / 64 sampled rows resident in LDS, look-ahead Gram matrices: csrc/bcd_persist.hip) whenever its workgroups fit the chip; 0: one launch per block of 32 atoms; 3 (tests): as 1, but the resolver waits for a workgroup that never comes - the bounded waits give up, modl_somf_status reports MODL_ETIMEOUT */
-#define MODL_DEBUG_STATS_RESIDENT 10  /* 1 (default): the f32 statistics product X^T code over at least 4096 features and at most 256 atoms runs on persistent workgroups that keep the code matrix in registers (csrc/gemm_resident.hpp), tiles of 16 or 32 features by balance; 2 / 3: always 16 / 32; 0: the 32 x 32 tiles or the k-wide tiles of rounds 2-4 */
+#define MODL_DEBUG_BCD_PERSIST 9      /* 1 (default): the f32 blocked dictionary update runs as ONE persistent launch (a resolver workgroup + one workgroup per 32 / 64 sampled rows resident in LDS, look-ahead Gram matrices: csrc/bcd_persist.hip) whenever its workgroups fit the chip (hipOccupancyMaxActiveBlocksPerMultiprocessor for the kernel's own footprint); 0: one launch per block of 32 atoms.  Diagnostics library only (the product library treats them as 1): 3 = the resolver waits for a workgroup that never comes before the first block (the launch cannot run: the resolver completes the update alone, modl_somf_persist_recoveries counts it), 4 = the same from the second block on (the update is incomplete: MODL_ETIMEOUT) */
+#define MODL_DEBUG_STATS_RESIDENT 10  /* 1 (default): the f32 statistics product X^T code over at least 4096 features and at most 256 atoms runs on persistent workgroups that keep the code matrix in registers (csrc/gemm_resident.hpp, tiles of 16 features); 0: the 32 x 32 tiles or the k-wide tiles of rounds 2-4 */
 int modl_debug_set(int what, int64_t value);
 /* 1 in libmodl_hip_diag.so (built with -DMODL_DIAG: the same sources plus the A/B-only kernel variants and the stamp
  * switches), 0 in the product library */
@@ -419,12 +419,23 @@ int modl_somf_sweeps_history(modl_somf_plan *plan, int32_t *d_buf, int64_t cap_m
 
 /* diagnostics: 48 shader-clock stamps of the last fused dictionary-update block launch (40 ..: the first riding tile),
  * h_out[48] (synchronises the device) */
-/* The persistent dictionary-update launch (csrc/bcd_persist.hip) needs all its workgroups resident at once; if they are not -
- * another process holding compute units of the same GPU for seconds - its bounded waits give up, the launch ends and the
- * dictionary is NOT updated correctly.  That raises a sticky word in the plan: modl_somf_status synchronises `stream`, returns
- * MODL_ETIMEOUT if a launch of this plan gave up since the last call (and clears the word), MODL_OK otherwise.  The Python
- * estimator checks it whenever it synchronises.  (The reference has no counterpart: it is CPU code.) */
+/* The persistent dictionary-update launch (csrc/bcd_persist.hip) needs all its workgroups resident at once.  The library asks
+ * the runtime whether they fit (occupancy of the kernel's own register / LDS footprint on the plan's device); what it cannot
+ * ask is whether another process, or a compute-unit mask, holds units of the same GPU.  Every wait inside the launch is
+ * bounded, and what a wait that gives up means is decided on the device:
+ *  - BEFORE the first block of atoms is resolved nothing has been applied: the row workgroups leave, the resolver workgroup
+ *    runs the reference's sweep by itself (milliseconds instead of microseconds) and the stream carries on with a correctly
+ *    updated dictionary - no error.  The plan counts the event (modl_somf_persist_recoveries, a plain read of pinned memory,
+ *    no synchronisation) and, from the first one on, keeps one launch per block: whatever held the units may still be there.
+ *  - LATER the update is incomplete.  The plan raises a flag that the host reads before every enqueue: the next
+ *    modl_somf_step / _code_and_partials / _apply_and_update_dict / _partial_fit_chunk of that plan returns MODL_ETIMEOUT
+ *    without enqueuing anything, and keeps doing so until modl_somf_status has been called.
+ * modl_somf_status synchronises `stream`, returns MODL_ETIMEOUT if an update of this plan was left incomplete since the last
+ * call (and clears the flag; the dictionary of that plan is then not to be trusted: DictFact.prepare again), MODL_OK otherwise.
+ * The Python estimator checks it whenever it synchronises and warns once per recovery.  (The reference has no counterpart: it
+ * is CPU code.) */
 int modl_somf_status(modl_somf_plan *plan, void *stream);
+int modl_somf_persist_recoveries(modl_somf_plan *plan, int64_t *count);
 int modl_somf_debug_stamps(modl_somf_plan *plan, unsigned long long *h_out);
 /* diagnostics: 192 shader-clock stamps of the last PERSISTENT dictionary-update launch (csrc/bcd_persist.hip; written by the
  * diagnostics build only): [0] resolver start, [1 + 5 b ..] per block b: arrivals complete, pieces in LDS, Gram matrix

@@ -170,6 +170,7 @@ def bind(lib):
     _sig('modl_somf_transform', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp)
     _sig('modl_somf_debug_stamps', C.c_int, _vp, _vp)
     _sig('modl_somf_status', C.c_int, _vp, _vp)
+    _sig('modl_somf_persist_recoveries', C.c_int, _vp, _P(_i64))
     _sig('modl_somf_debug_persist_stamps', C.c_int, _vp, _vp)
     _sig('modl_somf_debug_gemm_stamps', C.c_int, _vp, _vp)
     _sig('modl_somf_last_sweeps', C.c_int, _vp, _vp, C.c_int, _P(C.c_int), _vp)

@@ -2024,21 +2024,17 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
         // ONE persistent launch per dictionary update (bcd_persist.hip) when its workgroups - one per 32 or 64 sampled rows
         // plus the resolver - can all be resident at once; otherwise one launch per block of 32 atoms
         int persist_rt = 0;
-        if (fused && g_bcd_persist.load(std::memory_order_relaxed) && g_bcd_acc.load(std::memory_order_relaxed) &&
+        if (fused && a.allow_persist && g_bcd_persist.load(std::memory_order_relaxed) && g_bcd_acc.load(std::memory_order_relaxed) &&
             cdiv(k, kNB) <= kPersistBlocksMax) {
-            static const int ncu_p = [] {
-                int dev = 0;
-                hipDeviceProp_t prop;
-                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                    return prop.multiProcessorCount;
-                return 256;
-            }();
-            // (every workgroup must be resident: the resolver + one per 32 or 64 sampled rows.  Reduction 1 at the metric's shape:
-            //  157 workgroups of 64 rows, 0.173 -> 0.138 ms per dictionary update against one launch per block; config 5's
-            //  16.7 k sampled rows do not fit and keep one launch per block)
-            const int64_t rows_max = std::min<int64_t>(kPersistRowsMax, ncu_p - 1);
-            if (cdiv(s, 32) <= rows_max) persist_rt = 1;
-            else if (kp <= 256 && cdiv(s, 64) <= rows_max) persist_rt = 2;
+            // (every workgroup must be resident: the resolver + one per 32 or 64 sampled rows - asked of the runtime for the
+            //  kernel's own footprint on this device, bcd_persist_fits.  Reduction 1 at the metric's shape: 157 workgroups of
+            //  64 rows, 0.173 -> 0.138 ms per dictionary update against one launch per block; config 5's 16.7 k sampled rows
+            //  do not fit and keep one launch per block.  The LDS of riding k-wide tiles is part of the question: a launch
+            //  that cannot carry them must not have marked them consumed)
+            const size_t xl = (a.rider && a.rider->p >= 2048) ? wide_lds_bytes<32, 128>() : 0;
+            const int64_t n1 = cdiv(s, 32), n2 = cdiv(s, 64);
+            if (n1 <= kPersistRowsMax && bcd_persist_fits(kp, 1, (int)n1, xl)) persist_rt = 1;
+            else if (kp <= 256 && n2 <= kPersistRowsMax && bcd_persist_fits(kp, 2, (int)n2, xl)) persist_rt = 2;
         }
         if (persist_rt) RT = persist_rt;
         const int nslab = fused ? (int)cdiv(s, 32 * RT) : (int)cdiv(s, kGramRows);
@@ -2166,8 +2162,14 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             pa.rec = reinterpret_cast<double *>(ws + L.off_prec);
             pa.Sbuf = reinterpret_cast<double *>(ws + L.off_Sbuf);
             pa.arrive = pflags; pa.sflag = pflags + kPersistBlocksMax; pa.err = pflags + 2 * kPersistBlocksMax;
-            pa.sticky = a.sticky_err;
-            pa.expect = nslab + (g_bcd_persist.load(std::memory_order_relaxed) == 3 ? 1 : 0);   // (3: the give-up path, tests)
+            pa.flags = a.persist_flags;
+            pa.C = reinterpret_cast<const float *>(a.C);
+            pa.expect = nslab;
+#ifdef MODL_DIAG
+            // diagnostics build only: 3 makes the resolver wait for a workgroup that never comes (the recovery path), 4 makes it
+            // wait for it from the SECOND block on (the unrecoverable path), tests/test_gpu_step.py
+            pa.inject = g_bcd_persist.load(std::memory_order_relaxed);
+#endif
             pa.stamps = reinterpret_cast<unsigned long long *>(ws + L.off_pstamps);
             pa.s = s; pa.k = kp; pa.kout = k; pa.nblk = (int)cdiv(k, kNB); pa.nrow = nslab; pa.shards = pshards;
             BcdRiderArgs r = rid;                                       // every riding tile with the one launch

@@ -34,6 +34,8 @@
 // steps.  Contributions outside the accumulator's range raise its out-of-range word and the resolver sums the
 // per-workgroup records instead (any magnitude), as in bcd.hip.
 #include "bcd_shared.hpp"
+#include <mutex>
+#include <vector>
 
 namespace modl {
 
@@ -105,16 +107,21 @@ __device__ __forceinline__ long long load_sc1(const long long *ptr) {
 
 // ---- bounded waits --------------------------------------------------------------------------------------------------
 // ONE lane polls ONE word (relaxed, agent scope); the payload behind it is read with sc1 loads (no acquire).
-__device__ __forceinline__ void give_up(unsigned int *err, unsigned int *sticky) {
+// A wait that gives up raises the launch's error word: every other wait of the launch then ends as well.  What that MEANS is
+// decided by the resolver alone (persist_resolver): before its first block is resolved nothing has been applied anywhere and
+// it completes the update by itself (persist_recover); afterwards the update is incomplete and it raises the plan's flag.
+__device__ __forceinline__ void give_up(unsigned int *err) {
     __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (sticky) __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ __forceinline__ bool poll_word(unsigned int *word, unsigned int target, unsigned int *err, unsigned int *sticky) {
+__device__ __forceinline__ void raise_incomplete(const BcdPersistArgs &p) {
+    if (p.flags) __hip_atomic_store(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool poll_word(unsigned int *word, unsigned int target, unsigned int *err, unsigned limit = kSpinLimit) {
     for (unsigned spins = 0;; ++spins) {
         const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v >= target) break;
-        if (spins > kSpinLimit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-            give_up(err, sticky);
+        if (spins > limit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            give_up(err);
             return false;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -291,6 +298,76 @@ __device__ __forceinline__ void load_pieces(const BcdPersistArgs &p, int b, int 
     }
 }
 
+// ---- the update by ONE workgroup (the resolver, after a launch that could not run: persist_resolver) ---------------------
+// The reference's sweep as it is written (dict_fact.py:672-694 with l2 atoms, enet.pyx:59-67): atom after atom in sweep order,
+// candidate = (B_j - sum_{i != j} C[i][j] D_i) / C[j][j] against the dictionary AS IT IS NOW (frozen atoms keep their values,
+// :681), scaled into the ball of the atom's budget, the budget updated.  Rows are read from and written to the real
+// dictionary; sums in double.  Milliseconds instead of microseconds - it runs when the persistent launch cannot, once per
+// plan (the host then keeps that plan on one launch per block, bcd.hip).
+__device__ __forceinline__ void persist_recover(const BcdPersistArgs &p, char *smem_raw) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;                 // six waves
+    const int k = p.kout, kp = p.k;
+    float *u = reinterpret_cast<float *>(smem_raw);                               // [s] candidates of the current atom
+    double *red = reinterpret_cast<double *>(smem_raw + sizeof(float) * (size_t)((p.s + 3) & ~(int64_t)3));   // [3][8]
+    for (int jj = 0; jj < k; ++jj) {
+        const int oj = p.order[jj];
+        const float d = p.cdiag[jj];
+        const int fz = p.frozen[jj];
+        const float budget_in = p.norm_in[jj];
+        float cv[8];                                                             // row oj of C (= its column: C is symmetric), atoms lane + 64 q
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = lane + 64 * q;
+            cv[q] = (i < k && i != oj) ? p.C[(int64_t)oj * k + i] : 0.f;
+        }
+        double old2 = 0.0, new2 = 0.0;
+        for (int64_t f = wid; f < p.s; f += 6) {                                  // a row per wave
+            const int64_t row = p.subset ? (int64_t)p.subset[f] : f;
+            const float *dr = p.Dt_out + row * k;
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = lane + 64 * q;
+                if (i < k) acc += (double)cv[q] * (double)dr[i];
+            }
+#pragma unroll
+            for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
+            const float dold = dr[oj];
+            const float bv = p.BsP[dfrag(f, jj, kp)];
+            const float un = fz ? dold : (float)(((double)bv - acc) / (double)d);
+            if (lane == 0) u[f] = un;
+            old2 += (double)dold * (double)dold;
+            new2 += (double)un * (double)un;
+        }
+        if (lane == 0) { red[wid] = old2; red[8 + wid] = new2; }
+        __syncthreads();
+        double o2 = 0.0, n2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 6; ++w) { o2 += red[w]; n2 += red[8 + w]; }
+        const double budget = (double)budget_in + o2;                             // dict_fact.py:677
+        const double scale = (n2 <= budget) ? 1.0 : sqrt(n2 / budget);            // enet.pyx:60-66
+        double out2 = 0.0;
+        for (int64_t f = tid; f < p.s; f += 384) {
+            const int64_t row = p.subset ? (int64_t)p.subset[f] : f;
+            const float o = (budget > 0.0) ? (float)((double)u[f] / scale) : 0.f; // (enet.pyx:55: radius 0 -> the zero atom)
+            p.Dt_out[row * k + oj] = o;
+            out2 += (double)o * (double)o;
+        }
+#pragma unroll
+        for (int off = 32; off; off >>= 1) out2 += __shfl_xor(out2, off);
+        if (lane == 0) red[16 + wid] = out2;
+        __syncthreads();                                                         // (also: this atom's rows before the next atom reads them)
+        if (tid == 0) {
+            double t2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < 6; ++w) t2 += red[16 + w];
+            p.norm_out[oj] = (float)(budget - t2);                                // dict_fact.py:692
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && p.flags) __hip_atomic_fetch_add(p.flags + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- the resolver workgroup ------------------------------------------------------------------------------------------
 // Six wavefronts: 4 the chain of the recursion (it also publishes S while the others transform), 5 its helper, 0-3 everything
 // else.  Per block b:   [transform: pieces of b + S_{b-1} -> Gram matrix of b | wave 4 publishes S_{b-1}]  barrier
@@ -429,9 +506,20 @@ __device__ __forceinline__ void persist_resolver(const BcdPersistArgs &p, char *
         int tv = tid;
         asm volatile("" : "+v"(tv));
         if (wid < 4) { coef_request(0, tv); block_inputs(0, tv); }
-        if (tid == 0) flag[0] = poll_word(p.arrive + 0, (unsigned)p.expect, p.err, p.sticky) ? 1 : 0;
+#ifdef MODL_DIAG
+        if (tid == 0) flag[0] = poll_word(p.arrive + 0, (unsigned)p.expect + (p.inject == 3 ? 1u : 0u), p.err, p.inject == 3 ? (1u << 14) : kSpinLimit) ? 1 : 0;
+#else
+        if (tid == 0) flag[0] = poll_word(p.arrive + 0, (unsigned)p.expect, p.err) ? 1 : 0;
+#endif
         __syncthreads();
-        if (!flag[0]) return;
+        if (!flag[0]) {
+            // a wait gave up before the first block was resolved (a row workgroup that is not resident: another process or a
+            // mask holding compute units): no S has left this workgroup, so no row workgroup has applied anything - the
+            // dictionary, the norm budgets and every input of the update are as the set-up kernel left them.  The row
+            // workgroups see the error word and leave; this workgroup runs the whole sweep by itself.
+            persist_recover(p, smem_raw);
+            return;
+        }
         if (st && tid == 0) st[1] = clock64();
         if (wid < 4) {
             load_pieces<256, kPairsXM, kPairsAll>(p, 0, tv, Mp, dtab, dtab2);    // (<N', N'> of block 0 IS its Gram matrix)
@@ -476,7 +564,11 @@ __device__ __forceinline__ void persist_resolver(const BcdPersistArgs &p, char *
                 coef_request(b + 1, tv - 128);
                 coef_request2(b + 1, tv - 128);
                 if (tv == 128) {                                                // one lane waits for the row workgroups
-                    const int ok = poll_word(p.arrive + b + 1, (unsigned)p.expect, p.err, p.sticky) ? 1 : 2;
+#ifdef MODL_DIAG
+                    const int ok = poll_word(p.arrive + b + 1, (unsigned)p.expect + (p.inject == 4 ? 1u : 0u), p.err, p.inject == 4 ? (1u << 14) : kSpinLimit) ? 1 : 2;
+#else
+                    const int ok = poll_word(p.arrive + b + 1, (unsigned)p.expect, p.err) ? 1 : 2;
+#endif
                     if (st) st[5 + 4 * b] = clock64();
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     *(lds_vint *)(flag + 3) = ok + 4 * (b + 1);                  // (monotonic: verdict + 4 x block)
@@ -496,7 +588,10 @@ __device__ __forceinline__ void persist_resolver(const BcdPersistArgs &p, char *
         }
         lds_barrier();                                                           // ---- recursion done, pieces of b + 1 in LDS
         if (st && tid == 0) st[3 + 4 * b] = clock64();
-        if (b + 1 < p.nblk && (flag[3] & 3) != 1) return;                        // (a wait gave up: every thread leaves)
+        if (b + 1 < p.nblk && (flag[3] & 3) != 1) {                              // (a wait gave up: every thread leaves)
+            if (tid == 0) raise_incomplete(p);                                   // S_0 .. S_b have left: the update is incomplete
+            return;
+        }
         // ---- transform for block b + 1 ----
         if (b + 1 < p.nblk && wid < 4) {
             if (tv == 0) { *mail.pcount = 0; *mail.zcount = 0; }
@@ -515,6 +610,9 @@ __device__ __forceinline__ void persist_resolver(const BcdPersistArgs &p, char *
         __syncthreads();                                                         // ---- Gram matrix of block b + 1 ready
         if (st && tid == 0) st[4 + 4 * b] = clock64();
     }
+    // every S has been published: a row workgroup can only have given up before this point (off the update's critical path -
+    // the row workgroups are still applying the last block)
+    if (tid == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) raise_incomplete(p);
 }
 
 // ---- a row workgroup ---------------------------------------------------------------------------------------------------
@@ -831,7 +929,7 @@ __device__ __forceinline__ void persist_rows(const BcdPersistArgs &p, char *smem
                               __double_as_longlong(s2) != kSentinel && __double_as_longlong(s3) != kSentinel;
             if (__all(have)) break;
             if (spins > kSpinLimit || ((spins & 63) == 63 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                give_up(p.err, p.sticky);
+                give_up(p.err);
                 ok = false;
                 break;
             }
@@ -982,17 +1080,45 @@ size_t bcd_persist_lds(int kp, int RT) {
     return rows > res ? rows : res;
 }
 
+// Can the resolver + nrow row workgroups of the persistent launch be resident together on the CURRENT device?  Asked of the
+// runtime for the kernel's actual register / LDS footprint (hipOccupancyMaxActiveBlocksPerMultiprocessor), per device and
+// variant, once.  What it cannot know - another process or a mask holding compute units - is what persist_recover is for.
+bool bcd_persist_fits(int kp, int RT, int nrow, size_t extra_lds) {
+    size_t lds = bcd_persist_lds(kp, RT);
+    if (extra_lds > lds) lds = extra_lds;
+    if (lds > 160 * 1024 || nrow > kPersistRowsMax) return false;
+    struct Slot { int dev; int rt; size_t lds; int cap; };
+    static std::mutex mu;
+    static std::vector<Slot> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Slot &c : cache)
+        if (c.dev == dev && c.rt == RT && c.lds == lds) return 1 + nrow <= c.cap;
+    void (*kern)(BcdPersistArgs, BcdRiderArgs) = (RT == 1) ? bcd_persist_kernel<1> : bcd_persist_kernel<2>;
+    int per_cu = 0, ncu = 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 384, lds) != hipSuccess ||
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        per_cu = 0;
+    }
+    // one workgroup per compute unit is what the design counts on (the resolver alone on its unit; two row workgroups on one
+    // unit would share its matrix pipe and LDS bandwidth and lengthen every phase): more than one resident per unit does not
+    // raise the capacity
+    const int cap = per_cu >= 1 ? ncu : 0;
+    cache.push_back({dev, RT, lds, cap});
+    return 1 + nrow <= cap;
+}
+
 int launch_bcd_persist(hipStream_t stream, const BcdPersistArgs &p, const BcdRiderArgs &rider, int extra_wgs, size_t extra_lds,
                        int RT) {
     void (*kern)(BcdPersistArgs, BcdRiderArgs) = (RT == 1) ? bcd_persist_kernel<1> : bcd_persist_kernel<2>;
     size_t lds = bcd_persist_lds(p.k, RT);
     if (extra_wgs > 0 && extra_lds > lds) lds = extra_lds;
-    if (lds > 160 * 1024) return MODL_EINVAL;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[RT - 1]) {
-        MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[RT - 1] = true;
-    }
+    if (lds > 160 * 1024) return MODL_EINVAL;                                      // (bcd.hip asks bcd_persist_fits first)
+    // (per call, like every other launch of the library: plans may live on several devices of one process)
+    MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(kern, dim3((unsigned)(1 + p.nrow + extra_wgs)), dim3(384), lds, stream, p, rider);
     MODL_LAUNCH_CHECK();
     return MODL_OK;

@@ -689,14 +689,20 @@ struct BcdPersistArgs {
     double *rec;                    // [2][nrow][kPEntries] per-workgroup records (the out-of-range fallback)
     double *Sbuf;                   // [nblk][32 * 32]
     unsigned int *arrive, *sflag;   // [nblk] each, zero on entry
-    unsigned int *err;              // raised by a wait that gave up (zero on entry)
-    unsigned int *sticky;           // optional: raised with it, never cleared by the kernels (modl_somf_status)
+    unsigned int *err;              // raised by a wait that gave up (zero on entry): every workgroup of THIS launch leaves
+    unsigned int *flags;            // optional, pinned host memory, never cleared by the kernels: [0] raised when a launch gave up
+                                    // AFTER its first block had been resolved (the update is incomplete: modl_somf_status ->
+                                    // MODL_ETIMEOUT), [1] counts the launches that gave up BEFORE it - nothing had been applied - and
+                                    // were completed by the resolver workgroup alone (persist_recover)
+    const float *C;                 // [kout][kout] the statistics in natural order (persist_recover only)
     unsigned long long *stamps;     // diagnostics build: [kPersistStampWords]
     int64_t s;
     int k, kout, nblk, nrow, shards;
-    int expect;                     // arrivals the resolver waits for per block: nrow (diagnostics: nrow + 1 - a workgroup that never comes)
+    int expect;                     // arrivals the resolver waits for per block: nrow
+    int inject = 0;                 // diagnostics build: 3 / 4 - wait for one arrival more than will come at block 0 / from block 1 on
 };
 size_t bcd_persist_lds(int kp, int RT);
+bool bcd_persist_fits(int kp, int RT, int nrow, size_t extra_lds);   // resident together on the current device? (occupancy query, cached)
 // grid: the resolver, nrow row workgroups of 32 RT rows, extra_wgs riding workgroups (rider.nslab must be nrow + 1)
 int launch_bcd_persist(hipStream_t stream, const BcdPersistArgs &p, const BcdRiderArgs &rider, int extra_wgs, size_t extra_lds,
                        int RT);

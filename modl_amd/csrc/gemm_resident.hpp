@@ -306,12 +306,4 @@ int launch_gemm_stats_resident_pair(hipStream_t stream, const DenseProblem<float
     return MODL_OK;
 }
 
-// rounds x features per tile: what the slowest workgroup contracts
-inline int64_t resident_cost(int64_t M, int FT, int ncu) {
-    const int64_t ntile = cdiv(M, FT);
-    int64_t nwg = ntile < ncu ? ntile : ncu;
-    if (nwg >= 8) nwg &= ~(int64_t)7;
-    return cdiv(ntile, nwg) * FT;
-}
-
 }  // namespace modl

@@ -158,7 +158,10 @@ struct DictUpdateArgs {
     size_t ws_bytes;
     StatsRider *rider = nullptr;   // optional (f32 fused path only)
     StageRide *stage = nullptr;    // optional (f32 fused path only): rides the last launch; `consumed` says whether it did
-    unsigned int *sticky_err = nullptr;   // optional, PERSISTENT across calls (zero-initialised): raised when a wait of the persistent launch gives up
+    unsigned int *persist_flags = nullptr;   // optional, pinned host memory, PERSISTENT across calls (zero-initialised), BcdPersistArgs::flags:
+                                   // [0] a persistent launch gave up half-way (update incomplete), [1] launches that could not
+                                   // run and were completed by one workgroup
+    bool allow_persist = true;     // false: one launch per block (a plan whose persistent launch could not run once)
     double *level_hint = nullptr;  // optional [k], PERSISTENT across calls (zero-initialised): the soft-threshold level
                                    // each atom's l1 / elastic-net projection ended with, warm start of the next one
 };

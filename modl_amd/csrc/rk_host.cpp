@@ -344,7 +344,7 @@ const char *modl_error_string(int code) {
         case MODL_ENOGPU: return "no HIP device (or one with less than 160 KiB of LDS per compute unit)";
         case MODL_ENORCCL: return "librccl.so could not be loaded";
         case MODL_ERCCL: return "RCCL call failed";
-        case MODL_ETIMEOUT: return "a persistent kernel's wait gave up (workgroups not resident)";
+        case MODL_ETIMEOUT: return "a persistent dictionary-update launch gave up half-way (its wait gave up: workgroups not resident); the update is incomplete";
         default: return code > 0 ? "HIP runtime error (hipError_t)" : "unknown error";
     }
 }

@@ -292,7 +292,11 @@ struct modl_somf_plan {
     size_t off_params, off_xnorm, off_Dx, off_H0, off_G, off_F, off_Linv, off_split, off_du, off_sweeps, off_Ds, off_Xs, off_codeb, off_level;
     int last_b = 0;
     int64_t last_s = 0;
-    unsigned int *h_status = nullptr;  // pinned: where modl_somf_status receives the status word
+    // the persistent dictionary-update launch's words (pinned, device-mapped; BcdPersistArgs::flags): [0] an update gave up
+    // half-way, [1] launches that could not run and were completed by one workgroup.  Read by the host before every enqueue.
+    unsigned int *pflags = nullptr, *pflags_dev = nullptr;
+    unsigned int recoveries_seen = 0;
+    bool persist_ok = true;            // false once a persistent launch of this plan could not run: one launch per block from then on
     size_t split_bytes, du_bytes, params_bytes;
     // per-batch parameter block (device copy of the host arrays), layout within params:
     size_t po_idx, po_subset, po_order, po_wsample;
@@ -880,6 +884,23 @@ int phase1(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
     return MODL_OK;
 }
 
+// What the persistent dictionary-update launches of this plan have reported so far (pinned words, written by the device at
+// system scope; a plain read, no synchronisation).  A launch that could not run - its workgroups were not resident together -
+// and was completed by one workgroup (bcd_persist.hip: persist_recover) switches the plan to one launch per block for good:
+// whatever held the compute units may still be there.  An update that gave up half-way is incomplete: nothing more is
+// enqueued on this plan until modl_somf_status has reported it (not only when somebody synchronises).
+static int persist_gate(modl_somf_plan *pl) {
+    if (!pl->pflags) return MODL_OK;
+    volatile unsigned int *f = pl->pflags;
+    if (f[0] != 0) return MODL_ETIMEOUT;
+    const unsigned int r = f[1];
+    if (r != pl->recoveries_seen) {
+        pl->recoveries_seen = r;
+        pl->persist_ok = false;
+    }
+    return MODL_OK;
+}
+
 // The dictionary update (dict_fact.py:650-715).  After a two-phase phase 1, `head` = [ C | rows of B_ ] summed over
 // the ranks: C is read from it, the rows of B_ are scattered into a plan-owned [p][k] array (the rank's own B_ keeps
 // its partial sums) - without a subset array the head IS that array.
@@ -892,6 +913,7 @@ int phase2(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
     if (!pl->staged) return MODL_ESTATE;
     if (!stt || !stt->d_Dt || !stt->d_Bt || !stt->d_C || !stt->d_comp_norm) return MODL_EINVAL;
     if (pl->head_pending && !head) return MODL_EINVAL;
+    MODL_TRY(persist_gate(pl));
     char *P = pl->dws + pl->off_params;
     const int32_t *d_subset = pl->has_subset ? reinterpret_cast<const int32_t *>(P + pl->po_subset) : nullptr;
     const int32_t *d_order = reinterpret_cast<const int32_t *>(P + pl->po_order);
@@ -929,7 +951,8 @@ int phase2(modl_somf_plan *pl, const modl_somf_state *stt, const modl_somf_batch
         a.ws = pl->dws + pl->off_du; a.ws_bytes = pl->du_bytes;
         a.rider = pl->ride_pending ? &pl->rider : nullptr;
         a.level_hint = reinterpret_cast<double *>(pl->dws + pl->off_level);
-        a.sticky_err = reinterpret_cast<unsigned int *>(pl->dws + pl->off_level + sizeof(double) * (size_t)k);
+        a.persist_flags = pl->pflags_dev;
+        a.allow_persist = pl->persist_ok;
         // the next minibatch of the chunk loop: its pinned slot is filled now and the copy into the OTHER device block
         // rides on the update's last launch (or follows it as a launch of its own when that path has no riders); a
         // next minibatch that does not validate is simply staged - and reported - by its own step
@@ -1162,7 +1185,7 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     pl->off_split = take(pl->split_bytes);
     pl->du_bytes = dict_update_workspace(desc->dtype, (int64_t)p, desc->k);
     pl->off_du = take(pl->du_bytes);
-    pl->off_level = take(sizeof(double) * k + 64);   // per-atom projection levels (warm start of the next projection) + the sticky error word
+    pl->off_level = take(sizeof(double) * k + 64);   // per-atom projection levels (warm start of the next projection)
     pl->dws_bytes = o;
     hipError_t e = hipMalloc((void **)&pl->dws, pl->dws_bytes);
     if (e != hipSuccess) { delete pl; return (int)e; }
@@ -1170,6 +1193,10 @@ int modl_somf_plan_create(const modl_somf_desc *desc, modl_somf_plan **out) {
     if (e == hipSuccess) e = hipMemset(pl->dws + pl->off_level, 0, sizeof(double) * k + 64);
     if (e == hipSuccess && pl->ld_gpad) e = hipMemset(pl->dws + pl->off_Gpad, 0, t * ((size_t)pl->ld_gpad + 16) * pl->ld_gpad);
     if (e != hipSuccess) { modl_somf_plan_destroy(pl); return (int)e; }
+    e = hipHostMalloc((void **)&pl->pflags, 64, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&pl->pflags_dev, pl->pflags, 0);
+    if (e != hipSuccess) { modl_somf_plan_destroy(pl); return (int)e; }
+    std::memset(pl->pflags, 0, 64);
     for (int i = 0; i < kStageSlots; ++i) {
         e = hipHostMalloc((void **)&pl->hstage[i], align_up(pl->params_bytes, 16) + 64, hipHostMallocMapped);   // + acknowledgement word
         if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&pl->hstage_dev[i], pl->hstage[i], 0);
@@ -1186,7 +1213,7 @@ void modl_somf_plan_destroy(modl_somf_plan *pl) {
     if (pl->Bsum) (void)hipFree(pl->Bsum);
     if (pl->Gslots) (void)hipFree(pl->Gslots);
     if (pl->own_head) (void)hipFree(pl->own_head);
-    if (pl->h_status) (void)hipHostFree(pl->h_status);
+    if (pl->pflags) (void)hipHostFree(pl->pflags);
     for (int i = 0; i < kStageSlots; ++i) {
         if (pl->hstage[i]) (void)hipHostFree(pl->hstage[i]);
     }
@@ -1224,6 +1251,7 @@ int modl_somf_code_and_partials(modl_somf_plan *pl, const modl_somf_state *st, c
     if (!pl || !bt) return MODL_EINVAL;
     DeviceScope dev(pl);
     pl->ahead = false;
+    MODL_TRY(persist_gate(pl));
     return DISPATCH(pl, phase1<float>(pl, st, bt, static_cast<float *>(d_head), (hipStream_t)stream, true),
                     phase1<double>(pl, st, bt, static_cast<double *>(d_head), (hipStream_t)stream, true));
 }
@@ -1247,6 +1275,7 @@ int modl_somf_apply_and_update_dict(modl_somf_plan *pl, const modl_somf_state *s
 static int somf_step_next(modl_somf_plan *pl, const modl_somf_state *st, const modl_somf_batch *bt,
                           const modl_somf_batch *next, void *stream) {
     DeviceScope dev(pl);
+    MODL_TRY(persist_gate(pl));
     MODL_TRY(DISPATCH(pl, phase1<float>(pl, st, bt, nullptr, (hipStream_t)stream, false),
                       phase1<double>(pl, st, bt, nullptr, (hipStream_t)stream, false)));
     return DISPATCH(pl, phase2<float>(pl, st, bt, nullptr, (hipStream_t)stream, next),
@@ -1635,14 +1664,10 @@ int modl_somf_debug_stamps(modl_somf_plan *pl, unsigned long long *h_out) {
 int modl_somf_status(modl_somf_plan *pl, void *stream) {
     if (!pl) return MODL_EINVAL;
     DeviceScope dev(pl);
-    if (!pl->h_status) MODL_HIP(hipHostMalloc(reinterpret_cast<void **>(&pl->h_status), sizeof(unsigned int), hipHostMallocDefault));
-    unsigned int *d_word = reinterpret_cast<unsigned int *>(pl->dws + pl->off_level + sizeof(double) * (size_t)pl->d.k);
-    *pl->h_status = 0;
-    MODL_HIP(hipMemcpyAsync(pl->h_status, d_word, sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     // The wait: the stream is POLLED for the first 20 ms, then the thread blocks.  A blocking synchronisation returns
     // 50-100 us after the stream has drained on this stack (an interrupt and a wake-up) - 2 % of a partial_fit call of 20
-    // minibatches; hipStreamQuery sees it within a few microseconds.  (Pinned destination: the copy is a stream operation, not a
-    // host-side staging loop.)
+    // minibatches; hipStreamQuery sees it within a few microseconds.  (The words are in pinned host memory, written by the
+    // device at system scope: nothing is copied.)
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t q = hipStreamQuery((hipStream_t)stream);
@@ -1653,9 +1678,19 @@ int modl_somf_status(modl_somf_plan *pl, void *stream) {
             break;
         }
     }
-    if (*pl->h_status == 0) return MODL_OK;
-    MODL_HIP(hipMemsetAsync(d_word, 0, sizeof(unsigned int), (hipStream_t)stream));
+    (void)persist_gate(pl);                                   // (a recovery seen now keeps the next enqueue off the persistent launch)
+    volatile unsigned int *f = pl->pflags;
+    if (!f || f[0] == 0) return MODL_OK;
+    f[0] = 0;                                                 // (the stream is idle: nobody else writes)
+    pl->persist_ok = false;
     return MODL_ETIMEOUT;
+}
+
+int modl_somf_persist_recoveries(modl_somf_plan *pl, int64_t *count) {
+    if (!pl || !count) return MODL_EINVAL;
+    volatile unsigned int *f = pl->pflags;
+    *count = f ? (int64_t)f[1] : 0;
+    return MODL_OK;
 }
 
 int modl_somf_debug_persist_stamps(modl_somf_plan *pl, unsigned long long *h_out) {

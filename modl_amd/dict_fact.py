@@ -120,6 +120,7 @@ class HipBackend:
         with torch.cuda.device(self.device):
             check(lib.modl_somf_plan_create(C.byref(d), C.byref(h)), 'modl_somf_plan_create')
         self.plan = h
+        self.persist_recoveries = 0       # (of this plan: persistent launches completed by one workgroup, synchronize())
 
     def update_plan(self, kw):
         """set_params between minibatches (dict_fact.py:339-357)."""
@@ -263,8 +264,19 @@ class HipBackend:
             check(lib.modl_comm_wait(comm, stream_ptr(self.device), self.COMM_TIMEOUT_S), 'modl_comm_wait')
         if self.plan is not None:
             # (also a synchronisation of the stream) a persistent dictionary-update launch whose workgroups were not all
-            # resident gives up instead of hanging: that must not pass for a fit
+            # resident never hangs: before its first block it is completed on the device by one workgroup (counted here,
+            # with a warning; the plan keeps one launch per block from then on), later it leaves the update incomplete and
+            # that must not pass for a fit (MODL_ETIMEOUT)
             check(lib.modl_somf_status(self.plan, stream_ptr(self.device)), 'modl_somf_status')
+            n = C.c_int64(0)
+            check(lib.modl_somf_persist_recoveries(self.plan, C.byref(n)), 'modl_somf_persist_recoveries')
+            if n.value > self.persist_recoveries:
+                import warnings
+                warnings.warn('modl_amd: %d persistent dictionary-update launch(es) could not run (their workgroups were not '
+                              'resident together: is another process using this GPU?); each was completed by one workgroup '
+                              'and this estimator now runs one launch per block of atoms' % (n.value - self.persist_recoveries),
+                              RuntimeWarning, stacklevel=3)
+                self.persist_recoveries = n.value
         torch.cuda.synchronize(self.device)
 
     # -- the step -------------------------------------------------------------

@@ -26,7 +26,7 @@ def test_library_exports_header(lib):
     assert len(names) > 40
     missing = [n for n in sorted(names) if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.modl_abi_version() == 4
+    assert lib.modl_abi_version() == 5
     assert lib.modl_device_count() >= 0
     assert lib.modl_error_string(-1) == b'invalid argument'
 

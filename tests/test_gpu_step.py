@@ -1224,27 +1224,111 @@ def test_objective_on_device_chunked(dtype, tol):
     assert f(ptr(dX), p + 3, n, p, ptr(dDt), k, ptr(dcode), ptr(ws), 64, ptr(out), stream_ptr(dev)) == -2      # MODL_ENOMEM
 
 
-def test_persistent_launch_gives_up_loudly(DictFact):
-    """The persistent dictionary-update launch needs every workgroup resident; when one never arrives (another process holding
-    the compute units: here simulated, modl_debug_set(MODL_DEBUG_BCD_PERSIST, 3) makes the resolver wait for nrow + 1 arrivals)
-    its bounded waits give up, every workgroup leaves - no hang - and the next synchronisation raises (modl_somf_status:
-    MODL_ETIMEOUT) instead of passing a half-updated dictionary for a fit.  Afterwards the estimator works again."""
-    from modl_amd._lib import lib, check, ModlError, DEBUG_BCD_PERSIST
-    rs = np.random.RandomState(5)
-    n, p, k, b = 256, 600, 64, 64
-    X = (rs.randn(n, 24).dot(rs.randn(24, p)) + 0.3 * rs.randn(n, p)).astype(np.float32)
-    est = DictFact(n_components=k, batch_size=b, reduction=3, code_alpha=0.2, random_state=0)
-    est.prepare(n_samples=n, X=X)
-    est.partial_fit(X[:b], np.arange(b))
+_PERSIST_RECOVERY_SCRIPT = r"""
+import json, sys, warnings
+import numpy as np
+from modl_amd import DictFact
+from modl_amd._lib import lib, check, ModlError, DEBUG_BCD_PERSIST
+assert lib.modl_is_diag_build() == 1
+mode = sys.argv[1]
+rs = np.random.RandomState(5)
+n, p, k, b = 512, 600, 64, 64
+X = (rs.randn(n, 24).dot(rs.randn(24, p)) + 0.3 * rs.randn(n, p)).astype(np.float32)
+kw = dict(n_components=k, batch_size=b, reduction=3, code_alpha=0.2, random_state=0)
+out = {}
+if mode == 'recover':
+    # A: the second partial_fit's FIRST persistent launch cannot run (a workgroup that never arrives); B: one launch per block
+    check(lib.modl_debug_set(DEBUG_BCD_PERSIST, 1))
+    A = DictFact(**kw); A.prepare(n_samples=n, X=X)
+    A.partial_fit(X[:b], np.arange(b))
+    check(lib.modl_debug_set(DEBUG_BCD_PERSIST, 3))
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter('always')
+        A.partial_fit(X[b:4 * b], np.arange(b, 4 * b))          # three minibatches: recovered while the flag is unseen, then block launches
+        D_mid = A.components_.copy()
+    out['warned'] = sum('could not run' in str(w.message) for w in wlist)
+    out['recoveries'] = int(A._backend.persist_recoveries)
+    check(lib.modl_debug_set(DEBUG_BCD_PERSIST, 1))
+    A.partial_fit(X[4 * b:], np.arange(4 * b, n))               # no prepare(): the estimator carries on
+    check(lib.modl_debug_set(DEBUG_BCD_PERSIST, 0))
+    B = DictFact(**kw); B.prepare(n_samples=n, X=X)
+    B.partial_fit(X[:b], np.arange(b))
+    B.partial_fit(X[b:4 * b], np.arange(b, 4 * b))
+    DB_mid = B.components_.copy()
+    B.partial_fit(X[4 * b:], np.arange(4 * b, n))
+    rel = lambda a, c: float(np.linalg.norm(a - c) / np.linalg.norm(c))
+    out['mid'] = rel(D_mid, DB_mid)
+    out['end'] = rel(A.components_, B.components_)
+    out['code'] = rel(A.code_, B.code_)
+    out['norms_ok'] = bool(np.all(np.sum(A.components_ ** 2, axis=1) <= 1 + 1e-5))
+    np.save(sys.argv[2], A.components_)
+else:
+    # the resolver loses a workgroup from the SECOND block on: S_0 has been applied, the update is incomplete
+    A = DictFact(**kw); A.prepare(n_samples=n, X=X)
+    A.partial_fit(X[:b], np.arange(b))
+    check(lib.modl_debug_set(DEBUG_BCD_PERSIST, 4))
     try:
-        check(lib.modl_debug_set(DEBUG_BCD_PERSIST, 3))
-        with pytest.raises(ModlError, match='wait gave up'):
-            est.partial_fit(X[b:2 * b], np.arange(b, 2 * b))
-    finally:
-        check(lib.modl_debug_set(DEBUG_BCD_PERSIST, 1))
-    est.prepare(n_samples=n, X=X)                                   # (the dictionary of the failed update is not to be trusted)
-    est.partial_fit(X, np.arange(n))
-    assert np.all(np.isfinite(est.components_))
+        A.partial_fit(X[b:4 * b], np.arange(b, 4 * b))
+        out['raised'] = ''
+    except ModlError as e:
+        out['raised'] = str(e)
+    check(lib.modl_debug_set(DEBUG_BCD_PERSIST, 1))
+    A.prepare(n_samples=n, X=X)                                  # (the dictionary of the failed update is not to be trusted)
+    A.partial_fit(X, np.arange(n))
+    out['finite'] = bool(np.all(np.isfinite(A.components_)))
+print(json.dumps(out))
+"""
+
+
+def _run_diag_script(script, *args):
+    import json
+    import os
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    env = dict(os.environ)
+    env['MODL_AMD_DIAG'] = '1'
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    r = subprocess.run([sys.executable, '-c', script] + list(args), cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_persistent_launch_recovers(tmp_path):
+    """The persistent dictionary-update launch needs every workgroup resident; when one never arrives (another process or a mask
+    holding compute units: here simulated in the diagnostics build - modl_debug_set(MODL_DEBUG_BCD_PERSIST, 3) makes the resolver
+    wait for nrow + 1 arrivals before the first block) nothing has been applied yet: the row workgroups leave, the resolver
+    workgroup runs the sweep by itself (bcd_persist.hip: persist_recover) and the stream carries on.  No error, no prepare(): the
+    estimator warns once, counts the event, keeps one launch per block from then on, and ends where the run on block launches
+    ends, to f32 rounding (the recovered update sums in another order than the block kernel; the other minibatches then run
+    the very same kernels on inputs that differ in the last bits)."""
+    from oracle import somf_oracle as orc
+    f = str(tmp_path / 'D.npy')
+    out = _run_diag_script(_PERSIST_RECOVERY_SCRIPT, 'recover', f)
+    # (the host enqueues ahead: up to the whole call's three launches may have been enqueued before the first recovery is seen)
+    assert out['warned'] == 1 and 1 <= out['recoveries'] <= 3, out
+    assert out['norms_ok'], out
+    assert out['mid'] < 2e-5 and out['end'] < 2e-5 and out['code'] < 5e-5, out
+    # ... and against the oracle, like any other fit
+    rs = np.random.RandomState(5)
+    n, p, k, b = 512, 600, 64, 64
+    X = (rs.randn(n, 24).dot(rs.randn(24, p)) + 0.3 * rs.randn(n, p)).astype(np.float32)
+    kw = dict(n_components=k, batch_size=b, reduction=3, code_alpha=0.2, random_state=0)
+    pr = orc.SomfParams(**kw)
+    st = orc.prepare(pr, n_samples=n, X=X.astype(np.float64), dtype=np.float64)
+    for lo, hi in ((0, b), (b, 4 * b), (4 * b, n)):
+        orc.partial_fit(st, pr, X[lo:hi].astype(np.float64), np.arange(lo, hi))
+    D = np.load(f)
+    assert np.linalg.norm(D - st.D) / np.linalg.norm(st.D) < 5e-5
+
+
+def test_persistent_launch_incomplete_update_is_loud():
+    """A wait that gives up AFTER the first block has been resolved (diagnostics build, MODL_DEBUG_BCD_PERSIST = 4) leaves the
+    update incomplete: the plan's flag stops every further enqueue (MODL_ETIMEOUT from the next step - not only from the next
+    synchronisation) and the fit raises; after prepare() the estimator works again."""
+    out = _run_diag_script(_PERSIST_RECOVERY_SCRIPT, 'incomplete')
+    assert 'gave up' in out['raised'], out
+    assert out['finite'], out
 
 
 def test_bench_c5_shape_forced_reduce():
