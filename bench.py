@@ -322,6 +322,14 @@ def run_gpu(args, reduction, steps, warmup, rank, world, device, breakdown=True)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         res['replicas_identical'] = bool(torch.equal(lo, hi))
+    # persistent dictionary-update launches that could not run and were completed on the device by one workgroup (DESIGN 3.3:
+    # another process holding compute units; 0 on a GPU of one's own), summed over the ranks
+    rec = int(getattr(be, 'persist_recoveries', 0))
+    if world > 1:
+        t = torch.tensor([rec], dtype=torch.int64, device=device if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t)
+        rec = int(t.item())
+    res['persist_recoveries'] = rec
     res['rows_generated'] = run.stream.generated_rows
     res['rows_fitted'] = run.row
     res['collective'] = collective_route(run, world, args)
@@ -709,7 +717,7 @@ def main():
                                collective=res['collective']),
                    roofline=roof, sections=sections, cd_sweeps_mean=sweeps, cd_sweeps_max=res['sweeps_max'],
                    step_tflops=total_fl / (dt / args.steps) / 1e12, finite=res['finite'],
-                   replicas_identical=res['replicas_identical'],
+                   replicas_identical=res['replicas_identical'], persist_recoveries=res['persist_recoveries'],
                    host_enqueue_ms_per_step=res['enqueue_ms_per_step'],
                    rows=dict(fitted=res['rows_fitted'], generated=res['rows_generated']),
                    steady_state=steady)

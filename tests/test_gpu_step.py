@@ -1042,6 +1042,27 @@ def test_bench_two_ranks_share_gpu():
     assert rec['config']['global_batch'] == 512 and rec['value'] > 0
 
 
+def test_bench_eight_ranks_share_gpu():
+    """The driver's 8-GPU launch, dry: `python bench.py --gpus 8` starts eight ranks (here all on the box's one GPU, gloo) at a
+    small shape.  Eight persistent dictionary-update launches of 1 + 32 workgroups each do not fit 256 compute units together:
+    whichever cannot become resident is completed by its resolver workgroup and its plan falls back to one launch per block
+    (`persist_recoveries` in the line counts them) - the replicas must still be bit-identical and finite."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--share-gpu', '--backend', 'gloo',
+           '--features', '4096', '--reduction', '4', '--steps', '6', '--warmup', '2', '--steady-steps', '0', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec['n_gpus'] == 8 and rec['replicas_identical'] is True and rec['finite'] is True
+    assert rec['config']['global_batch'] == 8 * 256 and rec['value'] > 0
+    assert rec['persist_recoveries'] >= 0
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2 ...` with NO launcher (the way the driver starts `--gpus 1`): the parent starts the two
     ranks itself before anything touches the GPU and relays rank 0's line as its own last stdout line."""

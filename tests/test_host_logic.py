@@ -300,6 +300,106 @@ def test_two_rank_setters_set_the_sum():
         assert_array_equal(out[r]['B_from_local'], 3 * out[r]['v'])
 
 
+# ---- world sizes 4 and 8 (round 6: the driver's 8-GPU run must not be the first time eight ranks meet) ---------------------
+def _interleave(parts, b, steps):
+    """the one-rank run's rows: minibatch t = [rank 0's minibatch t ; rank 1's ; ...] (ragged tails included)"""
+    rows = []
+    for t in range(steps):
+        for X in parts:
+            rows.append(X[t * b:(t + 1) * b])
+    return np.concatenate(rows)
+
+
+def _rank_main_wide(rank, world, port, kw, X_parts, out):
+    import pickle
+    import warnings
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        est = _host_estimator()(**kw)
+        X = X_parts[rank]
+        est.prepare(n_samples=4 * max(x.shape[0] for x in X_parts), X=X_parts[0])
+        est.partial_fit(X, np.arange(X.shape[0]))
+        res = dict(D=est.components_, C=est.C_, B=est.B_, code=est.code_[:X.shape[0]], n_iter=est.n_iter_)
+        est.consolidate_statistics()                             # collective: rank 0 ends with the sums, the others with zeros
+        res['local_B_after'] = est.local_B_
+        if rank == 0:
+            with warnings.catch_warnings():
+                warnings.simplefilter('error')
+                res['pickle'] = pickle.dumps(est)
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_wide_world_gloo_equals_wide_batch(world, oracle):
+    """W ranks with local batch b == one rank with batch W b on the interleaved rows - at W = 4 and 8, with a RAGGED last
+    minibatch of a different length on every rank (weighed with the true global batch size), replicas bit-identical, the
+    statistics read through the estimator the same sums on every rank, and rank 0's pickle after consolidate_statistics()
+    holding the whole statistics (loads in a one-rank process)."""
+    import pickle
+    rs = np.random.RandomState(30 + world)
+    b, steps, p, k = 4, 4, 24, 4
+    tails = [1 + (r * 3) % b for r in range(world)]                       # rows of every rank's last minibatch: 1 .. b
+    parts = [rs.randn((steps - 1) * b + tails[r], 6).dot(rs.randn(6, p)) for r in range(world)]
+    kw = dict(n_components=k, batch_size=b, reduction=2, random_state=0, learning_rate=0.9, code_alpha=0.1)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rank_main_wide, args=(world, _free_port(), kw, parts, out), nprocs=world, join=True)
+    Xc = _interleave(parts, b, steps)
+    assert Xc.shape[0] == sum(x.shape[0] for x in parts)
+    pr = oracle.SomfParams(**dict(kw, batch_size=world * b))
+    st = oracle.prepare(pr, n_samples=Xc.shape[0], X=parts[0])
+    oracle.partial_fit(st, pr, Xc)
+    for r in range(world):
+        assert rel_fro(out[r]['D'], st.D) < 1e-10, r
+        assert rel_fro(out[r]['C'], st.C) < 1e-10 and rel_fro(out[r]['B'], st.B) < 1e-10
+        assert out[r]['n_iter'] == st.n_iter == Xc.shape[0]
+        assert_array_equal(out[r]['D'], out[0]['D'])                      # replicas bit-identical
+        assert_array_equal(out[r]['B'], out[0]['B'])                      # (collective read: the same sum everywhere)
+        if r:
+            assert not out[r]['local_B_after'].any()
+    codes = _interleave([out[r]['code'] for r in range(world)], b, steps)
+    assert rel_fro(codes, st.code) < 1e-10
+    assert_array_equal(out[0]['local_B_after'], out[0]['B'])
+    est = pickle.loads(out[0]['pickle'])                                  # no process group here: a one-rank process
+    assert_array_equal(est.B_, out[0]['B'])
+    assert_array_equal(est.C_, out[0]['C'])
+    assert_array_equal(est.components_, out[0]['D'])
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_wide_world_unequal_batch_counts_raise(world):
+    rs = np.random.RandomState(4)
+    parts = [rs.randn(40 if r != world - 1 else 17, 12) for r in range(world)]     # 5 minibatches everywhere but on the last rank (3)
+    kw = dict(n_components=3, batch_size=8, random_state=0)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rank_main_unseeded, args=(world, _free_port(), kw, parts, out), nprocs=world, join=True)
+    for r in range(world):
+        assert out[r]['err'] and 'same number of minibatches' in out[r]['err']
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_wide_world_unseeded_replicas_identical(world):
+    rs = np.random.RandomState(40 + world)
+    b, p, k = 8, 24, 4
+    parts = [rs.randn(41 + (r % 7), 6).dot(rs.randn(6, p)) for r in range(world)]   # 6 minibatches each, ragged tails 1 .. 7
+    kw = dict(n_components=k, batch_size=b, reduction=2, random_state=None, learning_rate=0.9, code_alpha=0.1)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rank_main_unseeded, args=(world, _free_port(), kw, parts, out), nprocs=world, join=True)
+    assert all(out[r]['err'] is None for r in range(world))
+    for r in range(1, world):
+        assert_array_equal(out[0]['D'], out[r]['D'])
+        assert_array_equal(out[0]['C'], out[r]['C'])
+        assert_array_equal(out[0]['B'], out[r]['B'])
+    assert out[0]['n_iter'] == sum(x.shape[0] for x in parts)
+    assert np.all(np.isfinite(out[0]['D']))
+
+
 def test_failed_minibatch_rewinds_the_subset_lookahead():
     """The feature subsets of the coming minibatches are drawn ahead on a worker thread.  When a minibatch fails, the
     draws nobody consumed must not be lost: after the error the sampler continues the reference's MT19937 subset
