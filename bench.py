@@ -384,7 +384,8 @@ def cpu_baseline(X, reduction, budget_s=20.0, threads=None):
         limiter, threads = nullcontext(), cores
     n_rows = X.shape[0]
     pr = orc.SomfParams(n_components=K_COMP, batch_size=BATCH, reduction=reduction, code_alpha=1.0, code_l1_ratio=1,
-                        comp_l1_ratio=0, learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0)
+                        comp_l1_ratio=0, learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0,
+                        n_threads=threads)          # (the reference's own thread pool over the samples of a minibatch, dict_fact.py:584-621)
     with limiter:
         st = orc.prepare(pr, n_samples=n_rows, X=X[:K_COMP])
         st.sweeps = []                                  # (one int32 per sample and minibatch: for the parity block)
@@ -397,11 +398,14 @@ def cpu_baseline(X, reduction, budget_s=20.0, threads=None):
         dt = time.perf_counter() - t0
     out = dict(value=done / dt, unit='samples/s', cores=threads, kind='port',
                sample='first %d rows of stream M1 (p=%d, k=%d, b=%d, reduction=%g), %.1f s; numpy/OpenBLAS with %d threads '
-                      '(of %d host cores) for the contractions, single-thread C for the CD solver and projections'
-                      % (done, P_FEAT, K_COMP, BATCH, reduction, dt, threads, cores))
+                      '(of %d host cores) for the contractions, the compiled CD solver on the reference\'s own thread pool over the '
+                      'samples of a minibatch (n_threads=%d, dict_fact.py:584-621; round 6 - it ran on one thread before), '
+                      'single-thread C for the projections'
+                      % (done, P_FEAT, K_COMP, BATCH, reduction, dt, threads, cores, threads))
     try:                                            # speed of this port relative to the real reference (build container)
         cal = json.load(open(os.path.join(ROOT, 'profiles', CALIBRATION_FILE)))
         out['calibration'] = cal.get('summary', cal)
+        out['calibration_note'] = 'measured in the build container with n_threads = 1 on both sides (round 2)'
     except (OSError, ValueError):
         out['calibration'] = None
     return out, st, done
@@ -433,7 +437,7 @@ def parity_block(X, done, st32, reduction, device):
     dt = time.perf_counter() - t0
     sw_gpu = hist()
     X64 = X[:done].astype(np.float64)
-    pr = orc.SomfParams(**kw)
+    pr = orc.SomfParams(n_threads=min(os.cpu_count() or 1, 32), **kw)
     try:
         from threadpoolctl import threadpool_limits
         limiter = threadpool_limits(limits=min(os.cpu_count() or 1, 32), user_api='blas')
@@ -490,6 +494,92 @@ def parity_block(X, done, st32, reduction, device):
                oracle_f32_sweep_flips=int((sw32 != sw64).sum()), samples=int(sw64.size),
                sweeps_agree=float(np.mean(sw_gpu[:, :BATCH] == sw64)), n_iter_equal=bool(est.n_iter_ == st64.n_iter),
                gpu_ms_per_step=dt / max(nb, 1) * 1e3)
+    return out
+
+
+def flip_rate_block(reduction, n_minibatches, device, threads=None, seed=4321, log=None):
+    """How often does a sample do another number of coordinate-descent sweeps than in the reference algorithm's f64 run - on the
+    GPU (f32) and in the reference algorithm's OWN f32 run?  (the parity gates allow for such flips -
+    a tolerance-stopped solver on a sample whose duality gap sits on the threshold - and this measures whether the GPU path
+    produces more of them than the CPU path does.)  Three free-running fits of the same fresh rows of stream M1 (a stream of its
+    own seed), same parameters and draws: the oracle in f64 (the yardstick), the oracle in f32, the GPU estimator in f32 (ONE
+    partial_fit call: the code path the bench times); every sample of every minibatch is compared by its sweep count
+    (modl_somf_sweeps_history on the GPU).  Counted twice: over the whole run, and up to each run's own first flip (behind a flip
+    a trajectory is 2e-5 away from the f64 one and flips more easily - in both runs alike).  `rel_fro_*_flip_free` = each f32
+    run against the f64 run after its last flip-free minibatch."""
+    import torch
+    from modl_amd import DictFact
+    from oracle import somf_oracle as orc
+    threads = threads or min(os.cpu_count() or 1, 32)
+    kw = dict(n_components=K_COMP, batch_size=BATCH, reduction=reduction, code_alpha=1.0, code_l1_ratio=1,
+              comp_l1_ratio=0, learning_rate=0.92, G_agg='masked', Dx_agg='masked', random_state=0)
+    n = n_minibatches * BATCH
+    stream = M1Stream(P_FEAT, seed, device, rank=0)
+    Xd = stream.rows(0, n)
+    est = DictFact(**kw)
+    est.prepare(n_samples=n, X=Xd[:K_COMP])
+    hist = est._backend.sweeps_history(n_minibatches)
+    est.partial_fit(Xd, np.arange(n))
+    sw_gpu = hist()[:, :BATCH]
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) /
+                             max(np.linalg.norm(np.asarray(b, np.float64)), 1e-300))
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads, user_api='blas')
+    except Exception:                               # pragma: no cover
+        from contextlib import nullcontext
+        limiter = nullcontext()
+    X0 = Xd[:K_COMP].cpu().numpy()
+    pr = orc.SomfParams(n_threads=threads, **kw)
+    t0 = time.perf_counter()
+    with limiter:
+        st64 = orc.prepare(pr, n_samples=n, X=X0.astype(np.float64))
+        st32 = orc.prepare(pr, n_samples=n, X=X0)
+        st64.sweeps, st32.sweeps = [], []
+        first = dict(gpu=None, o32=None)            # first minibatch with a flip, per run
+        free = dict(gpu=None, o32=None)             # the f64 state (D, C) after the last flip-free minibatch of each run, + that run's own
+        CH = 8192
+        for c0 in range(0, n, CH):
+            Xc = Xd[c0:c0 + CH].cpu().numpy()
+            Xc64 = Xc.astype(np.float64)
+            for r0 in range(0, Xc.shape[0], BATCH):
+                t = (c0 + r0) // BATCH
+                idx = np.arange(c0 + r0, c0 + r0 + BATCH)
+                prev64 = (st64.D.copy(), st64.C.copy()) if (first['gpu'] is None or first['o32'] is None) else None
+                prev32 = (st32.D.copy(), st32.C.copy()) if first['o32'] is None else None
+                orc.partial_fit(st64, pr, Xc64[r0:r0 + BATCH], idx)
+                orc.partial_fit(st32, pr, Xc[r0:r0 + BATCH], idx)
+                if first['gpu'] is None and (st64.sweeps[-1] != sw_gpu[t]).any():
+                    first['gpu'], free['gpu'] = t, prev64
+                if first['o32'] is None and (st32.sweeps[-1] != st64.sweeps[-1]).any():
+                    first['o32'], free['o32'] = t, (prev64, prev32)
+            if log:
+                log('flip_rate r=%g: %d / %d minibatches, %.0f s' % (reduction, min(n, c0 + CH) // BATCH, n_minibatches, time.perf_counter() - t0))
+    sw64, sw32 = np.stack(st64.sweeps), np.stack(st32.sweeps)
+    f_gpu, f_o32 = sw_gpu != sw64, sw32 != sw64
+    out = dict(reduction=reduction, samples=int(sw64.size), minibatches=n_minibatches,
+               gpu_f32_flips=int(f_gpu.sum()), oracle_f32_flips=int(f_o32.sum()),
+               gpu_f32_first_flip_minibatch=first['gpu'], oracle_f32_first_flip_minibatch=first['o32'],
+               gpu_f32_minibatches_with_a_flip=int(f_gpu.any(axis=1).sum()), oracle_f32_minibatches_with_a_flip=int(f_o32.any(axis=1).sum()),
+               sweeps_mean_f64=float(sw64.mean()), oracle_threads=threads, oracle_s=time.perf_counter() - t0,
+               protocol='free-running fits of the same fresh rows: oracle f64 (yardstick), oracle f32, GPU f32 (one partial_fit call); a flip = a '
+                        'sample whose sweep count differs from the f64 run\'s')
+    out['gpu_within_2x_oracle_plus_2'] = bool(out['gpu_f32_flips'] <= 2 * out['oracle_f32_flips'] + 2)
+    # each f32 run against the f64 run after its last flip-free minibatch (the whole run when it never flips)
+    if first['o32'] is None:
+        out['oracle_f32_rel_fro_flip_free'] = dict(minibatches=n_minibatches, D=rel(st32.D, st64.D), C=rel(st32.C, st64.C))
+    elif first['o32'] > 0:
+        (D64, C64), (D32, C32) = free['o32']
+        out['oracle_f32_rel_fro_flip_free'] = dict(minibatches=first['o32'], D=rel(D32, D64), C=rel(C32, C64))
+    if first['gpu'] is None:
+        out['gpu_f32_rel_fro_flip_free'] = dict(minibatches=n_minibatches, D=rel(est.components_, st64.D), C=rel(est.C_, st64.C))
+    elif first['gpu'] > 0:
+        e2 = DictFact(**kw)
+        e2.prepare(n_samples=n, X=Xd[:K_COMP])
+        e2.partial_fit(Xd[:first['gpu'] * BATCH], np.arange(first['gpu'] * BATCH))
+        out['gpu_f32_rel_fro_flip_free'] = dict(minibatches=first['gpu'], D=rel(e2.components_, free['gpu'][0]), C=rel(e2.C_, free['gpu'][1]))
+    out['rel_fro_end'] = dict(gpu_f32_D=rel(est.components_, st64.D), oracle_f32_D=rel(st32.D, st64.D),
+                              gpu_f32_C=rel(est.C_, st64.C), oracle_f32_C=rel(st32.C, st64.C))
     return out
 
 
@@ -614,6 +704,9 @@ def main():
     ap.add_argument('--torch-collective', action='store_true',
                     help='N > 1: dist.all_reduce of the head between two library calls per minibatch instead of the '
                          'library\'s own RCCL communicator')
+    ap.add_argument('--flip-minibatches', default='800,200', metavar='N10,N1',
+                    help='minibatches of the sweep-flip census at reduction 10 and 1 (parity.flip_rate; one GPU, with the CPU baseline; '
+                         '0,0: off).  Default: 204 800 and 51 200 samples; tests/test_gpu_step.py::test_sweep_flip_rate runs 800,800')
     ap.add_argument('--share-gpu', action='store_true', help='testing only: every rank uses cuda:0 (needs --backend gloo)')
     ap.add_argument('--debug-set', action='append', default=[], metavar='WHAT=VALUE',
                     help='diagnostics: modl_debug_set(WHAT, VALUE) before anything runs (A/B runs of scripts/; see include/modl_hip.h)')
@@ -726,6 +819,9 @@ def main():
             Xh = M1Stream(P_FEAT, 1234, device, rank=0).rows(0, n_cpu).cpu().numpy()
             out['cpu_baseline'], st_ref, done = cpu_baseline(Xh, args.reduction)
             out['parity'] = parity_block(Xh, done, st_ref, args.reduction, device)
+            if m1:
+                nf = [int(v) for v in args.flip_minibatches.split(',')]
+                out['parity']['flip_rate'] = [flip_rate_block(r, nmb, device) for r, nmb in zip((10.0, 1.0), nf) if nmb > 0]
             for rec in steady:
                 # the parity block of the other steady-state leg as well (r = 1: one extra call of 16 minibatches and
                 # two oracle runs on the same rows, outside every timed region)

@@ -333,7 +333,7 @@ __device__ __forceinline__ void persist_recover(const BcdPersistArgs &p, char *s
 #pragma unroll
             for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
             const float dold = dr[oj];
-            const float bv = p.BsP[dfrag(f, jj, kp)];
+            const float bv = p.BsP[f * kp + jj];                         // (bcd_setup_kernel: plain rows, sweep order)
             const float un = fz ? dold : (float)(((double)bv - acc) / (double)d);
             if (lane == 0) u[f] = un;
             old2 += (double)dold * (double)dold;

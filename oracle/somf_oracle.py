@@ -288,6 +288,7 @@ class SomfParams:
     batch_size: int = 10
     rand_size: bool = True
     replacement: bool = True
+    n_threads: int = 1              # dict_fact.py:150: the code solve of a minibatch split over a thread pool (:584-621)
 
 
 @dataclass
@@ -391,6 +392,16 @@ def sub_indices(indices, batch):
     return indices[batch]
 
 
+_POOLS = {}
+
+
+def _pool(n):
+    from concurrent.futures import ThreadPoolExecutor
+    if n not in _POOLS:
+        _POOLS[n] = ThreadPoolExecutor(n)                     # dict_fact.py:44-45
+    return _POOLS[n]
+
+
 def compute_code(st: SomfState, pr: SomfParams, X, idx, w_sample, subset):
     """dict_fact.py:577-648"""
     r = pr.reduction
@@ -421,7 +432,23 @@ def compute_code(st: SomfState, pr: SomfParams, X, idx, w_sample, subset):
     sweeps = np.zeros(len(idx), dtype=np.int32) if st.sweeps is not None else None
     args = (pr.code_l1_ratio, pr.code_alpha, pr.code_pos, pr.tol, pr.max_iter)
     Dx = np.ascontiguousarray(Dx)
-    if pr.G_agg == 'average':
+    nt = int(getattr(pr, 'n_threads', 1) or 1)
+    if nt > 1 and pr.code_l1_ratio != 0:
+        # dict_fact.py:584-586, 608-621: contiguous slices of the minibatch on a ThreadPoolExecutor (the compiled solver
+        # releases the GIL, as the reference's nogil Cython does); a sample's solve does not depend on the others, so the
+        # result is the serial run's bit for bit
+        size_job = -(-len(idx) // nt)
+        jobs = list(_gen_batches(len(idx), size_job))
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+
+        def job(batch):
+            sw = sweeps[batch] if sweeps is not None else None
+            if pr.G_agg == 'average':
+                enet_regression_multi_gram(G_avg[batch], Dx[batch], X[batch], st.code, idx[batch], *args, sweeps=sw)
+            else:
+                enet_regression_single_gram(G, Dx[batch], X[batch], st.code, idx[batch], *args, sweeps=sw)
+        list(_pool(nt).map(job, jobs))
+    elif pr.G_agg == 'average':
         enet_regression_multi_gram(G_avg, Dx, X, st.code, idx, *args, sweeps=sweeps)
     else:
         enet_regression_single_gram(G, Dx, X, st.code, idx, *args, sweeps=sweeps)

@@ -1245,6 +1245,36 @@ def test_objective_on_device_chunked(dtype, tol):
     assert f(ptr(dX), p + 3, n, p, ptr(dDt), k, ptr(dcode), ptr(ws), 64, ptr(out), stream_ptr(dev)) == -2      # MODL_ENOMEM
 
 
+@pytest.mark.parametrize('r', [10, 1])
+def test_sweep_flip_rate(r):
+    """the f32 parity gates allow for samples that do one coordinate-descent sweep more or less than in
+    the f64 run (a tolerance-stopped solver, a duality gap on the threshold).  That allowance rests on the premise that the GPU
+    path does not flip MORE OFTEN than the reference algorithm's own f32 arithmetic does - measured here instead of assumed:
+    204 800 fresh samples of stream M1 (800 minibatches at the metric's full shape) through the f64 oracle, the f32 oracle and the
+    GPU estimator (bench.py: flip_rate_block); every sample's sweep count compared with the f64 run's.
+    GPU flips <= 2 x the f32 oracle's + 2; before its first flip each f32 run is within the north star's 1e-5 of the f64 run."""
+    import importlib.util
+    import json
+    import os
+    import sys
+    from .conftest import ROOT
+    spec = importlib.util.spec_from_file_location('bench_for_flips', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import torch
+    nmb = int(os.environ.get('MODL_FLIP_MINIBATCHES', '800'))
+    out = bench.flip_rate_block(float(r), nmb, torch.device('cuda', 0))
+    sys.stderr.write('\nflip census r=%d: %s\n' % (r, json.dumps(out)))
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(ROOT, 'gpurun_out', 'flip_rate_r%d.json' % r), 'w') as fh:
+        json.dump(out, fh)
+    assert out['samples'] == nmb * 256
+    assert out['gpu_f32_flips'] <= 2 * out['oracle_f32_flips'] + 2, out
+    for who in ('gpu_f32_rel_fro_flip_free', 'oracle_f32_rel_fro_flip_free'):
+        if who in out:
+            assert out[who]['D'] <= 1e-5 and out[who]['C'] <= 1e-5, (who, out[who])
+
+
 _PERSIST_RECOVERY_SCRIPT = r"""
 import json, sys, warnings
 import numpy as np
