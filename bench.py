@@ -704,9 +704,10 @@ def main():
     ap.add_argument('--torch-collective', action='store_true',
                     help='N > 1: dist.all_reduce of the head between two library calls per minibatch instead of the '
                          'library\'s own RCCL communicator')
-    ap.add_argument('--flip-minibatches', default='800,200', metavar='N10,N1',
+    ap.add_argument('--flip-minibatches', default='200,50', metavar='N10,N1',
                     help='minibatches of the sweep-flip census at reduction 10 and 1 (parity.flip_rate; one GPU, with the CPU baseline; '
-                         '0,0: off).  Default: 204 800 and 51 200 samples; tests/test_gpu_step.py::test_sweep_flip_rate runs 800,800')
+                         '0,0: off).  Default: 51 200 and 12 800 samples, ~1.5 min of CPU oracle on the box; '
+                         'tests/test_gpu_step.py::test_sweep_flip_rate runs 400,200 and profiles/r06_flip_census.json 800,800')
     ap.add_argument('--share-gpu', action='store_true', help='testing only: every rank uses cuda:0 (needs --backend gloo)')
     ap.add_argument('--debug-set', action='append', default=[], metavar='WHAT=VALUE',
                     help='diagnostics: modl_debug_set(WHAT, VALUE) before anything runs (A/B runs of scripts/; see include/modl_hip.h)')

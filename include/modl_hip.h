@@ -82,6 +82,7 @@ const char *modl_error_string(int code);
 #define MODL_DEBUG_STAGE_AHEAD 8      /* 1 (default): inside modl_somf_partial_fit_chunk the next minibatch's parameters are copied to HBM by a workgroup of the dictionary update's last launch; 0: a staging launch at the head of every step */
 #define MODL_DEBUG_BCD_PERSIST 9      /* 1 (default): the f32 blocked dictionary update runs as ONE persistent launch (a resolver workgroup + one workgroup per 32 / 64 sampled rows resident in LDS, look-ahead Gram matrices: csrc/bcd_persist.hip) whenever its workgroups fit the chip (hipOccupancyMaxActiveBlocksPerMultiprocessor for the kernel's own footprint); 0: one launch per block of 32 atoms.  Diagnostics library only (the product library treats them as 1): 3 = the resolver waits for a workgroup that never comes before the first block (the launch cannot run: the resolver completes the update alone, modl_somf_persist_recoveries counts it), 4 = the same from the second block on (the update is incomplete: MODL_ETIMEOUT) */
 #define MODL_DEBUG_STATS_RESIDENT 10  /* 1 (default): the f32 statistics product X^T code over at least 4096 features and at most 256 atoms runs on persistent workgroups that keep the code matrix in registers (csrc/gemm_resident.hpp, tiles of 16 features); 0: the 32 x 32 tiles or the k-wide tiles of rounds 2-4 */
+#define MODL_DEBUG_RECSYS_FUSED 11    /* 1 (default): a masked minibatch of RecsysDictFact with at most 64 atoms and 64 rows runs as ONE launch (csrc/recsys.hip: recsys_fused_kernel); 0: the separate launches of rounds 2-5 (codes, B_, C_, the blocked dictionary update) */
 int modl_debug_set(int what, int64_t value);
 /* 1 in libmodl_hip_diag.so (built with -DMODL_DIAG: the same sources plus the A/B-only kernel variants and the stamp
  * switches), 0 in the product library */
@@ -244,6 +245,25 @@ int modl_recsys_minibatch_f64(modl_recsys_plan *plan, const int32_t *h_indptr, c
                               const int64_t *h_rows, int64_t b, const int64_t *h_order, double alpha, double w,
                               double n_iter, double *d_Dt, double *d_Bt, double *d_C, double *d_code,
                               double *d_comp_norm, int64_t *d_feature_n_iter, void *stream);
+/* The per-minibatch host loop of RecsysDictFact.fit (recsys.py:135-139, 147-165) for a run of minibatches in ONE call:
+ * h_rows[n_rows_fit] = the (permuted) row ids of the run, cut into minibatches of batch_size (the last one ragged).  Per
+ * minibatch: n_iter += its rows, w = _batch_weight(n_iter, rows, learning_rate, 0) (:154), order = the legacy permutation(k)
+ * of `order_rng` (:196; load it with numpy's state, modl_rk_set_mt_state), then the minibatch as modl_recsys_minibatch_*.
+ * *n_iter is advanced; *n_done (optional) = minibatches enqueued - on an error the ones before the failing minibatch, with
+ * n_iter and the generator left behind the last enqueued one.  Asynchronous. */
+int modl_recsys_fit_batches_f32(modl_recsys_plan *plan, const int32_t *h_indptr, const int32_t *h_indices, const float *h_data,
+                                int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const float *d_data,
+                                const int64_t *h_rows, int64_t n_rows_fit, int64_t batch_size, modl_rk *order_rng, double alpha,
+                                double learning_rate, int64_t *n_iter, float *d_Dt, float *d_Bt, float *d_C, float *d_code,
+                                float *d_comp_norm, int64_t *d_feature_n_iter, void *stream, int64_t *n_done);
+int modl_recsys_fit_batches_f64(modl_recsys_plan *plan, const int32_t *h_indptr, const int32_t *h_indices, const double *h_data,
+                                int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const double *d_data,
+                                const int64_t *h_rows, int64_t n_rows_fit, int64_t batch_size, modl_rk *order_rng, double alpha,
+                                double learning_rate, int64_t *n_iter, double *d_Dt, double *d_Bt, double *d_C, double *d_code,
+                                double *d_comp_norm, int64_t *d_feature_n_iter, void *stream, int64_t *n_done);
+/* diagnostics: minibatches of this plan that ran as ONE launch (csrc/recsys.hip: recsys_fused_kernel: at most 64 atoms, 64 rows
+ * and 8192 ratings per minibatch) / as the separate launches */
+int modl_recsys_plan_counts(const modl_recsys_plan *plan, int64_t *fused, int64_t *split);
 /* C = beta C + alpha rows^T rows, rows[b][k]  (recsys.py:159-160: beta = 1 - w, alpha = w / b) */
 int modl_gram_axpby_f32(const float *d_rows, int64_t b, int k, float *d_C, float beta, float alpha, void *stream);
 int modl_gram_axpby_f64(const double *d_rows, int64_t b, int k, double *d_C, double beta, double alpha, void *stream);

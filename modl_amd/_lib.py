@@ -21,6 +21,7 @@ DEBUG_BCD_TINY = 7
 DEBUG_STAGE_AHEAD = 8
 DEBUG_BCD_PERSIST = 9
 DEBUG_STATS_RESIDENT = 10
+DEBUG_RECSYS_FUSED = 11
 AGG = {'masked': 0, 'full': 1, 'average': 2}
 OPT = {'variational': 0, 'sgd': 1}
 
@@ -135,6 +136,8 @@ def bind(lib):
         _sig('modl_recsys_update_B_' + _sfx, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _i64, _vp)
         _sig('modl_recsys_minibatch_' + _sfx, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _f64, _f64, _f64,
              _vp, _vp, _vp, _vp, _vp, _vp, _vp)
+        _sig('modl_recsys_fit_batches_' + _sfx, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _f64, _f64,
+             _P(_i64), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _P(_i64))
         _sig('modl_recsys_predict_' + _sfx, C.c_int, _vp, _vp, _vp, _vp, _i64, C.c_int, _vp, _vp)
         _sig('modl_gram_axpby_' + _sfx, C.c_int, _vp, _i64, C.c_int, _vp, _ct, _ct, _vp)
         _sig('modl_dict_update_' + _sfx, C.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, C.c_int, C.c_int, C.c_int, _f64,
@@ -148,6 +151,7 @@ def bind(lib):
     _sig('modl_dict_update_workspace', _sz, C.c_int, _i64, C.c_int)
     _sig('modl_recsys_plan_create', C.c_int, C.c_int, _i64, C.c_int, _i64, _i64, _P(_vp))
     _sig('modl_recsys_plan_destroy', None, _vp)
+    _sig('modl_recsys_plan_counts', C.c_int, _vp, _P(_i64), _P(_i64))
     _sig('modl_predict_csr', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp)
     _sig('modl_somf_plan_create', C.c_int, _P(SomfDesc), _P(_vp))
     _sig('modl_somf_plan_destroy', None, _vp)

@@ -1,6 +1,7 @@
 // In-LDS Cholesky factorisation and substitutions for small systems (k <= 128), shared by the ridge code solve
 // (chol.hip: ridge_small_kernel) and the masked minibatch of RecsysDictFact (recsys.hip: recsys_code_kernel).
-// The matrix W[k][ld] (ld odd: a column is conflict-free) lives in LDS; 256 threads = four wavefronts.
+// The matrix W[k][ld] (ld odd: a column is conflict-free) lives in LDS; four wavefronts work (a workgroup with more -
+// recsys.hip's fused minibatch kernel has eight - brings them along to the barriers, idle).
 #pragma once
 #include <type_traits>
 #include "common.hpp"
@@ -30,7 +31,9 @@ __device__ __forceinline__ void chol_block_lds(T *W, int k, int ld, T *dinv, T *
             for (int u = 0; u < 4; ++u) c[q][u] = (wid == 0) ? W[row[q] * ld + pr[u]] : (T)0;
         const int steps = j0 / 4;                                       // steps of four finished columns
         const bool shared = steps >= 4;                                 // (fewer: wavefront 0 takes them all)
-        const int s_lo = shared ? steps * wid / 4 : 0, s_hi = shared ? steps * (wid + 1) / 4 : (wid == 0 ? steps : 0);
+        const bool worker = wid < 4;
+        const int s_lo = (shared && worker) ? steps * wid / 4 : 0;
+        const int s_hi = !worker ? 0 : (shared ? steps * (wid + 1) / 4 : (wid == 0 ? steps : 0));
         for (int m = 4 * s_lo; m < 4 * s_hi; m += 4) {                  // every read of the four columns first
             T lj[4][4], w[RPL][4];
 #pragma unroll
@@ -47,7 +50,7 @@ __device__ __forceinline__ void chol_block_lds(T *W, int k, int ld, T *dinv, T *
 #pragma unroll
                     for (int u = 0; u < 4; ++u) c[q][u] = fma(-w[q][v], lj[v][u], c[q][u]);
         }
-        if (shared && wid > 0) {
+        if (shared && wid > 0 && worker) {
 #pragma unroll
             for (int q = 0; q < RPL; ++q)
 #pragma unroll

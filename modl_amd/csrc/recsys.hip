@@ -17,6 +17,8 @@
 #include "kernels.hpp"
 #include "chol_small.hpp"
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <vector>
 
@@ -182,6 +184,315 @@ __global__ __launch_bounds__(256) void recsys_predict_kernel(double *out, const 
     }
 }
 
+// ---- the masked minibatch as ONE launch (round 6) -------------------------------------------------------------------------
+// recsys.py:147-213 for a batch of at most 64 rows, at most 64 (f64: 56) atoms: codes, B_, C_ and the dictionary update in one kernel
+// (it was ten launches per minibatch of ten rows: a code launch that lasted as long as the batch's heaviest row, the B_ and C_
+// updates, then the blocked dictionary update as separate launches).
+//   * CHUNK workgroups: a row's ratings are cut into chunks of 128 (the work is balanced by ratings, not by rows); a chunk's
+//     Gram contribution D_S^T D_S and right-hand side are accumulated from the feature-major dictionary rows in 4 x 4 register
+//     tiles (the next 32 rows requested while the current 32 are contracted).  A row of several chunks meets in a scratch
+//     record per chunk: write-through stores, one ticket per workgroup, the LAST to arrive sums the records in chunk order
+//     (a fixed order: run-to-run identical) - then factors and solves the row's k x k system in LDS (chol_small.hpp) and
+//     writes code_[row].
+//   * the LAST row to finish (a second ticket) goes on alone, 512 threads: C_ = (1 - w) C_ + (w / b) code_[batch]^T code_[batch]
+//     (recsys.py:159-160), the per-item B_ update in batch order (:175, :182-185: a wavefront per touched item), and the
+//     dictionary update on the touched items (:187-213) with ONE ITEM PER THREAD: the item's k dictionary entries stay in
+//     registers in sweep order for the whole sweep; per atom the candidate is (B_j - sum_{i != j} C[i][j] D_i) / C[j][j]
+//     against the registers as they are (the reference's two rank-1 passes per atom over a k x u gradient, evaluated lazily),
+//     its norm and the atom's old norm are ONE workgroup-wide reduction (wave sums, eight partial sums through LDS, one
+//     barrier per atom), the clip to the atom's budget, next atom.  The atom loop is unrolled (the register of atom j is a
+//     compile-time index), KP = 32 or 64 (f64: 56) registers per item.
+// More than 512 touched items: the kernel stops after B_ and the host runs the blocked dictionary update's launches.
+constexpr int kRfMaxChunks = 64, kRfMaxBatch = 64, kRfMaxItems = 512, kRfChunk = 128;
+struct RecsysChunk { int32_t pos, beg, cnt, nch, ci, part0; };   // row of the batch, first CSR entry, entries, chunks of the row, index among them, first record
+template <typename T> struct RecsysFusedArgs {
+    const int32_t *indptr, *indices;
+    const T *data;
+    T *Dt, *Bt, *C, *code, *comp_norm;
+    int64_t *feature_n_iter;
+    const int32_t *order, *subset, *fptr, *esample;      // the staged minibatch (device copy of the pinned slot)
+    const T *eval;
+    T *part;                                             // [chunks][k * k + k] records of rows with several chunks
+    unsigned int *tickets;                               // [kRfMaxBatch + 1], zero between launches (the last workgroup clears them)
+    double alpha, w, w_n_iter;
+    int64_t p;
+    int k, b, u, n_solve, do_dict;
+    int64_t rows[kRfMaxBatch];
+    RecsysChunk ch[kRfMaxChunks];
+};
+
+template <typename T> __device__ __forceinline__ void rf_store(T *ptr, T v);
+template <> __device__ __forceinline__ void rf_store<float>(float *ptr, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned int *>(ptr), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <> __device__ __forceinline__ void rf_store<double>(double *ptr, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(ptr), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float rf_load(const float *ptr) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int *>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ double rf_load(const double *ptr) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(ptr), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// the widest variant: an item's atoms in registers for the whole sweep, 512 threads = two waves per SIMD = 256 registers per
+// thread: 64 floats, or 56 doubles (64 doubles spill; a masked minibatch with more atoms takes the separate launches)
+template <typename T> struct kRfWide { static constexpr int value = sizeof(T) == 4 ? 64 : 56; };
+
+template <int J, int N, typename F> __device__ __forceinline__ void rf_static_for(F &&f) {
+    if constexpr (J < N) {
+        f(std::integral_constant<int, J>{});
+        rf_static_for<J + 1, N>(f);
+    }
+}
+
+template <typename T>
+size_t recsys_fused_lds(int k, int b, int KP) {
+    const size_t KS = (size_t)((k + 3) & ~3), ld = (size_t)(k | 1);
+    const size_t chunk = sizeof(T) * ((size_t)k * ld + 4 + 2 * KS + 768 + 2 * 32 * KS + kRfChunk) + sizeof(int) * (kRfChunk + 8);
+    const size_t fin = sizeof(T) * ((size_t)k * KP + (size_t)b * k + 3 * (size_t)KP) + sizeof(double) * (2 * 8 * 2 + 8 * (size_t)KP) +
+                       sizeof(int) * ((size_t)KP + 8);
+    return (chunk > fin ? chunk : fin) + 64;
+}
+
+template <typename T, int KP>
+__global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int k = a.k;
+    if (a.n_solve > 0) {
+        // ---------------------------------------------------------------- a chunk of a row
+        const int ld = k | 1, KS = (k + 3) & ~3;
+        T *G = reinterpret_cast<T *>(smem_raw);                 // [k][ld]
+        T *rhs = G + (((size_t)k * ld + 3) & ~(size_t)3);       // [KS] (16-byte aligned, like everything behind it)
+        T *dinv = rhs + KS;                                     // [KS]
+        T *cpart = dinv + KS;                                   // [3][4][64]
+        T *rowsb = cpart + 768;                                 // [2][32][KS]
+        T *xv = rowsb + 2 * 32 * KS;                            // [kRfChunk]
+        int *ids = reinterpret_cast<int *>(xv + kRfChunk);      // [kRfChunk]
+        int *flag = ids + kRfChunk;
+        const RecsysChunk c = a.ch[blockIdx.x];
+        const int64_t r = a.rows[c.pos];
+        if (tid < kRfChunk) {
+            const int e = c.beg + (tid < c.cnt ? tid : c.cnt - 1);
+            ids[tid] = a.indices[e];
+            xv[tid] = a.data[e];
+        }
+        __syncthreads();
+        const int TB = KS >> 2;
+        const bool gth = tid < TB * TB;
+        const int ti = gth ? tid / TB : 0, tj = gth ? tid % TB : 0;
+        const int ra = tid - 256;                               // the right-hand side's threads: 256 .. 256 + k - 1
+        T acc[4][4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) acc[x][y] = 0;
+        T racc = 0;
+        const int nsub = (c.cnt + 31) >> 5;
+        const int tot = 32 * KS;
+        T pre[8];
+        auto request = [&](int sb) {                            // 32 dictionary rows -> registers (waves 0-3), clamped addresses
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = tid + 256 * q;
+                const int j = (e < tot) ? e / KS : 0, cc = (e < tot) ? e % KS : 0;
+                const int jj = sb * 32 + j;
+                const bool ok = e < tot && jj < c.cnt && cc < k;
+                pre[q] = a.Dt[(int64_t)ids[ok ? jj : 0] * k + (ok ? cc : 0)];
+            }
+        };
+        auto deposit = [&](int sb, T *buf) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = tid + 256 * q;
+                if (e < tot) {
+                    const int j = e / KS, cc = e % KS;
+                    buf[e] = (sb * 32 + j < c.cnt && cc < k) ? pre[q] : (T)0;
+                }
+            }
+        };
+        if (tid < 256) request(0);
+        for (int sb = 0; sb < nsub; ++sb) {
+            T *buf = rowsb + (size_t)(sb & 1) * tot;
+            if (tid < 256) deposit(sb, buf);
+            __syncthreads();
+            if (tid < 256 && sb + 1 < nsub) request(sb + 1);
+            const int ncs = (c.cnt - 32 * sb < 32) ? c.cnt - 32 * sb : 32;
+            if (gth) {
+                for (int j = 0; j < ncs; ++j) {
+                    T av[4], bv[4];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) { av[x] = buf[j * KS + 4 * ti + x]; bv[x] = buf[j * KS + 4 * tj + x]; }
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) acc[x][y] = fma(av[x], bv[y], acc[x][y]);
+                }
+            } else if (ra >= 0 && ra < k) {
+                for (int j = 0; j < ncs; ++j) racc = fma(buf[j * KS + ra], xv[32 * sb + j], racc);
+            }
+        }
+        const int rec = k * k + k;
+        if (c.nch > 1) {                                        // several chunks: meet in the records, the last to arrive goes on
+            T *pp = a.part + (size_t)(c.part0 + c.ci) * rec;
+            if (gth) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y)
+                        if (4 * ti + x < k && 4 * tj + y < k) rf_store(pp + (4 * ti + x) * k + 4 * tj + y, acc[x][y]);
+            } else if (ra >= 0 && ra < k) rf_store(pp + k * k + ra, racc);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) flag[0] = (int)__hip_atomic_fetch_add(a.tickets + c.pos, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (flag[0] != c.nch - 1) return;
+            for (int e = tid; e < rec; e += 512) {
+                T t = 0;
+                for (int z = 0; z < c.nch; ++z) t += rf_load(a.part + (size_t)(c.part0 + z) * rec + e);
+                if (e < k * k) G[(e / k) * ld + e % k] = t;
+                else rhs[e - k * k] = t;
+            }
+        } else {
+            if (gth) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y)
+                        if (4 * ti + x < k && 4 * tj + y < k) G[(4 * ti + x) * ld + 4 * tj + y] = acc[x][y];
+            } else if (ra >= 0 && ra < k) rhs[ra] = racc;
+        }
+        __syncthreads();
+        {
+            const int nnz = a.indptr[r + 1] - a.indptr[r];
+            const T ridge = (T)(a.alpha * (double)nnz / (double)a.p);   // alpha / reduction, reduction = p / |S_i| (recsys.py:175,179)
+            if (tid < k) G[tid * ld + tid] += ridge;
+        }
+        __syncthreads();
+        chol_block_lds<T, 1>(G, k, ld, dinv, cpart);
+        if (wid == 0) {
+            T y[1][1];
+            y[0][0] = (lane < k) ? rhs[lane] : (T)0;
+            chol_solve_wave_lds<T, 1, 1>(G, dinv, k, ld, y);
+            if (lane < k) rf_store(a.code + r * k + lane, y[0][0]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (tid == 0) flag[1] = (int)__hip_atomic_fetch_add(a.tickets + kRfMaxBatch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (flag[1] != a.n_solve - 1) return;
+        __syncthreads();
+    }
+    // -------------------------------------------------------------------- the last workgroup: C_, B_, the dictionary
+    const int b = a.b, u = a.u;
+    T *Csw = reinterpret_cast<T *>(smem_raw);                   // [k][KP] C in sweep coordinates, zero diagonal, zero padding
+    T *codeb = Csw + (size_t)k * KP;                            // [b][k]
+    T *cdg = codeb + (size_t)b * k;                             // [KP] diagonal of C, sweep order
+    T *cn = cdg + KP;                                           // [KP] norm budgets, sweep order
+    T *bud = cn + KP;                                           // [KP] budget each atom was clipped to
+    double *red = reinterpret_cast<double *>(bud + KP);         // [2][8][2]
+    double *red2 = red + 32;                                    // [8][KP]
+    int *ord = reinterpret_cast<int *>(red2 + 8 * KP);          // [KP]
+    for (int e = tid; e < b * k; e += 512) codeb[e] = rf_load(a.code + a.rows[e / k] * k + e % k);
+    if (tid < KP) ord[tid] = (tid < k) ? a.order[tid] : 0;
+    __syncthreads();
+    for (int e = tid; e < k * KP; e += 512) {                   // C_ (recsys.py:159-160), kept in sweep coordinates
+        const int jj = e / KP, ii = e % KP;
+        T v = 0;
+        if (ii < k) {
+            const int oj = ord[jj], oi = ord[ii];
+            T dot = 0;
+            for (int rr = 0; rr < b; ++rr) dot = fma(codeb[rr * k + oj], codeb[rr * k + oi], dot);
+            T *cp = a.C + (int64_t)oj * k + oi;
+            v = (T)((1.0 - a.w) * (double)(*cp)) + (T)(a.w / (double)b) * dot;
+            *cp = v;
+            if (ii == jj) { cdg[jj] = v; v = 0; }
+        }
+        Csw[e] = v;
+    }
+    if (tid < KP) cn[tid] = (tid < k) ? a.comp_norm[ord[tid]] : (T)0;
+    for (int fi = wid; fi < u; fi += 8) {                       // B_: a wavefront per touched item, its entries in batch order
+        const int32_t f = a.subset[fi];
+        int64_t n = a.feature_n_iter[f];
+        T *brow = a.Bt + (int64_t)f * k;
+        const int e0 = a.fptr[fi], e1 = a.fptr[fi + 1];
+        T bv = (lane < k) ? brow[lane] : (T)0;
+        for (int e = e0; e < e1; ++e) {
+            n += 1;                                             // recsys.py:175
+            double wB = a.w_n_iter / (double)n;                 // :182-183
+            wB = wB < 1.0 ? wB : 1.0;
+            const double xw = (double)a.eval[e] * wB;
+            const int cpos = a.esample[e];
+            const T cv = (lane < k) ? codeb[cpos * k + lane] : (T)0;
+            bv = (T)((double)bv * (1.0 - wB));
+            bv = (T)((double)bv + (double)cv * xw);
+        }
+        if (lane < k) brow[lane] = bv;
+        if (lane == 0) a.feature_n_iter[f] = n;
+    }
+    __syncthreads();
+    if (a.do_dict) {
+        const bool live = tid < u;
+        const int64_t fo = (int64_t)a.subset[live ? tid : 0] * k;
+        T Dr[KP];
+#pragma unroll
+        for (int ii = 0; ii < KP; ++ii) Dr[ii] = a.Dt[fo + ord[ii]];
+#pragma unroll
+        for (int ii = 0; ii < KP; ++ii) Dr[ii] = (live && ii < k) ? Dr[ii] : (T)0;
+        T bn = a.Bt[fo + ord[0]];
+        // (the atom's register is a compile-time index: the loop over the atoms is unrolled by recursion - as a `#pragma unroll`
+        //  loop of 64 x 64 the compiler kept it rolled and put the registers in scratch)
+        rf_static_for<0, KP>([&](auto J) {
+            constexpr int jj = decltype(J)::value;
+            if (jj < k) {
+                const T bv = bn;
+                bn = a.Bt[fo + ord[(jj + 1 < k) ? jj + 1 : jj]];
+                T dot = 0;
+#pragma unroll
+                for (int ii = 0; ii < KP; ++ii)
+                    if (ii != jj) dot = fma(Csw[jj * KP + ii], Dr[ii], dot);
+                const T cd = cdg[jj];
+                const T dold = Dr[jj];
+                T un = (cd > (T)1e-20) ? (bv - dot) / cd : dold;       // recsys.py:201-203
+                un = live ? un : (T)0;
+                const double o2 = wave_sum((double)dold * (double)dold), n2 = wave_sum((double)un * (double)un);
+                double *rd = red + (jj & 1) * 16;
+                if (lane == 0) { rd[2 * wid] = o2; rd[2 * wid + 1] = n2; }
+                __syncthreads();
+                double so = 0, sn = 0;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) { so += rd[2 * x]; sn += rd[2 * x + 1]; }
+                const T budget = cn[jj] + (T)so;                         // :197-198 comp_norm_ += subset_norm
+                const T norm = (T)sqrt(sn), lim = sqrt(budget);          // :205-206
+                if (norm > lim) un = un / (norm / lim);                  // :207-208
+                Dr[jj] = un;
+                if (tid == 0) bud[jj] = budget;
+            }
+        });
+        // the projected atoms' norms leave the budgets (:211-212), the rows go back
+#pragma unroll
+        for (int ii = 0; ii < KP; ++ii) {
+            const double s2 = wave_sum((double)Dr[ii] * (double)Dr[ii]);
+            if (lane == 0) red2[wid * KP + ii] = s2;
+        }
+        if (live)
+#pragma unroll
+            for (int ii = 0; ii < KP; ++ii)
+                if (ii < k) a.Dt[fo + ord[ii]] = Dr[ii];
+        __syncthreads();
+        if (tid < k) {
+            double s2 = 0;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) s2 += red2[x * KP + tid];
+            a.comp_norm[ord[tid]] = bud[tid] - (T)s2;
+        }
+    }
+    if (tid <= kRfMaxBatch) a.tickets[tid] = 0;                 // for the next launch
+}
+
 template <typename T>
 int recsys_codes(const T *Dt, int64_t p, int k, const int32_t *indptr, const int32_t *indices, const T *data,
                  const int64_t *row_ids, const int64_t *code_rows, int64_t b, double alpha, T *code, hipStream_t st) {
@@ -225,6 +536,7 @@ template <typename T> struct EpiAxpbyC {
 // and the atom order into a pinned slot, moved to HBM by a kernel reading the device-mapped slot (no copy-engine hop
 // between kernels), then the four launches of the step.  Nothing is synchronised: a ring of slots + events.
 constexpr int kRecsysSlots = 8;
+std::atomic<int> g_recsys_fused{1};        // modl_debug_set(MODL_DEBUG_RECSYS_FUSED, ...): 0 = the separate launches of rounds 2-5
 
 }  // namespace modl
 
@@ -233,14 +545,19 @@ struct modl_recsys_plan {
     int64_t p = 0, max_entries = 0, max_batch = 0;
     char *h[modl::kRecsysSlots] = {nullptr};
     char *hdev[modl::kRecsysSlots] = {nullptr};
-    hipEvent_t ev[modl::kRecsysSlots] = {nullptr};
-    bool used[modl::kRecsysSlots] = {false};
     int slot = 0;
     char *dstage = nullptr;
     size_t stage_bytes = 0;
     char *ws = nullptr;
     size_t ws_bytes = 0;
     std::vector<int32_t> cnt, touched;
+    // the fused minibatch kernel (k <= 64, batches of at most 64 rows): chunk records, tickets; the slots are protected by an
+    // acknowledgement word the staging kernel writes into the slot itself (its use count; no stream event)
+    char *part = nullptr;
+    unsigned int *tickets = nullptr;
+    unsigned long long uses[modl::kRecsysSlots] = {0};
+    size_t ack_off = 0;
+    long fused_calls = 0, split_calls = 0;     // minibatches through the one-launch path / through the separate launches
 };
 
 namespace modl {
@@ -259,8 +576,21 @@ static RecsysLayout recsys_layout(size_t tsz, int64_t b, int k, int64_t u, int64
     return L;
 }
 
-__global__ __launch_bounds__(256) void recsys_stage_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+// ONE workgroup: the used part of the pinned slot -> HBM (eight 16-byte loads per thread in flight), then the slot's use count
+// into its acknowledgement word (host memory): the host checks that word before it refills the slot - no stream event (a
+// hipEventRecord between two kernels is a ~5 us bubble on this part)
+__global__ __launch_bounds__(256) void recsys_stage_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16,
+                                                           unsigned long long *ack, unsigned long long use) {
+    for (size_t i0 = threadIdx.x; i0 < n16; i0 += 8 * 256) {
+        uint4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = src[(i0 + 256 * q < n16) ? i0 + 256 * q : n16 - 1];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (i0 + 256 * q < n16) dst[i0 + 256 * q] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(ack, use, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <typename T>
@@ -300,8 +630,17 @@ int recsys_minibatch(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_
     }
     const int slot = pl->slot;
     pl->slot = (slot + 1) % kRecsysSlots;
-    if (pl->used[slot]) MODL_HIP(hipEventSynchronize(pl->ev[slot]));
     char *h = pl->h[slot];
+    if (pl->uses[slot]) {                                    // the staging kernel of the slot's last use has read it?
+        // (the host is eight minibatches ahead: the device is the bottleneck then, and this wait is where the host idles)
+        volatile unsigned long long *ack = reinterpret_cast<volatile unsigned long long *>(h + pl->ack_off);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (long spins = 0; *ack < pl->uses[slot]; ++spins)
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
+                MODL_HIP(hipStreamSynchronize(st));           // (another stream than the slot's last use, or a stuck device: settle it)
+                break;
+            }
+    }
     std::memcpy(h + L.rows, h_rows, sizeof(int64_t) * (size_t)b);
     int32_t *ho = reinterpret_cast<int32_t *>(h + L.order);
     for (int i = 0; i < k; ++i) ho[i] = (int32_t)h_order[i];
@@ -323,14 +662,11 @@ int recsys_minibatch(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_
     for (int32_t t : touched) cnt[t] = 0;
     {
         const size_t n16 = L.total / 16;
-        unsigned grid = (unsigned)((n16 + 255) / 256);
-        if (grid > 64) grid = 64;
-        if (grid < 1) grid = 1;
-        hipLaunchKernelGGL(recsys_stage_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint4 *>(pl->hdev[slot]),
-                           reinterpret_cast<uint4 *>(pl->dstage), n16);
+        const unsigned long long use = ++pl->uses[slot];
+        hipLaunchKernelGGL(recsys_stage_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const uint4 *>(pl->hdev[slot]),
+                           reinterpret_cast<uint4 *>(pl->dstage), n16,
+                           reinterpret_cast<unsigned long long *>(pl->hdev[slot] + pl->ack_off), use);
         MODL_LAUNCH_CHECK();
-        MODL_HIP(hipEventRecord(pl->ev[slot], st));
-        pl->used[slot] = true;
     }
     const int64_t *d_rows = reinterpret_cast<const int64_t *>(pl->dstage + L.rows);
     const int32_t *d_order = reinterpret_cast<const int32_t *>(pl->dstage + L.order);
@@ -338,6 +674,58 @@ int recsys_minibatch(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_
     const int32_t *d_fptr = reinterpret_cast<const int32_t *>(pl->dstage + L.fptr);
     const int32_t *d_es = reinterpret_cast<const int32_t *>(pl->dstage + L.esample);
     const T *d_ev = reinterpret_cast<const T *>(pl->dstage + L.eval);
+    // ---- ONE launch for the minibatch (recsys_fused_kernel) when it applies: at most 64 atoms, 64 rows, 64 chunks of 128 ratings
+    if (k <= kRfWide<T>::value && b <= kRfMaxBatch && pl->part && g_recsys_fused.load(std::memory_order_relaxed)) {
+        RecsysFusedArgs<T> fa;
+        int nc = 0, n_solve = 0;
+        bool fits = true;
+        for (int64_t i = 0; i < b && fits; ++i) {
+            const int32_t beg = h_indptr[h_rows[i]], nnz = h_indptr[h_rows[i] + 1] - beg;
+            fa.rows[i] = h_rows[i];
+            if (nnz == 0) continue;
+            ++n_solve;
+            const int nch = (nnz + kRfChunk - 1) / kRfChunk;
+            if (nc + nch > kRfMaxChunks) { fits = false; break; }
+            for (int ci = 0; ci < nch; ++ci) {
+                RecsysChunk &c = fa.ch[nc + ci];
+                c.pos = (int32_t)i; c.beg = beg + ci * kRfChunk; c.cnt = std::min(kRfChunk, nnz - ci * kRfChunk);
+                c.nch = nch; c.ci = ci; c.part0 = nc;
+            }
+            nc += nch;
+        }
+        if (fits) {
+            fa.indptr = d_indptr; fa.indices = d_indices; fa.data = d_data;
+            fa.Dt = Dt; fa.Bt = Bt; fa.C = C; fa.code = code; fa.comp_norm = comp_norm; fa.feature_n_iter = feature_n_iter;
+            fa.order = d_order; fa.subset = d_subset; fa.fptr = d_fptr; fa.esample = d_es; fa.eval = d_ev;
+            fa.part = reinterpret_cast<T *>(pl->part); fa.tickets = pl->tickets;
+            fa.alpha = alpha; fa.w = w; fa.w_n_iter = w * n_iter; fa.p = pl->p;
+            fa.k = k; fa.b = (int)b; fa.u = (int)u; fa.n_solve = n_solve;
+            fa.do_dict = (u > 0 && u <= kRfMaxItems) ? 1 : 0;
+            constexpr int KPW = kRfWide<T>::value;             // registers per item of the wide variant: 64 (f32) / 56 (f64)
+            const int KP = k <= 32 ? 32 : KPW;
+            const size_t lds = recsys_fused_lds<T>(k, (int)b, KP);
+            const unsigned grid = (unsigned)(nc > 0 ? nc : 1);
+            if (KP == 32) {
+                MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&recsys_fused_kernel<T, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                hipLaunchKernelGGL((recsys_fused_kernel<T, 32>), dim3(grid), dim3(512), lds, st, fa);
+            } else {
+                MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&recsys_fused_kernel<T, KPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                hipLaunchKernelGGL((recsys_fused_kernel<T, KPW>), dim3(grid), dim3(512), lds, st, fa);
+            }
+            MODL_LAUNCH_CHECK();
+            ++pl->fused_calls;
+            if (u > 0 && !fa.do_dict) {                      // more touched items than one workgroup holds: the blocked update's launches
+                DictUpdateArgs<T> a;
+                a.Dt = Dt; a.Bt = Bt; a.C = C; a.comp_norm = comp_norm; a.subset = d_subset; a.order = d_order;
+                a.h_order = h_order; a.s = u; a.k = k; a.optimizer = 0; a.comp_pos = 0;
+                a.comp_l1_ratio = 0.0; a.w = w; a.step_size = 1.0; a.ws = pl->ws; a.ws_bytes = pl->ws_bytes;
+                int nl = 0;
+                MODL_TRY(dict_update<T>(st, a, &nl));
+            }
+            return MODL_OK;
+        }
+    }
+    ++pl->split_calls;
     // codes of the batch's rows (recsys.py:176-181), written to code_[rows]
     MODL_TRY(recsys_codes<T>(Dt, pl->p, k, d_indptr, d_indices, d_data, d_rows, nullptr, b, alpha, code, st));
     if (u > 0) {                                             // :175, :182-185
@@ -438,14 +826,20 @@ int modl_recsys_plan_create(int dtype, int64_t p, int k, int64_t max_batch, int6
     const size_t tsz = dtype == MODL_F32 ? 4 : 8;
     const int64_t u_max = max_entries < p ? max_entries : p;
     pl->stage_bytes = recsys_layout(tsz, max_batch, k, u_max, max_entries).total;
+    pl->ack_off = pl->stage_bytes;                           // the acknowledgement word sits behind the staged arrays
     pl->ws_bytes = dict_update_workspace(dtype, p, k);
     pl->cnt.assign((size_t)p, 0);
     hipError_t e = hipMalloc((void **)&pl->dstage, pl->stage_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&pl->ws, pl->ws_bytes > 0 ? pl->ws_bytes : 16);
+    if (e == hipSuccess && k <= 64) {
+        e = hipMalloc((void **)&pl->part, tsz * (size_t)kRfMaxChunks * ((size_t)k * k + k));
+        if (e == hipSuccess) e = hipMalloc((void **)&pl->tickets, sizeof(unsigned int) * (kRfMaxBatch + 1));
+        if (e == hipSuccess) e = hipMemset(pl->tickets, 0, sizeof(unsigned int) * (kRfMaxBatch + 1));
+    }
     for (int i = 0; i < kRecsysSlots && e == hipSuccess; ++i) {
-        e = hipHostMalloc((void **)&pl->h[i], pl->stage_bytes, hipHostMallocMapped);
+        e = hipHostMalloc((void **)&pl->h[i], pl->stage_bytes + 64, hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&pl->hdev[i], pl->h[i], 0);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev[i], hipEventDisableTiming);
+        if (e == hipSuccess) std::memset(pl->h[i] + pl->stage_bytes, 0, 64);
     }
     if (e != hipSuccess) {
         modl_recsys_plan_destroy(pl);
@@ -459,9 +853,10 @@ void modl_recsys_plan_destroy(modl_recsys_plan *pl) {
     if (!pl) return;
     (void)hipDeviceSynchronize();
     for (int i = 0; i < kRecsysSlots; ++i) {
-        if (pl->ev[i]) (void)hipEventDestroy(pl->ev[i]);
         if (pl->h[i]) (void)hipHostFree(pl->h[i]);
     }
+    if (pl->part) (void)hipFree(pl->part);
+    if (pl->tickets) (void)hipFree(pl->tickets);
     if (pl->dstage) (void)hipFree(pl->dstage);
     if (pl->ws) (void)hipFree(pl->ws);
     delete pl;
@@ -489,6 +884,58 @@ int modl_recsys_minibatch_f64(modl_recsys_plan *pl, const int32_t *h_indptr, con
     return recsys_minibatch<double>(pl, h_indptr, h_indices, h_data, n_rows, d_indptr, d_indices, d_data, h_rows, b, h_order,
                                     alpha, w, n_iter, d_Dt, d_Bt, d_C, d_code, d_comp_norm, d_feature_n_iter,
                                     (hipStream_t)stream);
+}
+
+/* The per-minibatch host loop of RecsysDictFact.fit (recsys.py:135-139 + :147-165) for a run of minibatches in ONE call:
+ * h_rows[n_rows_fit] = the (permuted) row ids of the run, cut into minibatches of batch_size (the last one ragged); per
+ * minibatch n_iter += its rows, w = _batch_weight(n_iter, rows, learning_rate, 0), order = legacy permutation(k) of order_rng
+ * (load it with numpy's state, modl_rk_set_mt_state), then modl_recsys_minibatch.  *n_done = minibatches enqueued (on an
+ * error: before the failing one; n_iter and the generator are left behind the last enqueued one). */
+#define ABI_RECSYS_FIT(SFX, T)                                                                                        \
+    int modl_recsys_fit_batches_##SFX(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_t *h_indices,          \
+                                      const T *h_data, int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, \
+                                      const T *d_data, const int64_t *h_rows, int64_t n_rows_fit, int64_t batch_size,   \
+                                      modl_rk *order_rng, double alpha, double learning_rate, int64_t *n_iter,          \
+                                      T *d_Dt, T *d_Bt, T *d_C, T *d_code, T *d_comp_norm, int64_t *d_feature_n_iter,   \
+                                      void *stream, int64_t *n_done) {                                                \
+        if (!pl || !h_indptr || !h_indices || !h_data || !d_indptr || !d_indices || !d_data || !h_rows || !d_Dt || !d_Bt ||  \
+            !d_C || !d_code || !d_comp_norm || !d_feature_n_iter || n_rows < 0 || !order_rng || !n_iter ||              \
+            batch_size <= 0 || n_rows_fit < 0 || pl->dtype != (sizeof(T) == 4 ? MODL_F32 : MODL_F64))                   \
+            return MODL_EINVAL;                                                                                       \
+        std::vector<int64_t> order((size_t)pl->k);                                                                    \
+        int64_t done = 0;                                                                                             \
+        if (n_done) *n_done = 0;                                                                                      \
+        for (int64_t r0 = 0; r0 < n_rows_fit; r0 += batch_size) {                                                      \
+            const int64_t bb = std::min<int64_t>(batch_size, n_rows_fit - r0);                                         \
+            uint32_t key[624];                                                                                        \
+            int32_t pos = 0;                                                                                          \
+            MODL_TRY(modl_rk_get_mt_state(order_rng, key, &pos));                                                      \
+            double w = 0;                                                                                             \
+            MODL_TRY(modl_batch_weight(*n_iter + bb, bb, learning_rate, 0.0, &w));                                     \
+            MODL_TRY(modl_rk_permutation(order_rng, pl->k, order.data()));                                             \
+            const int rc = recsys_minibatch<T>(pl, h_indptr, h_indices, h_data, n_rows, d_indptr, d_indices, d_data,    \
+                                               h_rows + r0, bb, order.data(), alpha, w, (double)(*n_iter + bb), d_Dt,   \
+                                               d_Bt, d_C, d_code, d_comp_norm, d_feature_n_iter, (hipStream_t)stream); \
+            if (rc != MODL_OK) {                                                                                      \
+                (void)modl_rk_set_mt_state(order_rng, key, pos);          /* (the failed minibatch drew nothing) */    \
+                return rc;                                                                                            \
+            }                                                                                                         \
+            *n_iter += bb;                                                                                            \
+            ++done;                                                                                                   \
+            if (n_done) *n_done = done;                                                                               \
+        }                                                                                                             \
+        return MODL_OK;                                                                                               \
+    }
+ABI_RECSYS_FIT(f32, float)
+ABI_RECSYS_FIT(f64, double)
+#undef ABI_RECSYS_FIT
+
+/* diagnostics: minibatches of this plan that ran as one launch / as separate launches */
+int modl_recsys_plan_counts(const modl_recsys_plan *pl, int64_t *fused, int64_t *split) {
+    if (!pl || !fused || !split) return MODL_EINVAL;
+    *fused = pl->fused_calls;
+    *split = pl->split_calls;
+    return MODL_OK;
 }
 
 }  // extern "C"

@@ -105,6 +105,45 @@ class _RecsysDevice:
                 float(n_iter), ptr(self.Dt), ptr(self.Bt), ptr(self.C), ptr(self.code), ptr(self.comp_norm),
                 ptr(self.feature_n_iter), stream_ptr(self.device)), 'modl_recsys_minibatch')
 
+    def fit_batches(self, rows, batch_size, alpha, learning_rate, n_iter, np_random_state):
+        """A run of minibatches in ONE call (modl_recsys_fit_batches_*: the host loop of recsys.py:135-139 behind the ABI).
+        `rows`: the permuted row ids of the run; the atom orders are drawn inside the library by a generator loaded with
+        numpy's legacy MT19937 state and handed back afterwards, so `np_random_state` continues as if it had drawn them
+        (recsys.py:196).  Returns the new n_iter_."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        if self.plan is None or batch_size > self.plan_batch:
+            self._make_plan(batch_size)
+        if getattr(self, '_order_rk', None) is None:
+            h = C.c_void_p()
+            check(lib.modl_rk_create(0, C.byref(h)), 'modl_rk_create')
+            self._order_rk = h
+        kind, key, pos, has_gauss, cached = np_random_state.get_state()
+        key = np.ascontiguousarray(key, dtype=np.uint32)
+        check(lib.modl_rk_set_mt_state(self._order_rk, key.ctypes.data_as(C.c_void_p), int(pos)), 'modl_rk_set_mt_state')
+        n = C.c_int64(int(n_iter))
+        done = C.c_int64(0)
+        f = getattr(lib, 'modl_recsys_fit_batches_' + sfx(self.dtype))
+        try:
+            rc = f(self.plan, self.h_indptr.ctypes.data_as(C.c_void_p), self.h_indices.ctypes.data_as(C.c_void_p),
+                   self.h_data.ctypes.data_as(C.c_void_p), self.n, ptr(self.indptr), ptr(self.indices), ptr(self.data),
+                   rows.ctypes.data_as(C.c_void_p), len(rows), int(batch_size), self._order_rk, float(alpha),
+                   float(learning_rate), C.byref(n), ptr(self.Dt), ptr(self.Bt), ptr(self.C), ptr(self.code),
+                   ptr(self.comp_norm), ptr(self.feature_n_iter), stream_ptr(self.device), C.byref(done))
+        finally:
+            out = np.empty(624, dtype=np.uint32)
+            p2 = C.c_int32()
+            check(lib.modl_rk_get_mt_state(self._order_rk, out.ctypes.data_as(C.c_void_p), C.byref(p2)))
+            np_random_state.set_state((kind, out, int(p2.value), has_gauss, cached))
+        check(rc, 'modl_recsys_fit_batches')
+        return int(n.value)
+
+    def launch_counts(self):
+        """(minibatches that ran as one launch, minibatches that ran as separate launches) of the current plan"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        if self.plan is not None:
+            check(lib.modl_recsys_plan_counts(self.plan, C.byref(a), C.byref(b)), 'modl_recsys_plan_counts')
+        return int(a.value), int(b.value)
+
     def _make_plan(self, batch_size):
         self._free_plan()
         # the largest number of ratings a batch of this size can hold: its batch_size longest rows
@@ -121,6 +160,9 @@ class _RecsysDevice:
         # (a forked child - e.g. multiprocessing's helpers - must never release the parent's device objects)
         if getattr(self, 'plan', None) and getattr(self, '_pid', os.getpid()) == os.getpid():
             lib.modl_recsys_plan_destroy(self.plan)
+            if getattr(self, '_order_rk', None):
+                lib.modl_rk_destroy(self._order_rk)
+                self._order_rk = None
         self.plan, self.plan_batch = None, 0
 
     def __del__(self):
@@ -213,8 +255,13 @@ class RecsysDictFact(BaseEstimator):
             self.verbose_iter_ = ((np.logspace(0, log_lim, self.verbose, base=10) - 1) * batch_size).tolist()
         for _ in range(self.n_epochs):
             permutation = self.random_state.permutation(n_samples)
-            for batch in gen_batches(n_samples, batch_size):
-                self._single_batch_fit(X, permutation[batch])
+            if self.verbose or self.callback is not None or not hasattr(self.random_state, 'get_state'):
+                for batch in gen_batches(n_samples, batch_size):
+                    self._single_batch_fit(X, permutation[batch])
+            else:
+                # nothing to report between minibatches: the epoch's host loop runs behind the ABI, one call
+                self.n_iter_ = dev.fit_batches(permutation, batch_size, self.alpha, self.learning_rate, self.n_iter_,
+                                               self.random_state)
         self._refit()
         return self
 

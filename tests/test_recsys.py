@@ -105,6 +105,77 @@ def test_ref_dict_completion_missing():                       # test_recsys.py:6
     assert rmse < base
 
 
+def _ragged_ratings(n, p, k, heavy, empty, seed, dtype):
+    """CSR ratings with a few HEAVY rows (several chunks of 128 ratings in the one-launch kernel), rows WITHOUT ratings
+    (recsys.py:170: they keep their code) and a low-rank signal"""
+    rs = np.random.RandomState(seed)
+    full = rs.randn(n, k).dot(rs.randn(k, p)) + 0.1 * rs.randn(n, p)
+    dens = np.full(n, 0.04)
+    dens[rs.choice(n, heavy, replace=False)] = 0.9
+    dens[rs.choice(n, empty, replace=False)] = 0.0
+    mask = rs.rand(n, p) < dens[:, None]
+    return sp.csr_matrix(np.where(mask, full, 0.0).astype(dtype))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,k,p,b', [(np.float64, 50, 700, 10), (np.float64, 20, 300, 7), (np.float32, 64, 500, 16),
+                                         (np.float32, 30, 1500, 64), (np.float64, 50, 2500, 10)])
+def test_gpu_recsys_one_launch_vs_separate_launches(dtype, k, p, b):
+    """Round 6: a masked minibatch with at most 64 (f64: 56) atoms and 64 rows runs as ONE launch (csrc/recsys.hip:
+    recsys_fused_kernel: rating chunks of 128 with a ticketed fixed-order sum per row, Cholesky codes, then the last workgroup
+    alone: C_, the per-item B_ update, the dictionary sweep with one item per thread).  Against the separate launches of rounds
+    2-5 (MODL_DEBUG_RECSYS_FUSED = 0; pinned to the reference golden above) on ratings with heavy rows (several chunks), rows
+    without ratings and - p = 2500 - minibatches that touch more than 512 items (the kernel then stops after B_ and the blocked
+    dictionary update's launches follow): f64 to 1e-9, f32 within the reference algorithm's own f32 noise; and against the oracle."""
+    from modl_amd.recsys import RecsysDictFact
+    from modl_amd._lib import lib, check, DEBUG_RECSYS_FUSED
+    from oracle import wrappers_oracle as wo
+    from .conftest import assert_within_f32_noise
+    X = _ragged_ratings(160, p, 6, heavy=5, empty=6, seed=p + k, dtype=dtype)
+    kw = dict(alpha=0.2, beta=0.0, batch_size=b, n_epochs=1, learning_rate=0.9, random_state=1)
+    out = {}
+    for fused in (1, 0):
+        check(lib.modl_debug_set(DEBUG_RECSYS_FUSED, fused))
+        try:
+            est = RecsysDictFact(n_components=k, **kw).fit(X)
+            out[fused] = dict(D=est.components_, code=est.code_, C=est.C_, B=est.B_, cn=est.comp_norm_, fn=est.feature_n_iter_)
+            counts = est._dev.launch_counts()
+        finally:
+            check(lib.modl_debug_set(DEBUG_RECSYS_FUSED, 1))
+        if fused:
+            assert counts[0] > 0, counts                              # (a minibatch of more than 64 chunks takes the separate launches)
+        else:
+            assert counts[0] == 0
+    assert np.array_equal(out[1]['fn'], out[0]['fn'])
+    fit64 = wo.recsys_fit(X.astype(np.float64), n_components=k, **kw)
+    if dtype == np.float64:
+        for key in ('D', 'code', 'C', 'B', 'cn'):
+            assert rel_fro(out[1][key], out[0][key]) < 1e-9, key
+        for key in ('D', 'code', 'C', 'B'):
+            assert rel_fro(out[1][key], fit64[key]) < 1e-8, key
+    else:
+        fit32 = wo.recsys_fit(X, n_components=k, **kw)
+        for key in ('D', 'code', 'C', 'B'):
+            assert_within_f32_noise(out[1][key], fit32[key], fit64[key], key)
+    assert np.all(np.isfinite(out[1]['D']))
+
+
+@pytest.mark.gpu
+def test_gpu_recsys_fit_batches_equals_python_loop():
+    """The epoch's host loop behind the ABI (modl_recsys_fit_batches_*: minibatch weights, numpy's legacy permutation(k) drawn by a
+    generator loaded with numpy's state) == the Python loop of _single_batch_fit (taken when a callback is set), bit for bit,
+    with both generators left in step."""
+    from modl_amd.recsys import RecsysDictFact
+    X = _ragged_ratings(123, 400, 5, heavy=3, empty=4, seed=9, dtype=np.float64)
+    kw = dict(n_components=12, alpha=0.3, batch_size=10, n_epochs=2, learning_rate=0.9, random_state=3)
+    a = RecsysDictFact(**kw).fit(X)
+    b = RecsysDictFact(callback=lambda est: None, **kw).fit(X)
+    for name in ('components_', 'code_', 'C_', 'B_', 'comp_norm_', 'feature_n_iter_'):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert a.n_iter_ == b.n_iter_ == 2 * 123
+    assert a.random_state.randint(1 << 30) == b.random_state.randint(1 << 30)
+
+
 def test_shuffle_split_partitions_the_entries():
     """modl/utils/recsys/cross_validation.py:8-42: a partition of the stored entries, reproducible for a seed"""
     import scipy.sparse as sp
