@@ -203,7 +203,10 @@ __global__ __launch_bounds__(256) void recsys_predict_kernel(double *out, const 
 //     barrier per atom), the clip to the atom's budget, next atom.  The atom loop is unrolled (the register of atom j is a
 //     compile-time index), KP = 32 or 64 (f64: 56) registers per item.
 // More than 512 touched items: the kernel stops after B_ and the host runs the blocked dictionary update's launches.
-constexpr int kRfMaxChunks = 64, kRfMaxBatch = 64, kRfMaxItems = 512, kRfChunk = 128;
+constexpr int kRfMaxChunks = 64, kRfMaxBatch = 64, kRfChunk = 128;
+constexpr int kRfMaxSweep = 4;                          // sweep workgroups of 512 items each
+constexpr int kRfMaxItems = 512 * kRfMaxSweep;
+constexpr long long kRfSentinel = 0x7ff8dead0000beefll; // a NaN no sum produces
 struct RecsysChunk { int32_t pos, beg, cnt, nch, ci, part0; };   // row of the batch, first CSR entry, entries, chunks of the row, index among them, first record
 template <typename T> struct RecsysFusedArgs {
     const int32_t *indptr, *indices;
@@ -214,9 +217,16 @@ template <typename T> struct RecsysFusedArgs {
     const T *eval;
     T *part;                                             // [chunks][k * k + k] records of rows with several chunks
     unsigned int *tickets;                               // [kRfMaxBatch + 1], zero between launches (the last workgroup clears them)
+    double *xch;                                         // [(2 KP + KP) x kRfMaxSweep] exchange slots of the sweep workgroups, sentinels between launches
     double alpha, w, w_n_iter;
     int64_t p;
-    int k, b, u, n_solve, do_dict;
+    int k, b, u, n_solve, do_dict, nsweep;
+    // the NEXT minibatch's pinned slot -> the other device staging buffer, by one more workgroup at the end of the grid (the
+    // run of minibatches of modl_recsys_fit_batches_*: no staging launch between two minibatches); stage_n16 == 0: none
+    const uint4 *stage_src;
+    uint4 *stage_dst;
+    size_t stage_n16;
+    unsigned long long *stage_ack, stage_use;
     int64_t rows[kRfMaxBatch];
     RecsysChunk ch[kRfMaxChunks];
 };
@@ -262,6 +272,20 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int k = a.k;
+    int me = 0;                                                 // which of the sweep workgroups this one becomes (0: the last to finish)
+    if (a.stage_n16 && blockIdx.x == gridDim.x - 1) {           // the rider: the next minibatch's staged arrays
+        for (size_t i0 = tid; i0 < a.stage_n16; i0 += 8 * 512) {
+            uint4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = a.stage_src[(i0 + 512 * q < a.stage_n16) ? i0 + 512 * q : a.stage_n16 - 1];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (i0 + 512 * q < a.stage_n16) a.stage_dst[i0 + 512 * q] = v[q];
+        }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.stage_ack, a.stage_use, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     if (a.n_solve > 0) {
         // ---------------------------------------------------------------- a chunk of a row
         const int ld = k | 1, KS = (k + 3) & ~3;
@@ -383,11 +407,22 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
         __syncthreads();
         if (tid == 0) flag[1] = (int)__hip_atomic_fetch_add(a.tickets + kRfMaxBatch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        if (flag[1] != a.n_solve - 1) return;
+        me = a.n_solve - 1 - flag[1];                           // 0: the last row to finish, 1 .. : the ones just before it
+        if (me >= a.nsweep) return;
+        if (me > 0) {
+            // a helper of the sweep: every code is ready when the last row has taken its ticket.  (It WILL: every workgroup of
+            // this launch that has not run yet needs one free compute unit, and the helpers hold at most three.)
+            if (tid == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(a.tickets + kRfMaxBatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.n_solve &&
+                       ++spins < (1u << 26))
+                    __builtin_amdgcn_s_sleep(8);
+            }
+        }
         __syncthreads();
     }
-    // -------------------------------------------------------------------- the last workgroup: C_, B_, the dictionary
-    const int b = a.b, u = a.u;
+    // ------------------------------------------- the last nsweep workgroups: C_, B_ and the dictionary on 512 items each
+    const int b = a.b, u = a.u, W = a.nsweep;
     T *Csw = reinterpret_cast<T *>(smem_raw);                   // [k][KP] C in sweep coordinates, zero diagonal, zero padding
     T *codeb = Csw + (size_t)k * KP;                            // [b][k]
     T *cdg = codeb + (size_t)b * k;                             // [KP] diagonal of C, sweep order
@@ -399,44 +434,64 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
     for (int e = tid; e < b * k; e += 512) codeb[e] = rf_load(a.code + a.rows[e / k] * k + e % k);
     if (tid < KP) ord[tid] = (tid < k) ? a.order[tid] : 0;
     __syncthreads();
-    for (int e = tid; e < k * KP; e += 512) {                   // C_ (recsys.py:159-160), kept in sweep coordinates
+    // C_ = (1 - w) C_ + (w / b) code_[batch]^T code_[batch] (recsys.py:159-160) - formed by every sweep workgroup for itself, in
+    // sweep coordinates, from the C_ in memory, which the first of them replaces only at the very end (below)
+    auto c_new = [&](int oj, int oi) {
+        T dot = 0;
+        for (int rr = 0; rr < b; ++rr) dot = fma(codeb[rr * k + oj], codeb[rr * k + oi], dot);
+        return (T)((1.0 - a.w) * (double)a.C[(int64_t)oj * k + oi]) + (T)(a.w / (double)b) * dot;
+    };
+    for (int e = tid; e < k * KP; e += 512) {
         const int jj = e / KP, ii = e % KP;
         T v = 0;
         if (ii < k) {
-            const int oj = ord[jj], oi = ord[ii];
-            T dot = 0;
-            for (int rr = 0; rr < b; ++rr) dot = fma(codeb[rr * k + oj], codeb[rr * k + oi], dot);
-            T *cp = a.C + (int64_t)oj * k + oi;
-            v = (T)((1.0 - a.w) * (double)(*cp)) + (T)(a.w / (double)b) * dot;
-            *cp = v;
+            v = c_new(ord[jj], ord[ii]);
             if (ii == jj) { cdg[jj] = v; v = 0; }
         }
         Csw[e] = v;
     }
     if (tid < KP) cn[tid] = (tid < k) ? a.comp_norm[ord[tid]] : (T)0;
-    for (int fi = wid; fi < u; fi += 8) {                       // B_: a wavefront per touched item, its entries in batch order
-        const int32_t f = a.subset[fi];
+    // B_: ONE ITEM PER THREAD (recsys.py:175, 182-185: the item's entries in batch order), the items of this workgroup's slice -
+    // or, without an in-kernel sweep, all of them in passes.  Every load a thread needs for its item is independent of the other
+    // threads': 512 items in flight per pass (a wavefront per item, as a launch of its own did it, is a chain of three
+    // dependent round trips per item - 94 items per wavefront took 100 us here).
+    const int it0 = a.do_dict ? 512 * me : 0, it1 = a.do_dict ? ((u < it0 + 512) ? u : it0 + 512) : u;
+    for (int base = it0; base < it1; base += 512) {
+        const int fi = base + tid;
+        const bool on = fi < it1;
+        const int32_t f = a.subset[on ? fi : it0];
+        const int e0 = a.fptr[on ? fi : it0], e1 = on ? a.fptr[fi + 1] : e0;
         int64_t n = a.feature_n_iter[f];
         T *brow = a.Bt + (int64_t)f * k;
-        const int e0 = a.fptr[fi], e1 = a.fptr[fi + 1];
-        T bv = (lane < k) ? brow[lane] : (T)0;
+        T bv[KP];
+#pragma unroll
+        for (int c = 0; c < KP; ++c) bv[c] = brow[c < k ? c : 0];
         for (int e = e0; e < e1; ++e) {
             n += 1;                                             // recsys.py:175
             double wB = a.w_n_iter / (double)n;                 // :182-183
             wB = wB < 1.0 ? wB : 1.0;
             const double xw = (double)a.eval[e] * wB;
-            const int cpos = a.esample[e];
-            const T cv = (lane < k) ? codeb[cpos * k + lane] : (T)0;
-            bv = (T)((double)bv * (1.0 - wB));
-            bv = (T)((double)bv + (double)cv * xw);
+            const T *cr = codeb + a.esample[e] * k;
+#pragma unroll
+            for (int c = 0; c < KP; ++c) {
+                if (c < k) {
+                    T t = (T)((double)bv[c] * (1.0 - wB));      // B_[:, subset] *= 1 - w_B
+                    bv[c] = (T)((double)t + (double)cr[c] * xw); // += outer(code, X_subset * w_B)
+                }
+            }
         }
-        if (lane < k) brow[lane] = bv;
-        if (lane == 0) a.feature_n_iter[f] = n;
+        if (on && e1 > e0) {
+#pragma unroll
+            for (int c = 0; c < KP; ++c)
+                if (c < k) brow[c] = bv[c];
+            a.feature_n_iter[f] = n;
+        }
     }
     __syncthreads();
     if (a.do_dict) {
-        const bool live = tid < u;
-        const int64_t fo = (int64_t)a.subset[live ? tid : 0] * k;
+        const int fi = 512 * me + tid;
+        const bool live = fi < u;
+        const int64_t fo = (int64_t)a.subset[live ? fi : 0] * k;
         T Dr[KP];
 #pragma unroll
         for (int ii = 0; ii < KP; ++ii) Dr[ii] = a.Dt[fo + ord[ii]];
@@ -448,7 +503,7 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
         rf_static_for<0, KP>([&](auto J) {
             constexpr int jj = decltype(J)::value;
             if (jj < k) {
-                const T bv = bn;
+                const T bvj = live ? bn : (T)0;
                 bn = a.Bt[fo + ord[(jj + 1 < k) ? jj + 1 : jj]];
                 T dot = 0;
 #pragma unroll
@@ -456,7 +511,7 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
                     if (ii != jj) dot = fma(Csw[jj * KP + ii], Dr[ii], dot);
                 const T cd = cdg[jj];
                 const T dold = Dr[jj];
-                T un = (cd > (T)1e-20) ? (bv - dot) / cd : dold;       // recsys.py:201-203
+                T un = (cd > (T)1e-20) ? (bvj - dot) / cd : dold;      // recsys.py:201-203
                 un = live ? un : (T)0;
                 const double o2 = wave_sum((double)dold * (double)dold), n2 = wave_sum((double)un * (double)un);
                 double *rd = red + (jj & 1) * 16;
@@ -465,6 +520,24 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
                 double so = 0, sn = 0;
 #pragma unroll
                 for (int x = 0; x < 8; ++x) { so += rd[2 * x]; sn += rd[2 * x + 1]; }
+                if (W > 1) {
+                    // the other sweep workgroups' sums of this atom: written through, read past the caches, the data is its own
+                    // flag (a NaN no sum can be: the first workgroup restores it at the end of the launch) - one memory round trip
+                    double *slot = a.xch + (size_t)jj * 2 * kRfMaxSweep;
+                    if (tid < 2) rf_store(slot + 2 * me + tid, tid == 0 ? so : sn);
+                    double got = 0.0;
+                    if (tid < 2 * W) {
+                        unsigned spins = 0;
+                        do got = rf_load(slot + tid);
+                        while (__double_as_longlong(got) == kRfSentinel && ++spins < (1u << 24));
+                    }
+                    // (red2 is free until the end of the sweep; it is rewritten behind the NEXT atom's barrier, which every
+                    //  thread reaches only after it has read these)
+                    if (tid < 2 * kRfMaxSweep) red2[tid] = (tid < 2 * W) ? got : 0.0;
+                    __syncthreads();
+                    so = (red2[0] + red2[2]) + (red2[4] + red2[6]);
+                    sn = (red2[1] + red2[3]) + (red2[5] + red2[7]);
+                }
                 const T budget = cn[jj] + (T)so;                         // :197-198 comp_norm_ += subset_norm
                 const T norm = (T)sqrt(sn), lim = sqrt(budget);          // :205-206
                 if (norm > lim) un = un / (norm / lim);                  // :207-208
@@ -483,13 +556,40 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
             for (int ii = 0; ii < KP; ++ii)
                 if (ii < k) a.Dt[fo + ord[ii]] = Dr[ii];
         __syncthreads();
-        if (tid < k) {
-            double s2 = 0;
+        double s2 = 0;
+        if (tid < KP) {
 #pragma unroll
             for (int x = 0; x < 8; ++x) s2 += red2[x * KP + tid];
-            a.comp_norm[ord[tid]] = bud[tid] - (T)s2;
+        }
+        if (W > 1) {
+            double *slot = a.xch + (size_t)KP * 2 * kRfMaxSweep;           // [kRfMaxSweep][KP] behind the atoms' slots
+            if (me > 0) {
+                if (tid < k) rf_store(slot + (size_t)me * KP + tid, s2);
+                return;                                                  // (a helper is done)
+            }
+            for (int h = 1; h < W; ++h) {
+                double got = 0.0;
+                if (tid < k) {
+                    unsigned spins = 0;
+                    do got = rf_load(slot + (size_t)h * KP + tid);
+                    while (__double_as_longlong(got) == kRfSentinel && ++spins < (1u << 24));
+                }
+                s2 += got;
+            }
+        }
+        if (tid < k) a.comp_norm[ord[tid]] = bud[tid] - (T)s2;
+        if (W > 1) {                                                     // the slots back to sentinels: every helper has left them
+            long long *xs = reinterpret_cast<long long *>(a.xch);
+            for (int e2 = tid; e2 < (KP * 2 + KP) * kRfMaxSweep; e2 += 512) xs[e2] = kRfSentinel;
         }
     }
+    // (only the first sweep workgroup is left) C_ in memory, natural order: the same expression, the same bits as Csw
+    __syncthreads();
+    for (int e = tid; e < k * k; e += 512) {
+        a.part[e] = c_new(e / k, e % k);                                 // (staged: every C_[oj][oi] is still read by other threads' c_new)
+    }
+    __syncthreads();
+    for (int e = tid; e < k * k; e += 512) a.C[e] = a.part[e];
     if (tid <= kRfMaxBatch) a.tickets[tid] = 0;                 // for the next launch
 }
 
@@ -546,7 +646,9 @@ struct modl_recsys_plan {
     char *h[modl::kRecsysSlots] = {nullptr};
     char *hdev[modl::kRecsysSlots] = {nullptr};
     int slot = 0;
-    char *dstage = nullptr;
+    char *dstage = nullptr;                    // two staging buffers (dstage2[cur]: the minibatch being launched)
+    char *dstage2[2] = {nullptr, nullptr};
+    int cur = 0;
     size_t stage_bytes = 0;
     char *ws = nullptr;
     size_t ws_bytes = 0;
@@ -555,6 +657,7 @@ struct modl_recsys_plan {
     // acknowledgement word the staging kernel writes into the slot itself (its use count; no stream event)
     char *part = nullptr;
     unsigned int *tickets = nullptr;
+    double *xch = nullptr;                     // exchange slots of the sweep workgroups (sentinels between launches)
     unsigned long long uses[modl::kRecsysSlots] = {0};
     size_t ack_off = 0;
     long fused_calls = 0, split_calls = 0;     // minibatches through the one-launch path / through the separate launches
@@ -593,11 +696,12 @@ __global__ __launch_bounds__(256) void recsys_stage_kernel(const uint4 *__restri
     if (threadIdx.x == 0) __hip_atomic_store(ack, use, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// What the host prepares for one minibatch: its pinned slot filled (row ids, atom order, the batch's ratings grouped by item).
+struct RecsysPrep { int slot = -1; int64_t b = 0, u = 0, m = 0; RecsysLayout L{}; unsigned long long use = 0; };
+
 template <typename T>
-int recsys_minibatch(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_t *h_indices, const T *h_data,
-                     int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const T *d_data,
-                     const int64_t *h_rows, int64_t b, const int64_t *h_order, double alpha, double w, double n_iter,
-                     T *Dt, T *Bt, T *C, T *code, T *comp_norm, int64_t *feature_n_iter, hipStream_t st) {
+int recsys_prepare(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_t *h_indices, const T *h_data, int64_t n_rows,
+                   const int64_t *h_rows, int64_t b, const int64_t *h_order, hipStream_t st, RecsysPrep &out) {
     const int k = pl->k;
     if (b <= 0 || b > pl->max_batch) return MODL_EINVAL;
     int64_t m = 0;
@@ -631,7 +735,7 @@ int recsys_minibatch(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_
     const int slot = pl->slot;
     pl->slot = (slot + 1) % kRecsysSlots;
     char *h = pl->h[slot];
-    if (pl->uses[slot]) {                                    // the staging kernel of the slot's last use has read it?
+    if (pl->uses[slot]) {                                    // the copy of the slot's last use has read it?
         // (the host is eight minibatches ahead: the device is the bottleneck then, and this wait is where the host idles)
         volatile unsigned long long *ack = reinterpret_cast<volatile unsigned long long *>(h + pl->ack_off);
         const auto t0 = std::chrono::steady_clock::now();
@@ -660,20 +764,35 @@ int recsys_minibatch(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_
             hev[at] = h_data[e];
         }
     for (int32_t t : touched) cnt[t] = 0;
-    {
-        const size_t n16 = L.total / 16;
-        const unsigned long long use = ++pl->uses[slot];
-        hipLaunchKernelGGL(recsys_stage_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const uint4 *>(pl->hdev[slot]),
-                           reinterpret_cast<uint4 *>(pl->dstage), n16,
-                           reinterpret_cast<unsigned long long *>(pl->hdev[slot] + pl->ack_off), use);
+    out.slot = slot; out.b = b; out.u = u; out.m = m; out.L = L; out.use = ++pl->uses[slot];
+    return MODL_OK;
+}
+
+// The launches of a prepared minibatch.  staged: its arrays are already in the current device staging buffer (the previous
+// minibatch's launch carried them); next: the minibatch after this one, prepared - its arrays ride on this one's launch
+// (*next_staged says whether they did).
+template <typename T>
+int recsys_launch(modl_recsys_plan *pl, const RecsysPrep &pr, bool staged, const RecsysPrep *next, bool *next_staged,
+                  const int32_t *h_indptr, const int32_t *d_indptr, const int32_t *d_indices, const T *d_data,
+                  const int64_t *h_rows, const int64_t *h_order, double alpha, double w, double n_iter,
+                  T *Dt, T *Bt, T *C, T *code, T *comp_norm, int64_t *feature_n_iter, hipStream_t st) {
+    const int k = pl->k;
+    const int64_t b = pr.b, u = pr.u;
+    const RecsysLayout &L = pr.L;
+    if (next_staged) *next_staged = false;
+    char *dst = pl->dstage2[pl->cur];
+    if (!staged) {
+        hipLaunchKernelGGL(recsys_stage_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const uint4 *>(pl->hdev[pr.slot]),
+                           reinterpret_cast<uint4 *>(dst), L.total / 16,
+                           reinterpret_cast<unsigned long long *>(pl->hdev[pr.slot] + pl->ack_off), pr.use);
         MODL_LAUNCH_CHECK();
     }
-    const int64_t *d_rows = reinterpret_cast<const int64_t *>(pl->dstage + L.rows);
-    const int32_t *d_order = reinterpret_cast<const int32_t *>(pl->dstage + L.order);
-    const int32_t *d_subset = reinterpret_cast<const int32_t *>(pl->dstage + L.subset);
-    const int32_t *d_fptr = reinterpret_cast<const int32_t *>(pl->dstage + L.fptr);
-    const int32_t *d_es = reinterpret_cast<const int32_t *>(pl->dstage + L.esample);
-    const T *d_ev = reinterpret_cast<const T *>(pl->dstage + L.eval);
+    const int64_t *d_rows = reinterpret_cast<const int64_t *>(dst + L.rows);
+    const int32_t *d_order = reinterpret_cast<const int32_t *>(dst + L.order);
+    const int32_t *d_subset = reinterpret_cast<const int32_t *>(dst + L.subset);
+    const int32_t *d_fptr = reinterpret_cast<const int32_t *>(dst + L.fptr);
+    const int32_t *d_es = reinterpret_cast<const int32_t *>(dst + L.esample);
+    const T *d_ev = reinterpret_cast<const T *>(dst + L.eval);
     // ---- ONE launch for the minibatch (recsys_fused_kernel) when it applies: at most 64 atoms, 64 rows, 64 chunks of 128 ratings
     if (k <= kRfWide<T>::value && b <= kRfMaxBatch && pl->part && g_recsys_fused.load(std::memory_order_relaxed)) {
         RecsysFusedArgs<T> fa;
@@ -700,11 +819,22 @@ int recsys_minibatch(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_
             fa.part = reinterpret_cast<T *>(pl->part); fa.tickets = pl->tickets;
             fa.alpha = alpha; fa.w = w; fa.w_n_iter = w * n_iter; fa.p = pl->p;
             fa.k = k; fa.b = (int)b; fa.u = (int)u; fa.n_solve = n_solve;
-            fa.do_dict = (u > 0 && u <= kRfMaxItems) ? 1 : 0;
+            fa.nsweep = (int)std::max<int64_t>(1, (u + 511) / 512);
+            fa.do_dict = (u > 0 && fa.nsweep <= kRfMaxSweep && fa.nsweep <= std::max(n_solve, 1)) ? 1 : 0;
+            if (!fa.do_dict) fa.nsweep = 1;
+            fa.xch = pl->xch;
+            fa.stage_src = nullptr; fa.stage_dst = nullptr; fa.stage_n16 = 0; fa.stage_ack = nullptr; fa.stage_use = 0;
+            if (next) {                                      // the next minibatch's arrays ride along, into the other buffer
+                fa.stage_src = reinterpret_cast<const uint4 *>(pl->hdev[next->slot]);
+                fa.stage_dst = reinterpret_cast<uint4 *>(pl->dstage2[pl->cur ^ 1]);
+                fa.stage_n16 = next->L.total / 16;
+                fa.stage_ack = reinterpret_cast<unsigned long long *>(pl->hdev[next->slot] + pl->ack_off);
+                fa.stage_use = next->use;
+            }
             constexpr int KPW = kRfWide<T>::value;             // registers per item of the wide variant: 64 (f32) / 56 (f64)
             const int KP = k <= 32 ? 32 : KPW;
             const size_t lds = recsys_fused_lds<T>(k, (int)b, KP);
-            const unsigned grid = (unsigned)(nc > 0 ? nc : 1);
+            const unsigned grid = (unsigned)(nc > 0 ? nc : 1) + (fa.stage_n16 ? 1u : 0u);
             if (KP == 32) {
                 MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&recsys_fused_kernel<T, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 hipLaunchKernelGGL((recsys_fused_kernel<T, 32>), dim3(grid), dim3(512), lds, st, fa);
@@ -714,6 +844,10 @@ int recsys_minibatch(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_
             }
             MODL_LAUNCH_CHECK();
             ++pl->fused_calls;
+            if (fa.stage_n16) {
+                pl->cur ^= 1;
+                if (next_staged) *next_staged = true;
+            }
             if (u > 0 && !fa.do_dict) {                      // more touched items than one workgroup holds: the blocked update's launches
                 DictUpdateArgs<T> a;
                 a.Dt = Dt; a.Bt = Bt; a.C = C; a.comp_norm = comp_norm; a.subset = d_subset; a.order = d_order;
@@ -747,6 +881,76 @@ int recsys_minibatch(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_
         a.comp_l1_ratio = 0.0; a.w = w; a.step_size = 1.0; a.ws = pl->ws; a.ws_bytes = pl->ws_bytes;
         int nl = 0;
         MODL_TRY(dict_update<T>(st, a, &nl));
+    }
+    return MODL_OK;
+}
+
+template <typename T>
+int recsys_minibatch(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_t *h_indices, const T *h_data,
+                     int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const T *d_data,
+                     const int64_t *h_rows, int64_t b, const int64_t *h_order, double alpha, double w, double n_iter,
+                     T *Dt, T *Bt, T *C, T *code, T *comp_norm, int64_t *feature_n_iter, hipStream_t st) {
+    RecsysPrep pr;
+    MODL_TRY(recsys_prepare<T>(pl, h_indptr, h_indices, h_data, n_rows, h_rows, b, h_order, st, pr));
+    return recsys_launch<T>(pl, pr, false, nullptr, nullptr, h_indptr, d_indptr, d_indices, d_data, h_rows, h_order, alpha, w, n_iter,
+                            Dt, Bt, C, code, comp_norm, feature_n_iter, st);
+}
+
+// A run of minibatches (modl_recsys_fit_batches_*): minibatch t + 1 is drawn and prepared BEFORE minibatch t is launched, and its
+// staged arrays ride on t's launch - one launch per minibatch.  Same draws in the same order as one minibatch at a time.
+template <typename T>
+int recsys_fit_batches(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_t *h_indices, const T *h_data, int64_t n_rows,
+                       const int32_t *d_indptr, const int32_t *d_indices, const T *d_data, const int64_t *h_rows,
+                       int64_t n_rows_fit, int64_t batch_size, modl_rk *order_rng, double alpha, double learning_rate,
+                       int64_t *n_iter, T *Dt, T *Bt, T *C, T *code, T *comp_norm, int64_t *feature_n_iter, hipStream_t st,
+                       int64_t *n_done) {
+    struct Drawn { RecsysPrep pr; std::vector<int64_t> order; double w = 0; int64_t bb = 0, r0 = 0, n_after = 0;
+                   uint32_t key[624]; int32_t pos = 0; int rc = MODL_OK; };
+    Drawn q[2];
+    q[0].order.resize((size_t)pl->k);
+    q[1].order.resize((size_t)pl->k);
+    int64_t n_virtual = *n_iter;                             // n_iter_ behind the last DRAWN minibatch
+    auto draw = [&](Drawn &d, int64_t r0) {                  // weights, order, the slot: everything but the launch
+        d.r0 = r0;
+        d.bb = std::min<int64_t>(batch_size, n_rows_fit - r0);
+        d.rc = modl_rk_get_mt_state(order_rng, d.key, &d.pos);
+        if (d.rc == MODL_OK) d.rc = modl_batch_weight(n_virtual + d.bb, d.bb, learning_rate, 0.0, &d.w);   // recsys.py:153-154
+        if (d.rc == MODL_OK) d.rc = modl_rk_permutation(order_rng, pl->k, d.order.data());                 // :196
+        if (d.rc == MODL_OK)
+            d.rc = recsys_prepare<T>(pl, h_indptr, h_indices, h_data, n_rows, h_rows + r0, d.bb, d.order.data(), st, d.pr);
+        if (d.rc != MODL_OK) (void)modl_rk_set_mt_state(order_rng, d.key, d.pos);     // (a minibatch that fails drew nothing)
+        else { n_virtual += d.bb; d.n_after = n_virtual; }
+    };
+    int64_t done = 0;
+    if (n_done) *n_done = 0;
+    if (n_rows_fit <= 0) return MODL_OK;
+    int cur = 0;
+    draw(q[0], 0);
+    if (q[0].rc != MODL_OK) return q[0].rc;
+    bool staged = false;
+    for (;;) {
+        Drawn &d = q[cur];
+        const int64_t r1 = d.r0 + d.bb;
+        Drawn *nx = nullptr;
+        if (r1 < n_rows_fit) {
+            nx = &q[cur ^ 1];
+            draw(*nx, r1);
+        }
+        bool next_staged = false;
+        const int rc = recsys_launch<T>(pl, d.pr, staged, (nx && nx->rc == MODL_OK) ? &nx->pr : nullptr, &next_staged, h_indptr,
+                                        d_indptr, d_indices, d_data, h_rows + d.r0, d.order.data(), alpha, d.w, (double)d.n_after,
+                                        Dt, Bt, C, code, comp_norm, feature_n_iter, st);
+        if (rc != MODL_OK) {                                 // leave the generator behind the last ENQUEUED minibatch
+            (void)modl_rk_set_mt_state(order_rng, d.key, d.pos);
+            return rc;
+        }
+        *n_iter = d.n_after;
+        ++done;
+        if (n_done) *n_done = done;
+        if (!nx) break;
+        if (nx->rc != MODL_OK) return nx->rc;                // (its draws are rewound already)
+        staged = next_staged;
+        cur ^= 1;
     }
     return MODL_OK;
 }
@@ -829,12 +1033,19 @@ int modl_recsys_plan_create(int dtype, int64_t p, int k, int64_t max_batch, int6
     pl->ack_off = pl->stage_bytes;                           // the acknowledgement word sits behind the staged arrays
     pl->ws_bytes = dict_update_workspace(dtype, p, k);
     pl->cnt.assign((size_t)p, 0);
-    hipError_t e = hipMalloc((void **)&pl->dstage, pl->stage_bytes);
+    hipError_t e = hipMalloc((void **)&pl->dstage, 2 * align_up(pl->stage_bytes, 256));
+    pl->dstage2[0] = pl->dstage;
+    pl->dstage2[1] = pl->dstage ? pl->dstage + align_up(pl->stage_bytes, 256) : nullptr;
     if (e == hipSuccess) e = hipMalloc((void **)&pl->ws, pl->ws_bytes > 0 ? pl->ws_bytes : 16);
     if (e == hipSuccess && k <= 64) {
         e = hipMalloc((void **)&pl->part, tsz * (size_t)kRfMaxChunks * ((size_t)k * k + k));
         if (e == hipSuccess) e = hipMalloc((void **)&pl->tickets, sizeof(unsigned int) * (kRfMaxBatch + 1));
         if (e == hipSuccess) e = hipMemset(pl->tickets, 0, sizeof(unsigned int) * (kRfMaxBatch + 1));
+        if (e == hipSuccess) e = hipMalloc((void **)&pl->xch, sizeof(double) * 3 * 64 * kRfMaxSweep);
+        if (e == hipSuccess) {
+            std::vector<long long> fill((size_t)3 * 64 * kRfMaxSweep, kRfSentinel);
+            e = hipMemcpy(pl->xch, fill.data(), sizeof(long long) * fill.size(), hipMemcpyHostToDevice);
+        }
     }
     for (int i = 0; i < kRecsysSlots && e == hipSuccess; ++i) {
         e = hipHostMalloc((void **)&pl->h[i], pl->stage_bytes + 64, hipHostMallocMapped);
@@ -857,6 +1068,7 @@ void modl_recsys_plan_destroy(modl_recsys_plan *pl) {
     }
     if (pl->part) (void)hipFree(pl->part);
     if (pl->tickets) (void)hipFree(pl->tickets);
+    if (pl->xch) (void)hipFree(pl->xch);
     if (pl->dstage) (void)hipFree(pl->dstage);
     if (pl->ws) (void)hipFree(pl->ws);
     delete pl;
@@ -902,29 +1114,9 @@ int modl_recsys_minibatch_f64(modl_recsys_plan *pl, const int32_t *h_indptr, con
             !d_C || !d_code || !d_comp_norm || !d_feature_n_iter || n_rows < 0 || !order_rng || !n_iter ||              \
             batch_size <= 0 || n_rows_fit < 0 || pl->dtype != (sizeof(T) == 4 ? MODL_F32 : MODL_F64))                   \
             return MODL_EINVAL;                                                                                       \
-        std::vector<int64_t> order((size_t)pl->k);                                                                    \
-        int64_t done = 0;                                                                                             \
-        if (n_done) *n_done = 0;                                                                                      \
-        for (int64_t r0 = 0; r0 < n_rows_fit; r0 += batch_size) {                                                      \
-            const int64_t bb = std::min<int64_t>(batch_size, n_rows_fit - r0);                                         \
-            uint32_t key[624];                                                                                        \
-            int32_t pos = 0;                                                                                          \
-            MODL_TRY(modl_rk_get_mt_state(order_rng, key, &pos));                                                      \
-            double w = 0;                                                                                             \
-            MODL_TRY(modl_batch_weight(*n_iter + bb, bb, learning_rate, 0.0, &w));                                     \
-            MODL_TRY(modl_rk_permutation(order_rng, pl->k, order.data()));                                             \
-            const int rc = recsys_minibatch<T>(pl, h_indptr, h_indices, h_data, n_rows, d_indptr, d_indices, d_data,    \
-                                               h_rows + r0, bb, order.data(), alpha, w, (double)(*n_iter + bb), d_Dt,   \
-                                               d_Bt, d_C, d_code, d_comp_norm, d_feature_n_iter, (hipStream_t)stream); \
-            if (rc != MODL_OK) {                                                                                      \
-                (void)modl_rk_set_mt_state(order_rng, key, pos);          /* (the failed minibatch drew nothing) */    \
-                return rc;                                                                                            \
-            }                                                                                                         \
-            *n_iter += bb;                                                                                            \
-            ++done;                                                                                                   \
-            if (n_done) *n_done = done;                                                                               \
-        }                                                                                                             \
-        return MODL_OK;                                                                                               \
+        return recsys_fit_batches<T>(pl, h_indptr, h_indices, h_data, n_rows, d_indptr, d_indices, d_data, h_rows, n_rows_fit, \
+                                     batch_size, order_rng, alpha, learning_rate, n_iter, d_Dt, d_Bt, d_C, d_code, d_comp_norm, \
+                                     d_feature_n_iter, (hipStream_t)stream, n_done);                                    \
     }
 ABI_RECSYS_FIT(f32, float)
 ABI_RECSYS_FIT(f64, double)
