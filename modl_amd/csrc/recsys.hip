@@ -207,6 +207,7 @@ constexpr int kRfMaxChunks = 64, kRfMaxBatch = 64, kRfChunk = 128;
 constexpr int kRfMaxSweep = 4;                          // sweep workgroups of 512 items each
 constexpr int kRfMaxItems = 512 * kRfMaxSweep;
 constexpr long long kRfSentinel = 0x7ff8dead0000beefll; // a NaN no sum produces
+typedef unsigned int rf_u4 __attribute__((ext_vector_type(4)));   // (a native vector: an array of HIP's uint4 structs went to scratch)
 struct RecsysChunk { int32_t pos, beg, cnt, nch, ci, part0; };   // row of the batch, first CSR entry, entries, chunks of the row, index among them, first record
 template <typename T> struct RecsysFusedArgs {
     const int32_t *indptr, *indices;
@@ -223,8 +224,8 @@ template <typename T> struct RecsysFusedArgs {
     int k, b, u, n_solve, do_dict, nsweep;
     // the NEXT minibatch's pinned slot -> the other device staging buffer, by one more workgroup at the end of the grid (the
     // run of minibatches of modl_recsys_fit_batches_*: no staging launch between two minibatches); stage_n16 == 0: none
-    const uint4 *stage_src;
-    uint4 *stage_dst;
+    const rf_u4 *stage_src;
+    rf_u4 *stage_dst;
     size_t stage_n16;
     unsigned long long *stage_ack, stage_use;
     int64_t rows[kRfMaxBatch];
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
     int me = 0;                                                 // which of the sweep workgroups this one becomes (0: the last to finish)
     if (a.stage_n16 && blockIdx.x == gridDim.x - 1) {           // the rider: the next minibatch's staged arrays
         for (size_t i0 = tid; i0 < a.stage_n16; i0 += 8 * 512) {
-            uint4 v[8];
+            rf_u4 v[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = a.stage_src[(i0 + 512 * q < a.stage_n16) ? i0 + 512 * q : a.stage_n16 - 1];
 #pragma unroll
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
             if (tid == 0) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(a.tickets + kRfMaxBatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.n_solve &&
-                       ++spins < (1u << 26))
+                       ++spins < (1u << 20))
                     __builtin_amdgcn_s_sleep(8);
             }
         }
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
                     if (tid < 2 * W) {
                         unsigned spins = 0;
                         do got = rf_load(slot + tid);
-                        while (__double_as_longlong(got) == kRfSentinel && ++spins < (1u << 24));
+                        while (__double_as_longlong(got) == kRfSentinel && ++spins < (1u << 18));
                     }
                     // (red2 is free until the end of the sweep; it is rewritten behind the NEXT atom's barrier, which every
                     //  thread reaches only after it has read these)
@@ -546,6 +547,7 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
             }
         });
         // the projected atoms' norms leave the budgets (:211-212), the rows go back
+        __syncthreads();                                                 // (red2 held the last atom's exchanged sums)
 #pragma unroll
         for (int ii = 0; ii < KP; ++ii) {
             const double s2 = wave_sum((double)Dr[ii] * (double)Dr[ii]);
@@ -572,13 +574,14 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
                 if (tid < k) {
                     unsigned spins = 0;
                     do got = rf_load(slot + (size_t)h * KP + tid);
-                    while (__double_as_longlong(got) == kRfSentinel && ++spins < (1u << 24));
+                    while (__double_as_longlong(got) == kRfSentinel && ++spins < (1u << 18));
                 }
                 s2 += got;
             }
         }
         if (tid < k) a.comp_norm[ord[tid]] = bud[tid] - (T)s2;
         if (W > 1) {                                                     // the slots back to sentinels: every helper has left them
+            __syncthreads();                                             // (... once wave 0 has READ the helpers' last ones)
             long long *xs = reinterpret_cast<long long *>(a.xch);
             for (int e2 = tid; e2 < (KP * 2 + KP) * kRfMaxSweep; e2 += 512) xs[e2] = kRfSentinel;
         }
@@ -682,10 +685,10 @@ static RecsysLayout recsys_layout(size_t tsz, int64_t b, int k, int64_t u, int64
 // ONE workgroup: the used part of the pinned slot -> HBM (eight 16-byte loads per thread in flight), then the slot's use count
 // into its acknowledgement word (host memory): the host checks that word before it refills the slot - no stream event (a
 // hipEventRecord between two kernels is a ~5 us bubble on this part)
-__global__ __launch_bounds__(256) void recsys_stage_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16,
+__global__ __launch_bounds__(256) void recsys_stage_kernel(const rf_u4 *__restrict__ src, rf_u4 *__restrict__ dst, size_t n16,
                                                            unsigned long long *ack, unsigned long long use) {
     for (size_t i0 = threadIdx.x; i0 < n16; i0 += 8 * 256) {
-        uint4 v[8];
+        rf_u4 v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = src[(i0 + 256 * q < n16) ? i0 + 256 * q : n16 - 1];
 #pragma unroll
@@ -782,8 +785,8 @@ int recsys_launch(modl_recsys_plan *pl, const RecsysPrep &pr, bool staged, const
     if (next_staged) *next_staged = false;
     char *dst = pl->dstage2[pl->cur];
     if (!staged) {
-        hipLaunchKernelGGL(recsys_stage_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const uint4 *>(pl->hdev[pr.slot]),
-                           reinterpret_cast<uint4 *>(dst), L.total / 16,
+        hipLaunchKernelGGL(recsys_stage_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const rf_u4 *>(pl->hdev[pr.slot]),
+                           reinterpret_cast<rf_u4 *>(dst), L.total / 16,
                            reinterpret_cast<unsigned long long *>(pl->hdev[pr.slot] + pl->ack_off), pr.use);
         MODL_LAUNCH_CHECK();
     }
@@ -825,8 +828,8 @@ int recsys_launch(modl_recsys_plan *pl, const RecsysPrep &pr, bool staged, const
             fa.xch = pl->xch;
             fa.stage_src = nullptr; fa.stage_dst = nullptr; fa.stage_n16 = 0; fa.stage_ack = nullptr; fa.stage_use = 0;
             if (next) {                                      // the next minibatch's arrays ride along, into the other buffer
-                fa.stage_src = reinterpret_cast<const uint4 *>(pl->hdev[next->slot]);
-                fa.stage_dst = reinterpret_cast<uint4 *>(pl->dstage2[pl->cur ^ 1]);
+                fa.stage_src = reinterpret_cast<const rf_u4 *>(pl->hdev[next->slot]);
+                fa.stage_dst = reinterpret_cast<rf_u4 *>(pl->dstage2[pl->cur ^ 1]);
                 fa.stage_n16 = next->L.total / 16;
                 fa.stage_ack = reinterpret_cast<unsigned long long *>(pl->hdev[next->slot] + pl->ack_off);
                 fa.stage_use = next->use;
