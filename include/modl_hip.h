@@ -264,6 +264,12 @@ int modl_recsys_fit_batches_f64(modl_recsys_plan *plan, const int32_t *h_indptr,
 /* diagnostics: minibatches of this plan that ran as ONE launch (csrc/recsys.hip: recsys_fused_kernel: at most 64 atoms, 64 rows
  * and 8192 ratings per minibatch) / as the separate launches */
 int modl_recsys_plan_counts(const modl_recsys_plan *plan, int64_t *fused, int64_t *split);
+/* diagnostics: on = 1 makes the last workgroup of every one-launch minibatch leave 100 MHz wall-clock stamps ([0] entry, [1] ids,
+ * [2] Gram chunk, [3] records summed, [4] factor, [5] ticket, [6] last phase, [7] C_, [8] B_, [9] sweep, [10] end, [11] items,
+ * [12] sweep workgroups); h_out[16] (may be NULL) receives the last launch's (synchronises the device); on = 0 frees them */
+int modl_recsys_plan_stamps(modl_recsys_plan *plan, int on, unsigned long long *h_out);
+/* diagnostics: host time (ms) the plan has spent waiting for the device to read a staging slot (eight minibatches of lead) */
+int modl_recsys_plan_wait_ms(const modl_recsys_plan *plan, double *ms);
 /* C = beta C + alpha rows^T rows, rows[b][k]  (recsys.py:159-160: beta = 1 - w, alpha = w / b) */
 int modl_gram_axpby_f32(const float *d_rows, int64_t b, int k, float *d_C, float beta, float alpha, void *stream);
 int modl_gram_axpby_f64(const double *d_rows, int64_t b, int k, double *d_C, double beta, double alpha, void *stream);

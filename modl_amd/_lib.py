@@ -152,6 +152,8 @@ def bind(lib):
     _sig('modl_recsys_plan_create', C.c_int, C.c_int, _i64, C.c_int, _i64, _i64, _P(_vp))
     _sig('modl_recsys_plan_destroy', None, _vp)
     _sig('modl_recsys_plan_counts', C.c_int, _vp, _P(_i64), _P(_i64))
+    _sig('modl_recsys_plan_wait_ms', C.c_int, _vp, _P(_f64))
+    _sig('modl_recsys_plan_stamps', C.c_int, _vp, C.c_int, _vp)
     _sig('modl_predict_csr', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp)
     _sig('modl_somf_plan_create', C.c_int, _P(SomfDesc), _P(_vp))
     _sig('modl_somf_plan_destroy', None, _vp)

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void recsys_predict_kernel(double *out, const 
 // More than 512 touched items: the kernel stops after B_ and the host runs the blocked dictionary update's launches.
 constexpr int kRfMaxChunks = 64, kRfMaxBatch = 64, kRfChunk = 128;
 constexpr int kRfMaxSweep = 4;                          // sweep workgroups of 512 items each
-constexpr int kRfMaxItems = 512 * kRfMaxSweep;
+constexpr int kRfMaxItems = 1024 * kRfMaxSweep;          // (registers + the LDS tier)
 constexpr long long kRfSentinel = 0x7ff8dead0000beefll; // a NaN no sum produces
 typedef unsigned int rf_u4 __attribute__((ext_vector_type(4)));   // (a native vector: an array of HIP's uint4 structs went to scratch)
 struct RecsysChunk { int32_t pos, beg, cnt, nch, ci, part0; };   // row of the batch, first CSR entry, entries, chunks of the row, index among them, first record
@@ -222,6 +222,8 @@ template <typename T> struct RecsysFusedArgs {
     double alpha, w, w_n_iter;
     int64_t p;
     int k, b, u, n_solve, do_dict, nsweep;
+    int cap2;                                            // items of a sweep workgroup's LDS tier (a multiple of 64, at most 512)
+    unsigned long long *dbg;                             // optional: 100 MHz wall-clock stamps of the LAST workgroup (modl_recsys_plan_stamps)
     // the NEXT minibatch's pinned slot -> the other device staging buffer, by one more workgroup at the end of the grid (the
     // run of minibatches of modl_recsys_fit_batches_*: no staging launch between two minibatches); stage_n16 == 0: none
     const rf_u4 *stage_src;
@@ -259,12 +261,38 @@ template <int J, int N, typename F> __device__ __forceinline__ void rf_static_fo
     }
 }
 
+// a workgroup barrier that orders LDS traffic only (global requests stay in flight across it)
+__device__ __forceinline__ void rf_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// D[jj] = v for a wavefront-uniform jj, every register index a compile-time constant: a uniform branch to the group of eight
+// registers, eight selects
+template <typename T, int KP> __device__ __forceinline__ void rf_set(T (&D)[KP], int jj, T v) {
+    static_assert(KP % 8 == 0, "groups of eight registers");
+    const int g = jj >> 3, r = jj & 7;
+    rf_static_for<0, KP / 8>([&](auto G) {
+        constexpr int gg = decltype(G)::value;
+        if (g == gg) {
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                D[8 * gg + x] = (r == x) ? v : D[8 * gg + x];
+                // (opaque: the optimiser recognises the chain of selects as an insertion at a variable index and moves the
+                //  whole array to scratch)
+                asm volatile("" : "+v"(D[8 * gg + x]));
+            }
+        }
+    });
+}
+
 template <typename T>
-size_t recsys_fused_lds(int k, int b, int KP) {
+size_t recsys_fused_lds(int k, int b, int KP, int cap2) {
     const size_t KS = (size_t)((k + 3) & ~3), ld = (size_t)(k | 1);
     const size_t chunk = sizeof(T) * ((size_t)k * ld + 4 + 2 * KS + 768 + 2 * 32 * KS + kRfChunk) + sizeof(int) * (kRfChunk + 8);
     const size_t fin = sizeof(T) * ((size_t)k * KP + (size_t)b * k + 3 * (size_t)KP) + sizeof(double) * (2 * 8 * 2 + 8 * (size_t)KP) +
-                       sizeof(int) * ((size_t)KP + 8);
+                       ((sizeof(int) * ((size_t)KP + 8) + 15) & ~(size_t)15) + sizeof(T) * (size_t)KP * cap2 + 16;
     return (chunk > fin ? chunk : fin) + 64;
 }
 
@@ -274,6 +302,8 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int k = a.k;
     int me = 0;                                                 // which of the sweep workgroups this one becomes (0: the last to finish)
+    unsigned long long stp[8];                                  // stamps of the chunk phase (kept only by the last workgroup)
+    stp[0] = a.dbg ? wall_clock64() : 0;
     if (a.stage_n16 && blockIdx.x == gridDim.x - 1) {           // the rider: the next minibatch's staged arrays
         for (size_t i0 = tid; i0 < a.stage_n16; i0 += 8 * 512) {
             rf_u4 v[8];
@@ -339,6 +369,7 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
                 }
             }
         };
+        stp[1] = a.dbg ? wall_clock64() : 0;
         if (tid < 256) request(0);
         for (int sb = 0; sb < nsub; ++sb) {
             T *buf = rowsb + (size_t)(sb & 1) * tot;
@@ -360,6 +391,7 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
                 for (int j = 0; j < ncs; ++j) racc = fma(buf[j * KS + ra], xv[32 * sb + j], racc);
             }
         }
+        stp[2] = a.dbg ? wall_clock64() : 0;
         const int rec = k * k + k;
         if (c.nch > 1) {                                        // several chunks: meet in the records, the last to arrive goes on
             T *pp = a.part + (size_t)(c.part0 + c.ci) * rec;
@@ -397,7 +429,9 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
             if (tid < k) G[tid * ld + tid] += ridge;
         }
         __syncthreads();
+        stp[3] = a.dbg ? wall_clock64() : 0;
         chol_block_lds<T, 1>(G, k, ld, dinv, cpart);
+        stp[4] = a.dbg ? wall_clock64() : 0;
         if (wid == 0) {
             T y[1][1];
             y[0][0] = (lane < k) ? rhs[lane] : (T)0;
@@ -408,6 +442,7 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
         __syncthreads();
         if (tid == 0) flag[1] = (int)__hip_atomic_fetch_add(a.tickets + kRfMaxBatch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+        stp[5] = a.dbg ? wall_clock64() : 0;
         me = a.n_solve - 1 - flag[1];                           // 0: the last row to finish, 1 .. : the ones just before it
         if (me >= a.nsweep) return;
         if (me > 0) {
@@ -426,12 +461,17 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
     const int b = a.b, u = a.u, W = a.nsweep;
     T *Csw = reinterpret_cast<T *>(smem_raw);                   // [k][KP] C in sweep coordinates, zero diagonal, zero padding
     T *codeb = Csw + (size_t)k * KP;                            // [b][k]
-    T *cdg = codeb + (size_t)b * k;                             // [KP] diagonal of C, sweep order
+    T *cdg = codeb + (size_t)b * k;                             // [KP] reciprocals of the diagonal of C (0: frozen), sweep order
     T *cn = cdg + KP;                                           // [KP] norm budgets, sweep order
     T *bud = cn + KP;                                           // [KP] budget each atom was clipped to
     double *red = reinterpret_cast<double *>(bud + KP);         // [2][8][2]
     double *red2 = red + 32;                                    // [8][KP]
     int *ord = reinterpret_cast<int *>(red2 + 8 * KP);          // [KP]
+    const bool stamp = a.dbg && me == 0 && tid == 0;
+    if (stamp) {
+        for (int x = 0; x < 6; ++x) a.dbg[x] = stp[x];
+        a.dbg[6] = wall_clock64();
+    }
     for (int e = tid; e < b * k; e += 512) codeb[e] = rf_load(a.code + a.rows[e / k] * k + e % k);
     if (tid < KP) ord[tid] = (tid < k) ? a.order[tid] : 0;
     __syncthreads();
@@ -447,7 +487,7 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
         T v = 0;
         if (ii < k) {
             v = c_new(ord[jj], ord[ii]);
-            if (ii == jj) { cdg[jj] = v; v = 0; }
+            if (ii == jj) { cdg[jj] = (v > (T)1e-20) ? (T)1 / v : (T)0; v = 0; }     // (the reciprocal; 0: recsys.py:201 "else do not update")
         }
         Csw[e] = v;
     }
@@ -456,7 +496,9 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
     // or, without an in-kernel sweep, all of them in passes.  Every load a thread needs for its item is independent of the other
     // threads': 512 items in flight per pass (a wavefront per item, as a launch of its own did it, is a chain of three
     // dependent round trips per item - 94 items per wavefront took 100 us here).
-    const int it0 = a.do_dict ? 512 * me : 0, it1 = a.do_dict ? ((u < it0 + 512) ? u : it0 + 512) : u;
+    if (stamp) a.dbg[7] = wall_clock64();
+    const int per = 512 + a.cap2;                               // items of a sweep workgroup: 512 in registers + cap2 in LDS
+    const int it0 = a.do_dict ? per * me : 0, it1 = a.do_dict ? ((u < it0 + per) ? u : it0 + per) : u;
     for (int base = it0; base < it1; base += 512) {
         const int fi = base + tid;
         const bool on = fi < it1;
@@ -489,35 +531,105 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
         }
     }
     __syncthreads();
+    if (stamp) a.dbg[8] = wall_clock64();
     if (a.do_dict) {
-        const int fi = 512 * me + tid;
-        const bool live = fi < u;
+        const int fi = it0 + tid;
+        const bool live = fi < it1;
         const int64_t fo = (int64_t)a.subset[live ? fi : 0] * k;
+        // the LDS tier: a SECOND item for the first cap2 threads, its atoms in LDS (D2[atom][thread]: a wavefront reads
+        // consecutive words) - a minibatch of ten MovieLens rows touches 700-800 items, more than 512 threads hold in registers
+        const int cap2 = a.cap2;
+        T *D2 = reinterpret_cast<T *>(reinterpret_cast<char *>(ord) + ((sizeof(int) * (KP + 8) + 15) & ~(size_t)15));   // [KP][cap2]
+        const int fi2 = it0 + 512 + tid;
+        const bool live2 = tid < cap2 && fi2 < it1;
+        const bool wave2 = (wid * 64 < cap2) && (it0 + 512 + wid * 64 < it1);     // (wave-uniform: this wave has second items)
+        const int64_t fo2 = (int64_t)a.subset[live2 ? fi2 : 0] * k;
+        T bn2 = 0;
+        if (wave2) {                                                     // (before the first item's registers are live)
+#pragma unroll 8
+            for (int ii = 0; ii < KP; ++ii) {
+                const T v = a.Dt[fo2 + ord[ii]];
+                if (tid < cap2) D2[ii * cap2 + tid] = (live2 && ii < k) ? v : (T)0;
+            }
+            bn2 = a.Bt[fo2 + ord[0]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         T Dr[KP];
 #pragma unroll
         for (int ii = 0; ii < KP; ++ii) Dr[ii] = a.Dt[fo + ord[ii]];
 #pragma unroll
         for (int ii = 0; ii < KP; ++ii) Dr[ii] = (live && ii < k) ? Dr[ii] : (T)0;
         T bn = a.Bt[fo + ord[0]];
-        // (the atom's register is a compile-time index: the loop over the atoms is unrolled by recursion - as a `#pragma unroll`
-        //  loop of 64 x 64 the compiler kept it rolled and put the registers in scratch)
-        rf_static_for<0, KP>([&](auto J) {
-            constexpr int jj = decltype(J)::value;
-            if (jj < k) {
+        // The atom loop is a RUNTIME loop with one shared body.  (Round 6, first version: unrolled by recursion so that the atom's
+        // register was a compile-time index - 56 copies of a 300-instruction body, 134 KB of straight-line code executed once:
+        // the sweep was bound by INSTRUCTION FETCH, 1.8 us per atom whatever the number of items, 89 of a minibatch's 172 us.)
+        // (Measured and not kept: the row of C read with SCALAR loads from a copy in memory - no LDS traffic, but seven dependent
+        //  scalar-memory round trips per wavefront and atom: 88 -> 128 us.)
+        // What needs the atom's index: the dot product does not (C in sweep coordinates has a zero diagonal); the atom's old
+        // value comes from memory with the B_ entry, one atom ahead; the new value goes into its register through a uniform
+        // switch over groups of eight registers (rf_set: a scalar branch + eight selects).
+        // The B_ entry and the old value of an atom are requested TWO atoms ahead, and the barriers inside the loop order LDS
+        // traffic only (rf_lds_barrier): __syncthreads() also waits for every outstanding global load - it drained the requests
+        // it was meant to overlap, a memory round trip per atom (4.5 k cycles per atom, 93 of a minibatch's 175 us, measured).
+        T dn = a.Dt[fo + ord[0]];
+        T dn2 = wave2 ? a.Dt[fo2 + ord[0]] : (T)0;
+        T bm = a.Bt[fo + ord[k > 1 ? 1 : 0]], dm = a.Dt[fo + ord[k > 1 ? 1 : 0]];
+        T bm2 = wave2 ? a.Bt[fo2 + ord[k > 1 ? 1 : 0]] : (T)0, dm2 = wave2 ? a.Dt[fo2 + ord[k > 1 ? 1 : 0]] : (T)0;
+        for (int jj = 0; jj < k; ++jj) {
+            {
+                const int jn = (jj + 2 < k) ? jj + 2 : k - 1;
                 const T bvj = live ? bn : (T)0;
-                bn = a.Bt[fo + ord[(jj + 1 < k) ? jj + 1 : jj]];
-                T dot = 0;
+                const T dold = live ? dn : (T)0;
+                bn = bm; dn = dm;
+                bm = a.Bt[fo + ord[jn]];
+                dm = a.Dt[fo + ord[jn]];
+                // the row of C as explicit 16-byte LDS reads (KP / VW of them: the LDS pipe is what bounds this loop - eight
+                // wavefronts broadcast-read every row)
+                constexpr int VW = 16 / (int)sizeof(T);
+                typedef T rf_vec __attribute__((ext_vector_type(VW)));
+                const rf_vec *crow = reinterpret_cast<const rf_vec *>(Csw + jj * KP);
+                T dot = 0, dot2 = 0;
+                const int t2 = tid < cap2 ? tid : 0;
+                if (!wave2) {
 #pragma unroll
-                for (int ii = 0; ii < KP; ++ii)
-                    if (ii != jj) dot = fma(Csw[jj * KP + ii], Dr[ii], dot);
-                const T cd = cdg[jj];
-                const T dold = Dr[jj];
-                T un = (cd > (T)1e-20) ? (bvj - dot) / cd : dold;      // recsys.py:201-203
+                    for (int iv = 0; iv < KP / VW; ++iv) {
+                        const rf_vec c = crow[iv];
+#pragma unroll
+                        for (int x = 0; x < VW; ++x) dot = fma(c[x], Dr[iv * VW + x], dot);
+                    }
+                } else {                                         // (both items of the thread on one read of the row of C)
+#pragma unroll
+                    for (int iv = 0; iv < KP / VW; ++iv) {
+                        const rf_vec c = crow[iv];
+#pragma unroll
+                        for (int x = 0; x < VW; ++x) {
+                            dot = fma(c[x], Dr[iv * VW + x], dot);
+                            dot2 = fma(c[x], D2[(iv * VW + x) * cap2 + t2], dot2);
+                        }
+                        if ((iv & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (a few LDS reads in flight, not all KP: registers)
+                    }
+                }
+                const T icd = cdg[jj];                                   // 1 / C[j][j], or 0: "else do not update"
+                T un = (icd != (T)0) ? (bvj - dot) * icd : dold;       // recsys.py:201-203
                 un = live ? un : (T)0;
-                const double o2 = wave_sum((double)dold * (double)dold), n2 = wave_sum((double)un * (double)un);
+                double o2 = (double)dold * (double)dold, n2 = (double)un * (double)un;
+                T un2 = 0;
+                if (wave2) {
+                    const T bv2 = live2 ? bn2 : (T)0;
+                    const T dold2 = live2 ? dn2 : (T)0;
+                    bn2 = bm2; dn2 = dm2;
+                    bm2 = a.Bt[fo2 + ord[jn]];
+                    dm2 = a.Dt[fo2 + ord[jn]];
+                    un2 = (icd != (T)0) ? (bv2 - dot2) * icd : dold2;
+                    un2 = live2 ? un2 : (T)0;
+                    o2 += (double)dold2 * (double)dold2;
+                    n2 += (double)un2 * (double)un2;
+                }
+                o2 = wave_sum(o2);
+                n2 = wave_sum(n2);
                 double *rd = red + (jj & 1) * 16;
                 if (lane == 0) { rd[2 * wid] = o2; rd[2 * wid + 1] = n2; }
-                __syncthreads();
+                rf_lds_barrier();
                 double so = 0, sn = 0;
 #pragma unroll
                 for (int x = 0; x < 8; ++x) { so += rd[2 * x]; sn += rd[2 * x + 1]; }
@@ -535,22 +647,36 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
                     // (red2 is free until the end of the sweep; it is rewritten behind the NEXT atom's barrier, which every
                     //  thread reaches only after it has read these)
                     if (tid < 2 * kRfMaxSweep) red2[tid] = (tid < 2 * W) ? got : 0.0;
-                    __syncthreads();
+                    rf_lds_barrier();
                     so = (red2[0] + red2[2]) + (red2[4] + red2[6]);
                     sn = (red2[1] + red2[3]) + (red2[5] + red2[7]);
                 }
                 const T budget = cn[jj] + (T)so;                         // :197-198 comp_norm_ += subset_norm
-                const T norm = (T)sqrt(sn), lim = sqrt(budget);          // :205-206
-                if (norm > lim) un = un / (norm / lim);                  // :207-208
-                Dr[jj] = un;
+                // :205-208 norm = sqrt(sum), lim = sqrt(budget), "if norm > lim: atom /= norm / lim" as ONE factor
+                // sqrt(budget / sum) (a negative or NaN budget never clips, as there)
+                const bool clip = (T)sn > budget && budget >= (T)0;
+                const T scale = clip ? (T)sqrt((double)budget / sn) : (T)1;
+                un *= scale;
+                rf_set<T, KP>(Dr, jj, un);
+                if (wave2) {
+                    un2 *= scale;
+                    if (tid < cap2) D2[jj * cap2 + tid] = un2;
+                }
                 if (tid == 0) bud[jj] = budget;
             }
-        });
+        }
         // the projected atoms' norms leave the budgets (:211-212), the rows go back
         __syncthreads();                                                 // (red2 held the last atom's exchanged sums)
+        if (stamp) a.dbg[9] = wall_clock64();
 #pragma unroll
         for (int ii = 0; ii < KP; ++ii) {
-            const double s2 = wave_sum((double)Dr[ii] * (double)Dr[ii]);
+            double q2 = (double)Dr[ii] * (double)Dr[ii];
+            if (wave2) {
+                const T d2 = D2[ii * cap2 + (tid < cap2 ? tid : 0)];
+                q2 += live2 ? (double)d2 * (double)d2 : 0.0;
+                if (live2 && ii < k) a.Dt[fo2 + ord[ii]] = d2;
+            }
+            const double s2 = wave_sum(q2);
             if (lane == 0) red2[wid * KP + ii] = s2;
         }
         if (live)
@@ -593,6 +719,7 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
     }
     __syncthreads();
     for (int e = tid; e < k * k; e += 512) a.C[e] = a.part[e];
+    if (stamp) { a.dbg[10] = wall_clock64(); a.dbg[11] = (unsigned long long)a.u; a.dbg[12] = (unsigned long long)a.nsweep; }
     if (tid <= kRfMaxBatch) a.tickets[tid] = 0;                 // for the next launch
 }
 
@@ -661,9 +788,11 @@ struct modl_recsys_plan {
     char *part = nullptr;
     unsigned int *tickets = nullptr;
     double *xch = nullptr;                     // exchange slots of the sweep workgroups (sentinels between launches)
+    unsigned long long *dbg = nullptr;         // modl_recsys_plan_stamps(plan, 1, ...): stamps of the last workgroup of each launch
     unsigned long long uses[modl::kRecsysSlots] = {0};
     size_t ack_off = 0;
     long fused_calls = 0, split_calls = 0;     // minibatches through the one-launch path / through the separate launches
+    double wait_ms = 0;                        // host time spent waiting for a staging slot (the host is eight minibatches ahead)
 };
 
 namespace modl {
@@ -747,6 +876,7 @@ int recsys_prepare(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_t 
                 MODL_HIP(hipStreamSynchronize(st));           // (another stream than the slot's last use, or a stuck device: settle it)
                 break;
             }
+        pl->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     std::memcpy(h + L.rows, h_rows, sizeof(int64_t) * (size_t)b);
     int32_t *ho = reinterpret_cast<int32_t *>(h + L.order);
@@ -822,10 +952,23 @@ int recsys_launch(modl_recsys_plan *pl, const RecsysPrep &pr, bool staged, const
             fa.part = reinterpret_cast<T *>(pl->part); fa.tickets = pl->tickets;
             fa.alpha = alpha; fa.w = w; fa.w_n_iter = w * n_iter; fa.p = pl->p;
             fa.k = k; fa.b = (int)b; fa.u = (int)u; fa.n_solve = n_solve;
-            fa.nsweep = (int)std::max<int64_t>(1, (u + 511) / 512);
+            constexpr int KPW0 = kRfWide<T>::value;
+            const int KP0 = k <= 32 ? 32 : KPW0;
+            {   // the LDS tier: what 160 KB leave next to the last phase's other arrays, in whole wavefronts
+                const size_t base = recsys_fused_lds<T>(k, (int)b, KP0, 0);
+                const size_t room = base < 156 * 1024 ? 156 * 1024 - base : 0;
+                int cap = (int)(room / (sizeof(T) * KP0)) & ~63;
+                if (cap > 512) cap = 512;
+                if (g_recsys_fused.load(std::memory_order_relaxed) == 3) cap = 0;      // (A/B: registers only)
+                fa.cap2 = cap;
+            }
+            const int per = 512 + fa.cap2;
+            fa.nsweep = (int)std::max<int64_t>(1, (u + per - 1) / per);
             fa.do_dict = (u > 0 && fa.nsweep <= kRfMaxSweep && fa.nsweep <= std::max(n_solve, 1)) ? 1 : 0;
+            if (fa.nsweep > 1 && g_recsys_fused.load(std::memory_order_relaxed) == 2) fa.do_dict = 0;   // (A/B: several sweep workgroups off)
             if (!fa.do_dict) fa.nsweep = 1;
             fa.xch = pl->xch;
+            fa.dbg = pl->dbg;
             fa.stage_src = nullptr; fa.stage_dst = nullptr; fa.stage_n16 = 0; fa.stage_ack = nullptr; fa.stage_use = 0;
             if (next) {                                      // the next minibatch's arrays ride along, into the other buffer
                 fa.stage_src = reinterpret_cast<const rf_u4 *>(pl->hdev[next->slot]);
@@ -836,7 +979,7 @@ int recsys_launch(modl_recsys_plan *pl, const RecsysPrep &pr, bool staged, const
             }
             constexpr int KPW = kRfWide<T>::value;             // registers per item of the wide variant: 64 (f32) / 56 (f64)
             const int KP = k <= 32 ? 32 : KPW;
-            const size_t lds = recsys_fused_lds<T>(k, (int)b, KP);
+            const size_t lds = recsys_fused_lds<T>(k, (int)b, KP, fa.cap2);
             const unsigned grid = (unsigned)(nc > 0 ? nc : 1) + (fa.stage_n16 ? 1u : 0u);
             if (KP == 32) {
                 MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&recsys_fused_kernel<T, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1072,6 +1215,7 @@ void modl_recsys_plan_destroy(modl_recsys_plan *pl) {
     if (pl->part) (void)hipFree(pl->part);
     if (pl->tickets) (void)hipFree(pl->tickets);
     if (pl->xch) (void)hipFree(pl->xch);
+    if (pl->dbg) (void)hipFree(pl->dbg);
     if (pl->dstage) (void)hipFree(pl->dstage);
     if (pl->ws) (void)hipFree(pl->ws);
     delete pl;
@@ -1130,6 +1274,31 @@ int modl_recsys_plan_counts(const modl_recsys_plan *pl, int64_t *fused, int64_t 
     if (!pl || !fused || !split) return MODL_EINVAL;
     *fused = pl->fused_calls;
     *split = pl->split_calls;
+    return MODL_OK;
+}
+
+/* diagnostics: on = 1 allocates 16 words the last workgroup of every one-launch minibatch stamps with the 100 MHz wall clock
+ * ([0] entry, [1] ids, [2] Gram chunk, [3] records summed, [4] factor, [5] ticket, [6] last phase, [7] C_, [8] B_, [9] sweep,
+ * [10] end, [11] items, [12] sweep workgroups); h_out[16] (may be NULL) receives the last launch's (synchronises the device) */
+int modl_recsys_plan_stamps(modl_recsys_plan *pl, int on, unsigned long long *h_out) {
+    if (!pl) return MODL_EINVAL;
+    if (on && !pl->dbg) {
+        MODL_HIP(hipMalloc((void **)&pl->dbg, 16 * sizeof(unsigned long long)));
+        MODL_HIP(hipMemset(pl->dbg, 0, 16 * sizeof(unsigned long long)));
+    }
+    if (h_out && pl->dbg) {
+        MODL_HIP(hipDeviceSynchronize());
+        MODL_HIP(hipMemcpy(h_out, pl->dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    if (!on && pl->dbg) { (void)hipFree(pl->dbg); pl->dbg = nullptr; }
+    return MODL_OK;
+}
+
+/* diagnostics: host time (ms) this plan has spent waiting for a staging slot to be read by the device - zero while the host
+ * is the bottleneck, the device's lead otherwise */
+int modl_recsys_plan_wait_ms(const modl_recsys_plan *pl, double *ms) {
+    if (!pl || !ms) return MODL_EINVAL;
+    *ms = pl->wait_ms;
     return MODL_OK;
 }
 
