@@ -498,7 +498,10 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
     // dependent round trips per item - 94 items per wavefront took 100 us here).
     if (stamp) a.dbg[7] = wall_clock64();
     const int per = 512 + a.cap2;                               // items of a sweep workgroup: 512 in registers + cap2 in LDS
-    const int it0 = a.do_dict ? per * me : 0, it1 = a.do_dict ? ((u < it0 + per) ? u : it0 + per) : u;
+    // (without an in-kernel sweep B_ is not updated here either: one workgroup walking every item's row takes 50 us for the
+    //  thousand items of a MovieLens minibatch, the launch of its own that the host enqueues behind this one - a wavefront per
+    //  item over the whole chip - 6 us)
+    const int it0 = a.do_dict ? per * me : 0, it1 = a.do_dict ? ((u < it0 + per) ? u : it0 + per) : 0;
     for (int base = it0; base < it1; base += 512) {
         const int fi = base + tid;
         const bool on = fi < it1;
@@ -959,13 +962,21 @@ int recsys_launch(modl_recsys_plan *pl, const RecsysPrep &pr, bool staged, const
                 const size_t room = base < 156 * 1024 ? 156 * 1024 - base : 0;
                 int cap = (int)(room / (sizeof(T) * KP0)) & ~63;
                 if (cap > 512) cap = 512;
-                if (g_recsys_fused.load(std::memory_order_relaxed) == 3) cap = 0;      // (A/B: registers only)
+                if (g_recsys_fused.load(std::memory_order_relaxed) == 3) cap = 0;      // (registers only)
                 fa.cap2 = cap;
             }
             const int per = 512 + fa.cap2;
             fa.nsweep = (int)std::max<int64_t>(1, (u + per - 1) / per);
             fa.do_dict = (u > 0 && fa.nsweep <= kRfMaxSweep && fa.nsweep <= std::max(n_solve, 1)) ? 1 : 0;
-            if (fa.nsweep > 1 && g_recsys_fused.load(std::memory_order_relaxed) == 2) fa.do_dict = 0;   // (A/B: several sweep workgroups off)
+            // Where B_ and the dictionary update run.  MEASURED (scripts/ab_recsys_fused.sh, MovieLens-10M-shaped rows, k = 50,
+            // b = 10, f64; profiles/r06_ab_recsys_fused.txt): as launches of their own behind this one - a wavefront per item, the
+            // blocked update over the whole chip - 197 us per minibatch at 109 ratings per row, 169 at 36, 130 at 13; inside this
+            // kernel on ONE workgroup (value 2; 3 without the LDS tier) 251-333 / 203 / 172 us - one compute unit walks a thousand
+            // item rows and broadcasts every row of C to eight wavefronts (1.5 us per atom, bound by the LDS pipe) while 255 units
+            // idle; on up to four workgroups that exchange every atom's sums through memory (value 4) 345 us.  So the default (1)
+            // keeps this launch to the codes and C_; the in-kernel variants stay selectable (and tested: they are correct).
+            const int mode = g_recsys_fused.load(std::memory_order_relaxed);
+            if (mode == 1 || (fa.nsweep > 1 && mode != 4)) fa.do_dict = 0;
             if (!fa.do_dict) fa.nsweep = 1;
             fa.xch = pl->xch;
             fa.dbg = pl->dbg;
@@ -994,7 +1005,11 @@ int recsys_launch(modl_recsys_plan *pl, const RecsysPrep &pr, bool staged, const
                 pl->cur ^= 1;
                 if (next_staged) *next_staged = true;
             }
-            if (u > 0 && !fa.do_dict) {                      // more touched items than one workgroup holds: the blocked update's launches
+            if (u > 0 && !fa.do_dict) {                      // more touched items than the sweep's workgroups hold: B_ and the
+                                                             // blocked dictionary update as launches of their own
+                hipLaunchKernelGGL((recsys_update_B_kernel<T>), dim3((unsigned)cdiv(u, 4)), dim3(256), 0, st, Bt, k, feature_n_iter,
+                                   d_subset, d_fptr, d_es, d_ev, (const T *)code, d_rows, w * n_iter, u);
+                MODL_LAUNCH_CHECK();
                 DictUpdateArgs<T> a;
                 a.Dt = Dt; a.Bt = Bt; a.C = C; a.comp_norm = comp_norm; a.subset = d_subset; a.order = d_order;
                 a.h_order = h_order; a.s = u; a.k = k; a.optimizer = 0; a.comp_pos = 0;

@@ -10,7 +10,7 @@ from modl_amd.randomkit import batch_weight
 from modl_amd._lib import lib, check, DEBUG_RECSYS_FUSED
 v = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 check(lib.modl_debug_set(DEBUG_RECSYS_FUSED, v))
-X = ml10m_like(nnz=2_000_000)[:4000]
+X = ml10m_like(nnz=10_000_000)[:3000]
 est = RecsysDictFact(n_components=50, alpha=1, beta=.1, batch_size=10, detrend=True, learning_rate=.95, n_epochs=1, random_state=0,
                      callback=lambda e: None)
 names = ['ids', 'gram', 'records', 'factor', 'solve+ticket', 'wait/entry', 'codes+C', 'B', 'sweep', 'tail']

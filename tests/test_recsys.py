@@ -121,12 +121,13 @@ def _ragged_ratings(n, p, k, heavy, empty, seed, dtype):
 @pytest.mark.parametrize('dtype,k,p,b', [(np.float64, 50, 700, 10), (np.float64, 20, 300, 7), (np.float32, 64, 500, 16),
                                          (np.float32, 30, 1500, 64), (np.float64, 50, 2500, 10)])
 def test_gpu_recsys_one_launch_vs_separate_launches(dtype, k, p, b):
-    """Round 6: a masked minibatch with at most 64 (f64: 56) atoms and 64 rows runs as ONE launch (csrc/recsys.hip:
-    recsys_fused_kernel: rating chunks of 128 with a ticketed fixed-order sum per row, Cholesky codes, then the last workgroup
-    alone: C_, the per-item B_ update, the dictionary sweep with one item per thread).  Against the separate launches of rounds
-    2-5 (MODL_DEBUG_RECSYS_FUSED = 0; pinned to the reference golden above) on ratings with heavy rows (several chunks), rows
-    without ratings and - p = 2500 - minibatches that touch more than 512 items (the kernel then stops after B_ and the blocked
-    dictionary update's launches follow): f64 to 1e-9, f32 within the reference algorithm's own f32 noise; and against the oracle."""
+    """Round 6: a masked minibatch with at most 64 (f64: 56) atoms and 64 rows runs its codes and C_ as ONE launch
+    (csrc/recsys.hip: recsys_fused_kernel: rating chunks of 128 with a ticketed fixed-order sum per row, Cholesky codes, the last
+    workgroup C_), B_ and the blocked dictionary update behind it (the default), or - MODL_DEBUG_RECSYS_FUSED = 2 / 4 - B_ and the
+    dictionary sweep inside that launch with one item per thread, on one workgroup or on up to four that exchange every atom's
+    sums through memory.  All of them against the separate launches of rounds 2-5 (= 0; pinned to the reference golden above) on
+    ratings with heavy rows (several chunks), rows without ratings and - p = 2500 - minibatches that touch more items than the
+    sweep's workgroups hold: f64 to 1e-9, f32 within the reference algorithm's own f32 noise; and against the oracle."""
     from modl_amd.recsys import RecsysDictFact
     from modl_amd._lib import lib, check, DEBUG_RECSYS_FUSED
     from oracle import wrappers_oracle as wo
@@ -134,7 +135,7 @@ def test_gpu_recsys_one_launch_vs_separate_launches(dtype, k, p, b):
     X = _ragged_ratings(160, p, 6, heavy=5, empty=6, seed=p + k, dtype=dtype)
     kw = dict(alpha=0.2, beta=0.0, batch_size=b, n_epochs=1, learning_rate=0.9, random_state=1)
     out = {}
-    for fused in (1, 0):
+    for fused in (1, 2, 4, 0):                               # the default, the in-kernel sweep (one workgroup / up to four), the old launches
         check(lib.modl_debug_set(DEBUG_RECSYS_FUSED, fused))
         try:
             est = RecsysDictFact(n_components=k, **kw).fit(X)
@@ -146,19 +147,20 @@ def test_gpu_recsys_one_launch_vs_separate_launches(dtype, k, p, b):
             assert counts[0] > 0, counts                              # (a minibatch of more than 64 chunks takes the separate launches)
         else:
             assert counts[0] == 0
-    assert np.array_equal(out[1]['fn'], out[0]['fn'])
     fit64 = wo.recsys_fit(X.astype(np.float64), n_components=k, **kw)
-    if dtype == np.float64:
-        for key in ('D', 'code', 'C', 'B'):
-            assert rel_fro(out[1][key], out[0][key]) < 1e-9, key
-        assert np.allclose(out[1]['cn'], out[0]['cn'], rtol=0, atol=1e-10)      # (budgets left: ~0, differences of O(1) numbers)
-        for key in ('D', 'code', 'C', 'B'):
-            assert rel_fro(out[1][key], fit64[key]) < 1e-8, key
-    else:
-        fit32 = wo.recsys_fit(X, n_components=k, **kw)
-        for key in ('D', 'code', 'C', 'B'):
-            assert_within_f32_noise(out[1][key], fit32[key], fit64[key], key)
-    assert np.all(np.isfinite(out[1]['D']))
+    fit32 = wo.recsys_fit(X, n_components=k, **kw) if dtype == np.float32 else None
+    for fused in (1, 2, 4):
+        assert np.array_equal(out[fused]['fn'], out[0]['fn'])
+        if dtype == np.float64:
+            for key in ('D', 'code', 'C', 'B'):
+                assert rel_fro(out[fused][key], out[0][key]) < 1e-9, (fused, key)
+            assert np.allclose(out[fused]['cn'], out[0]['cn'], rtol=0, atol=1e-10)      # (budgets left: ~0, differences of O(1) numbers)
+            for key in ('D', 'code', 'C', 'B'):
+                assert rel_fro(out[fused][key], fit64[key]) < 1e-8, (fused, key)
+        else:
+            for key in ('D', 'code', 'C', 'B'):
+                assert_within_f32_noise(out[fused][key], fit32[key], fit64[key], (fused, key))
+        assert np.all(np.isfinite(out[fused]['D']))
 
 
 @pytest.mark.gpu
