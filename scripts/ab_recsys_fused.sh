@@ -9,7 +9,7 @@ from modl_amd._lib import lib, check, DEBUG_RECSYS_FUSED
 for nnz in (10_000_000, 3_000_000, 1_000_000):
     X = ml10m_like(nnz=nnz)
     Xs = X[:20000]
-    for v in (1, 3, 5, 0, 1, 3, 5):
+    for v in (1, 2, 3, 4, 0, 1, 2, 3, 4):
         check(lib.modl_debug_set(DEBUG_RECSYS_FUSED, v))
         est = RecsysDictFact(n_components=50, alpha=1, beta=.1, batch_size=10, detrend=True, learning_rate=.95, n_epochs=1, random_state=0)
         t0 = time.perf_counter(); est.fit(Xs); torch.cuda.synchronize(); dt = time.perf_counter() - t0
