@@ -178,7 +178,12 @@ def main():
     ap.add_argument('--c3-records', type=int, default=40)
     ap.add_argument('--c4-batches', type=int, default=7000)
     ap.add_argument('--c4-nnz', type=int, default=10_000_000)
+    ap.add_argument('--debug-set', action='append', default=[], metavar='WHAT=VALUE', help='modl_debug_set before anything runs (A/B runs)')
     args = ap.parse_args()
+    for item in args.debug_set:
+        from modl_amd._lib import lib, check
+        what, value = item.split('=')
+        check(lib.modl_debug_set(int(what), int(value)), 'modl_debug_set')
     for name in args.only.split(','):
         out = dict(c2=c2, c3=c3, c4=c4, c6=c6)[name](args)
         print(json.dumps(out), flush=True)
