@@ -41,7 +41,6 @@ std::atomic<int> g_bcd_tiny{1};
 // diagnostics (modl_debug_set(MODL_DEBUG_BCD_PERSIST, 0)): one launch per block of 32 atoms (bcd_block_kernel) instead of the
 // persistent launch of bcd_persist.hip
 std::atomic<int> g_bcd_persist{1};
-std::atomic<int> g_atom_group16{1};     // modl_debug_set(MODL_DEBUG_ATOM_GROUP16, ...): f32 l1 / elastic-net atoms in groups of 16 (0: of 8)
 
 struct DuLayout {
     size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, off_BsP, off_gpartial, off_norm_in, off_pacc, off_prec, off_Sbuf, off_pflags, off_qcoef, off_pstamps, total;
@@ -57,7 +56,7 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     L.nslab_max = cdiv(s_max > 0 ? s_max : 1, 32);      // the fused block kernel uses slabs of 32 or 64 rows
-    L.nwg_grad = 8192;                                               // (groups of 16 atoms x up to 512 gradient workgroups)
+    L.nwg_grad = 4096;
     const size_t k4 = (size_t)cdiv(k, 4) * 4;                         // the fused path pads the atoms to a multiple of 4
     L.off_CP = take(tsz * (size_t)(cdiv(k, 32) * 32) * k4);           // (fused path: fragment order, whole tiles of 32 columns)
     L.off_cdiag = take(tsz * k4);
@@ -1772,7 +1771,7 @@ void atom_project_group_kernel(const T *C, int64_t s, int k, AtomGroupN<G> g, T 
                 pv[h][u] = partial_old[(int64_t)ac * nparts + (i < nparts ? i : nparts - 1)];
             }
         }
-        const int t = threadIdx.x;                                        // (G * G <= 256: one element per thread)
+        const int t = threadIdx.x;                                        // (G * G <= 64 < 256: one element per thread)
         const int b = (t / G) % G, a = t % G;
         const int jb = g.j[b < g.n ? b : 0], jaa = g.j[a < g.n ? a : 0];   // (from the kernel arguments)
         const double cba = (double)C[(int64_t)jb * k + jaa], caa = (double)C[(int64_t)jaa * k + jaa];
@@ -1794,12 +1793,7 @@ void atom_project_group_kernel(const T *C, int64_t s, int k, AtomGroupN<G> g, T 
     __syncthreads();
     if (dbg && threadIdx.x == 0) { dbg[0] += 1; dbg[3] += clock64() - t0; }
     int par = 0;
-    // what the atoms of the group changed.  Groups of 16 (f32 problems, round 6: five launch pairs instead of nine for the 70
-    // maps of the fMRI shape) keep it in single precision - a difference of two f32 values rounded to f32, 6e-8 of a change that
-    // is itself multiplied by a coefficient of C: far below the candidate's own rounding to f32; f64 problems keep groups of 8
-    // and doubles
-    typedef typename std::conditional<(G > 8), float, double>::type DL;
-    DL dl[G > 1 ? G - 1 : 1][EPT];
+    double dl[G > 1 ? G - 1 : 1][EPT];                                  // what the atoms of the group changed
     auto step = [&](auto A_) {
         constexpr int a = decltype(A_)::value;
         if (a >= g.n) return;                                            // workgroup-uniform
@@ -1812,7 +1806,7 @@ void atom_project_group_kernel(const T *C, int64_t s, int k, AtomGroupN<G> g, T 
         for (int b = 0; b < a; ++b) {
             const double c = s_coef[b][a];
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) x[e] -= c * (double)dl[b][e];
+            for (int e = 0; e < EPT; ++e) x[e] -= c * dl[b][e];
         }
         const int j = g.j[a];
         const double radius = (double)(T)(s_cn[a] + s_old[a]);          // comp_norm_[k] += subset_norm (:676-678)
@@ -1831,7 +1825,7 @@ void atom_project_group_kernel(const T *C, int64_t s, int k, AtomGroupN<G> g, T 
                                                               level_hint ? level_hint + j : nullptr, dbg ? dbg + 32 : nullptr);
         if (a + 1 < G) {
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) dl[a < G - 1 ? a : 0][e] = (DL)((atom_elem(e) < s) ? x[e] - (double)dd[e] : 0.0);
+            for (int e = 0; e < EPT; ++e) dl[a < G - 1 ? a : 0][e] = (atom_elem(e) < s) ? x[e] - (double)dd[e] : 0.0;
         }
         if (dbg && threadIdx.x == 0) {
             const unsigned long long tc = clock64();
@@ -2316,8 +2310,7 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
     // groups of atoms per launch pair while the vector fits the registers of the projecting workgroup
     if (s <= (int64_t)kProjEpt * 256 && k <= 512) {
         const bool l1 = a.comp_l1_ratio == 1.0;
-        const int G = (s <= 20 * 256) ? ((std::is_same<T, float>::value && g_atom_group16.load(std::memory_order_relaxed)) ? 16 : 8)
-                                      : 4;                               // (24 elements per thread: the changes of 3 atoms fit, not of 7)
+        const int G = (s <= 20 * 256) ? 8 : 4;                           // (24 elements per thread: the changes of 3 atoms fit, not of 7)
         nwg = (int)cdiv(s, 4 * kGradRows);                               // kGradRows rows per wavefront (<= 512: s <= 24 * 256)
         const int64_t ldr = atom_row_stride(s);       // rows of the group's scratch: whole passes of the projecting workgroup
         char *gb = ws + L.off_Dnew;
@@ -2351,7 +2344,7 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
 #define MODL_PROJ(EPT, L1)                                                                                                    \
     hipLaunchKernelGGL((atom_project_group_kernel<T, EPT, GG, L1>), dim3(1), dim3(256), 0, stream, a.C, s, k, g, stage[gi & 1],   \
                        a.comp_pos, a.comp_l1_ratio, num, dold, pold, nwg, a.comp_norm, a.level_hint, dbg)
-                if constexpr (GG >= 8) {
+                if constexpr (GG == 8) {
                     if (s <= 12 * 256) { if (l1) MODL_PROJ(12, true); else MODL_PROJ(12, false); }
                     else { if (l1) MODL_PROJ(20, true); else MODL_PROJ(20, false); }
                 } else {
@@ -2368,9 +2361,6 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
             if (launches) *launches += 1;
             return MODL_OK;
         };
-        if constexpr (std::is_same<T, float>::value) {
-            if (G == 16) return run(std::integral_constant<int, 16>{});
-        }
         return G == 8 ? run(std::integral_constant<int, 8>{}) : run(std::integral_constant<int, 4>{});
     }
     // beyond the register-resident projection (24 elements per thread): groups of atoms, compact rows (atom_grad4_kernel)

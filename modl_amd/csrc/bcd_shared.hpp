@@ -38,7 +38,7 @@ constexpr int kGramRows = 128;     // feature rows per Gram slab
 #endif
 constexpr int kGroup = MODL_KGROUP;         // minimum workgroups per group of the two-level partial reduction
 constexpr int kCounters = 64;      // arrival counters: [0] final, [1 + g] group g
-constexpr int kAtomGroupMax = 16;  // atoms per launch pair of the grouped atom update (l1 / elastic-net atoms): 8 (f64), 16 (f32, round 6)
+constexpr int kAtomGroupMax = 8;   // atoms per launch pair of the grouped atom update (l1 / elastic-net atoms)
 
 __device__ __forceinline__ int64_t sub_row(const int32_t *subset, int64_t f) { return subset ? (int64_t)subset[f] : f; }
 // Element (sampled feature f, sweep position c) of the PACKED dictionary of the fused block kernel, stored in the order
