@@ -22,6 +22,7 @@ DEBUG_STAGE_AHEAD = 8
 DEBUG_BCD_PERSIST = 9
 DEBUG_STATS_RESIDENT = 10
 DEBUG_RECSYS_FUSED = 11
+DEBUG_ATOM_MWG = 12
 AGG = {'masked': 0, 'full': 1, 'average': 2}
 OPT = {'variational': 0, 'sgd': 1}
 

@@ -1376,18 +1376,210 @@ __global__ __launch_bounds__(256) void atom_grad4_kernel(T *Dt, const T *Bt, con
 // (256 threads: the projection is 22 of the 24 us of such a launch, scans of the 10 000-element vector and block-wide
 // sums - and with 1024 threads, sixteen wavefronts, it took 29: the sums and their barriers grow faster than the scans
 // shrink.)
+// ---- the l1 projection of a vector SPREAD OVER THE LAUNCH'S WORKGROUPS (round 6; the reference's HCP configuration: 10 000 sampled
+// features, 1024 positive l1 atoms, one launch per atom).  The launch's last workgroup used to project the whole vector alone from
+// LDS - 22 of the launch's 24 us, 40 elements per thread and Michelot pass.  Here every thread keeps ITS element in a register and a
+// pass is: the workgroup's two sums (wave sums, LDS), written through to a slot of this pass, one lane per workgroup polls the
+// slots (sentinels: the data is its own flag, bcd_persist.hip), wave sum, broadcast - one memory round trip per pass instead of a
+// scan of the vector.  Same iteration as block_l1_project_inplace (warm start at 0.9 x the atom's last level, verified; Michelot's
+// update; the closed form of enet.pyx:119), the sums in a fixed order: run-to-run identical.
+// Every wait is bounded; a wait that gives up (a workgroup of the launch that is not resident: another process on the GPU) raises
+// the launch's abort word and the launch ends as it always has - every workgroup has left its candidates in `u`, the last one to
+// arrive projects them alone: nothing has been written that this would not overwrite (the budget and the level hint are written
+// by workgroup 0 only once EVERY workgroup has delivered its last sum).
+constexpr int kMwgMaxWg = 64, kMwgMaxPass = 23;
+constexpr int kMwgWords = (kMwgMaxPass + 1) * 2 * kMwgMaxWg;          // doubles of one exchange buffer (two in rotation)
+constexpr unsigned int kMwgSentinel32 = 0x7ff8deadu;                  // both halves of the sentinel (a NaN): hipMemsetD32Async fills it
+constexpr long long kMwgSentinel = ((long long)kMwgSentinel32 << 32) | kMwgSentinel32;
+std::atomic<int> g_atom_mwg{1};                                       // modl_debug_set(MODL_DEBUG_ATOM_MWG, ...)
+
+__device__ __forceinline__ void mwg_store(double *ptr, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(ptr), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double mwg_load(const double *ptr) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(ptr), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+// the launch-wide sums of (S, cnt); false: a wait gave up.  red: >= 24 doubles of LDS.  Called by every thread (256).
+__device__ __forceinline__ bool mwg_sum2(double &S, double &cnt, double *xb, int slot, unsigned int *abort_word, double *red,
+                                         bool withhold = false) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nwg = (int)gridDim.x, wg = (int)blockIdx.x;
+    S = wave_sum(S);
+    cnt = wave_sum(cnt);
+    if (lane == 0) { red[2 * wid] = S; red[2 * wid + 1] = cnt; }
+    __syncthreads();
+    if (wid == 0) {
+        double *sl = xb + (size_t)slot * 2 * kMwgMaxWg;
+        if (lane == 0 && !withhold) {                            // (withhold: diagnostics build - the workgroup that never delivers)
+            mwg_store(sl + 2 * wg, (red[0] + red[2]) + (red[4] + red[6]));
+            mwg_store(sl + 2 * wg + 1, (red[1] + red[3]) + (red[5] + red[7]));
+        }
+        double gs = 0.0, gc = 0.0;
+        bool ok = true;
+        if (lane < nwg) {
+            for (unsigned spins = 0;; ++spins) {
+                gs = mwg_load(sl + 2 * lane);
+                gc = mwg_load(sl + 2 * lane + 1);
+                if (__double_as_longlong(gs) != kMwgSentinel && __double_as_longlong(gc) != kMwgSentinel) break;
+                if (spins > (1u << 17) || ((spins & 63) == 63 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        const bool all_ok = __all(ok);
+        gs = wave_sum((lane < nwg && all_ok) ? gs : 0.0);
+        gc = wave_sum((lane < nwg && all_ok) ? gc : 0.0);
+        if (lane == 0) {
+            if (!all_ok) __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            red[16] = gs; red[17] = gc; red[18] = all_ok ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+    S = red[16];
+    cnt = red[17];
+    const bool ok = red[18] != 0.0;
+    __syncthreads();
+    return ok;
+}
+// x: this thread's element (0 beyond the vector).  On success: out = the projected element, nrm = the l1 norm of the projected
+// vector (every workgroup has it), level_out / searched = the level the search ended at.
+template <typename T>
+__device__ __forceinline__ bool mwg_l1_project(T x, double radius, double l_prev, double *xb, unsigned int *abort_word, double *red,
+                                               T &out, double &nrm, double &level_out, bool &searched, bool withhold) {
+    searched = false;
+    level_out = 0.0;
+    if (!(radius > 0.0)) {                                   // enet.pyx:57-59 (radius == 0 -> zeros); the same on every workgroup
+        out = 0;
+        nrm = 0.0;
+        return true;
+    }
+    const double R = radius, a = fabs((double)x);
+    int slot = 0;
+    double S, cnt, level = 0.0, prev_cnt = -1.0;
+    bool warm = false, inside = false;
+    auto scan = [&](double lv) {
+        S = a > lv ? a : 0.0;
+        cnt = a > lv ? 1.0 : 0.0;
+        return mwg_sum2(S, cnt, xb, slot++, abort_word, red, withhold);
+    };
+    const double l0 = 0.9 * l_prev;
+    if (l0 > 0.0 && l0 < 1e300) {
+        if (!scan(l0)) return false;
+        if (S - cnt * l0 >= R * (1.0 + 1e-9) && cnt != 0.0) { warm = true; prev_cnt = cnt; level = (S - R) / cnt; }
+    }
+    if (!warm) {
+        if (!scan(0.0)) return false;
+        if (S <= R) inside = true;                           // inside the ball: nothing moves
+        else if (cnt != 0.0) { prev_cnt = cnt; level = (S - R) / cnt; }
+    }
+    double total = S;
+    if (!inside) {
+        searched = true;
+        for (;;) {
+            if (cnt == 0.0) break;
+            if (slot >= kMwgMaxPass) return false;           // (never seen: the old path takes any number of passes)
+            if (!scan(level)) return false;
+            if (cnt == prev_cnt || cnt == 0.0) break;
+            prev_cnt = cnt;
+            level = (S - R) / cnt;                           // enet.pyx:119
+        }
+        const double lT = (double)(T)level;
+        double pos = a - lT;
+        pos = pos > 0 ? pos : 0;
+        out = (T)(((double)x >= 0) ? pos : -pos);            // enet.pyx:121, sign(0) = +1
+        double mine = fabs((double)out), dummy = 0.0;
+        if (!mwg_sum2(mine, dummy, xb, kMwgMaxPass, abort_word, red)) return false;
+        total = mine;
+    } else {
+        out = x;
+        double mine = 0.0, dummy = 0.0;                      // (the last slot is the "everybody is done" exchange in every case)
+        if (!mwg_sum2(mine, dummy, xb, kMwgMaxPass, abort_word, red)) return false;
+    }
+    nrm = total;
+    level_out = level;
+    return true;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *C, const int32_t *subset, int64_t s, int k,
                                                                 AtomGroupN<kStepGroup> g, int a, int pos, double rho, T *u,
                                                                 const double *num, const T *dold, T *stage_cur, int64_t ldr,
                                                                 const double *partial_old, int part_stride, T *comp_norm,
-                                                                unsigned int *counter, unsigned long long *dbg, double *level_hint) {
+                                                                unsigned int *counter, unsigned long long *dbg, double *level_hint,
+                                                                double *xch, unsigned int *xabort, int parity) {
     constexpr int G = kStepGroup;
     extern __shared__ __attribute__((aligned(16))) char step_smem[];   // the s-vector for the projection
     __shared__ double red[32];
     __shared__ int flag;
     const unsigned long long t0 = clock64();
     const int j = g.j[a];
+    if (xch) {
+        // ---- the projection spread over the launch's workgroups (a thread per feature: gridDim.x * 256 >= s, at most 64 workgroups)
+        double *xb = xch + (size_t)(parity & 1) * kMwgWords;
+        {   // the buffer of the NEXT launch back to sentinels (its last user was the launch before this one)
+            long long *xo = reinterpret_cast<long long *>(xch + (size_t)((parity & 1) ^ 1) * kMwgWords);
+            const int per = (kMwgWords + (int)gridDim.x - 1) / (int)gridDim.x;
+            for (int e = (int)blockIdx.x * per + threadIdx.x; e < ((int)blockIdx.x + 1) * per && e < kMwgWords; e += 256) xo[e] = kMwgSentinel;
+        }
+        const double cjj = (double)C[(int64_t)j * k + j];
+        const bool frozen = !((T)cjj > (T)1e-20);
+        double cb[G];
+#pragma unroll
+        for (int b = 0; b < G; ++b) cb[b] = (b < a) ? (double)C[(int64_t)g.j[b] * k + j] : 0.0;
+        const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        const int64_t fc = f < s ? f : s - 1;
+        double x = num[(int64_t)a * ldr + fc];
+        const T dj = dold[(int64_t)a * ldr + fc];
+        T sn[G], so[G];
+#pragma unroll
+        for (int b = 0; b < G; ++b) {
+            const int bc = b < a ? b : 0;
+            sn[b] = stage_cur[(int64_t)bc * ldr + fc];
+            so[b] = dold[(int64_t)bc * ldr + fc];
+        }
+        // radius = the budget + the atom's old norm on the sampled features: the partial sums of the group's gradient launch,
+        // summed by every workgroup in the same order (block_sum2: fixed association)
+        double old = 0, dummy = 0;
+        for (int i = threadIdx.x; i < part_stride; i += 256) old += partial_old[(int64_t)a * part_stride + i];
+        const double cn = (double)comp_norm[j], lprev = level_hint ? level_hint[j] : 0.0;
+#pragma unroll
+        for (int b = 0; b < G; ++b)
+            if (b < a) x -= cb[b] * ((double)sn[b] - (double)so[b]);
+        T val = dj;
+        if (!frozen) val = (T)(x / cjj);
+        if (pos && val < (T)0) val = 0;                              // dict_fact.py:684-685
+        if (f >= s) val = 0;
+        if (f < s) u[f] = val;                                       // (what the last workgroup projects if this attempt gives up)
+        block_sum2(old, dummy, red, 256);
+        const double radius = (double)(T)(cn + old);                 // comp_norm_[k] += subset_norm (:676-678)
+        T outv;
+        double nrm, level;
+        bool searched;
+#ifdef MODL_DIAG
+        const bool withhold = (parity & 2) && blockIdx.x == 1;       // (MODL_DEBUG_ATOM_MWG = 2: the fallback path, tests)
+#else
+        const bool withhold = false;
+#endif
+        const bool ok = mwg_l1_project<T>(val, radius, lprev, xb, xabort, red, outv, nrm, level, searched, withhold);
+        if (ok) {
+            if (f < s) stage_cur[(int64_t)a * ldr + f] = outv;
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                comp_norm[j] = (T)(radius - nrm);                    // :690-692
+                if (level_hint && searched) level_hint[j] = level;
+            }
+        }
+        // every workgroup arrives; the last one looks at the abort word and, if it is raised, projects everything the old way
+        if (!arrive_last(counter, gridDim.x, &flag)) return;
+        if (__hip_atomic_load(xabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+        if (threadIdx.x == 0) __hip_atomic_store(xabort, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atom_project<T, false>(u, reinterpret_cast<T *>(step_smem), partial_old + (int64_t)a * part_stride, part_stride, Dt, subset, s, k, j,
+                               rho, comp_norm, red, dbg, level_hint, stage_cur + (int64_t)a * ldr);
+        return;
+    }
     // the numerators of the group's launch, minus what the atoms before this one changed
     const double cjj = (double)C[(int64_t)j * k + j];
     const bool frozen = !((T)cjj > (T)1e-20);
@@ -2377,6 +2569,17 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
         if (align_up(sizeof(T) * (size_t)3 * G * ldr, 16) + sizeof(double) * (size_t)G * ldr > sizeof(T) * (size_t)s * kNB) return MODL_ENOMEM;
         if ((int64_t)G * nwg > L.nwg_grad) return MODL_ENOMEM;
         const int nwg_corr = (int)cdiv(s, 256);                           // a thread per feature
+        // l1 atoms on at most 64 workgroups: the projection spread over the launch (mwg_l1_project); its two exchange buffers
+        // (sentinels) and the abort word live in the blocked path's record space, unused here
+        const bool mwg = a.comp_l1_ratio == 1.0 && nwg_corr <= kMwgMaxWg && g_atom_mwg.load(std::memory_order_relaxed) &&
+                         sizeof(double) * 2 * (size_t)L.nslab_max * (kNB * kNB + kNB) >= sizeof(double) * 2 * kMwgWords + 64;
+        double *xch = reinterpret_cast<double *>(ws + L.off_partial);
+        unsigned int *xabort = reinterpret_cast<unsigned int *>(xch + 2 * kMwgWords);
+        unsigned long launch_no = 0;
+        if (mwg) {
+            MODL_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(xch), (int)kMwgSentinel32, 2 * (size_t)kMwgWords * 2, stream));
+            MODL_HIP(hipMemsetAsync(xabort, 0, sizeof(unsigned int), stream));
+        }
         AtomGroupN<G> g, gp;
         gp.n = 0;
         for (int b = 0; b < G; ++b) gp.j[b] = 0;
@@ -2401,7 +2604,9 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
                 hipLaunchKernelGGL((atom_corr_project_kernel<T>), dim3(nwg_corr), dim3(256), u_lds, stream, a.Dt, a.C, a.subset, s, k,
                                    g, ai, a.comp_pos, a.comp_l1_ratio, u, (const double *)num, (const T *)dold, stage[gi & 1], ldr,
                                    (const double *)pold, nwg, a.comp_norm, counter,
-                                   reinterpret_cast<unsigned long long *>(counter + kCounters), a.level_hint);
+                                   reinterpret_cast<unsigned long long *>(counter + kCounters), a.level_hint,
+                                   mwg ? xch : nullptr, xabort,
+                                   (int)(launch_no++ & 1) | (g_atom_mwg.load(std::memory_order_relaxed) == 2 ? 2 : 0));
                 MODL_LAUNCH_CHECK();
             }
             gp = g;
