@@ -1381,8 +1381,13 @@ __global__ __launch_bounds__(256) void atom_grad4_kernel(T *Dt, const T *Bt, con
 // LDS - 22 of the launch's 24 us, 40 elements per thread and Michelot pass.  Here every thread keeps ITS element in a register and a
 // pass is: the workgroup's two sums (wave sums, LDS), written through to a slot of this pass, one lane per workgroup polls the
 // slots (sentinels: the data is its own flag, bcd_persist.hip), wave sum, broadcast - one memory round trip per pass instead of a
-// scan of the vector.  Same iteration as block_l1_project_inplace (warm start at 0.9 x the atom's last level, verified; Michelot's
-// update; the closed form of enet.pyx:119), the sums in a fixed order: run-to-run identical.
+// scan of the vector.  Michelot's iteration with the closed form of enet.pyx:119, warm-started at the atom's last level (the
+// register-resident projection's rule, enet_project_slim), the sums in a fixed order: run-to-run identical.
+// MEASURED at the HCP shape (39 workgroups, scripts/diag_atom_stamps_c6.py): an exchange costs 5.5 k cycles (2.3 us: a write-through
+// store, its way to memory, a polled load); a two-minibatch-old dictionary needs ten of them per atom, the launch 21.5 us against
+// 24.3 with the last workgroup's projection (minibatch 35.7 -> 33.9 ms).  Not kept: EIGHT levels per exchange (every Newton step
+// is a lower bound, every level with f <= 0 an upper one; the next exchange brackets between them) - five exchanges instead of
+// ten, but 11.7 k cycles each (sixteen wave sums on either side of the round trip, sixteen polled words per lane): 39.3 ms.
 // Every wait is bounded; a wait that gives up (a workgroup of the launch that is not resident: another process on the GPU) raises
 // the launch's abort word and the launch ends as it always has - every workgroup has left its candidates in `u`, the last one to
 // arrive projects them alone: nothing has been written that this would not overwrite (the budget and the level hint are written
@@ -1466,10 +1471,14 @@ __device__ __forceinline__ bool mwg_l1_project(T x, double radius, double l_prev
         cnt = a > lv ? 1.0 : 0.0;
         return mwg_sum2(S, cnt, xb, slot++, abort_word, red, withhold);
     };
-    const double l0 = 0.9 * l_prev;
-    if (l0 > 0.0 && l0 < 1e300) {
-        if (!scan(l0)) return false;
-        if (S - cnt * l0 >= R * (1.0 + 1e-9) && cnt != 0.0) { warm = true; prev_cnt = cnt; level = (S - R) / cnt; }
+    // warm start: the level the atom ended with at the previous minibatch ITSELF - f(l) = sum_{|x| > l} (|x| - l) - R is convex and
+    // decreasing, so the Newton step that Michelot's update is lands at or left of the root from EITHER side and the iteration
+    // rises monotonically from there (enet_project_slim: no verification pass, no safety factor); a step that lands at or below
+    // zero proves nothing and falls back to the cold start
+    if (l_prev > 0.0 && l_prev < 1e300) {
+        if (!scan(l_prev)) return false;
+        const double l1 = (S - R) / cnt;
+        if (cnt != 0.0 && l1 > 0.0) { warm = true; prev_cnt = cnt; level = l1; }
     }
     if (!warm) {
         if (!scan(0.0)) return false;
@@ -1501,6 +1510,7 @@ __device__ __forceinline__ bool mwg_l1_project(T x, double radius, double l_prev
     }
     nrm = total;
     level_out = level;
+    if (threadIdx.x == 0) red[19] = (double)slot;            // (diagnostics: exchanges of the search)
     return true;
 }
 
@@ -1564,7 +1574,9 @@ __global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *
 #else
         const bool withhold = false;
 #endif
+        const unsigned long long t1 = clock64();
         const bool ok = mwg_l1_project<T>(val, radius, lprev, xb, xabort, red, outv, nrm, level, searched, withhold);
+        const unsigned long long t2 = clock64();
         if (ok) {
             if (f < s) stage_cur[(int64_t)a * ldr + f] = outv;
             if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1572,6 +1584,7 @@ __global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *
                 if (level_hint && searched) level_hint[j] = level;
             }
         }
+        if (dbg && blockIdx.x == 0 && threadIdx.x == 0) { dbg[8] = t0; dbg[9] = t1; dbg[10] = t2; dbg[11] = clock64(); dbg[12] = (unsigned long long)red[19]; }
         // every workgroup arrives; the last one looks at the abort word and, if it is raised, projects everything the old way
         if (!arrive_last(counter, gridDim.x, &flag)) return;
         if (__hip_atomic_load(xabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;

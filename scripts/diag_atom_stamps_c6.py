@@ -20,3 +20,5 @@ check(lib.modl_somf_debug_stamps(est._backend.plan, out))
 o = [int(v) for v in out[:8]]
 print('last workgroup of the last atom launch: gradient rows + partial norms %d  arrival %d  projection + write-back %d cycles' % (o[1]-o[0], o[2]-o[1], o[3]-o[2]))
 print('   projection: radius known +%d, %d Michelot passes until +%d, projected vector in LDS +%d, written back +%d' % (o[7]-o[2], o[4] & 0xffff, o[6]-o[2], o[5]-o[2], o[3]-o[2]))
+o = [int(v) for v in out[8:13]]
+print('spread projection (workgroup 0 of the last atom launch): candidates + radius %d cycles, projection %d cycles (%d exchanges of the search + the last one), tail %d' % (o[1]-o[0], o[2]-o[1], o[4], o[3]-o[2]))
