@@ -1,8 +1,8 @@
 #!/bin/bash
 # Regenerates the round's profile artifacts on the GPU box (run through gpurun from the repo root):
-#   bash scripts/make_profiles.sh r05
+#   bash scripts/make_profiles.sh r06
 # writes gpurun_out/<tag>_*; copy what is to be judged into profiles/.
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 mkdir -p $OUT /tmp/w
@@ -81,4 +81,21 @@ rm -rf /tmp/w/sq1; timeout 600 rocprofv3 --kernel-trace --pmc $SQC -d /tmp/w/sq1
 { echo "rocprofv3 --kernel-trace --pmc $SQC -- python3 bench.py --reduction 1 --steps 100 --warmup 40 ..."; echo "(SQ_* cycle counters are in quad-cycles; use the RATIOS)"; echo; python3 $R/scripts/pmc_summary.py $(find /tmp/w/sq1 -name '*.db' | head -1); } > $OUT/${TAG}_pmc_sq_counters_r1.txt 2>&1
 rm -rf /tmp/w/sq5; timeout 600 rocprofv3 --kernel-trace --pmc $SQC -d /tmp/w/sq5 -o t -- python3 $R/bench.py --features 200000 --reduction 12 --steps 40 --warmup 20 --no-cpu-baseline --no-breakdown > /tmp/w/sq5.log 2>&1
 { echo "rocprofv3 --kernel-trace --pmc $SQC -- python3 bench.py --features 200000 --reduction 12 --steps 40 --warmup 20 ..."; echo "(SQ_* cycle counters are in quad-cycles; use the RATIOS)"; echo; python3 $R/scripts/pmc_summary.py $(find /tmp/w/sq5 -name '*.db' | head -1); } > $OUT/${TAG}_pmc_sq_counters_c5.txt 2>&1
+ls -la $OUT | grep $TAG
+# round 6: the masked minibatch (C4) - kernel trace, the in-kernel stamps of the one-launch variants, the A/B of the policies
+rm -rf /tmp/w/c4; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/w/c4 -o t -- python3 $R/scripts/bench_configs.py --only c4 --c4-batches 2000 > /tmp/w/c4.log 2>&1
+{ tail -2 /tmp/w/c4.log; python3 $R/scripts/prof_summary.py $(find /tmp/w/c4 -name "*.db" | head -1) 0.0; } > $OUT/${TAG}_cfg_c4_kernel_trace.txt 2>&1
+{ for v in 2 4; do timeout 300 python3 $R/scripts/diag_recsys_stamps.py $v; done; } > $OUT/${TAG}_recsys_fused_stamps.txt 2>&1
+timeout 600 bash $R/scripts/ab_recsys_fused.sh 2>&1 | grep fused= > $OUT/${TAG}_ab_recsys_fused.txt
+# the spread l1 projection at the HCP shape: stamps, and the A/B against the last workgroup's projection
+timeout 300 python3 $R/scripts/diag_atom_stamps_c6.py > $OUT/${TAG}_atom_mwg_c6_stamps.txt 2>&1
+{ for v in 1 0 1 0; do timeout 300 python3 $R/scripts/bench_configs.py --only c6 --debug-set 12=$v 2>/dev/null; done; } > $OUT/${TAG}_ab_atom_mwg_c6.jsonl
+# the sweep-flip census at 204 800 samples of both reductions (bench.py: flip_rate_block; ~15 min of CPU oracle)
+python3 - > $OUT/${TAG}_flip_census.json 2> $OUT/${TAG}_flip_census.err <<PY
+import sys, json
+sys.path.insert(0, "$R")
+import torch, bench
+out = [bench.flip_rate_block(r, 800, torch.device("cuda", 0), log=lambda m: sys.stderr.write(m + "\n")) for r in (10.0, 1.0)]
+print(json.dumps(out))
+PY
 ls -la $OUT | grep $TAG
