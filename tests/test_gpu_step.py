@@ -377,6 +377,9 @@ def test_gram_accumulator_out_of_range_falls_back_to_records(DictFact, scale, p,
         if scale > 1:
             assert np.all(np.abs(np.sqrt(np.sum(D1.astype(np.float64) ** 2, axis=1)) - 1) < 1e-4)   # projected onto the ball
         assert rel_fro(D1, D0) < tol, (acc, rel_fro(D1, D0))
+        import sys
+        sys.stderr.write('\n[accumulator vs records] scale %g: %s %.2e (gate %.0e)\n'
+                         % (scale, 'block launches' if acc == 1 else 'persistent launch', rel_fro(D1, D0), tol))
 
 
 @pytest.mark.parametrize('k,p,b,red', [(320, 1200, 64, 2), (512, 700, 48, 1), (40, 333, 32, 3), (250, 1200, 64, 2), (70, 2001, 96, 3)])
