@@ -84,6 +84,7 @@ const char *modl_error_string(int code);
 #define MODL_DEBUG_STATS_RESIDENT 10  /* 1 (default): the f32 statistics product X^T code over at least 4096 features and at most 256 atoms runs on persistent workgroups that keep the code matrix in registers (csrc/gemm_resident.hpp, tiles of 16 features); 0: the 32 x 32 tiles or the k-wide tiles of rounds 2-4 */
 #define MODL_DEBUG_RECSYS_FUSED 11    /* 1 (default): a masked minibatch of RecsysDictFact with at most 64 (f64: 56) atoms and 64 rows runs its codes (rating chunks of 128, ticketed fixed-order sums, Cholesky) and C_ as ONE launch (csrc/recsys.hip: recsys_fused_kernel), B_ and the blocked dictionary update as launches of their own behind it; 2: B_ and the dictionary sweep inside that launch when one workgroup holds every touched item (512 in registers + what fits LDS), 3: the same without the LDS tier, 4: the sweep also on up to four workgroups that exchange an atom's sums through memory (all three measured slower, kept selectable and tested); 0: the separate launches of rounds 2-5 for everything */
 #define MODL_DEBUG_ATOM_MWG 12        /* 1 (default): the l1 projection of an atom with more than 6144 and at most 16 384 sampled features (one launch per atom: the reference's HCP configuration) is spread over the launch's workgroups - an element per thread, a memory round trip per Michelot pass (csrc/bcd.hip: mwg_l1_project); 0: the launch's last workgroup projects the whole vector from LDS; diagnostics library: 2 = as 1 with a workgroup that withholds its sums (the attempt gives up and the last workgroup projects: the fallback path) */
+#define MODL_DEBUG_BCD_FEW 13         /* 1 (default): the f64 blocked dictionary update of 193 to 2048 sampled features runs as ONE launch on up to sixteen workgroups of 128 features that exchange a block's Gram record through memory (csrc/bcd.hip: bcd_few_kernel); 0: four launches per block of 32 atoms */
 int modl_debug_set(int what, int64_t value);
 /* 1 in libmodl_hip_diag.so (built with -DMODL_DIAG: the same sources plus the A/B-only kernel variants and the stamp
  * switches), 0 in the product library */
@@ -262,6 +263,10 @@ int modl_recsys_fit_batches_f64(modl_recsys_plan *plan, const int32_t *h_indptr,
                                 const int64_t *h_rows, int64_t n_rows_fit, int64_t batch_size, modl_rk *order_rng, double alpha,
                                 double learning_rate, int64_t *n_iter, double *d_Dt, double *d_Bt, double *d_C, double *d_code,
                                 double *d_comp_norm, int64_t *d_feature_n_iter, void *stream, int64_t *n_done);
+/* Synchronises `stream`; MODL_ETIMEOUT if a dictionary-update launch of this plan gave up in a cross-workgroup wait since the last
+ * call (csrc/bcd.hip: bcd_few_kernel on up to sixteen workgroups; the update is incomplete, the flag is cleared), MODL_OK otherwise.
+ * While the flag is up every further minibatch of the plan is refused with MODL_ETIMEOUT. */
+int modl_recsys_plan_status(modl_recsys_plan *plan, void *stream);
 /* diagnostics: minibatches of this plan that ran as ONE launch (csrc/recsys.hip: recsys_fused_kernel: at most 64 atoms, 64 rows
  * and 8192 ratings per minibatch) / as the separate launches */
 int modl_recsys_plan_counts(const modl_recsys_plan *plan, int64_t *fused, int64_t *split);

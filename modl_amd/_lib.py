@@ -23,6 +23,7 @@ DEBUG_BCD_PERSIST = 9
 DEBUG_STATS_RESIDENT = 10
 DEBUG_RECSYS_FUSED = 11
 DEBUG_ATOM_MWG = 12
+DEBUG_BCD_FEW = 13
 AGG = {'masked': 0, 'full': 1, 'average': 2}
 OPT = {'variational': 0, 'sgd': 1}
 
@@ -154,6 +155,7 @@ def bind(lib):
     _sig('modl_recsys_plan_destroy', None, _vp)
     _sig('modl_recsys_plan_counts', C.c_int, _vp, _P(_i64), _P(_i64))
     _sig('modl_recsys_plan_wait_ms', C.c_int, _vp, _P(_f64))
+    _sig('modl_recsys_plan_status', C.c_int, _vp, _vp)
     _sig('modl_recsys_plan_stamps', C.c_int, _vp, C.c_int, _vp)
     _sig('modl_predict_csr', C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp)
     _sig('modl_somf_plan_create', C.c_int, _P(SomfDesc), _P(_vp))

@@ -43,12 +43,18 @@ std::atomic<int> g_bcd_tiny{1};
 std::atomic<int> g_bcd_persist{1};
 
 struct DuLayout {
-    size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, off_BsP, off_gpartial, off_norm_in, off_pacc, off_prec, off_Sbuf, off_pflags, off_qcoef, off_pstamps, total;
+    size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, off_BsP, off_gpartial, off_norm_in, off_pacc, off_prec, off_Sbuf, off_pflags, off_qcoef, off_pstamps, off_few, total;
     int64_t nslab_max, nwg_grad;
 };
 
 // row stride of the scratch of the grouped atom update: what the projecting workgroup covers with 12 / 20 / 24 elements
 // per thread (s beyond that: the group path is not taken, the stride is never used)
+constexpr int kFewRows = 128;                        // sampled features per workgroup of bcd_few_kernel
+constexpr int kFewMaxWg = 16;                        // ... and the most workgroups it runs on (2048 features)
+constexpr int kFewRec = kNB * kNB + kNB;             // a Gram record: the 32 x 32 matrix of a block's candidates + their old norms
+constexpr long long kFewSentinel = 0x7ff8feed7ff8feedll;   // what an exchange slot holds until its record arrives (a NaN no sum produces)
+std::atomic<int> g_bcd_few{1};                       // modl_debug_set(MODL_DEBUG_BCD_FEW, ...)
+
 static int64_t atom_row_stride(int64_t s) { return s <= 12 * 256 ? 12 * 256 : (s <= 20 * 256 ? 20 * 256 : 24 * 256); }
 
 static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
@@ -85,6 +91,9 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     L.off_pflags = take(persist ? sizeof(unsigned int) * 64 : 0);      // arrive[16], sflag[16], err
     L.off_qcoef = take(persist ? sizeof(double) * (size_t)kNB * k4 : 0);
     L.off_pstamps = take(persist ? sizeof(unsigned long long) * kPersistStampWords : 0);
+    // the f64 update of a few hundred to two thousand sampled features on several workgroups (bcd_few_kernel): three exchange
+    // slots of kFewMaxWg Gram records + the launch's error word
+    L.off_few = take(tsz == 8 ? sizeof(double) * 3 * (size_t)kFewMaxWg * kFewRec + 64 : 0);
     L.total = o;
     return L;
 }
@@ -106,7 +115,14 @@ size_t dict_update_workspace(int dtype, int64_t s_max, int k) {
 template <typename T>
 __global__ __launch_bounds__(256) void bcd_prepare_kernel(const T *C, const int32_t *order, int k, T *CP, T *cdiag,
                                                           int32_t *frozen, double *coef_all, unsigned int *counter,
-                                                          const T *comp_norm, T *norm_in) {
+                                                          const T *comp_norm, T *norm_in, long long *few = nullptr,
+                                                          long long few_words = 0) {
+    if (few) {                                       // bcd_few_kernel's exchange slots: sentinels (a slice per workgroup); its error word
+        const long long sl = (few_words + gridDim.x - 1) / gridDim.x;
+        const long long e1 = ((long long)(blockIdx.x + 1) * sl < few_words) ? (long long)(blockIdx.x + 1) * sl : few_words;
+        for (long long e = (long long)blockIdx.x * sl + threadIdx.x; e < e1; e += 256) few[e] = kFewSentinel;
+        if (blockIdx.x == 0 && threadIdx.x == 0) few[few_words] = 0;
+    }
     if (blockIdx.x == 0 && threadIdx.x < kCounters) counter[threadIdx.x] = 0;   // arrival tickets of the fused block kernel
     if (blockIdx.x == 0)                             // the budgets as they are before this update (fused path)
         for (int j = threadIdx.x; j < k; j += 256) norm_in[j] = comp_norm[j];
@@ -507,6 +523,181 @@ __global__ __launch_bounds__(256) void bcd_tiny_kernel(T *Dt, const T *Bt, const
 #pragma unroll
                 for (int m = 0; m < kNB; ++m) ar[m] = As[f * (kNB + 1) + m];
                 apply_row<T, 4>(ar, CAs, Dt + sub_row(subset, f) * k, order, j0, nb, tid % 4);
+            }
+        }
+        __syncthreads();                                   // (the rows are written: the next block reads them)
+    }
+}
+// ---- the same sweep on A FEW workgroups (round 6): 193 to 2048 sampled features, f64 - the masked minibatch of RecsysDictFact
+// touches about a thousand items, and as separate launches (candidates, Gram matrix, recursion, apply: four launches of 7-19 us of
+// latency per block of 32 atoms) its dictionary update was 125 of the minibatch's 197 us.  Every workgroup keeps kFewRows features:
+// the candidates, their Gram contribution and the apply are the one-workgroup kernel's, on its own rows - the rows of different
+// workgroups never meet - and the ONE thing the workgroups share per block is the 32 x 32 Gram matrix (+ 32 old norms): each writes
+// its record through to a slot, every thread sums its entries over the workgroups in workgroup order (run-to-run identical; the
+// slots hold a sentinel until the record arrives: the data is its own flag), and every workgroup runs the recursion for itself.
+// One memory round trip per block.  Three slots in rotation (a workgroup restores its own record of the block BEFORE the one it has
+// just summed: every workgroup has delivered this block, so every workgroup is done reading the one before).  The budgets are read
+// from the snapshot the prepare launch took; workgroup 0 writes the new ones.
+// The waits are bounded; with at most sixteen workgroups co-residency is not in question on a part of 256 compute units - a wait
+// that nevertheless gives up raises the launch's error word and the plan's flag (MODL_ETIMEOUT from the next enqueue).
+template <typename T>
+__global__ __launch_bounds__(256) void bcd_few_kernel(T *Dt, const T *Bt, const T *CP, const T *cdiag, const int32_t *frozen,
+                                                      const double *coef_all, const int32_t *subset, const int32_t *order,
+                                                      int s, int k, T *comp_norm, const T *norm_in, double *xch,
+                                                      unsigned int *err, unsigned int *flags) {
+    extern __shared__ __attribute__((aligned(16))) char tiny_smem[];
+    double (*M)[kNB + 1] = reinterpret_cast<double (*)[kNB + 1]>(tiny_smem);             // [NB][NB + 1]
+    double *D2 = reinterpret_cast<double *>(tiny_smem) + kNB * (kNB + 1);                // [NB]
+    double *Cs = D2 + kNB;                                                               // [NB * NB]
+    double *scr = Cs + kNB * kNB;                                                        // [4 NB]
+    double *CAs = scr + 4 * kNB;                                                         // [kResStride]
+    double *d2red = CAs + kResStride;                                                    // [8][NB]
+    T *As = reinterpret_cast<T *>(d2red + 8 * kNB);                                      // [kFewRows][NB + 1]
+    T *sink = As + (size_t)kFewRows * (kNB + 1);                                         // [k] where the other workgroups' budgets go
+    __shared__ int gave_up;
+    const int tid = threadIdx.x;
+    const int W = (int)gridDim.x, w = (int)blockIdx.x;
+    const int r0 = w * kFewRows;
+    const int rows = (s - r0 < kFewRows) ? s - r0 : kFewRows;
+    if (tid == 0) gave_up = 0;
+    int bi = 0;
+    for (int j0 = 0; j0 < k; j0 += kNB, ++bi) {
+        const int nb = (k - j0 < kNB) ? k - j0 : kNB;
+        stage_coef(coef_all, k, j0, Cs);
+        // (1) candidates of this workgroup's rows on the f64 matrix cores (bcd_tiny_kernel)
+        {
+            typedef double d4v __attribute__((ext_vector_type(4)));
+            const int lane = tid & 63, wid = tid >> 6;
+            const int ntile = ((rows + 15) / 16) * 2;
+            for (int t = wid; t < ntile; t += 4) {
+                const int ft = t >> 1, ct = t & 1;
+                const int f = ft * 16 + (lane & 15);
+                const int64_t rowoff = sub_row(subset, r0 + (f < rows ? f : rows - 1)) * k;
+                const int jj = ct * 16 + (lane & 15);
+                const int jc = (jj < nb) ? jj : 0;
+                d4v acc = {0.0, 0.0, 0.0, 0.0};
+                const int64_t ocolv = order[j0 + jc];
+                const T cd = cdiag[j0 + jc];
+                const int fz = frozen[j0 + jc];
+                T eB[4], eD[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int fr = ft * 16 + (lane >> 4) + 4 * r;
+                    const int64_t el = sub_row(subset, r0 + (fr < rows ? fr : rows - 1)) * k + ocolv;
+                    eB[r] = Bt[el];
+                    eD[r] = Dt[el];
+                }
+                constexpr int CH = 16;                                   // products per chunk (64 atoms)
+                for (int m0 = 0; m0 < k; m0 += 4 * CH) {
+                    double av[CH], bv[CH];
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int m = m0 + 4 * c + (lane >> 4);
+                        const int mc = (m < k) ? m : k - 1;
+                        av[c] = (double)Dt[rowoff + mc];
+                        bv[c] = (double)CP[(int64_t)mc * k + j0 + jc];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int m = m0 + 4 * c + (lane >> 4);
+                        const double a = (m < k) ? av[c] : 0.0, b = (m < k) ? bv[c] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int fr = ft * 16 + (lane >> 4) + 4 * r;
+                    const T av2 = fz ? eD[r] : (T)(((double)eB[r] - acc[r]) / (double)cd);
+                    if (fr < rows) As[fr * (kNB + 1) + jj] = (jj < nb) ? av2 : (T)0;
+                }
+            }
+        }
+        __syncthreads();
+        // (2) this workgroup's share of the Gram matrix of the candidates and of the old squared norms
+        {
+            const int i = tid / 8, jb = (tid % 8) * 4;
+            double acc[4] = {0, 0, 0, 0};
+            for (int f = 0; f < rows; ++f) {
+                const double ai = (double)As[f * (kNB + 1) + i];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += ai * (double)As[f * (kNB + 1) + jb + q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) M[i][jb + q] = acc[q];
+            const int col = tid % kNB, rg = tid / kNB;
+            const int ocol = order[j0 + (col < nb ? col : 0)];
+            double d2 = 0;
+            for (int f = rg; f < rows; f += 8) {
+                const double x = (double)Dt[sub_row(subset, r0 + f) * k + ocol];
+                d2 += x * x;
+            }
+            d2red[rg * kNB + col] = (col < nb) ? d2 : 0.0;
+        }
+        __syncthreads();
+        if (tid < kNB) {
+            double t = 0;
+            for (int g = 0; g < 8; ++g) t += d2red[g * kNB + tid];
+            D2[tid] = t;
+        }
+        __syncthreads();
+        if (W > 1) {
+            // (2b) the records meet: every thread its entries e = tid + 256 q of the record
+            double *slot = xch + (size_t)(bi % 3) * W * kFewRec;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the sentinels this workgroup restored two blocks ago have landed)
+            for (int e = tid; e < kFewRec; e += 256) {
+                const double v = (e < kNB * kNB) ? M[e / kNB][e % kNB] : D2[e - kNB * kNB];
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot + (size_t)w * kFewRec + e),
+                                   (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            bool ok = true;
+            for (int e = tid; e < kFewRec; e += 256) {
+                double sum = 0.0;
+                for (int ww = 0; ww < W; ++ww) {
+                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(slot + (size_t)ww * kFewRec + e);
+                    long long bits;
+                    unsigned spins = 0;
+                    do bits = (long long)__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while (bits == kFewSentinel && ++spins < (1u << 20) &&
+                           !((spins & 255) == 255 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0));
+                    ok = ok && bits != kFewSentinel;
+                    sum += __longlong_as_double(bits);
+                }
+                if (e < kNB * kNB) M[e / kNB][e % kNB] = sum;
+                else D2[e - kNB * kNB] = sum;
+            }
+            if (!ok) {
+                gave_up = 1;
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (flags) __hip_atomic_store(flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __syncthreads();
+            if (gave_up) return;                                         // (blocks before this one are applied: the update is incomplete)
+            // this workgroup's record of the block BEFORE back to sentinels (everybody has delivered this block: nobody reads that one any more)
+            // (written through, like the records: a cached store could reach memory AFTER the record this workgroup writes to the
+            //  same slot two blocks later)
+            if (bi >= 1) {
+                unsigned long long *old = reinterpret_cast<unsigned long long *>(xch + ((size_t)((bi + 2) % 3) * W + w) * kFewRec);
+                for (int e = tid; e < kFewRec; e += 256)
+                    __hip_atomic_store(old + e, (unsigned long long)kFewSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // (3) the recursion of the block, one wavefront (every workgroup for itself; workgroup 0 keeps the new budgets)
+        if (tid < 64) {
+            const int x = tid & 31;
+            const int jj_x = (x < nb) ? order[j0 + x] : 0;
+            const double budget_x = (x < nb) ? (double)norm_in[jj_x] : 0.0;
+            resolve_wave<T>(M, D2, Cs, jj_x, budget_x, nb, w == 0 ? comp_norm : sink, CAs, kNB, scr);
+        }
+        __syncthreads();
+        // (4) apply: four threads per feature
+        for (int f0 = 0; f0 < rows; f0 += 64) {
+            const int f = f0 + tid / 4;
+            if (f < rows) {
+                T ar[kNB];
+#pragma unroll
+                for (int m = 0; m < kNB; ++m) ar[m] = As[f * (kNB + 1) + m];
+                apply_row<T, 4>(ar, CAs, Dt + sub_row(subset, r0 + f) * k, order, j0, nb, tid % 4);
             }
         }
         __syncthreads();                                   // (the rows are written: the next block reads them)
@@ -2266,11 +2457,29 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             MODL_LAUNCH_CHECK();
             ++nl;
         } else {
+            const int nfew = (int)cdiv(s, kFewRows);
+            const bool few = std::is_same<T, double>::value && s > kTinyRows && nfew <= kFewMaxWg && g_bcd_tiny.load(std::memory_order_relaxed) &&
+                             g_bcd_few.load(std::memory_order_relaxed);
+            long long *few_x = few ? reinterpret_cast<long long *>(ws + L.off_few) : nullptr;
+            const long long few_words = 3LL * nfew * kFewRec;             // (the error word sits right behind them)
             hipLaunchKernelGGL((bcd_prepare_kernel<T>), dim3(k > kNB ? k : kNB), dim3(256), sizeof(int32_t) * (size_t)k,
                                stream, a.C, a.order, k, CP, cdiag, frozen, coef_all, counter, a.comp_norm,
-                               reinterpret_cast<T *>(ws + L.off_norm_in));
+                               reinterpret_cast<T *>(ws + L.off_norm_in), few_x, few_words);
             MODL_LAUNCH_CHECK();
             ++nl;
+            if (few) {                                       // the whole sweep in one launch on a few workgroups
+                const size_t lds = bcd_tiny_lds(sizeof(T), kFewRows) + sizeof(T) * (size_t)k + 16;
+                MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bcd_few_kernel<T>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                hipLaunchKernelGGL((bcd_few_kernel<T>), dim3(nfew), dim3(256), lds, stream, a.Dt, a.Bt, CP, cdiag, frozen, coef_all,
+                                   a.subset, a.order, (int)s, k, a.comp_norm, reinterpret_cast<const T *>(ws + L.off_norm_in),
+                                   reinterpret_cast<double *>(few_x), reinterpret_cast<unsigned int *>(few_x + few_words),
+                                   a.persist_flags);
+                MODL_LAUNCH_CHECK();
+                ++nl;
+                if (launches) *launches += nl;
+                return MODL_OK;
+            }
             if (std::is_same<T, double>::value && s <= kTinyRows && g_bcd_tiny.load(std::memory_order_relaxed)) {   // the whole sweep by one workgroup
                 MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bcd_tiny_kernel<T>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -796,6 +796,9 @@ struct modl_recsys_plan {
     size_t ack_off = 0;
     long fused_calls = 0, split_calls = 0;     // minibatches through the one-launch path / through the separate launches
     double wait_ms = 0;                        // host time spent waiting for a staging slot (the host is eight minibatches ahead)
+    // raised (pinned, system scope) by a dictionary-update launch whose cross-workgroup wait gave up (bcd_few_kernel): the update is
+    // incomplete, every further minibatch of the plan is refused with MODL_ETIMEOUT until modl_recsys_plan_status has reported it
+    unsigned int *pflags = nullptr, *pflags_dev = nullptr;
 };
 
 namespace modl {
@@ -839,6 +842,7 @@ int recsys_prepare(modl_recsys_plan *pl, const int32_t *h_indptr, const int32_t 
                    const int64_t *h_rows, int64_t b, const int64_t *h_order, hipStream_t st, RecsysPrep &out) {
     const int k = pl->k;
     if (b <= 0 || b > pl->max_batch) return MODL_EINVAL;
+    if (pl->pflags && *reinterpret_cast<volatile unsigned int *>(pl->pflags) != 0) return MODL_ETIMEOUT;
     int64_t m = 0;
     for (int64_t i = 0; i < b; ++i) {
         const int64_t r = h_rows[i];
@@ -1014,6 +1018,7 @@ int recsys_launch(modl_recsys_plan *pl, const RecsysPrep &pr, bool staged, const
                 a.Dt = Dt; a.Bt = Bt; a.C = C; a.comp_norm = comp_norm; a.subset = d_subset; a.order = d_order;
                 a.h_order = h_order; a.s = u; a.k = k; a.optimizer = 0; a.comp_pos = 0;
                 a.comp_l1_ratio = 0.0; a.w = w; a.step_size = 1.0; a.ws = pl->ws; a.ws_bytes = pl->ws_bytes;
+                a.persist_flags = pl->pflags_dev;
                 int nl = 0;
                 MODL_TRY(dict_update<T>(st, a, &nl));
             }
@@ -1040,6 +1045,7 @@ int recsys_launch(modl_recsys_plan *pl, const RecsysPrep &pr, bool staged, const
         a.Dt = Dt; a.Bt = Bt; a.C = C; a.comp_norm = comp_norm; a.subset = d_subset; a.order = d_order;
         a.h_order = h_order; a.s = u; a.k = k; a.optimizer = 0; a.comp_pos = 0;
         a.comp_l1_ratio = 0.0; a.w = w; a.step_size = 1.0; a.ws = pl->ws; a.ws_bytes = pl->ws_bytes;
+        a.persist_flags = pl->pflags_dev;
         int nl = 0;
         MODL_TRY(dict_update<T>(st, a, &nl));
     }
@@ -1208,6 +1214,9 @@ int modl_recsys_plan_create(int dtype, int64_t p, int k, int64_t max_batch, int6
             e = hipMemcpy(pl->xch, fill.data(), sizeof(long long) * fill.size(), hipMemcpyHostToDevice);
         }
     }
+    if (e == hipSuccess) e = hipHostMalloc((void **)&pl->pflags, 64, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&pl->pflags_dev, pl->pflags, 0);
+    if (e == hipSuccess) std::memset(pl->pflags, 0, 64);
     for (int i = 0; i < kRecsysSlots && e == hipSuccess; ++i) {
         e = hipHostMalloc((void **)&pl->h[i], pl->stage_bytes + 64, hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&pl->hdev[i], pl->h[i], 0);
@@ -1227,6 +1236,7 @@ void modl_recsys_plan_destroy(modl_recsys_plan *pl) {
     for (int i = 0; i < kRecsysSlots; ++i) {
         if (pl->h[i]) (void)hipHostFree(pl->h[i]);
     }
+    if (pl->pflags) (void)hipHostFree(pl->pflags);
     if (pl->part) (void)hipFree(pl->part);
     if (pl->tickets) (void)hipFree(pl->tickets);
     if (pl->xch) (void)hipFree(pl->xch);
@@ -1290,6 +1300,17 @@ int modl_recsys_plan_counts(const modl_recsys_plan *pl, int64_t *fused, int64_t 
     *fused = pl->fused_calls;
     *split = pl->split_calls;
     return MODL_OK;
+}
+
+/* Synchronises `stream`; MODL_ETIMEOUT if a dictionary-update launch of this plan gave up since the last call (the update is
+ * incomplete; the flag is cleared), MODL_OK otherwise. */
+int modl_recsys_plan_status(modl_recsys_plan *pl, void *stream) {
+    if (!pl) return MODL_EINVAL;
+    MODL_HIP(hipStreamSynchronize((hipStream_t)stream));
+    volatile unsigned int *f = pl->pflags;
+    if (!f || f[0] == 0) return MODL_OK;
+    f[0] = 0;
+    return MODL_ETIMEOUT;
 }
 
 /* diagnostics: on = 1 allocates 16 words the last workgroup of every one-launch minibatch stamps with the 100 MHz wall clock

@@ -262,6 +262,8 @@ class RecsysDictFact(BaseEstimator):
                 # nothing to report between minibatches: the epoch's host loop runs behind the ABI, one call
                 self.n_iter_ = dev.fit_batches(permutation, batch_size, self.alpha, self.learning_rate, self.n_iter_,
                                                self.random_state)
+        if dev.plan is not None:         # (a dictionary-update launch whose workgroups could not meet must not pass for a fit)
+            check(lib.modl_recsys_plan_status(dev.plan, stream_ptr(dev.device)), 'modl_recsys_plan_status')
         self._refit()
         return self
 

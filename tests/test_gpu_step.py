@@ -1248,6 +1248,35 @@ def test_objective_on_device_chunked(dtype, tol):
     assert f(ptr(dX), p + 3, n, p, ptr(dDt), k, ptr(dcode), ptr(ws), 64, ptr(out), stream_ptr(dev)) == -2      # MODL_ENOMEM
 
 
+@pytest.mark.parametrize('p,k,red', [(1500, 50, 2), (1500, 100, 2), (2040, 40, 1), (900, 130, 3)])
+def test_f64_dictionary_update_on_a_few_workgroups(DictFact, oracle, p, k, red):
+    """Round 6: the f64 blocked dictionary update of 193 to 2048 sampled features runs as ONE launch on up to sixteen workgroups of
+    128 features that exchange a block's Gram record through memory (csrc/bcd.hip: bcd_few_kernel; the shape of a masked minibatch
+    of RecsysDictFact).  Against the four launches per block it replaces (MODL_DEBUG_BCD_FEW = 0) and against the oracle, over
+    several minibatches: two to five blocks of atoms (the three exchange slots rotate and are restored), a ragged last workgroup."""
+    from modl_amd._lib import lib, check, DEBUG_BCD_FEW
+    rs = np.random.RandomState(p + k)
+    n, b = 4 * 48, 48
+    X = rs.randn(n, 20).dot(rs.randn(20, p)) + 0.3 * rs.randn(n, p)
+    kw = dict(n_components=k, batch_size=b, reduction=red, code_alpha=0.1, random_state=0, learning_rate=0.9)
+    out = {}
+    for few in (1, 0):
+        check(lib.modl_debug_set(DEBUG_BCD_FEW, few))
+        try:
+            est = DictFact(**kw)
+            est.prepare(n_samples=n, X=X)
+            est.partial_fit(X, np.arange(n))
+            out[few] = (est.components_, est.comp_norm_, est.code_)
+        finally:
+            check(lib.modl_debug_set(DEBUG_BCD_FEW, 1))
+    pr = oracle.SomfParams(**kw)
+    st = oracle.prepare(pr, n_samples=n, X=X)
+    oracle.partial_fit(st, pr, X, np.arange(n))
+    assert rel_fro(out[1][0], out[0][0]) < 1e-10 and rel_fro(out[1][2], out[0][2]) < 1e-10
+    assert np.allclose(out[1][1], out[0][1], rtol=0, atol=1e-10)
+    assert rel_fro(out[1][0], st.D) < 1e-9 and rel_fro(out[1][2], st.code) < 1e-9
+
+
 _MWG_SCRIPT = r"""
 import json, sys
 import numpy as np
