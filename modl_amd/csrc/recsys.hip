@@ -205,7 +205,6 @@ __global__ __launch_bounds__(256) void recsys_predict_kernel(double *out, const 
 // More than 512 touched items: the kernel stops after B_ and the host runs the blocked dictionary update's launches.
 constexpr int kRfMaxChunks = 64, kRfMaxBatch = 64, kRfChunk = 128;
 constexpr int kRfMaxSweep = 4;                          // sweep workgroups of 512 items each
-constexpr int kRfMaxItems = 1024 * kRfMaxSweep;          // (registers + the LDS tier)
 constexpr long long kRfSentinel = 0x7ff8dead0000beefll; // a NaN no sum produces
 typedef unsigned int rf_u4 __attribute__((ext_vector_type(4)));   // (a native vector: an array of HIP's uint4 structs went to scratch)
 struct RecsysChunk { int32_t pos, beg, cnt, nch, ci, part0; };   // row of the batch, first CSR entry, entries, chunks of the row, index among them, first record
@@ -290,7 +289,7 @@ template <typename T, int KP> __device__ __forceinline__ void rf_set(T (&D)[KP],
 template <typename T>
 size_t recsys_fused_lds(int k, int b, int KP, int cap2) {
     const size_t KS = (size_t)((k + 3) & ~3), ld = (size_t)(k | 1);
-    const size_t chunk = sizeof(T) * ((size_t)k * ld + 4 + 2 * KS + 768 + 2 * 32 * KS + kRfChunk) + sizeof(int) * (kRfChunk + 8);
+    const size_t chunk = sizeof(T) * ((size_t)k * ld + 4 + 2 * KS + 768 + 2 * 32 * (size_t)((k + 15) & ~15) + kRfChunk) + sizeof(int) * (kRfChunk + 8);
     const size_t fin = sizeof(T) * ((size_t)k * KP + (size_t)b * k + 3 * (size_t)KP) + sizeof(double) * (2 * 8 * 2 + 8 * (size_t)KP) +
                        ((sizeof(int) * ((size_t)KP + 8) + 15) & ~(size_t)15) + sizeof(T) * (size_t)KP * cap2 + 16;
     return (chunk > fin ? chunk : fin) + 64;
@@ -324,8 +323,8 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
         T *rhs = G + (((size_t)k * ld + 3) & ~(size_t)3);       // [KS] (16-byte aligned, like everything behind it)
         T *dinv = rhs + KS;                                     // [KS]
         T *cpart = dinv + KS;                                   // [3][4][64]
-        T *rowsb = cpart + 768;                                 // [2][32][KS]
-        T *xv = rowsb + 2 * 32 * KS;                            // [kRfChunk]
+        T *rowsb = cpart + 768;                                 // [2][32][KQ], KQ = k rounded up to 16
+        T *xv = rowsb + 2 * 32 * ((k + 15) & ~15);              // [kRfChunk]
         int *ids = reinterpret_cast<int *>(xv + kRfChunk);      // [kRfChunk]
         int *flag = ids + kRfChunk;
         const RecsysChunk c = a.ch[blockIdx.x];
@@ -336,37 +335,43 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
             xv[tid] = a.data[e];
         }
         __syncthreads();
-        const int TB = KS >> 2;
-        const bool gth = tid < TB * TB;
-        const int ti = gth ? tid / TB : 0, tj = gth ? tid % TB : 0;
+        // The chunk's Gram contribution on the MATRIX CORES (16 x 16 x 4 tiles, f64 or f32: G[i][j] += sum_items D[item][i] D[item][j];
+        // both operands of a tile are columns of the staged rows, four items per instruction), two tiles per wavefront and
+        // sub-chunk of 32 items.  (First version: 4 x 4 register tiles on 169 threads, 1.7 us per sub-chunk, plus - eight times
+        // per sub-chunk and thread - an integer division by the row stride in the staging loops: 4.5 us per sub-chunk, measured.)
+        const int KT = (k + 15) >> 4, KQ = KT * 16;             // tiles per side, padded row stride of the staged rows
         const int ra = tid - 256;                               // the right-hand side's threads: 256 .. 256 + k - 1
-        T acc[4][4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int y = 0; y < 4; ++y) acc[x][y] = 0;
+        typedef typename std::conditional<sizeof(T) == 8, double, float>::type AT;
+        typedef AT acc_t __attribute__((ext_vector_type(4)));
+        acc_t acc[2];
+        acc[0] = (acc_t){0, 0, 0, 0};
+        acc[1] = (acc_t){0, 0, 0, 0};
+        const int nt = KT * KT;
+        const int t0 = wid, t1 = wid + 8;                       // this wavefront's tiles (k <= 64: at most 16)
         T racc = 0;
         const int nsub = (c.cnt + 31) >> 5;
-        const int tot = 32 * KS;
+        const int tot = 32 * KQ;
         T pre[8];
+        int jq[8], cq[8];                                       // (item of the sub-chunk, atom) of this thread's staged elements
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * q;
+            jq[q] = (e < tot) ? e / KQ : 0;
+            cq[q] = (e < tot) ? e % KQ : KQ;                    // (KQ: beyond the row - stored as zero)
+        }
         auto request = [&](int sb) {                            // 32 dictionary rows -> registers (waves 0-3), clamped addresses
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int e = tid + 256 * q;
-                const int j = (e < tot) ? e / KS : 0, cc = (e < tot) ? e % KS : 0;
-                const int jj = sb * 32 + j;
-                const bool ok = e < tot && jj < c.cnt && cc < k;
-                pre[q] = a.Dt[(int64_t)ids[ok ? jj : 0] * k + (ok ? cc : 0)];
+                const int jj = sb * 32 + jq[q];
+                const bool ok = jj < c.cnt && cq[q] < k;
+                pre[q] = a.Dt[(int64_t)ids[ok ? jj : 0] * k + (ok ? cq[q] : 0)];
             }
         };
         auto deposit = [&](int sb, T *buf) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int e = tid + 256 * q;
-                if (e < tot) {
-                    const int j = e / KS, cc = e % KS;
-                    buf[e] = (sb * 32 + j < c.cnt && cc < k) ? pre[q] : (T)0;
-                }
+                if (e < tot) buf[e] = (sb * 32 + jq[q] < c.cnt && cq[q] < k) ? pre[q] : (T)0;
             }
         };
         stp[1] = a.dbg ? wall_clock64() : 0;
@@ -377,31 +382,46 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
             __syncthreads();
             if (tid < 256 && sb + 1 < nsub) request(sb + 1);
             const int ncs = (c.cnt - 32 * sb < 32) ? c.cnt - 32 * sb : 32;
-            if (gth) {
-                for (int j = 0; j < ncs; ++j) {
-                    T av[4], bv[4];
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) { av[x] = buf[j * KS + 4 * ti + x]; bv[x] = buf[j * KS + 4 * tj + x]; }
+            for (int u = 0; u < 2; ++u) {
+                const int t = u ? t1 : t0;
+                if (t < nt) {                                   // (wavefront-uniform)
+                    const int ta = t / KT, tb = t % KT;
+                    const T *pa = buf + (lane >> 4) * KQ + 16 * ta + (lane & 15);
+                    const T *pb = buf + (lane >> 4) * KQ + 16 * tb + (lane & 15);
 #pragma unroll
-                    for (int x = 0; x < 4; ++x)
-#pragma unroll
-                        for (int y = 0; y < 4; ++y) acc[x][y] = fma(av[x], bv[y], acc[x][y]);
+                    for (int st = 0; st < 8; ++st) {            // (items beyond the chunk are zero rows)
+                        const AT av = pa[4 * st * KQ], bv = pb[4 * st * KQ];
+                        if constexpr (sizeof(T) == 8) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[u], 0, 0, 0);
+                        else acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[u], 0, 0, 0);
+                    }
                 }
-            } else if (ra >= 0 && ra < k) {
-                for (int j = 0; j < ncs; ++j) racc = fma(buf[j * KS + ra], xv[32 * sb + j], racc);
             }
+            if (ra >= 0 && ra < k)
+                for (int j = 0; j < ncs; ++j) racc = fma(buf[j * KQ + ra], xv[32 * sb + j], racc);
         }
         stp[2] = a.dbg ? wall_clock64() : 0;
         const int rec = k * k + k;
+        // element (row, column) of register r of a tile's accumulator (f64: row = (lane >> 4) + 4 r; f32: row = 4 (lane >> 4) + r)
+        auto tile_rc = [&](int t, int r, int &row, int &col) {
+            const int ta = t / KT, tb = t % KT;
+            row = 16 * ta + (sizeof(T) == 8 ? (lane >> 4) + 4 * r : 4 * (lane >> 4) + r);
+            col = 16 * tb + (lane & 15);
+        };
         if (c.nch > 1) {                                        // several chunks: meet in the records, the last to arrive goes on
             T *pp = a.part + (size_t)(c.part0 + c.ci) * rec;
-            if (gth) {
 #pragma unroll
-                for (int x = 0; x < 4; ++x)
+            for (int u = 0; u < 2; ++u) {
+                const int t = u ? t1 : t0;
+                if (t < nt)
 #pragma unroll
-                    for (int y = 0; y < 4; ++y)
-                        if (4 * ti + x < k && 4 * tj + y < k) rf_store(pp + (4 * ti + x) * k + 4 * tj + y, acc[x][y]);
-            } else if (ra >= 0 && ra < k) rf_store(pp + k * k + ra, racc);
+                    for (int r = 0; r < 4; ++r) {
+                        int row, col;
+                        tile_rc(t, r, row, col);
+                        if (row < k && col < k) rf_store(pp + row * k + col, (T)acc[u][r]);
+                    }
+            }
+            if (ra >= 0 && ra < k) rf_store(pp + k * k + ra, racc);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) flag[0] = (int)__hip_atomic_fetch_add(a.tickets + c.pos, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -414,13 +434,18 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
                 else rhs[e - k * k] = t;
             }
         } else {
-            if (gth) {
 #pragma unroll
-                for (int x = 0; x < 4; ++x)
+            for (int u = 0; u < 2; ++u) {
+                const int t = u ? t1 : t0;
+                if (t < nt)
 #pragma unroll
-                    for (int y = 0; y < 4; ++y)
-                        if (4 * ti + x < k && 4 * tj + y < k) G[(4 * ti + x) * ld + 4 * tj + y] = acc[x][y];
-            } else if (ra >= 0 && ra < k) rhs[ra] = racc;
+                    for (int r = 0; r < 4; ++r) {
+                        int row, col;
+                        tile_rc(t, r, row, col);
+                        if (row < k && col < k) G[row * ld + col] = (T)acc[u][r];
+                    }
+            }
+            if (ra >= 0 && ra < k) rhs[ra] = racc;
         }
         __syncthreads();
         {
