@@ -286,6 +286,60 @@ template <typename T, int KP> __device__ __forceinline__ void rf_set(T (&D)[KP],
     });
 }
 
+// The row's k x k system (k <= KC) factored and solved by ONE wavefront with the matrix in REGISTERS: lane i holds row i, column j
+// is a compile-time register index (the loops are unrolled), the pivot row's entries reach the other lanes as v_readlane
+// broadcasts: right-looking, G[i][m] -= L[i][j] L[m][j] - no LDS traffic, no barrier.  (chol_block_lds + chol_solve_wave_lds, four
+// wavefronts working on the matrix in LDS with two barriers per four columns, took 18.5 + 9.2 us at k = 50.)  Rows and columns
+// beyond k are the identity: no branch anywhere.  The reciprocal pivot: rsq + two Newton steps (f64) / one (f32), d = pivot * inv.
+// Backward substitution: x_j = (y_j - sum_{m > j} L[m][j] x_m) / L[j][j] with the sum over the lanes (a wave sum per column).
+template <typename T, int KC>
+__device__ __forceinline__ T chol_solve_wave_reg(const T *G, int ld, int k, const T *rhs) {
+    const int lane = threadIdx.x & 63;
+    T R[KC];
+#pragma unroll
+    for (int m = 0; m < KC; ++m) {
+        const T v = G[(lane < k ? lane : 0) * ld + (m < k ? m : 0)];
+        R[m] = (lane < k && m < k) ? v : ((lane == m) ? (T)1 : (T)0);
+    }
+    T b = (lane < k) ? rhs[lane] : (T)0;
+    T myinv = 1;
+    rf_static_for<0, KC>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        const T piv = bcast_lane(R[j], j);
+        T inv;
+        if constexpr (sizeof(T) == 8) {
+            double y0 = __builtin_amdgcn_rsq(piv);
+            y0 = y0 * fma(-0.5 * piv * y0, y0, 1.5);
+            inv = y0 * fma(-0.5 * piv * y0, y0, 1.5);
+        } else {
+            const float y0 = __builtin_amdgcn_rsqf(piv);
+            inv = y0 * fmaf(-0.5f * piv * y0, y0, 1.5f);
+        }
+        const T l = R[j] * inv;                                  // lane i: L[i][j] (lane j: the pivot's square root)
+        R[j] = l;
+        myinv = (lane == j) ? inv : myinv;
+        rf_static_for<j + 1, KC>([&](auto M) {
+            constexpr int m = decltype(M)::value;
+            R[m] = fma(-l, bcast_lane(l, m), R[m]);
+        });
+    });
+    // L y = b (column j of L is register j of the lanes below j)
+    rf_static_for<0, KC>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        const T yj = bcast_lane(b * myinv, j);
+        b = (lane == j) ? yj : ((lane > j) ? fma(-R[j], yj, b) : b);
+    });
+    // L^T x = y
+    T x = 0;
+    rf_static_for<0, KC>([&](auto J) {
+        constexpr int j = KC - 1 - decltype(J)::value;
+        const T t = wave_sum((lane > j) ? R[j] * x : (T)0);      // sum_{m > j} L[m][j] x_m
+        const T xj = bcast_lane((b - t) * myinv, j);
+        x = (lane == j) ? xj : x;
+    });
+    return x;
+}
+
 template <typename T>
 size_t recsys_fused_lds(int k, int b, int KP, int cap2) {
     const size_t KS = (size_t)((k + 3) & ~3), ld = (size_t)(k | 1);
@@ -455,13 +509,11 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
         }
         __syncthreads();
         stp[3] = a.dbg ? wall_clock64() : 0;
-        chol_block_lds<T, 1>(G, k, ld, dinv, cpart);
         stp[4] = a.dbg ? wall_clock64() : 0;
-        if (wid == 0) {
-            T y[1][1];
-            y[0][0] = (lane < k) ? rhs[lane] : (T)0;
-            chol_solve_wave_lds<T, 1, 1>(G, dinv, k, ld, y);
-            if (lane < k) rf_store(a.code + r * k + lane, y[0][0]);
+        if (wid == 0) {                                          // one wavefront, the matrix in its registers (chol_solve_wave_reg)
+            T xs;
+            xs = chol_solve_wave_reg<T, KP>(G, ld, k, rhs);         // (KP = 32: k <= 32; KP = 56 / 64: 32 < k <= KP)
+            if (lane < k) rf_store(a.code + r * k + lane, xs);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
