@@ -49,8 +49,8 @@ struct DuLayout {
 
 // row stride of the scratch of the grouped atom update: what the projecting workgroup covers with 12 / 20 / 24 elements
 // per thread (s beyond that: the group path is not taken, the stride is never used)
-constexpr int kFewRows = 128;                        // sampled features per workgroup of bcd_few_kernel
-constexpr int kFewMaxWg = 16;                        // ... and the most workgroups it runs on (2048 features)
+constexpr int kFewRows = 64;                         // sampled features per workgroup of bcd_few_kernel
+constexpr int kFewMaxWg = 32;                        // ... and the most workgroups it runs on (2048 features)
 constexpr int kFewRec = kNB * kNB + kNB;             // a Gram record: the 32 x 32 matrix of a block's candidates + their old norms
 constexpr long long kFewSentinel = 0x7ff8feed7ff8feedll;   // what an exchange slot holds until its record arrives (a NaN no sum produces)
 std::atomic<int> g_bcd_few{1};                       // modl_debug_set(MODL_DEBUG_BCD_FEW, ...)
@@ -554,12 +554,17 @@ __global__ __launch_bounds__(256) void bcd_few_kernel(T *Dt, const T *Bt, const 
     double *d2red = CAs + kResStride;                                                    // [8][NB]
     T *As = reinterpret_cast<T *>(d2red + 8 * kNB);                                      // [kFewRows][NB + 1]
     T *sink = As + (size_t)kFewRows * (kNB + 1);                                         // [k] where the other workgroups' budgets go
-    __shared__ int gave_up;
+    int64_t *roff = reinterpret_cast<int64_t *>(sink + k + (k & 1));                     // [kFewRows] element offsets of this workgroup's rows
+    int &gave_up = *reinterpret_cast<int *>(roff + kFewRows);                            // (dynamic LDS only: the attribute below asks for all of it)
     const int tid = threadIdx.x;
     const int W = (int)gridDim.x, w = (int)blockIdx.x;
     const int r0 = w * kFewRows;
     const int rows = (s - r0 < kFewRows) ? s - r0 : kFewRows;
     if (tid == 0) gave_up = 0;
+    // the rows' offsets ONCE (subset -> offset -> element was two dependent round trips in front of every tile and, in the loop of
+    // the old norms, sixteen times per block: 20 of a block's 41 us)
+    if (tid < kFewRows) roff[tid] = sub_row(subset, r0 + (tid < rows ? tid : rows - 1)) * k;
+    __syncthreads();
     int bi = 0;
     for (int j0 = 0; j0 < k; j0 += kNB, ++bi) {
         const int nb = (k - j0 < kNB) ? k - j0 : kNB;
@@ -569,10 +574,11 @@ __global__ __launch_bounds__(256) void bcd_few_kernel(T *Dt, const T *Bt, const 
             typedef double d4v __attribute__((ext_vector_type(4)));
             const int lane = tid & 63, wid = tid >> 6;
             const int ntile = ((rows + 15) / 16) * 2;
+            double dsq[2] = {0.0, 0.0};                              // this lane's share of the old squared norms of its columns
             for (int t = wid; t < ntile; t += 4) {
                 const int ft = t >> 1, ct = t & 1;
                 const int f = ft * 16 + (lane & 15);
-                const int64_t rowoff = sub_row(subset, r0 + (f < rows ? f : rows - 1)) * k;
+                const int64_t rowoff = roff[f < rows ? f : rows - 1];
                 const int jj = ct * 16 + (lane & 15);
                 const int jc = (jj < nb) ? jj : 0;
                 d4v acc = {0.0, 0.0, 0.0, 0.0};
@@ -583,7 +589,7 @@ __global__ __launch_bounds__(256) void bcd_few_kernel(T *Dt, const T *Bt, const 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int fr = ft * 16 + (lane >> 4) + 4 * r;
-                    const int64_t el = sub_row(subset, r0 + (fr < rows ? fr : rows - 1)) * k + ocolv;
+                    const int64_t el = roff[fr < rows ? fr : rows - 1] + ocolv;
                     eB[r] = Bt[el];
                     eD[r] = Dt[el];
                 }
@@ -610,7 +616,15 @@ __global__ __launch_bounds__(256) void bcd_few_kernel(T *Dt, const T *Bt, const 
                     const int fr = ft * 16 + (lane >> 4) + 4 * r;
                     const T av2 = fz ? eD[r] : (T)(((double)eB[r] - acc[r]) / (double)cd);
                     if (fr < rows) As[fr * (kNB + 1) + jj] = (jj < nb) ? av2 : (T)0;
+                    if (fr < rows && jj < nb) dsq[ct] += (double)eD[r] * (double)eD[r];   // (every (row, atom) of the block passes here once)
                 }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {                         // rows (lane >> 4) + 4 r of all this wavefront's tiles -> the column's sum
+                double v = dsq[ct];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (lane < 16) d2red[wid * kNB + 16 * ct + lane] = v;
             }
         }
         __syncthreads();
@@ -625,21 +639,9 @@ __global__ __launch_bounds__(256) void bcd_few_kernel(T *Dt, const T *Bt, const 
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) M[i][jb + q] = acc[q];
-            const int col = tid % kNB, rg = tid / kNB;
-            const int ocol = order[j0 + (col < nb ? col : 0)];
-            double d2 = 0;
-            for (int f = rg; f < rows; f += 8) {
-                const double x = (double)Dt[sub_row(subset, r0 + f) * k + ocol];
-                d2 += x * x;
-            }
-            d2red[rg * kNB + col] = (col < nb) ? d2 : 0.0;
         }
         __syncthreads();
-        if (tid < kNB) {
-            double t = 0;
-            for (int g = 0; g < 8; ++g) t += d2red[g * kNB + tid];
-            D2[tid] = t;
-        }
+        if (tid < kNB) D2[tid] = (d2red[tid] + d2red[kNB + tid]) + (d2red[2 * kNB + tid] + d2red[3 * kNB + tid]);   // (the four wavefronts' sums)
         __syncthreads();
         if (W > 1) {
             // (2b) the records meet: every thread its entries e = tid + 256 q of the record
@@ -650,21 +652,40 @@ __global__ __launch_bounds__(256) void bcd_few_kernel(T *Dt, const T *Bt, const 
                 __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot + (size_t)w * kFewRec + e),
                                    (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            // every load of a batch is requested before the first is looked at (one at a time - load, test, add - a thread paid
+            // forty dependent memory round trips per block: 28 of the block's 47 us); a record that has not arrived yet is
+            // simply asked for again
             bool ok = true;
-            for (int e = tid; e < kFewRec; e += 256) {
+            constexpr int NE = (kFewRec + 255) / 256;
+#pragma unroll
+            for (int q = 0; q < NE; ++q) {
+                const int e = tid + 256 * q;
+                const int ec = e < kFewRec ? e : kFewRec - 1;
                 double sum = 0.0;
-                for (int ww = 0; ww < W; ++ww) {
-                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(slot + (size_t)ww * kFewRec + e);
-                    long long bits;
-                    unsigned spins = 0;
-                    do bits = (long long)__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    while (bits == kFewSentinel && ++spins < (1u << 20) &&
-                           !((spins & 255) == 255 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0));
-                    ok = ok && bits != kFewSentinel;
-                    sum += __longlong_as_double(bits);
+                for (int w0 = 0; w0 < W; w0 += 8) {
+                    long long bits[8];
+                    for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+                        for (int u2 = 0; u2 < 8; ++u2) {
+                            const int ww = (w0 + u2 < W) ? w0 + u2 : W - 1;
+                            bits[u2] = (long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(slot + (size_t)ww * kFewRec + ec),
+                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        bool have = true;
+#pragma unroll
+                        for (int u2 = 0; u2 < 8; ++u2) have = have && bits[u2] != kFewSentinel;
+                        if (have) break;
+                        if (spins > (1u << 18) || ((spins & 63) == 63 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                            ok = false;
+                            break;
+                        }
+                    }
+#pragma unroll
+                    for (int u2 = 0; u2 < 8; ++u2)
+                        if (w0 + u2 < W) sum += __longlong_as_double(bits[u2]);
                 }
                 if (e < kNB * kNB) M[e / kNB][e % kNB] = sum;
-                else D2[e - kNB * kNB] = sum;
+                else if (e < kFewRec) D2[e - kNB * kNB] = sum;
             }
             if (!ok) {
                 gave_up = 1;
@@ -697,7 +718,7 @@ __global__ __launch_bounds__(256) void bcd_few_kernel(T *Dt, const T *Bt, const 
                 T ar[kNB];
 #pragma unroll
                 for (int m = 0; m < kNB; ++m) ar[m] = As[f * (kNB + 1) + m];
-                apply_row<T, 4>(ar, CAs, Dt + sub_row(subset, r0 + f) * k, order, j0, nb, tid % 4);
+                apply_row<T, 4>(ar, CAs, Dt + roff[f], order, j0, nb, tid % 4);
             }
         }
         __syncthreads();                                   // (the rows are written: the next block reads them)
@@ -2468,7 +2489,7 @@ int dict_update(hipStream_t stream, const DictUpdateArgs<T> &a, int *launches) {
             MODL_LAUNCH_CHECK();
             ++nl;
             if (few) {                                       // the whole sweep in one launch on a few workgroups
-                const size_t lds = bcd_tiny_lds(sizeof(T), kFewRows) + sizeof(T) * (size_t)k + 16;
+                const size_t lds = bcd_tiny_lds(sizeof(T), kFewRows) + sizeof(T) * ((size_t)k + 1) + sizeof(int64_t) * kFewRows + 32;
                 MODL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bcd_few_kernel<T>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 hipLaunchKernelGGL((bcd_few_kernel<T>), dim3(nfew), dim3(256), lds, stream, a.Dt, a.Bt, CP, cdiag, frozen, coef_all,

@@ -289,9 +289,11 @@ template <typename T, int KP> __device__ __forceinline__ void rf_set(T (&D)[KP],
 // The row's k x k system (k <= KC) factored and solved by ONE wavefront with the matrix in REGISTERS: lane i holds row i, column j
 // is a compile-time register index (the loops are unrolled), the pivot row's entries reach the other lanes as v_readlane
 // broadcasts: right-looking, G[i][m] -= L[i][j] L[m][j] - no LDS traffic, no barrier.  (chol_block_lds + chol_solve_wave_lds, four
-// wavefronts working on the matrix in LDS with two barriers per four columns, took 18.5 + 9.2 us at k = 50.)  Rows and columns
+// wavefronts working on the matrix in LDS with two barriers per four columns, took 18.5 + 9.2 us at k = 50; this one 23.8.)  Rows and columns
 // beyond k are the identity: no branch anywhere.  The reciprocal pivot: rsq + two Newton steps (f64) / one (f32), d = pivot * inv.
 // Backward substitution: x_j = (y_j - sum_{m > j} L[m][j] x_m) / L[j][j] with the sum over the lanes (a wave sum per column).
+// (Measured and not kept: the pivot column through LDS - one store, then broadcast reads - instead of a v_readlane pair per entry:
+//  half the instructions, 23.8 -> 30.6 us: each read waits for its LDS round trip on the lone wavefront.)
 template <typename T, int KC>
 __device__ __forceinline__ T chol_solve_wave_reg(const T *G, int ld, int k, const T *rhs) {
     const int lane = threadIdx.x & 63;
@@ -481,9 +483,18 @@ __global__ __launch_bounds__(512) void recsys_fused_kernel(const RecsysFusedArgs
             if (tid == 0) flag[0] = (int)__hip_atomic_fetch_add(a.tickets + c.pos, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             if (flag[0] != c.nch - 1) return;
+            // (every chunk's record has landed - written through before its ticket - so these are plain loads behind an acquire:
+            //  one at a time through the atomic path they were a memory round trip each, 9-30 us for two to eight chunks)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             for (int e = tid; e < rec; e += 512) {
                 T t = 0;
-                for (int z = 0; z < c.nch; ++z) t += rf_load(a.part + (size_t)(c.part0 + z) * rec + e);
+                for (int z0 = 0; z0 < c.nch; z0 += 8) {
+                    T v[8];
+#pragma unroll
+                    for (int z = 0; z < 8; ++z) v[z] = a.part[(size_t)(c.part0 + (z0 + z < c.nch ? z0 + z : c.nch - 1)) * rec + e];
+#pragma unroll
+                    for (int z = 0; z < 8; ++z) t += (z0 + z < c.nch) ? v[z] : (T)0;
+                }
                 if (e < k * k) G[(e / k) * ld + e % k] = t;
                 else rhs[e - k * k] = t;
             }

@@ -90,8 +90,8 @@ timeout 600 bash $R/scripts/ab_recsys_fused.sh 2>&1 | grep fused= > $OUT/${TAG}_
 # the spread l1 projection at the HCP shape: stamps, and the A/B against the last workgroup's projection
 timeout 300 python3 $R/scripts/diag_atom_stamps_c6.py > $OUT/${TAG}_atom_mwg_c6_stamps.txt 2>&1
 { for v in 1 0 1 0; do timeout 300 python3 $R/scripts/bench_configs.py --only c6 --debug-set 12=$v 2>/dev/null; done; } > $OUT/${TAG}_ab_atom_mwg_c6.jsonl
-# the sweep-flip census at 204 800 samples of both reductions (bench.py: flip_rate_block; ~15 min of CPU oracle)
-python3 - > $OUT/${TAG}_flip_census.json 2> $OUT/${TAG}_flip_census.err <<PY
+# the sweep-flip census at 204 800 samples of both reductions (bench.py: flip_rate_block; ~15 min of CPU oracle; FLIP=0 skips it)
+[ "${FLIP:-1}" = "1" ] && python3 - > $OUT/${TAG}_flip_census.json 2> $OUT/${TAG}_flip_census.err <<PY
 import sys, json
 sys.path.insert(0, "$R")
 import torch, bench
