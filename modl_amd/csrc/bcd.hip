@@ -49,8 +49,8 @@ struct DuLayout {
 
 // row stride of the scratch of the grouped atom update: what the projecting workgroup covers with 12 / 20 / 24 elements
 // per thread (s beyond that: the group path is not taken, the stride is never used)
-constexpr int kFewRows = 64;                         // sampled features per workgroup of bcd_few_kernel
-constexpr int kFewMaxWg = 32;                        // ... and the most workgroups it runs on (2048 features)
+constexpr int kFewRows = 32;                         // sampled features per workgroup of bcd_few_kernel
+constexpr int kFewMaxWg = 64;                        // ... and the most workgroups it runs on (2048 features)
 constexpr int kFewRec = kNB * kNB + kNB;             // a Gram record: the 32 x 32 matrix of a block's candidates + their old norms
 constexpr long long kFewSentinel = 0x7ff8feed7ff8feedll;   // what an exchange slot holds until its record arrives (a NaN no sum produces)
 std::atomic<int> g_bcd_few{1};                       // modl_debug_set(MODL_DEBUG_BCD_FEW, ...)
