@@ -85,6 +85,10 @@ ls -la $OUT | grep $TAG
 # round 6: the masked minibatch (C4) - kernel trace, the in-kernel stamps of the one-launch variants, the A/B of the policies
 rm -rf /tmp/w/c4; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/w/c4 -o t -- python3 $R/scripts/bench_configs.py --only c4 --c4-batches 2000 > /tmp/w/c4.log 2>&1
 { tail -2 /tmp/w/c4.log; python3 $R/scripts/prof_summary.py $(find /tmp/w/c4 -name "*.db" | head -1) 0.0; } > $OUT/${TAG}_cfg_c4_kernel_trace.txt 2>&1
+python3 $R/scripts/c4_timeline.py $(find /tmp/w/c4 -name "*.db" | head -1) > $OUT/${TAG}_cfg_c4_timeline.txt 2>&1
+timeout 300 python3 $R/scripts/diag_c4_host.py > $OUT/${TAG}_cfg_c4_host_cprofile.txt 2>&1
+# the measured values behind two tolerances of the suite
+timeout 600 python3 -m pytest $R/tests/test_gpu_step.py -q -m gpu -s -k "gram_accumulator_out_of_range" 2>&1 | grep -a "accumulator vs records" > $OUT/${TAG}_accumulator_vs_records.txt
 { for v in 2 4; do timeout 300 python3 $R/scripts/diag_recsys_stamps.py $v; done; } > $OUT/${TAG}_recsys_fused_stamps.txt 2>&1
 timeout 600 bash $R/scripts/ab_recsys_fused.sh 2>&1 | grep fused= > $OUT/${TAG}_ab_recsys_fused.txt
 # the spread l1 projection at the HCP shape: stamps, and the A/B against the last workgroup's projection
