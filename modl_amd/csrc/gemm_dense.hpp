@@ -38,6 +38,17 @@ template <class E, typename T, class = void> struct EpiOldT { typedef T type; };
 template <class E, typename T> struct EpiOldT<E, T, std::void_t<typename E::Old>> { typedef typename E::Old type; };
 template <class E, typename T> using EpiOld = typename EpiOldT<E, T>::type;
 
+// Column swizzle of the k-major LDS tiles: element (k-row kl, column il) lives at column il ^ gd_swz(kl).  The operand that is
+// contiguous along K is written TRANSPOSED - a thread's 16-byte vector becomes four scalar stores to four consecutive k-rows - and
+// with the plain layout (row stride BI + 4 words: 4 banks) the eight threads that hold one operand row hit two banks, four-way
+// conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.235, round 5's counters).  XOR-ing bits 2-4 of the
+// column with bits 2-4 of the k-row spreads them over eight banks; a fragment read (32 consecutive columns of one k-row) and a
+// 16-byte vector store along the columns are permuted in whole groups of four: both stay conflict-free and aligned.
+#ifndef MODL_GEMM_SWZ
+#define MODL_GEMM_SWZ 1
+#endif
+__device__ __forceinline__ int gd_swz(int kl) { return MODL_GEMM_SWZ ? (((kl >> 2) & 7) << 2) : 0; }
+
 template <typename T> struct Vec4;   // 16-byte vector of T
 template <> struct Vec4<float> { typedef float4 type; static constexpr int N = 4; };
 template <> struct Vec4<double> { typedef double2 type; static constexpr int N = 2; };
@@ -99,11 +110,11 @@ struct TileLoader {
             for (int c = 0; c < VN; ++c) t[c] = ((msk >> (q * VN + c)) & 1u) ? (T)0 : t[c];
             if (IFAST) {
                 const int il = (e % (BI / VN)) * VN, kl = e / (BI / VN);
-                *reinterpret_cast<V *>(&S[kl][il]) = v;
+                *reinterpret_cast<V *>(&S[kl][il ^ gd_swz(kl)]) = v;
             } else {
                 const int kl = (e % (BK / VN)) * VN, il = e / (BK / VN);
 #pragma unroll
-                for (int c = 0; c < VN; ++c) S[kl + c][il] = t[c];
+                for (int c = 0; c < VN; ++c) S[kl + c][il ^ gd_swz(kl + c)] = t[c];
             }
         }
     }
@@ -203,9 +214,9 @@ __device__ __forceinline__ void gemm_dense_tile(const DenseOperand &A, const Den
             T af[RM], bf[RN];
             const int kr = kk + MT::frag_k(lane);
 #pragma unroll
-            for (int i = 0; i < RM; ++i) af[i] = As[cur][kr][wm * WM + i * MT::TM + MT::frag_i(lane)];
+            for (int i = 0; i < RM; ++i) af[i] = As[cur][kr][(wm * WM + i * MT::TM + MT::frag_i(lane)) ^ gd_swz(kr)];
 #pragma unroll
-            for (int j = 0; j < RN; ++j) bf[j] = Bs[cur][kr][wn * WN + j * MT::TN + MT::frag_i(lane)];
+            for (int j = 0; j < RN; ++j) bf[j] = Bs[cur][kr][(wn * WN + j * MT::TN + MT::frag_i(lane)) ^ gd_swz(kr)];
 #pragma unroll
             for (int i = 0; i < RM; ++i)
 #pragma unroll
@@ -335,9 +346,9 @@ __device__ __forceinline__ void gemm_dense_tile_rk(const DenseOperand &A, const 
             for (int u = 0; u < NS; ++u) {
                 const int kr = u * MT::TK + MT::frag_k(lane);
 #pragma unroll
-                for (int i = 0; i < RM; ++i) af[u][i] = As[t & 1][kr][wm * WM + i * MT::TM + MT::frag_i(lane)];
+                for (int i = 0; i < RM; ++i) af[u][i] = As[t & 1][kr][(wm * WM + i * MT::TM + MT::frag_i(lane)) ^ gd_swz(kr)];
 #pragma unroll
-                for (int j = 0; j < RN; ++j) bf[u][j] = Bs[t & 1][kr][wn * WN + j * MT::TN + MT::frag_i(lane)];
+                for (int j = 0; j < RN; ++j) bf[u][j] = Bs[t & 1][kr][(wn * WN + j * MT::TN + MT::frag_i(lane)) ^ gd_swz(kr)];
             }
             // two accumulators (even / odd k-steps): a matrix-core instruction that accumulates onto the result of
             // the previous one waits for it (~2x its issue time, measured), two independent chains do not
