@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 K_COMP, P_FEAT, BATCH, CHUNK, BLOCK = 256, 10000, 256, 65536, 8192
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
-PMC_FILES = ('r05_pmc_hbm_traffic.json', 'r04_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic.json')     # the newest committed PMC passes
+PMC_FILES = ('r06_pmc_hbm_traffic.json', 'r05_pmc_hbm_traffic.json', 'r04_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic.json')     # the newest committed PMC passes
 DOM_KERNEL = {'dict_update': ('modl::bcd_persist_kernel', 'modl::bcd_block_kernel'), 'code_solve': 'modl::cd_split_kernel', 'stats_gemm': 'modl::gemm_stats_pair_kernel',
               'code_gemm': 'modl::gemm_dense_pair_kernel<float, false', 'stats_apply': 'modl::stats_apply2_kernel'}
 # the calibration of the CPU port against the real reference, measured in the build container
