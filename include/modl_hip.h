@@ -85,6 +85,7 @@ const char *modl_error_string(int code);
 #define MODL_DEBUG_RECSYS_FUSED 11    /* 1 (default): a masked minibatch of RecsysDictFact with at most 64 (f64: 56) atoms and 64 rows runs its codes (rating chunks of 128, ticketed fixed-order sums, Cholesky) and C_ as ONE launch (csrc/recsys.hip: recsys_fused_kernel), B_ and the blocked dictionary update as launches of their own behind it; 2: B_ and the dictionary sweep inside that launch when one workgroup holds every touched item (512 in registers + what fits LDS), 3: the same without the LDS tier, 4: the sweep also on up to four workgroups that exchange an atom's sums through memory (all three measured slower, kept selectable and tested); 0: the separate launches of rounds 2-5 for everything */
 #define MODL_DEBUG_ATOM_MWG 12        /* 1 (default): the l1 projection of an atom with more than 6144 and at most 16 384 sampled features (one launch per atom: the reference's HCP configuration) is spread over the launch's workgroups - an element per thread, a memory round trip per Michelot pass (csrc/bcd.hip: mwg_l1_project); 0: the launch's last workgroup projects the whole vector from LDS; diagnostics library: 2 = as 1 with a workgroup that withholds its sums (the attempt gives up and the last workgroup projects: the fallback path) */
 #define MODL_DEBUG_BCD_FEW 13         /* 1 (default): the f64 blocked dictionary update of 193 to 2048 sampled features runs as ONE launch on up to sixteen workgroups of 128 features that exchange a block's Gram record through memory (csrc/bcd.hip: bcd_few_kernel); 0: four launches per block of 32 atoms */
+#define MODL_DEBUG_ATOM_PIPE 14       /* 1 (default): in the per-atom sweep of MODL_DEBUG_ATOM_MWG the gradient rows of the NEXT group of four atoms are formed by workgroups riding on the launches of this group's atoms (against the dictionary as it is then; what this group changes is subtracted afterwards from its compact rows - csrc/bcd.hip: atom_corr_project_kernel, GradRide); 0: a gradient launch of its own between two groups */
 int modl_debug_set(int what, int64_t value);
 /* 1 in libmodl_hip_diag.so (built with -DMODL_DIAG: the same sources plus the A/B-only kernel variants and the stamp
  * switches), 0 in the product library */

@@ -24,6 +24,7 @@ DEBUG_STATS_RESIDENT = 10
 DEBUG_RECSYS_FUSED = 11
 DEBUG_ATOM_MWG = 12
 DEBUG_BCD_FEW = 13
+DEBUG_ATOM_PIPE = 14
 AGG = {'masked': 0, 'full': 1, 'average': 2}
 OPT = {'variational': 0, 'sgd': 1}
 

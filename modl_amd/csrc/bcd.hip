@@ -43,7 +43,7 @@ std::atomic<int> g_bcd_tiny{1};
 std::atomic<int> g_bcd_persist{1};
 
 struct DuLayout {
-    size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, off_BsP, off_gpartial, off_norm_in, off_pacc, off_prec, off_Sbuf, off_pflags, off_qcoef, off_pstamps, off_few, total;
+    size_t off_CP, off_cdiag, off_frozen, off_coef, off_a, off_partial, off_Tp, off_u, off_pold, off_Dnew, off_colp, off_BsP, off_gpartial, off_norm_in, off_pacc, off_prec, off_Sbuf, off_pflags, off_qcoef, off_pstamps, off_few, off_pipe, total;
     int64_t nslab_max, nwg_grad;
 };
 
@@ -55,6 +55,7 @@ constexpr int kFewRec = kNB * kNB + kNB;             // a Gram record: the 32 x 
 constexpr long long kFewSentinel = 0x7ff8feed7ff8feedll;   // what an exchange slot holds until its record arrives (a NaN no sum produces)
 std::atomic<int> g_bcd_few{1};                       // modl_debug_set(MODL_DEBUG_BCD_FEW, ...)
 
+constexpr int64_t kPipeMinRows = 24 * 256;           // (= kProjEpt * 256: beyond the register-resident projection)
 static int64_t atom_row_stride(int64_t s) { return s <= 12 * 256 ? 12 * 256 : (s <= 20 * 256 ? 20 * 256 : 24 * 256); }
 
 static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
@@ -94,6 +95,9 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     // the f64 update of a few hundred to two thousand sampled features on several workgroups (bcd_few_kernel): three exchange
     // slots of kFewMaxWg Gram records + the launch's error word
     L.off_few = take(tsz == 8 ? sizeof(double) * 3 * (size_t)kFewMaxWg * kFewRec + 64 : 0);
+    // the pipelined per-atom sweep of large sampled sets (atom_corr_project_kernel, round 6): two staged groups of four atoms, three
+    // sets of old values, two sets of f64 numerators (the sets are s-strided inside; s <= s_max)
+    L.off_pipe = take(s_max > kPipeMinRows ? align_up(tsz * (size_t)5 * 4 * (size_t)s_max, 16) + sizeof(double) * (size_t)2 * 4 * (size_t)s_max : 0);
     L.total = o;
     return L;
 }
@@ -1495,13 +1499,14 @@ template <int G> struct AtomGroupN { int j[G]; int n; };
 constexpr int kStepGroup = 4;
 // (1) the group's gradient rows: numerators and old values of all its atoms, the old-norm partial sums, and the rows of
 // the group BEFORE put where they belong
+// vblock of nvblocks: the workgroup's place in the gradient launch's grid (a launch of its own: blockIdx.x of gridDim.x; riding on
+// the launches of the group before, round 6: a quarter of the virtual grid per launch)
 template <typename T, int KPL>
-__global__ __launch_bounds__(256) void atom_grad4_kernel(T *Dt, const T *Bt, const T *C, const int32_t *subset, int64_t s, int k,
-                                                         AtomGroupN<kStepGroup> g, AtomGroupN<kStepGroup> gp, const T *stage_prev,
-                                                         double rho, double *num, T *dold, int64_t ldr, double *partial_old,
-                                                         int part_stride) {
+__device__ __forceinline__ void atom_grad4_body(T *Dt, const T *Bt, const T *C, const int32_t *subset, int64_t s, int k,
+                                                const AtomGroupN<kStepGroup> &g, const AtomGroupN<kStepGroup> &gp, const T *stage_prev,
+                                                double rho, double *num, T *dold, int64_t ldr, double *partial_old,
+                                                int part_stride, int vblock, int nvblocks, double (*s_oldw)[kStepGroup]) {
     constexpr int G = kStepGroup;
-    __shared__ double s_oldw[4][G];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int ja[G];
     T cc[G][KPL], Cjj[G];
@@ -1519,8 +1524,8 @@ __global__ __launch_bounds__(256) void atom_grad4_kernel(T *Dt, const T *Bt, con
     double old = 0;                                                 // lane b: atom b
     const int nwv = (int)(blockDim.x >> 6);
     constexpr int kRows = 2;                                        // (2 x (KPL + 3 G) loads in flight at KPL = 16)
-    const int64_t fstride = (int64_t)gridDim.x * nwv;
-    for (int64_t fb = (int64_t)blockIdx.x * nwv + wid; fb < s; fb += fstride * kRows) {
+    const int64_t fstride = (int64_t)nvblocks * nwv;
+    for (int64_t fb = (int64_t)vblock * nwv + wid; fb < s; fb += fstride * kRows) {
         int64_t r[kRows];
 #pragma unroll
         for (int q = 0; q < kRows; ++q) {
@@ -1579,9 +1584,31 @@ __global__ __launch_bounds__(256) void atom_grad4_kernel(T *Dt, const T *Bt, con
     if (lane < G) s_oldw[wid][lane] = old;
     __syncthreads();
     if (threadIdx.x < G)
-        partial_old[(int64_t)threadIdx.x * part_stride + blockIdx.x] =
+        partial_old[(int64_t)threadIdx.x * part_stride + vblock] =
             (s_oldw[0][threadIdx.x] + s_oldw[1][threadIdx.x]) + (s_oldw[2][threadIdx.x] + s_oldw[3][threadIdx.x]);
 }
+
+template <typename T, int KPL>
+__global__ __launch_bounds__(256) void atom_grad4_kernel(T *Dt, const T *Bt, const T *C, const int32_t *subset, int64_t s, int k,
+                                                         AtomGroupN<kStepGroup> g, AtomGroupN<kStepGroup> gp, const T *stage_prev,
+                                                         double rho, double *num, T *dold, int64_t ldr, double *partial_old,
+                                                         int part_stride) {
+    __shared__ double s_oldw[4][kStepGroup];
+    atom_grad4_body<T, KPL>(Dt, Bt, C, subset, s, k, g, gp, stage_prev, rho, num, dold, ldr, partial_old, part_stride, (int)blockIdx.x,
+                            (int)gridDim.x, s_oldw);
+}
+
+// The gradient rows of the NEXT group riding on a launch of this group's atoms (round 6, the pipelined sweep below): workgroups
+// beyond the launch's own do the part [vb0, vb0 + their number) of that group's gradient launch.
+template <typename T> struct GradRide {
+    const T *Bt;
+    AtomGroupN<kStepGroup> gn, gfold;     // the group whose numerators are formed; the finished group whose rows are put home on the way
+    const T *stage_fold;
+    double *num;
+    T *dold;
+    double *pold;
+    int part_stride, vb0, nvb;
+};
 
 // (2) one atom of the group: its candidate from the stored numerator minus what the atoms before it in the group changed (a
 // thread per feature), then the last workgroup to arrive projects from LDS (atom_project) and leaves the compact row.
@@ -1609,6 +1636,7 @@ constexpr int kMwgWords = (kMwgMaxPass + 1) * 2 * kMwgMaxWg;          // doubles
 constexpr unsigned int kMwgSentinel32 = 0x7ff8deadu;                  // both halves of the sentinel (a NaN): hipMemsetD32Async fills it
 constexpr long long kMwgSentinel = ((long long)kMwgSentinel32 << 32) | kMwgSentinel32;
 std::atomic<int> g_atom_mwg{1};                                       // modl_debug_set(MODL_DEBUG_ATOM_MWG, ...)
+std::atomic<int> g_atom_pipe{1};                                      // modl_debug_set(MODL_DEBUG_ATOM_PIPE, ...): 0 = a gradient launch per group
 
 __device__ __forceinline__ void mwg_store(double *ptr, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(ptr), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
@@ -1620,9 +1648,9 @@ __device__ __forceinline__ double mwg_load(const double *ptr) {
 }
 // the launch-wide sums of (S, cnt); false: a wait gave up.  red: >= 24 doubles of LDS.  Called by every thread (256).
 __device__ __forceinline__ bool mwg_sum2(double &S, double &cnt, double *xb, int slot, unsigned int *abort_word, double *red,
-                                         bool withhold = false) {
+                                         int nwg, bool withhold = false) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int nwg = (int)gridDim.x, wg = (int)blockIdx.x;
+    const int wg = (int)blockIdx.x;                              // (nwg: the workgroups that take part - a launch may carry riders)
     S = wave_sum(S);
     cnt = wave_sum(cnt);
     if (lane == 0) { red[2 * wid] = S; red[2 * wid + 1] = cnt; }
@@ -1666,7 +1694,7 @@ __device__ __forceinline__ bool mwg_sum2(double &S, double &cnt, double *xb, int
 // vector (every workgroup has it), level_out / searched = the level the search ended at.
 template <typename T>
 __device__ __forceinline__ bool mwg_l1_project(T x, double radius, double l_prev, double *xb, unsigned int *abort_word, double *red,
-                                               T &out, double &nrm, double &level_out, bool &searched, bool withhold) {
+                                               T &out, double &nrm, double &level_out, bool &searched, bool withhold, int nwg) {
     searched = false;
     level_out = 0.0;
     if (!(radius > 0.0)) {                                   // enet.pyx:57-59 (radius == 0 -> zeros); the same on every workgroup
@@ -1681,7 +1709,7 @@ __device__ __forceinline__ bool mwg_l1_project(T x, double radius, double l_prev
     auto scan = [&](double lv) {
         S = a > lv ? a : 0.0;
         cnt = a > lv ? 1.0 : 0.0;
-        return mwg_sum2(S, cnt, xb, slot++, abort_word, red, withhold);
+        return mwg_sum2(S, cnt, xb, slot++, abort_word, red, nwg, withhold);
     };
     // warm start: the level the atom ended with at the previous minibatch ITSELF - f(l) = sum_{|x| > l} (|x| - l) - R is convex and
     // decreasing, so the Newton step that Michelot's update is lands at or left of the root from EITHER side and the iteration
@@ -1713,12 +1741,12 @@ __device__ __forceinline__ bool mwg_l1_project(T x, double radius, double l_prev
         pos = pos > 0 ? pos : 0;
         out = (T)(((double)x >= 0) ? pos : -pos);            // enet.pyx:121, sign(0) = +1
         double mine = fabs((double)out), dummy = 0.0;
-        if (!mwg_sum2(mine, dummy, xb, kMwgMaxPass, abort_word, red)) return false;
+        if (!mwg_sum2(mine, dummy, xb, kMwgMaxPass, abort_word, red, nwg)) return false;
         total = mine;
     } else {
         out = x;
         double mine = 0.0, dummy = 0.0;                      // (the last slot is the "everybody is done" exchange in every case)
-        if (!mwg_sum2(mine, dummy, xb, kMwgMaxPass, abort_word, red)) return false;
+        if (!mwg_sum2(mine, dummy, xb, kMwgMaxPass, abort_word, red, nwg)) return false;
     }
     nrm = total;
     level_out = level;
@@ -1726,17 +1754,34 @@ __device__ __forceinline__ bool mwg_l1_project(T x, double radius, double l_prev
     return true;
 }
 
-template <typename T>
+// Round 6, the PIPELINED sweep (KPL > 0): the gradient launch of group g + 1 (25 us: one read of the 41 MB sampled dictionary)
+// used to sit between the last atom of group g and the first of group g + 1, with 217 of the 256 compute units idle during the
+// 4 x 22 us of atom launches around it.  Now it RIDES on those launches: nride workgroups beyond the launch's own nwg_main do a
+// quarter of it each (atom_grad4_body on a part of its virtual grid).  They read the dictionary as it is while group g is still
+// being projected, so what group g changes is missing from group g + 1's numerators as well: the launches of group g + 1
+// subtract it with the same identity that handles their own group, from the PREVIOUS group's compact rows (gprev, stage_prev,
+// dold_prev).  The riders put the rows of group g - 1 home (the newest finished one), so the host flushes the last TWO groups.
+template <typename T, int KPL>
 __global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *C, const int32_t *subset, int64_t s, int k,
                                                                 AtomGroupN<kStepGroup> g, int a, int pos, double rho, T *u,
                                                                 const double *num, const T *dold, T *stage_cur, int64_t ldr,
                                                                 const double *partial_old, int part_stride, T *comp_norm,
                                                                 unsigned int *counter, unsigned long long *dbg, double *level_hint,
-                                                                double *xch, unsigned int *xabort, int parity) {
+                                                                double *xch, unsigned int *xabort, int parity, int nwg_main,
+                                                                AtomGroupN<kStepGroup> gprev, const T *stage_prev, const T *dold_prev,
+                                                                GradRide<T> ride) {
     constexpr int G = kStepGroup;
     extern __shared__ __attribute__((aligned(16))) char step_smem[];   // the s-vector for the projection
     __shared__ double red[32];
     __shared__ int flag;
+    if constexpr (KPL > 0) {
+        __shared__ double s_oldw[4][G];
+        if ((int)blockIdx.x >= nwg_main) {
+            atom_grad4_body<T, KPL>(Dt, ride.Bt, C, subset, s, k, ride.gn, ride.gfold, ride.stage_fold, rho, ride.num, ride.dold, ldr,
+                                    ride.pold, ride.part_stride, ride.vb0 + (int)blockIdx.x - nwg_main, ride.nvb, s_oldw);
+            return;
+        }
+    }
     const unsigned long long t0 = clock64();
     const int j = g.j[a];
     if (xch) {
@@ -1744,24 +1789,37 @@ __global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *
         double *xb = xch + (size_t)(parity & 1) * kMwgWords;
         {   // the buffer of the NEXT launch back to sentinels (its last user was the launch before this one)
             long long *xo = reinterpret_cast<long long *>(xch + (size_t)((parity & 1) ^ 1) * kMwgWords);
-            const int per = (kMwgWords + (int)gridDim.x - 1) / (int)gridDim.x;
+            const int per = (kMwgWords + nwg_main - 1) / nwg_main;
             for (int e = (int)blockIdx.x * per + threadIdx.x; e < ((int)blockIdx.x + 1) * per && e < kMwgWords; e += 256) xo[e] = kMwgSentinel;
         }
         const double cjj = (double)C[(int64_t)j * k + j];
         const bool frozen = !((T)cjj > (T)1e-20);
-        double cb[G];
+        double cb[G], cp[G];
 #pragma unroll
         for (int b = 0; b < G; ++b) cb[b] = (b < a) ? (double)C[(int64_t)g.j[b] * k + j] : 0.0;
+#pragma unroll
+        for (int b = 0; b < G; ++b) cp[b] = (KPL > 0 && b < gprev.n) ? (double)C[(int64_t)gprev.j[b] * k + j] : 0.0;
         const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
         const int64_t fc = f < s ? f : s - 1;
         double x = num[(int64_t)a * ldr + fc];
         const T dj = dold[(int64_t)a * ldr + fc];
-        T sn[G], so[G];
+        T sn[G], so[G], pn[G], po[G];
 #pragma unroll
         for (int b = 0; b < G; ++b) {
             const int bc = b < a ? b : 0;
             sn[b] = stage_cur[(int64_t)bc * ldr + fc];
             so[b] = dold[(int64_t)bc * ldr + fc];
+        }
+        if constexpr (KPL > 0) {
+#pragma unroll
+            for (int b = 0; b < G; ++b) {                            // (pipelined sweep: what the group before changed)
+                const int bc = b < gprev.n ? b : 0;
+                pn[b] = stage_prev[(int64_t)bc * ldr + fc];
+                po[b] = dold_prev[(int64_t)bc * ldr + fc];
+            }
+#pragma unroll
+            for (int b = 0; b < G; ++b)
+                if (b < gprev.n) x -= cp[b] * ((double)pn[b] - (double)po[b]);
         }
         // radius = the budget + the atom's old norm on the sampled features: the partial sums of the group's gradient launch,
         // summed by every workgroup in the same order (block_sum2: fixed association)
@@ -1787,7 +1845,7 @@ __global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *
         const bool withhold = false;
 #endif
         const unsigned long long t1 = clock64();
-        const bool ok = mwg_l1_project<T>(val, radius, lprev, xb, xabort, red, outv, nrm, level, searched, withhold);
+        const bool ok = mwg_l1_project<T>(val, radius, lprev, xb, xabort, red, outv, nrm, level, searched, withhold, nwg_main);
         const unsigned long long t2 = clock64();
         if (ok) {
             if (f < s) stage_cur[(int64_t)a * ldr + f] = outv;
@@ -1798,7 +1856,7 @@ __global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *
         }
         if (dbg && blockIdx.x == 0 && threadIdx.x == 0) { dbg[8] = t0; dbg[9] = t1; dbg[10] = t2; dbg[11] = clock64(); dbg[12] = (unsigned long long)red[19]; }
         // every workgroup arrives; the last one looks at the abort word and, if it is raised, projects everything the old way
-        if (!arrive_last(counter, gridDim.x, &flag)) return;
+        if (!arrive_last(counter, (unsigned)nwg_main, &flag)) return;
         if (__hip_atomic_load(xabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
         if (threadIdx.x == 0) __hip_atomic_store(xabort, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atom_project<T, false>(u, reinterpret_cast<T *>(step_smem), partial_old + (int64_t)a * part_stride, part_stride, Dt, subset, s, k, j,
@@ -1811,7 +1869,7 @@ __global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *
     double cb[G];
 #pragma unroll
     for (int b = 0; b < G; ++b) cb[b] = (b < a) ? (double)C[(int64_t)g.j[b] * k + j] : 0.0;
-    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < s; f += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < s; f += (int64_t)nwg_main * blockDim.x) {
         double x = num[(int64_t)a * ldr + f];
         const T dj = dold[(int64_t)a * ldr + f];
         T sn[G], so[G];
@@ -1830,7 +1888,7 @@ __global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *
         u[f] = val;
     }
     const unsigned long long t1 = clock64();
-    if (!arrive_last(counter, gridDim.x, &flag)) return;
+    if (!arrive_last(counter, (unsigned)nwg_main, &flag)) return;
     const unsigned long long t2 = clock64();
     atom_project<T, false>(u, reinterpret_cast<T *>(step_smem), partial_old + (int64_t)a * part_stride, part_stride, Dt, subset, s, k, j,
                            rho, comp_norm, red, dbg, level_hint, stage_cur + (int64_t)a * ldr);
@@ -2826,6 +2884,89 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
         AtomGroupN<G> g, gp;
         gp.n = 0;
         for (int b = 0; b < G; ++b) gp.j[b] = 0;
+        GradRide<T> no_ride{};
+        // ---- the pipelined sweep (round 6; atom_corr_project_kernel): the gradient launch of group g + 1 rides on the atom launches of
+        // group g.  Scratch of its own (DuLayout::off_pipe): two staged groups, THREE sets of old values
+        // (the riders write group g + 1's while the launches of group g still read group g - 1's), two sets of numerators and of
+        // old-norm partial sums.
+        const int ngroups = (int)cdiv(k, G);
+        static_assert(G == 4 && kPipeMinRows == (int64_t)kProjEpt * 256, "du_layout sizes off_pipe for groups of four");
+        const bool pipelined = mwg && ngroups >= 2 && g_atom_pipe.load(std::memory_order_relaxed) != 0 && s > kPipeMinRows &&
+                               (int64_t)2 * G * nwg <= L.nwg_grad;
+        if (pipelined) {
+            T *pb = reinterpret_cast<T *>(ws + L.off_pipe);
+            T *pstage[2] = {pb, pb + (size_t)G * ldr};
+            T *pdold[3] = {pb + (size_t)2 * G * ldr, pb + (size_t)3 * G * ldr, pb + (size_t)4 * G * ldr};
+            double *pnum0 = reinterpret_cast<double *>(ws + L.off_pipe + align_up(sizeof(T) * (size_t)5 * G * ldr, 16));
+            double *pnum[2] = {pnum0, pnum0 + (size_t)G * ldr};
+            double *ppold[2] = {pold, pold + (size_t)G * nwg};
+            auto group_of = [&](int gi_, AtomGroupN<G> &out) -> bool {
+                const int t0 = gi_ * G;
+                out.n = (k - t0 < G) ? k - t0 : G;
+                for (int b = 0; b < G; ++b) {
+                    out.j[b] = (int)h_order[t0 + (b < out.n ? b : 0)];
+                    if (out.j[b] < 0 || out.j[b] >= k) return false;
+                }
+                return true;
+            };
+            AtomGroupN<G> none;
+            none.n = 0;
+            for (int b = 0; b < G; ++b) none.j[b] = 0;
+            AtomGroupN<G> gcur, gnext, gprev = none;
+            if (!group_of(0, gcur)) return MODL_EINVAL;
+#define MODL_GRAD4(KPL)                                                                                               \
+    hipLaunchKernelGGL((atom_grad4_kernel<T, KPL>), dim3(nwg), dim3(256), 0, stream, a.Dt, a.Bt, a.C, a.subset, s, k, gcur, none,     \
+                       (const T *)pstage[1], a.comp_l1_ratio, pnum[0], pdold[0], ldr, ppold[0], nwg)
+            if (k <= 64) MODL_GRAD4(1);
+            else if (k <= 128) MODL_GRAD4(2);
+            else if (k <= 256) MODL_GRAD4(4);
+            else if (k <= 512) MODL_GRAD4(8);
+            else MODL_GRAD4(16);
+#undef MODL_GRAD4
+            MODL_LAUNCH_CHECK();
+            for (int gi = 0; gi < ngroups; ++gi) {
+                const bool has_next = gi + 1 < ngroups;
+                if (has_next && !group_of(gi + 1, gnext)) return MODL_EINVAL;
+                for (int ai = 0; ai < gcur.n; ++ai) {
+                    GradRide<T> ride{};
+                    int nride = 0;
+                    if (has_next) {                                       // (then this group is a full one: G launches, a part each)
+                        const int lo = (int)((int64_t)ai * nwg / G), hi = (int)((int64_t)(ai + 1) * nwg / G);
+                        nride = hi - lo;
+                        ride.Bt = a.Bt; ride.gn = gnext; ride.gfold = gprev; ride.stage_fold = pstage[(gi + 1) & 1];
+                        ride.num = pnum[(gi + 1) & 1]; ride.dold = pdold[(gi + 1) % 3]; ride.pold = ppold[(gi + 1) & 1];
+                        ride.part_stride = nwg; ride.vb0 = lo; ride.nvb = nwg;
+                    }
+#define MODL_CORR(KPL)                                                                                                            \
+    hipLaunchKernelGGL((atom_corr_project_kernel<T, KPL>), dim3(nwg_corr + nride), dim3(256), u_lds, stream, a.Dt, a.C, a.subset, s, k,       \
+                       gcur, ai, a.comp_pos, a.comp_l1_ratio, u, (const double *)pnum[gi & 1], (const T *)pdold[gi % 3], pstage[gi & 1], ldr,  \
+                       (const double *)ppold[gi & 1], nwg, a.comp_norm, counter,                                                                \
+                       reinterpret_cast<unsigned long long *>(counter + kCounters), a.level_hint, xch, xabort,                                 \
+                       (int)(launch_no++ & 1) | (g_atom_mwg.load(std::memory_order_relaxed) == 2 ? 2 : 0), nwg_corr, gprev,                    \
+                       (const T *)pstage[(gi + 1) & 1], (const T *)pdold[(gi + 2) % 3], ride)
+                    if (k <= 64) MODL_CORR(1);
+                    else if (k <= 128) MODL_CORR(2);
+                    else if (k <= 256) MODL_CORR(4);
+                    else if (k <= 512) MODL_CORR(8);
+                    else MODL_CORR(16);
+#undef MODL_CORR
+                    MODL_LAUNCH_CHECK();
+                }
+                if (has_next) { gprev = gcur; gcur = gnext; }
+            }
+            // home: the last two groups (the riders of a group's launches put the group BEFORE it home; the last group has none)
+            int nflush = 0;
+            for (int gi = ngroups - 2; gi < ngroups; ++gi) {
+                const AtomGroupN<G> &gf = (gi == ngroups - 1) ? gcur : gprev;
+                for (int b = 0; b < gf.n; ++b, ++nflush) {
+                    hipLaunchKernelGGL((atom_stage_flush_kernel<T>), dim3((unsigned)cdiv(s, 256)), dim3(256), 0, stream, a.Dt, a.subset, s, k,
+                                       gf.j[b], (const T *)(pstage[gi & 1] + (size_t)b * ldr));
+                    MODL_LAUNCH_CHECK();
+                }
+            }
+            if (launches) *launches += k + 1 + nflush;
+            return MODL_OK;
+        }
         int gi = 0;
         for (int t0 = 0; t0 < k; t0 += G, ++gi) {
             g.n = (k - t0 < G) ? k - t0 : G;
@@ -2844,12 +2985,13 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
 #undef MODL_GRAD4
             MODL_LAUNCH_CHECK();
             for (int ai = 0; ai < g.n; ++ai) {
-                hipLaunchKernelGGL((atom_corr_project_kernel<T>), dim3(nwg_corr), dim3(256), u_lds, stream, a.Dt, a.C, a.subset, s, k,
+                hipLaunchKernelGGL((atom_corr_project_kernel<T, 0>), dim3(nwg_corr), dim3(256), u_lds, stream, a.Dt, a.C, a.subset, s, k,
                                    g, ai, a.comp_pos, a.comp_l1_ratio, u, (const double *)num, (const T *)dold, stage[gi & 1], ldr,
                                    (const double *)pold, nwg, a.comp_norm, counter,
                                    reinterpret_cast<unsigned long long *>(counter + kCounters), a.level_hint,
                                    mwg ? xch : nullptr, xabort,
-                                   (int)(launch_no++ & 1) | (g_atom_mwg.load(std::memory_order_relaxed) == 2 ? 2 : 0));
+                                   (int)(launch_no++ & 1) | (g_atom_mwg.load(std::memory_order_relaxed) == 2 ? 2 : 0), nwg_corr, gp,
+                                   (const T *)nullptr, (const T *)nullptr, no_ride);
                 MODL_LAUNCH_CHECK();
             }
             gp = g;

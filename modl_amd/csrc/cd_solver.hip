@@ -522,6 +522,7 @@ extern std::atomic<int> g_stats_resident;               // somf_step.hip
 extern std::atomic<int> g_recsys_fused;                 // recsys.hip
 extern std::atomic<int> g_atom_mwg;                     // bcd.hip
 extern std::atomic<int> g_bcd_few;                      // bcd.hip
+extern std::atomic<int> g_atom_pipe;                    // bcd.hip
 extern std::atomic<int> g_stage_ahead;                  // somf_step.hip
 
 template <typename T>
@@ -727,6 +728,10 @@ extern "C" int modl_debug_set(int what, int64_t value) {
     }
     if (what == MODL_DEBUG_BCD_FEW) {
         modl::g_bcd_few.store((int)value, std::memory_order_relaxed);
+        return MODL_OK;
+    }
+    if (what == MODL_DEBUG_ATOM_PIPE) {
+        modl::g_atom_pipe.store((int)value, std::memory_order_relaxed);
         return MODL_OK;
     }
     if (what == MODL_DEBUG_ATOM_MWG) {

@@ -208,7 +208,7 @@ def test_debug_switch_numbers_match_the_header(lib):
     for name, value in defs.items():
         if hasattr(_lib, name):
             assert getattr(_lib, name) == value, name
-    defaults = {'DEBUG_CD_SPARSE_PCT': -1, 'DEBUG_CD_SPLIT': 1, 'DEBUG_BCD_ACC': 1, 'DEBUG_BCD_TINY': 1, 'DEBUG_STAGE_AHEAD': 1, 'DEBUG_BCD_PERSIST': 1, 'DEBUG_STATS_RESIDENT': 1, 'DEBUG_RECSYS_FUSED': 1, 'DEBUG_ATOM_MWG': 1, 'DEBUG_BCD_FEW': 1,
+    defaults = {'DEBUG_CD_SPARSE_PCT': -1, 'DEBUG_CD_SPLIT': 1, 'DEBUG_BCD_ACC': 1, 'DEBUG_BCD_TINY': 1, 'DEBUG_STAGE_AHEAD': 1, 'DEBUG_BCD_PERSIST': 1, 'DEBUG_STATS_RESIDENT': 1, 'DEBUG_RECSYS_FUSED': 1, 'DEBUG_ATOM_MWG': 1, 'DEBUG_BCD_FEW': 1, 'DEBUG_ATOM_PIPE': 1,
                 'DEBUG_CD_STAMPS': 0, 'DEBUG_ATOM_STAMPS': 0}
     assert set(defaults) == set(defs)
     # the product library only has switches between CORRECT code paths: the stamp switches (they write to a

@@ -1281,58 +1281,70 @@ _MWG_SCRIPT = r"""
 import json, sys
 import numpy as np
 from modl_amd import DictFact
-from modl_amd._lib import lib, check, DEBUG_ATOM_MWG
+from modl_amd._lib import lib, check, DEBUG_ATOM_MWG, DEBUG_ATOM_PIPE
 dtype = np.float32 if sys.argv[1] == 'f32' else np.float64
 pos = bool(int(sys.argv[2]))
 rs = np.random.RandomState(11)
-n, p, k, b = 96, 15000, 12, 32
+n, p, k, b = 96, 15000, int(sys.argv[4]), 32
 X = (np.abs(rs.randn(n, 10)).dot(np.abs(rs.randn(10, p))) + 0.2 * rs.randn(n, p)).astype(dtype)
 kw = dict(n_components=k, batch_size=b, reduction=2, code_alpha=0.05, code_l1_ratio=0, comp_l1_ratio=1, comp_pos=pos, random_state=0,
           learning_rate=0.9)
 out = {}
-for v in (1, 0, 2):                                   # spread over the launch / the last workgroup alone / the spread attempt gives up
+# (projection, gradient rows): spread over the launch / the last workgroup alone / the spread attempt gives up;
+# the next group's gradient rows riding on this group's launches (1) or a launch of their own (0)
+for v, pipe in ((1, 1), (1, 0), (0, 0), (2, 0), (2, 1)):
     check(lib.modl_debug_set(DEBUG_ATOM_MWG, v))
+    check(lib.modl_debug_set(DEBUG_ATOM_PIPE, pipe))
     est = DictFact(**kw)
     est.prepare(n_samples=n, X=X)
     est.partial_fit(X, np.arange(n))
-    out[v] = dict(D=est.components_.astype(np.float64), cn=est.comp_norm_.astype(np.float64))
+    out[(v, pipe)] = dict(D=est.components_.astype(np.float64), cn=est.comp_norm_.astype(np.float64))
 check(lib.modl_debug_set(DEBUG_ATOM_MWG, 1))
-np.savez(sys.argv[3], D1=out[1]['D'], D0=out[0]['D'], D2=out[2]['D'], cn1=out[1]['cn'], cn0=out[0]['cn'], cn2=out[2]['cn'], X=X)
+check(lib.modl_debug_set(DEBUG_ATOM_PIPE, 1))
+np.savez(sys.argv[3], X=X, **{'%s%d%d' % (name, v, pipe): o[name] for (v, pipe), o in out.items() for name in ('D', 'cn')})
 print(json.dumps(dict(ok=True)))
 """
 
 
-@pytest.mark.parametrize('dt,pos', [('f32', 1), ('f64', 1), ('f64', 0)])
-def test_l1_projection_spread_over_the_launch(tmp_path, dt, pos):
+@pytest.mark.parametrize('dt,pos,k', [('f32', 1, 12), ('f64', 1, 12), ('f64', 0, 12), ('f64', 1, 14), ('f32', 0, 7)])
+def test_l1_projection_spread_over_the_launch(tmp_path, dt, pos, k):
     """Round 6: with more than 6144 sampled features (one launch per atom: the shape class of the reference's HCP run) the l1
     projection of an atom is no longer the work of the launch's last workgroup - every thread of the launch keeps its element and
-    a Michelot pass is one exchange of sums through memory (csrc/bcd.hip: mwg_l1_project).  Against the old path
+    a Michelot pass is one exchange of sums through memory (csrc/bcd.hip: mwg_l1_project) - and the gradient rows of the next
+    group of four atoms ride on the launches of this group's atoms (MODL_DEBUG_ATOM_PIPE; what this group changes is subtracted
+    afterwards, the last two groups are put home at the end; k = 14 and 7: a short last group).  Against the old path
     (MODL_DEBUG_ATOM_MWG = 0), against a run in which a workgroup withholds its sums (diagnostics build, = 2: every wait gives up,
-    the abort word is raised and the last workgroup projects the candidates alone - the results must be the old path's BIT FOR BIT)
-    and against the oracle: 7500 sampled features of 15 000, l1 atoms with and without positivity."""
+    the abort word is raised and the last workgroup projects the candidates alone - with a gradient launch per group the results
+    must be the old path's BIT FOR BIT, with the riding rows they must be the pipelined run's to rounding) and against the oracle:
+    7500 sampled features of 15 000, l1 atoms with and without positivity."""
     from oracle import somf_oracle as orc
     from .conftest import assert_within_f32_noise
     f = str(tmp_path / 'mwg.npz')
-    _run_diag_script(_MWG_SCRIPT, dt, str(pos), f)
+    _run_diag_script(_MWG_SCRIPT, dt, str(pos), f, str(k))
     z = np.load(f)
-    assert np.array_equal(z['D2'], z['D0']) and np.array_equal(z['cn2'], z['cn0'])       # the fallback IS the old path
+    assert np.array_equal(z['D20'], z['D00']) and np.array_equal(z['cn20'], z['cn00'])       # the fallback IS the old path
     X = z['X']
-    n, k, b = X.shape[0], 12, 32
+    n, b = X.shape[0], 32
     kw = dict(n_components=k, batch_size=b, reduction=2, code_alpha=0.05, code_l1_ratio=0, comp_l1_ratio=1, comp_pos=bool(pos),
               random_state=0, learning_rate=0.9)
     pr = orc.SomfParams(**kw)
     st64 = orc.prepare(pr, n_samples=n, X=X.astype(np.float64))
     orc.partial_fit(st64, pr, X.astype(np.float64), np.arange(n))
     if dt == 'f64':
-        assert rel_fro(z['D1'], z['D0']) < 1e-10
-        assert rel_fro(z['D1'], st64.D) < 1e-8 and rel_fro(z['D0'], st64.D) < 1e-8
+        for name in ('D11', 'D10', 'D21'):
+            assert rel_fro(z[name], z['D00']) < 1e-10, name
+            assert rel_fro(z[name], st64.D) < 1e-8, name
+        assert rel_fro(z['D00'], st64.D) < 1e-8
+        assert np.allclose(z['cn11'], z['cn00'], rtol=0, atol=1e-9) and np.allclose(z['cn21'], z['cn00'], rtol=0, atol=1e-9)
     else:
         st32 = orc.prepare(pr, n_samples=n, X=X)
         orc.partial_fit(st32, pr, X, np.arange(n))
-        assert_within_f32_noise(z['D1'], st32.D, st64.D, 'dictionary, projection spread over the launch')
-        assert_within_f32_noise(z['D0'], st32.D, st64.D, 'dictionary, last workgroup')
+        assert_within_f32_noise(z['D11'], st32.D, st64.D, 'dictionary, projection spread over the launch, riding gradient rows')
+        assert_within_f32_noise(z['D10'], st32.D, st64.D, 'dictionary, projection spread over the launch')
+        assert_within_f32_noise(z['D21'], st32.D, st64.D, 'dictionary, riding gradient rows, the spread attempt gives up')
+        assert_within_f32_noise(z['D00'], st32.D, st64.D, 'dictionary, last workgroup')
     if pos:
-        assert (z['D1'] >= 0).all()
+        assert (z['D11'] >= 0).all() and (z['D21'] >= 0).all()
 
 
 @pytest.mark.parametrize('r', [10, 1])
