@@ -1607,7 +1607,8 @@ template <typename T> struct GradRide {
     double *num;
     T *dold;
     double *pold;
-    int part_stride, vb0, nvb;
+    int part_stride, vb0, nvb, nride;     // nride riders do the workgroups [vb0, vb0 + nride) of the gradient launch's nvb
+    int ept;                              // elements per thread of the launch's own workgroups (1, or 2: half as many workgroups)
 };
 
 // (2) one atom of the group: its candidate from the stored numerator minus what the atoms before it in the group changed (a
@@ -1646,11 +1647,13 @@ __device__ __forceinline__ double mwg_load(const double *ptr) {
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(ptr), __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_AGENT));
 }
+struct MwgPlace { int wg, nwg; };                               // this workgroup's place among the nwg that take part (a launch may carry riders)
+
 // the launch-wide sums of (S, cnt); false: a wait gave up.  red: >= 24 doubles of LDS.  Called by every thread (256).
 __device__ __forceinline__ bool mwg_sum2(double &S, double &cnt, double *xb, int slot, unsigned int *abort_word, double *red,
-                                         int nwg, bool withhold = false) {
+                                         const MwgPlace &pl, bool withhold = false) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int wg = (int)blockIdx.x;                              // (nwg: the workgroups that take part - a launch may carry riders)
+    const int wg = pl.wg, nwg = pl.nwg;                          // (a launch may carry riders: not gridDim.x)
     S = wave_sum(S);
     cnt = wave_sum(cnt);
     if (lane == 0) { red[2 * wid] = S; red[2 * wid + 1] = cnt; }
@@ -1693,23 +1696,25 @@ __device__ __forceinline__ bool mwg_sum2(double &S, double &cnt, double *xb, int
 // x: this thread's element (0 beyond the vector).  On success: out = the projected element, nrm = the l1 norm of the projected
 // vector (every workgroup has it), level_out / searched = the level the search ended at.
 template <typename T>
-__device__ __forceinline__ bool mwg_l1_project(T x, double radius, double l_prev, double *xb, unsigned int *abort_word, double *red,
-                                               T &out, double &nrm, double &level_out, bool &searched, bool withhold, int nwg) {
+__device__ __forceinline__ bool mwg_l1_project(T x, T x1, double radius, double l_prev, double *xb, unsigned int *abort_word, double *red,
+                                               T &out, T &out1, double &nrm, double &level_out, bool &searched, bool withhold, MwgPlace pl) {
+    // (x1, out1: a second element of this thread - zero when it has one; a zero adds 0.0 to every sum: the same bits)
     searched = false;
     level_out = 0.0;
     if (!(radius > 0.0)) {                                   // enet.pyx:57-59 (radius == 0 -> zeros); the same on every workgroup
         out = 0;
+        out1 = 0;
         nrm = 0.0;
         return true;
     }
-    const double R = radius, a = fabs((double)x);
+    const double R = radius, a = fabs((double)x), a1 = fabs((double)x1);
     int slot = 0;
     double S, cnt, level = 0.0, prev_cnt = -1.0;
     bool warm = false, inside = false;
     auto scan = [&](double lv) {
-        S = a > lv ? a : 0.0;
-        cnt = a > lv ? 1.0 : 0.0;
-        return mwg_sum2(S, cnt, xb, slot++, abort_word, red, nwg, withhold);
+        S = (a > lv ? a : 0.0) + (a1 > lv ? a1 : 0.0);
+        cnt = (a > lv ? 1.0 : 0.0) + (a1 > lv ? 1.0 : 0.0);
+        return mwg_sum2(S, cnt, xb, slot++, abort_word, red, pl, withhold);
     };
     // warm start: the level the atom ended with at the previous minibatch ITSELF - f(l) = sum_{|x| > l} (|x| - l) - R is convex and
     // decreasing, so the Newton step that Michelot's update is lands at or left of the root from EITHER side and the iteration
@@ -1737,16 +1742,19 @@ __device__ __forceinline__ bool mwg_l1_project(T x, double radius, double l_prev
             level = (S - R) / cnt;                           // enet.pyx:119
         }
         const double lT = (double)(T)level;
-        double pos = a - lT;
+        double pos = a - lT, pos1 = a1 - lT;
         pos = pos > 0 ? pos : 0;
+        pos1 = pos1 > 0 ? pos1 : 0;
         out = (T)(((double)x >= 0) ? pos : -pos);            // enet.pyx:121, sign(0) = +1
-        double mine = fabs((double)out), dummy = 0.0;
-        if (!mwg_sum2(mine, dummy, xb, kMwgMaxPass, abort_word, red, nwg)) return false;
+        out1 = (T)(((double)x1 >= 0) ? pos1 : -pos1);
+        double mine = fabs((double)out) + fabs((double)out1), dummy = 0.0;
+        if (!mwg_sum2(mine, dummy, xb, kMwgMaxPass, abort_word, red, pl)) return false;
         total = mine;
     } else {
         out = x;
+        out1 = x1;
         double mine = 0.0, dummy = 0.0;                      // (the last slot is the "everybody is done" exchange in every case)
-        if (!mwg_sum2(mine, dummy, xb, kMwgMaxPass, abort_word, red, nwg)) return false;
+        if (!mwg_sum2(mine, dummy, xb, kMwgMaxPass, abort_word, red, pl)) return false;
     }
     nrm = total;
     level_out = level;
@@ -1774,11 +1782,13 @@ __global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *
     extern __shared__ __attribute__((aligned(16))) char step_smem[];   // the s-vector for the projection
     __shared__ double red[32];
     __shared__ int flag;
+    const int wg = (int)blockIdx.x;                                  // one of the launch's own nwg_main workgroups, or a rider behind them
     if constexpr (KPL > 0) {
         __shared__ double s_oldw[4][G];
-        if ((int)blockIdx.x >= nwg_main) {
-            atom_grad4_body<T, KPL>(Dt, ride.Bt, C, subset, s, k, ride.gn, ride.gfold, ride.stage_fold, rho, ride.num, ride.dold, ldr,
-                                    ride.pold, ride.part_stride, ride.vb0 + (int)blockIdx.x - nwg_main, ride.nvb, s_oldw);
+        if (wg >= nwg_main) {
+            if (wg - nwg_main < ride.nride)
+                atom_grad4_body<T, KPL>(Dt, ride.Bt, C, subset, s, k, ride.gn, ride.gfold, ride.stage_fold, rho, ride.num, ride.dold, ldr,
+                                        ride.pold, ride.part_stride, ride.vb0 + wg - nwg_main, ride.nvb, s_oldw);
             return;
         }
     }
@@ -1790,7 +1800,7 @@ __global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *
         {   // the buffer of the NEXT launch back to sentinels (its last user was the launch before this one)
             long long *xo = reinterpret_cast<long long *>(xch + (size_t)((parity & 1) ^ 1) * kMwgWords);
             const int per = (kMwgWords + nwg_main - 1) / nwg_main;
-            for (int e = (int)blockIdx.x * per + threadIdx.x; e < ((int)blockIdx.x + 1) * per && e < kMwgWords; e += 256) xo[e] = kMwgSentinel;
+            for (int e = wg * per + threadIdx.x; e < (wg + 1) * per && e < kMwgWords; e += 256) xo[e] = kMwgSentinel;
         }
         const double cjj = (double)C[(int64_t)j * k + j];
         const bool frozen = !((T)cjj > (T)1e-20);
@@ -1799,62 +1809,73 @@ __global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *
         for (int b = 0; b < G; ++b) cb[b] = (b < a) ? (double)C[(int64_t)g.j[b] * k + j] : 0.0;
 #pragma unroll
         for (int b = 0; b < G; ++b) cp[b] = (KPL > 0 && b < gprev.n) ? (double)C[(int64_t)gprev.j[b] * k + j] : 0.0;
-        const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-        const int64_t fc = f < s ? f : s - 1;
-        double x = num[(int64_t)a * ldr + fc];
-        const T dj = dold[(int64_t)a * ldr + fc];
-        T sn[G], so[G], pn[G], po[G];
-#pragma unroll
-        for (int b = 0; b < G; ++b) {
-            const int bc = b < a ? b : 0;
-            sn[b] = stage_cur[(int64_t)bc * ldr + fc];
-            so[b] = dold[(int64_t)bc * ldr + fc];
-        }
-        if constexpr (KPL > 0) {
-#pragma unroll
-            for (int b = 0; b < G; ++b) {                            // (pipelined sweep: what the group before changed)
-                const int bc = b < gprev.n ? b : 0;
-                pn[b] = stage_prev[(int64_t)bc * ldr + fc];
-                po[b] = dold_prev[(int64_t)bc * ldr + fc];
-            }
-#pragma unroll
-            for (int b = 0; b < G; ++b)
-                if (b < gprev.n) x -= cp[b] * ((double)pn[b] - (double)po[b]);
-        }
+        // one or (ride.ept == 2) two elements per thread: feature f0 and f0 + 256 of the workgroup's 256 ept
+        const int ept = (KPL > 0 && ride.ept == 2) ? 2 : 1;
+        const int64_t fq[2] = {(int64_t)wg * 256 * ept + threadIdx.x, ept == 2 ? (int64_t)wg * 512 + 256 + threadIdx.x : s};
         // radius = the budget + the atom's old norm on the sampled features: the partial sums of the group's gradient launch,
         // summed by every workgroup in the same order (block_sum2: fixed association)
         double old = 0, dummy = 0;
         for (int i = threadIdx.x; i < part_stride; i += 256) old += partial_old[(int64_t)a * part_stride + i];
         const double cn = (double)comp_norm[j], lprev = level_hint ? level_hint[j] : 0.0;
+        T val[2];
 #pragma unroll
-        for (int b = 0; b < G; ++b)
-            if (b < a) x -= cb[b] * ((double)sn[b] - (double)so[b]);
-        T val = dj;
-        if (!frozen) val = (T)(x / cjj);
-        if (pos && val < (T)0) val = 0;                              // dict_fact.py:684-685
-        if (f >= s) val = 0;
-        if (f < s) u[f] = val;                                       // (what the last workgroup projects if this attempt gives up)
+        for (int q = 0; q < 2; ++q) {
+            const int64_t f = fq[q];
+            const int64_t fc = f < s ? f : s - 1;
+            double x = num[(int64_t)a * ldr + fc];
+            const T dj = dold[(int64_t)a * ldr + fc];
+            T sn[G], so[G], pn[G], po[G];
+#pragma unroll
+            for (int b = 0; b < G; ++b) {
+                const int bc = b < a ? b : 0;
+                sn[b] = stage_cur[(int64_t)bc * ldr + fc];
+                so[b] = dold[(int64_t)bc * ldr + fc];
+            }
+            if constexpr (KPL > 0) {
+#pragma unroll
+                for (int b = 0; b < G; ++b) {                        // (pipelined sweep: what the group before changed)
+                    const int bc = b < gprev.n ? b : 0;
+                    pn[b] = stage_prev[(int64_t)bc * ldr + fc];
+                    po[b] = dold_prev[(int64_t)bc * ldr + fc];
+                }
+#pragma unroll
+                for (int b = 0; b < G; ++b)
+                    if (b < gprev.n) x -= cp[b] * ((double)pn[b] - (double)po[b]);
+            }
+#pragma unroll
+            for (int b = 0; b < G; ++b)
+                if (b < a) x -= cb[b] * ((double)sn[b] - (double)so[b]);
+            T v = dj;
+            if (!frozen) v = (T)(x / cjj);
+            if (pos && v < (T)0) v = 0;                              // dict_fact.py:684-685
+            if (f >= s) v = 0;
+            if (f < s) u[f] = v;                                     // (what the last workgroup projects if this attempt gives up)
+            val[q] = v;
+        }
         block_sum2(old, dummy, red, 256);
         const double radius = (double)(T)(cn + old);                 // comp_norm_[k] += subset_norm (:676-678)
-        T outv;
+        T outv[2];
         double nrm, level;
         bool searched;
 #ifdef MODL_DIAG
-        const bool withhold = (parity & 2) && blockIdx.x == 1;       // (MODL_DEBUG_ATOM_MWG = 2: the fallback path, tests)
+        const bool withhold = (parity & 2) && wg == 1;               // (MODL_DEBUG_ATOM_MWG = 2: the fallback path, tests)
 #else
         const bool withhold = false;
 #endif
         const unsigned long long t1 = clock64();
-        const bool ok = mwg_l1_project<T>(val, radius, lprev, xb, xabort, red, outv, nrm, level, searched, withhold, nwg_main);
+        const bool ok = mwg_l1_project<T>(val[0], val[1], radius, lprev, xb, xabort, red, outv[0], outv[1], nrm, level, searched, withhold,
+                                          MwgPlace{wg, nwg_main});
         const unsigned long long t2 = clock64();
         if (ok) {
-            if (f < s) stage_cur[(int64_t)a * ldr + f] = outv;
-            if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (fq[q] < s) stage_cur[(int64_t)a * ldr + fq[q]] = outv[q];
+            if (wg == 0 && threadIdx.x == 0) {
                 comp_norm[j] = (T)(radius - nrm);                    // :690-692
                 if (level_hint && searched) level_hint[j] = level;
             }
         }
-        if (dbg && blockIdx.x == 0 && threadIdx.x == 0) { dbg[8] = t0; dbg[9] = t1; dbg[10] = t2; dbg[11] = clock64(); dbg[12] = (unsigned long long)red[19]; }
+        if (dbg && wg == 0 && threadIdx.x == 0) { dbg[8] = t0; dbg[9] = t1; dbg[10] = t2; dbg[11] = clock64(); dbg[12] = (unsigned long long)red[19]; }
         // every workgroup arrives; the last one looks at the abort word and, if it is raised, projects everything the old way
         if (!arrive_last(counter, (unsigned)nwg_main, &flag)) return;
         if (__hip_atomic_load(xabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
@@ -1869,7 +1890,7 @@ __global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *
     double cb[G];
 #pragma unroll
     for (int b = 0; b < G; ++b) cb[b] = (b < a) ? (double)C[(int64_t)g.j[b] * k + j] : 0.0;
-    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < s; f += (int64_t)nwg_main * blockDim.x) {
+    for (int64_t f = (int64_t)wg * blockDim.x + threadIdx.x; f < s; f += (int64_t)nwg_main * blockDim.x) {
         double x = num[(int64_t)a * ldr + f];
         const T dj = dold[(int64_t)a * ldr + f];
         T sn[G], so[G];
@@ -2894,6 +2915,9 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
         const bool pipelined = mwg && ngroups >= 2 && g_atom_pipe.load(std::memory_order_relaxed) != 0 && s > kPipeMinRows &&
                                (int64_t)2 * G * nwg <= L.nwg_grad;
         if (pipelined) {
+            // two elements per thread beyond 32 workgroups: half as many slots to poll and sum per exchange (C6: 26.8 against 27.3 ms)
+            const int ept = nwg_corr > 32 ? 2 : 1;
+            const int nwg_p = (int)cdiv(s, 256 * ept);
             T *pb = reinterpret_cast<T *>(ws + L.off_pipe);
             T *pstage[2] = {pb, pb + (size_t)G * ldr};
             T *pdold[3] = {pb + (size_t)2 * G * ldr, pb + (size_t)3 * G * ldr, pb + (size_t)4 * G * ldr};
@@ -2935,14 +2959,16 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
                         nride = hi - lo;
                         ride.Bt = a.Bt; ride.gn = gnext; ride.gfold = gprev; ride.stage_fold = pstage[(gi + 1) & 1];
                         ride.num = pnum[(gi + 1) & 1]; ride.dold = pdold[(gi + 1) % 3]; ride.pold = ppold[(gi + 1) & 1];
-                        ride.part_stride = nwg; ride.vb0 = lo; ride.nvb = nwg;
+                        ride.part_stride = nwg; ride.vb0 = lo; ride.nvb = nwg; ride.nride = nride;
                     }
+                    ride.ept = ept;
+                    const int grid = nwg_p + nride;
 #define MODL_CORR(KPL)                                                                                                            \
-    hipLaunchKernelGGL((atom_corr_project_kernel<T, KPL>), dim3(nwg_corr + nride), dim3(256), u_lds, stream, a.Dt, a.C, a.subset, s, k,       \
+    hipLaunchKernelGGL((atom_corr_project_kernel<T, KPL>), dim3(grid), dim3(256), u_lds, stream, a.Dt, a.C, a.subset, s, k,       \
                        gcur, ai, a.comp_pos, a.comp_l1_ratio, u, (const double *)pnum[gi & 1], (const T *)pdold[gi % 3], pstage[gi & 1], ldr,  \
                        (const double *)ppold[gi & 1], nwg, a.comp_norm, counter,                                                                \
                        reinterpret_cast<unsigned long long *>(counter + kCounters), a.level_hint, xch, xabort,                                 \
-                       (int)(launch_no++ & 1) | (g_atom_mwg.load(std::memory_order_relaxed) == 2 ? 2 : 0), nwg_corr, gprev,                    \
+                       (int)(launch_no++ & 1) | (g_atom_mwg.load(std::memory_order_relaxed) == 2 ? 2 : 0), nwg_p, gprev,                       \
                        (const T *)pstage[(gi + 1) & 1], (const T *)pdold[(gi + 2) % 3], ride)
                     if (k <= 64) MODL_CORR(1);
                     else if (k <= 128) MODL_CORR(2);

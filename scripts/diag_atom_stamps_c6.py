@@ -8,6 +8,9 @@ import numpy as np, torch
 import bench
 from modl_amd import DictFact
 from modl_amd._lib import lib, check
+for item in sys.argv[1:]:                                  # what=value: modl_debug_set before anything runs
+    what, value = item.split('=')
+    check(lib.modl_debug_set(int(what), int(value)))
 dev = torch.device('cuda')
 p, n, b, k = 200000, 1200, 200, 1024
 X = bench.M1Stream(p, 3, dev, k0=64).rows(0, n)

@@ -1285,7 +1285,7 @@ from modl_amd._lib import lib, check, DEBUG_ATOM_MWG, DEBUG_ATOM_PIPE
 dtype = np.float32 if sys.argv[1] == 'f32' else np.float64
 pos = bool(int(sys.argv[2]))
 rs = np.random.RandomState(11)
-n, p, k, b = 96, 15000, int(sys.argv[4]), 32
+n, p, k, b = 96, int(sys.argv[5]), int(sys.argv[4]), 32
 X = (np.abs(rs.randn(n, 10)).dot(np.abs(rs.randn(10, p))) + 0.2 * rs.randn(n, p)).astype(dtype)
 kw = dict(n_components=k, batch_size=b, reduction=2, code_alpha=0.05, code_l1_ratio=0, comp_l1_ratio=1, comp_pos=pos, random_state=0,
           learning_rate=0.9)
@@ -1306,8 +1306,9 @@ print(json.dumps(dict(ok=True)))
 """
 
 
-@pytest.mark.parametrize('dt,pos,k', [('f32', 1, 12), ('f64', 1, 12), ('f64', 0, 12), ('f64', 1, 14), ('f32', 0, 7)])
-def test_l1_projection_spread_over_the_launch(tmp_path, dt, pos, k):
+@pytest.mark.parametrize('dt,pos,k,p', [('f32', 1, 12, 15000), ('f64', 1, 12, 15000), ('f64', 0, 12, 15000), ('f64', 1, 14, 18000),
+                                        ('f32', 0, 7, 18000)])
+def test_l1_projection_spread_over_the_launch(tmp_path, dt, pos, k, p):
     """Round 6: with more than 6144 sampled features (one launch per atom: the shape class of the reference's HCP run) the l1
     projection of an atom is no longer the work of the launch's last workgroup - every thread of the launch keeps its element and
     a Michelot pass is one exchange of sums through memory (csrc/bcd.hip: mwg_l1_project) - and the gradient rows of the next
@@ -1316,11 +1317,12 @@ def test_l1_projection_spread_over_the_launch(tmp_path, dt, pos, k):
     (MODL_DEBUG_ATOM_MWG = 0), against a run in which a workgroup withholds its sums (diagnostics build, = 2: every wait gives up,
     the abort word is raised and the last workgroup projects the candidates alone - with a gradient launch per group the results
     must be the old path's BIT FOR BIT, with the riding rows they must be the pipelined run's to rounding) and against the oracle:
-    7500 sampled features of 15 000, l1 atoms with and without positivity."""
+    7500 sampled features of 15 000 (30 workgroups, an element per thread) and 9000 of 18 000 (two elements per thread on 18
+    workgroups: what the reference's HCP shape takes), l1 atoms with and without positivity."""
     from oracle import somf_oracle as orc
     from .conftest import assert_within_f32_noise
     f = str(tmp_path / 'mwg.npz')
-    _run_diag_script(_MWG_SCRIPT, dt, str(pos), f, str(k))
+    _run_diag_script(_MWG_SCRIPT, dt, str(pos), f, str(k), str(p))
     z = np.load(f)
     assert np.array_equal(z['D20'], z['D00']) and np.array_equal(z['cn20'], z['cn00'])       # the fallback IS the old path
     X = z['X']
