@@ -287,11 +287,13 @@ def test_generic_dictionary_update_multi_workgroup_vs_oracle(DictFact, oracle, v
 
 
 @pytest.mark.parametrize('p,k,l1', [(3000, 72, 1), (9000, 36, 1), (9000, 36, 0.5), (11500, 27, 1), (11500, 27, 0.5),
-                                    (14000, 20, 1), (14000, 20, 0.5), (2600, 520, 1)])
+                                    (14000, 20, 1), (14000, 20, 0.5), (2600, 520, 1), (14000, 520, 1)])
 def test_generic_dictionary_update_f32_groups_vs_oracle(DictFact, oracle, p, k, l1):
     """f32, first minibatch from identical state, through the atom groups (12 / 20 / 24 elements per thread of the
     projecting workgroup; l1 and elastic-net atoms) and, beyond 6144 sampled features or 512 atoms (the shape class of the
-    reference's HCP run), through one launch per atom (atom_step_kernel): within the oracle's own f32 noise of its f64 run."""
+    reference's HCP run), through one launch per atom (atom_step_kernel; 7000 sampled features and 520 l1 atoms: the pipelined
+    sweep with the 16-registers-per-lane gradient rows riding on the atom launches, round 6): within the oracle's own f32 noise
+    of its f64 run."""
     kw = dict(n=max(160, k + 40), p=p, k=k, b=20, r=2, code_l1_ratio=0, comp_l1_ratio=l1, code_alpha=1e-2)
     from .conftest import assert_within_f32_noise
     est, pr, st32, X = _make_pair(DictFact, oracle, np.float32, **kw)
