@@ -83,7 +83,7 @@ const char *modl_error_string(int code);
 #define MODL_DEBUG_BCD_PERSIST 9      /* 1 (default): the f32 blocked dictionary update runs as ONE persistent launch (a resolver workgroup + one workgroup per 32 / 64 sampled rows resident in LDS, look-ahead Gram matrices: csrc/bcd_persist.hip) whenever its workgroups fit the chip (hipOccupancyMaxActiveBlocksPerMultiprocessor for the kernel's own footprint); 0: one launch per block of 32 atoms.  Diagnostics library only (the product library treats them as 1): 3 = the resolver waits for a workgroup that never comes before the first block (the launch cannot run: the resolver completes the update alone, modl_somf_persist_recoveries counts it), 4 = the same from the second block on (the update is incomplete: MODL_ETIMEOUT) */
 #define MODL_DEBUG_STATS_RESIDENT 10  /* 1 (default): the f32 statistics product X^T code over at least 4096 features and at most 256 atoms runs on persistent workgroups that keep the code matrix in registers (csrc/gemm_resident.hpp, tiles of 16 features); 0: the 32 x 32 tiles or the k-wide tiles of rounds 2-4 */
 #define MODL_DEBUG_RECSYS_FUSED 11    /* 1 (default): a masked minibatch of RecsysDictFact with at most 64 (f64: 56) atoms and 64 rows runs its codes (rating chunks of 128, ticketed fixed-order sums, Cholesky) and C_ as ONE launch (csrc/recsys.hip: recsys_fused_kernel), B_ and the blocked dictionary update as launches of their own behind it; 2: B_ and the dictionary sweep inside that launch when one workgroup holds every touched item (512 in registers + what fits LDS), 3: the same without the LDS tier, 4: the sweep also on up to four workgroups that exchange an atom's sums through memory (all three measured slower, kept selectable and tested); 0: the separate launches of rounds 2-5 for everything */
-#define MODL_DEBUG_ATOM_MWG 12        /* 1 (default): the l1 projection of an atom with more than 6144 and at most 16 384 sampled features (one launch per atom: the reference's HCP configuration) is spread over the launch's workgroups - an element per thread, a memory round trip per Michelot pass (csrc/bcd.hip: mwg_l1_project); 0: the launch's last workgroup projects the whole vector from LDS; diagnostics library: 2 = as 1 with a workgroup that withholds its sums (the attempt gives up and the last workgroup projects: the fallback path) */
+#define MODL_DEBUG_ATOM_MWG 12        /* the l1 projection of an atom with more than 6144 and at most 16 384 sampled features (one launch per atom: the reference's HCP configuration).  1 (default): by the launch's last workgroup with the vector in registers, 40 or 64 elements per thread (csrc/bcd.hip: atom_project_regs; needs MODL_DEBUG_ATOM_PIPE != 0, else as 3); 3: spread over the launch's workgroups - an element or two per thread, a memory round trip per Michelot pass (mwg_l1_project: measured slower, kept selectable and tested); 0: the last workgroup projects from an LDS copy; diagnostics library: 2 = as 3 with a workgroup that withholds its sums (the attempt gives up and the last workgroup projects: the fallback path) */
 #define MODL_DEBUG_BCD_FEW 13         /* 1 (default): the f64 blocked dictionary update of 193 to 2048 sampled features runs as ONE launch on up to sixteen workgroups of 128 features that exchange a block's Gram record through memory (csrc/bcd.hip: bcd_few_kernel); 0: four launches per block of 32 atoms */
 #define MODL_DEBUG_ATOM_PIPE 14       /* 1 (default): in the per-atom sweep of MODL_DEBUG_ATOM_MWG the gradient rows of the NEXT group of four atoms are formed by workgroups riding on the launches of this group's atoms (against the dictionary as it is then; what this group changes is subtracted afterwards from its compact rows - csrc/bcd.hip: atom_corr_project_kernel, GradRide); 0: a gradient launch of its own between two groups */
 int modl_debug_set(int what, int64_t value);

@@ -56,6 +56,8 @@ constexpr long long kFewSentinel = 0x7ff8feed7ff8feedll;   // what an exchange s
 std::atomic<int> g_bcd_few{1};                       // modl_debug_set(MODL_DEBUG_BCD_FEW, ...)
 
 constexpr int64_t kPipeMinRows = 24 * 256;           // (= kProjEpt * 256: beyond the register-resident projection)
+// row stride of the pipelined sweep's scratch: what the last workgroup covers with 40 / 64 elements per thread (atom_project_regs)
+static int64_t pipe_row_stride(int64_t s) { return s <= 40 * 256 ? 40 * 256 : (s <= 64 * 256 ? 64 * 256 : s); }
 static int64_t atom_row_stride(int64_t s) { return s <= 12 * 256 ? 12 * 256 : (s <= 20 * 256 ? 20 * 256 : 24 * 256); }
 
 static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
@@ -97,7 +99,8 @@ static DuLayout du_layout(size_t tsz, int64_t s_max, int k) {
     L.off_few = take(tsz == 8 ? sizeof(double) * 3 * (size_t)kFewMaxWg * kFewRec + 64 : 0);
     // the pipelined per-atom sweep of large sampled sets (atom_corr_project_kernel, round 6): two staged groups of four atoms, three
     // sets of old values, two sets of f64 numerators (the sets are s-strided inside; s <= s_max)
-    L.off_pipe = take(s_max > kPipeMinRows ? align_up(tsz * (size_t)5 * 4 * (size_t)s_max, 16) + sizeof(double) * (size_t)2 * 4 * (size_t)s_max : 0);
+    L.off_pipe = take(s_max > kPipeMinRows ? align_up(tsz * (size_t)5 * 4 * (size_t)pipe_row_stride(s_max), 16) +
+                                                 sizeof(double) * (size_t)2 * 4 * (size_t)pipe_row_stride(s_max) : 0);
     L.total = o;
     return L;
 }
@@ -1609,6 +1612,7 @@ template <typename T> struct GradRide {
     double *pold;
     int part_stride, vb0, nvb, nride;     // nride riders do the workgroups [vb0, vb0 + nride) of the gradient launch's nvb
     int ept;                              // elements per thread of the launch's own workgroups (1, or 2: half as many workgroups)
+    int regs;                             // 1: no spread projection - the launch's last workgroup projects from registers (atom_project_regs)
 };
 
 // (2) one atom of the group: its candidate from the stored numerator minus what the atoms before it in the group changed (a
@@ -1769,6 +1773,153 @@ __device__ __forceinline__ bool mwg_l1_project(T x, T x1, double radius, double 
 // being projected, so what group g changes is missing from group g + 1's numerators as well: the launches of group g + 1
 // subtract it with the same identity that handles their own group, from the PREVIOUS group's compact rows (gprev, stage_prev,
 // dold_prev).  The riders put the rows of group g - 1 home (the newest finished one), so the host flushes the last TWO groups.
+// (defined with the grouped atom update below)
+template <typename T, int EPT, bool L1>
+__device__ __forceinline__ double enet_project_slim(double (&x)[EPT], T *out, double radius, double l1_ratio, double *red4, int &par,
+                                                    double l_prev, double *level_out, unsigned long long *dbg);
+__device__ __forceinline__ void block_sum1_pp(double &a, double *red4, int &par);
+__device__ __forceinline__ void block_sum2_pp(double &a, double &b, double *red4, int &par);
+template <int EPT> __device__ __forceinline__ void store_row4(double *row, const double (&v)[EPT]);
+template <int EPT> __device__ __forceinline__ void store_row4(float *row, const float (&v)[EPT]);
+template <int EPT> __device__ __forceinline__ void load_row4(const double *row, double (&v)[EPT]);
+template <int EPT> __device__ __forceinline__ void load_row4(const float *row, float (&v)[EPT]);
+
+__device__ __forceinline__ void store_wt(float *ptr, float v) {       // a write-through store (a relaxed agent-scope atomic store IS one)
+    __hip_atomic_store(reinterpret_cast<unsigned int *>(ptr), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_wt(double *ptr, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(ptr), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+// load_row4 past the caches (16-byte sc1 loads): the row was written by OTHER workgroups of this launch, write-through
+template <typename T, int EPT>
+__device__ __forceinline__ void load_row4_sc1(const T *row, T (&v)[EPT]) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    constexpr int PER = 16 / (int)sizeof(T);                         // elements per 16-byte load
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(row), 0, EPT * 256 * (int)sizeof(T), 0x00020000);
+#pragma unroll
+    for (int q = 0; q < EPT / 4; ++q)
+#pragma unroll
+        for (int h = 0; h < 4 / PER; ++h) {
+            const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)sizeof(T) * (4 * (int)threadIdx.x + 1024 * q + PER * h), 0, 16);   // (aux 16: sc1)
+            __builtin_memcpy(&v[4 * q + PER * h], &raw, 16);
+        }
+}
+
+// block_sum2_pp for a sum and a small COUNT (per thread at most 64: a wavefront's total is exact in f32, whose lane exchanges are
+// one instruction a stage instead of three).  (Measured and not kept: the wavefront's count as scalar population counts of the
+// compares - the scalar unit waits for every compare: 2.3 k cycles per pass instead of 2.1 k; the first passes with f32 sums,
+// guarded by a relative 4e-6 - a pass costs the same, its instruction count is not what bounds it.)
+__device__ __forceinline__ void block_sum_count_pp(double &a, double &cnt, double *red4, int &par) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    a = wave_sum(a);
+    const float c = wave_sum((float)cnt);
+    double *r = red4 + 8 * par;
+    par ^= 1;
+    if (lane == 0) { r[2 * wid] = a; r[2 * wid + 1] = (double)c; }
+    __syncthreads();
+    a = (r[0] + r[2]) + (r[4] + r[6]);
+    cnt = (r[1] + r[3]) + (r[5] + r[7]);
+}
+
+// The l1 projection of the launch's candidates by its LAST workgroup with the whole vector in REGISTERS (round 6; EPT = 40 or 64
+// elements per thread: up to 16 384 sampled features): a Michelot pass is EPT compare-select-adds and one LDS exchange, ~1.7 k
+// cycles, against a 2 us round trip through memory per pass of the spread projection and 5-7 k cycles per scan of the LDS copy.
+// Writes the compact row (whole 1024-element chunks: the rows of the pipelined sweep are padded to that), the budget, the level.
+template <typename T, int EPT>
+__device__ __forceinline__ void atom_project_regs(const T *u, int64_t s, int j, const double *partial_old, int nparts, T *comp_norm,
+                                                  double *level_hint, T *stage_row, double *red, unsigned long long *dbg) {
+    double old = 0;
+    for (int i = threadIdx.x; i < nparts; i += 256) old += partial_old[i];
+    T v[EPT], ax[EPT];                                               // the candidates and their magnitudes, in T: a register each in f32
+    load_row4_sc1<T, EPT>(u, v);                                     // (beyond s: whatever follows in the workspace, masked)
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        v[e] = (4 * (int)threadIdx.x + (e & 3) + 1024 * (e >> 2) < s) ? v[e] : (T)0;
+        ax[e] = v[e] < (T)0 ? -v[e] : v[e];
+    }
+    int par = 0;
+    block_sum1_pp(old, red, par);
+    const double radius = (double)(T)((double)comp_norm[j] + old);   // comp_norm_[k] += subset_norm (:676-678)
+    if (dbg && threadIdx.x == 0) dbg[7] = clock64();
+    // Michelot's iteration with the closed form of enet.pyx:119 (enet_project_slim's rules: the previous level ITSELF as the warm
+    // start - the Newton step lands at or left of the root from either side -, the cold start settles "inside the ball").  A
+    // pass compares in T: for a T-representable magnitude, a > level (in double) <=> a > the level rounded DOWN to T.
+    const bool zero = !(radius > 0.0);                               // enet.pyx:57-59 (radius == 0 -> zeros)
+    const double R = radius;
+    auto pass = [&](double lv, double &S, double &cnt) {
+        T lt = (T)lv;
+        if ((double)lt > lv) lt = sizeof(T) == 4 ? (T)__uint_as_float(__float_as_uint((float)lt) - 1u) : (T)__longlong_as_double(__double_as_longlong((double)lt) - 1ll);   // (lv > 0 here)
+        double S0 = 0, S1 = 0, S2 = 0, S3 = 0;
+        int c0 = 0, c1 = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; e += 4) {                           // selects, no branches; four chains
+            const bool i0 = ax[e] > lt, i1 = ax[e + 1] > lt, i2 = ax[e + 2] > lt, i3 = ax[e + 3] > lt;
+            S0 += (double)(i0 ? ax[e] : (T)0);
+            S1 += (double)(i1 ? ax[e + 1] : (T)0);
+            S2 += (double)(i2 ? ax[e + 2] : (T)0);
+            S3 += (double)(i3 ? ax[e + 3] : (T)0);
+            c0 += (i0 ? 1 : 0) + (i2 ? 1 : 0);
+            c1 += (i1 ? 1 : 0) + (i3 ? 1 : 0);
+        }
+        S = (S0 + S1) + (S2 + S3);
+        cnt = (double)(c0 + c1);
+        block_sum_count_pp(S, cnt, red, par);
+    };
+    double level = 0.0, prev_cnt = -1.0;
+    bool warm = false, search = !zero;
+    int npass = 0;
+    const double l_prev = level_hint ? level_hint[j] : 0.0;
+    if (search && l_prev > 0.0 && l_prev < 1e300) {
+        double S, cnt;
+        pass(l_prev, S, cnt);
+        ++npass;
+        const double l1 = (S - R) / cnt;
+        if (cnt != 0.0 && l1 > 0.0) { warm = true; prev_cnt = cnt; level = l1; }
+    }
+    if (search && !warm) {
+        double tot = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) tot += (double)ax[e];
+        block_sum1_pp(tot, red, par);
+        if (tot <= R) search = false;                                // inside the ball: level 0 is the identity
+    }
+    if (search) {
+        for (int p = 0; p < 256; ++p) {
+            double S, cnt;
+            if (level > 0.0) pass(level, S, cnt);
+            else {                                                   // (level 0 - the cold start's first pass: every non-zero counts)
+                double S0 = 0;
+                int c0 = 0;
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) { S0 += (double)ax[e]; c0 += ax[e] > (T)0 ? 1 : 0; }
+                S = S0; cnt = (double)c0;
+                block_sum_count_pp(S, cnt, red, par);
+            }
+            ++npass;
+            if (cnt == prev_cnt || cnt == 0.0) break;
+            prev_cnt = cnt;
+            level = (S - R) / cnt;                                   // enet.pyx:119
+        }
+    }
+    if (dbg && threadIdx.x == 0) { dbg[4] = (unsigned)npass | (warm ? 1u << 16 : 0u); dbg[5] = clock64(); }
+    if (level_hint && threadIdx.x == 0 && search) level_hint[j] = level;
+    const double lT = (double)(T)level;
+    double mine = 0;
+    T o[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        double pos = (double)ax[e] - lT;
+        pos = pos > 0 ? pos : 0;
+        o[e] = (T)((v[e] >= (T)0) ? pos : -pos);                     // enet.pyx:121, sign(0) = +1
+        o[e] = zero ? (T)0 : o[e];
+        mine += fabs((double)o[e]);
+    }
+    store_row4<EPT>(stage_row, o);
+    block_sum1_pp(mine, red, par);
+    if (threadIdx.x == 0) comp_norm[j] = (T)(radius - mine);         // :690-692
+}
+
 template <typename T, int KPL>
 __global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *C, const int32_t *subset, int64_t s, int k,
                                                                 AtomGroupN<kStepGroup> g, int a, int pos, double rho, T *u,
@@ -1887,9 +2038,13 @@ __global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *
     // the numerators of the group's launch, minus what the atoms before this one changed
     const double cjj = (double)C[(int64_t)j * k + j];
     const bool frozen = !((T)cjj > (T)1e-20);
-    double cb[G];
+    // (rows padded to whole passes: pipe_row_stride)
+    const bool use_regs = KPL > 0 && ride.regs && rho == 1.0 && s <= 64 * 256 && ldr >= (s <= 40 * 256 ? 40 : 64) * 256;
+    double cb[G], cp[G];
 #pragma unroll
     for (int b = 0; b < G; ++b) cb[b] = (b < a) ? (double)C[(int64_t)g.j[b] * k + j] : 0.0;
+#pragma unroll
+    for (int b = 0; b < G; ++b) cp[b] = (KPL > 0 && b < gprev.n) ? (double)C[(int64_t)gprev.j[b] * k + j] : 0.0;
     for (int64_t f = (int64_t)wg * blockDim.x + threadIdx.x; f < s; f += (int64_t)nwg_main * blockDim.x) {
         double x = num[(int64_t)a * ldr + f];
         const T dj = dold[(int64_t)a * ldr + f];
@@ -1900,19 +2055,59 @@ __global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *
             sn[b] = stage_cur[(int64_t)bc * ldr + f];
             so[b] = dold[(int64_t)bc * ldr + f];
         }
+        if constexpr (KPL > 0) {                                     // (pipelined sweep: what the group before changed)
+            T pn[G], po[G];
+#pragma unroll
+            for (int b = 0; b < G; ++b) {
+                const int bc = b < gprev.n ? b : 0;
+                pn[b] = stage_prev[(int64_t)bc * ldr + f];
+                po[b] = dold_prev[(int64_t)bc * ldr + f];
+            }
+#pragma unroll
+            for (int b = 0; b < G; ++b)
+                if (b < gprev.n) x -= cp[b] * ((double)pn[b] - (double)po[b]);
+        }
 #pragma unroll
         for (int b = 0; b < G; ++b)
             if (b < a) x -= cb[b] * ((double)sn[b] - (double)so[b]);
         T val = dj;
         if (!frozen) val = (T)(x / cjj);
         if (pos && val < (T)0) val = 0;                              // dict_fact.py:684-685
-        u[f] = val;
+        if (use_regs) store_wt(u + f, val);                          // (write-through: the hand-off below has no fence)
+        else u[f] = val;
     }
     const unsigned long long t1 = clock64();
-    if (!arrive_last(counter, (unsigned)nwg_main, &flag)) return;
+    if (use_regs) {
+        // hand-off without fences (bcd_persist.hip: signal_word): the write-through stores drained, one relaxed ticket; the last
+        // workgroup reads the candidates past its caches (atom_project_regs: sc1 loads).  An agent-scope release would write back
+        // the XCD's whole L2 - the riders' dictionary rows included - and the acquire invalidate it: 4 k cycles per atom
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = ticket == (unsigned)nwg_main - 1;
+            if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            flag = last;
+        }
+        __syncthreads();
+        if (!flag) return;
+    } else if (!arrive_last(counter, (unsigned)nwg_main, &flag)) return;
     const unsigned long long t2 = clock64();
-    atom_project<T, false>(u, reinterpret_cast<T *>(step_smem), partial_old + (int64_t)a * part_stride, part_stride, Dt, subset, s, k, j,
-                           rho, comp_norm, red, dbg, level_hint, stage_cur + (int64_t)a * ldr);
+    bool done = false;
+    if constexpr (KPL > 0) {
+        if (use_regs) {
+            if (s <= 40 * 256)
+                atom_project_regs<T, 40>(u, s, j, partial_old + (int64_t)a * part_stride, part_stride, comp_norm, level_hint,
+                                         stage_cur + (int64_t)a * ldr, red, dbg);
+            else
+                atom_project_regs<T, 64>(u, s, j, partial_old + (int64_t)a * part_stride, part_stride, comp_norm, level_hint,
+                                         stage_cur + (int64_t)a * ldr, red, dbg);
+            done = true;
+        }
+    }
+    if (!done)
+        atom_project<T, false>(u, reinterpret_cast<T *>(step_smem), partial_old + (int64_t)a * part_stride, part_stride, Dt, subset, s, k,
+                               j, rho, comp_norm, red, dbg, level_hint, stage_cur + (int64_t)a * ldr);
     if (dbg && threadIdx.x == 0) { dbg[0] = t0; dbg[1] = t1; dbg[2] = t2; dbg[3] = clock64(); }
 }
 
@@ -2912,11 +3107,15 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
         // old-norm partial sums.
         const int ngroups = (int)cdiv(k, G);
         static_assert(G == 4 && kPipeMinRows == (int64_t)kProjEpt * 256, "du_layout sizes off_pipe for groups of four");
-        const bool pipelined = mwg && ngroups >= 2 && g_atom_pipe.load(std::memory_order_relaxed) != 0 && s > kPipeMinRows &&
+        // MODL_DEBUG_ATOM_MWG = 1 (default): the launch's LAST workgroup projects the vector from registers (atom_project_regs: 20.2 ms
+        // per minibatch at the HCP shape); 3: the projection spread over the launch's workgroups (mwg_l1_project: 27.0 ms)
+        const bool regs = a.comp_l1_ratio == 1.0 && g_atom_mwg.load(std::memory_order_relaxed) == 1 && s <= 64 * 256;
+        const bool pipelined = (mwg || regs) && ngroups >= 2 && g_atom_pipe.load(std::memory_order_relaxed) != 0 && s > kPipeMinRows &&
                                (int64_t)2 * G * nwg <= L.nwg_grad;
         if (pipelined) {
+            const int64_t ldr = pipe_row_stride(s);                       // (shadows the a-tile's stride: this scratch is its own)
             // two elements per thread beyond 32 workgroups: half as many slots to poll and sum per exchange (C6: 26.8 against 27.3 ms)
-            const int ept = nwg_corr > 32 ? 2 : 1;
+            const int ept = (nwg_corr > 32 && !regs) ? 2 : 1;
             const int nwg_p = (int)cdiv(s, 256 * ept);
             T *pb = reinterpret_cast<T *>(ws + L.off_pipe);
             T *pstage[2] = {pb, pb + (size_t)G * ldr};
@@ -2962,12 +3161,13 @@ int dict_update_generic(hipStream_t stream, const DictUpdateArgs<T> &a, int *lau
                         ride.part_stride = nwg; ride.vb0 = lo; ride.nvb = nwg; ride.nride = nride;
                     }
                     ride.ept = ept;
+                    ride.regs = regs ? 1 : 0;
                     const int grid = nwg_p + nride;
 #define MODL_CORR(KPL)                                                                                                            \
     hipLaunchKernelGGL((atom_corr_project_kernel<T, KPL>), dim3(grid), dim3(256), u_lds, stream, a.Dt, a.C, a.subset, s, k,       \
                        gcur, ai, a.comp_pos, a.comp_l1_ratio, u, (const double *)pnum[gi & 1], (const T *)pdold[gi % 3], pstage[gi & 1], ldr,  \
                        (const double *)ppold[gi & 1], nwg, a.comp_norm, counter,                                                                \
-                       reinterpret_cast<unsigned long long *>(counter + kCounters), a.level_hint, xch, xabort,                                 \
+                       reinterpret_cast<unsigned long long *>(counter + kCounters), a.level_hint, regs ? nullptr : xch, xabort,                \
                        (int)(launch_no++ & 1) | (g_atom_mwg.load(std::memory_order_relaxed) == 2 ? 2 : 0), nwg_p, gprev,                       \
                        (const T *)pstage[(gi + 1) & 1], (const T *)pdold[(gi + 2) % 3], ride)
                     if (k <= 64) MODL_CORR(1);

@@ -1292,9 +1292,10 @@ X = (np.abs(rs.randn(n, 10)).dot(np.abs(rs.randn(10, p))) + 0.2 * rs.randn(n, p)
 kw = dict(n_components=k, batch_size=b, reduction=2, code_alpha=0.05, code_l1_ratio=0, comp_l1_ratio=1, comp_pos=pos, random_state=0,
           learning_rate=0.9)
 out = {}
-# (projection, gradient rows): spread over the launch / the last workgroup alone / the spread attempt gives up;
+# (projection, gradient rows): 1 the last workgroup from registers (with riding gradient rows; spread over the launch without) /
+# 0 the last workgroup from LDS / 2 the spread attempt gives up / 3 spread over the launch;
 # the next group's gradient rows riding on this group's launches (1) or a launch of their own (0)
-for v, pipe in ((1, 1), (1, 0), (0, 0), (2, 0), (2, 1)):
+for v, pipe in ((1, 1), (1, 0), (0, 0), (2, 0), (2, 1), (3, 1)):
     check(lib.modl_debug_set(DEBUG_ATOM_MWG, v))
     check(lib.modl_debug_set(DEBUG_ATOM_PIPE, pipe))
     est = DictFact(**kw)
@@ -1311,14 +1312,15 @@ print(json.dumps(dict(ok=True)))
 @pytest.mark.parametrize('dt,pos,k,p', [('f32', 1, 12, 15000), ('f64', 1, 12, 15000), ('f64', 0, 12, 15000), ('f64', 1, 14, 18000),
                                         ('f32', 0, 7, 18000)])
 def test_l1_projection_spread_over_the_launch(tmp_path, dt, pos, k, p):
-    """Round 6: with more than 6144 sampled features (one launch per atom: the shape class of the reference's HCP run) the l1
-    projection of an atom is no longer the work of the launch's last workgroup - every thread of the launch keeps its element and
-    a Michelot pass is one exchange of sums through memory (csrc/bcd.hip: mwg_l1_project) - and the gradient rows of the next
-    group of four atoms ride on the launches of this group's atoms (MODL_DEBUG_ATOM_PIPE; what this group changes is subtracted
-    afterwards, the last two groups are put home at the end; k = 14 and 7: a short last group).  Against the old path
-    (MODL_DEBUG_ATOM_MWG = 0), against a run in which a workgroup withholds its sums (diagnostics build, = 2: every wait gives up,
-    the abort word is raised and the last workgroup projects the candidates alone - with a gradient launch per group the results
-    must be the old path's BIT FOR BIT, with the riding rows they must be the pipelined run's to rounding) and against the oracle:
+    """Round 6, the per-atom l1 sweep of more than 6144 sampled features (one launch per atom: the shape class of the reference's
+    HCP run).  The gradient rows of the next group of four atoms ride on the launches of this group's atoms (MODL_DEBUG_ATOM_PIPE;
+    what this group changes is subtracted afterwards, the last two groups are put home at the end; k = 14 and 7: a short last
+    group).  The projection: by the launch's last workgroup with the vector in registers (40 elements per thread, the default),
+    spread over the launch's workgroups (= 3: every thread keeps an element or two, a Michelot pass is one exchange of sums through
+    memory, csrc/bcd.hip: mwg_l1_project), by the last workgroup from LDS (= 0, a gradient launch per group: the old path).
+    Against the old path, against a run in which a workgroup withholds its sums (diagnostics build, = 2: every wait gives up, the
+    abort word is raised and the last workgroup projects the candidates alone - with a gradient launch per group the results must
+    be the old path's BIT FOR BIT, with the riding rows they must be the pipelined run's to rounding) and against the oracle:
     7500 sampled features of 15 000 (30 workgroups, an element per thread) and 9000 of 18 000 (two elements per thread on 18
     workgroups: what the reference's HCP shape takes), l1 atoms with and without positivity."""
     from oracle import somf_oracle as orc
@@ -1335,20 +1337,22 @@ def test_l1_projection_spread_over_the_launch(tmp_path, dt, pos, k, p):
     st64 = orc.prepare(pr, n_samples=n, X=X.astype(np.float64))
     orc.partial_fit(st64, pr, X.astype(np.float64), np.arange(n))
     if dt == 'f64':
-        for name in ('D11', 'D10', 'D21'):
+        for name in ('D11', 'D10', 'D21', 'D31'):
             assert rel_fro(z[name], z['D00']) < 1e-10, name
             assert rel_fro(z[name], st64.D) < 1e-8, name
         assert rel_fro(z['D00'], st64.D) < 1e-8
-        assert np.allclose(z['cn11'], z['cn00'], rtol=0, atol=1e-9) and np.allclose(z['cn21'], z['cn00'], rtol=0, atol=1e-9)
+        for name in ('cn11', 'cn21', 'cn31'):
+            assert np.allclose(z[name], z['cn00'], rtol=0, atol=1e-9), name
     else:
         st32 = orc.prepare(pr, n_samples=n, X=X)
         orc.partial_fit(st32, pr, X, np.arange(n))
-        assert_within_f32_noise(z['D11'], st32.D, st64.D, 'dictionary, projection spread over the launch, riding gradient rows')
+        assert_within_f32_noise(z['D11'], st32.D, st64.D, 'dictionary, the last workgroup projects from registers, riding gradient rows')
         assert_within_f32_noise(z['D10'], st32.D, st64.D, 'dictionary, projection spread over the launch')
         assert_within_f32_noise(z['D21'], st32.D, st64.D, 'dictionary, riding gradient rows, the spread attempt gives up')
+        assert_within_f32_noise(z['D31'], st32.D, st64.D, 'dictionary, projection spread over the launch, riding gradient rows')
         assert_within_f32_noise(z['D00'], st32.D, st64.D, 'dictionary, last workgroup')
     if pos:
-        assert (z['D11'] >= 0).all() and (z['D21'] >= 0).all()
+        assert (z['D11'] >= 0).all() and (z['D21'] >= 0).all() and (z['D31'] >= 0).all()
 
 
 @pytest.mark.parametrize('r', [10, 1])
