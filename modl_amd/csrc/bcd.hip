@@ -1921,7 +1921,7 @@ __device__ __forceinline__ void atom_project_regs(const T *u, int64_t s, int j, 
 }
 
 template <typename T, int KPL>
-__global__ __launch_bounds__(256) void atom_corr_project_kernel(T *Dt, const T *C, const int32_t *subset, int64_t s, int k,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void atom_corr_project_kernel(T *Dt, const T *C, const int32_t *subset, int64_t s, int k,
                                                                 AtomGroupN<kStepGroup> g, int a, int pos, double rho, T *u,
                                                                 const double *num, const T *dold, T *stage_cur, int64_t ldr,
                                                                 const double *partial_old, int part_stride, T *comp_norm,
