@@ -92,8 +92,10 @@ timeout 600 python3 -m pytest $R/tests/test_gpu_step.py -q -m gpu -s -k "gram_ac
 { for v in 2 4; do timeout 300 python3 $R/scripts/diag_recsys_stamps.py $v; done; } > $OUT/${TAG}_recsys_fused_stamps.txt 2>&1
 timeout 600 bash $R/scripts/ab_recsys_fused.sh 2>&1 | grep fused= > $OUT/${TAG}_ab_recsys_fused.txt
 # the spread l1 projection at the HCP shape: stamps, and the A/B against the last workgroup's projection
-timeout 300 python3 $R/scripts/diag_atom_stamps_c6.py > $OUT/${TAG}_atom_mwg_c6_stamps.txt 2>&1
-{ for v in 1 0 1 0; do timeout 300 python3 $R/scripts/bench_configs.py --only c6 --debug-set 12=$v 2>/dev/null; done; } > $OUT/${TAG}_ab_atom_mwg_c6.jsonl
+# C6's per-atom launch: stamps of the last workgroup (register projection, the default) and of the spread projection (12=3);
+# A/B of the projection routes (12 = 1 registers / 3 spread / 0 LDS scans) and of the riding gradient rows (14 = 1 / 0)
+{ timeout 300 python3 $R/scripts/diag_atom_stamps_c6.py; timeout 300 python3 $R/scripts/diag_atom_stamps_c6.py 12=3; } > $OUT/${TAG}_atom_mwg_c6_stamps.txt 2>&1
+{ for v in "12=1" "12=3" "12=0" "14=0" "12=1"; do echo "# --debug-set $v"; timeout 300 python3 $R/scripts/bench_configs.py --only c6 --debug-set $v 2>/dev/null; done; } > $OUT/${TAG}_ab_atom_mwg_c6.jsonl
 # the sweep-flip census at 204 800 samples of both reductions (bench.py: flip_rate_block; ~15 min of CPU oracle; FLIP=0 skips it)
 [ "${FLIP:-1}" = "1" ] && python3 - > $OUT/${TAG}_flip_census.json 2> $OUT/${TAG}_flip_census.err <<PY
 import sys, json

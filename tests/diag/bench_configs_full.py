@@ -101,7 +101,8 @@ def main():
                                    bound='hbm', achieved=by / sec[dom] / 1e6, peak=PEAK['hbm'], unit='GB/s',
                                    frac=by / sec[dom] / 1e6 / PEAK['hbm'],
                                    note='dictionary update with l1 atoms and more than 6144 sampled features: one launch per '
-                                        'atom (atom_step_kernel), 1024 dependent launches per minibatch')
+                                        'atom (atom_corr_project_kernel: candidates on 39 workgroups, the last one projects from '
+                                        'registers; the next group\'s gradient rows ride along), 1024 dependent launches per minibatch')
         else:
             # the masked path has its own plan (no section events): algorithmic HBM bytes per rating - its code row,
             # the item's dictionary column and the read-modify-write of its B_ column: (3 k + k) e bytes, f64
