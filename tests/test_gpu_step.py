@@ -1310,7 +1310,7 @@ print(json.dumps(dict(ok=True)))
 
 
 @pytest.mark.parametrize('dt,pos,k,p', [('f32', 1, 12, 15000), ('f64', 1, 12, 15000), ('f64', 0, 12, 15000), ('f64', 1, 14, 18000),
-                                        ('f32', 0, 7, 18000)])
+                                        ('f32', 0, 7, 18000), ('f32', 1, 12, 24000)])
 def test_l1_projection_spread_over_the_launch(tmp_path, dt, pos, k, p):
     """Round 6, the per-atom l1 sweep of more than 6144 sampled features (one launch per atom: the shape class of the reference's
     HCP run).  The gradient rows of the next group of four atoms ride on the launches of this group's atoms (MODL_DEBUG_ATOM_PIPE;
@@ -1322,7 +1322,8 @@ def test_l1_projection_spread_over_the_launch(tmp_path, dt, pos, k, p):
     abort word is raised and the last workgroup projects the candidates alone - with a gradient launch per group the results must
     be the old path's BIT FOR BIT, with the riding rows they must be the pipelined run's to rounding) and against the oracle:
     7500 sampled features of 15 000 (30 workgroups, an element per thread) and 9000 of 18 000 (two elements per thread on 18
-    workgroups: what the reference's HCP shape takes), l1 atoms with and without positivity."""
+    workgroups: what the reference's HCP shape takes) and 12 000 of 24 000 (64 elements per thread of the projecting workgroup),
+    l1 atoms with and without positivity."""
     from oracle import somf_oracle as orc
     from .conftest import assert_within_f32_noise
     f = str(tmp_path / 'mwg.npz')
